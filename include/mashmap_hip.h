@@ -1,0 +1,180 @@
+/*
+ * include/mashmap_hip.h -- C ABI of libmashmap_hip.so: MashMap's sketch + L1/L2 hot path as
+ * hand-written HIP kernels for gfx950 (MI355X).
+ *
+ * The reference (marbl/MashMap v3.1.3) has no FFI: its boundary is the two C++ classes main()
+ * constructs (src/map/mash_map.cpp:43,51) and the free functions they call.  Every entry point
+ * below names the reference interface it stands in for (file:line relative to the reference
+ * tree).  Plain pointers and sizes only; the library owns all device memory; the caller owns
+ * every host buffer.  All functions return 0 on success or a negative MM_ERR_* code
+ * (mm_last_error() gives the text); nothing here ever falls back to a CPU implementation --
+ * if no gfx950 device / kernel image is available mm_create() fails.
+ *
+ * Thread model: one mm_ctx per GPU (one process per GPU in multi-GPU runs); a ctx is
+ * thread-compatible, not thread-safe; all work of a ctx is ordered on its own HIP stream.
+ */
+#ifndef MASHMAP_HIP_H
+#define MASHMAP_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MM_ABI_VERSION 1
+
+enum {
+  MM_OK = 0,
+  MM_ERR_ARG = -1,        /* bad argument / unsupported parameter combination */
+  MM_ERR_DEVICE = -2,     /* HIP runtime error (no device, launch failure, out of memory ...) */
+  MM_ERR_STATE = -3,      /* call sequence violated (e.g. map before index upload) */
+  MM_ERR_CAPACITY = -4    /* an internal device buffer overflowed and could not be grown */
+};
+
+/* skch::Parameters fields the hot path reads (map_parameters.hpp:32-80) */
+enum {
+  MM_FLAG_HG_FILTER = 1,        /* stage1_topANI_filter   (parseCmdArgs.hpp:397) */
+  MM_FLAG_SKIP_SELF = 2,        /* skip_self              (parseCmdArgs.hpp:341) */
+  MM_FLAG_SKIP_PREFIX = 4,      /* skip_prefix            (parseCmdArgs.hpp:349) */
+  MM_FLAG_LOWER_TRIANGULAR = 8, /* lower_triangular       (parseCmdArgs.hpp:334) */
+  MM_FLAG_NO_SPLIT = 16         /* !split                 (parseCmdArgs.hpp:427) */
+};
+
+typedef struct {
+  int32_t kmerSize;       /* Parameters::kmerSize   (1..32) */
+  int32_t segLength;      /* Parameters::segLength  */
+  int32_t sketchSize;     /* Parameters::sketchSize (1..1024) */
+  int32_t flags;          /* MM_FLAG_* */
+} mm_params;
+
+/* bit-for-bit skch::MinmerInfo (base_types.hpp:31; 24 bytes) */
+typedef struct { uint64_t hash; int32_t wpos, wpos_end, seqId; int16_t strand; int16_t pad_; } mm_minmer;
+/* bit-for-bit skch::IntervalPoint (base_types.hpp:66; 24 bytes) */
+typedef struct { int32_t pos; int32_t pad0_; uint64_t hash; int32_t seqId; int8_t side; int8_t pad1_[3]; } mm_interval_point;
+
+/* one query fragment, as Map::mapModule cuts them (computeMap.hpp:587-671) */
+typedef struct {
+  int32_t readId;         /* index of the read in the uploaded batch (InputSeqContainer::seqCounter - first) */
+  int32_t fragStart;      /* offset of the fragment inside the read == MappingResult::queryStartPos */
+  int32_t len;            /* QueryMetaData::len */
+  int32_t pad_;
+} mm_fragment;
+
+/* per-fragment integers behind QueryMetaData (base_types.hpp:265) after getSeedHits (computeMap.hpp:818) */
+typedef struct {
+  int32_t rawSketchSize;  /* |minmerTableQuery| before frequent-seed removal (feeds kmerComplexity, :830) */
+  int32_t sketchSize;     /* Q.sketchSize (:839) */
+  uint64_t maxHash;       /* minmerTableQuery.back().hash before removal (:830) */
+  int32_t nPoints;        /* interval points that survived the seqId filters (:891-896) */
+  int32_t nL1;            /* L1 candidates (:916) */
+} mm_frag_stats;
+
+/* Map::L1_candidateLocus_t (computeMap.hpp:58) + owning fragment */
+typedef struct { int32_t frag; int32_t seqId, rangeStartPos, rangeEndPos, intersectionSize; } mm_l1_candidate;
+/* Map::L2_mapLocus_t (computeMap.hpp:76) + owning fragment / candidate (index into the L1 array) */
+typedef struct {
+  int32_t frag, cand;
+  int32_t seqId, meanOptimalPos, optimalStart, optimalEnd, sharedSketchSize, strand;
+} mm_l2_locus;
+
+typedef struct mm_ctx mm_ctx;
+
+/* ------------------------------------------------------------------------------------------ */
+int  mm_abi_version(void);
+/* creates the context on HIP device `device`; fails (MM_ERR_DEVICE) when there is none */
+int  mm_create(mm_ctx** out, int device, const mm_params* params);
+void mm_destroy(mm_ctx* ctx);
+const char* mm_last_error(const mm_ctx* ctx);   /* ctx may be NULL for mm_create failures */
+
+/*
+ * Reference index -> device.  Stands in for how Map reads `const skch::Sketch&`:
+ *   minmerIndex            (winSketch.hpp:102; read by computeL2MappedRegions, computeMap.hpp:1284-1340)
+ *   minmerPosLookupIndex   (winSketch.hpp:101; read by getSeedIntervalPoints, computeMap.hpp:878)
+ *   isFreqSeed()           (winSketch.hpp:506; read by getSeedHits, computeMap.hpp:835)
+ *   metadata[i].len        (winSketch.hpp:79)
+ * `minmers` is minmerIndex *after* dropFreqSeedSet (:497).  The lookup map is passed flattened:
+ * keys[i] owns points[offsets[i] .. offsets[i+1]) in the map's own per-key order.
+ * refGroup[i] is Map::refIdGroup (computeMap.hpp:113), or NULL when skip_prefix is off.
+ */
+int mm_index_upload(mm_ctx* ctx,
+                    const mm_minmer* minmers, size_t nMinmers,
+                    const uint64_t* keys, const uint64_t* offsets, size_t nKeys,
+                    const mm_interval_point* points, size_t nPoints,
+                    const uint64_t* freqSeeds, size_t nFreq,
+                    const int32_t* contigLen, const int32_t* refGroup, size_t nContigs);
+
+/*
+ * Host-computed integer tables (they depend on GSL-class floating point, kept on the host):
+ *   minHits[q]      = Stat::estimateMinimumHitsRelaxed(q, k, pi, 0.95), q = 0..sketchSize   (computeMap.hpp:1144)
+ *   sketchCutoffs[] = Map::sketchCutoffs (computeMap.hpp:109,178-258), nCutoffs entries
+ */
+int mm_set_tables(mm_ctx* ctx, const int32_t* minHits, size_t nMinHits, const int32_t* sketchCutoffs, size_t nCutoffs);
+
+/*
+ * A batch of query reads -> device.  Replaces the `char* seq` handed to sketchSequence
+ * (commonFunc.hpp:183): ASCII in, normalised (makeUpperCaseAndValidDNA, :97) and packed to
+ * 2 bit/base + N mask on the device.  readOffsets has nReads+1 entries into `bases`.
+ * Fragments are cut exactly as mapModule does (computeMap.hpp:587-671).
+ * readRefGroup[r] = Map::getRefGroup(name) (computeMap.hpp:164) or NULL;
+ * readSelfSeqId[r] = reference seqId whose name equals the read's name, -1 if none, or NULL
+ * (this is what the skip_self test `Q.seqName != ref.name` needs, computeMap.hpp:891);
+ * seqCounterBase = seqCounter of read 0 (lower_triangular compares seqCounter with seqId, :893).
+ */
+int mm_reads_upload(mm_ctx* ctx, const char* bases, const int64_t* readOffsets, size_t nReads,
+                    const int32_t* readRefGroup, const int32_t* readSelfSeqId, int32_t seqCounterBase);
+/* same, from already device-resident ASCII (hipMalloc'ed by the caller, e.g. a torch tensor) */
+int mm_reads_upload_device(mm_ctx* ctx, const void* dBases, size_t nBases, const int64_t* readOffsets, size_t nReads,
+                           const int32_t* readRefGroup, const int32_t* readSelfSeqId, int32_t seqCounterBase);
+size_t mm_num_fragments(const mm_ctx* ctx);
+int mm_fragments_download(mm_ctx* ctx, mm_fragment* out);
+
+/* a4: CommonFunc::sketchSequence for every resident fragment (commonFunc.hpp:183) */
+int mm_sketch_fragments(mm_ctx* ctx);
+/* raw sketches (before frequent-seed removal): out[f*sketchSize + r], counts[f]; seqId := readId+seqCounterBase */
+int mm_sketch_download(mm_ctx* ctx, mm_minmer* out, uint32_t* counts);
+
+/*
+ * The whole hot path for every resident fragment: sketch (a4) -> getSeedHits (a8) ->
+ * getSeedIntervalPoints (a9) -> computeL1CandidateRegions (a10) -> computeL2MappedRegions for
+ * every L1 candidate (a13).  Equivalent of the integer part of Map::mapSingleQueryFrag
+ * (computeMap.hpp:756); identities and the best-first / early-exit replay of doL2Mapping
+ * (:1182-1267) are host work on these integers.  Results stay on the device until downloaded.
+ */
+int mm_map_fragments(mm_ctx* ctx);
+int mm_result_counts(const mm_ctx* ctx, size_t* nL1, size_t* nL2);
+/* any pointer may be NULL.  l1/l2 are sorted by (frag, emission order of the reference) */
+int mm_results_download(mm_ctx* ctx, mm_frag_stats* stats, mm_l1_candidate* l1, mm_l2_locus* l2);
+/* post-removal sketches Q.minmerTableQuery: out[f*sketchSize + r] (valid r < stats[f].sketchSize) */
+int mm_query_sketch_download(mm_ctx* ctx, mm_minmer* out);
+/* sorted, filtered interval points of fragment f (debug/parity; (seqId,pos,side) only, hash = 0) */
+int mm_points_download(mm_ctx* ctx, size_t frag, mm_interval_point* out, size_t cap, size_t* n);
+/* device addresses of the result arrays (for RCCL all-gatherv by the caller); valid until the next map call */
+int mm_results_device(const mm_ctx* ctx, const mm_l2_locus** dL2, size_t* nL2);
+
+/*
+ * a5-a7 on the device: CommonFunc::addMinmers per contig (commonFunc.hpp:302), Sketch::index
+ * (winSketch.hpp:379) and the frequent-seed filter (:410-504), leaving the index resident.
+ * contigOffsets has nContigs+1 entries into `bases` (ASCII).  kmerPctThreshold as Parameters::kmer_pct_threshold.
+ */
+int mm_index_build(mm_ctx* ctx, const char* bases, const int64_t* contigOffsets, size_t nContigs,
+                   const int32_t* refGroup, float kmerPctThreshold);
+/* the resident index back on the host in reference layout (sizes first, then fill) */
+int mm_index_sizes(const mm_ctx* ctx, size_t* nMinmers, size_t* nKeys, size_t* nPoints, size_t* nFreq, int32_t* freqThreshold);
+int mm_index_download(mm_ctx* ctx, mm_minmer* minmers, uint64_t* keys, uint64_t* offsets, mm_interval_point* points,
+                      uint64_t* freqSeeds);
+
+/* per-kernel device timing, measured with hipEvents on the ctx stream (bench.py roofline leg) */
+enum { MM_K_PACK = 0, MM_K_SKETCH, MM_K_SKETCH_HARD, MM_K_LOOKUP, MM_K_SORT, MM_K_L1, MM_K_L2, MM_K_REFHASH, MM_K_COUNT };
+int mm_profile_enable(mm_ctx* ctx, int on);
+/* ms[i] = accumulated milliseconds, launches[i] = launch count since the last reset */
+int mm_profile_read(mm_ctx* ctx, double* ms, uint64_t* launches, int reset);
+const char* mm_kernel_name(int which);
+int mm_synchronize(mm_ctx* ctx);
+/* the HIP stream all work of this ctx is ordered on (a hipStream_t) */
+void* mm_stream(const mm_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

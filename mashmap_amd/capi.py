@@ -1,0 +1,249 @@
+"""ctypes binding of libmashmap_hip.so (include/mashmap_hip.h).
+
+Plumbing only: the product is the HIP library; the C++ host side lives in mashmap_amd/host/.
+There is no CPU fallback here -- if the library is missing or no gfx950 device is present every
+call fails loudly (LibraryMissing / MashmapError).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libmashmap_hip.so")
+
+MM_FLAG_HG_FILTER, MM_FLAG_SKIP_SELF, MM_FLAG_SKIP_PREFIX, MM_FLAG_LOWER_TRIANGULAR, MM_FLAG_NO_SPLIT = 1, 2, 4, 8, 16
+KERNELS = ["pack", "sketch", "sketch_hard", "lookup", "sort", "l1", "l2", "refhash"]
+
+
+class LibraryMissing(RuntimeError):
+    pass
+
+
+class MashmapError(RuntimeError):
+    pass
+
+
+class Params(C.Structure):
+    _fields_ = [("kmerSize", C.c_int32), ("segLength", C.c_int32), ("sketchSize", C.c_int32), ("flags", C.c_int32)]
+
+
+MINMER_DT = np.dtype([("hash", "<u8"), ("wpos", "<i4"), ("wpos_end", "<i4"), ("seqId", "<i4"), ("strand", "<i2"),
+                      ("pad", "<i2")])
+POINT_DT = np.dtype([("pos", "<i4"), ("pad0", "<i4"), ("hash", "<u8"), ("seqId", "<i4"), ("side", "i1"),
+                     ("pad1", "i1", (3,))])
+FRAG_DT = np.dtype([("readId", "<i4"), ("fragStart", "<i4"), ("len", "<i4"), ("pad", "<i4")])
+STATS_DT = np.dtype([("rawSketchSize", "<i4"), ("sketchSize", "<i4"), ("maxHash", "<u8"), ("nPoints", "<i4"),
+                     ("nL1", "<i4")])
+L1_DT = np.dtype([("frag", "<i4"), ("seqId", "<i4"), ("rangeStartPos", "<i4"), ("rangeEndPos", "<i4"),
+                  ("intersectionSize", "<i4")])
+L2_DT = np.dtype([("frag", "<i4"), ("cand", "<i4"), ("seqId", "<i4"), ("meanOptimalPos", "<i4"),
+                  ("optimalStart", "<i4"), ("optimalEnd", "<i4"), ("sharedSketchSize", "<i4"), ("strand", "<i4")])
+assert MINMER_DT.itemsize == 24 and POINT_DT.itemsize == 24 and STATS_DT.itemsize == 24 and L2_DT.itemsize == 32
+
+_lib = None
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def load():
+    """dlopen the in-tree library; raises LibraryMissing when it has not been built"""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LibraryMissing("%s not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                             "(or make -C mashmap_amd/csrc)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, sz, i32, i64 = C.c_void_p, C.c_size_t, C.c_int32, C.c_int64
+    sig = {
+        "mm_abi_version": (C.c_int, []),
+        "mm_create": (C.c_int, [C.POINTER(vp), C.c_int, C.POINTER(Params)]),
+        "mm_destroy": (None, [vp]),
+        "mm_last_error": (C.c_char_p, [vp]),
+        "mm_index_upload": (C.c_int, [vp, vp, sz, vp, vp, sz, vp, sz, vp, sz, vp, vp, sz]),
+        "mm_set_tables": (C.c_int, [vp, vp, sz, vp, sz]),
+        "mm_reads_upload": (C.c_int, [vp, vp, vp, sz, vp, vp, i32]),
+        "mm_reads_upload_device": (C.c_int, [vp, vp, sz, vp, sz, vp, vp, i32]),
+        "mm_num_fragments": (sz, [vp]),
+        "mm_fragments_download": (C.c_int, [vp, vp]),
+        "mm_sketch_fragments": (C.c_int, [vp]),
+        "mm_sketch_download": (C.c_int, [vp, vp, vp]),
+        "mm_map_fragments": (C.c_int, [vp]),
+        "mm_result_counts": (C.c_int, [vp, C.POINTER(sz), C.POINTER(sz)]),
+        "mm_results_download": (C.c_int, [vp, vp, vp, vp]),
+        "mm_query_sketch_download": (C.c_int, [vp, vp]),
+        "mm_points_download": (C.c_int, [vp, sz, vp, sz, C.POINTER(sz)]),
+        "mm_results_device": (C.c_int, [vp, C.POINTER(vp), C.POINTER(sz)]),
+        "mm_index_build": (C.c_int, [vp, vp, vp, sz, vp, C.c_float]),
+        "mm_index_sizes": (C.c_int, [vp, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz), C.POINTER(sz), C.POINTER(i32)]),
+        "mm_index_download": (C.c_int, [vp, vp, vp, vp, vp, vp]),
+        "mm_profile_enable": (C.c_int, [vp, C.c_int]),
+        "mm_profile_read": (C.c_int, [vp, vp, vp, C.c_int]),
+        "mm_kernel_name": (C.c_char_p, [C.c_int]),
+        "mm_synchronize": (C.c_int, [vp]),
+        "mm_stream": (vp, [vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)   # AttributeError here == header and library disagree
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+EXPORTS = ["mm_abi_version", "mm_create", "mm_destroy", "mm_last_error", "mm_index_upload", "mm_set_tables",
+           "mm_reads_upload", "mm_reads_upload_device", "mm_num_fragments", "mm_fragments_download",
+           "mm_sketch_fragments", "mm_sketch_download", "mm_map_fragments", "mm_result_counts",
+           "mm_results_download", "mm_query_sketch_download", "mm_points_download", "mm_results_device",
+           "mm_index_build", "mm_index_sizes", "mm_index_download", "mm_profile_enable", "mm_profile_read",
+           "mm_kernel_name", "mm_synchronize", "mm_stream"]
+
+
+class Context:
+    """one mm_ctx (one GPU)"""
+
+    def __init__(self, k=19, segLength=5000, sketchSize=130, flags=MM_FLAG_HG_FILTER, device=0):
+        self.lib = load()
+        self.params = Params(k, segLength, sketchSize, flags)
+        h = C.c_void_p()
+        rc = self.lib.mm_create(C.byref(h), device, C.byref(self.params))
+        if rc != 0:
+            raise MashmapError("mm_create failed (%d): %s" % (rc, self.lib.mm_last_error(None).decode()))
+        self.h = h
+        self.s = sketchSize
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc, what):
+        if rc != 0:
+            raise MashmapError("%s failed (%d): %s" % (what, rc, self.lib.mm_last_error(self.h).decode()))
+
+    # ---- index
+    def index_upload(self, minmers, keys, offsets, points, freq, contigLen, refGroup=None):
+        minmers = np.ascontiguousarray(minmers, dtype=MINMER_DT); keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64); points = np.ascontiguousarray(points, dtype=POINT_DT)
+        freq = np.ascontiguousarray(freq, dtype=np.uint64); contigLen = np.ascontiguousarray(contigLen, dtype=np.int32)
+        rg = np.ascontiguousarray(refGroup, dtype=np.int32) if refGroup is not None else None
+        self._keep = (minmers, keys, offsets, points, freq, contigLen, rg)
+        self._ck(self.lib.mm_index_upload(self.h, _ptr(minmers), len(minmers), _ptr(keys), _ptr(offsets), len(keys),
+                                          _ptr(points), len(points), _ptr(freq), len(freq), _ptr(contigLen), _ptr(rg),
+                                          len(contigLen)), "mm_index_upload")
+
+    def index_build(self, contigs, refGroup=None, kmerPct=0.001):
+        """contigs: list of uint8 arrays (ASCII)"""
+        offs = np.zeros(len(contigs) + 1, dtype=np.int64)
+        offs[1:] = np.cumsum([len(c) for c in contigs])
+        buf = np.concatenate(contigs) if len(contigs) else np.zeros(0, dtype=np.uint8)
+        rg = np.ascontiguousarray(refGroup, dtype=np.int32) if refGroup is not None else None
+        self._ck(self.lib.mm_index_build(self.h, _ptr(buf), _ptr(offs), len(contigs), _ptr(rg), kmerPct), "mm_index_build")
+
+    def index_download(self):
+        n = [C.c_size_t() for _ in range(4)]; ft = C.c_int32()
+        self._ck(self.lib.mm_index_sizes(self.h, *[C.byref(x) for x in n], C.byref(ft)), "mm_index_sizes")
+        nm, nk, npt, nf = [x.value for x in n]
+        mins = np.zeros(nm, dtype=MINMER_DT); keys = np.zeros(nk, dtype=np.uint64); offs = np.zeros(nk + 1, dtype=np.uint64)
+        pts = np.zeros(npt, dtype=POINT_DT); fr = np.zeros(nf, dtype=np.uint64)
+        self._ck(self.lib.mm_index_download(self.h, _ptr(mins), _ptr(keys), _ptr(offs), _ptr(pts), _ptr(fr)), "mm_index_download")
+        return dict(minmers=mins, keys=keys, offsets=offs, points=pts, freq=fr, freqThreshold=ft.value)
+
+    def set_tables(self, minHits, cutoffs):
+        a = np.ascontiguousarray(minHits, dtype=np.int32); b = np.ascontiguousarray(cutoffs, dtype=np.int32)
+        self._ck(self.lib.mm_set_tables(self.h, _ptr(a), len(a), _ptr(b), len(b)), "mm_set_tables")
+
+    # ---- reads
+    def reads_upload(self, reads, refGroup=None, selfSeqId=None, seqCounterBase=0):
+        """reads: list of uint8 arrays (ASCII) or (concatenated uint8 array, int64 offsets)"""
+        if isinstance(reads, tuple):
+            buf, offs = reads
+            buf = np.ascontiguousarray(buf, dtype=np.uint8); offs = np.ascontiguousarray(offs, dtype=np.int64)
+        else:
+            offs = np.zeros(len(reads) + 1, dtype=np.int64)
+            offs[1:] = np.cumsum([len(r) for r in reads])
+            buf = np.concatenate(reads) if len(reads) else np.zeros(0, dtype=np.uint8)
+        n = len(offs) - 1
+        rg = np.ascontiguousarray(refGroup, dtype=np.int32) if refGroup is not None else None
+        ss = np.ascontiguousarray(selfSeqId, dtype=np.int32) if selfSeqId is not None else None
+        self._ck(self.lib.mm_reads_upload(self.h, _ptr(buf), _ptr(offs), n, _ptr(rg), _ptr(ss), seqCounterBase), "mm_reads_upload")
+        return self.num_fragments()
+
+    def reads_upload_device(self, dptr, nbytes, offs, refGroup=None, selfSeqId=None, seqCounterBase=0):
+        offs = np.ascontiguousarray(offs, dtype=np.int64)
+        rg = np.ascontiguousarray(refGroup, dtype=np.int32) if refGroup is not None else None
+        ss = np.ascontiguousarray(selfSeqId, dtype=np.int32) if selfSeqId is not None else None
+        self._ck(self.lib.mm_reads_upload_device(self.h, C.c_void_p(dptr), nbytes, _ptr(offs), len(offs) - 1, _ptr(rg), _ptr(ss),
+                                                 seqCounterBase), "mm_reads_upload_device")
+        return self.num_fragments()
+
+    def num_fragments(self):
+        return int(self.lib.mm_num_fragments(self.h))
+
+    def fragments(self):
+        out = np.zeros(self.num_fragments(), dtype=FRAG_DT)
+        self._ck(self.lib.mm_fragments_download(self.h, _ptr(out)), "mm_fragments_download")
+        return out
+
+    # ---- kernels
+    def sketch(self):
+        self._ck(self.lib.mm_sketch_fragments(self.h), "mm_sketch_fragments")
+        nF = self.num_fragments()
+        out = np.zeros((nF, self.s), dtype=MINMER_DT); cnt = np.zeros(nF, dtype=np.uint32)
+        self._ck(self.lib.mm_sketch_download(self.h, _ptr(out), _ptr(cnt)), "mm_sketch_download")
+        return out, cnt
+
+    def sketch_only(self):
+        self._ck(self.lib.mm_sketch_fragments(self.h), "mm_sketch_fragments")
+
+    def map(self):
+        self._ck(self.lib.mm_map_fragments(self.h), "mm_map_fragments")
+
+    def results(self):
+        n1, n2 = C.c_size_t(), C.c_size_t()
+        self._ck(self.lib.mm_result_counts(self.h, C.byref(n1), C.byref(n2)), "mm_result_counts")
+        nF = self.num_fragments()
+        stats = np.zeros(nF, dtype=STATS_DT); l1 = np.zeros(n1.value, dtype=L1_DT); l2 = np.zeros(n2.value, dtype=L2_DT)
+        self._ck(self.lib.mm_results_download(self.h, _ptr(stats), _ptr(l1), _ptr(l2)), "mm_results_download")
+        return stats, l1, l2
+
+    def result_counts(self):
+        n1, n2 = C.c_size_t(), C.c_size_t()
+        self._ck(self.lib.mm_result_counts(self.h, C.byref(n1), C.byref(n2)), "mm_result_counts")
+        return n1.value, n2.value
+
+    def results_device(self):
+        p, n = C.c_void_p(), C.c_size_t()
+        self._ck(self.lib.mm_results_device(self.h, C.byref(p), C.byref(n)), "mm_results_device")
+        return p.value, n.value
+
+    def query_sketches(self):
+        out = np.zeros((self.num_fragments(), self.s), dtype=MINMER_DT)
+        self._ck(self.lib.mm_query_sketch_download(self.h, _ptr(out)), "mm_query_sketch_download")
+        return out
+
+    def points(self, frag, cap=1 << 16):
+        out = np.zeros(cap, dtype=POINT_DT); n = C.c_size_t()
+        self._ck(self.lib.mm_points_download(self.h, frag, _ptr(out), cap, C.byref(n)), "mm_points_download")
+        return out[:n.value]
+
+    # ---- profiling
+    def profile(self, on=True):
+        self.lib.mm_profile_enable(self.h, 1 if on else 0)
+
+    def profile_read(self, reset=True):
+        ms = np.zeros(len(KERNELS), dtype=np.float64); ln = np.zeros(len(KERNELS), dtype=np.uint64)
+        self.lib.mm_profile_read(self.h, _ptr(ms), _ptr(ln), 1 if reset else 0)
+        return {KERNELS[i]: (float(ms[i]), int(ln[i])) for i in range(len(KERNELS))}
+
+    def synchronize(self):
+        self._ck(self.lib.mm_synchronize(self.h), "mm_synchronize")

@@ -1,0 +1,285 @@
+// mashmap_amd/csrc/mm_api.hip -- the extern "C" surface declared in include/mashmap_hip.h.
+#include "mm_internal.h"
+#include <algorithm>
+#include <cstring>
+
+static thread_local std::string g_createErr;
+
+static const char* kKernelNames[MM_K_COUNT] = {
+  "k_pack2bit", "k_sketch_fragments", "k_sketch_fragments(hard)", "k_seed_lookup", "k_sort_points",
+  "k_l1_sweep", "k_l2_slide", "k_ref_hash"};
+
+extern "C" {
+
+int mm_abi_version(void) { return MM_ABI_VERSION; }
+const char* mm_kernel_name(int which) { return (which >= 0 && which < MM_K_COUNT) ? kKernelNames[which] : "?"; }
+
+const char* mm_last_error(const mm_ctx* ctx) { return ctx ? ctx->err.c_str() : g_createErr.c_str(); }
+
+int mm_create(mm_ctx** out, int device, const mm_params* p) {
+  if (!out || !p) { g_createErr = "mm_create: null argument"; return MM_ERR_ARG; }
+  *out = nullptr;
+  if (p->kmerSize < 1 || p->kmerSize > 32 || p->sketchSize < 1 || p->sketchSize > 1024 || p->segLength < p->kmerSize) {
+    g_createErr = "mm_create: unsupported parameters (need 1<=k<=32, 1<=sketchSize<=1024, segLength>=k)";
+    return MM_ERR_ARG;
+  }
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+    g_createErr = std::string("mm_create: no usable HIP device (") + (e == hipSuccess ? "index out of range" : hipGetErrorString(e)) + ")";
+    return MM_ERR_DEVICE;
+  }
+  if ((e = hipSetDevice(device)) != hipSuccess) { g_createErr = hipGetErrorString(e); return MM_ERR_DEVICE; }
+  hipDeviceProp_t prop;
+  if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) { g_createErr = hipGetErrorString(e); return MM_ERR_DEVICE; }
+  if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos) {
+    g_createErr = std::string("mm_create: kernels are built for gfx950 only, device is ") + prop.gcnArchName;
+    return MM_ERR_DEVICE;
+  }
+  mm_ctx* c = new mm_ctx();
+  c->device = device; c->P = *p;
+  if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
+      (e = hipEventCreate(&c->evA)) != hipSuccess || (e = hipEventCreate(&c->evB)) != hipSuccess) {
+    g_createErr = hipGetErrorString(e); delete c; return MM_ERR_DEVICE;
+  }
+  *out = c;
+  return MM_OK;
+}
+
+void mm_destroy(mm_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  DevBuf* bufs[] = {&c->idx.recS, &c->idx.recE, &c->idx.contigOff, &c->idx.contigLen, &c->idx.refGroup, &c->idx.htKeys,
+                    &c->idx.htVals, &c->idx.ptKeys, &c->dMinHits, &c->dCutoffs, &c->dAscii, &c->dReadSrcOff, &c->dReadPackOff,
+                    &c->dReadLen, &c->dReadGroup, &c->dReadSelf, &c->dReadHasN, &c->dBases2, &c->dNmask, &c->dFrags, &c->dSkHash,
+                    &c->dSkPos, &c->dSkStrand, &c->dSkCount, &c->dHardList, &c->dCounters, &c->dQHash, &c->dQStrand, &c->dSeedVal,
+                    &c->dStats, &c->dPtOff, &c->dPts, &c->dL1, &c->dL1Off, &c->dL2, &c->dL2Count};
+  for (DevBuf* b : bufs) b->release();
+  if (c->evA) (void)hipEventDestroy(c->evA);
+  if (c->evB) (void)hipEventDestroy(c->evB);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int mm_synchronize(mm_ctx* c) { MM_HIP(c, hipStreamSynchronize(c->stream)); return MM_OK; }
+void* mm_stream(const mm_ctx* c) { return (void*)c->stream; }
+
+int mm_profile_enable(mm_ctx* c, int on) { c->profile = on != 0; return MM_OK; }
+int mm_profile_read(mm_ctx* c, double* ms, uint64_t* launches, int reset) {
+  for (int i = 0; i < MM_K_COUNT; i++) { if (ms) ms[i] = c->kMs[i]; if (launches) launches[i] = c->kLaunches[i]; }
+  if (reset) for (int i = 0; i < MM_K_COUNT; i++) { c->kMs[i] = 0; c->kLaunches[i] = 0; }
+  return MM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// index
+// ---------------------------------------------------------------------------------------------
+int mm_index_upload(mm_ctx* c, const mm_minmer* minmers, size_t nMinmers, const uint64_t* keys, const uint64_t* offsets,
+                    size_t nKeys, const mm_interval_point* points, size_t nPoints, const uint64_t* freqSeeds, size_t nFreq,
+                    const int32_t* contigLen, const int32_t* refGroup, size_t nContigs) {
+  if ((nMinmers && !minmers) || (nKeys && (!keys || !offsets)) || (nPoints && !points) || (nFreq && !freqSeeds) || !contigLen || !nContigs) {
+    c->err = "mm_index_upload: null argument"; return MM_ERR_ARG;
+  }
+  MM_HIP(c, hipSetDevice(c->device));
+  c->hMinmers.assign(minmers, minmers + nMinmers);
+  c->hKeys.assign(keys, keys + nKeys);
+  c->hOffsets.assign(offsets, offsets + nKeys + (nKeys ? 1 : 0));
+  if (!nKeys) c->hOffsets.assign(1, 0);
+  c->hPoints.assign(points, points + nPoints);
+  c->hFreq.assign(freqSeeds, freqSeeds + nFreq);
+  std::sort(c->hFreq.begin(), c->hFreq.end());
+  if (c->hOffsets.back() != nPoints) { c->err = "mm_index_upload: offsets[nKeys] != nPoints"; return MM_ERR_ARG; }
+  c->mapped = false;
+  return mm_build_device_index(c, contigLen, refGroup, nContigs);
+}
+
+int mm_set_tables(mm_ctx* c, const int32_t* minHits, size_t nMinHits, const int32_t* cutoffs, size_t nCutoffs) {
+  if (!minHits || nMinHits < (size_t)c->P.sketchSize + 1 || !cutoffs || nCutoffs < 2) {
+    c->err = "mm_set_tables: need sketchSize+1 minHits entries and the sketchCutoffs table"; return MM_ERR_ARG;
+  }
+  MM_HIP(c, hipSetDevice(c->device));
+  MM_HIP(c, c->dMinHits.ensure(nMinHits * 4));
+  MM_HIP(c, c->dCutoffs.ensure(nCutoffs * 4));
+  MM_HIP(c, hipMemcpyAsync(c->dMinHits.p, minHits, nMinHits * 4, hipMemcpyHostToDevice, c->stream));
+  MM_HIP(c, hipMemcpyAsync(c->dCutoffs.p, cutoffs, nCutoffs * 4, hipMemcpyHostToDevice, c->stream));
+  MM_HIP(c, hipStreamSynchronize(c->stream));
+  c->nMinHits = nMinHits; c->nCutoffs = nCutoffs;
+  return MM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// reads
+// ---------------------------------------------------------------------------------------------
+static int upload_reads_common(mm_ctx* c, const void* src, bool srcOnDevice, size_t nBasesTotal, const int64_t* readOffsets,
+                               size_t nReads, const int32_t* readRefGroup, const int32_t* readSelfSeqId, int32_t seqCounterBase) {
+  if (!readOffsets || (nBasesTotal && !src)) { c->err = "mm_reads_upload: null argument"; return MM_ERR_ARG; }
+  MM_HIP(c, hipSetDevice(c->device));
+  const int k = c->P.kmerSize, L = c->P.segLength;
+  const bool split = !(c->P.flags & MM_FLAG_NO_SPLIT);
+  std::vector<int64_t> srcOff(nReads + 1), packOff(nReads + 1);
+  std::vector<int32_t> rlen(nReads);
+  c->hFrags.clear();
+  std::vector<DFrag> dfr;
+  int64_t pk = 0; int32_t maxLen = 0;
+  for (size_t r = 0; r < nReads; r++) {
+    const int64_t len64 = readOffsets[r + 1] - readOffsets[r];
+    if (len64 < 0 || len64 > 0x7fffffff) { c->err = "mm_reads_upload: read length out of range (offset_t is int32, base_types.hpp:21)"; return MM_ERR_ARG; }
+    const int32_t len = (int32_t)len64;
+    srcOff[r] = readOffsets[r]; packOff[r] = pk; rlen[r] = len;
+    if (len >= k) {                                   // computeMap.hpp:325 (shorter reads are skipped)
+      if (!split || len <= L) {                       // :587
+        if (len > L) { c->err = "mm_reads_upload: a read longer than segLength with split off (windowLen != 0) is not supported on the device path"; return MM_ERR_ARG; }
+        c->hFrags.push_back(mm_fragment{(int32_t)r, 0, len, 0});
+        dfr.push_back(DFrag{pk, len, (int32_t)r});
+        maxLen = std::max(maxLen, len);
+      } else {
+        const int nfull = len / L;                    // :610
+        for (int i = 0; i < nfull; i++) {
+          c->hFrags.push_back(mm_fragment{(int32_t)r, i * L, L, 0});
+          dfr.push_back(DFrag{pk + (int64_t)i * L, L, (int32_t)r});
+        }
+        if (nfull >= 1 && len % L != 0) {             // :644
+          c->hFrags.push_back(mm_fragment{(int32_t)r, len - L, L, 0});
+          dfr.push_back(DFrag{pk + (int64_t)(len - L), L, (int32_t)r});
+        }
+        maxLen = std::max(maxLen, L);
+      }
+    }
+    pk += ((int64_t)len + 31) / 32 * 32;
+  }
+  srcOff[nReads] = readOffsets[nReads]; packOff[nReads] = pk;
+  c->nReads = nReads; c->nFrags = dfr.size(); c->nPackedBases = (size_t)pk; c->seqCounterBase = seqCounterBase; c->maxFragLen = maxLen;
+  c->sketched = false; c->mapped = false;
+
+  const size_t srcBase = (size_t)readOffsets[0];
+  const size_t nSrc = (size_t)(readOffsets[nReads] - readOffsets[0]);
+  for (size_t r = 0; r <= nReads; r++) srcOff[r] -= (int64_t)srcBase;
+  MM_HIP(c, c->dAscii.ensure(nSrc + 64));
+  MM_HIP(c, c->dReadSrcOff.ensure((nReads + 1) * 8)); MM_HIP(c, c->dReadPackOff.ensure((nReads + 1) * 8));
+  MM_HIP(c, c->dReadLen.ensure(nReads * 4 + 4)); MM_HIP(c, c->dReadGroup.ensure(nReads * 4 + 4)); MM_HIP(c, c->dReadSelf.ensure(nReads * 4 + 4));
+  MM_HIP(c, c->dReadHasN.ensure(nReads * 4 + 4));
+  MM_HIP(c, c->dBases2.ensure((size_t)pk / 4 + 64)); MM_HIP(c, c->dNmask.ensure((size_t)pk / 8 + 64));
+  MM_HIP(c, c->dFrags.ensure(dfr.size() * sizeof(DFrag) + 16));
+  if (nSrc) MM_HIP(c, hipMemcpyAsync(c->dAscii.p, (const char*)src + srcBase, nSrc, srcOnDevice ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+  MM_HIP(c, hipMemcpyAsync(c->dReadSrcOff.p, srcOff.data(), (nReads + 1) * 8, hipMemcpyHostToDevice, c->stream));
+  MM_HIP(c, hipMemcpyAsync(c->dReadPackOff.p, packOff.data(), (nReads + 1) * 8, hipMemcpyHostToDevice, c->stream));
+  if (nReads) MM_HIP(c, hipMemcpyAsync(c->dReadLen.p, rlen.data(), nReads * 4, hipMemcpyHostToDevice, c->stream));
+  std::vector<int32_t> grp(nReads, -1), self(nReads, -1);
+  if (readRefGroup) grp.assign(readRefGroup, readRefGroup + nReads);
+  if (readSelfSeqId) self.assign(readSelfSeqId, readSelfSeqId + nReads);
+  if (nReads) {
+    MM_HIP(c, hipMemcpyAsync(c->dReadGroup.p, grp.data(), nReads * 4, hipMemcpyHostToDevice, c->stream));
+    MM_HIP(c, hipMemcpyAsync(c->dReadSelf.p, self.data(), nReads * 4, hipMemcpyHostToDevice, c->stream));
+  }
+  MM_HIP(c, hipMemsetAsync(c->dReadHasN.p, 0, nReads * 4 + 4, c->stream));
+  MM_HIP(c, hipMemsetAsync((char*)c->dBases2.p + pk / 4, 0, 64, c->stream));   // run-off words read by the last fragment
+  MM_HIP(c, hipMemsetAsync((char*)c->dNmask.p + pk / 8, 0, 64, c->stream));
+  if (!dfr.empty()) MM_HIP(c, hipMemcpyAsync(c->dFrags.p, dfr.data(), dfr.size() * sizeof(DFrag), hipMemcpyHostToDevice, c->stream));
+  int rc = mm_launch_pack(c);
+  if (rc != MM_OK) return rc;
+  MM_HIP(c, hipStreamSynchronize(c->stream));         // host staging vectors go out of scope
+  return MM_OK;
+}
+
+int mm_reads_upload(mm_ctx* c, const char* bases, const int64_t* readOffsets, size_t nReads, const int32_t* g, const int32_t* s, int32_t base) {
+  return upload_reads_common(c, bases, false, 0 + (size_t)(readOffsets ? readOffsets[nReads] : 0), readOffsets, nReads, g, s, base);
+}
+int mm_reads_upload_device(mm_ctx* c, const void* dBases, size_t nBases, const int64_t* readOffsets, size_t nReads, const int32_t* g,
+                           const int32_t* s, int32_t base) {
+  return upload_reads_common(c, dBases, true, nBases, readOffsets, nReads, g, s, base);
+}
+
+size_t mm_num_fragments(const mm_ctx* c) { return c->nFrags; }
+int mm_fragments_download(mm_ctx* c, mm_fragment* out) {
+  if (c->nFrags) std::memcpy(out, c->hFrags.data(), c->nFrags * sizeof(mm_fragment));
+  return MM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// sketch
+// ---------------------------------------------------------------------------------------------
+int mm_sketch_fragments(mm_ctx* c) {
+  MM_HIP(c, hipSetDevice(c->device));
+  int rc = mm_launch_sketch(c);
+  if (rc != MM_OK) return rc;
+  MM_HIP(c, hipStreamSynchronize(c->stream));
+  c->sketched = true;
+  return MM_OK;
+}
+
+int mm_sketch_download(mm_ctx* c, mm_minmer* out, uint32_t* counts) {
+  if (!c->sketched) { c->err = "mm_sketch_download: no sketches resident"; return MM_ERR_STATE; }
+  MM_HIP(c, hipSetDevice(c->device));
+  const size_t nF = c->nFrags, s = (size_t)c->P.sketchSize;
+  std::vector<uint64_t> h(nF * s); std::vector<int2> p(nF * s); std::vector<int8_t> st(nF * s); std::vector<uint32_t> cnt(nF);
+  if (nF) {
+    MM_HIP(c, hipMemcpyAsync(h.data(), c->dSkHash.p, nF * s * 8, hipMemcpyDeviceToHost, c->stream));
+    MM_HIP(c, hipMemcpyAsync(p.data(), c->dSkPos.p, nF * s * 8, hipMemcpyDeviceToHost, c->stream));
+    MM_HIP(c, hipMemcpyAsync(st.data(), c->dSkStrand.p, nF * s, hipMemcpyDeviceToHost, c->stream));
+    MM_HIP(c, hipMemcpyAsync(cnt.data(), c->dSkCount.p, nF * 4, hipMemcpyDeviceToHost, c->stream));
+    MM_HIP(c, hipStreamSynchronize(c->stream));
+  }
+  for (size_t f = 0; f < nF; f++) {
+    if (counts) counts[f] = cnt[f];
+    if (!out) continue;
+    for (uint32_t r = 0; r < cnt[f]; r++) {
+      const size_t o = f * s + r;
+      out[o] = mm_minmer{h[o], p[o].x, p[o].y, c->hFrags[f].readId + c->seqCounterBase, (int16_t)st[o], 0};
+    }
+  }
+  return MM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// map
+// ---------------------------------------------------------------------------------------------
+int mm_map_fragments(mm_ctx* c) {
+  if (!c->idx.ready) { c->err = "mm_map_fragments: no index resident (mm_index_upload / mm_index_build first)"; return MM_ERR_STATE; }
+  if (!c->nMinHits) { c->err = "mm_map_fragments: mm_set_tables first"; return MM_ERR_STATE; }
+  MM_HIP(c, hipSetDevice(c->device));
+  int rc = mm_launch_sketch(c);
+  if (rc != MM_OK) return rc;
+  c->sketched = true;
+  rc = mm_launch_map(c);
+  if (rc != MM_OK) return rc;
+  MM_HIP(c, hipStreamSynchronize(c->stream));
+  c->mapped = true;
+  return MM_OK;
+}
+
+int mm_result_counts(const mm_ctx* c, size_t* nL1, size_t* nL2) {
+  if (!c->mapped) return MM_ERR_STATE;
+  if (nL1) *nL1 = c->nL1;
+  if (nL2) *nL2 = c->nL2;
+  return MM_OK;
+}
+
+int mm_results_device(const mm_ctx* c, const mm_l2_locus** dL2, size_t* nL2) {
+  if (!c->mapped) return MM_ERR_STATE;
+  if (dL2) *dL2 = c->dL2.as<mm_l2_locus>();
+  if (nL2) *nL2 = c->nL2;
+  return MM_OK;
+}
+
+int mm_index_sizes(const mm_ctx* c, size_t* nMinmers, size_t* nKeys, size_t* nPoints, size_t* nFreq, int32_t* freqThreshold) {
+  if (!c->idx.ready) return MM_ERR_STATE;
+  if (nMinmers) *nMinmers = c->hMinmers.size();
+  if (nKeys) *nKeys = c->hKeys.size();
+  if (nPoints) *nPoints = c->hPoints.size();
+  if (nFreq) *nFreq = c->hFreq.size();
+  if (freqThreshold) *freqThreshold = c->freqThreshold;
+  return MM_OK;
+}
+
+int mm_index_download(mm_ctx* c, mm_minmer* minmers, uint64_t* keys, uint64_t* offsets, mm_interval_point* points, uint64_t* freqSeeds) {
+  if (!c->idx.ready) { c->err = "mm_index_download: no index resident"; return MM_ERR_STATE; }
+  if (minmers && !c->hMinmers.empty()) std::memcpy(minmers, c->hMinmers.data(), c->hMinmers.size() * sizeof(mm_minmer));
+  if (keys && !c->hKeys.empty()) std::memcpy(keys, c->hKeys.data(), c->hKeys.size() * 8);
+  if (offsets) std::memcpy(offsets, c->hOffsets.data(), c->hOffsets.size() * 8);
+  if (points && !c->hPoints.empty()) std::memcpy(points, c->hPoints.data(), c->hPoints.size() * sizeof(mm_interval_point));
+  if (freqSeeds && !c->hFreq.empty()) std::memcpy(freqSeeds, c->hFreq.data(), c->hFreq.size() * 8);
+  return MM_OK;
+}
+
+}  // extern "C"

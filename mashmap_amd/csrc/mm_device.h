@@ -1,0 +1,88 @@
+// mashmap_amd/csrc/mm_device.h -- device-side building blocks (gfx950, wave64).
+//
+// Bit-exact MurmurHash3_x64_128 (low word, seed 42) of the *ASCII* k-mer, both strands, computed
+// from 2-bit packed bases.  Replaces CommonFunc::getHash (src/map/include/commonFunc.hpp:138) over
+// MurmurHash3_x64_128 (src/common/murmur3.h:226) for the alphabet {A,C,G,T}.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MM_SEED 42u
+#define MM_C1 0x87c37b91114253d5ULL
+#define MM_C2 0x4cf5ad432745937fULL
+#define MM_HASH_MAX 0xFFFFFFFFFFFFFFFFULL
+
+__device__ __forceinline__ uint64_t mm_rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+__device__ __forceinline__ uint64_t mm_fmix64(uint64_t k) {
+  k ^= k >> 33; k *= 0xff51afd7ed558ccdULL;
+  k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ULL;
+  k ^= k >> 33; return k;
+}
+__device__ __forceinline__ uint64_t mm_mix_k1(uint64_t k) { k *= MM_C1; k = mm_rotl64(k, 31); k *= MM_C2; return k; }
+__device__ __forceinline__ uint64_t mm_mix_k2(uint64_t k) { k *= MM_C2; k = mm_rotl64(k, 33); k *= MM_C1; return k; }
+
+// 8 two-bit codes (A=0,C=1,G=2,T=3) in the low 16 bits -> nothing; 4 codes in the low 8 bits -> 4 ASCII bytes
+__device__ __forceinline__ uint32_t mm_ascii4(uint32_t codes8) {
+  uint32_t y = codes8 & 0xFFu;
+  y = (y | (y << 12)) & 0x000F000Fu;
+  y = (y | (y << 6)) & 0x03030303u;                 // one code per byte
+  const uint32_t b0 = y & 0x01010101u, b1 = (y >> 1) & 0x01010101u, both = b0 & b1;
+  // A=0x41, C=0x43 (+2), G=0x47 (+6), T=0x54 (+19 = 2+6+11)
+  return 0x41414141u + (b0 << 1) + (b1 << 2) + (b1 << 1) + (both << 3) + (both << 1) + both;
+}
+// 16 codes -> 16 ASCII bytes (4 dwords)
+__device__ __forceinline__ void mm_expand16(uint32_t w, uint32_t* out) {
+  out[0] = mm_ascii4(w); out[1] = mm_ascii4(w >> 8); out[2] = mm_ascii4(w >> 16); out[3] = mm_ascii4(w >> 24);
+}
+// reverse the order of the sixteen 2-bit fields of w
+__device__ __forceinline__ uint32_t mm_rev2(uint32_t w) {
+  uint32_t r = __brev(w);
+  return ((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1);
+}
+
+// n (1..8) bytes starting at compile-time byte offset `off` of the dword stream A, zero-extended
+template <int N>
+__device__ __forceinline__ uint64_t mm_bytes(const uint32_t* A, int off) {
+  const int w = off >> 2, sh = (off & 3) * 8;
+  uint32_t lo, hi = 0;
+  lo = sh ? __builtin_amdgcn_alignbit(A[w + 1], A[w], sh) : A[w];
+  if (N > 4) hi = sh ? __builtin_amdgcn_alignbit(A[w + 2], A[w + 1], sh) : A[w + 1];
+  if (N < 4) lo &= (1u << (8 * (N & 3))) - 1u;
+  if (N > 4 && N < 8) hi &= (1u << (8 * (N & 3))) - 1u;
+  return ((uint64_t)hi << 32) | lo;
+}
+
+// MurmurHash3_x64_128(key = K ASCII bytes at byte offset off of A, seed 42), low 64 bits.  1 <= K <= 32.
+template <int K>
+__device__ __forceinline__ uint64_t mm_murmur_kmer(const uint32_t* A, int off) {
+  uint64_t h1 = MM_SEED, h2 = MM_SEED;
+  constexpr int NB = K / 16, TAIL = K & 15;
+#pragma unroll
+  for (int b = 0; b < NB; b++) {
+    const uint64_t k1 = mm_bytes<8>(A, off + 16 * b), k2 = mm_bytes<8>(A, off + 16 * b + 8);
+    h1 ^= mm_mix_k1(k1); h1 = mm_rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
+    h2 ^= mm_mix_k2(k2); h2 = mm_rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
+  }
+  if (TAIL > 8) h2 ^= mm_mix_k2(mm_bytes<(TAIL > 8 ? TAIL - 8 : 1)>(A, off + 16 * NB + 8));
+  if (TAIL > 0) h1 ^= mm_mix_k1(mm_bytes<(TAIL > 8 ? 8 : (TAIL > 0 ? TAIL : 1))>(A, off + 16 * NB));
+  h1 ^= (uint64_t)K; h2 ^= (uint64_t)K;
+  h1 += h2; h2 += h1;
+  h1 = mm_fmix64(h1); h2 = mm_fmix64(h2);
+  return h1 + h2;
+}
+
+// The 16 k-mer positions of one strip: forward and reverse-complement ASCII streams of a 48-base window.
+//   F[m]  = ascii(code[m])            m = 0..47   forward k-mer j starts at byte j
+//   RC[m] = ascii(3 - code[47 - m])               reverse-complement of k-mer j starts at byte 48-K-j
+struct MMStrip {
+  uint32_t F[13], R[13];
+  __device__ __forceinline__ void load(uint32_t w0, uint32_t w1, uint32_t w2) {
+    mm_expand16(w0, F); mm_expand16(w1, F + 4); mm_expand16(w2, F + 8); F[12] = 0;
+    mm_expand16(mm_rev2(~w2), R); mm_expand16(mm_rev2(~w1), R + 4); mm_expand16(mm_rev2(~w0), R + 8); R[12] = 0;
+  }
+};
+
+__device__ __forceinline__ uint32_t mm_lane() { return threadIdx.x & 63u; }
+__device__ __forceinline__ uint32_t mm_popc_below(uint64_t mask) {    // set bits of mask strictly below this lane
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}

@@ -1,0 +1,118 @@
+// mashmap_amd/csrc/mm_internal.h -- shared between the translation units of libmashmap_hip.so.
+// gfx950 (MI355X, wave64) only.  No CUDA, no portability macros.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/mashmap_hip.h"
+
+#define MM_WAVE 64
+
+// ---------------------------------------------------------------------------------------------
+// host-side helpers
+// ---------------------------------------------------------------------------------------------
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  hipError_t ensure(size_t need) {          // grow-only; contents are NOT preserved
+    if (need <= bytes) return hipSuccess;
+    if (p) { hipError_t e = hipFree(p); p = nullptr; bytes = 0; if (e != hipSuccess) return e; }
+    size_t cap = need + need / 8 + 256;
+    hipError_t e = hipMalloc(&p, cap);
+    if (e == hipSuccess) bytes = cap;
+    return e;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+  template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// fragment descriptor on the device
+struct DFrag {
+  int64_t base;      // absolute index of the fragment's first base in the packed buffer
+  int32_t len;       // bases
+  int32_t readId;
+};
+
+// device index (see DESIGN.md "data layout in HBM")
+struct DRecS { uint64_t hash; int32_t wpos; uint32_t wendStrand; };   // wend in bits 0..30, bit 31 = REV strand
+struct DRecE { uint64_t hash; int32_t wend; int32_t pad; };
+
+struct DeviceIndex {
+  size_t nRec = 0, nKeys = 0, nPoints = 0, nContigs = 0, htCap = 0;
+  DevBuf recS, recE;           // DRecS[nRec] in minmerIndex order; DRecE[nRec] per contig sorted by wend
+  DevBuf contigOff;            // int64[nContigs+1] record offsets
+  DevBuf contigLen;            // int32[nContigs]
+  DevBuf refGroup;             // int32[nContigs] (all 0 when unused)
+  DevBuf htKeys, htVals;       // uint64[htCap] each; val = offset<<24 | count<<1 | freq
+  DevBuf ptKeys;               // uint64[nPoints]: seqId<<33 | pos<<1 | (side==OPEN)
+  bool ready = false;
+};
+
+struct mm_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  mm_params P{};
+  std::string err;
+
+  // host mirrors needed for downloads in reference layout
+  std::vector<mm_minmer> hMinmers;
+  std::vector<uint64_t> hKeys, hOffsets, hFreq;
+  std::vector<mm_interval_point> hPoints;
+  int32_t freqThreshold = 0x7fffffff;
+
+  DeviceIndex idx;
+  DevBuf dMinHits, dCutoffs; size_t nMinHits = 0, nCutoffs = 0;
+
+  // resident reads
+  size_t nReads = 0, nFrags = 0, nPackedBases = 0;
+  int32_t seqCounterBase = 0, maxFragLen = 0;
+  DevBuf dAscii, dReadSrcOff, dReadPackOff, dReadLen, dReadGroup, dReadSelf, dReadHasN;
+  DevBuf dBases2, dNmask, dFrags;
+  std::vector<mm_fragment> hFrags;
+
+  // sketches: raw (a4) and after frequent-seed removal (a8)
+  DevBuf dSkHash, dSkPos, dSkStrand, dSkCount;          // [nFrags*s] u64, int2, i8 ; [nFrags] u32
+  DevBuf dHardList, dCounters;
+  DevBuf dQHash, dQStrand, dSeedVal;                    // post-removal sketch + per-seed lookup value
+  DevBuf dStats;                                        // mm_frag_stats[nFrags]
+  DevBuf dPtOff, dPts; size_t ptsCap = 0;               // per-fragment offset (int64) + sorted keys
+  DevBuf dL1; size_t l1Cap = 0, nL1 = 0;
+  DevBuf dL1Off;                                        // int64[nFrags] first candidate of a fragment
+  DevBuf dL2; size_t l2Cap = 0, nL2 = 0;
+  DevBuf dL2Count;                                      // per-candidate locus count
+  bool sketched = false, mapped = false;
+
+  // profiling
+  bool profile = false;
+  double kMs[MM_K_COUNT] = {0};
+  uint64_t kLaunches[MM_K_COUNT] = {0};
+  hipEvent_t evA = nullptr, evB = nullptr;
+};
+
+#define MM_HIP(ctx, call)                                                                        \
+  do {                                                                                           \
+    hipError_t e__ = (call);                                                                     \
+    if (e__ != hipSuccess) {                                                                     \
+      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e__);                           \
+      return MM_ERR_DEVICE;                                                                      \
+    }                                                                                            \
+  } while (0)
+
+struct KernelTimer {   // RAII hipEvent bracket on the ctx stream
+  mm_ctx* c; int which;
+  KernelTimer(mm_ctx* c_, int w) : c(c_), which(w) { if (c->profile) (void)hipEventRecord(c->evA, c->stream); }
+  ~KernelTimer() {
+    if (!c->profile) return;
+    (void)hipEventRecord(c->evB, c->stream);
+    (void)hipEventSynchronize(c->evB);
+    float ms = 0; (void)hipEventElapsedTime(&ms, c->evA, c->evB);
+    c->kMs[which] += ms; c->kLaunches[which] += 1;
+  }
+};
+
+// launchers implemented in the .hip files
+int mm_launch_pack(mm_ctx* c);
+int mm_launch_sketch(mm_ctx* c);
+int mm_launch_map(mm_ctx* c);
+int mm_build_device_index(mm_ctx* c, const int32_t* contigLen, const int32_t* refGroup, size_t nContigs);

@@ -1,0 +1,701 @@
+// mashmap_amd/csrc/mm_map.hip -- device index + L1/L2 mapping kernels (gfx950).
+//
+//   mm_build_device_index   flattening of skch::Sketch for the device     winSketch.hpp:100-102
+//   k_seed_lookup           getSeedHits (freq. seed removal) + getSeedIntervalPoints gather
+//                                                                         computeMap.hpp:818-843, 857-912
+//   k_sort_points_*         the (seqId,pos,side) order of getSeedIntervalPoints  computeMap.hpp:885-907
+//   k_l1_sweep              computeL1CandidateRegions                      computeMap.hpp:916-1116
+//   k_l2_slide              computeL2MappedRegions + SlideMapper           computeMap.hpp:1276-1451, slidingMap.hpp:28-212
+#include "mm_internal.h"
+#include "mm_device.h"
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+
+#define MM_EMPTY 0xFFFFFFFFFFFFFFFFULL
+#define MM_LOCAP 8          // private L2 locus slots per candidate before the final compaction
+
+// ---------------------------------------------------------------------------------------------
+// host: flatten the reference index
+// ---------------------------------------------------------------------------------------------
+static inline uint64_t pack_point(int32_t seqId, int32_t pos, int side) {
+  return ((uint64_t)(uint32_t)seqId << 33) | ((uint64_t)(uint32_t)pos << 1) | (side == 1 ? 1ull : 0ull);
+}
+
+int mm_build_device_index(mm_ctx* c, const int32_t* contigLen, const int32_t* refGroup, size_t nContigs) {
+  DeviceIndex& I = c->idx;
+  I.ready = false;
+  const size_t n = c->hMinmers.size(), nk = c->hKeys.size(), np = c->hPoints.size();
+  std::vector<DRecS> rs(n); std::vector<DRecE> re(n);
+  std::vector<int64_t> coff(nContigs + 1, 0);
+  {
+    int32_t prevSeq = 0; size_t i = 0;
+    for (size_t sId = 0; sId < nContigs; sId++) {
+      coff[sId] = (int64_t)i;
+      while (i < n && c->hMinmers[i].seqId == (int32_t)sId) i++;
+      (void)prevSeq;
+    }
+    coff[nContigs] = (int64_t)i;
+    if (i != n) { c->err = "mm_index_upload: minmerIndex is not grouped by ascending seqId"; return MM_ERR_ARG; }
+  }
+  for (size_t i = 0; i < n; i++) {
+    const mm_minmer& m = c->hMinmers[i];
+    if (m.wpos < 0 || m.wpos_end < 0) { c->err = "mm_index_upload: negative minmer position"; return MM_ERR_ARG; }
+    rs[i] = DRecS{m.hash, m.wpos, (uint32_t)m.wpos_end | (m.strand < 0 ? 0x80000000u : 0u)};
+  }
+  {
+    std::vector<uint32_t> order;
+    for (size_t sId = 0; sId < nContigs; sId++) {
+      const size_t b = (size_t)coff[sId], e = (size_t)coff[sId + 1];
+      order.resize(e - b);
+      std::iota(order.begin(), order.end(), 0u);
+      std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return c->hMinmers[b + x].wpos_end < c->hMinmers[b + y].wpos_end; });
+      for (size_t j = 0; j < order.size(); j++) { const mm_minmer& m = c->hMinmers[b + order[j]]; re[b + j] = DRecE{m.hash, m.wpos_end, 0}; }
+    }
+  }
+  size_t cap = 16; while (cap < 2 * nk + 2) cap <<= 1;
+  std::vector<uint64_t> hk(cap, MM_EMPTY), hv(cap, 0);
+  for (size_t i = 0; i < nk; i++) {
+    const uint64_t key = c->hKeys[i];
+    const uint64_t off = c->hOffsets[i], cnt = c->hOffsets[i + 1] - c->hOffsets[i];
+    if (cnt >= (1ull << 23) || off >= (1ull << 40)) { c->err = "mm_index_upload: lookup list too large for the packed table value"; return MM_ERR_ARG; }
+    const bool freq = std::binary_search(c->hFreq.begin(), c->hFreq.end(), key);
+    size_t slot = (size_t)key & (cap - 1);
+    while (hk[slot] != MM_EMPTY) { if (hk[slot] == key) { c->err = "mm_index_upload: duplicate key"; return MM_ERR_ARG; } slot = (slot + 1) & (cap - 1); }
+    hk[slot] = key; hv[slot] = (off << 24) | (cnt << 1) | (freq ? 1ull : 0ull);
+  }
+  std::vector<uint64_t> pk(np);
+  for (size_t i = 0; i < np; i++) pk[i] = pack_point(c->hPoints[i].seqId, c->hPoints[i].pos, c->hPoints[i].side);
+  std::vector<int32_t> grp(nContigs, 0);
+  if (refGroup) grp.assign(refGroup, refGroup + nContigs);
+
+  MM_HIP(c, I.recS.ensure(n * sizeof(DRecS) + 64)); MM_HIP(c, I.recE.ensure(n * sizeof(DRecE) + 64));
+  MM_HIP(c, I.contigOff.ensure((nContigs + 1) * 8)); MM_HIP(c, I.contigLen.ensure(nContigs * 4)); MM_HIP(c, I.refGroup.ensure(nContigs * 4));
+  MM_HIP(c, I.htKeys.ensure(cap * 8)); MM_HIP(c, I.htVals.ensure(cap * 8)); MM_HIP(c, I.ptKeys.ensure(np * 8 + 64));
+  if (n) { MM_HIP(c, hipMemcpyAsync(I.recS.p, rs.data(), n * sizeof(DRecS), hipMemcpyHostToDevice, c->stream));
+           MM_HIP(c, hipMemcpyAsync(I.recE.p, re.data(), n * sizeof(DRecE), hipMemcpyHostToDevice, c->stream)); }
+  MM_HIP(c, hipMemcpyAsync(I.contigOff.p, coff.data(), (nContigs + 1) * 8, hipMemcpyHostToDevice, c->stream));
+  MM_HIP(c, hipMemcpyAsync(I.contigLen.p, contigLen, nContigs * 4, hipMemcpyHostToDevice, c->stream));
+  MM_HIP(c, hipMemcpyAsync(I.refGroup.p, grp.data(), nContigs * 4, hipMemcpyHostToDevice, c->stream));
+  MM_HIP(c, hipMemcpyAsync(I.htKeys.p, hk.data(), cap * 8, hipMemcpyHostToDevice, c->stream));
+  MM_HIP(c, hipMemcpyAsync(I.htVals.p, hv.data(), cap * 8, hipMemcpyHostToDevice, c->stream));
+  if (np) MM_HIP(c, hipMemcpyAsync(I.ptKeys.p, pk.data(), np * 8, hipMemcpyHostToDevice, c->stream));
+  MM_HIP(c, hipStreamSynchronize(c->stream));
+  I.nRec = n; I.nKeys = nk; I.nPoints = np; I.nContigs = nContigs; I.htCap = cap; I.ready = true;
+  return MM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int mm_wave_sum(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ int mm_wave_excl_scan(int v) {      // exclusive prefix sum across the 64 lanes
+  int x = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o); if ((int)mm_lane() >= o) x += y; }
+  return x - v;
+}
+
+struct MapFlags { int hg, skipSelf, skipPrefix, lowerTri; };
+
+// ---------------------------------------------------------------------------------------------
+// k_seed_lookup: one wave per fragment.
+//   * probes the s sketch hashes in the open-addressing table (key -> offset,count,frequent)
+//   * drops frequent seeds and compacts the sketch (Q.minmerTableQuery / Q.sketchSize, computeMap.hpp:834-839)
+//   * reserves space for the fragment's interval points and gathers them as packed 64-bit keys
+//     (seqId<<33 | pos<<1 | isOpen), applying the skip_self / skip_prefix / lower_triangular
+//     filters of computeMap.hpp:891-896 (filtered points become MM_EMPTY and sort to the end).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_seed_lookup(int nFrags, int s, const DFrag* __restrict__ frags,
+              const uint64_t* __restrict__ skHash, const int8_t* __restrict__ skStrand, const uint32_t* __restrict__ skCount,
+              const uint64_t* __restrict__ htKeys, const uint64_t* __restrict__ htVals, uint64_t htMask,
+              const uint64_t* __restrict__ ptKeys, const int32_t* __restrict__ refGroup,
+              const int32_t* __restrict__ readGroup, const int32_t* __restrict__ readSelf, int seqCounterBase, MapFlags fl,
+              uint64_t* __restrict__ qHash, int8_t* __restrict__ qStrand, uint64_t* __restrict__ seedVal,
+              mm_frag_stats* __restrict__ stats, int64_t* __restrict__ ptOff, uint64_t* __restrict__ pts, unsigned long long ptsCap,
+              unsigned long long* __restrict__ counters /* [0] point cursor, [1] overflow flag */) {
+  const int f = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (f >= nFrags) return;
+  const int lane = (int)mm_lane();
+  const int cnt = (int)skCount[f];
+  const size_t fo = (size_t)f * s;
+  int outIdx = 0, P = 0;
+  for (int base = 0; base < cnt; base += 64) {
+    const int r = base + lane;
+    const bool act = r < cnt;
+    uint64_t h = 0, val = 0; bool found = false;
+    if (act) {
+      h = skHash[fo + r];
+      uint64_t slot = h & htMask;
+      while (true) {
+        const uint64_t kx = htKeys[slot];
+        if (kx == h) { found = true; val = htVals[slot]; break; }
+        if (kx == MM_EMPTY) break;
+        slot = (slot + 1) & htMask;
+      }
+    }
+    const bool keep = act && !(found && (val & 1ull));
+    const uint64_t m = __ballot(keep);
+    if (keep) {
+      const int idx = outIdx + (int)mm_popc_below(m);
+      qHash[fo + idx] = h; qStrand[fo + idx] = skStrand[fo + r]; seedVal[fo + idx] = found ? val : 0ull;
+    }
+    P += mm_wave_sum(keep && found ? (int)((val >> 1) & 0x7fffffull) : 0);
+    outIdx += __popcll(m);
+  }
+  // reserve point slots (a power of two above 64 so that the sorters can work in place)
+  int slots = P;
+  if (P > 64) { slots = 128; while (slots < P) slots <<= 1; }
+  unsigned long long off = 0;
+  if (lane == 0 && slots > 0) off = atomicAdd(&counters[0], (unsigned long long)slots);
+  off = __shfl(off, 0);
+  bool ok = true;
+  if (slots > 0 && off + (unsigned long long)slots > ptsCap) { ok = false; if (lane == 0) atomicOr(&counters[1], 1ull); }
+  int nValid = 0;
+  if (ok && slots > 0) {
+    const int readId = frags[f].readId;
+    const int rg = readGroup[readId], self = readSelf[readId], seqCounter = seqCounterBase + readId;
+    int done = 0;
+    for (int base = 0; base < outIdx; base += 64) {
+      const int i = base + lane;
+      uint64_t val = 0;
+      if (i < outIdx) val = seedVal[fo + i];
+      const int c = (int)((val >> 1) & 0x7fffffull);
+      const int my = done + mm_wave_excl_scan(c);
+      const uint64_t src = val >> 24;
+      for (int j = 0; j < c; j++) {
+        uint64_t key = ptKeys[src + j];
+        const int seqId = (int)(key >> 33);
+        bool drop = false;
+        if (fl.skipSelf && seqId == self) drop = true;
+        if (fl.skipPrefix && refGroup[seqId] == rg) drop = true;
+        if (fl.lowerTri && !(seqCounter > seqId)) drop = true;
+        if (drop) key = MM_EMPTY; else nValid++;
+        pts[off + my + j] = key;
+      }
+      done += mm_wave_sum(c);
+    }
+    for (int j = P + lane; j < slots; j += 64) pts[off + j] = MM_EMPTY;
+    nValid = mm_wave_sum(nValid);
+  }
+  if (lane == 0) {
+    mm_frag_stats st;
+    st.rawSketchSize = cnt; st.sketchSize = outIdx; st.maxHash = cnt ? skHash[fo + cnt - 1] : 0ull;
+    st.nPoints = nValid; st.nL1 = 0;
+    stats[f] = st;
+    ptOff[2 * f] = (int64_t)off; ptOff[2 * f + 1] = ok ? (int64_t)slots : 0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// point sorters (ascending packed key == ascending (seqId, pos, CLOSE-before-OPEN))
+// ---------------------------------------------------------------------------------------------
+// <= 64 points: one wave per fragment, bitonic network over the lanes
+__global__ void __launch_bounds__(256)
+k_sort_points_wave(int nFrags, const int64_t* __restrict__ ptOff, uint64_t* __restrict__ pts) {
+  const int f = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (f >= nFrags) return;
+  const int64_t off = ptOff[2 * f]; const int n = (int)ptOff[2 * f + 1];
+  if (n <= 1 || n > 64) return;
+  const int lane = (int)mm_lane();
+  uint64_t key = lane < n ? pts[off + lane] : MM_EMPTY;
+#pragma unroll
+  for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const uint32_t olo = __shfl_xor((uint32_t)key, j), ohi = __shfl_xor((uint32_t)(key >> 32), j);
+      const uint64_t other = ((uint64_t)ohi << 32) | olo;
+      const bool up = (lane & k) == 0, lower = (lane & j) == 0;
+      const uint64_t mn = key < other ? key : other, mx = key < other ? other : key;
+      key = (lower == up) ? mn : mx;
+    }
+  }
+  if (lane < n) pts[off + lane] = key;
+}
+
+// 65..LDSCAP points (power of two): one 256-thread workgroup per fragment, bitonic sort staged in LDS
+#define MM_SORT_LDSCAP 4096
+__global__ void __launch_bounds__(256)
+k_sort_points_block(int nFrags, const int64_t* __restrict__ ptOff, uint64_t* __restrict__ pts, const int32_t* __restrict__ list) {
+  __shared__ uint64_t sk[MM_SORT_LDSCAP];
+  const int f = list[blockIdx.x];
+  const int64_t off = ptOff[2 * f]; const int n = (int)ptOff[2 * f + 1];
+  for (int i = threadIdx.x; i < n; i += 256) sk[i] = pts[off + i];
+  __syncthreads();
+  for (int k = 2; k <= n; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < n; i += 256) {
+        const int p = i ^ j;
+        if (p > i) { const uint64_t a = sk[i], b = sk[p]; if ((a > b) == ((i & k) == 0)) { sk[i] = b; sk[p] = a; } }
+      }
+      __syncthreads();
+    }
+  for (int i = threadIdx.x; i < n; i += 256) pts[off + i] = sk[i];
+}
+
+// > LDSCAP points: one 1024-thread workgroup per fragment, bitonic sort in global memory (rare: very repetitive seeds)
+__global__ void __launch_bounds__(1024)
+k_sort_points_global(const int64_t* __restrict__ ptOff, uint64_t* __restrict__ pts, const int32_t* __restrict__ list) {
+  const int f = list[blockIdx.x];
+  const int64_t off = ptOff[2 * f]; const int64_t n = ptOff[2 * f + 1];
+  uint64_t* a = pts + off;
+  for (int64_t k = 2; k <= n; k <<= 1)
+    for (int64_t j = k >> 1; j > 0; j >>= 1) {
+      for (int64_t i = threadIdx.x; i < n; i += 1024) {
+        const int64_t p = i ^ j;
+        if (p > i) { const uint64_t x = a[i], y = a[p]; if ((x > y) == ((i & k) == 0)) { a[i] = y; a[p] = x; } }
+      }
+      __threadfence_block();
+      __syncthreads();
+    }
+}
+
+// builds the lists of fragments for the block / global sorters
+__global__ void k_classify_sort(int nFrags, const int64_t* __restrict__ ptOff, int32_t* __restrict__ listB, int32_t* __restrict__ listC,
+                                unsigned int* __restrict__ cnt /* [0] B, [1] C */) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= nFrags) return;
+  const int64_t n = ptOff[2 * f + 1];
+  if (n > MM_SORT_LDSCAP) listC[atomicAdd(&cnt[1], 1u)] = f;
+  else if (n > 64) listB[atomicAdd(&cnt[0], 1u)] = f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_l1_sweep: one thread per fragment over its sorted points (windowLen == 0, i.e. split mode).
+// Literal two-pointer restatement of computeMap.hpp:948-1115 on packed keys:
+//   key>>1 == (seqId<<32 | pos)  so  "trail <= lead in (seqId,pos)"  is one 64-bit compare.
+// Emits the joined candidates of each reference group (skip_prefix) in the reference's order.
+// ---------------------------------------------------------------------------------------------
+struct L1Emit {
+  mm_l1_candidate* out; int frag; int count; bool write;
+  bool have; mm_l1_candidate pend;
+  __device__ __forceinline__ void run(int seqId, int start, int end, int isize, int clusterLen, bool& firstOfGroup) {
+    // join with the previous candidate of the same computeL1CandidateRegions call when close (computeMap.hpp:1102-1115)
+    if (have && !firstOfGroup && seqId == pend.seqId && !(start > pend.rangeEndPos + clusterLen)) {
+      pend.rangeEndPos = end; pend.intersectionSize = isize > pend.intersectionSize ? isize : pend.intersectionSize;
+    } else {
+      flush();
+      pend.frag = frag; pend.seqId = seqId; pend.rangeStartPos = start; pend.rangeEndPos = end; pend.intersectionSize = isize; have = true;
+    }
+    firstOfGroup = false;
+  }
+  __device__ __forceinline__ void flush() { if (have) { if (write) out[count] = pend; count++; have = false; } }
+};
+
+__device__ void l1_sweep_fragment(const uint64_t* __restrict__ p, int nPts, int sketchSizeQ, int minHits0, const int32_t* __restrict__ cutoffs,
+                                  int nCutoffs, int sParam, int segLength, MapFlags fl, const int32_t* __restrict__ refGroup, L1Emit& em) {
+  int b = 0;
+  while (b < nPts) {
+    int e = nPts;
+    if (fl.skipPrefix) {
+      const int g = refGroup[(int)(p[b] >> 33)];
+      e = b; while (e < nPts && refGroup[(int)(p[e] >> 33)] == g) e++;
+    }
+    int minHits = minHits0;
+    bool go = true;
+    if (fl.hg) {                                                 // pass 1: best overlap (computeMap.hpp:948-999)
+      int overlap = 0, best = 0, trail = b, lead = b;
+      while (lead < e) {
+        const uint64_t lk = p[lead] >> 1;
+        while (trail < e && (p[trail] >> 1) <= lk) { if (!(p[trail] & 1ull)) overlap--; trail++; }
+        const uint32_t cur = (uint32_t)lk;
+        while (lead < e && (uint32_t)(p[lead] >> 1) == cur) { if (p[lead] & 1ull) overlap++; lead++; }
+        best = overlap > best ? overlap : best;
+      }
+      if (best < minHits) go = false;
+      else {
+        const double div = (double)sParam / 1000.0 > 1.0 ? (double)sParam / 1000.0 : 1.0;
+        int ci = (int)((double)(best < sketchSizeQ ? best : sketchSizeQ) / div);
+        if (ci >= nCutoffs) ci = nCutoffs - 1;
+        const int cut = cutoffs[ci];
+        minHits = cut > minHits ? cut : minHits;
+      }
+    }
+    if (go) {                                                    // pass 2: runs (computeMap.hpp:1009-1098)
+      bool firstOfGroup = true, inRun = false;
+      int rSeq = 0, rStart = 0, rEnd = 0, rSize = 0;
+      int overlap = 0, trail = b, lead = b;
+      int prevSeq = 0, prevPos = 0;
+      int curSeq = (int)(p[b] >> 33), curPos = (int)(uint32_t)(p[b] >> 1);
+      while (lead < e) {
+        const int prevOverlap = overlap;
+        const uint64_t lk = p[lead] >> 1;
+        while (trail < e && (p[trail] >> 1) <= lk) { if (!(p[trail] & 1ull)) overlap--; trail++; }
+        if ((int)(uint32_t)lk != curPos) { prevSeq = curSeq; prevPos = curPos; curSeq = (int)(lk >> 32); curPos = (int)(uint32_t)lk; }
+        while (lead < e && (int)(uint32_t)(p[lead] >> 1) == curPos) { if (p[lead] & 1ull) overlap++; lead++; }
+        if (prevOverlap >= minHits) {
+          if (inRun && rSeq != prevSeq) { em.run(rSeq, rStart, rEnd, rSize, segLength, firstOfGroup); inRun = false; }
+          if (!inRun) { rStart = prevPos; rEnd = prevPos; rSeq = prevSeq; rSize = prevOverlap; inRun = true; }
+          else { rSize = prevOverlap > rSize ? prevOverlap : rSize; rEnd = prevPos; }
+        } else {
+          if (inRun) em.run(rSeq, rStart, rEnd, rSize, segLength, firstOfGroup);
+          inRun = false;
+        }
+      }
+      if (inRun) em.run(rSeq, rStart, rEnd, rSize, segLength, firstOfGroup);
+    }
+    em.flush();
+    b = e;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_l1_sweep(int nFrags, const int64_t* __restrict__ ptOff, const uint64_t* __restrict__ pts, mm_frag_stats* __restrict__ stats,
+           const int32_t* __restrict__ minHitsTab, const int32_t* __restrict__ cutoffs, int nCutoffs, int sParam, int segLength,
+           MapFlags fl, const int32_t* __restrict__ refGroup, mm_l1_candidate* __restrict__ l1, unsigned long long l1Cap,
+           int64_t* __restrict__ l1Off, unsigned long long* __restrict__ counters /* [2] l1 cursor, [3] overflow */) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= nFrags) return;
+  const int nPts = stats[f].nPoints, S = stats[f].sketchSize;
+  int nOut = 0; long long base = 0;
+  if (nPts > 0 && S > 0) {
+    const uint64_t* p = pts + ptOff[2 * f];
+    const int minHits0 = minHitsTab[S];
+    L1Emit em; em.out = nullptr; em.frag = f; em.count = 0; em.write = false; em.have = false;
+    l1_sweep_fragment(p, nPts, S, minHits0, cutoffs, nCutoffs, sParam, segLength, fl, refGroup, em);
+    nOut = em.count;
+    if (nOut > 0) {
+      base = (long long)atomicAdd(&counters[2], (unsigned long long)nOut);
+      if ((unsigned long long)base + nOut > l1Cap) { atomicOr(&counters[3], 1ull); nOut = 0; }
+      else {
+        L1Emit ew; ew.out = l1 + base; ew.frag = f; ew.count = 0; ew.write = true; ew.have = false;
+        l1_sweep_fragment(p, nPts, S, minHits0, cutoffs, nCutoffs, sParam, segLength, fl, refGroup, ew);
+      }
+    }
+  }
+  stats[f].nL1 = nOut;
+  l1Off[f] = base;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_l2_slide: one lane per L1 candidate; the lane runs the SlideMapper sweep sequentially.
+// Per-lane state lives in LDS, transposed (cell p of lane l at word p*64+l => conflict-free for any p):
+//   bits 0..15  num_before_inc   bit 16 active   bits 24..31 strand_vote (int8)
+// Records come from two streams over the same contig: recS in minmerIndex order (inserts) and recE
+// ordered by wpos_end (evictions), which replaces the reference's heap (computeMap.hpp:1296-1358).
+// ---------------------------------------------------------------------------------------------
+struct L2Tmp { int32_t start, end, shared, strand; };
+
+__global__ void __launch_bounds__(64)
+k_l2_slide(int nCand, int s, int segLength, const mm_l1_candidate* __restrict__ l1, const mm_frag_stats* __restrict__ stats,
+           const uint64_t* __restrict__ qHash, const int8_t* __restrict__ qStrand,
+           const DRecS* __restrict__ recS, const DRecE* __restrict__ recE, const int64_t* __restrict__ contigOff,
+           const int64_t* __restrict__ l1Off, L2Tmp* __restrict__ tmp, mm_l2_locus* __restrict__ l2, unsigned long long l2Cap,
+           unsigned long long* __restrict__ counters /* [4] l2 cursor, [5] overflow, [6] locus-slot overflow */) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t cell[];
+  const int lane = threadIdx.x;
+  const int cIdx = blockIdx.x * 64 + lane;
+  if (cIdx >= nCand) return;
+  const mm_l1_candidate cand = l1[cIdx];
+  const int f = cand.frag;
+  const int S = stats[f].sketchSize;
+  const uint64_t* q = qHash + (size_t)f * s;
+  const int8_t* qs = qStrand + (size_t)f * s;
+#define CELL(p) cell[(p) * 64 + lane]
+  CELL(0) = 0;
+  for (int p = 1; p <= S; p++) CELL(p) = 1u;
+  int pivot = S, pivRank = S, shared = 0, votes = 0;
+  const uint64_t qmax = q[S - 1];
+
+  auto locate = [&](uint64_t h) {            // 1-based lower_bound over q[0..S)
+    int lo = 0, hi = S;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (q[mid] < h) lo = mid + 1; else hi = mid; }
+    return lo + 1;
+  };
+  auto insert = [&](uint64_t h, int rStrand) {      // slidingMap.hpp:125-165
+    if (h > qmax) return;
+    const int j = locate(h);
+    uint32_t cw = CELL(j);
+    if (q[j - 1] == h) {
+      int v = (int)(int8_t)(cw >> 24) + (int)qs[j - 1] * rStrand;
+      cw = (cw & 0x0000FFFFu) | 0x00010000u | ((uint32_t)(uint8_t)(int8_t)v << 24);
+      CELL(j) = cw;
+      if (j <= pivot) { shared++; votes += v; }
+    } else {
+      CELL(j) = cw + 1u;
+      if (j <= pivot) pivRank++;
+      if (pivRank > S) {
+        const uint32_t pw = (pivot == j) ? cw + 1u : CELL(pivot);
+        shared -= (int)((pw >> 16) & 1u); votes -= (int)(int8_t)(pw >> 24); pivRank -= (int)(pw & 0xFFFFu); pivot--;
+      }
+    }
+  };
+  auto remove = [&](uint64_t h) {                   // slidingMap.hpp:171-211
+    if (h > qmax) return;
+    const int j = locate(h);
+    uint32_t cw = CELL(j);
+    if (q[j - 1] == h) {
+      if (j <= pivot) { shared--; votes -= (int)(int8_t)(cw >> 24); }
+      CELL(j) = cw & 0x0000FFFFu;
+    } else {
+      CELL(j) = cw - 1u;
+      if (j <= pivot) pivRank--;
+      if (pivot + 1 <= S) {
+        const uint32_t nw = (pivot + 1 == j) ? cw - 1u : CELL(pivot + 1);
+        if (pivRank + (int)(nw & 0xFFFFu) <= S) { pivot++; shared += (int)((nw >> 16) & 1u); votes += (int)(int8_t)(nw >> 24); pivRank += (int)(nw & 0xFFFFu); }
+      }
+    }
+  };
+
+  const int64_t cb = contigOff[cand.seqId], ce = contigOff[cand.seqId + 1];
+  int64_t it, itE;
+  {                                                  // std::lower_bound(minmerIndex, (seqId, rangeStart - segLength - 1)) (:1290-1293)
+    const int target = cand.rangeStartPos - segLength - 1;
+    int64_t lo = cb, hi = ce;
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (recS[mid].wpos < target) lo = mid + 1; else hi = mid; }
+    it = lo;
+    lo = cb; hi = ce;                               // first eviction candidate: wpos_end > rangeStart
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (recE[mid].wend <= cand.rangeStartPos) lo = mid + 1; else hi = mid; }
+    itE = lo;
+  }
+  // pre-load (:1323-1338)
+  while (it < ce) {
+    const DRecS r = recS[it];
+    if (!(r.wpos < cand.rangeStartPos)) break;
+    if ((int)(r.wendStrand & 0x7fffffffu) > cand.rangeStartPos) insert(r.hash, (r.wendStrand >> 31) ? -1 : 1);
+    it++;
+  }
+  // slide (:1340-1434)
+  int bestShared = 1; bool inRun = false;
+  int curStart = 0, curEnd = 0, curShared = 0;
+  int nFlushed = 0; bool havePend = false; L2Tmp pend{0, 0, 0, 0};
+  L2Tmp* mySlots = tmp + (size_t)cIdx * MM_LOCAP;
+  bool slotOverflow = false;
+  auto close_run = [&](int strand) {                // :1417-1426 / :1440-1449
+    if (!havePend || pend.end + segLength < curStart) {
+      if (havePend) { if (nFlushed < MM_LOCAP) mySlots[nFlushed] = pend; else slotOverflow = true; nFlushed++; }
+      pend.start = curStart; pend.end = curEnd; pend.shared = curShared; pend.strand = strand; havePend = true;
+    } else {
+      pend.end = curEnd;
+    }
+  };
+  while (it < ce) {
+    const DRecS r = recS[it];
+    if (!(r.wpos <= cand.rangeEndPos)) break;
+    const int prevVotes = votes;
+    while (itE < ce) { const DRecE d = recE[itE]; if (!(d.wend <= r.wpos)) break; remove(d.hash); itE++; }
+    insert(r.hash, (r.wendStrand >> 31) ? -1 : 1);
+    const int nextW = (it + 1 < ce) ? recS[it + 1].wpos : r.wpos;
+    if (shared > bestShared) {
+      nFlushed = 0; havePend = false;               // l2_vec_out.clear()
+      inRun = true; bestShared = shared; curShared = shared; curStart = r.wpos; curEnd = nextW;
+    } else if (shared == bestShared) {
+      if (!inRun) { curShared = shared; curStart = r.wpos; }
+      inRun = true; curEnd = nextW;
+    } else {
+      if (inRun) { curEnd = nextW; close_run(prevVotes >= 0 ? 1 : -1); curStart = 0; curEnd = 0; curShared = 0; }
+      inRun = false;
+    }
+    it++;
+  }
+  if (inRun) close_run(votes >= 0 ? 1 : -1);
+#undef CELL
+  const int total = nFlushed + (havePend ? 1 : 0);
+  if (slotOverflow) atomicOr(&counters[6], 1ull);
+  if (total > 0 && !slotOverflow) {
+    const unsigned long long base = atomicAdd(&counters[4], (unsigned long long)total);
+    if (base + total > l2Cap) { atomicOr(&counters[5], 1ull); return; }
+    const int candLocal = (int)(cIdx - l1Off[f]);
+    for (int i = 0; i < total; i++) {
+      const L2Tmp t = (i < nFlushed) ? mySlots[i] : pend;
+      mm_l2_locus o;
+      o.frag = f; o.cand = candLocal; o.seqId = cand.seqId; o.optimalStart = t.start; o.optimalEnd = t.end;
+      o.meanOptimalPos = (t.start + t.end) / 2; o.sharedSketchSize = t.shared; o.strand = t.strand;
+      // keep the per-candidate emission order recoverable: ordinal in the low bits of a scratch field is not needed,
+      // entries of one candidate are contiguous and in order starting at `base`
+      l2[base + i] = o;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// launcher
+// ---------------------------------------------------------------------------------------------
+int mm_launch_map(mm_ctx* c) {
+  const int nF = (int)c->nFrags, s = c->P.sketchSize;
+  const DeviceIndex& I = c->idx;
+  MM_HIP(c, c->dQHash.ensure((size_t)nF * s * 8 + 64)); MM_HIP(c, c->dQStrand.ensure((size_t)nF * s + 64));
+  MM_HIP(c, c->dSeedVal.ensure((size_t)nF * s * 8 + 64)); MM_HIP(c, c->dStats.ensure((size_t)nF * sizeof(mm_frag_stats) + 64));
+  MM_HIP(c, c->dPtOff.ensure((size_t)nF * 16 + 64)); MM_HIP(c, c->dL1Off.ensure((size_t)nF * 8 + 64));
+  MM_HIP(c, c->dCounters.ensure(256));
+  c->nL1 = c->nL2 = 0;
+  if (nF == 0) return MM_OK;
+  MapFlags fl{(c->P.flags & MM_FLAG_HG_FILTER) ? 1 : 0, (c->P.flags & MM_FLAG_SKIP_SELF) ? 1 : 0,
+              (c->P.flags & MM_FLAG_SKIP_PREFIX) ? 1 : 0, (c->P.flags & MM_FLAG_LOWER_TRIANGULAR) ? 1 : 0};
+  if (c->ptsCap == 0) c->ptsCap = (size_t)nF * 128 + 4096;
+  if (c->l1Cap == 0) c->l1Cap = (size_t)nF * 2 + 1024;
+  DevBuf listB, listC;
+  MM_HIP(c, listB.ensure((size_t)nF * 4 + 16)); MM_HIP(c, listC.ensure((size_t)nF * 4 + 16));
+  int rc = MM_OK;
+  unsigned long long hc[8];
+
+  for (int attempt = 0; attempt < 8; attempt++) {           // grow-and-retry on capacity overflow
+    MM_HIP(c, c->dPts.ensure(c->ptsCap * 8 + 64));
+    MM_HIP(c, hipMemsetAsync(c->dCounters.p, 0, 256, c->stream));
+    unsigned long long* cnt = c->dCounters.as<unsigned long long>() + 8;   // [8..15]; [0..7] belong to the sketch launcher
+    {
+      KernelTimer t(c, MM_K_LOOKUP);
+      hipLaunchKernelGGL(k_seed_lookup, dim3((nF + 3) / 4), dim3(256), 0, c->stream, nF, s, c->dFrags.as<DFrag>(),
+                         c->dSkHash.as<uint64_t>(), c->dSkStrand.as<int8_t>(), c->dSkCount.as<uint32_t>(),
+                         I.htKeys.as<uint64_t>(), I.htVals.as<uint64_t>(), (uint64_t)(I.htCap - 1), I.ptKeys.as<uint64_t>(),
+                         I.refGroup.as<int32_t>(), c->dReadGroup.as<int32_t>(), c->dReadSelf.as<int32_t>(), c->seqCounterBase, fl,
+                         c->dQHash.as<uint64_t>(), c->dQStrand.as<int8_t>(), c->dSeedVal.as<uint64_t>(), c->dStats.as<mm_frag_stats>(),
+                         c->dPtOff.as<int64_t>(), c->dPts.as<uint64_t>(), (unsigned long long)c->ptsCap, cnt);
+      MM_HIP(c, hipGetLastError());
+    }
+    MM_HIP(c, hipMemcpyAsync(hc, cnt, 64, hipMemcpyDeviceToHost, c->stream));
+    MM_HIP(c, hipStreamSynchronize(c->stream));
+    if (hc[1]) { c->ptsCap = (size_t)hc[0] + (size_t)hc[0] / 8 + 4096; continue; }
+    break;
+  }
+  if (hc[1]) { c->err = "interval-point buffer overflow"; listB.release(); listC.release(); return MM_ERR_CAPACITY; }
+  unsigned long long* cnt = c->dCounters.as<unsigned long long>() + 8;
+  unsigned int* cls = (unsigned int*)(c->dCounters.as<unsigned long long>() + 16);   // [16] two 32-bit class counters
+  {
+    KernelTimer t(c, MM_K_SORT);
+    hipLaunchKernelGGL(k_sort_points_wave, dim3((nF + 3) / 4), dim3(256), 0, c->stream, nF, c->dPtOff.as<int64_t>(), c->dPts.as<uint64_t>());
+    hipLaunchKernelGGL(k_classify_sort, dim3((nF + 255) / 256), dim3(256), 0, c->stream, nF, c->dPtOff.as<int64_t>(),
+                       listB.as<int32_t>(), listC.as<int32_t>(), cls);
+    MM_HIP(c, hipGetLastError());
+    unsigned int hcls[2];
+    MM_HIP(c, hipMemcpyAsync(hcls, cls, 8, hipMemcpyDeviceToHost, c->stream));
+    MM_HIP(c, hipStreamSynchronize(c->stream));
+    if (hcls[0]) hipLaunchKernelGGL(k_sort_points_block, dim3(hcls[0]), dim3(256), 0, c->stream, nF, c->dPtOff.as<int64_t>(), c->dPts.as<uint64_t>(), listB.as<int32_t>());
+    if (hcls[1]) hipLaunchKernelGGL(k_sort_points_global, dim3(hcls[1]), dim3(1024), 0, c->stream, c->dPtOff.as<int64_t>(), c->dPts.as<uint64_t>(), listC.as<int32_t>());
+    MM_HIP(c, hipGetLastError());
+  }
+  for (int attempt = 0; attempt < 8; attempt++) {
+    MM_HIP(c, c->dL1.ensure(c->l1Cap * sizeof(mm_l1_candidate) + 64));
+    MM_HIP(c, hipMemsetAsync(cnt + 2, 0, 16, c->stream));
+    {
+      KernelTimer t(c, MM_K_L1);
+      hipLaunchKernelGGL(k_l1_sweep, dim3((nF + 255) / 256), dim3(256), 0, c->stream, nF, c->dPtOff.as<int64_t>(), c->dPts.as<uint64_t>(),
+                         c->dStats.as<mm_frag_stats>(), c->dMinHits.as<int32_t>(), c->dCutoffs.as<int32_t>(), (int)c->nCutoffs, s,
+                         c->P.segLength, fl, I.refGroup.as<int32_t>(), c->dL1.as<mm_l1_candidate>(), (unsigned long long)c->l1Cap,
+                         c->dL1Off.as<int64_t>(), cnt);
+      MM_HIP(c, hipGetLastError());
+    }
+    MM_HIP(c, hipMemcpyAsync(hc, cnt, 64, hipMemcpyDeviceToHost, c->stream));
+    MM_HIP(c, hipStreamSynchronize(c->stream));
+    if (hc[3]) { c->l1Cap = (size_t)hc[2] + (size_t)hc[2] / 8 + 1024; continue; }
+    break;
+  }
+  listB.release(); listC.release();
+  if (hc[3]) { c->err = "L1 candidate buffer overflow"; return MM_ERR_CAPACITY; }
+  c->nL1 = (size_t)hc[2];
+  if (c->nL1 == 0) { c->nL2 = 0; return rc; }
+
+  const size_t ldsL2 = (size_t)(s + 1) * 64 * 4;
+  if (ldsL2 > 160 * 1024) { c->err = "sketchSize too large for the LDS-resident L2 state"; return MM_ERR_ARG; }
+  MM_HIP(c, hipFuncSetAttribute((const void*)k_l2_slide, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsL2));
+  DevBuf tmp;
+  MM_HIP(c, tmp.ensure(c->nL1 * MM_LOCAP * sizeof(L2Tmp) + 64));
+  if (c->l2Cap < c->nL1 * 2 + 1024) c->l2Cap = c->nL1 * 2 + 1024;
+  for (int attempt = 0; attempt < 8; attempt++) {
+    MM_HIP(c, c->dL2.ensure(c->l2Cap * sizeof(mm_l2_locus) + 64));
+    MM_HIP(c, hipMemsetAsync(cnt + 4, 0, 24, c->stream));
+    {
+      KernelTimer t(c, MM_K_L2);
+      hipLaunchKernelGGL(k_l2_slide, dim3((unsigned)((c->nL1 + 63) / 64)), dim3(64), ldsL2, c->stream, (int)c->nL1, s, c->P.segLength,
+                         c->dL1.as<mm_l1_candidate>(), c->dStats.as<mm_frag_stats>(), c->dQHash.as<uint64_t>(), c->dQStrand.as<int8_t>(),
+                         I.recS.as<DRecS>(), I.recE.as<DRecE>(), I.contigOff.as<int64_t>(), c->dL1Off.as<int64_t>(), tmp.as<L2Tmp>(),
+                         c->dL2.as<mm_l2_locus>(), (unsigned long long)c->l2Cap, cnt);
+      MM_HIP(c, hipGetLastError());
+    }
+    MM_HIP(c, hipMemcpyAsync(hc, cnt, 64, hipMemcpyDeviceToHost, c->stream));
+    MM_HIP(c, hipStreamSynchronize(c->stream));
+    if (hc[5]) { c->l2Cap = (size_t)hc[4] + (size_t)hc[4] / 8 + 1024; continue; }
+    break;
+  }
+  tmp.release();
+  if (hc[6]) { c->err = "more than MM_LOCAP tied L2 loci for one candidate"; return MM_ERR_CAPACITY; }
+  if (hc[5]) { c->err = "L2 locus buffer overflow"; return MM_ERR_CAPACITY; }
+  c->nL2 = (size_t)hc[4];
+  return rc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// downloads
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+int mm_results_download(mm_ctx* c, mm_frag_stats* stats, mm_l1_candidate* l1, mm_l2_locus* l2) {
+  if (!c->mapped) { c->err = "mm_results_download: nothing mapped"; return MM_ERR_STATE; }
+  MM_HIP(c, hipSetDevice(c->device));
+  const size_t nF = c->nFrags;
+  std::vector<int64_t> l1off(nF);
+  std::vector<mm_frag_stats> st(nF);
+  if (nF) {
+    MM_HIP(c, hipMemcpyAsync(st.data(), c->dStats.p, nF * sizeof(mm_frag_stats), hipMemcpyDeviceToHost, c->stream));
+    MM_HIP(c, hipMemcpyAsync(l1off.data(), c->dL1Off.p, nF * 8, hipMemcpyDeviceToHost, c->stream));
+  }
+  std::vector<mm_l1_candidate> h1(c->nL1); std::vector<mm_l2_locus> h2(c->nL2);
+  if (c->nL1) MM_HIP(c, hipMemcpyAsync(h1.data(), c->dL1.p, c->nL1 * sizeof(mm_l1_candidate), hipMemcpyDeviceToHost, c->stream));
+  if (c->nL2) MM_HIP(c, hipMemcpyAsync(h2.data(), c->dL2.p, c->nL2 * sizeof(mm_l2_locus), hipMemcpyDeviceToHost, c->stream));
+  MM_HIP(c, hipStreamSynchronize(c->stream));
+  if (stats && nF) std::memcpy(stats, st.data(), nF * sizeof(mm_frag_stats));
+  // fragment-major order: candidates of fragment f are contiguous on the device at l1off[f]
+  std::vector<int64_t> newBase(nF, 0);
+  size_t w = 0;
+  for (size_t f = 0; f < nF; f++) {
+    newBase[f] = (int64_t)w;
+    for (int i = 0; i < st[f].nL1; i++) { if (l1) l1[w] = h1[(size_t)l1off[f] + i]; w++; }
+  }
+  if (l2 && c->nL2) {
+    // device order keeps every candidate's loci contiguous and in emission order; a stable sort by (frag, cand) finishes the job
+    std::vector<uint32_t> ord(c->nL2);
+    std::iota(ord.begin(), ord.end(), 0u);
+    std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) {
+      if (h2[a].frag != h2[b].frag) return h2[a].frag < h2[b].frag;
+      return h2[a].cand < h2[b].cand; });
+    for (size_t i = 0; i < c->nL2; i++) { mm_l2_locus o = h2[ord[i]]; o.cand = (int32_t)(newBase[o.frag] + o.cand); l2[i] = o; }
+  }
+  return MM_OK;
+}
+
+int mm_query_sketch_download(mm_ctx* c, mm_minmer* out) {
+  if (!c->mapped) { c->err = "mm_query_sketch_download: nothing mapped"; return MM_ERR_STATE; }
+  MM_HIP(c, hipSetDevice(c->device));
+  const size_t nF = c->nFrags, s = (size_t)c->P.sketchSize;
+  if (!nF) return MM_OK;
+  std::vector<uint64_t> h(nF * s); std::vector<int8_t> st(nF * s); std::vector<mm_frag_stats> fs(nF);
+  MM_HIP(c, hipMemcpyAsync(h.data(), c->dQHash.p, nF * s * 8, hipMemcpyDeviceToHost, c->stream));
+  MM_HIP(c, hipMemcpyAsync(st.data(), c->dQStrand.p, nF * s, hipMemcpyDeviceToHost, c->stream));
+  MM_HIP(c, hipMemcpyAsync(fs.data(), c->dStats.p, nF * sizeof(mm_frag_stats), hipMemcpyDeviceToHost, c->stream));
+  MM_HIP(c, hipStreamSynchronize(c->stream));
+  for (size_t f = 0; f < nF; f++)
+    for (int r = 0; r < fs[f].sketchSize; r++) {
+      const size_t o = f * s + r;
+      out[o] = mm_minmer{h[o], 0, 0, c->hFrags[f].readId + c->seqCounterBase, (int16_t)st[o], 0};
+    }
+  return MM_OK;
+}
+
+int mm_points_download(mm_ctx* c, size_t frag, mm_interval_point* out, size_t cap, size_t* n) {
+  if (!c->mapped || frag >= c->nFrags) { c->err = "mm_points_download: bad state / fragment"; return MM_ERR_STATE; }
+  MM_HIP(c, hipSetDevice(c->device));
+  int64_t po[2]; mm_frag_stats fs;
+  MM_HIP(c, hipMemcpy(po, c->dPtOff.as<int64_t>() + 2 * frag, 16, hipMemcpyDeviceToHost));
+  MM_HIP(c, hipMemcpy(&fs, c->dStats.as<mm_frag_stats>() + frag, sizeof fs, hipMemcpyDeviceToHost));
+  const size_t np = (size_t)fs.nPoints;
+  if (n) *n = np;
+  if (np > cap) { c->err = "mm_points_download: capacity"; return MM_ERR_ARG; }
+  std::vector<uint64_t> k(np);
+  if (np) MM_HIP(c, hipMemcpy(k.data(), c->dPts.as<uint64_t>() + po[0], np * 8, hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < np; i++) {
+    std::memset(&out[i], 0, sizeof out[i]);
+    out[i].seqId = (int32_t)(k[i] >> 33); out[i].pos = (int32_t)(uint32_t)(k[i] >> 1); out[i].side = (k[i] & 1ull) ? 1 : -1;
+  }
+  return MM_OK;
+}
+
+int mm_index_build(mm_ctx* c, const char*, const int64_t*, size_t, const int32_t*, float) {
+  c->err = "mm_index_build: not implemented yet"; return MM_ERR_STATE;
+}
+
+}  // extern "C"

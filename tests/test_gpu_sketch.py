@@ -1,0 +1,77 @@
+"""a4 on the device vs the CPU oracle: CommonFunc::sketchSequence (commonFunc.hpp:183).
+Bit-exact: hash, first position, last position, strand sign, count -- through the C ABI."""
+import numpy as np
+import pytest
+
+import mmutil as U
+
+pytestmark = pytest.mark.gpu
+
+
+def _expect(oracle, reads, k, s, L):
+    out = []
+    for ri, a in enumerate(reads):
+        n = len(a)
+        if n < k:
+            continue
+        if n <= L:
+            frs = [a]
+        else:
+            frs = [a[i * L:(i + 1) * L] for i in range(n // L)]
+            if n % L:
+                frs.append(a[n - L:])
+        for fr in frs:
+            out.append(oracle.sketch_sequence(fr, k, s, ri))
+    return out
+
+
+def _check(oracle, reads, k=19, s=130, L=5000):
+    from mashmap_amd import capi
+    ctx = capi.Context(k=k, segLength=L, sketchSize=s)
+    nF = ctx.reads_upload(reads)
+    got, cnt = ctx.sketch()
+    exp = _expect(oracle, reads, k, s, L)
+    assert nF == len(exp)
+    bad = 0
+    for f in range(nF):
+        g = [(int(x["hash"]), int(x["wpos"]), int(x["wpos_end"]), int(x["seqId"]), int(x["strand"])) for x in got[f, :cnt[f]]]
+        if g != exp[f]:
+            bad += 1
+            if bad < 3:
+                print("fragment", f, "count", cnt[f], len(exp[f]), g[:3], exp[f][:3])
+    ctx.close()
+    assert bad == 0
+
+
+def test_sketch_random_reads(oracle):
+    g = U.random_dna(1, 400000)
+    reads = [a for _, a, _ in U.sample_reads([g], 2, 40, 10000, 0.1)]
+    reads += [a for _, a, _ in U.sample_reads([g], 3, 10, 12345, 0.05)]     # overlapping tail fragment
+    reads += [U.random_dna(50, 700), U.random_dna(51, 19), U.random_dna(52, 18), U.random_dna(53, 5000), U.random_dna(54, 5001)]
+    _check(oracle, reads)
+
+
+def test_sketch_adversarial(oracle):
+    reads = []
+    for i in range(12):
+        L = 5000 + 777 * i
+        a = U.random_dna(100 + i, L)
+        if i % 4 == 0: a = U.tandem_repeat(100 + i, L, 23 + 5 * i)          # few distinct k-mers -> hard path
+        if i % 4 == 1: a = U.with_n_runs(a, i, 6, 45)
+        if i % 4 == 2: a = U.lowercase_some(a, i)
+        if i % 4 == 3: a[:] = ord("A")                                      # homopolymer: fwd != rc but one hash
+        reads.append(a)
+    reads.append(np.frombuffer(b"N" * 6000, dtype=np.uint8).copy())
+    reads.append(np.frombuffer(b"ACGT" * 2000, dtype=np.uint8).copy())
+    x = U.random_dna(7, 9000); x[100] = ord("N"); x[4990:5010] = ord("n"); x[8999] = ord("X")
+    reads.append(x)
+    _check(oracle, reads)
+
+
+@pytest.mark.parametrize("k,s,L", [(16, 60, 1000), (19, 498, 5000), (19, 40, 10000), (15, 200, 3000), (21, 130, 5000), (32, 100, 2500), (11, 30, 500)])
+def test_sketch_parameter_grid(oracle, k, s, L):
+    g = U.random_dna(11, 200000)
+    reads = [a for _, a, _ in U.sample_reads([g], 5 + k, 12, 2 * L + 123, 0.08)]
+    reads.append(U.with_n_runs(U.random_dna(9, L), 3, 4, 33))
+    reads.append(U.tandem_repeat(8, L, 101))
+    _check(oracle, reads, k, s, L)
