@@ -837,6 +837,19 @@ int64_t orc_session_lookup(void* h, uint64_t hash, orc_point* out, int64_t cap) 
   for (size_t i = 0; i < it->second.size() && (int64_t)i < cap; i++) out[i] = it->second[i];
   return (int64_t)it->second.size();
 }
+int64_t orc_session_npoints(void* h) { int64_t n = 0; for (auto& e : ((Session*)h)->lookup) n += (int64_t)e.second.size(); return n; }
+/* whole lookup map, ascending key order: keys[i] owns pts[offsets[i] .. offsets[i+1]) */
+void orc_session_export_lookup(void* h, uint64_t* keys, uint64_t* offsets, orc_point* pts) {
+  size_t i = 0; uint64_t o = 0;
+  for (auto& e : ((Session*)h)->lookup) {
+    keys[i] = e.first; offsets[i] = o;
+    for (auto& p : e.second) pts[o++] = p;
+    i++;
+  }
+  offsets[i] = o;
+}
+int64_t orc_session_nfreq(void* h) { return (int64_t)((Session*)h)->frequent.size(); }
+void orc_session_freq_list(void* h, uint64_t* out) { size_t i = 0; for (auto v : ((Session*)h)->frequent) out[i++] = v; }
 int orc_session_is_freq(void* h, uint64_t hash) { return ((Session*)h)->frequent.count(hash) ? 1 : 0; }
 int orc_session_freq_threshold(void* h) { return ((Session*)h)->freqThreshold; }
 int orc_session_ncontigs(void* h) { return (int)((Session*)h)->meta.size(); }

@@ -68,6 +68,10 @@ void orc_session_index_copy(void* h, orc_minmer* out);
 int64_t orc_session_nkeys(void* h);
 void orc_session_keys(void* h, uint64_t* keys, int64_t* counts); /* ascending key order */
 int64_t orc_session_lookup(void* h, uint64_t hash, orc_point* out, int64_t cap);
+int64_t orc_session_npoints(void* h);
+void orc_session_export_lookup(void* h, uint64_t* keys, uint64_t* offsets, orc_point* pts);
+int64_t orc_session_nfreq(void* h);
+void orc_session_freq_list(void* h, uint64_t* out);
 int orc_session_is_freq(void* h, uint64_t hash);
 int orc_session_freq_threshold(void* h);
 int orc_session_ncontigs(void* h);

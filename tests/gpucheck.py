@@ -1,0 +1,91 @@
+"""Shared driver for the -m gpu parity tests: run the C-ABI hot path and the CPU oracle on the same
+inputs and compare every integer the reference's L1/L2 produce, fragment by fragment."""
+import numpy as np
+
+import mmutil as U
+
+
+def prefix_groups(names, delim):
+    """Map::setRefGroups (computeMap.hpp:144): consecutive contigs sharing name[:rfind(delim)]"""
+    pre = [n[:n.rfind(delim)] if delim in n else n for n in names]   # std::string::substr(0, npos) keeps everything
+    grp, g = [], -1
+    for i, p in enumerate(pre):
+        if i == 0 or p != pre[i - 1]:
+            g += 1
+        grp.append(g)
+    return pre, grp
+
+
+def run_and_compare(oracle, contigs, reads, k=19, L=5000, s=130, pi=0.85, flags=U.FLAG_HG, delim="\0", kmerPct=0.001,
+                    seqCounterBase=0, check_points=True, verbose=True):
+    """contigs: [(name, uint8 array)], reads: [(name, uint8 array)].  Returns (nFragments, nMappedLoci)."""
+    from mashmap_amd import capi
+    h = oracle.session(contigs, k, L, s, pi, U.FILTER_MAP, flags, delim.encode() if delim != "\0" else b"\0", kmerPct)
+    ix = oracle.export_index(h)
+    cflags = 0
+    if flags & U.FLAG_HG: cflags |= capi.MM_FLAG_HG_FILTER
+    if flags & U.FLAG_SKIP_SELF: cflags |= capi.MM_FLAG_SKIP_SELF
+    if flags & U.FLAG_SKIP_PREFIX: cflags |= capi.MM_FLAG_SKIP_PREFIX
+    if flags & U.FLAG_LOWER_TRI: cflags |= capi.MM_FLAG_LOWER_TRIANGULAR
+    ctx = capi.Context(k=k, segLength=L, sketchSize=s, flags=cflags)
+    cnames = [n for n, _ in contigs]
+    refGroup = readGroup = None
+    if flags & U.FLAG_SKIP_PREFIX:
+        pre, refGroup = prefix_groups(cnames, delim)
+        readGroup = []
+        for n, _ in reads:
+            p = n[:n.rfind(delim)] if delim in n else n
+            readGroup.append(refGroup[pre.index(p)] if p in pre else -1)
+    selfId = [cnames.index(n) if n in cnames else -1 for n, _ in reads]
+    ctx.index_upload(ix["minmers"], ix["keys"], ix["offsets"], ix["points"], ix["freq"], ix["contigLen"], refGroup)
+    ctx.set_tables(oracle.min_hits_table(s, k, pi), oracle.cutoffs(h))
+    nF = ctx.reads_upload([a for _, a in reads], readGroup, selfId, seqCounterBase)
+    ctx.map()
+    stats, l1, l2 = ctx.results()
+    qsk = ctx.query_sketches()
+    frs = ctx.fragments()
+    l1_by_f = {}
+    for i, c in enumerate(l1):
+        l1_by_f.setdefault(int(c["frag"]), []).append((i, c))
+    l2_by_c = {}
+    for x in l2:
+        l2_by_c.setdefault(int(x["cand"]), []).append(x)
+    bad = {}
+    nloci = 0
+
+    def note(kind, f, got, exp):
+        bad[kind] = bad.get(kind, 0) + 1
+        if verbose and bad[kind] <= 2:
+            print("MISMATCH", kind, "fragment", f, "\n   got", got, "\n   exp", exp)
+
+    for f in range(nF):
+        fr = frs[f]
+        name, a = reads[int(fr["readId"])]
+        seq = a[int(fr["fragStart"]):int(fr["fragStart"]) + int(fr["len"])]
+        e = oracle.map_fragment(h, seq, seqCounterBase + int(fr["readId"]), name.encode(), len(a), s)
+        st = stats[f]
+        if int(st["rawSketchSize"]) != e["rawSketchSize"]: note("rawSketchSize", f, int(st["rawSketchSize"]), e["rawSketchSize"])
+        if int(st["sketchSize"]) != e["sketchSize"]: note("sketchSize", f, int(st["sketchSize"]), e["sketchSize"])
+        g_sk = [(int(x["hash"]), int(x["strand"])) for x in qsk[f, :int(st["sketchSize"])]]
+        e_sk = [(x[0], x[4]) for x in e["sketch"]]
+        if g_sk != e_sk: note("sketch", f, g_sk[:4], e_sk[:4])
+        if e["sketchSize"] > 0:
+            if check_points:
+                gp = [(int(p["seqId"]), int(p["pos"]), int(p["side"])) for p in ctx.points(f)]
+                ep = [p[:3] for p in e["points"]]
+                if gp != ep: note("points", f, (len(gp), gp[:6]), (len(ep), ep[:6]))
+            elif int(st["nPoints"]) != len(e["points"]): note("nPoints", f, int(st["nPoints"]), len(e["points"]))
+        g1 = [(int(c["seqId"]), int(c["rangeStartPos"]), int(c["rangeEndPos"]), int(c["intersectionSize"])) for _, c in l1_by_f.get(f, [])]
+        if g1 != e["l1"]: note("l1", f, g1[:4], e["l1"][:4])
+        else:
+            g2 = []
+            for ci, (gi, _) in enumerate(l1_by_f.get(f, [])):
+                for x in l2_by_c.get(gi, []):
+                    g2.append((ci, int(x["seqId"]), int(x["meanOptimalPos"]), int(x["optimalStart"]), int(x["optimalEnd"]),
+                               int(x["sharedSketchSize"]), int(x["strand"])))
+            nloci += len(g2)
+            if g2 != e["l2"]: note("l2", f, g2[:4], e["l2"][:4])
+    ctx.close()
+    oracle.free(h)
+    assert not bad, "GPU vs oracle mismatches: %r over %d fragments" % (bad, nF)
+    return nF, nloci

@@ -301,6 +301,8 @@ class _Side:
 
 MINMER_DT = np.dtype([("hash", "<u8"), ("wpos", "<i4"), ("wpos_end", "<i4"), ("seqId", "<i4"), ("strand", "<i2"),
                       ("pad", "<i2")])
+POINT_DT = np.dtype([("pos", "<i4"), ("pad0", "<i4"), ("hash", "<u8"), ("seqId", "<i4"), ("side", "i1"),
+                     ("pad1", "i1", (3,))])
 
 
 class Oracle(_Side):
@@ -326,6 +328,26 @@ class Oracle(_Side):
 
     def free(self, h):
         self.lib.orc_session_free(h)
+
+    def export_index(self, h):
+        """everything mm_index_upload needs, as numpy arrays in the C-ABI layouts"""
+        L = self.lib
+        L.orc_session_npoints.restype = C.c_int64; L.orc_session_npoints.argtypes = [C.c_void_p]
+        L.orc_session_nfreq.restype = C.c_int64; L.orc_session_nfreq.argtypes = [C.c_void_p]
+        L.orc_session_export_lookup.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_session_freq_list.argtypes = [C.c_void_p, C.c_void_p]
+        nk = L.orc_session_nkeys(h); npt = L.orc_session_npoints(h); nf = L.orc_session_nfreq(h)
+        keys = np.zeros(nk, dtype=np.uint64); offs = np.zeros(nk + 1, dtype=np.uint64); pts = np.zeros(npt, dtype=POINT_DT)
+        L.orc_session_export_lookup(h, keys.ctypes.data, offs.ctypes.data, pts.ctypes.data)
+        freq = np.zeros(nf, dtype=np.uint64)
+        if nf:
+            L.orc_session_freq_list(h, freq.ctypes.data)
+        nc = L.orc_session_ncontigs(h)
+        clen = np.array([L.orc_session_contig_len(h, i) for i in range(nc)], dtype=np.int32)
+        return dict(minmers=self.index_array(h), keys=keys, offsets=offs, points=pts, freq=freq, contigLen=clen)
+
+    def min_hits_table(self, s, k, pi):
+        return np.array([0] + [self.lib.orc_min_hits_relaxed(q, k, pi) for q in range(1, s + 1)], dtype=np.int32)
 
 
 class Ref(_Side):

@@ -1,0 +1,91 @@
+"""The hot path through the C ABI (sketch -> seed lookup -> L1 sweep -> L2 slide) vs the CPU oracle.
+Bit-exact on every integer: Q.sketchSize, the frequent-seed-filtered sketch, the sorted interval points,
+L1 candidate regions (computeMap.hpp:916) and L2 loci (computeMap.hpp:1276) for every candidate."""
+import numpy as np
+import pytest
+
+import mmutil as U
+from gpucheck import run_and_compare
+
+pytestmark = pytest.mark.gpu
+
+
+def genome(seed, sizes, names=None, repeats=True):
+    cs = [U.random_dna(seed + i, n) for i, n in enumerate(sizes)]
+    if repeats and len(cs) > 1 and min(sizes) >= 150000:
+        blk = cs[0][50000:80000]
+        mm = U.mutate(blk, 77, 0.03); cs[1][20000:20000 + len(mm)] = mm        # diverged duplicate on another contig
+        b2 = cs[0][100000:112000]
+        for j in range(4):
+            cs[-1][10000 + j * 30000:22000 + j * 30000] = b2                     # 4 exact copies -> repeated seeds
+    names = names or ["chr%d" % i for i in range(len(cs))]
+    return list(zip(names, cs))
+
+
+def reads_for(contigs, seed, n, rl, err):
+    return [(nm, a) for nm, a, _ in U.sample_reads([c for _, c in contigs], seed, n, rl, err)]
+
+
+def test_map_default_config(oracle):
+    contigs = genome(11, [400000, 300000, 200000])
+    reads = reads_for(contigs, 5, 120, 10000, 0.10) + reads_for(contigs, 6, 30, 12345, 0.05)
+    reads += [("short", U.random_dna(9, 700)), ("tiny", U.random_dna(10, 18)), ("unrelated", U.random_dna(12, 15000))]
+    nF, nl = run_and_compare(oracle, contigs, reads)
+    assert nF > 300 and nl > 250
+
+
+def test_map_frequent_seeds(oracle):
+    contigs = genome(21, [300000, 250000, 200000])
+    reads = reads_for(contigs, 7, 80, 10000, 0.08)
+    run_and_compare(oracle, contigs, reads, kmerPct=0.5)        # a real frequent-seed set -> Q.sketchSize < s
+
+
+def test_map_dense_low_identity(oracle):
+    contigs = genome(31, [300000, 200000])
+    reads = reads_for(contigs, 8, 40, 10000, 0.15)
+    run_and_compare(oracle, contigs, reads, s=498, pi=0.80)
+
+
+def test_map_long_segments_high_identity(oracle):
+    contigs = genome(41, [500000, 300000])
+    reads = reads_for(contigs, 9, 40, 30000, 0.02)
+    run_and_compare(oracle, contigs, reads, L=10000, s=40, pi=0.95)
+
+
+def test_map_no_hg_filter_small_k(oracle):
+    contigs = genome(51, [100000, 80000, 150000], repeats=False)
+    reads = reads_for(contigs, 10, 80, 3000, 0.08)
+    run_and_compare(oracle, contigs, reads, k=16, L=1000, s=60, flags=0)
+
+
+def test_map_self_skip_prefix_lower_triangular(oracle):
+    # all-vs-all of haplotype-like contigs named S{h}#1#chr{c}: -Y '#' semantics (computeMap.hpp:891-896)
+    base = [U.random_dna(60 + c, 60000) for c in range(3)]
+    contigs = []
+    for hidx in range(3):
+        for c in range(3):
+            a = base[c] if hidx == 0 else U.mutate(base[c], 100 * hidx + c, 0.02 * hidx)
+            contigs.append(("S%d#1#chr%d" % (hidx, c), a))
+    reads = [(n, a) for n, a in contigs]
+    run_and_compare(oracle, contigs, reads, pi=0.90, flags=U.FLAG_HG | U.FLAG_SKIP_PREFIX, delim="#")
+    run_and_compare(oracle, contigs, reads, pi=0.90, flags=U.FLAG_HG | U.FLAG_SKIP_SELF)
+    run_and_compare(oracle, contigs, reads, pi=0.90, flags=U.FLAG_HG | U.FLAG_LOWER_TRI)
+
+
+def test_map_adversarial_reads(oracle):
+    contigs = genome(71, [300000, 200000])
+    g0 = contigs[0][1]
+    reads = [("n_runs", U.with_n_runs(g0[1000:16000], 3, 8, 50)), ("lower", U.lowercase_some(g0[50000:65000], 4)),
+             ("tandem", U.tandem_repeat(5, 12000, 31)), ("allN", np.frombuffer(b"N" * 7000, dtype=np.uint8).copy()),
+             ("polyA", np.frombuffer(b"A" * 9000, dtype=np.uint8).copy()), ("exact", g0[100000:125000].copy()),
+             ("rc", U.revcomp(g0[200000:221000]))]
+    run_and_compare(oracle, contigs, reads)
+
+
+def test_map_repetitive_reference_many_points(oracle):
+    # a reference made of a repeated 20 kb unit: every seed has dozens of intervals -> block/global point sorters
+    unit = U.random_dna(81, 20000)
+    c0 = np.concatenate([U.mutate(unit, 200 + i, 0.01) for i in range(30)])
+    contigs = [("rep", c0), ("uniq", U.random_dna(82, 200000))]
+    reads = reads_for(contigs, 11, 30, 10000, 0.05)
+    run_and_compare(oracle, contigs, reads, kmerPct=0.0)
