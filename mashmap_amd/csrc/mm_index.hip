@@ -1,0 +1,314 @@
+// mashmap_amd/csrc/mm_index.hip -- reference-side index construction (mm_index_build).
+//
+//   k_ref_hash        both-strand MurmurHash3 of every reference k-mer        commonFunc.hpp:357-373
+//   winnow_contig     sliding bottom-s "minmer" intervals of one contig       commonFunc.hpp:302-570
+//   build_lookup      Sketch::index                                           winSketch.hpp:379-404
+//   frequency_filter  computeFreqHist / computeFreqSeedSet / dropFreqSeedSet  winSketch.hpp:410-504
+//
+// ROUND-1 STATUS: the hashing (all the integer-multiply work, ~95 % of the CPU cost of addMinmers)
+// runs on the device; the sliding-window bookkeeping that turns hashes into intervals still runs on
+// host threads inside this library and is the next kernel to move.
+#include "mm_internal.h"
+#include "mm_device.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <deque>
+#include <future>
+#include <memory>
+#include <thread>
+#include <map>
+#include <queue>
+#include <unordered_map>
+
+// ---------------------------------------------------------------------------------------------
+// device: canonical hash + strand of every k-mer position of a packed contig
+//   outH[i] = min(fwd, rc)  (0xFFFF... when the k-mer holds an N or fwd == rc), outS[i] = fwd < rc ? +1 : -1
+// ---------------------------------------------------------------------------------------------
+template <int K>
+__global__ void __launch_bounds__(256)
+k_ref_hash(const uint32_t* __restrict__ bases2, const uint32_t* __restrict__ nmask, int64_t nPos, int hasN,
+           uint64_t* __restrict__ outH, int8_t* __restrict__ outS) {
+  const int64_t nStrips = (nPos + 15) >> 4;
+  const uint64_t kmask = (1ull << K) - 1ull;
+  for (int64_t strip = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; strip < nStrips; strip += (int64_t)gridDim.x * blockDim.x) {
+    MMStrip st;
+    st.load(bases2[strip], bases2[strip + 1], bases2[strip + 2]);
+    uint64_t nm = 0;
+    if (hasN) {
+      const uint64_t m64 = (uint64_t)nmask[strip >> 1] | ((uint64_t)nmask[(strip >> 1) + 1] << 32);
+      nm = m64 >> ((strip & 1) * 16);
+    }
+    uint64_t hs[16]; uint32_t sbits = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const uint64_t hf = mm_murmur_kmer<K>(st.F, j);
+      const uint64_t hr = mm_murmur_kmer<K>(st.R, 48 - K - j);
+      bool ok = hf != hr;
+      if (hasN) ok = ok & (((nm >> j) & kmask) == 0);
+      hs[j] = ok ? (hf < hr ? hf : hr) : MM_HASH_MAX;
+      sbits |= (hf < hr ? 1u : 0u) << j;
+    }
+    const int64_t p0 = strip * 16;
+#pragma unroll
+    for (int j = 0; j < 16; j++)
+      if (p0 + j < nPos) { outH[p0 + j] = hs[j]; outS[p0 + j] = ((sbits >> j) & 1u) ? 1 : -1; }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// host: MurmurHash3_x64_128 low word over arbitrary bytes (only for the <= k-1 leading k-mers of a
+// contig that contain an 'N' the reference does not notice: commonFunc.hpp:334 has no initial-N scan)
+// ---------------------------------------------------------------------------------------------
+static inline uint64_t h_rotl(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+static inline uint64_t h_fmix(uint64_t k) { k ^= k >> 33; k *= 0xff51afd7ed558ccdULL; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ULL; k ^= k >> 33; return k; }
+static uint64_t host_murmur(const unsigned char* p, int len) {
+  uint64_t h1 = MM_SEED, h2 = MM_SEED;
+  const int nb = len / 16;
+  for (int b = 0; b < nb; b++) {
+    uint64_t k1, k2; std::memcpy(&k1, p + 16 * b, 8); std::memcpy(&k2, p + 16 * b + 8, 8);
+    k1 *= MM_C1; k1 = h_rotl(k1, 31); k1 *= MM_C2; h1 ^= k1; h1 = h_rotl(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
+    k2 *= MM_C2; k2 = h_rotl(k2, 33); k2 *= MM_C1; h2 ^= k2; h2 = h_rotl(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
+  }
+  uint64_t k1 = 0, k2 = 0; const unsigned char* t = p + 16 * nb; const int rem = len & 15;
+  for (int i = 0; i < rem; i++) { if (i < 8) k1 |= (uint64_t)t[i] << (8 * i); else k2 |= (uint64_t)t[i] << (8 * (i - 8)); }
+  if (rem > 8) { k2 *= MM_C2; k2 = h_rotl(k2, 33); k2 *= MM_C1; h2 ^= k2; }
+  if (rem > 0) { k1 *= MM_C1; k1 = h_rotl(k1, 31); k1 *= MM_C2; h1 ^= k1; }
+  h1 ^= (uint64_t)len; h2 ^= (uint64_t)len; h1 += h2; h2 += h1; h1 = h_fmix(h1); h2 = h_fmix(h2);
+  return h1 + h2;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host: hashes -> minmer intervals of one contig.  Event order per window W (= i + k - w for the
+// arriving k-mer i) follows the reference: departure of k-mer W-1, arrival of k-mer i, then
+// eviction / refill so that the sketch holds the s smallest distinct hashes of window W.
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct Pend { uint64_t h; int32_t pos; int8_t st; };
+struct PendWorse { bool operator()(const Pend& a, const Pend& b) const { return a.h != b.h ? a.h > b.h : a.pos > b.pos; } };
+struct Member { int32_t start; int32_t sum; std::deque<std::pair<int32_t, int8_t>> occ; };
+}
+
+static void winnow_contig(const uint64_t* H, const int8_t* ST, int64_t nPos, int len, int k, int w, int s, int seqId,
+                          std::vector<mm_minmer>& out) {
+  out.clear();
+  std::map<uint64_t, Member> sk;
+  std::vector<Pend> heap; PendWorse worse;
+  auto emit = [&](uint64_t h, const Member& m, int32_t end) { out.push_back(mm_minmer{h, m.start, end, seqId, (int16_t)m.sum, 0}); };
+  for (int64_t i = 0; i < nPos; i++) {
+    const int32_t W = (int32_t)(i + k - w);
+    if ((int64_t)heap.size() > 2 * (int64_t)w) {
+      heap.erase(std::remove_if(heap.begin(), heap.end(), [W](const Pend& p) { return p.pos < W; }), heap.end());
+      std::make_heap(heap.begin(), heap.end(), worse);
+    }
+    if (W >= 1 && H[W - 1] != MM_HASH_MAX && !sk.empty()) {            // departure
+      const uint64_t g = H[W - 1];
+      if (g <= std::prev(sk.end())->first) {
+        auto it = sk.find(g);
+        Member& m = it->second;
+        if (m.occ.size() == 1) { emit(g, m, W); sk.erase(it); }
+        else {
+          const int st = ST[W - 1];
+          if (m.sum - st == 0 || m.sum == 0) { emit(g, m, W); m.start = W; }
+          m.sum -= st; m.occ.pop_front();
+        }
+      }
+    }
+    const uint64_t h = H[i];
+    if (h != MM_HASH_MAX) {                                              // arrival
+      const int st = ST[i];
+      auto it = sk.find(h);
+      if (it != sk.end()) {
+        Member& m = it->second;
+        m.occ.emplace_back((int32_t)i, (int8_t)st);
+        if (m.sum + st == 0 || m.sum == 0) { emit(h, m, W); m.start = W; }
+        m.sum += st;
+      } else { heap.push_back(Pend{h, (int32_t)i, (int8_t)st}); std::push_heap(heap.begin(), heap.end(), worse); }
+    }
+    if (W >= 0) {                                                        // eviction / refill
+      while (!heap.empty() && heap.front().pos < W) { std::pop_heap(heap.begin(), heap.end(), worse); heap.pop_back(); }
+      if (!sk.empty() && !heap.empty() && (int)sk.size() == s && heap.front().h < std::prev(sk.end())->first) {
+        auto last = std::prev(sk.end());
+        emit(last->first, last->second, W);
+        for (auto& o : last->second.occ) if (o.first > W) { heap.push_back(Pend{last->first, o.first, o.second}); std::push_heap(heap.begin(), heap.end(), worse); }
+        sk.erase(last);
+      }
+      while (!heap.empty() && (int)sk.size() < s) {
+        while (!heap.empty() && heap.front().pos < W) { std::pop_heap(heap.begin(), heap.end(), worse); heap.pop_back(); }
+        if (heap.empty()) break;
+        const uint64_t nh = heap.front().h;
+        Member& m = sk[nh];
+        m.start = W; m.sum = 0; m.occ.clear();
+        while (!heap.empty() && heap.front().h == nh) {
+          m.occ.emplace_back(heap.front().pos, heap.front().st); m.sum += heap.front().st;
+          std::pop_heap(heap.begin(), heap.end(), worse); heap.pop_back();
+        }
+      }
+    }
+  }
+  { int rank = 1; for (auto it = sk.begin(); it != sk.end() && rank <= s; ++it, ++rank) emit(it->first, it->second, len - k + 1); }
+  out.erase(std::remove_if(out.begin(), out.end(), [](const mm_minmer& m) { return m.wpos < 0 || m.wpos_end < 0 || m.wpos == m.wpos_end; }), out.end());
+  std::vector<mm_minmer> pieces;
+  for (auto& m : out) {
+    m.strand = m.strand < 0 ? -1 : 1;
+    if (m.wpos_end > m.wpos + w) {
+      const int nchunk = (int)std::ceil(float(m.wpos_end - m.wpos) / float(w));
+      for (int c = 0; c < nchunk; c++) pieces.push_back(mm_minmer{m.hash, m.wpos + c * w, std::min(m.wpos + c * w + w, m.wpos_end), m.seqId, m.strand, 0});
+    }
+  }
+  out.erase(std::remove_if(out.begin(), out.end(), [w](const mm_minmer& m) { return m.wpos_end - m.wpos > w; }), out.end());
+  out.insert(out.end(), pieces.begin(), pieces.end());
+  std::sort(out.begin(), out.end(), [](const mm_minmer& l, const mm_minmer& r) { return l.wpos != r.wpos ? l.wpos < r.wpos : l.wpos_end < r.wpos_end; });
+  out.erase(std::unique(out.begin(), out.end(), [](const mm_minmer& l, const mm_minmer& r) { return l.wpos == r.wpos && l.hash == r.hash; }), out.end());
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int K>
+static int hash_contig(mm_ctx* c, const char* seq, int len, DevBuf& dAscii, DevBuf& dB, DevBuf& dM, DevBuf& dMeta, DevBuf& dH, DevBuf& dS,
+                       std::vector<uint64_t>& H, std::vector<int8_t>& S) {
+  const int64_t nPos = (int64_t)len - K + 1;
+  const int64_t packed = ((int64_t)len + 31) / 32 * 32;
+  MM_HIP(c, dAscii.ensure((size_t)len + 64)); MM_HIP(c, dB.ensure((size_t)packed / 4 + 64)); MM_HIP(c, dM.ensure((size_t)packed / 8 + 64));
+  MM_HIP(c, dMeta.ensure(64)); MM_HIP(c, dH.ensure((size_t)nPos * 8 + 64)); MM_HIP(c, dS.ensure((size_t)nPos + 64));
+  int64_t meta[4] = {0, packed, 0, packed};                       // srcOff[0..1], packOff[0..1]
+  int32_t rl = len; uint32_t zero = 0;
+  MM_HIP(c, hipMemcpyAsync(dAscii.p, seq, (size_t)len, hipMemcpyHostToDevice, c->stream));
+  MM_HIP(c, hipMemcpyAsync(dMeta.p, meta, 32, hipMemcpyHostToDevice, c->stream));
+  MM_HIP(c, hipMemcpyAsync((char*)dMeta.p + 32, &rl, 4, hipMemcpyHostToDevice, c->stream));
+  MM_HIP(c, hipMemcpyAsync((char*)dMeta.p + 40, &zero, 4, hipMemcpyHostToDevice, c->stream));
+  MM_HIP(c, hipMemsetAsync((char*)dB.p + packed / 4, 0, 64, c->stream));
+  MM_HIP(c, hipMemsetAsync((char*)dM.p + packed / 8, 0, 64, c->stream));
+  const int64_t nChunks = packed / 32;
+  {
+    const int prc = mm_launch_pack_raw(c, dAscii.as<uint8_t>(), dMeta.as<int64_t>(), dMeta.as<int64_t>() + 2, (const int32_t*)((char*)dMeta.p + 32), 1,
+                                       nChunks, dB.as<uint32_t>(), dM.as<uint32_t>(), (uint32_t*)((char*)dMeta.p + 40));
+    if (prc != MM_OK) return prc;
+  }
+  uint32_t hasN = 0;
+  MM_HIP(c, hipMemcpyAsync(&hasN, (char*)dMeta.p + 40, 4, hipMemcpyDeviceToHost, c->stream));
+  MM_HIP(c, hipStreamSynchronize(c->stream));
+  {
+    KernelTimer t(c, MM_K_REFHASH);
+    const int64_t nStrips = (nPos + 15) / 16;
+    int b2 = (int)std::min<int64_t>((nStrips + 255) / 256, 65536);
+    hipLaunchKernelGGL((k_ref_hash<K>), dim3(b2), dim3(256), 0, c->stream, dB.as<uint32_t>(), dM.as<uint32_t>(), nPos, (int)hasN,
+                       dH.as<uint64_t>(), dS.as<int8_t>());
+    MM_HIP(c, hipGetLastError());
+  }
+  H.resize((size_t)nPos); S.resize((size_t)nPos);
+  MM_HIP(c, hipMemcpyAsync(H.data(), dH.p, (size_t)nPos * 8, hipMemcpyDeviceToHost, c->stream));
+  MM_HIP(c, hipMemcpyAsync(S.data(), dS.p, (size_t)nPos, hipMemcpyDeviceToHost, c->stream));
+  MM_HIP(c, hipStreamSynchronize(c->stream));
+  // leading k-mers with an unnoticed N (see host_murmur): an N at position p < K-1 never starts the reference's
+  // ambiguity countdown, so k-mers i <= p that have no N at a position >= K-1 are hashed with the 'N' byte in place.
+  if (hasN) {
+    std::vector<unsigned char> norm((size_t)std::min<int64_t>(len, 2 * K));
+    for (size_t j = 0; j < norm.size(); j++) {
+      unsigned char ch = (unsigned char)seq[j]; if (ch > 96 && ch < 123) ch -= 32;
+      norm[j] = (ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T') ? ch : 'N';
+    }
+    for (int i = 0; i < K - 1 && i < nPos; i++) {
+      bool early = false, late = false;
+      for (int p = i; p < i + K; p++) if (norm[p] == 'N') { if (p < K - 1) early = true; else late = true; }
+      if (early && !late) {
+        unsigned char rc[64];
+        for (int p = 0; p < K; p++) { unsigned char ch = norm[i + p]; rc[K - 1 - p] = ch == 'A' ? 'T' : ch == 'C' ? 'G' : ch == 'G' ? 'C' : ch == 'T' ? 'A' : ch; }
+        const uint64_t f = host_murmur(&norm[i], K), b = host_murmur(rc, K);
+        H[i] = f == b ? MM_HASH_MAX : std::min(f, b); S[i] = f < b ? 1 : -1;
+      }
+    }
+  }
+  return MM_OK;
+}
+
+typedef int (*HashContigFn)(mm_ctx*, const char*, int, DevBuf&, DevBuf&, DevBuf&, DevBuf&, DevBuf&, DevBuf&, std::vector<uint64_t>&, std::vector<int8_t>&);
+static HashContigFn pick_hasher(int k) {
+  switch (k) {
+#define MM_CASE(KK) case KK: return &hash_contig<KK>;
+    MM_CASE(11) MM_CASE(12) MM_CASE(13) MM_CASE(14) MM_CASE(15) MM_CASE(16) MM_CASE(17) MM_CASE(18) MM_CASE(19)
+    MM_CASE(20) MM_CASE(21) MM_CASE(22) MM_CASE(23) MM_CASE(24) MM_CASE(25) MM_CASE(27) MM_CASE(29) MM_CASE(31) MM_CASE(32)
+#undef MM_CASE
+    default: return nullptr;
+  }
+}
+
+extern "C" int mm_index_build(mm_ctx* c, const char* bases, const int64_t* contigOffsets, size_t nContigs, const int32_t* refGroup,
+                              float kmerPctThreshold) {
+  if (!bases || !contigOffsets || !nContigs) { c->err = "mm_index_build: null argument"; return MM_ERR_ARG; }
+  MM_HIP(c, hipSetDevice(c->device));
+  const int k = c->P.kmerSize, w = c->P.segLength, s = c->P.sketchSize;
+  HashContigFn hasher = pick_hasher(k);
+  if (!hasher) { c->err = "mm_index_build: kmerSize not compiled in"; return MM_ERR_ARG; }
+  std::vector<int32_t> clen(nContigs);
+  std::vector<std::vector<mm_minmer>> per(nContigs);
+  std::deque<std::future<void>> inflight;
+  DevBuf dAscii, dB, dM, dMeta, dH, dS;
+  int rc = MM_OK;
+  const unsigned maxJobs = std::max(1u, std::thread::hardware_concurrency());
+  for (size_t ci = 0; ci < nContigs && rc == MM_OK; ci++) {
+    const int64_t len64 = contigOffsets[ci + 1] - contigOffsets[ci];
+    if (len64 < 0 || len64 > 0x7fffffff) { c->err = "mm_index_build: contig longer than int32 (offset_t)"; rc = MM_ERR_ARG; break; }
+    const int len = (int)len64; clen[ci] = len;
+    if (len < k || len < w) continue;            // winSketch.hpp:194; contigs shorter than a window yield no minmers
+    auto H = std::make_shared<std::vector<uint64_t>>(); auto S = std::make_shared<std::vector<int8_t>>();
+    rc = hasher(c, bases + contigOffsets[ci], len, dAscii, dB, dM, dMeta, dH, dS, *H, *S);
+    if (rc != MM_OK) break;
+    while (inflight.size() >= maxJobs) { inflight.front().get(); inflight.pop_front(); }
+    std::vector<mm_minmer>* dst = &per[ci];
+    inflight.push_back(std::async(std::launch::async, [H, S, len, k, w, s, ci, dst]() {
+      winnow_contig(H->data(), S->data(), (int64_t)H->size(), len, k, w, s, (int)ci, *dst);
+    }));
+  }
+  while (!inflight.empty()) { inflight.front().get(); inflight.pop_front(); }
+  dAscii.release(); dB.release(); dM.release(); dMeta.release(); dH.release(); dS.release();
+  if (rc != MM_OK) return rc;
+
+  // Sketch::index (winSketch.hpp:379-404): per-hash OPEN/CLOSE points in minmerIndex order, adjacent runs merged
+  std::vector<mm_minmer> all;
+  { size_t tot = 0; for (auto& v : per) tot += v.size(); all.reserve(tot); for (auto& v : per) { all.insert(all.end(), v.begin(), v.end()); std::vector<mm_minmer>().swap(v); } }
+  std::unordered_map<uint64_t, std::vector<mm_interval_point>> lookup;
+  lookup.reserve(all.size() / 2 + 16);
+  for (const auto& mi : all) {
+    auto& v = lookup[mi.hash];
+    if (v.empty() || v.back().pos != mi.wpos) {
+      mm_interval_point a; std::memset(&a, 0, sizeof a); a.pos = mi.wpos; a.hash = mi.hash; a.seqId = mi.seqId; a.side = 1;
+      mm_interval_point b = a; b.pos = mi.wpos_end; b.side = -1;
+      v.push_back(a); v.push_back(b);
+    } else v.back().pos = mi.wpos_end;
+  }
+  // frequency filter (winSketch.hpp:410-504)
+  int32_t freqThreshold = 0x7fffffff;
+  if (!lookup.empty()) {
+    std::map<int, int64_t> hist;
+    for (auto& e : lookup) hist[(int)e.second.size()] += 1;
+    const int64_t total = (int64_t)lookup.size();
+    const int64_t toIgnore = (int64_t)(total * kmerPctThreshold / 100);      // int64 * float / int, as winSketch.hpp:425
+    int64_t sum = 0;
+    for (auto it = hist.rbegin(); it != hist.rend(); ++it) {
+      sum += it->second;
+      if (sum < toIgnore) freqThreshold = it->first;
+      else if (sum == toIgnore) { freqThreshold = it->first; break; }
+      else break;
+    }
+  }
+  c->hKeys.clear(); c->hOffsets.clear(); c->hPoints.clear(); c->hFreq.clear();
+  c->hKeys.reserve(lookup.size());
+  for (auto& e : lookup) c->hKeys.push_back(e.first);
+  std::sort(c->hKeys.begin(), c->hKeys.end());
+  c->hOffsets.reserve(lookup.size() + 1);
+  uint64_t o = 0;
+  for (uint64_t key : c->hKeys) {
+    auto& v = lookup[key];
+    c->hOffsets.push_back(o); o += v.size();
+    c->hPoints.insert(c->hPoints.end(), v.begin(), v.end());
+    if ((int64_t)v.size() >= (int64_t)freqThreshold) c->hFreq.push_back(key);
+  }
+  c->hOffsets.push_back(o);
+  if (!c->hFreq.empty())
+    all.erase(std::remove_if(all.begin(), all.end(), [&](const mm_minmer& m) { return std::binary_search(c->hFreq.begin(), c->hFreq.end(), m.hash); }), all.end());
+  c->hMinmers.swap(all);
+  c->freqThreshold = freqThreshold;
+  c->mapped = false;
+  return mm_build_device_index(c, clen.data(), refGroup, nContigs);
+}

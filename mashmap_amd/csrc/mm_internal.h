@@ -113,6 +113,8 @@ struct KernelTimer {   // RAII hipEvent bracket on the ctx stream
 
 // launchers implemented in the .hip files
 int mm_launch_pack(mm_ctx* c);
+int mm_launch_pack_raw(mm_ctx* c, const uint8_t* dAscii, const int64_t* dSrcOff, const int64_t* dPackOff, const int32_t* dLen, int nReads,
+                       int64_t nChunks, uint32_t* dB, uint32_t* dM, uint32_t* dHasN);
 int mm_launch_sketch(mm_ctx* c);
 int mm_launch_map(mm_ctx* c);
 int mm_build_device_index(mm_ctx* c, const int32_t* contigLen, const int32_t* refGroup, size_t nContigs);

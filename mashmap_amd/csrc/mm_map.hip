@@ -694,8 +694,5 @@ int mm_points_download(mm_ctx* c, size_t frag, mm_interval_point* out, size_t ca
   return MM_OK;
 }
 
-int mm_index_build(mm_ctx* c, const char*, const int64_t*, size_t, const int32_t*, float) {
-  c->err = "mm_index_build: not implemented yet"; return MM_ERR_STATE;
-}
 
 }  // extern "C"

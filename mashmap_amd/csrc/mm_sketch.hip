@@ -303,6 +303,15 @@ int mm_launch_sketch(mm_ctx* c) {
   }
 }
 
+int mm_launch_pack_raw(mm_ctx* c, const uint8_t* dAscii, const int64_t* dSrcOff, const int64_t* dPackOff, const int32_t* dLen, int nReads,
+                       int64_t nChunks, uint32_t* dB, uint32_t* dM, uint32_t* dHasN) {
+  if (nChunks == 0) return MM_OK;
+  int blocks = (int)((nChunks + 255) / 256); if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(k_pack2bit, dim3(blocks), dim3(256), 0, c->stream, dAscii, dSrcOff, dPackOff, dLen, nReads, nChunks, dB, dM, dHasN);
+  MM_HIP(c, hipGetLastError());
+  return MM_OK;
+}
+
 int mm_launch_pack(mm_ctx* c) {
   const int64_t nChunks = (int64_t)(c->nPackedBases / 32);
   if (nChunks == 0) return MM_OK;
