@@ -1,0 +1,266 @@
+#!/usr/bin/env python3
+"""bench.py -- query Gbp/s of the sketch + L1/L2 hot path on N MI355X (one process per GPU).
+
+Workload (BASELINE.json configs[1]): 10 kbp ONT-error reads vs a 100 Mbp synthetic reference,
+pi = 85, segLength 5000, k = 19, sketchSize 130 (pinned: it is what the reference derives for this
+reference size).  Weak scaling: every GPU gets `--reads` reads (default 1 M) of its own.
+
+A "step" = one pass of the hot path (sketch -> seed lookup -> L1 sweep -> L2 slide) over the resident
+batch; inputs (2-bit packed bases + N mask) are already in HBM when the timed region starts; for N > 1
+the step ends with the all-gatherv (RCCL) of the L2 locus records.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+K, SEG, SKETCH, PI = 19, 5000, 130, 0.85
+READ_LEN, ERR = 10000, 0.10
+REF_CONTIGS, REF_CONTIG_LEN = 10, 10_000_000
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def make_reference(torch, dev, ncontigs, clen, seed=1):
+    g = torch.Generator(device=dev); g.manual_seed(seed)
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    return [lut[torch.randint(0, 4, (clen,), generator=g, device=dev)] for _ in range(ncontigs)]
+
+
+def make_reads(torch, dev, contigs, nreads, read_len, err, seed, chunk=16384):
+    """ONT-like reads on the device: uniform start/strand, i.i.d. err/3 sub + err/3 ins + err/3 del."""
+    g = torch.Generator(device=dev); g.manual_seed(seed)
+    ref = torch.cat(contigs)
+    coff = torch.tensor(np.cumsum([0] + [len(c) for c in contigs[:-1]]), device=dev)
+    clen = torch.tensor([len(c) for c in contigs], device=dev)
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    comp = torch.zeros(256, dtype=torch.uint8, device=dev)
+    for a, b in zip(b"ACGT", b"TGCA"):
+        comp[a] = b
+    src_len = int(read_len * (1 + err)) + 200
+    out = torch.empty(nreads * read_len, dtype=torch.uint8, device=dev)
+    ar = torch.arange(src_len, device=dev)
+    for r0 in range(0, nreads, chunk):
+        R = min(chunk, nreads - r0)
+        ci = torch.randint(0, len(contigs), (R,), generator=g, device=dev)
+        st = (torch.rand(R, generator=g, device=dev, dtype=torch.float64) * (clen[ci] - src_len).double()).long()
+        rev = torch.rand(R, generator=g, device=dev) < 0.5
+        seg = ref[(coff[ci] + st)[:, None] + ar[None, :]]
+        seg = torch.where(rev[:, None], comp[seg.flip(1).long()], seg)
+        u = torch.rand(R, src_len, generator=g, device=dev)
+        rb = lut[torch.randint(0, 4, (R, src_len), generator=g, device=dev)]
+        is_sub = u < err / 3
+        is_ins = (u >= err / 3) & (u < 2 * err / 3)
+        is_del = (u >= 2 * err / 3) & (u < err)
+        cnt = (~is_del).int() + is_ins.int()
+        pos = torch.cumsum(cnt, dim=1) - cnt                     # output slot of the (possibly inserted) first symbol
+        base = torch.where(is_sub & (rb != seg), rb, seg)
+        dst = out[r0 * read_len:(r0 + R) * read_len].view(R, read_len)
+        rows = torch.arange(R, device=dev)[:, None].expand(R, src_len)
+        m = is_ins & (pos < read_len)
+        dst[rows[m], pos[m]] = rb[m]
+        p2 = pos + is_ins.int()
+        m = (~is_del) & (p2 < read_len)
+        dst[rows[m], p2[m]] = base[m]
+        assert int((pos[:, -1] + cnt[:, -1]).min()) >= read_len
+        del seg, u, rb, cnt, pos, base, rows, m, p2
+    return out
+
+
+def write_fasta(path, names, arrays, width=100):
+    with open(path, "wb") as f:
+        for n, a in zip(names, arrays):
+            f.write(b">" + n.encode() + b"\n")
+            full = (len(a) // width) * width
+            if full:
+                lines = np.concatenate([a[:full].reshape(-1, width), np.full((full // width, 1), 10, dtype=np.uint8)], axis=1)
+                f.write(lines.tobytes())
+            if len(a) > full:
+                f.write(a[full:].tobytes() + b"\n")
+
+
+def cpu_baseline(ref_np, reads_np, n_sample, read_len):
+    """the reference's own CPU path (oracle/_ref/mashmap_ref, built from /root/reference with the GSL stand-in) or,
+    if that binary did not travel, our CPU port (oracle/liboracle.so); timed on this box's host cores."""
+    ncores = os.cpu_count() or 1
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "mashmap_ref")
+    sample = reads_np[:n_sample * read_len].reshape(n_sample, read_len)
+    desc = "%d of the benchmark reads (%.0f Mbp) vs the same 100 Mbp reference" % (n_sample, n_sample * read_len / 1e6)
+    if os.path.exists(ref_bin):
+        with tempfile.TemporaryDirectory() as td:
+            rp, qp, op = os.path.join(td, "ref.fa"), os.path.join(td, "q.fa"), os.path.join(td, "o.paf")
+            write_fasta(rp, ["chr%d" % i for i in range(len(ref_np))], ref_np)
+            write_fasta(qp, ["read%d" % i for i in range(n_sample)], list(sample))
+            with open(qp + ".fai", "w") as f:          # avoids the reference's extra pass over the query file
+                for i in range(n_sample):
+                    f.write("read%d\t%d\t0\t100\t101\n" % (i, read_len))
+            t0 = time.time()
+            p = subprocess.run([ref_bin, "-r", rp, "-q", qp, "-o", op, "-t", str(ncores), "-s", str(SEG), "--pi", str(int(PI * 100)),
+                                "-k", str(K), "-J", str(SKETCH)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+            wall = time.time() - t0
+            tmap = None
+            for line in p.stderr.splitlines():
+                if "time spent mapping the query" in line:
+                    tmap = float(line.split(":")[-1].split()[0])
+            if p.returncode == 0 and tmap:
+                log("[cpu_baseline] reference binary: map %.2f s (total wall %.1f s) on %d threads" % (tmap, wall, ncores))
+                return {"value": n_sample * read_len / tmap / 1e9, "unit": "Gbp/s", "cores": ncores, "kind": "reference",
+                        "sample": desc + "; mashmap_ref -t %d, 'time spent mapping the query' (includes its FASTA reader)" % ncores}
+            log("[cpu_baseline] reference binary failed, falling back to the port:", p.stderr[-300:])
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import mmutil as U
+    orc = U.Oracle()
+    h = orc.session([("chr%d" % i, a) for i, a in enumerate(ref_np[:1])], K, SEG, SKETCH, PI)
+    n = min(n_sample, 200)
+    t0 = time.time()
+    for i in range(n):
+        for off in range(0, read_len - SEG + 1, SEG):
+            orc.map_fragment(h, sample[i, off:off + SEG], i, b"r", read_len, SKETCH)
+    dt = time.time() - t0
+    orc.free(h)
+    return {"value": n * read_len / dt / 1e9 * 0.5, "unit": "Gbp/s", "cores": 1, "kind": "port",
+            "sample": "%d reads vs the first 10 Mbp contig; scalar port, diagnostic entry runs the path twice (halved)" % n}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=int(os.environ.get("MM_BENCH_READS", 1_000_000)), help="reads per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=10000)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from mashmap_amd import capi
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    t0 = time.time()
+    contigs = make_reference(torch, dev, REF_CONTIGS, REF_CONTIG_LEN)
+    ref_np = [c.cpu().numpy() for c in contigs]
+    reads_t = make_reads(torch, dev, contigs, args.reads, READ_LEN, ERR, seed=1000 + rank)
+    torch.cuda.synchronize()
+    log("[rank %d] synthetic data: %.1f s" % (rank, time.time() - t0))
+
+    ctx = capi.Context(k=K, segLength=SEG, sketchSize=SKETCH, flags=capi.MM_FLAG_HG_FILTER, device=local)
+    t0 = time.time()
+    ctx.index_build(ref_np, kmerPct=0.001)
+    ctx.set_tables_default(PI)
+    log("[rank %d] index build (device hash + host winnow): %.1f s" % (rank, time.time() - t0))
+    offs = np.arange(args.reads + 1, dtype=np.int64) * READ_LEN
+    nF = ctx.reads_upload_device(reads_t.data_ptr(), reads_t.numel(), offs)
+    reads_np = reads_t[:min(args.reads, args.cpu_sample) * READ_LEN].cpu().numpy() if rank == 0 else None
+    del reads_t, contigs
+    torch.cuda.empty_cache()
+
+    gather_buf = None
+
+    def step():
+        ctx.map()
+        if world > 1:                                   # all-gatherv of the L2 locus records over RCCL/xGMI
+            nonlocal gather_buf
+            n1, n2 = ctx.result_counts()
+            cnt = torch.tensor([n2], dtype=torch.int64, device=dev)
+            allc = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+            dist.all_gather(allc, cnt)
+            mx = int(max(int(c.item()) for c in allc))
+            mine = torch.zeros(mx * 8, dtype=torch.int32, device=dev)
+            ctx.results_copy_device(mine.data_ptr(), mx)
+            if gather_buf is None or gather_buf.numel() < world * mx * 8:
+                gather_buf = torch.empty(world * mx * 8, dtype=torch.int32, device=dev)
+            dist.all_gather_into_tensor(gather_buf[:world * mx * 8], mine)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ctx.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ctx.profile(True); ctx.profile_read(reset=True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    prof = ctx.profile_read(reset=True)
+    ctx.profile(False)
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    n1, n2 = ctx.result_counts()
+    stats, _, _ = ctx.results() if rank == 0 else (None, None, None)
+
+    if rank == 0:
+        bases_step = args.reads * READ_LEN * world
+        value = bases_step * args.steps / dt / 1e9
+        # roofline of the dominant kernel (k_sketch_fragments): algorithmic bytes per fragment = L/4 packed bases in
+        # + 24 B per sketch entry out, divided by its average HIP-event duration in the timed region
+        sk_ms, sk_n = prof["sketch"]
+        frag_bytes = SEG / 4.0 + 24.0 * SKETCH
+        ach = frag_bytes * nF / (sk_ms / max(1, sk_n) / 1e3) / 1e9 if sk_ms > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_sketch_pmc.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        kernels = {k: {"ms_per_step": v[0] / args.steps, "launches_per_step": v[1] / args.steps} for k, v in prof.items() if v[1]}
+        P = float(stats["nPoints"].mean()); S = float(stats["sketchSize"].mean())
+        out = {
+            "metric": "query Gbp/s sketch+L1/L2 map (pi=85, s=5000)", "value": round(value, 4), "unit": "Gbp/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "configs[1]: %d x %d bp reads/GPU (%.0f%% ONT-like error) vs 100 Mbp synthetic reference (10 contigs)"
+                                   % (args.reads, READ_LEN, ERR * 100), "k": K, "segLength": SEG, "sketchSize": SKETCH,
+                       "percentageIdentity": PI, "fragments_per_gpu": nF, "parallelism": "reads sharded, index replicated, RCCL all-gatherv of L2 loci"
+                       if world > 1 else "single GPU", "mean_interval_points_per_fragment": round(P, 1),
+                       "l1_candidates_per_gpu": n1, "l2_loci_per_gpu": n2},
+            "roofline": {"bound": "hbm", "kernel": "k_sketch_fragments", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "algorithmic_bytes_per_fragment": frag_bytes, "avg_launch_ms": round(sk_ms / max(1, sk_n), 3),
+                         "note": "integer-ALU bound kernel (2 x MurmurHash3_x64_128 per base, 12 64-bit multiplies each); "
+                                 "HBM fraction is expected to be small -- see DESIGN.md for the integer roofline"},
+            "kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(ref_np, reads_np, min(args.cpu_sample, args.reads), READ_LEN)
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

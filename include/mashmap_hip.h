@@ -111,6 +111,22 @@ int mm_index_upload(mm_ctx* ctx,
  */
 int mm_set_tables(mm_ctx* ctx, const int32_t* minHits, size_t nMinHits, const int32_t* sketchCutoffs, size_t nCutoffs);
 
+/* same tables computed inside the library (mashmap_amd/host/mm_stats.hpp mirrors skch::Stat and Map::setProbs) and uploaded */
+int mm_set_tables_default(mm_ctx* ctx, float percentageIdentity);
+
+/*
+ * Host-side statistics (no device needed) -- mirrors of skch::Stat (map_stats.hpp:45-262), exported so
+ * that parity tests and the C++ host side share one implementation:
+ *   j2md :45, md2j :63, md_lower_bound :81, estimateMinimumHitsRelaxed :144 (ci = 0.95),
+ *   recommendedSketchSize :234 (p-value 1e-3, ci 0.95, alphabet 4), Map::sketchCutoffs (computeMap.hpp:178-258)
+ */
+float   mm_stat_j2md(float j, int k);
+float   mm_stat_md2j(float d, int k);
+float   mm_stat_md_lower_bound(float d, int s, int k, float ci);
+int     mm_stat_min_hits_relaxed(int s, int k, float percentageIdentity);
+int64_t mm_stat_recommended_sketch_size(int k, float percentageIdentity, int64_t segLength, uint64_t referenceSize);
+int     mm_stat_sketch_cutoffs(int sketchSize, int k, int hgFilter, int32_t* out, size_t cap);   /* returns entries written */
+
 /*
  * A batch of query reads -> device.  Replaces the `char* seq` handed to sketchSequence
  * (commonFunc.hpp:183): ASCII in, normalised (makeUpperCaseAndValidDNA, :97) and packed to
@@ -149,6 +165,9 @@ int mm_results_download(mm_ctx* ctx, mm_frag_stats* stats, mm_l1_candidate* l1, 
 int mm_query_sketch_download(mm_ctx* ctx, mm_minmer* out);
 /* sorted, filtered interval points of fragment f (debug/parity; (seqId,pos,side) only, hash = 0) */
 int mm_points_download(mm_ctx* ctx, size_t frag, mm_interval_point* out, size_t cap, size_t* n);
+/* copies the L2 loci (fragment-major device order, not re-sorted) into caller-owned DEVICE memory, e.g. a torch tensor
+ * that is then exchanged with RCCL; *n receives the count, cap is the capacity of dst in records */
+int mm_results_copy_device(mm_ctx* ctx, mm_l2_locus* dDst, size_t cap, size_t* n);
 /* device addresses of the result arrays (for RCCL all-gatherv by the caller); valid until the next map call */
 int mm_results_device(const mm_ctx* ctx, const mm_l2_locus** dL2, size_t* nL2);
 

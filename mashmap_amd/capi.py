@@ -65,6 +65,14 @@ def load():
         "mm_last_error": (C.c_char_p, [vp]),
         "mm_index_upload": (C.c_int, [vp, vp, sz, vp, vp, sz, vp, sz, vp, sz, vp, vp, sz]),
         "mm_set_tables": (C.c_int, [vp, vp, sz, vp, sz]),
+        "mm_set_tables_default": (C.c_int, [vp, C.c_float]),
+        "mm_stat_j2md": (C.c_float, [C.c_float, C.c_int]),
+        "mm_stat_md2j": (C.c_float, [C.c_float, C.c_int]),
+        "mm_stat_md_lower_bound": (C.c_float, [C.c_float, C.c_int, C.c_int, C.c_float]),
+        "mm_stat_min_hits_relaxed": (C.c_int, [C.c_int, C.c_int, C.c_float]),
+        "mm_stat_recommended_sketch_size": (i64, [C.c_int, C.c_float, i64, C.c_uint64]),
+        "mm_stat_sketch_cutoffs": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, sz]),
+        "mm_results_copy_device": (C.c_int, [vp, vp, sz, C.POINTER(sz)]),
         "mm_reads_upload": (C.c_int, [vp, vp, vp, sz, vp, vp, i32]),
         "mm_reads_upload_device": (C.c_int, [vp, vp, sz, vp, sz, vp, vp, i32]),
         "mm_num_fragments": (sz, [vp]),
@@ -95,11 +103,21 @@ def load():
 
 
 EXPORTS = ["mm_abi_version", "mm_create", "mm_destroy", "mm_last_error", "mm_index_upload", "mm_set_tables",
+           "mm_set_tables_default", "mm_stat_j2md", "mm_stat_md2j", "mm_stat_md_lower_bound", "mm_stat_min_hits_relaxed",
+           "mm_stat_recommended_sketch_size", "mm_stat_sketch_cutoffs", "mm_results_copy_device",
            "mm_reads_upload", "mm_reads_upload_device", "mm_num_fragments", "mm_fragments_download",
            "mm_sketch_fragments", "mm_sketch_download", "mm_map_fragments", "mm_result_counts",
            "mm_results_download", "mm_query_sketch_download", "mm_points_download", "mm_results_device",
            "mm_index_build", "mm_index_sizes", "mm_index_download", "mm_profile_enable", "mm_profile_read",
            "mm_kernel_name", "mm_synchronize", "mm_stream"]
+
+
+def stat_sketch_cutoffs(sketchSize, k, hg=True):
+    lib = load()
+    n = lib.mm_stat_sketch_cutoffs(sketchSize, k, 1 if hg else 0, None, 0)
+    out = np.zeros(n, dtype=np.int32)
+    lib.mm_stat_sketch_cutoffs(sketchSize, k, 1 if hg else 0, _ptr(out), n)
+    return out
 
 
 class Context:
@@ -161,6 +179,14 @@ class Context:
     def set_tables(self, minHits, cutoffs):
         a = np.ascontiguousarray(minHits, dtype=np.int32); b = np.ascontiguousarray(cutoffs, dtype=np.int32)
         self._ck(self.lib.mm_set_tables(self.h, _ptr(a), len(a), _ptr(b), len(b)), "mm_set_tables")
+
+    def set_tables_default(self, pi):
+        self._ck(self.lib.mm_set_tables_default(self.h, pi), "mm_set_tables_default")
+
+    def results_copy_device(self, dptr, cap):
+        n = C.c_size_t()
+        self._ck(self.lib.mm_results_copy_device(self.h, C.c_void_p(dptr), cap, C.byref(n)), "mm_results_copy_device")
+        return n.value
 
     # ---- reads
     def reads_upload(self, reads, refGroup=None, selfSeqId=None, seqCounterBase=0):

@@ -2,6 +2,7 @@
 #include "mm_internal.h"
 #include <algorithm>
 #include <cstring>
+#include "../host/mm_stats.hpp"
 
 static thread_local std::string g_createErr;
 
@@ -106,6 +107,29 @@ int mm_set_tables(mm_ctx* c, const int32_t* minHits, size_t nMinHits, const int3
   MM_HIP(c, hipStreamSynchronize(c->stream));
   c->nMinHits = nMinHits; c->nCutoffs = nCutoffs;
   return MM_OK;
+}
+
+int mm_set_tables_default(mm_ctx* c, float pi) {
+  const int s = c->P.sketchSize, k = c->P.kmerSize;
+  std::vector<int32_t> mh((size_t)s + 1, 0);
+  for (int q = 1; q <= s; q++) mh[q] = mmhost::Stat::estimateMinimumHitsRelaxed(q, k, pi, mmhost::fixed::confidence_interval);
+  std::vector<int> cut = mmhost::sketchCutoffs(s, k, mmhost::fixed::ANIDiff, mmhost::fixed::ANIDiffConf, (c->P.flags & MM_FLAG_HG_FILTER) != 0);
+  std::vector<int32_t> cut32(cut.begin(), cut.end());
+  return mm_set_tables(c, mh.data(), mh.size(), cut32.data(), cut32.size());
+}
+
+float mm_stat_j2md(float j, int k) { return mmhost::Stat::j2md(j, k); }
+float mm_stat_md2j(float d, int k) { return mmhost::Stat::md2j(d, k); }
+float mm_stat_md_lower_bound(float d, int s, int k, float ci) { return mmhost::Stat::md_lower_bound(d, s, k, ci); }
+int mm_stat_min_hits_relaxed(int s, int k, float pi) { return mmhost::Stat::estimateMinimumHitsRelaxed(s, k, pi, mmhost::fixed::confidence_interval); }
+int64_t mm_stat_recommended_sketch_size(int k, float pi, int64_t segLength, uint64_t referenceSize) {
+  return mmhost::Stat::recommendedSketchSize(mmhost::fixed::pval_cutoff, mmhost::fixed::confidence_interval, k, 4, pi, segLength, referenceSize);
+}
+int mm_stat_sketch_cutoffs(int sketchSize, int k, int hgFilter, int32_t* out, size_t cap) {
+  std::vector<int> cut = mmhost::sketchCutoffs(sketchSize, k, mmhost::fixed::ANIDiff, mmhost::fixed::ANIDiffConf, hgFilter != 0);
+  size_t n = std::min(cap, cut.size());
+  for (size_t i = 0; i < n; i++) out[i] = cut[i];
+  return (int)cut.size();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -259,6 +283,15 @@ int mm_results_device(const mm_ctx* c, const mm_l2_locus** dL2, size_t* nL2) {
   if (!c->mapped) return MM_ERR_STATE;
   if (dL2) *dL2 = c->dL2.as<mm_l2_locus>();
   if (nL2) *nL2 = c->nL2;
+  return MM_OK;
+}
+
+int mm_results_copy_device(mm_ctx* c, mm_l2_locus* dDst, size_t cap, size_t* n) {
+  if (!c->mapped) { c->err = "mm_results_copy_device: nothing mapped"; return MM_ERR_STATE; }
+  if (n) *n = c->nL2;
+  if (c->nL2 > cap) { c->err = "mm_results_copy_device: destination too small"; return MM_ERR_ARG; }
+  if (c->nL2) MM_HIP(c, hipMemcpyAsync(dDst, c->dL2.p, c->nL2 * sizeof(mm_l2_locus), hipMemcpyDeviceToDevice, c->stream));
+  MM_HIP(c, hipStreamSynchronize(c->stream));
   return MM_OK;
 }
 

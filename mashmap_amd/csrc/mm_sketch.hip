@@ -7,6 +7,8 @@
 // packed input is only 0.25 B/bp (+0.125 B/bp N mask).  See DESIGN.md for the roofline terms.
 #include "mm_internal.h"
 #include "mm_device.h"
+#include <cstdio>
+#include <cstdlib>
 
 // ---------------------------------------------------------------------------------------------
 // k_pack2bit: ASCII -> 2 bit/base + 1 bit/base N mask.  One thread per 32 output bases.
@@ -69,7 +71,7 @@ struct SkTable {
 // ---------------------------------------------------------------------------------------------
 // k_sketch_fragments<K, HARD>
 //   FAST (HARD=false): hash every k-mer on both strands, keep canonical hashes below a threshold
-//     T ~ 1.75 * s / n * 2^64 in an LDS queue (wave ballot compaction), de-duplicate them in an LDS
+//     T ~ 1.75 * s / (2n) * 2^64 in an LDS queue (wave ballot compaction), de-duplicate them in an LDS
 //     hash table (first / last position, strand sum), bitonic-sort the distinct ones, emit the s
 //     smallest.  If the queue or table overflows, or fewer than s distinct survive while T < max,
 //     the fragment is appended to the hard list instead.
@@ -127,8 +129,9 @@ k_sketch_fragments(const uint32_t* __restrict__ bases2, const uint32_t* __restri
   // threshold: expected s-th smallest of n uniform hashes is s/n * 2^64; take 1.75x (fast) as the cut
   uint64_t T;
   {
+    // the canonical hash is the smaller of two uniform 64-bit values, so P[h < T] ~ 2T / 2^64
     const uint64_t want = HARD ? (uint64_t)s * 2u : ((uint64_t)s * 7u + 3u) / 4u;
-    T = (want >= (uint64_t)n) ? MM_HASH_MAX : (MM_HASH_MAX / (uint64_t)n) * want;
+    T = (want >= (uint64_t)n) ? MM_HASH_MAX : (MM_HASH_MAX / (2ull * (uint64_t)n)) * want;
   }
   uint64_t lo = 0, hi = MM_HASH_MAX; bool hiInf = true;   // HARD bisection state (uniform across the block)
   const int nStrips = (n + 15) >> 4;
@@ -274,6 +277,7 @@ static int launch_sketch_k(mm_ctx* c) {
   uint32_t nHard = 0;
   MM_HIP(c, hipMemcpyAsync(&nHard, c->dCounters.p, 4, hipMemcpyDeviceToHost, c->stream));
   MM_HIP(c, hipStreamSynchronize(c->stream));
+  if (getenv("MM_DEBUG")) fprintf(stderr, "[mm] sketch: %d fragments, %u to the hard path, threads %d, HT %d, lds %zu/%zu\n", nF, nHard, threads, HT, ldsFast, ldsHard);
   if (nHard) {
     KernelTimer t(c, MM_K_SKETCH_HARD);
     hipLaunchKernelGGL((k_sketch_fragments<K, true>), dim3(nHard), dim3(threads), ldsHard, c->stream,

@@ -1,0 +1,154 @@
+// mashmap_amd/host/mm_stats.hpp -- host-side mirror of skch::Stat (src/map/include/map_stats.hpp:45-262)
+// and of Map::setProbs (src/map/include/computeMap.hpp:178-258).
+//
+// Same function names, argument meaning and float/double mixing as the reference; the integers these
+// produce (minimum hits, sketch cut-offs, recommended sketch size) are what the device kernels consume
+// (include/mashmap_hip.h: mm_set_tables).  The reference delegates two tail probabilities to GNU GSL
+// (gsl_cdf_binomial_Q, gsl_ran_hypergeometric_pdf / gsl_cdf_hypergeometric_P; GSL is not in this image).
+// Here they are evaluated by direct log-space summation, which is exact to ~1e-13 for the n <= 1024
+// these routines ever see.  They feed threshold comparisons only.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <numeric>
+#include <vector>
+
+namespace mmhost {
+namespace Stat {
+
+inline double lnChoose(unsigned n, unsigned m) { return std::lgamma(n + 1.0) - std::lgamma(m + 1.0) - std::lgamma((double)n - m + 1.0); }
+
+// P[X > k], X ~ Binomial(n, p)  (== gsl_cdf_binomial_Q(k, p, n))
+inline double binomialUpperTail(unsigned k, double p, unsigned n) {
+  if (k >= n) return 0.0;
+  if (p <= 0.0) return 0.0;
+  if (p >= 1.0) return 1.0;
+  const double lp = std::log(p), lq = std::log1p(-p);
+  // sum the smaller side to avoid cancellation
+  const double mean = (double)n * p;
+  if ((double)k + 1.0 >= mean) {
+    double acc = 0.0;
+    for (unsigned i = k + 1; i <= n; i++) acc += std::exp(lnChoose(n, i) + i * lp + (double)(n - i) * lq);
+    return acc > 1.0 ? 1.0 : acc;
+  }
+  double acc = 0.0;
+  for (unsigned i = 0; i <= k; i++) acc += std::exp(lnChoose(n, i) + i * lp + (double)(n - i) * lq);
+  return acc > 1.0 ? 0.0 : 1.0 - acc;
+}
+
+// == gsl_ran_hypergeometric_pdf(k, n1, n2, t)
+inline double hypergeometricPdf(unsigned k, unsigned n1, unsigned n2, unsigned t) {
+  if (t > n1 + n2) t = n1 + n2;
+  if (k > n1 || k > t) return 0.0;
+  if (t > n2 && k + n2 < t) return 0.0;
+  return std::exp(lnChoose(n1, k) + lnChoose(n2, t - k) - lnChoose(n1 + n2, t));
+}
+// == gsl_cdf_hypergeometric_P(k, n1, n2, t)
+inline double hypergeometricCdf(unsigned k, unsigned n1, unsigned n2, unsigned t) {
+  if (k >= n1 || k >= t) return 1.0;
+  double acc = 0.0;
+  for (unsigned i = 0; i <= k; i++) acc += hypergeometricPdf(i, n1, n2, t);
+  return acc > 1.0 ? 1.0 : acc;
+}
+
+inline float j2md(float j, int k) {                       // map_stats.hpp:45
+  if (j == 0) return 1.0f;
+  if (j == 1) return 0.0f;
+  float mash_dist = 1 - std::pow(2 * j / (1 + j), 1.0 / k);
+  return mash_dist;
+}
+inline float md2j(float d, int k) {                       // map_stats.hpp:63
+  float sim = 1 - d;
+  float jaccard = std::pow((double)sim, (double)k) / (2 - std::pow((double)sim, (double)k));
+  return jaccard;
+}
+inline float md_lower_bound(float d, int s, int k, float ci) {   // map_stats.hpp:81 (GSL branch)
+  float q2 = (1.0 - ci) / 2;
+  int x = std::max(int(std::ceil(s * md2j(d, k))), 1);
+  while (x <= s) {
+    double cdf_complement = binomialUpperTail(x - 1, md2j(d, k), s);
+    if (cdf_complement < q2) { x--; break; }
+    x++;
+  }
+  float jaccard = float(x) / s;
+  return j2md(jaccard, k);
+}
+inline int estimateMinimumHits(int s, int k, float perc_identity) {   // map_stats.hpp:122
+  float mash_dist = 1.0 - perc_identity;
+  float jaccard = md2j(mash_dist, k);
+  return (int)std::ceil(1.0 * s * jaccard);
+}
+inline int estimateMinimumHitsRelaxed(int s, int k, float perc_identity, float confidence_interval) {   // map_stats.hpp:144
+  const int first = estimateMinimumHits(s, k, perc_identity);
+  int relaxed = first;
+  for (int i = first; i >= 0; i--) {
+    float jaccard = 1.0 * i / s;
+    float d = j2md(jaccard, k);
+    float d_lower = md_lower_bound(d, s, k, confidence_interval);
+    float id_upper = 1.0 - d_lower;
+    if (id_upper >= perc_identity) relaxed = i; else break;
+  }
+  return relaxed;
+}
+inline double estimate_pvalue(int s, int k, int alphabetSize, float identity, int64_t lengthQuery, uint64_t lengthReference,
+                              float confidence_interval) {   // map_stats.hpp:181
+  double kmerSpace = std::pow((double)alphabetSize, (double)k);
+  double pX, pY; pX = pY = 1. / (1. + kmerSpace / lengthQuery);
+  double r = pX * pY / (pX + pY - pX * pY);
+  int x = estimateMinimumHitsRelaxed(s, k, identity, confidence_interval);
+  double cdf_complement = (x == 0) ? 1.0 : binomialUpperTail(x - 1, r, s);
+  return lengthReference * cdf_complement;
+}
+inline int64_t recommendedSketchSize(double pValue_cutoff, float confidence_interval, int k, int alphabetSize, float identity,
+                                     int64_t segmentLength, uint64_t lengthReference) {   // map_stats.hpp:234
+  int64_t lengthQuery = segmentLength - k;
+  int optimalSketchSize;
+  for (optimalSketchSize = 10; optimalSketchSize < lengthQuery; optimalSketchSize += 10)
+    if (estimate_pvalue(optimalSketchSize, k, alphabetSize, identity, lengthQuery, lengthReference, confidence_interval) <= pValue_cutoff) break;
+  return optimalSketchSize;
+}
+
+}  // namespace Stat
+
+namespace fixed {                                          // map_parameters.hpp:86-102
+constexpr double ss_table_max = 1000.0;
+constexpr double pval_cutoff = 1e-3;
+constexpr float confidence_interval = 0.95f;
+constexpr float ANIDiff = 0.0f;
+constexpr float ANIDiffConf = 0.999f;
+}
+
+// Map::sketchCutoffs as filled by Map::setProbs (computeMap.hpp:128,178-258)
+inline std::vector<int> sketchCutoffs(int sketchSize, int kmerSize, float ANIDiff, float ANIDiffConf, bool stage1_topANI_filter) {
+  std::vector<int> cut((size_t)(std::min<double>(sketchSize, fixed::ss_table_max) + 1), 1);
+  if (!stage1_topANI_filter) return cut;
+  const float deltaANI = ANIDiff;
+  const float min_p = 1 - ANIDiffConf;
+  const int ss = (int)std::min<double>(sketchSize, fixed::ss_table_max);
+  std::vector<std::vector<double>> probs(ss + 1, std::vector<double>(ss + 1));
+  for (int ci = 0; ci <= ss; ci++)
+    for (int y = 0; y <= ci; y++) probs[ci][y] = Stat::hypergeometricPdf(y, ss, ss - ci, ci);
+  auto distDiff = [&](int cmax, int ci) {
+    double prAbove = 0;
+    for (int ymax = 0; ymax <= cmax; ymax++) {
+      const double pymax = probs[cmax][ymax];
+      const double yi_cutoff = deltaANI == 0 ? (double)ymax
+          : std::floor(Stat::md2j(Stat::j2md((float)((double)ymax / ss), kmerSize) + deltaANI, kmerSize) * ss);
+      double pi_acc = (yi_cutoff - 1) >= 0 ? Stat::hypergeometricCdf((unsigned)(yi_cutoff - 1), ss, ss - ci, ci) : 0;
+      pi_acc = 1 - pi_acc;
+      prAbove += pymax * pi_acc;
+      if (prAbove > min_p) return true;
+    }
+    return prAbove > min_p;
+  };
+  for (int cmax = 1; cmax <= ss; cmax++) {
+    // lowest ci in [0, ss) for which distDiff holds (the reference binary-searches a monotone predicate with std::upper_bound)
+    int lo = 0, hi = ss;
+    while (lo < hi) { const int mid = lo + (hi - lo) / 2; if (distDiff(cmax, mid)) hi = mid; else lo = mid + 1; }
+    cut[cmax] = lo == 0 ? 1 : lo;
+  }
+  return cut;
+}
+
+}  // namespace mmhost
