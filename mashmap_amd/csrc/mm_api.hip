@@ -8,7 +8,7 @@ static thread_local std::string g_createErr;
 
 static const char* kKernelNames[MM_K_COUNT] = {
   "k_pack2bit", "k_sketch_fragments", "k_sketch_fragments(hard)", "k_seed_lookup", "k_sort_points",
-  "k_l1_sweep", "k_l2_slide", "k_ref_hash"};
+  "k_l1_sweep", "k_l2_sweep", "k_ref_hash", "k_l2_locate"};
 
 extern "C" {
 
@@ -51,11 +51,11 @@ void mm_destroy(mm_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
-  DevBuf* bufs[] = {&c->idx.recS, &c->idx.recE, &c->idx.contigOff, &c->idx.contigLen, &c->idx.refGroup, &c->idx.htKeys,
+  DevBuf* bufs[] = {&c->idx.recH, &c->idx.recW, &c->idx.recEh, &c->idx.recEw, &c->idx.contigOff, &c->idx.contigLen, &c->idx.refGroup, &c->idx.htKeys,
                     &c->idx.htVals, &c->idx.ptKeys, &c->dMinHits, &c->dCutoffs, &c->dAscii, &c->dReadSrcOff, &c->dReadPackOff,
                     &c->dReadLen, &c->dReadGroup, &c->dReadSelf, &c->dReadHasN, &c->dBases2, &c->dNmask, &c->dFrags, &c->dSkHash,
                     &c->dSkPos, &c->dSkStrand, &c->dSkCount, &c->dHardList, &c->dCounters, &c->dQHash, &c->dQStrand, &c->dSeedVal,
-                    &c->dStats, &c->dPtOff, &c->dPts, &c->dL1, &c->dL1Off, &c->dL2, &c->dL2Count};
+                    &c->dStats, &c->dPtOff, &c->dPts, &c->dL1, &c->dL1Off, &c->dL2, &c->dL2Info, &c->dL2Cnt, &c->dL2Off, &c->dL2Ops, &c->dScanTmp, &c->dL2Tmp, &c->dListB, &c->dListC};
   for (DevBuf* b : bufs) b->release();
   if (c->evA) (void)hipEventDestroy(c->evA);
   if (c->evB) (void)hipEventDestroy(c->evB);

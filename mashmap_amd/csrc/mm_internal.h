@@ -35,12 +35,14 @@ struct DFrag {
 };
 
 // device index (see DESIGN.md "data layout in HBM")
-struct DRecS { uint64_t hash; int32_t wpos; uint32_t wendStrand; };   // wend in bits 0..30, bit 31 = REV strand
-struct DRecE { uint64_t hash; int32_t wend; int32_t pad; };
 
 struct DeviceIndex {
   size_t nRec = 0, nKeys = 0, nPoints = 0, nContigs = 0, htCap = 0;
-  DevBuf recS, recE;           // DRecS[nRec] in minmerIndex order; DRecE[nRec] per contig sorted by wend
+  // minmerIndex as structure-of-arrays, in minmerIndex order ("insert stream"):
+  DevBuf recH;                 //   uint64 hash
+  DevBuf recW;                 //   int2 {wpos, wpos_end | REV<<31}
+  // the same records per contig ordered by wpos_end ("eviction stream", replaces the reference's heap):
+  DevBuf recEh, recEw;         //   uint64 hash ; int32 wpos_end
   DevBuf contigOff;            // int64[nContigs+1] record offsets
   DevBuf contigLen;            // int32[nContigs]
   DevBuf refGroup;             // int32[nContigs] (all 0 when unused)
@@ -80,7 +82,7 @@ struct mm_ctx {
   DevBuf dL1; size_t l1Cap = 0, nL1 = 0;
   DevBuf dL1Off;                                        // int64[nFrags] first candidate of a fragment
   DevBuf dL2; size_t l2Cap = 0, nL2 = 0;
-  DevBuf dL2Count;                                      // per-candidate locus count
+  DevBuf dL2Info, dL2Cnt, dL2Off, dL2Ops, dScanTmp, dL2Tmp, dListB, dListC;     // L2 staging: per-candidate stream extents, op counts/offsets, located ops
   bool sketched = false, mapped = false;
 
   // profiling
@@ -117,4 +119,5 @@ int mm_launch_pack_raw(mm_ctx* c, const uint8_t* dAscii, const int64_t* dSrcOff,
                        int64_t nChunks, uint32_t* dB, uint32_t* dM, uint32_t* dHasN);
 int mm_launch_sketch(mm_ctx* c);
 int mm_launch_map(mm_ctx* c);
+int mm_launch_l2(mm_ctx* c, unsigned long long* cnt);   // cnt: device counters [4] cursor [5] overflow [6] slot overflow
 int mm_build_device_index(mm_ctx* c, const int32_t* contigLen, const int32_t* refGroup, size_t nContigs);

@@ -5,7 +5,7 @@
 //                                                                         computeMap.hpp:818-843, 857-912
 //   k_sort_points_*         the (seqId,pos,side) order of getSeedIntervalPoints  computeMap.hpp:885-907
 //   k_l1_sweep              computeL1CandidateRegions                      computeMap.hpp:916-1116
-//   k_l2_slide              computeL2MappedRegions + SlideMapper           computeMap.hpp:1276-1451, slidingMap.hpp:28-212
+//   (L2 lives in mm_l2.hip)
 #include "mm_internal.h"
 #include "mm_device.h"
 #include <algorithm>
@@ -13,7 +13,6 @@
 #include <numeric>
 
 #define MM_EMPTY 0xFFFFFFFFFFFFFFFFULL
-#define MM_LOCAP 8          // private L2 locus slots per candidate before the final compaction
 
 // ---------------------------------------------------------------------------------------------
 // host: flatten the reference index
@@ -26,7 +25,7 @@ int mm_build_device_index(mm_ctx* c, const int32_t* contigLen, const int32_t* re
   DeviceIndex& I = c->idx;
   I.ready = false;
   const size_t n = c->hMinmers.size(), nk = c->hKeys.size(), np = c->hPoints.size();
-  std::vector<DRecS> rs(n); std::vector<DRecE> re(n);
+  std::vector<uint64_t> rh(n), reh(n); std::vector<int2> rw(n); std::vector<int32_t> rew(n);
   std::vector<int64_t> coff(nContigs + 1, 0);
   {
     int32_t prevSeq = 0; size_t i = 0;
@@ -41,7 +40,7 @@ int mm_build_device_index(mm_ctx* c, const int32_t* contigLen, const int32_t* re
   for (size_t i = 0; i < n; i++) {
     const mm_minmer& m = c->hMinmers[i];
     if (m.wpos < 0 || m.wpos_end < 0) { c->err = "mm_index_upload: negative minmer position"; return MM_ERR_ARG; }
-    rs[i] = DRecS{m.hash, m.wpos, (uint32_t)m.wpos_end | (m.strand < 0 ? 0x80000000u : 0u)};
+    rh[i] = m.hash; rw[i] = make_int2(m.wpos, (int)((uint32_t)m.wpos_end | (m.strand < 0 ? 0x80000000u : 0u)));
   }
   {
     std::vector<uint32_t> order;
@@ -50,7 +49,7 @@ int mm_build_device_index(mm_ctx* c, const int32_t* contigLen, const int32_t* re
       order.resize(e - b);
       std::iota(order.begin(), order.end(), 0u);
       std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return c->hMinmers[b + x].wpos_end < c->hMinmers[b + y].wpos_end; });
-      for (size_t j = 0; j < order.size(); j++) { const mm_minmer& m = c->hMinmers[b + order[j]]; re[b + j] = DRecE{m.hash, m.wpos_end, 0}; }
+      for (size_t j = 0; j < order.size(); j++) { const mm_minmer& m = c->hMinmers[b + order[j]]; reh[b + j] = m.hash; rew[b + j] = m.wpos_end; }
     }
   }
   size_t cap = 16; while (cap < 2 * nk + 2) cap <<= 1;
@@ -69,11 +68,13 @@ int mm_build_device_index(mm_ctx* c, const int32_t* contigLen, const int32_t* re
   std::vector<int32_t> grp(nContigs, 0);
   if (refGroup) grp.assign(refGroup, refGroup + nContigs);
 
-  MM_HIP(c, I.recS.ensure(n * sizeof(DRecS) + 64)); MM_HIP(c, I.recE.ensure(n * sizeof(DRecE) + 64));
+  MM_HIP(c, I.recH.ensure(n * 8 + 64)); MM_HIP(c, I.recW.ensure(n * 8 + 64)); MM_HIP(c, I.recEh.ensure(n * 8 + 64)); MM_HIP(c, I.recEw.ensure(n * 4 + 64));
   MM_HIP(c, I.contigOff.ensure((nContigs + 1) * 8)); MM_HIP(c, I.contigLen.ensure(nContigs * 4)); MM_HIP(c, I.refGroup.ensure(nContigs * 4));
   MM_HIP(c, I.htKeys.ensure(cap * 8)); MM_HIP(c, I.htVals.ensure(cap * 8)); MM_HIP(c, I.ptKeys.ensure(np * 8 + 64));
-  if (n) { MM_HIP(c, hipMemcpyAsync(I.recS.p, rs.data(), n * sizeof(DRecS), hipMemcpyHostToDevice, c->stream));
-           MM_HIP(c, hipMemcpyAsync(I.recE.p, re.data(), n * sizeof(DRecE), hipMemcpyHostToDevice, c->stream)); }
+  if (n) { MM_HIP(c, hipMemcpyAsync(I.recH.p, rh.data(), n * 8, hipMemcpyHostToDevice, c->stream));
+           MM_HIP(c, hipMemcpyAsync(I.recW.p, rw.data(), n * 8, hipMemcpyHostToDevice, c->stream));
+           MM_HIP(c, hipMemcpyAsync(I.recEh.p, reh.data(), n * 8, hipMemcpyHostToDevice, c->stream));
+           MM_HIP(c, hipMemcpyAsync(I.recEw.p, rew.data(), n * 4, hipMemcpyHostToDevice, c->stream)); }
   MM_HIP(c, hipMemcpyAsync(I.contigOff.p, coff.data(), (nContigs + 1) * 8, hipMemcpyHostToDevice, c->stream));
   MM_HIP(c, hipMemcpyAsync(I.contigLen.p, contigLen, nContigs * 4, hipMemcpyHostToDevice, c->stream));
   MM_HIP(c, hipMemcpyAsync(I.refGroup.p, grp.data(), nContigs * 4, hipMemcpyHostToDevice, c->stream));
@@ -373,147 +374,6 @@ k_l1_sweep(int nFrags, const int64_t* __restrict__ ptOff, const uint64_t* __rest
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_l2_slide: one lane per L1 candidate; the lane runs the SlideMapper sweep sequentially.
-// Per-lane state lives in LDS, transposed (cell p of lane l at word p*64+l => conflict-free for any p):
-//   bits 0..15  num_before_inc   bit 16 active   bits 24..31 strand_vote (int8)
-// Records come from two streams over the same contig: recS in minmerIndex order (inserts) and recE
-// ordered by wpos_end (evictions), which replaces the reference's heap (computeMap.hpp:1296-1358).
-// ---------------------------------------------------------------------------------------------
-struct L2Tmp { int32_t start, end, shared, strand; };
-
-__global__ void __launch_bounds__(64)
-k_l2_slide(int nCand, int s, int segLength, const mm_l1_candidate* __restrict__ l1, const mm_frag_stats* __restrict__ stats,
-           const uint64_t* __restrict__ qHash, const int8_t* __restrict__ qStrand,
-           const DRecS* __restrict__ recS, const DRecE* __restrict__ recE, const int64_t* __restrict__ contigOff,
-           const int64_t* __restrict__ l1Off, L2Tmp* __restrict__ tmp, mm_l2_locus* __restrict__ l2, unsigned long long l2Cap,
-           unsigned long long* __restrict__ counters /* [4] l2 cursor, [5] overflow, [6] locus-slot overflow */) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t cell[];
-  const int lane = threadIdx.x;
-  const int cIdx = blockIdx.x * 64 + lane;
-  if (cIdx >= nCand) return;
-  const mm_l1_candidate cand = l1[cIdx];
-  const int f = cand.frag;
-  const int S = stats[f].sketchSize;
-  const uint64_t* q = qHash + (size_t)f * s;
-  const int8_t* qs = qStrand + (size_t)f * s;
-#define CELL(p) cell[(p) * 64 + lane]
-  CELL(0) = 0;
-  for (int p = 1; p <= S; p++) CELL(p) = 1u;
-  int pivot = S, pivRank = S, shared = 0, votes = 0;
-  const uint64_t qmax = q[S - 1];
-
-  auto locate = [&](uint64_t h) {            // 1-based lower_bound over q[0..S)
-    int lo = 0, hi = S;
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (q[mid] < h) lo = mid + 1; else hi = mid; }
-    return lo + 1;
-  };
-  auto insert = [&](uint64_t h, int rStrand) {      // slidingMap.hpp:125-165
-    if (h > qmax) return;
-    const int j = locate(h);
-    uint32_t cw = CELL(j);
-    if (q[j - 1] == h) {
-      int v = (int)(int8_t)(cw >> 24) + (int)qs[j - 1] * rStrand;
-      cw = (cw & 0x0000FFFFu) | 0x00010000u | ((uint32_t)(uint8_t)(int8_t)v << 24);
-      CELL(j) = cw;
-      if (j <= pivot) { shared++; votes += v; }
-    } else {
-      CELL(j) = cw + 1u;
-      if (j <= pivot) pivRank++;
-      if (pivRank > S) {
-        const uint32_t pw = (pivot == j) ? cw + 1u : CELL(pivot);
-        shared -= (int)((pw >> 16) & 1u); votes -= (int)(int8_t)(pw >> 24); pivRank -= (int)(pw & 0xFFFFu); pivot--;
-      }
-    }
-  };
-  auto remove = [&](uint64_t h) {                   // slidingMap.hpp:171-211
-    if (h > qmax) return;
-    const int j = locate(h);
-    uint32_t cw = CELL(j);
-    if (q[j - 1] == h) {
-      if (j <= pivot) { shared--; votes -= (int)(int8_t)(cw >> 24); }
-      CELL(j) = cw & 0x0000FFFFu;
-    } else {
-      CELL(j) = cw - 1u;
-      if (j <= pivot) pivRank--;
-      if (pivot + 1 <= S) {
-        const uint32_t nw = (pivot + 1 == j) ? cw - 1u : CELL(pivot + 1);
-        if (pivRank + (int)(nw & 0xFFFFu) <= S) { pivot++; shared += (int)((nw >> 16) & 1u); votes += (int)(int8_t)(nw >> 24); pivRank += (int)(nw & 0xFFFFu); }
-      }
-    }
-  };
-
-  const int64_t cb = contigOff[cand.seqId], ce = contigOff[cand.seqId + 1];
-  int64_t it, itE;
-  {                                                  // std::lower_bound(minmerIndex, (seqId, rangeStart - segLength - 1)) (:1290-1293)
-    const int target = cand.rangeStartPos - segLength - 1;
-    int64_t lo = cb, hi = ce;
-    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (recS[mid].wpos < target) lo = mid + 1; else hi = mid; }
-    it = lo;
-    lo = cb; hi = ce;                               // first eviction candidate: wpos_end > rangeStart
-    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (recE[mid].wend <= cand.rangeStartPos) lo = mid + 1; else hi = mid; }
-    itE = lo;
-  }
-  // pre-load (:1323-1338)
-  while (it < ce) {
-    const DRecS r = recS[it];
-    if (!(r.wpos < cand.rangeStartPos)) break;
-    if ((int)(r.wendStrand & 0x7fffffffu) > cand.rangeStartPos) insert(r.hash, (r.wendStrand >> 31) ? -1 : 1);
-    it++;
-  }
-  // slide (:1340-1434)
-  int bestShared = 1; bool inRun = false;
-  int curStart = 0, curEnd = 0, curShared = 0;
-  int nFlushed = 0; bool havePend = false; L2Tmp pend{0, 0, 0, 0};
-  L2Tmp* mySlots = tmp + (size_t)cIdx * MM_LOCAP;
-  bool slotOverflow = false;
-  auto close_run = [&](int strand) {                // :1417-1426 / :1440-1449
-    if (!havePend || pend.end + segLength < curStart) {
-      if (havePend) { if (nFlushed < MM_LOCAP) mySlots[nFlushed] = pend; else slotOverflow = true; nFlushed++; }
-      pend.start = curStart; pend.end = curEnd; pend.shared = curShared; pend.strand = strand; havePend = true;
-    } else {
-      pend.end = curEnd;
-    }
-  };
-  while (it < ce) {
-    const DRecS r = recS[it];
-    if (!(r.wpos <= cand.rangeEndPos)) break;
-    const int prevVotes = votes;
-    while (itE < ce) { const DRecE d = recE[itE]; if (!(d.wend <= r.wpos)) break; remove(d.hash); itE++; }
-    insert(r.hash, (r.wendStrand >> 31) ? -1 : 1);
-    const int nextW = (it + 1 < ce) ? recS[it + 1].wpos : r.wpos;
-    if (shared > bestShared) {
-      nFlushed = 0; havePend = false;               // l2_vec_out.clear()
-      inRun = true; bestShared = shared; curShared = shared; curStart = r.wpos; curEnd = nextW;
-    } else if (shared == bestShared) {
-      if (!inRun) { curShared = shared; curStart = r.wpos; }
-      inRun = true; curEnd = nextW;
-    } else {
-      if (inRun) { curEnd = nextW; close_run(prevVotes >= 0 ? 1 : -1); curStart = 0; curEnd = 0; curShared = 0; }
-      inRun = false;
-    }
-    it++;
-  }
-  if (inRun) close_run(votes >= 0 ? 1 : -1);
-#undef CELL
-  const int total = nFlushed + (havePend ? 1 : 0);
-  if (slotOverflow) atomicOr(&counters[6], 1ull);
-  if (total > 0 && !slotOverflow) {
-    const unsigned long long base = atomicAdd(&counters[4], (unsigned long long)total);
-    if (base + total > l2Cap) { atomicOr(&counters[5], 1ull); return; }
-    const int candLocal = (int)(cIdx - l1Off[f]);
-    for (int i = 0; i < total; i++) {
-      const L2Tmp t = (i < nFlushed) ? mySlots[i] : pend;
-      mm_l2_locus o;
-      o.frag = f; o.cand = candLocal; o.seqId = cand.seqId; o.optimalStart = t.start; o.optimalEnd = t.end;
-      o.meanOptimalPos = (t.start + t.end) / 2; o.sharedSketchSize = t.shared; o.strand = t.strand;
-      // keep the per-candidate emission order recoverable: ordinal in the low bits of a scratch field is not needed,
-      // entries of one candidate are contiguous and in order starting at `base`
-      l2[base + i] = o;
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
 // launcher
 // ---------------------------------------------------------------------------------------------
 int mm_launch_map(mm_ctx* c) {
@@ -529,7 +389,7 @@ int mm_launch_map(mm_ctx* c) {
               (c->P.flags & MM_FLAG_SKIP_PREFIX) ? 1 : 0, (c->P.flags & MM_FLAG_LOWER_TRIANGULAR) ? 1 : 0};
   if (c->ptsCap == 0) c->ptsCap = (size_t)nF * 128 + 4096;
   if (c->l1Cap == 0) c->l1Cap = (size_t)nF * 2 + 1024;
-  DevBuf listB, listC;
+  DevBuf& listB = c->dListB; DevBuf& listC = c->dListC;
   MM_HIP(c, listB.ensure((size_t)nF * 4 + 16)); MM_HIP(c, listC.ensure((size_t)nF * 4 + 16));
   int rc = MM_OK;
   unsigned long long hc[8];
@@ -553,7 +413,7 @@ int mm_launch_map(mm_ctx* c) {
     if (hc[1]) { c->ptsCap = (size_t)hc[0] + (size_t)hc[0] / 8 + 4096; continue; }
     break;
   }
-  if (hc[1]) { c->err = "interval-point buffer overflow"; listB.release(); listC.release(); return MM_ERR_CAPACITY; }
+  if (hc[1]) { c->err = "interval-point buffer overflow"; return MM_ERR_CAPACITY; }
   unsigned long long* cnt = c->dCounters.as<unsigned long long>() + 8;
   unsigned int* cls = (unsigned int*)(c->dCounters.as<unsigned long long>() + 16);   // [16] two 32-bit class counters
   {
@@ -585,37 +445,11 @@ int mm_launch_map(mm_ctx* c) {
     if (hc[3]) { c->l1Cap = (size_t)hc[2] + (size_t)hc[2] / 8 + 1024; continue; }
     break;
   }
-  listB.release(); listC.release();
   if (hc[3]) { c->err = "L1 candidate buffer overflow"; return MM_ERR_CAPACITY; }
   c->nL1 = (size_t)hc[2];
   if (c->nL1 == 0) { c->nL2 = 0; return rc; }
 
-  const size_t ldsL2 = (size_t)(s + 1) * 64 * 4;
-  if (ldsL2 > 160 * 1024) { c->err = "sketchSize too large for the LDS-resident L2 state"; return MM_ERR_ARG; }
-  MM_HIP(c, hipFuncSetAttribute((const void*)k_l2_slide, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsL2));
-  DevBuf tmp;
-  MM_HIP(c, tmp.ensure(c->nL1 * MM_LOCAP * sizeof(L2Tmp) + 64));
-  if (c->l2Cap < c->nL1 * 2 + 1024) c->l2Cap = c->nL1 * 2 + 1024;
-  for (int attempt = 0; attempt < 8; attempt++) {
-    MM_HIP(c, c->dL2.ensure(c->l2Cap * sizeof(mm_l2_locus) + 64));
-    MM_HIP(c, hipMemsetAsync(cnt + 4, 0, 24, c->stream));
-    {
-      KernelTimer t(c, MM_K_L2);
-      hipLaunchKernelGGL(k_l2_slide, dim3((unsigned)((c->nL1 + 63) / 64)), dim3(64), ldsL2, c->stream, (int)c->nL1, s, c->P.segLength,
-                         c->dL1.as<mm_l1_candidate>(), c->dStats.as<mm_frag_stats>(), c->dQHash.as<uint64_t>(), c->dQStrand.as<int8_t>(),
-                         I.recS.as<DRecS>(), I.recE.as<DRecE>(), I.contigOff.as<int64_t>(), c->dL1Off.as<int64_t>(), tmp.as<L2Tmp>(),
-                         c->dL2.as<mm_l2_locus>(), (unsigned long long)c->l2Cap, cnt);
-      MM_HIP(c, hipGetLastError());
-    }
-    MM_HIP(c, hipMemcpyAsync(hc, cnt, 64, hipMemcpyDeviceToHost, c->stream));
-    MM_HIP(c, hipStreamSynchronize(c->stream));
-    if (hc[5]) { c->l2Cap = (size_t)hc[4] + (size_t)hc[4] / 8 + 1024; continue; }
-    break;
-  }
-  tmp.release();
-  if (hc[6]) { c->err = "more than MM_LOCAP tied L2 loci for one candidate"; return MM_ERR_CAPACITY; }
-  if (hc[5]) { c->err = "L2 locus buffer overflow"; return MM_ERR_CAPACITY; }
-  c->nL2 = (size_t)hc[4];
+  rc = mm_launch_l2(c, cnt);
   return rc;
 }
 
