@@ -1,0 +1,76 @@
+"""Seeded inputs shared by make_golden.py (which runs the REAL reference on them, in the build container)
+and by the tests that replay them against the oracle (CPU) and the HIP path (GPU).  Everything is derived
+from mmutil's counter-based generators, so the inputs regenerate bit-identically anywhere."""
+import numpy as np
+
+import mmutil as U
+
+KNOWN_KMERS = [b"ACGTACGTACGTACGTACG", b"CGTACGTACGTACGTACGT", b"AAAAAAAAAAAAAAAAAAA", b"TTTTTTTTTTTTTTTTTTT",
+               b"GATTACAGATTACAGATTA", b"TAATCTGTAATCTGTAATC", b"ACGTACGTACGTACGT"]
+
+
+def hash_inputs():
+    out = list(KNOWN_KMERS)
+    for k in (11, 15, 16, 17, 19, 21, 24, 27, 31, 32):
+        a = U.random_dna(900 + k, 40 * k)
+        out += [bytes(a[i * k:(i + 1) * k]) for i in range(4)]
+    return out
+
+
+def sketch_cases():
+    """(name, k, s, sequence)"""
+    g = U.random_dna(101, 60000)
+    return [
+        ("random5000", 19, 130, g[:5000]),
+        ("random5000_s498", 19, 498, g[5000:10000]),
+        ("random10000_s40", 19, 40, g[10000:20000]),
+        ("short300_s5", 19, 5, g[20000:20300]),
+        ("tandem", 19, 130, U.tandem_repeat(7, 5000, 37)),
+        ("n_runs", 19, 130, U.with_n_runs(g[30000:35000], 3, 6, 40)),
+        ("lowercase", 19, 130, U.lowercase_some(g[35000:40000], 4)),
+        ("k16", 16, 60, g[40000:41000]),
+        ("k27", 27, 100, g[41000:46000]),
+        ("fewer_than_s", 19, 498, g[46000:46300]),
+        ("polyA", 19, 130, np.frombuffer(b"A" * 3000, dtype=np.uint8).copy()),
+        ("allN", 19, 130, np.frombuffer(b"N" * 3000, dtype=np.uint8).copy()),
+    ]
+
+
+def minmer_cases():
+    """(name, k, w, s, sequence)"""
+    g = U.random_dna(202, 200000)
+    rep = np.concatenate([U.mutate(g[:8000], 300 + i, 0.01) for i in range(6)])
+    return [
+        ("random_w5000", 19, 5000, 130, g[:60000]),
+        ("random_w1000_s50", 19, 1000, 50, g[60000:90000]),
+        ("repeat_w5000", 19, 5000, 130, rep),
+        ("tandem_w500_s100", 19, 500, 100, U.tandem_repeat(9, 12000, 41)),
+        ("n_runs_w1000", 19, 1000, 60, U.with_n_runs(g[90000:110000], 5, 8, 60)),
+        ("early_N", 19, 300, 400, np.concatenate([g[110000:110005], np.frombuffer(b"N", dtype=np.uint8), g[110006:110400]])),
+        ("shorter_than_w", 19, 5000, 130, g[120000:123000]),
+        ("w10000_s20", 19, 10000, 20, g[130000:170000]),
+    ]
+
+
+def session_case():
+    """a small reference + reads for the L1/L2 leg: (contigs, reads, params)"""
+    cs = [U.random_dna(401, 160000), U.random_dna(402, 120000), U.random_dna(403, 3000)]
+    blk = U.mutate(cs[0][50000:70000], 77, 0.03)
+    cs[1][20000:20000 + len(blk)] = blk                        # a diverged duplicate -> two candidate regions
+    contigs = [("chrA", cs[0]), ("chrB", cs[1]), ("tiny", cs[2])]
+    reads = [(n, a) for n, a, _ in U.sample_reads([c for _, c in contigs], 5, 24, 10000, 0.10)]
+    reads += [(n + "b", a) for n, a, _ in U.sample_reads([c for _, c in contigs], 6, 8, 7777, 0.04)]
+    reads += [("dup", cs[0][52000:64000].copy()), ("unrelated", U.random_dna(404, 10000)),
+              ("withN", U.with_n_runs(cs[1][70000:80000], 8, 4, 30))]
+    params = dict(k=19, segLength=5000, sketchSize=130, pi=0.85, kmerPct=0.001)
+    return contigs, reads, params
+
+
+def fragments_of(read_len, L):
+    """Map::mapModule's cut (computeMap.hpp:587-671): full segments + one overlapping tail"""
+    if read_len <= L:
+        return [(0, read_len)]
+    fr = [(i * L, L) for i in range(read_len // L)]
+    if read_len % L:
+        fr.append((read_len - L, L))
+    return fr

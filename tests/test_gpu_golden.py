@@ -1,0 +1,98 @@
+"""The HIP path, through the C ABI, against the golden vectors produced by the REAL reference
+(tests/golden/make_golden.py).  No oracle in the loop: this is GPU vs marbl/MashMap v3.1.3 directly."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import mmutil as U
+from golden import cases as CS
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return json.load(open(os.path.join(GOLD, "golden.json")))
+
+
+def test_sketch_vs_reference_golden(gold):
+    from mashmap_amd import capi
+    for name, k, s, seq in CS.sketch_cases():
+        ctx = capi.Context(k=k, segLength=max(len(seq), k), sketchSize=s)
+        nF = ctx.reads_upload([seq], seqCounterBase=7)
+        assert nF == 1
+        got, cnt = ctx.sketch()
+        g = [(int(x["hash"]), int(x["wpos"]), int(x["wpos_end"]), int(x["seqId"]), int(x["strand"])) for x in got[0, :cnt[0]]]
+        exp = [(int(h), a, b, c, d) for h, a, b, c, d in gold["sketch"][name]]
+        assert g == exp, name
+        ctx.close()
+
+
+def test_index_build_vs_reference_golden(gold):
+    """mm_index_build (a5-a7) must reproduce the reference's minmerIndex and lookup-key counts"""
+    from mashmap_amd import capi
+    contigs, reads, P = CS.session_case()
+    z = np.load(os.path.join(GOLD, "session_index.npz"))
+    ctx = capi.Context(k=P["k"], segLength=P["segLength"], sketchSize=P["sketchSize"])
+    ctx.index_build([a for _, a in contigs], kmerPct=P["kmerPct"])
+    ix = ctx.index_download()
+    assert len(ix["minmers"]) == gold["session"]["n_minmers"]
+    for f in ("hash", "wpos", "wpos_end", "seqId", "strand"):
+        assert np.array_equal(ix["minmers"][f], z["minmers"][f]), f
+    assert np.array_equal(ix["keys"], z["keys"])
+    assert np.array_equal(np.diff(ix["offsets"].astype(np.int64)), z["counts"])
+    assert ix["freqThreshold"] == gold["session"]["freq_threshold"]
+    ctx.close()
+
+
+def test_map_vs_reference_golden(gold):
+    """index built on the device, tables from the library's own statistics mirror, all L1/L2 integers vs the reference"""
+    from mashmap_amd import capi
+    contigs, reads, P = CS.session_case()
+    ctx = capi.Context(k=P["k"], segLength=P["segLength"], sketchSize=P["sketchSize"], flags=capi.MM_FLAG_HG_FILTER)
+    ctx.index_build([a for _, a in contigs], kmerPct=P["kmerPct"])
+    ctx.set_tables_default(P["pi"])
+    nF = ctx.reads_upload([a for _, a in reads])
+    ctx.map()
+    stats, l1, l2 = ctx.results()
+    frs = ctx.fragments()
+    gf = gold["session"]["fragments"]
+    assert nF == len(gf)
+    l1_by_f, l2_by_c = {}, {}
+    for i, c in enumerate(l1):
+        l1_by_f.setdefault(int(c["frag"]), []).append((i, c))
+    for x in l2:
+        l2_by_c.setdefault(int(x["cand"]), []).append(x)
+    nl2 = 0
+    for f in range(nF):
+        e = gf[f]
+        assert (int(frs[f]["readId"]), int(frs[f]["fragStart"]), int(frs[f]["len"])) == (e["read"], e["off"], e["len"])
+        assert int(stats[f]["sketchSize"]) == e["sketchSize"] and int(stats[f]["rawSketchSize"]) == e["rawSketchSize"]
+        gp = [[int(p["seqId"]), int(p["pos"]), int(p["side"])] for p in ctx.points(f)] if e["sketchSize"] else []
+        assert gp == e["points"], f
+        g1 = [[int(c["seqId"]), int(c["rangeStartPos"]), int(c["rangeEndPos"]), int(c["intersectionSize"])] for _, c in l1_by_f.get(f, [])]
+        assert g1 == e["l1"], f
+        g2 = []
+        for ci, (gi, _) in enumerate(l1_by_f.get(f, [])):
+            for x in l2_by_c.get(gi, []):
+                g2.append([ci, int(x["seqId"]), int(x["meanOptimalPos"]), int(x["optimalStart"]), int(x["optimalEnd"]),
+                           int(x["sharedSketchSize"]), int(x["strand"])])
+        assert g2 == e["l2"], f
+        nl2 += len(g2)
+    assert nl2 > 60
+    ctx.close()
+
+
+def test_stats_mirror_vs_reference_golden(gold):
+    from mashmap_amd import capi
+    lib = capi.load()
+    st = gold["stats"]
+    for i, v in enumerate(st["j2md_130"]):
+        assert abs(lib.mm_stat_j2md(i / 130.0, 19) - float(v)) <= 1e-6
+    for key, tab in st["min_hits_relaxed"].items():
+        s, pi = key.split("_")
+        assert [lib.mm_stat_min_hits_relaxed(q, 19, int(pi) / 100.0) for q in range(1, int(s) + 1)] == tab
+    assert list(capi.stat_sketch_cutoffs(130, 19, True)) == gold["session"]["cutoffs"]
