@@ -1,0 +1,131 @@
+// mashmap_amd/host/skch_types.hpp -- the data contracts the host side shares with its callers.
+//
+// Two build modes:
+//   * inside the reference tree (-DMASHMAP_HIP_REFERENCE_TREE): the reference's own
+//     src/map/include/base_types.hpp and map_parameters.hpp are used unchanged, so mash_map.cpp and
+//     parseCmdArgs.hpp keep compiling against skch::Parameters / skch::MappingResult as they are;
+//   * standalone (this repository, the GPU box): the same contracts are declared here with the same
+//     names and field meaning (base_types.hpp:17-281, map_parameters.hpp:32-102), because the
+//     reference sources do not travel.
+#pragma once
+
+#ifdef MASHMAP_HIP_REFERENCE_TREE
+#include "map/include/base_types.hpp"
+#include "map/include/map_parameters.hpp"
+#else
+
+#include <chrono>
+#include <cstdint>
+#include <filesystem>
+#include <limits>
+#include <string>
+#include <vector>
+
+namespace skch {
+
+typedef uint64_t hash_t;
+typedef int32_t offset_t;      // base_types.hpp:21 (the LARGE_CONTIG variant is not supported by the device layouts)
+typedef int32_t seqno_t;
+typedef int16_t strand_t;
+typedef int8_t side_t;
+typedef std::chrono::high_resolution_clock Time;
+
+struct MinmerInfo {            // base_types.hpp:31 (24 bytes, same layout as mm_minmer)
+  hash_t hash; offset_t wpos; offset_t wpos_end; seqno_t seqId; strand_t strand;
+  bool operator<(const MinmerInfo& x) const { return seqId != x.seqId ? seqId < x.seqId : wpos < x.wpos; }
+};
+struct IntervalPoint {         // base_types.hpp:66 (24 bytes, same layout as mm_interval_point)
+  offset_t pos; hash_t hash; seqno_t seqId; side_t side;
+  bool operator<(const IntervalPoint& x) const {
+    if (seqId != x.seqId) return seqId < x.seqId;
+    if (pos != x.pos) return pos < x.pos;
+    return side < x.side;
+  }
+};
+typedef hash_t MinmerMapKeyType;
+typedef std::vector<IntervalPoint> MinmerMapValueType;
+struct ContigInfo { std::string name; offset_t len; };          // base_types.hpp:94
+
+enum strnd : strand_t { FWD = 1, AMBIG = 0, REV = -1 };
+enum event : int { BEGIN = 1, END = 2 };
+enum filter : int { MAP = 1, ONETOONE = 2, NONE = 3 };
+enum side : side_t { OPEN = 1, CLOSE = -1 };
+
+struct MappingResult {         // base_types.hpp:154
+  offset_t queryLen, refStartPos, refEndPos, queryStartPos, queryEndPos;
+  seqno_t refSeqId, querySeqId;
+  int blockLength;
+  float nucIdentity, nucIdentityUpperBound;
+  int sketchSize, conservedSketches;
+  strand_t strand;
+  int approxMatches;
+  long double kmerComplexity;
+  int n_merged;
+  offset_t splitMappingId;
+  uint8_t discard;
+  bool selfMapFilter;
+
+  size_t hash() {              // base_types.hpp:188 (used by --sparsifyMappings)
+    size_t s = 0;
+    auto mix = [&s](size_t hv) { s ^= hv + 0x9e3779b9 + (s << 6) + (s >> 2); };
+    mix(std::hash<offset_t>()(queryLen)); mix(std::hash<offset_t>()(refStartPos)); mix(std::hash<offset_t>()(refEndPos));
+    mix(std::hash<offset_t>()(queryStartPos)); mix(std::hash<offset_t>()(queryEndPos)); mix(std::hash<seqno_t>()(refSeqId));
+    mix(std::hash<seqno_t>()(querySeqId)); mix(std::hash<int>()(blockLength)); mix(std::hash<float>()(nucIdentity));
+    mix(std::hash<float>()(nucIdentityUpperBound)); mix(std::hash<int>()(sketchSize)); mix(std::hash<int>()(conservedSketches));
+    mix(std::hash<strand_t>()(strand)); mix(std::hash<int>()(approxMatches));
+    return s;
+  }
+};
+typedef std::vector<MappingResult> MappingResultsVector_t;
+
+struct Parameters {            // map_parameters.hpp:32
+  int kmerSize = 19;
+  float kmer_pct_threshold = 0.001f;
+  offset_t segLength = 5000;
+  offset_t block_length = 5000;
+  offset_t chain_gap = 5000;
+  int alphabetSize = 4;
+  offset_t referenceSize = 0;
+  float percentageIdentity = 0.85f;
+  bool stage2_full_scan = true;
+  bool stage1_topANI_filter = true;
+  float ANIDiff = 0.0f;
+  float ANIDiffConf = 0.999f;
+  int filterMode = filter::MAP;
+  uint32_t numMappingsForSegment = 1;
+  uint32_t numMappingsForShortSequence = 1;
+  int threads = 1;
+  std::vector<std::string> refSequences;
+  std::vector<std::string> querySequences;
+  std::string outFileName = "mashmap.out";
+  std::filesystem::path saveIndexFilename;
+  std::filesystem::path loadIndexFilename;
+  bool split = true;
+  bool lower_triangular = false;
+  bool skip_self = false;
+  bool skip_prefix = false;
+  char prefix_delim = '\0';
+  std::string target_list;
+  std::string target_prefix;
+  bool mergeMappings = true;
+  bool keep_low_pct_id = true;
+  bool report_ANI_percentage = false;
+  bool filterLengthMismatches = false;
+  float kmerComplexityThreshold = 0.0f;
+  int sketchSize = 0;
+  uint64_t sparsity_hash_threshold = std::numeric_limits<uint64_t>::max();
+  bool legacy_output = false;
+};
+
+namespace fixed {              // map_parameters.hpp:86
+static const double ss_table_max = 1000.0;
+static const double pval_cutoff = 1e-3;
+static const float confidence_interval = 0.95f;
+static const float percentage_identity = 0.85f;
+static const float ANIDiff = 0.0f;
+static const float ANIDiffConf = 0.999f;
+static const std::string VERSION = "3.1.3";
+}
+
+}  // namespace skch
+#endif

@@ -74,3 +74,38 @@ def fragments_of(read_len, L):
     if read_len % L:
         fr.append((read_len - L, L))
     return fr
+
+
+def paf_cases():
+    """end-to-end command lines: (name, reference records, query records or None for self-map, extra argv)"""
+    cs = [U.random_dna(601, 300000), U.random_dna(602, 200000), U.random_dna(603, 120000), U.random_dna(604, 3000)]
+    blk = U.mutate(cs[0][40000:75000], 78, 0.03)
+    cs[1][30000:30000 + len(blk)] = blk
+    inv = U.revcomp(cs[0][150000:180000])
+    cs[2][50000:50000 + len(inv)] = U.mutate(inv, 79, 0.02)[:30000]
+    ref = [("chr1", cs[0]), ("chr2", cs[1]), ("chr3", cs[2]), ("tiny", cs[3])]
+    reads = [(n, a) for n, a, _ in U.sample_reads(cs[:3], 15, 40, 10000, 0.10)]
+    reads += [(n + "_s", a) for n, a, _ in U.sample_reads(cs[:3], 16, 12, 6200, 0.06)]
+    reads += [(n + "_l", a) for n, a, _ in U.sample_reads(cs[:3], 17, 6, 31000, 0.04)]
+    reads += [("short3k", cs[1][5000:8000].copy()), ("tiny12", cs[1][100:112].copy()), ("unrelated", U.random_dna(605, 12000)),
+              ("chimera", np.concatenate([cs[0][10000:22000], U.revcomp(cs[2][20000:31000])]))]
+    # haplotype-like set for the CI-style all-vs-all run (-Y '#')
+    base = [U.random_dna(610 + c, 70000) for c in range(3)]
+    hap = []
+    for h in range(3):
+        for c in range(3):
+            a = base[c] if h == 0 else U.mutate(base[c], 700 + 10 * h + c, 0.015 * h)
+            hap.append(("S%d#1#chr%d" % (h, c), a))
+    asm = [("q_chr1", U.mutate(cs[0], 90, 0.01)), ("q_chr2", U.revcomp(U.mutate(cs[1], 91, 0.01))), ("q_chr3", U.mutate(cs[2], 92, 0.02))]
+    return [
+        ("default", ref, reads, []),
+        ("pi90_n2", ref, reads, ["--pi", "90", "-n", "2"]),
+        ("dense_pi80", ref, reads, ["--dense", "--pi", "80"]),
+        ("nomerge", ref, reads, ["-M"]),
+        ("filter_none", ref, reads, ["-f", "none"]),
+        ("nohg_dropK", ref, reads, ["--noHgFilter", "-K"]),
+        ("legacy_pct", ref, reads, ["--legacy"]),
+        ("asm_one2one", ref, asm, ["--pi", "95", "-s", "10000", "-f", "one-to-one", "-J", "40"]),
+        ("allvsall_Y", hap, None, ["--pi", "95", "-n", "1", "-Y", "#"]),
+        ("allvsall_X_lower", hap, hap, ["--pi", "90", "-X", "--lowerTriangular", "-n", "3"]),
+    ]

@@ -64,6 +64,17 @@ def main():
                     "maps_i": [list(x) for x in e["maps_i"]], "maps_f": [[repr(float(v)) for v in x] for x in e["maps_f"]]})
         ref.free(h)
     out["session"] = sess
+    # end-to-end PAF fixtures: the reference binary's own output for the command lines of cases.paf_cases()
+    import subprocess
+    pafdir = os.path.join(HERE, "paf")
+    os.makedirs(pafdir, exist_ok=True)
+    with tempfile.TemporaryDirectory() as td:
+        for name, refrec, qrec, extra in CS.paf_cases():
+            rf = os.path.join(td, name + ".ref.fa"); U.write_fasta(rf, refrec)
+            args = [U.REF_BIN, "-r", rf, "-o", os.path.join(pafdir, name + ".paf"), "-t", "2"] + extra
+            if qrec is not None:
+                qf = os.path.join(td, name + ".q.fa"); U.write_fasta(qf, qrec); args += ["-q", qf]
+            subprocess.run(args, check=True, capture_output=True)
     with open(os.path.join(HERE, "golden.json"), "w") as f:
         json.dump(out, f, indent=0, separators=(",", ":"))
     print("golden: %d hashes, %d sketches, %d minmer cases, %d fragments" %
