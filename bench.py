@@ -179,22 +179,15 @@ def main():
     del reads_t, contigs
     torch.cuda.empty_cache()
 
-    gather_buf = None
+    from mashmap_amd import shard
 
     def step():
         ctx.map()
-        if world > 1:                                   # all-gatherv of the L2 locus records over RCCL/xGMI
-            nonlocal gather_buf
+        if world > 1:                                   # all-gatherv of the L2 locus records over RCCL/xGMI (mashmap_amd/shard.py)
             n1, n2 = ctx.result_counts()
-            cnt = torch.tensor([n2], dtype=torch.int64, device=dev)
-            allc = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-            dist.all_gather(allc, cnt)
-            mx = int(max(int(c.item()) for c in allc))
-            mine = torch.zeros(mx * 8, dtype=torch.int32, device=dev)
-            ctx.results_copy_device(mine.data_ptr(), mx)
-            if gather_buf is None or gather_buf.numel() < world * mx * 8:
-                gather_buf = torch.empty(world * mx * 8, dtype=torch.int32, device=dev)
-            dist.all_gather_into_tensor(gather_buf[:world * mx * 8], mine)
+            mine = torch.empty((n2, shard.L2_WORDS), dtype=torch.int32, device=dev)
+            ctx.results_copy_device(mine.data_ptr(), n2)
+            shard.allgatherv_records(mine, dist, device=dev)
 
     def fence():
         if world > 1:
