@@ -163,7 +163,14 @@ int mm_result_counts(const mm_ctx* ctx, size_t* nL1, size_t* nL2);
 int mm_results_download(mm_ctx* ctx, mm_frag_stats* stats, mm_l1_candidate* l1, mm_l2_locus* l2);
 /* post-removal sketches Q.minmerTableQuery: out[f*sketchSize + r] (valid r < stats[f].sketchSize) */
 int mm_query_sketch_download(mm_ctx* ctx, mm_minmer* out);
-/* sorted, filtered interval points of fragment f (debug/parity; (seqId,pos,side) only, hash = 0) */
+/*
+ * Options.  MM_OPT_KEEP_POINTS (default 0): by default the interval points of a fragment (getSeedIntervalPoints,
+ * computeMap.hpp:857) live only in LDS/registers between the seed lookup and the L1 sweep; with 1 every fragment's sorted
+ * point list is also kept in HBM so that mm_points_download can return it (parity tests).
+ */
+enum { MM_OPT_KEEP_POINTS = 1 };
+int mm_set_option(mm_ctx* ctx, int option, int value);
+/* sorted, filtered interval points of fragment f (needs MM_OPT_KEEP_POINTS; (seqId,pos,side) only, hash = 0) */
 int mm_points_download(mm_ctx* ctx, size_t frag, mm_interval_point* out, size_t cap, size_t* n);
 /* copies the L2 loci (fragment-major device order, not re-sorted) into caller-owned DEVICE memory, e.g. a torch tensor
  * that is then exchanged with RCCL; *n receives the count, cap is the capacity of dst in records */

@@ -88,6 +88,7 @@ def load():
         "mm_index_build": (C.c_int, [vp, vp, vp, sz, vp, C.c_float]),
         "mm_index_sizes": (C.c_int, [vp, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz), C.POINTER(sz), C.POINTER(i32)]),
         "mm_index_download": (C.c_int, [vp, vp, vp, vp, vp, vp]),
+        "mm_set_option": (C.c_int, [vp, C.c_int, C.c_int]),
         "mm_profile_enable": (C.c_int, [vp, C.c_int]),
         "mm_profile_read": (C.c_int, [vp, vp, vp, C.c_int]),
         "mm_kernel_name": (C.c_char_p, [C.c_int]),
@@ -108,7 +109,7 @@ EXPORTS = ["mm_abi_version", "mm_create", "mm_destroy", "mm_last_error", "mm_ind
            "mm_reads_upload", "mm_reads_upload_device", "mm_num_fragments", "mm_fragments_download",
            "mm_sketch_fragments", "mm_sketch_download", "mm_map_fragments", "mm_result_counts",
            "mm_results_download", "mm_query_sketch_download", "mm_points_download", "mm_results_device",
-           "mm_index_build", "mm_index_sizes", "mm_index_download", "mm_profile_enable", "mm_profile_read",
+           "mm_index_build", "mm_index_sizes", "mm_index_download", "mm_set_option", "mm_profile_enable", "mm_profile_read",
            "mm_kernel_name", "mm_synchronize", "mm_stream"]
 
 
@@ -256,6 +257,10 @@ class Context:
         out = np.zeros((self.num_fragments(), self.s), dtype=MINMER_DT)
         self._ck(self.lib.mm_query_sketch_download(self.h, _ptr(out)), "mm_query_sketch_download")
         return out
+
+    def keep_points(self, on=True):
+        """MM_OPT_KEEP_POINTS: keep every fragment's sorted interval points in HBM (needed by points())"""
+        self._ck(self.lib.mm_set_option(self.h, 1, 1 if on else 0), "mm_set_option")
 
     def points(self, frag, cap=1 << 16):
         out = np.zeros(cap, dtype=POINT_DT); n = C.c_size_t()

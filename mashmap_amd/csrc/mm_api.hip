@@ -51,11 +51,10 @@ void mm_destroy(mm_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
-  DevBuf* bufs[] = {&c->idx.recH, &c->idx.recW, &c->idx.recEh, &c->idx.recEw, &c->idx.contigOff, &c->idx.contigLen, &c->idx.refGroup, &c->idx.htKeys,
-                    &c->idx.htVals, &c->idx.ptKeys, &c->dMinHits, &c->dCutoffs, &c->dAscii, &c->dReadSrcOff, &c->dReadPackOff,
+  DevBuf* bufs[] = {&c->idx.recH, &c->idx.recW, &c->idx.recEh, &c->idx.recEw, &c->idx.contigOff, &c->idx.contigLen, &c->idx.refGroup, &c->idx.htSlots, &c->idx.ptKeys, &c->dMinHits, &c->dCutoffs, &c->dAscii, &c->dReadSrcOff, &c->dReadPackOff,
                     &c->dReadLen, &c->dReadGroup, &c->dReadSelf, &c->dReadHasN, &c->dBases2, &c->dNmask, &c->dFrags, &c->dSkHash,
                     &c->dSkPos, &c->dSkStrand, &c->dSkCount, &c->dHardList, &c->dCounters, &c->dQHash, &c->dQStrand, &c->dSeedVal,
-                    &c->dStats, &c->dPtOff, &c->dPts, &c->dL1, &c->dL1Off, &c->dL2, &c->dL2Info, &c->dL2Cnt, &c->dL2Off, &c->dL2Ops, &c->dScanTmp, &c->dL2Tmp, &c->dListB, &c->dListC};
+                    &c->dStats, &c->dPtOff, &c->dPts, &c->dL1, &c->dL1Off, &c->dL2, &c->dL2Info, &c->dL2Cnt, &c->dL2Off, &c->dL2Ops, &c->dScanTmp, &c->dL2Tmp, &c->dListB, &c->dListC, &c->dBigList};
   for (DevBuf* b : bufs) b->release();
   if (c->evA) (void)hipEventDestroy(c->evA);
   if (c->evB) (void)hipEventDestroy(c->evB);
@@ -65,6 +64,11 @@ void mm_destroy(mm_ctx* c) {
 
 int mm_synchronize(mm_ctx* c) { MM_HIP(c, hipStreamSynchronize(c->stream)); return MM_OK; }
 void* mm_stream(const mm_ctx* c) { return (void*)c->stream; }
+
+int mm_set_option(mm_ctx* c, int option, int value) {
+  if (option == MM_OPT_KEEP_POINTS) { c->keepPoints = value != 0; c->ptsCap = 0; return MM_OK; }
+  c->err = "mm_set_option: unknown option"; return MM_ERR_ARG;
+}
 
 int mm_profile_enable(mm_ctx* c, int on) { c->profile = on != 0; return MM_OK; }
 int mm_profile_read(mm_ctx* c, double* ms, uint64_t* launches, int reset) {

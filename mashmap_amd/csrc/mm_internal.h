@@ -46,7 +46,7 @@ struct DeviceIndex {
   DevBuf contigOff;            // int64[nContigs+1] record offsets
   DevBuf contigLen;            // int32[nContigs]
   DevBuf refGroup;             // int32[nContigs] (all 0 when unused)
-  DevBuf htKeys, htVals;       // uint64[htCap] each; val = offset<<24 | count<<1 | freq
+  DevBuf htSlots;              // {uint64 key, uint64 val}[htCap]; val = offset<<24 | count<<1 | freq (one 16-byte slot per probe)
   DevBuf ptKeys;               // uint64[nPoints]: seqId<<33 | pos<<1 | (side==OPEN)
   bool ready = false;
 };
@@ -82,8 +82,9 @@ struct mm_ctx {
   DevBuf dL1; size_t l1Cap = 0, nL1 = 0;
   DevBuf dL1Off;                                        // int64[nFrags] first candidate of a fragment
   DevBuf dL2; size_t l2Cap = 0, nL2 = 0;
-  DevBuf dL2Info, dL2Cnt, dL2Off, dL2Ops, dScanTmp, dL2Tmp, dListB, dListC;     // L2 staging: per-candidate stream extents, op counts/offsets, located ops
+  DevBuf dL2Info, dL2Cnt, dL2Off, dL2Ops, dScanTmp, dL2Tmp, dListB, dListC, dBigList;     // L2 staging: per-candidate stream extents, op counts/offsets, located ops
   bool sketched = false, mapped = false;
+  bool keepPoints = false;                              // mm_set_option(MM_OPT_KEEP_POINTS): route every fragment through the HBM point list
 
   // profiling
   bool profile = false;

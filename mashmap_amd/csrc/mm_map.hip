@@ -1,14 +1,16 @@
 // mashmap_amd/csrc/mm_map.hip -- device index + L1/L2 mapping kernels (gfx950).
 //
 //   mm_build_device_index   flattening of skch::Sketch for the device     winSketch.hpp:100-102
-//   k_seed_lookup           getSeedHits (freq. seed removal) + getSeedIntervalPoints gather
-//                                                                         computeMap.hpp:818-843, 857-912
-//   k_sort_points_*         the (seqId,pos,side) order of getSeedIntervalPoints  computeMap.hpp:885-907
-//   k_l1_sweep              computeL1CandidateRegions                      computeMap.hpp:916-1116
+//   k_lookup_l1             getSeedHits (freq. seed removal) + getSeedIntervalPoints + computeL1CandidateRegions, fused:
+//                           wave per fragment, points sorted in registers   computeMap.hpp:818-843, 857-912, 916-1116
+//   k_sort_points_* / k_l1_sweep   the same through HBM for the fragments the fused path hands over (> 128 points,
+//                           -Y groups, position groups spanning contigs) or when MM_OPT_KEEP_POINTS is set
 //   (L2 lives in mm_l2.hip)
 #include "mm_internal.h"
 #include "mm_device.h"
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 
@@ -53,15 +55,16 @@ int mm_build_device_index(mm_ctx* c, const int32_t* contigLen, const int32_t* re
     }
   }
   size_t cap = 16; while (cap < 2 * nk + 2) cap <<= 1;
-  std::vector<uint64_t> hk(cap, MM_EMPTY), hv(cap, 0);
+  std::vector<uint64_t> hs(2 * cap, 0);                 // interleaved {key, val} slots
+  for (size_t i = 0; i < cap; i++) hs[2 * i] = MM_EMPTY;
   for (size_t i = 0; i < nk; i++) {
     const uint64_t key = c->hKeys[i];
     const uint64_t off = c->hOffsets[i], cnt = c->hOffsets[i + 1] - c->hOffsets[i];
     if (cnt >= (1ull << 23) || off >= (1ull << 40)) { c->err = "mm_index_upload: lookup list too large for the packed table value"; return MM_ERR_ARG; }
     const bool freq = std::binary_search(c->hFreq.begin(), c->hFreq.end(), key);
     size_t slot = (size_t)key & (cap - 1);
-    while (hk[slot] != MM_EMPTY) { if (hk[slot] == key) { c->err = "mm_index_upload: duplicate key"; return MM_ERR_ARG; } slot = (slot + 1) & (cap - 1); }
-    hk[slot] = key; hv[slot] = (off << 24) | (cnt << 1) | (freq ? 1ull : 0ull);
+    while (hs[2 * slot] != MM_EMPTY) { if (hs[2 * slot] == key) { c->err = "mm_index_upload: duplicate key"; return MM_ERR_ARG; } slot = (slot + 1) & (cap - 1); }
+    hs[2 * slot] = key; hs[2 * slot + 1] = (off << 24) | (cnt << 1) | (freq ? 1ull : 0ull);
   }
   std::vector<uint64_t> pk(np);
   for (size_t i = 0; i < np; i++) pk[i] = pack_point(c->hPoints[i].seqId, c->hPoints[i].pos, c->hPoints[i].side);
@@ -70,7 +73,7 @@ int mm_build_device_index(mm_ctx* c, const int32_t* contigLen, const int32_t* re
 
   MM_HIP(c, I.recH.ensure(n * 8 + 64)); MM_HIP(c, I.recW.ensure(n * 8 + 64)); MM_HIP(c, I.recEh.ensure(n * 8 + 64)); MM_HIP(c, I.recEw.ensure(n * 4 + 64));
   MM_HIP(c, I.contigOff.ensure((nContigs + 1) * 8)); MM_HIP(c, I.contigLen.ensure(nContigs * 4)); MM_HIP(c, I.refGroup.ensure(nContigs * 4));
-  MM_HIP(c, I.htKeys.ensure(cap * 8)); MM_HIP(c, I.htVals.ensure(cap * 8)); MM_HIP(c, I.ptKeys.ensure(np * 8 + 64));
+  MM_HIP(c, I.htSlots.ensure(cap * 16)); MM_HIP(c, I.ptKeys.ensure(np * 8 + 64));
   if (n) { MM_HIP(c, hipMemcpyAsync(I.recH.p, rh.data(), n * 8, hipMemcpyHostToDevice, c->stream));
            MM_HIP(c, hipMemcpyAsync(I.recW.p, rw.data(), n * 8, hipMemcpyHostToDevice, c->stream));
            MM_HIP(c, hipMemcpyAsync(I.recEh.p, reh.data(), n * 8, hipMemcpyHostToDevice, c->stream));
@@ -78,8 +81,7 @@ int mm_build_device_index(mm_ctx* c, const int32_t* contigLen, const int32_t* re
   MM_HIP(c, hipMemcpyAsync(I.contigOff.p, coff.data(), (nContigs + 1) * 8, hipMemcpyHostToDevice, c->stream));
   MM_HIP(c, hipMemcpyAsync(I.contigLen.p, contigLen, nContigs * 4, hipMemcpyHostToDevice, c->stream));
   MM_HIP(c, hipMemcpyAsync(I.refGroup.p, grp.data(), nContigs * 4, hipMemcpyHostToDevice, c->stream));
-  MM_HIP(c, hipMemcpyAsync(I.htKeys.p, hk.data(), cap * 8, hipMemcpyHostToDevice, c->stream));
-  MM_HIP(c, hipMemcpyAsync(I.htVals.p, hv.data(), cap * 8, hipMemcpyHostToDevice, c->stream));
+  MM_HIP(c, hipMemcpyAsync(I.htSlots.p, hs.data(), cap * 16, hipMemcpyHostToDevice, c->stream));
   if (np) MM_HIP(c, hipMemcpyAsync(I.ptKeys.p, pk.data(), np * 8, hipMemcpyHostToDevice, c->stream));
   MM_HIP(c, hipStreamSynchronize(c->stream));
   I.nRec = n; I.nKeys = nk; I.nPoints = np; I.nContigs = nContigs; I.htCap = cap; I.ready = true;
@@ -94,34 +96,229 @@ __device__ __forceinline__ int mm_wave_sum(int v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
+__device__ __forceinline__ int mm_wave_max(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const int y = __shfl_xor(v, o); v = y > v ? y : v; }
+  return v;
+}
 __device__ __forceinline__ int mm_wave_excl_scan(int v) {      // exclusive prefix sum across the 64 lanes
   int x = v;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o); if ((int)mm_lane() >= o) x += y; }
   return x - v;
 }
+__device__ __forceinline__ uint64_t mm_shfl_xor64(uint64_t v, int m) {
+  return ((uint64_t)(uint32_t)__shfl_xor((int)(v >> 32), m) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)v, m);
+}
+__device__ __forceinline__ uint64_t mm_shfl_up64(uint64_t v, int d) {
+  return ((uint64_t)(uint32_t)__shfl_up((int)(v >> 32), d) << 32) | (uint32_t)__shfl_up((int)(uint32_t)v, d);
+}
+__device__ __forceinline__ uint64_t mm_shfl_down64(uint64_t v, int d) {
+  return ((uint64_t)(uint32_t)__shfl_down((int)(v >> 32), d) << 32) | (uint32_t)__shfl_down((int)(uint32_t)v, d);
+}
 
 struct MapFlags { int hg, skipSelf, skipPrefix, lowerTri; };
+struct HtSlot { uint64_t key, val; };                          // one 16-byte slot: a probe costs one memory sector
+
+// ascending bitonic sort of 64*R keys held R per lane, element index = lane*R + r
+template <int R>
+__device__ __forceinline__ void mm_wave_bitonic(uint64_t (&k)[R], int lane) {
+  constexpr int N = 64 * R;
+#pragma unroll
+  for (int k2 = 2; k2 <= N; k2 <<= 1) {
+#pragma unroll
+    for (int j = k2 >> 1; j > 0; j >>= 1) {
+      if (R == 2 && j == 1) {
+        const bool up = ((lane * 2) & k2) == 0;
+        const uint64_t a = k[0], b = k[R - 1];
+        const uint64_t mn = a < b ? a : b, mx = a < b ? b : a;
+        k[0] = up ? mn : mx; k[R - 1] = up ? mx : mn;
+      } else {
+        const int lj = (R == 2) ? (j >> 1) : j;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+          const int idx = lane * R + r;
+          const uint64_t other = mm_shfl_xor64(k[r], lj);
+          const bool up = (idx & k2) == 0, lower = (idx & j) == 0;
+          const uint64_t mn = k[r] < other ? k[r] : other, mx = k[r] < other ? other : k[r];
+          k[r] = (lower == up) ? mn : mx;
+        }
+      }
+    }
+  }
+}
+
+// per-wave LDS scratch of the fused kernel
+#define MM_FUSE_MAXPTS 128
+struct L1Run { int32_t seq, start, end, isize; };
+struct FuseScratch {
+  uint64_t a[MM_FUSE_MAXPTS];        // gathered points, later (seqId<<32 | pos) of every position group
+  int32_t v[MM_FUSE_MAXPTS];         // overlap count after every position group
+  L1Run run[MM_FUSE_MAXPTS];
+};
+
+// Interval points of the fragment's surviving seeds -> dst[0..P) (skip_self / skip_prefix / lower_triangular applied,
+// computeMap.hpp:891-896; dropped points become MM_EMPTY and sort to the end).  Returns the wave-wide count of kept points.
+template <class Dst>
+__device__ __forceinline__ int mm_gather_points(Dst dst, int outIdx, const uint64_t* __restrict__ seedVal, size_t fo,
+                                                const uint64_t* __restrict__ ptKeys, const int32_t* __restrict__ refGroup,
+                                                int rg, int self, int seqCounter, MapFlags fl, int lane) {
+  int nValid = 0, done = 0;
+  for (int base = 0; base < outIdx; base += 64) {
+    const int i = base + lane;
+    uint64_t val = 0;
+    if (i < outIdx) val = seedVal[fo + i];
+    const int c = (int)((val >> 1) & 0x7fffffull);
+    const int my = done + mm_wave_excl_scan(c);
+    const uint64_t src = val >> 24;
+    for (int j = 0; j < c; j++) {
+      uint64_t key = ptKeys[src + j];
+      const int seqId = (int)(key >> 33);
+      bool drop = false;
+      if (fl.skipSelf && seqId == self) drop = true;
+      if (fl.skipPrefix && refGroup[seqId] == rg) drop = true;
+      if (fl.lowerTri && !(seqCounter > seqId)) drop = true;
+      if (drop) key = MM_EMPTY; else nValid++;
+      dst[my + j] = key;
+    }
+    done += mm_wave_sum(c);
+  }
+  return mm_wave_sum(nValid);
+}
+
+// computeL1CandidateRegions (computeMap.hpp:916-1116, windowLen == 0) on a wave-sorted point list, data-parallel form
+// (SURVEY App. A.4): position groups = runs of equal pos; overlap after group g = inclusive prefix sum of (+1 OPEN, -1 CLOSE);
+// pass 1 best = max; pass 2 runs of consecutive groups -- the last one excluded -- with overlap >= minimumHits, cut on seqId
+// change; runs closer than segLength joined.  Returns -1 when the list needs the literal sweep instead (a position group that
+// spans two contigs: there the reference's trailing pointer, which compares (seqId,pos), lags its leading pointer, which
+// compares pos only); otherwise the number of candidates, which have been stored at sc.run[0..n).
+template <int R>
+__device__ __forceinline__ int mm_l1_fused(uint64_t (&k)[R], FuseScratch& sc, int sketchSizeQ, int minHits, int hg,
+                                           const int32_t* __restrict__ cutoffs, int nCutoffs, int sParam, int segLength, int lane) {
+  bool valid[R]; uint64_t prv[R], nxt[R];
+#pragma unroll
+  for (int e = 0; e < R; e++) valid[e] = k[e] != MM_EMPTY;
+  {
+    const uint64_t up = mm_shfl_up64(k[R - 1], 1), dn = mm_shfl_down64(k[0], 1);
+    prv[0] = lane == 0 ? MM_EMPTY : up;
+    nxt[R - 1] = lane == 63 ? MM_EMPTY : dn;
+    if (R == 2) { prv[R - 1] = k[0]; nxt[0] = k[R - 1]; }
+  }
+  bool mixed = false; int delta[R]; bool gLast[R];
+#pragma unroll
+  for (int e = 0; e < R; e++) {
+    const bool pv = prv[e] != MM_EMPTY, nv = nxt[e] != MM_EMPTY;
+    if (valid[e] && pv && (uint32_t)(prv[e] >> 1) == (uint32_t)(k[e] >> 1) && (prv[e] >> 33) != (k[e] >> 33)) mixed = true;
+    delta[e] = valid[e] ? ((k[e] & 1ull) ? 1 : -1) : 0;
+    gLast[e] = valid[e] && (!nv || (uint32_t)(nxt[e] >> 1) != (uint32_t)(k[e] >> 1));
+  }
+  if (__ballot(mixed)) return -1;
+  int laneSum = 0, laneGroups = 0;
+#pragma unroll
+  for (int e = 0; e < R; e++) { laneSum += delta[e]; laneGroups += gLast[e] ? 1 : 0; }
+  int run = mm_wave_excl_scan(laneSum);
+  int gidx = mm_wave_excl_scan(laneGroups);
+  const int G = mm_wave_sum(laneGroups);
+  int best = 0;
+#pragma unroll
+  for (int e = 0; e < R; e++) {
+    run += delta[e];
+    if (gLast[e]) { sc.a[gidx] = k[e] >> 1; sc.v[gidx] = run; gidx++; best = run > best ? run : best; }
+  }
+  best = mm_wave_max(best);
+  if (G == 0) return 0;
+  if (hg) {                                                       // computeMap.hpp:984-998
+    if (best < minHits) return 0;
+    const double div = (double)sParam / 1000.0 > 1.0 ? (double)sParam / 1000.0 : 1.0;
+    int ci = (int)((double)(best < sketchSizeQ ? best : sketchSizeQ) / div);
+    if (ci >= nCutoffs) ci = nCutoffs - 1;
+    const int cut = cutoffs[ci];
+    minHits = cut > minHits ? cut : minHits;
+  }
+  __threadfence_block();
+  // pass 2 over the groups, again R per lane
+  uint64_t gk[R]; bool flag[R];
+#pragma unroll
+  for (int e = 0; e < R; e++) {
+    const int j = lane * R + e;
+    gk[e] = j < G ? sc.a[j] : 0ull;
+    flag[e] = j < G - 1 && sc.v[j] >= minHits;
+  }
+  bool pflag[R], nflag[R]; uint32_t pseq[R], nseq[R];
+  {
+    const int upf = __shfl_up((int)flag[R - 1], 1), dnf = __shfl_down((int)flag[0], 1);
+    const int ups = __shfl_up((int)(gk[R - 1] >> 32), 1), dns = __shfl_down((int)(gk[0] >> 32), 1);
+    pflag[0] = lane != 0 && upf; pseq[0] = (uint32_t)ups;
+    nflag[R - 1] = lane != 63 && dnf; nseq[R - 1] = (uint32_t)dns;
+    if (R == 2) { pflag[R - 1] = flag[0]; pseq[R - 1] = (uint32_t)(gk[0] >> 32); nflag[0] = flag[R - 1]; nseq[0] = (uint32_t)(gk[R - 1] >> 32); }
+  }
+  bool rStart[R], rEnd[R]; int laneStarts = 0;
+#pragma unroll
+  for (int e = 0; e < R; e++) {
+    const uint32_t sq = (uint32_t)(gk[e] >> 32);
+    rStart[e] = flag[e] && (!pflag[e] || pseq[e] != sq);
+    rEnd[e] = flag[e] && (!nflag[e] || nseq[e] != sq);
+    laneStarts += rStart[e] ? 1 : 0;
+  }
+  int ridx = mm_wave_excl_scan(laneStarts);                       // runs that started before this lane
+  const int nRuns = mm_wave_sum(laneStarts);
+  if (nRuns == 0) return 0;
+  int myRun[R];
+#pragma unroll
+  for (int e = 0; e < R; e++) {
+    if (rStart[e]) { sc.run[ridx].seq = (int32_t)(gk[e] >> 32); sc.run[ridx].start = (int32_t)(uint32_t)gk[e]; sc.run[ridx].isize = 0; ridx++; }
+    myRun[e] = ridx - 1;
+  }
+  __threadfence_block();
+#pragma unroll
+  for (int e = 0; e < R; e++) {
+    if (flag[e]) atomicMax(&sc.run[myRun[e]].isize, sc.v[lane * R + e]);
+    if (rEnd[e]) sc.run[myRun[e]].end = (int32_t)(uint32_t)gk[e];
+  }
+  __threadfence_block();
+  // join runs closer than segLength (computeMap.hpp:1102-1115); uniform across the wave, compacted in place
+  int nOut = 0;
+  L1Run pend = sc.run[0];
+  for (int r = 1; r < nRuns; r++) {
+    const L1Run x = sc.run[r];
+    if (x.seq != pend.seq || x.start > pend.end + segLength) {
+      __threadfence_block();
+      if (lane == 0) sc.run[nOut] = pend;
+      nOut++; pend = x;
+    } else { pend.end = x.end; pend.isize = x.isize > pend.isize ? x.isize : pend.isize; }
+  }
+  __threadfence_block();
+  if (lane == 0) sc.run[nOut] = pend;
+  nOut++;
+  __threadfence_block();
+  return nOut;
+}
 
 // ---------------------------------------------------------------------------------------------
-// k_seed_lookup: one wave per fragment.
+// k_lookup_l1: one wave per fragment (4 per workgroup, no workgroup barrier).
 //   * probes the s sketch hashes in the open-addressing table (key -> offset,count,frequent)
 //   * drops frequent seeds and compacts the sketch (Q.minmerTableQuery / Q.sketchSize, computeMap.hpp:834-839)
-//   * reserves space for the fragment's interval points and gathers them as packed 64-bit keys
-//     (seqId<<33 | pos<<1 | isOpen), applying the skip_self / skip_prefix / lower_triangular
-//     filters of computeMap.hpp:891-896 (filtered points become MM_EMPTY and sort to the end).
+//   * FAST (<= 128 interval points, no skip_prefix grouping): gathers the points into LDS, sorts them in registers
+//     (ascending packed key == (seqId, pos, CLOSE-before-OPEN), computeMap.hpp:885-907) and runs L1 on the spot --
+//     the points never touch HBM
+//   * otherwise (many points, -Y groups, a position group spanning contigs, or keepPoints for the parity API): reserves
+//     slots in the global point buffer, gathers there and queues the fragment for k_sort_points_* + k_l1_sweep.
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-k_seed_lookup(int nFrags, int s, const DFrag* __restrict__ frags,
-              const uint64_t* __restrict__ skHash, const int8_t* __restrict__ skStrand, const uint32_t* __restrict__ skCount,
-              const uint64_t* __restrict__ htKeys, const uint64_t* __restrict__ htVals, uint64_t htMask,
-              const uint64_t* __restrict__ ptKeys, const int32_t* __restrict__ refGroup,
-              const int32_t* __restrict__ readGroup, const int32_t* __restrict__ readSelf, int seqCounterBase, MapFlags fl,
-              uint64_t* __restrict__ qHash, int8_t* __restrict__ qStrand, uint64_t* __restrict__ seedVal,
-              mm_frag_stats* __restrict__ stats, int64_t* __restrict__ ptOff, uint64_t* __restrict__ pts, unsigned long long ptsCap,
-              unsigned long long* __restrict__ counters /* [0] point cursor, [1] overflow flag */) {
+k_lookup_l1(int nFrags, int s, const DFrag* __restrict__ frags,
+            const uint64_t* __restrict__ skHash, const int8_t* __restrict__ skStrand, const uint32_t* __restrict__ skCount,
+            const HtSlot* __restrict__ ht, uint64_t htMask,
+            const uint64_t* __restrict__ ptKeys, const int32_t* __restrict__ refGroup,
+            const int32_t* __restrict__ readGroup, const int32_t* __restrict__ readSelf, int seqCounterBase, MapFlags fl, int keepPoints,
+            uint64_t* __restrict__ qHash, int8_t* __restrict__ qStrand, uint64_t* __restrict__ seedVal,
+            mm_frag_stats* __restrict__ stats, int64_t* __restrict__ ptOff, uint64_t* __restrict__ pts, unsigned long long ptsCap,
+            const int32_t* __restrict__ minHitsTab, const int32_t* __restrict__ cutoffs, int nCutoffs, int segLength,
+            mm_l1_candidate* __restrict__ l1, unsigned long long l1Cap, int64_t* __restrict__ l1Off, int32_t* __restrict__ bigList,
+            unsigned long long* __restrict__ counters /* [0] point cursor [1] pts overflow [2] l1 cursor [3] l1 overflow [7] big count */) {
+  __shared__ FuseScratch scratch[4];
   const int f = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (f >= nFrags) return;
+  FuseScratch& sc = scratch[threadIdx.x >> 6];
   const int lane = (int)mm_lane();
   const int cnt = (int)skCount[f];
   const size_t fo = (size_t)f * s;
@@ -134,9 +331,9 @@ k_seed_lookup(int nFrags, int s, const DFrag* __restrict__ frags,
       h = skHash[fo + r];
       uint64_t slot = h & htMask;
       while (true) {
-        const uint64_t kx = htKeys[slot];
-        if (kx == h) { found = true; val = htVals[slot]; break; }
-        if (kx == MM_EMPTY) break;
+        const HtSlot sl = ht[slot];
+        if (sl.key == h) { found = true; val = sl.val; break; }
+        if (sl.key == MM_EMPTY) break;
         slot = (slot + 1) & htMask;
       }
     }
@@ -149,80 +346,90 @@ k_seed_lookup(int nFrags, int s, const DFrag* __restrict__ frags,
     P += mm_wave_sum(keep && found ? (int)((val >> 1) & 0x7fffffull) : 0);
     outIdx += __popcll(m);
   }
-  // reserve point slots (a power of two above 64 so that the sorters can work in place)
+  __threadfence_block();                                           // seedVal is re-read by the gather below
+  const int readId = frags[f].readId;
+  const int rg = readGroup[readId], self = readSelf[readId], seqCounter = seqCounterBase + readId;
+  const int minHits0 = outIdx > 0 ? minHitsTab[outIdx] : 0;
+  int nValid = 0, nOut = -1;
+  if (!keepPoints && !fl.skipPrefix && P <= MM_FUSE_MAXPTS && minHits0 > 0) {
+    if (P == 0) nOut = 0;
+    else {
+      nValid = mm_gather_points(sc.a, outIdx, seedVal, fo, ptKeys, refGroup, rg, self, seqCounter, fl, lane);
+      const int padTo = P <= 64 ? 64 : 128;
+      for (int j = P + lane; j < padTo; j += 64) sc.a[j] = MM_EMPTY;
+      __threadfence_block();
+      if (P <= 64) {
+        uint64_t k[1] = {sc.a[lane]};
+        mm_wave_bitonic<1>(k, lane);
+        nOut = mm_l1_fused<1>(k, sc, outIdx, minHits0, fl.hg, cutoffs, nCutoffs, s, segLength, lane);
+      } else {
+        uint64_t k[2] = {sc.a[lane * 2], sc.a[lane * 2 + 1]};
+        mm_wave_bitonic<2>(k, lane);
+        nOut = mm_l1_fused<2>(k, sc, outIdx, minHits0, fl.hg, cutoffs, nCutoffs, s, segLength, lane);
+      }
+    }
+  }
+  mm_frag_stats st;
+  st.rawSketchSize = cnt; st.sketchSize = outIdx; st.maxHash = cnt ? skHash[fo + cnt - 1] : 0ull;
+  if (nOut >= 0) {                                                 // fast path complete: emit the candidates
+    unsigned long long base = 0;
+    if (nOut > 0) {
+      if (lane == 0) base = atomicAdd(&counters[2], (unsigned long long)nOut);
+      base = ((unsigned long long)(uint32_t)__shfl((int)(base >> 32), 0) << 32) | (uint32_t)__shfl((int)(uint32_t)base, 0);
+      if (base + (unsigned long long)nOut > l1Cap) { if (lane == 0) atomicOr(&counters[3], 1ull); nOut = 0; }
+      for (int i = lane; i < nOut; i += 64) {
+        const L1Run x = sc.run[i];
+        mm_l1_candidate o; o.frag = f; o.seqId = x.seq; o.rangeStartPos = x.start; o.rangeEndPos = x.end; o.intersectionSize = x.isize;
+        l1[base + i] = o;
+      }
+    }
+    if (lane == 0) {
+      st.nPoints = nValid; st.nL1 = nOut; stats[f] = st;
+      ptOff[2 * f] = 0; ptOff[2 * f + 1] = 0; l1Off[f] = (int64_t)base;
+    }
+    return;
+  }
+  // slow path: points go to HBM, sorted and swept by the follow-up kernels (slots: a power of two above 64 for the sorters)
   int slots = P;
   if (P > 64) { slots = 128; while (slots < P) slots <<= 1; }
   unsigned long long off = 0;
   if (lane == 0 && slots > 0) off = atomicAdd(&counters[0], (unsigned long long)slots);
-  off = __shfl(off, 0);
+  off = ((unsigned long long)(uint32_t)__shfl((int)(off >> 32), 0) << 32) | (uint32_t)__shfl((int)(uint32_t)off, 0);
   bool ok = true;
   if (slots > 0 && off + (unsigned long long)slots > ptsCap) { ok = false; if (lane == 0) atomicOr(&counters[1], 1ull); }
-  int nValid = 0;
+  nValid = 0;
   if (ok && slots > 0) {
-    const int readId = frags[f].readId;
-    const int rg = readGroup[readId], self = readSelf[readId], seqCounter = seqCounterBase + readId;
-    int done = 0;
-    for (int base = 0; base < outIdx; base += 64) {
-      const int i = base + lane;
-      uint64_t val = 0;
-      if (i < outIdx) val = seedVal[fo + i];
-      const int c = (int)((val >> 1) & 0x7fffffull);
-      const int my = done + mm_wave_excl_scan(c);
-      const uint64_t src = val >> 24;
-      for (int j = 0; j < c; j++) {
-        uint64_t key = ptKeys[src + j];
-        const int seqId = (int)(key >> 33);
-        bool drop = false;
-        if (fl.skipSelf && seqId == self) drop = true;
-        if (fl.skipPrefix && refGroup[seqId] == rg) drop = true;
-        if (fl.lowerTri && !(seqCounter > seqId)) drop = true;
-        if (drop) key = MM_EMPTY; else nValid++;
-        pts[off + my + j] = key;
-      }
-      done += mm_wave_sum(c);
-    }
+    nValid = mm_gather_points(pts + off, outIdx, seedVal, fo, ptKeys, refGroup, rg, self, seqCounter, fl, lane);
     for (int j = P + lane; j < slots; j += 64) pts[off + j] = MM_EMPTY;
-    nValid = mm_wave_sum(nValid);
   }
   if (lane == 0) {
-    mm_frag_stats st;
-    st.rawSketchSize = cnt; st.sketchSize = outIdx; st.maxHash = cnt ? skHash[fo + cnt - 1] : 0ull;
-    st.nPoints = nValid; st.nL1 = 0;
-    stats[f] = st;
-    ptOff[2 * f] = (int64_t)off; ptOff[2 * f + 1] = ok ? (int64_t)slots : 0;
+    st.nPoints = nValid; st.nL1 = 0; stats[f] = st;
+    ptOff[2 * f] = (int64_t)off; ptOff[2 * f + 1] = ok ? (int64_t)slots : 0; l1Off[f] = 0;
+    if (slots > 0 && ok) bigList[atomicAdd(&counters[7], 1ull)] = f;
   }
 }
 
 // ---------------------------------------------------------------------------------------------
-// point sorters (ascending packed key == ascending (seqId, pos, CLOSE-before-OPEN))
+// point sorters for the queued fragments (ascending packed key == ascending (seqId, pos, CLOSE-before-OPEN))
 // ---------------------------------------------------------------------------------------------
 // <= 64 points: one wave per fragment, bitonic network over the lanes
 __global__ void __launch_bounds__(256)
-k_sort_points_wave(int nFrags, const int64_t* __restrict__ ptOff, uint64_t* __restrict__ pts) {
-  const int f = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (f >= nFrags) return;
+k_sort_points_wave(int nList, const int32_t* __restrict__ list, const int64_t* __restrict__ ptOff, uint64_t* __restrict__ pts) {
+  const int li = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (li >= nList) return;
+  const int f = list[li];
   const int64_t off = ptOff[2 * f]; const int n = (int)ptOff[2 * f + 1];
   if (n <= 1 || n > 64) return;
   const int lane = (int)mm_lane();
-  uint64_t key = lane < n ? pts[off + lane] : MM_EMPTY;
-#pragma unroll
-  for (int k = 2; k <= 64; k <<= 1) {
-#pragma unroll
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      const uint32_t olo = __shfl_xor((uint32_t)key, j), ohi = __shfl_xor((uint32_t)(key >> 32), j);
-      const uint64_t other = ((uint64_t)ohi << 32) | olo;
-      const bool up = (lane & k) == 0, lower = (lane & j) == 0;
-      const uint64_t mn = key < other ? key : other, mx = key < other ? other : key;
-      key = (lower == up) ? mn : mx;
-    }
-  }
-  if (lane < n) pts[off + lane] = key;
+  uint64_t k[1] = {lane < n ? pts[off + lane] : MM_EMPTY};
+  mm_wave_bitonic<1>(k, lane);
+  if (lane < n) pts[off + lane] = k[0];
 }
 
 // 65..LDSCAP points (power of two): one 256-thread workgroup per fragment, bitonic sort staged in LDS
 #define MM_SORT_LDSCAP 4096
 __global__ void __launch_bounds__(256)
-k_sort_points_block(int nFrags, const int64_t* __restrict__ ptOff, uint64_t* __restrict__ pts, const int32_t* __restrict__ list) {
+k_sort_points_block(const int64_t* __restrict__ ptOff, uint64_t* __restrict__ pts, const int32_t* __restrict__ list) {
   __shared__ uint64_t sk[MM_SORT_LDSCAP];
   const int f = list[blockIdx.x];
   const int64_t off = ptOff[2 * f]; const int n = (int)ptOff[2 * f + 1];
@@ -256,18 +463,25 @@ k_sort_points_global(const int64_t* __restrict__ ptOff, uint64_t* __restrict__ p
     }
 }
 
-// builds the lists of fragments for the block / global sorters
-__global__ void k_classify_sort(int nFrags, const int64_t* __restrict__ ptOff, int32_t* __restrict__ listB, int32_t* __restrict__ listC,
-                                unsigned int* __restrict__ cnt /* [0] B, [1] C */) {
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
-  if (f >= nFrags) return;
-  const int64_t n = ptOff[2 * f + 1];
-  if (n > MM_SORT_LDSCAP) listC[atomicAdd(&cnt[1], 1u)] = f;
-  else if (n > 64) listB[atomicAdd(&cnt[0], 1u)] = f;
+// splits the queued fragments into the block / global sorter lists (wave-aggregated cursors)
+__global__ void k_classify_sort(int nList, const int32_t* __restrict__ list, const int64_t* __restrict__ ptOff,
+                                int32_t* __restrict__ listB, int32_t* __restrict__ listC, unsigned int* __restrict__ cnt /* [0] B, [1] C */) {
+  const int li = blockIdx.x * blockDim.x + threadIdx.x;
+  int f = -1; int64_t n = 0;
+  if (li < nList) { f = list[li]; n = ptOff[2 * f + 1]; }
+  const bool isC = n > MM_SORT_LDSCAP, isB = !isC && n > 64;
+  const uint64_t mB = __ballot(isB), mC = __ballot(isC);
+  unsigned int bB = 0, bC = 0;
+  if (mB && mm_lane() == (uint32_t)__builtin_ctzll(mB)) bB = atomicAdd(&cnt[0], (unsigned int)__popcll(mB));
+  if (mC && mm_lane() == (uint32_t)__builtin_ctzll(mC)) bC = atomicAdd(&cnt[1], (unsigned int)__popcll(mC));
+  if (mB) bB = __shfl(bB, __builtin_ctzll(mB));
+  if (mC) bC = __shfl(bC, __builtin_ctzll(mC));
+  if (isB) listB[bB + mm_popc_below(mB)] = f;
+  if (isC) listC[bC + mm_popc_below(mC)] = f;
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_l1_sweep: one thread per fragment over its sorted points (windowLen == 0, i.e. split mode).
+// k_l1_sweep: one thread per queued fragment over its sorted points (windowLen == 0, i.e. split mode).
 // Literal two-pointer restatement of computeMap.hpp:948-1115 on packed keys:
 //   key>>1 == (seqId<<32 | pos)  so  "trail <= lead in (seqId,pos)"  is one 64-bit compare.
 // Emits the joined candidates of each reference group (skip_prefix) in the reference's order.
@@ -346,12 +560,14 @@ __device__ void l1_sweep_fragment(const uint64_t* __restrict__ p, int nPts, int 
 }
 
 __global__ void __launch_bounds__(256)
-k_l1_sweep(int nFrags, const int64_t* __restrict__ ptOff, const uint64_t* __restrict__ pts, mm_frag_stats* __restrict__ stats,
+k_l1_sweep(int nList, const int32_t* __restrict__ list, const int64_t* __restrict__ ptOff, const uint64_t* __restrict__ pts,
+           mm_frag_stats* __restrict__ stats,
            const int32_t* __restrict__ minHitsTab, const int32_t* __restrict__ cutoffs, int nCutoffs, int sParam, int segLength,
            MapFlags fl, const int32_t* __restrict__ refGroup, mm_l1_candidate* __restrict__ l1, unsigned long long l1Cap,
            int64_t* __restrict__ l1Off, unsigned long long* __restrict__ counters /* [2] l1 cursor, [3] overflow */) {
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
-  if (f >= nFrags) return;
+  const int li = blockIdx.x * blockDim.x + threadIdx.x;
+  if (li >= nList) return;
+  const int f = list[li];
   const int nPts = stats[f].nPoints, S = stats[f].sketchSize;
   int nOut = 0; long long base = 0;
   if (nPts > 0 && S > 0) {
@@ -387,65 +603,87 @@ int mm_launch_map(mm_ctx* c) {
   if (nF == 0) return MM_OK;
   MapFlags fl{(c->P.flags & MM_FLAG_HG_FILTER) ? 1 : 0, (c->P.flags & MM_FLAG_SKIP_SELF) ? 1 : 0,
               (c->P.flags & MM_FLAG_SKIP_PREFIX) ? 1 : 0, (c->P.flags & MM_FLAG_LOWER_TRIANGULAR) ? 1 : 0};
-  if (c->ptsCap == 0) c->ptsCap = (size_t)nF * 128 + 4096;
+  const bool allSlow = c->keepPoints || fl.skipPrefix;
+  if (c->ptsCap == 0) c->ptsCap = allSlow ? (size_t)nF * 128 + 4096 : (size_t)nF * 8 + 65536;
   if (c->l1Cap == 0) c->l1Cap = (size_t)nF * 2 + 1024;
   DevBuf& listB = c->dListB; DevBuf& listC = c->dListC;
-  MM_HIP(c, listB.ensure((size_t)nF * 4 + 16)); MM_HIP(c, listC.ensure((size_t)nF * 4 + 16));
+  MM_HIP(c, listB.ensure((size_t)nF * 4 + 16)); MM_HIP(c, listC.ensure((size_t)nF * 4 + 16)); MM_HIP(c, c->dBigList.ensure((size_t)nF * 4 + 16));
   int rc = MM_OK;
   unsigned long long hc[8];
+  unsigned long long* cnt = c->dCounters.as<unsigned long long>() + 8;   // [8..15]; [0..7] belong to the sketch launcher
 
-  for (int attempt = 0; attempt < 8; attempt++) {           // grow-and-retry on capacity overflow
+  for (int attempt = 0; attempt < 10; attempt++) {          // grow-and-retry on capacity overflow (points or L1 candidates)
     MM_HIP(c, c->dPts.ensure(c->ptsCap * 8 + 64));
+    MM_HIP(c, c->dL1.ensure(c->l1Cap * sizeof(mm_l1_candidate) + 64));
     MM_HIP(c, hipMemsetAsync(c->dCounters.p, 0, 256, c->stream));
-    unsigned long long* cnt = c->dCounters.as<unsigned long long>() + 8;   // [8..15]; [0..7] belong to the sketch launcher
     {
       KernelTimer t(c, MM_K_LOOKUP);
-      hipLaunchKernelGGL(k_seed_lookup, dim3((nF + 3) / 4), dim3(256), 0, c->stream, nF, s, c->dFrags.as<DFrag>(),
+      hipLaunchKernelGGL(k_lookup_l1, dim3((nF + 3) / 4), dim3(256), 0, c->stream, nF, s, c->dFrags.as<DFrag>(),
                          c->dSkHash.as<uint64_t>(), c->dSkStrand.as<int8_t>(), c->dSkCount.as<uint32_t>(),
-                         I.htKeys.as<uint64_t>(), I.htVals.as<uint64_t>(), (uint64_t)(I.htCap - 1), I.ptKeys.as<uint64_t>(),
+                         I.htSlots.as<HtSlot>(), (uint64_t)(I.htCap - 1), I.ptKeys.as<uint64_t>(),
                          I.refGroup.as<int32_t>(), c->dReadGroup.as<int32_t>(), c->dReadSelf.as<int32_t>(), c->seqCounterBase, fl,
+                         c->keepPoints ? 1 : 0,
                          c->dQHash.as<uint64_t>(), c->dQStrand.as<int8_t>(), c->dSeedVal.as<uint64_t>(), c->dStats.as<mm_frag_stats>(),
-                         c->dPtOff.as<int64_t>(), c->dPts.as<uint64_t>(), (unsigned long long)c->ptsCap, cnt);
+                         c->dPtOff.as<int64_t>(), c->dPts.as<uint64_t>(), (unsigned long long)c->ptsCap,
+                         c->dMinHits.as<int32_t>(), c->dCutoffs.as<int32_t>(), (int)c->nCutoffs, c->P.segLength,
+                         c->dL1.as<mm_l1_candidate>(), (unsigned long long)c->l1Cap, c->dL1Off.as<int64_t>(), c->dBigList.as<int32_t>(), cnt);
       MM_HIP(c, hipGetLastError());
     }
     MM_HIP(c, hipMemcpyAsync(hc, cnt, 64, hipMemcpyDeviceToHost, c->stream));
     MM_HIP(c, hipStreamSynchronize(c->stream));
     if (hc[1]) { c->ptsCap = (size_t)hc[0] + (size_t)hc[0] / 8 + 4096; continue; }
+    if (hc[3]) { c->l1Cap = (size_t)hc[2] * 2 + 1024; continue; }
     break;
   }
   if (hc[1]) { c->err = "interval-point buffer overflow"; return MM_ERR_CAPACITY; }
-  unsigned long long* cnt = c->dCounters.as<unsigned long long>() + 8;
-  unsigned int* cls = (unsigned int*)(c->dCounters.as<unsigned long long>() + 16);   // [16] two 32-bit class counters
-  {
-    KernelTimer t(c, MM_K_SORT);
-    hipLaunchKernelGGL(k_sort_points_wave, dim3((nF + 3) / 4), dim3(256), 0, c->stream, nF, c->dPtOff.as<int64_t>(), c->dPts.as<uint64_t>());
-    hipLaunchKernelGGL(k_classify_sort, dim3((nF + 255) / 256), dim3(256), 0, c->stream, nF, c->dPtOff.as<int64_t>(),
-                       listB.as<int32_t>(), listC.as<int32_t>(), cls);
-    MM_HIP(c, hipGetLastError());
-    unsigned int hcls[2];
-    MM_HIP(c, hipMemcpyAsync(hcls, cls, 8, hipMemcpyDeviceToHost, c->stream));
-    MM_HIP(c, hipStreamSynchronize(c->stream));
-    if (hcls[0]) hipLaunchKernelGGL(k_sort_points_block, dim3(hcls[0]), dim3(256), 0, c->stream, nF, c->dPtOff.as<int64_t>(), c->dPts.as<uint64_t>(), listB.as<int32_t>());
-    if (hcls[1]) hipLaunchKernelGGL(k_sort_points_global, dim3(hcls[1]), dim3(1024), 0, c->stream, c->dPtOff.as<int64_t>(), c->dPts.as<uint64_t>(), listC.as<int32_t>());
-    MM_HIP(c, hipGetLastError());
-  }
-  for (int attempt = 0; attempt < 8; attempt++) {
-    MM_HIP(c, c->dL1.ensure(c->l1Cap * sizeof(mm_l1_candidate) + 64));
-    MM_HIP(c, hipMemsetAsync(cnt + 2, 0, 16, c->stream));
+  if (hc[3]) { c->err = "L1 candidate buffer overflow"; return MM_ERR_CAPACITY; }
+  const int nBig = (int)hc[7];
+  if (getenv("MM_DEBUG")) fprintf(stderr, "[mm] lookup+L1: %d fragments, %d to the sort+sweep path, %llu fused candidates\n", nF, nBig, hc[2]);
+  if (nBig > 0) {
+    unsigned int* cls = (unsigned int*)(c->dCounters.as<unsigned long long>() + 16);   // [16] two 32-bit class counters
     {
-      KernelTimer t(c, MM_K_L1);
-      hipLaunchKernelGGL(k_l1_sweep, dim3((nF + 255) / 256), dim3(256), 0, c->stream, nF, c->dPtOff.as<int64_t>(), c->dPts.as<uint64_t>(),
-                         c->dStats.as<mm_frag_stats>(), c->dMinHits.as<int32_t>(), c->dCutoffs.as<int32_t>(), (int)c->nCutoffs, s,
-                         c->P.segLength, fl, I.refGroup.as<int32_t>(), c->dL1.as<mm_l1_candidate>(), (unsigned long long)c->l1Cap,
-                         c->dL1Off.as<int64_t>(), cnt);
+      KernelTimer t(c, MM_K_SORT);
+      hipLaunchKernelGGL(k_sort_points_wave, dim3((nBig + 3) / 4), dim3(256), 0, c->stream, nBig, c->dBigList.as<int32_t>(), c->dPtOff.as<int64_t>(), c->dPts.as<uint64_t>());
+      hipLaunchKernelGGL(k_classify_sort, dim3((nBig + 255) / 256), dim3(256), 0, c->stream, nBig, c->dBigList.as<int32_t>(), c->dPtOff.as<int64_t>(),
+                         listB.as<int32_t>(), listC.as<int32_t>(), cls);
+      MM_HIP(c, hipGetLastError());
+      unsigned int hcls[2];
+      MM_HIP(c, hipMemcpyAsync(hcls, cls, 8, hipMemcpyDeviceToHost, c->stream));
+      MM_HIP(c, hipStreamSynchronize(c->stream));
+      if (hcls[0]) hipLaunchKernelGGL(k_sort_points_block, dim3(hcls[0]), dim3(256), 0, c->stream, c->dPtOff.as<int64_t>(), c->dPts.as<uint64_t>(), listB.as<int32_t>());
+      if (hcls[1]) hipLaunchKernelGGL(k_sort_points_global, dim3(hcls[1]), dim3(1024), 0, c->stream, c->dPtOff.as<int64_t>(), c->dPts.as<uint64_t>(), listC.as<int32_t>());
       MM_HIP(c, hipGetLastError());
     }
-    MM_HIP(c, hipMemcpyAsync(hc, cnt, 64, hipMemcpyDeviceToHost, c->stream));
-    MM_HIP(c, hipStreamSynchronize(c->stream));
-    if (hc[3]) { c->l1Cap = (size_t)hc[2] + (size_t)hc[2] / 8 + 1024; continue; }
-    break;
+    for (int attempt = 0; attempt < 8; attempt++) {
+      // candidates of the fused path sit at [0, fusedL1); the sweep appends behind them, so a retry only rewinds to fusedL1
+      const unsigned long long fusedL1 = hc[2];
+      MM_HIP(c, hipMemcpyAsync(cnt + 2, &fusedL1, 8, hipMemcpyHostToDevice, c->stream));
+      MM_HIP(c, hipMemsetAsync(cnt + 3, 0, 8, c->stream));
+      {
+        KernelTimer t(c, MM_K_L1);
+        hipLaunchKernelGGL(k_l1_sweep, dim3((nBig + 255) / 256), dim3(256), 0, c->stream, nBig, c->dBigList.as<int32_t>(), c->dPtOff.as<int64_t>(),
+                           c->dPts.as<uint64_t>(), c->dStats.as<mm_frag_stats>(), c->dMinHits.as<int32_t>(), c->dCutoffs.as<int32_t>(),
+                           (int)c->nCutoffs, s, c->P.segLength, fl, I.refGroup.as<int32_t>(), c->dL1.as<mm_l1_candidate>(),
+                           (unsigned long long)c->l1Cap, c->dL1Off.as<int64_t>(), cnt);
+        MM_HIP(c, hipGetLastError());
+      }
+      unsigned long long h2[2];
+      MM_HIP(c, hipMemcpyAsync(h2, cnt + 2, 16, hipMemcpyDeviceToHost, c->stream));
+      MM_HIP(c, hipStreamSynchronize(c->stream));
+      if (h2[1]) {
+        // grow, keeping the fused candidates already in the buffer
+        const size_t newCap = (size_t)h2[0] + (size_t)h2[0] / 8 + 1024;
+        DevBuf nb; MM_HIP(c, nb.ensure(newCap * sizeof(mm_l1_candidate) + 64));
+        if (fusedL1) MM_HIP(c, hipMemcpyAsync(nb.p, c->dL1.p, (size_t)fusedL1 * sizeof(mm_l1_candidate), hipMemcpyDeviceToDevice, c->stream));
+        MM_HIP(c, hipStreamSynchronize(c->stream));
+        c->dL1.release(); c->dL1 = nb; c->l1Cap = newCap;
+        hc[3] = 1; continue;
+      }
+      hc[2] = h2[0]; hc[3] = 0;
+      break;
+    }
+    if (hc[3]) { c->err = "L1 candidate buffer overflow"; return MM_ERR_CAPACITY; }
   }
-  if (hc[3]) { c->err = "L1 candidate buffer overflow"; return MM_ERR_CAPACITY; }
   c->nL1 = (size_t)hc[2];
   if (c->nL1 == 0) { c->nL2 = 0; return rc; }
 
@@ -512,6 +750,7 @@ int mm_query_sketch_download(mm_ctx* c, mm_minmer* out) {
 
 int mm_points_download(mm_ctx* c, size_t frag, mm_interval_point* out, size_t cap, size_t* n) {
   if (!c->mapped || frag >= c->nFrags) { c->err = "mm_points_download: bad state / fragment"; return MM_ERR_STATE; }
+  if (!c->keepPoints && !(c->P.flags & MM_FLAG_SKIP_PREFIX)) { c->err = "mm_points_download: interval points are not kept in HBM (mm_set_option MM_OPT_KEEP_POINTS)"; return MM_ERR_STATE; }
   MM_HIP(c, hipSetDevice(c->device));
   int64_t po[2]; mm_frag_stats fs;
   MM_HIP(c, hipMemcpy(po, c->dPtOff.as<int64_t>() + 2 * frag, 16, hipMemcpyDeviceToHost));

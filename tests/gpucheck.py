@@ -40,8 +40,15 @@ def run_and_compare(oracle, contigs, reads, k=19, L=5000, s=130, pi=0.85, flags=
     ctx.index_upload(ix["minmers"], ix["keys"], ix["offsets"], ix["points"], ix["freq"], ix["contigLen"], refGroup)
     ctx.set_tables(oracle.min_hits_table(s, k, pi), oracle.cutoffs(h))
     nF = ctx.reads_upload([a for _, a in reads], readGroup, selfId, seqCounterBase)
+    # first the default path (interval points stay in LDS/registers: fused lookup + sort + L1), then again with the point lists
+    # kept in HBM (sort + literal sweep kernels); both must reproduce the reference, and agree with each other
+    ctx.map()
+    fast = ctx.results()
+    ctx.keep_points(True)
     ctx.map()
     stats, l1, l2 = ctx.results()
+    for a, b, what in zip(fast, (stats, l1, l2), ("stats", "l1", "l2")):
+        assert len(a) == len(b) and a.tobytes() == b.tobytes(), "fused and HBM point paths disagree on " + what
     qsk = ctx.query_sketches()
     frs = ctx.fragments()
     l1_by_f = {}

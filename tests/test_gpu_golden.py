@@ -56,8 +56,13 @@ def test_map_vs_reference_golden(gold):
     ctx.index_build([a for _, a in contigs], kmerPct=P["kmerPct"])
     ctx.set_tables_default(P["pi"])
     nF = ctx.reads_upload([a for _, a in reads])
+    ctx.map()                                            # default path: fused lookup + sort + L1
+    fast = ctx.results()
+    ctx.keep_points(True)                                # and again with the sorted point lists kept in HBM (for ctx.points)
     ctx.map()
     stats, l1, l2 = ctx.results()
+    for a, b in zip(fast, (stats, l1, l2)):
+        assert a.tobytes() == b.tobytes()
     frs = ctx.fragments()
     gf = gold["session"]["fragments"]
     assert nF == len(gf)
