@@ -8,14 +8,18 @@
 //
 //   k_l2_extents   thread / candidate : the two record ranges a candidate touches
 //                                       (insert stream: minmerIndex order; eviction stream: same records ordered by wpos_end)
-//   mm_scan        exclusive scan of the per-candidate op counts
-//   k_l2_locate    wave / candidate   : query sketch staged in LDS; every record of both ranges is located in it
-//                                       (coalesced hash loads, LDS binary search) and reduced to a 16-bit "op"
-//   k_l2_sweep     lane / candidate   : the sequential SlideMapper sweep over the pre-located ops; per-lane state in
-//                                       LDS, transposed so that any cell index is bank-conflict free
+//   scan           exclusive scan of the per-candidate entry counts
+//   k_l2_locate    wave / candidate   : merges the two streams into ONE time-ordered stream of 8-byte entries.  The query
+//                                       sketch and both position arrays are staged in LDS; every record is located in the
+//                                       sketch (LDS binary search) and its slot in the merged order is computed by counting
+//                                       (eviction e precedes insert i  <=>  wpos_end[e] <= wpos[i], computeMap.hpp:1344-1367)
+//   k_l2_sweep     lane / candidate   : the sequential SlideMapper sweep over the merged stream; 64 bytes (8 entries) per lane
+//                                       are fetched per step and the next step is prefetched while the current one is
+//                                       consumed; per-lane SlideMapper state sits in LDS as 16-bit cells laid out so that a
+//                                       lane always hits its own bank
 //
-// so the latency-bound pointer chasing of the sweep (two dependent 8-step searches per record) becomes a
-// throughput-bound, coalesced pre-pass.
+// so the latency-bound pointer chasing of the reference (two dependent 8-step searches per record plus a heap) becomes a
+// throughput-bound, coalesced pre-pass followed by a sweep whose only memory traffic is one sequential stream per lane.
 #include "mm_internal.h"
 #include "mm_device.h"
 
@@ -24,11 +28,22 @@
 struct L2Info { int64_t it0; int64_t itE0; int32_t nIns; int32_t nDel; };
 struct L2Tmp { int32_t start, end, shared, strand; };
 
-// op layout: bits 0..10 = 1-based position j of the hash in the query sketch (0: beyond the sketch -> no-op),
-//            bit 11 = hash equals q[j], bits 12..13 = query strand + 1
+// merged-stream entry (uint64):
+//   bits 0..10  1-based position j of the hash in the query sketch (0: beyond the sketch -> no effect on the state)
+//   bit  11     hash equals q[j]
+//   bits 12..13 query strand + 1
+//   bits 16..17 type: 0 eviction, 1 insert + evaluate, 2 end of stream, 3 pre-load insert (computeMap.hpp:1323-1338)
+//   bit  18     reference strand is REV
+//   bits 32..63 wpos of the record (insert), or of the record after the last one (end)
+#define E_DEL 0u
+#define E_INS 1u
+#define E_END 2u
+#define E_PRE 3u
 #define OP_J(op) ((int)((op) & 0x7FFu))
 #define OP_MATCH(op) ((int)(((op) >> 11) & 1u))
 #define OP_QS(op) ((int)(((op) >> 12) & 3u) - 1)
+#define OP_TYPE(op) (((op) >> 16) & 3u)
+#define OP_RSTRAND(op) ((((op) >> 18) & 1u) ? -1 : 1)
 
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
@@ -53,7 +68,8 @@ k_l2_extents(int nCand, int segLength, const mm_l1_candidate* __restrict__ l1, c
   while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (recEw[mid] <= cand.rangeEndPos) lo = mid + 1; else hi = mid; }
   L2Info o; o.it0 = it0; o.itE0 = itE0; o.nIns = (int32_t)(itEnd - it0); o.nDel = (int32_t)(lo - itE0);
   info[c] = o;
-  cnt[c] = o.nIns + o.nDel;
+  // merged stream: every insert, every eviction, the end marker; padded to a whole number of 64-byte sweep steps
+  cnt[c] = (o.nIns + o.nDel + 1 + 7) & ~7;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -112,86 +128,150 @@ k_scan_add(int64_t n, int64_t* __restrict__ out, const int64_t* __restrict__ til
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_l2_locate: one wave per candidate (4 per workgroup).  The fragment's query sketch (<= 8 KB) is staged in
-// LDS once; the record hashes of both streams are read coalesced and located with an LDS binary search.
+// k_l2_locate: one wave per candidate (4 per workgroup).  LDS per wave: the fragment's query sketch (9 B per entry) and,
+// when they fit (posCap int32 words), the wpos of the insert range and the wpos_end of the eviction range; candidates with
+// longer ranges search those two arrays in global memory instead (same code, X = pointer + stride).
 // ---------------------------------------------------------------------------------------------
+struct PosArr {            // int32 array with an element stride (LDS copy: stride 1; recW.x in global memory: stride 2)
+  const int32_t* p; int stride;
+  __device__ __forceinline__ int operator[](int i) const { return p[(size_t)i * stride]; }
+};
+// #{ i in [0,n) : a[i] < v }   /   #{ i : a[i] <= v }
+__device__ __forceinline__ int mm_count_lt(const PosArr a, int n, int v) {
+  int lo = 0, hi = n;
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (a[mid] < v) lo = mid + 1; else hi = mid; }
+  return lo;
+}
+__device__ __forceinline__ int mm_count_le(const PosArr a, int n, int v) {
+  int lo = 0, hi = n;
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (a[mid] <= v) lo = mid + 1; else hi = mid; }
+  return lo;
+}
+
 __global__ void __launch_bounds__(256)
-k_l2_locate(int nCand, int s, const mm_l1_candidate* __restrict__ l1, const mm_frag_stats* __restrict__ stats,
+k_l2_locate(int nCand, int s, int posCap, const mm_l1_candidate* __restrict__ l1, const mm_frag_stats* __restrict__ stats,
             const uint64_t* __restrict__ qHash, const int8_t* __restrict__ qStrand, const uint64_t* __restrict__ recH,
-            const uint64_t* __restrict__ recEh, const L2Info* __restrict__ info, const int64_t* __restrict__ opOff,
-            uint16_t* __restrict__ ops) {
+            const int2* __restrict__ recW, const uint64_t* __restrict__ recEh, const int32_t* __restrict__ recEw,
+            const int64_t* __restrict__ contigOff, const L2Info* __restrict__ info, const int64_t* __restrict__ opOff,
+            uint64_t* __restrict__ ops) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  uint64_t* q = (uint64_t*)smem + (size_t)wave * s;
-  int8_t* qs = (int8_t*)((uint64_t*)smem + (size_t)4 * s) + (size_t)wave * s;
-  for (int c0 = blockIdx.x * 4; c0 < nCand; c0 += gridDim.x * 4) {      // uniform trip count across the workgroup
-    const int c = c0 + wave;
-    const bool act = c < nCand;
-    int S = 0, f = 0; L2Info in{0, 0, 0, 0}; int64_t off = 0;
-    if (act) { f = l1[c].frag; S = stats[f].sketchSize; in = info[c]; off = opOff[c]; }
-    __syncthreads();                                                      // previous iteration done with q
+  // per-wave carve: q[s] u64 | pos[posCap] i32 | qs[s] i8
+  const size_t perWave = (size_t)s * 8 + (size_t)posCap * 4 + (((size_t)s + 15) & ~(size_t)15);
+  unsigned char* base = smem + (size_t)wave * perWave;
+  uint64_t* q = (uint64_t*)base;
+  int32_t* posL = (int32_t*)(base + (size_t)s * 8);
+  int8_t* qs = (int8_t*)(base + (size_t)s * 8 + (size_t)posCap * 4);
+  for (int c = blockIdx.x * 4 + wave; c < nCand; c += gridDim.x * 4) {    // waves are independent: no workgroup barrier below
+    const mm_l1_candidate cand = l1[c];
+    const int f = cand.frag;
+    const int S = stats[f].sketchSize;
+    const L2Info in = info[c];
+    uint64_t* out = ops + opOff[c];
+    __threadfence_block();                                                 // previous candidate's LDS reads are done
     for (int p = lane; p < S; p += 64) { q[p] = qHash[(size_t)f * s + p]; qs[p] = qStrand[(size_t)f * s + p]; }
-    __syncthreads();
-    if (!act) continue;
+    const bool inLds = in.nIns + in.nDel <= posCap;
+    PosArr insX, delX;
+    if (inLds) {
+      for (int i = lane; i < in.nIns; i += 64) posL[i] = recW[in.it0 + i].x;
+      for (int e = lane; e < in.nDel; e += 64) posL[in.nIns + e] = recEw[in.itE0 + e];
+      insX.p = posL; insX.stride = 1; delX.p = posL + in.nIns; delX.stride = 1;
+    } else {
+      insX.p = (const int32_t*)(recW + in.it0); insX.stride = 2; delX.p = recEw + in.itE0; delX.stride = 1;
+    }
+    __threadfence_block();
     const uint64_t qmax = q[S - 1];
-    const int total = in.nIns + in.nDel;
-    for (int i = lane; i < total; i += 64) {
-      const bool isIns = i < in.nIns;
-      const uint64_t h = isIns ? recH[in.it0 + i] : recEh[in.itE0 + (i - in.nIns)];
-      uint32_t op = 0;
-      if (h <= qmax) {
-        int lo = 0, hi = S;
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (q[mid] < h) lo = mid + 1; else hi = mid; }
-        op = (uint32_t)(lo + 1) | (q[lo] == h ? 0x800u : 0u) | ((uint32_t)((int)qs[lo] + 1) << 12);
+    auto locate = [&](uint64_t h) -> uint32_t {
+      if (h > qmax) return 0u;
+      int lo = 0, hi = S;
+      while (lo < hi) { const int mid = (lo + hi) >> 1; if (q[mid] < h) lo = mid + 1; else hi = mid; }
+      return (uint32_t)(lo + 1) | (q[lo] == h ? 0x800u : 0u) | ((uint32_t)((int)qs[lo] + 1) << 12);
+    };
+    // records left of the range (wpos < rangeStart): only those still open at rangeStart are pre-loaded (:1323-1338)
+    const int nPreAll = mm_count_lt(insX, in.nIns, cand.rangeStartPos);
+    int nPre = 0;
+    for (int b0 = 0; b0 < nPreAll; b0 += 64) {
+      const int i = b0 + lane;
+      bool keep = false; int2 w = make_int2(0, 0);
+      if (i < nPreAll) { w = recW[in.it0 + i]; keep = (int)((uint32_t)w.y & 0x7fffffffu) > cand.rangeStartPos; }
+      const uint64_t m = __ballot(keep);
+      if (keep) {
+        const uint32_t op = locate(recH[in.it0 + i]) | (E_PRE << 16) | (w.y < 0 ? (1u << 18) : 0u);
+        out[nPre + (int)mm_popc_below(m)] = ((uint64_t)(uint32_t)w.x << 32) | op;
       }
-      ops[off + i] = (uint16_t)op;
+      nPre += __popcll(m);
+    }
+    const int nMain = in.nIns - nPreAll;
+    PosArr mainX = insX; mainX.p += (size_t)nPreAll * insX.stride;
+    for (int mi = lane; mi < nMain; mi += 64) {                            // inserts that are evaluated
+      const int2 w = recW[in.it0 + nPreAll + mi];
+      const uint32_t op = locate(recH[in.it0 + nPreAll + mi]) | (E_INS << 16) | (w.y < 0 ? (1u << 18) : 0u);
+      out[nPre + mi + mm_count_le(delX, in.nDel, w.x)] = ((uint64_t)(uint32_t)w.x << 32) | op;
+    }
+    for (int e = lane; e < in.nDel; e += 64) {                             // evictions that happen before some insert
+      const int ew = delX[e];
+      const int before = mm_count_lt(mainX, nMain, ew);                    // inserts with wpos < wpos_end[e] come first
+      if (before < nMain) out[nPre + e + before] = (uint64_t)(locate(recEh[in.itE0 + e]) | (E_DEL << 16));
+    }
+    if (lane == 0) {                                                       // end marker right behind the last insert
+      int endPos = nPre, nextW = 0;
+      if (nMain > 0) {
+        const int wl = mainX[nMain - 1];
+        endPos = nPre + nMain + mm_count_le(delX, in.nDel, wl);
+        // wpos of the next record of the same contig, or of the last one when it closes the contig (:1387-1390)
+        nextW = (in.it0 + in.nIns < contigOff[cand.seqId + 1]) ? recW[in.it0 + in.nIns].x : wl;
+      }
+      out[endPos] = ((uint64_t)(uint32_t)nextW << 32) | (uint64_t)(E_END << 16);
     }
   }
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_l2_sweep: one lane per candidate.  Per-lane SlideMapper state in LDS, cell p of lane l at word p*64+l:
-//   bits 0..15 num_before_inc   bit 16 active   bits 24..31 strand_vote (int8)
+// k_l2_sweep: one lane per candidate.  Per-lane SlideMapper state in LDS, one 16-bit cell per query position p:
+//   bits 0..11 num_before_inc   bit 12 active   bits 13..14 strand_vote + 1
+// cell p of lane l lives in dword p*32 + (l & 31), half l >> 5: both 32-lane halves of a DS instruction see 32 distinct banks.
 // ---------------------------------------------------------------------------------------------
+#define CELL_CNT(x) ((int)((x) & 0xFFFu))
+#define CELL_ACT(x) ((int)(((x) >> 12) & 1u))
+#define CELL_VOTE(x) ((int)(((x) >> 13) & 3u) - 1)
+
 __global__ void __launch_bounds__(64)
 k_l2_sweep(int nCand, int segLength, const mm_l1_candidate* __restrict__ l1, const mm_frag_stats* __restrict__ stats,
-           const int2* __restrict__ recW, const int32_t* __restrict__ recEw, const int64_t* __restrict__ contigOff,
-           const L2Info* __restrict__ info, const int64_t* __restrict__ opOff, const uint16_t* __restrict__ ops,
+           const int64_t* __restrict__ opOff, const int32_t* __restrict__ opCnt, const uint64_t* __restrict__ ops,
            const int64_t* __restrict__ l1Off, L2Tmp* __restrict__ tmp, mm_l2_locus* __restrict__ l2, unsigned long long l2Cap,
            unsigned long long* __restrict__ counters /* [4] l2 cursor, [5] overflow, [6] locus-slot overflow */) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t cell[];
+  extern __shared__ __attribute__((aligned(16))) uint16_t cell[];
   const int lane = threadIdx.x;
   const int cIdx = blockIdx.x * 64 + lane;
   if (cIdx >= nCand) return;
   const mm_l1_candidate cand = l1[cIdx];
   const int f = cand.frag;
   const int S = stats[f].sketchSize;
-  const L2Info in = info[cIdx];
-  const uint16_t* opS = ops + opOff[cIdx];
-  const uint16_t* opE = opS + in.nIns;
-  const int2* rw = recW + in.it0;
-  const int32_t* ew = recEw + in.itE0;
-  const int64_t ce = contigOff[cand.seqId + 1];
-#define CELL(p) cell[(p) * 64 + lane]
+  const uint4* src = (const uint4*)(ops + opOff[cIdx]);
+  const int nSteps = opCnt[cIdx] >> 3;                 // 8 entries = 4 x 16 bytes per step
+  const int lbase = (lane & 31) * 2 + (lane >> 5);
+#define CELL(p) cell[(p) * 64 + lbase]
   CELL(0) = 0;
-  for (int p = 1; p <= S; p++) CELL(p) = 1u;
+  for (int p = 1; p <= S; p++) CELL(p) = 1u | (1u << 13);       // num_before_inc = 1, inactive, vote 0
   int pivot = S, pivRank = S, shared = 0, votes = 0;
+  bool doubleOpen = false;
 
-  auto insert = [&](uint32_t op, int rStrand) {       // slidingMap.hpp:125-165
+  auto insert = [&](uint32_t op) {                     // slidingMap.hpp:125-165
     const int j = OP_J(op);
     if (j == 0) return;
     uint32_t cw = CELL(j);
     if (OP_MATCH(op)) {
-      const int v = (int)(int8_t)(cw >> 24) + OP_QS(op) * rStrand;
-      cw = (cw & 0x0000FFFFu) | 0x00010000u | ((uint32_t)(uint8_t)(int8_t)v << 24);
-      CELL(j) = cw;
+      const int v = OP_QS(op) * OP_RSTRAND(op);        // a query hash has one open reference window at a time (windowLen == 0);
+      if (CELL_ACT(cw)) doubleOpen = true;             // the 2-bit vote relies on it, so a violation is reported, not absorbed
+      cw = (cw & 0xFFFu) | (1u << 12) | ((uint32_t)(v + 1) << 13);
+      CELL(j) = (uint16_t)cw;
       if (j <= pivot) { shared++; votes += v; }
     } else {
-      CELL(j) = cw + 1u;
+      CELL(j) = (uint16_t)(cw + 1u);
       if (j <= pivot) pivRank++;
       if (pivRank > S) {
-        const uint32_t pw = (pivot == j) ? cw + 1u : CELL(pivot);
-        shared -= (int)((pw >> 16) & 1u); votes -= (int)(int8_t)(pw >> 24); pivRank -= (int)(pw & 0xFFFFu); pivot--;
+        const uint32_t pw = (pivot == j) ? cw + 1u : (uint32_t)CELL(pivot);
+        shared -= CELL_ACT(pw); votes -= CELL_ACT(pw) ? CELL_VOTE(pw) : 0; pivRank -= CELL_CNT(pw); pivot--;
       }
     }
   };
@@ -200,26 +280,19 @@ k_l2_sweep(int nCand, int segLength, const mm_l1_candidate* __restrict__ l1, con
     if (j == 0) return;
     const uint32_t cw = CELL(j);
     if (OP_MATCH(op)) {
-      if (j <= pivot) { shared--; votes -= (int)(int8_t)(cw >> 24); }
-      CELL(j) = cw & 0x0000FFFFu;
+      if (j <= pivot) { shared--; votes -= CELL_VOTE(cw); }
+      CELL(j) = (uint16_t)((cw & 0xFFFu) | (1u << 13));
     } else {
-      CELL(j) = cw - 1u;
+      CELL(j) = (uint16_t)(cw - 1u);
       if (j <= pivot) pivRank--;
       if (pivot + 1 <= S) {
-        const uint32_t nw = (pivot + 1 == j) ? cw - 1u : CELL(pivot + 1);
-        if (pivRank + (int)(nw & 0xFFFFu) <= S) { pivot++; shared += (int)((nw >> 16) & 1u); votes += (int)(int8_t)(nw >> 24); pivRank += (int)(nw & 0xFFFFu); }
+        const uint32_t nw = (pivot + 1 == j) ? cw - 1u : (uint32_t)CELL(pivot + 1);
+        if (pivRank + CELL_CNT(nw) <= S) { pivot++; shared += CELL_ACT(nw); votes += CELL_ACT(nw) ? CELL_VOTE(nw) : 0; pivRank += CELL_CNT(nw); }
       }
     }
   };
 
-  int i = 0, e = 0;
-  // pre-load (:1323-1338): records left of the range that are still open at rangeStart
-  for (; i < in.nIns; i++) {
-    const int2 w = rw[i];
-    if (!(w.x < cand.rangeStartPos)) break;
-    if ((int)((uint32_t)w.y & 0x7fffffffu) > cand.rangeStartPos) insert(opS[i], w.y < 0 ? -1 : 1);
-  }
-  // slide (:1340-1434)
+  // best-position bookkeeping (:1376-1449)
   int bestShared = 1; bool inRun = false;
   int curStart = 0, curEnd = 0, curShared = 0;
   int nFlushed = 0; bool havePend = false; L2Tmp pend{0, 0, 0, 0};
@@ -233,30 +306,58 @@ k_l2_sweep(int nCand, int segLength, const mm_l1_candidate* __restrict__ l1, con
       pend.end = curEnd;
     }
   };
-  int2 w = i < in.nIns ? rw[i] : make_int2(0, 0);
-  for (; i < in.nIns; i++) {
-    // next record of the same contig, or this one when it is the contig's last (:1387-1390)
-    const int2 wn = (in.it0 + i + 1 < ce) ? rw[i + 1] : w;
-    const int prevVotes = votes;
-    while (e < in.nDel && ew[e] <= w.x) { remove(opE[e]); e++; }
-    insert(opS[i], w.y < 0 ? -1 : 1);
-    const int nextW = wn.x;
-    if (shared > bestShared) {
+  // the evaluation of insert i needs the wpos of record i+1, so it is carried until the next insert / end entry arrives
+  // lastVotes = strand_votes right after the most recent insert (pre-load included): the reference samples it before the
+  // evictions that precede the next insert (:1342)
+  bool evalPending = false; int evW = 0, evShared = 0, evPrevVotes = 0, lastVotes = 0;
+  auto evaluate = [&](int nextW) {
+    if (evShared > bestShared) {
       nFlushed = 0; havePend = false;                  // l2_vec_out.clear()
-      inRun = true; bestShared = shared; curShared = shared; curStart = w.x; curEnd = nextW;
-    } else if (shared == bestShared) {
-      if (!inRun) { curShared = shared; curStart = w.x; }
+      inRun = true; bestShared = evShared; curShared = evShared; curStart = evW; curEnd = nextW;
+    } else if (evShared == bestShared) {
+      if (!inRun) { curShared = evShared; curStart = evW; }
       inRun = true; curEnd = nextW;
     } else {
-      if (inRun) { curEnd = nextW; close_run(prevVotes >= 0 ? 1 : -1); curStart = 0; curEnd = 0; curShared = 0; }
+      if (inRun) { curEnd = nextW; close_run(evPrevVotes >= 0 ? 1 : -1); curStart = 0; curEnd = 0; curShared = 0; }
       inRun = false;
     }
-    w = wn;
+  };
+
+  bool done = false;
+  uint4 cur[4], nxt[4];
+  if (nSteps > 0) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) cur[k] = src[k];
+  }
+  for (int step = 0; step < nSteps && !done; step++) {
+    if (step + 1 < nSteps) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) nxt[k] = src[(size_t)(step + 1) * 4 + k];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const uint32_t lo = (k & 1) ? cur[k >> 1].z : cur[k >> 1].x;
+      const int wpos = (int)((k & 1) ? cur[k >> 1].w : cur[k >> 1].y);
+      if (done) continue;
+      const uint32_t type = OP_TYPE(lo);
+      if (type == E_DEL) remove(lo);
+      else if (type == E_PRE) { insert(lo); lastVotes = votes; }
+      else {
+        if (evalPending) { evaluate(wpos); evalPending = false; }
+        if (type == E_END) { done = true; continue; }
+        evPrevVotes = lastVotes;
+        insert(lo);
+        evW = wpos; evShared = shared; lastVotes = votes; evalPending = true;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) cur[k] = nxt[k];
   }
   if (inRun) close_run(votes >= 0 ? 1 : -1);
 #undef CELL
   const int total = nFlushed + (havePend ? 1 : 0);
   if (slotOverflow) atomicOr(&counters[6], 1ull);
+  if (doubleOpen) atomicOr(&counters[6], 2ull);
   if (total > 0 && !slotOverflow) {
     const unsigned long long base = atomicAdd(&counters[4], (unsigned long long)total);
     if (base + total > l2Cap) { atomicOr(&counters[5], 1ull); return; }
@@ -301,15 +402,21 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt) {
     MM_HIP(c, hipGetLastError());
     int rc = scan_i32_to_i64(c, nC, c->dL2Cnt.as<int32_t>(), c->dL2Off.as<int64_t>(), &totalOps);
     if (rc != MM_OK) return rc;
-    MM_HIP(c, c->dL2Ops.ensure((size_t)totalOps * 2 + 64));
-    const size_t ldsLoc = (size_t)4 * s * 9 + 16;
-    int blocks = (nC + 3) / 4; if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(k_l2_locate, dim3(blocks), dim3(256), ldsLoc, c->stream, nC, s, c->dL1.as<mm_l1_candidate>(), c->dStats.as<mm_frag_stats>(),
-                       c->dQHash.as<uint64_t>(), c->dQStrand.as<int8_t>(), I.recH.as<uint64_t>(), I.recEh.as<uint64_t>(),
-                       c->dL2Info.as<L2Info>(), c->dL2Off.as<int64_t>(), c->dL2Ops.as<uint16_t>());
+    MM_HIP(c, c->dL2Ops.ensure((size_t)totalOps * 8 + 256));
+    // LDS for the two position arrays of a candidate: ~4x the sketch size covers the typical candidate (2 records per
+    // sketch entry per segLength of range, both streams); longer ones search global memory
+    int posCap = 16 * s; if (posCap < 2048) posCap = 2048; if (posCap > 8192) posCap = 8192;
+    const size_t perWave = (size_t)s * 8 + (size_t)posCap * 4 + (((size_t)s + 15) & ~(size_t)15);
+    const size_t ldsLoc = perWave * 4;
+    MM_HIP(c, hipFuncSetAttribute((const void*)k_l2_locate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsLoc));
+    int blocks = (nC + 3) / 4; if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(k_l2_locate, dim3(blocks), dim3(256), ldsLoc, c->stream, nC, s, posCap, c->dL1.as<mm_l1_candidate>(),
+                       c->dStats.as<mm_frag_stats>(), c->dQHash.as<uint64_t>(), c->dQStrand.as<int8_t>(), I.recH.as<uint64_t>(),
+                       I.recW.as<int2>(), I.recEh.as<uint64_t>(), I.recEw.as<int32_t>(), I.contigOff.as<int64_t>(),
+                       c->dL2Info.as<L2Info>(), c->dL2Off.as<int64_t>(), c->dL2Ops.as<uint64_t>());
     MM_HIP(c, hipGetLastError());
   }
-  const size_t ldsL2 = (size_t)(s + 1) * 64 * 4;
+  const size_t ldsL2 = (size_t)(s + 1) * 64 * 2;
   if (ldsL2 > 160 * 1024) { c->err = "sketchSize too large for the LDS-resident L2 state"; return MM_ERR_ARG; }
   MM_HIP(c, hipFuncSetAttribute((const void*)k_l2_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsL2));
   if (c->l2Cap < c->nL1 * 2 + 1024) c->l2Cap = c->nL1 * 2 + 1024;
@@ -320,9 +427,8 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt) {
     {
       KernelTimer t(c, MM_K_L2);
       hipLaunchKernelGGL(k_l2_sweep, dim3((unsigned)((nC + 63) / 64)), dim3(64), ldsL2, c->stream, nC, c->P.segLength, c->dL1.as<mm_l1_candidate>(),
-                         c->dStats.as<mm_frag_stats>(), I.recW.as<int2>(), I.recEw.as<int32_t>(), I.contigOff.as<int64_t>(), c->dL2Info.as<L2Info>(),
-                         c->dL2Off.as<int64_t>(), c->dL2Ops.as<uint16_t>(), c->dL1Off.as<int64_t>(), c->dL2Tmp.as<L2Tmp>(),
-                         c->dL2.as<mm_l2_locus>(), (unsigned long long)c->l2Cap, cnt);
+                         c->dStats.as<mm_frag_stats>(), c->dL2Off.as<int64_t>(), c->dL2Cnt.as<int32_t>(), c->dL2Ops.as<uint64_t>(),
+                         c->dL1Off.as<int64_t>(), c->dL2Tmp.as<L2Tmp>(), c->dL2.as<mm_l2_locus>(), (unsigned long long)c->l2Cap, cnt);
       MM_HIP(c, hipGetLastError());
     }
     MM_HIP(c, hipMemcpyAsync(hc, cnt, 64, hipMemcpyDeviceToHost, c->stream));
@@ -330,6 +436,7 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt) {
     if (hc[5]) { c->l2Cap = (size_t)hc[4] + (size_t)hc[4] / 8 + 1024; continue; }
     break;
   }
+  if (hc[6] & 2ull) { c->err = "a query hash had two open reference windows at once (index intervals of one hash overlap)"; return MM_ERR_STATE; }
   if (hc[6]) { c->err = "more than MM_LOCAP tied L2 loci for one candidate"; return MM_ERR_CAPACITY; }
   if (hc[5]) { c->err = "L2 locus buffer overflow"; return MM_ERR_CAPACITY; }
   c->nL2 = (size_t)hc[4];
