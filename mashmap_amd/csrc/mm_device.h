@@ -86,3 +86,78 @@ __device__ __forceinline__ uint32_t mm_lane() { return threadIdx.x & 63u; }
 __device__ __forceinline__ uint32_t mm_popc_below(uint64_t mask) {    // set bits of mask strictly below this lane
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
+
+// ---------------------------------------------------------------------------------------------
+// Strip hasher.  For K = 17..19 (one 16-byte block + a tail of K-16 <= 3 bytes; K = 19 is MashMap's default) the tail has
+// at most 64 values, so its complete mix (k1*C1, rotl 31, *C2) comes from a 64-entry LDS table indexed by the 2-bit codes:
+// 2 of the 10 64-bit multiplies per hash and the tail's byte assembly go away.  Bit-exact with mm_murmur_kmer<K>.
+// (Also tried: the two block products k1*C1, k2*C2 by the sliding recurrence K1(j)*C1 = b(j)*C1 + ((K1(j+1)*C1) << 8) with
+// 4-entry tables -- 4 fewer multiplies per hash on paper, but the same VALU instruction count and its LDS look-ups land on
+// the dependency chain: 135-193 ms instead of 73 ms per 10 Gbp on MI355X.  The kernel issues VALU ~93 % of the time, so only
+// fewer instructions help; see DESIGN.md.)
+// ---------------------------------------------------------------------------------------------
+struct MMTables {            // lives in LDS; filled by mm_tables_init
+  uint64_t tailF[64];        // mix_k1 of the forward tail, indexed by the 2-bit codes of bases j+16.. (first base in the low bits)
+  uint64_t tailR[64];        // mix_k1 of the reverse-complement tail, indexed by the codes of bases j..j+TAIL-1
+};
+
+__device__ __forceinline__ uint32_t mm_ascii1(uint32_t code) { return code == 0 ? 0x41u : code == 1 ? 0x43u : code == 2 ? 0x47u : 0x54u; }
+
+template <int K> struct MMFastK { static constexpr bool value = (K >= 17 && K <= 19); };
+
+template <int K>
+__device__ __forceinline__ void mm_tables_init(MMTables& T, int tid, int nthr) {
+  constexpr int TAIL = MMFastK<K>::value ? K - 16 : 0;
+  for (int c = tid; c < 64; c += nthr) {
+    uint64_t kf = 0, kr = 0;
+#pragma unroll
+    for (int i = 0; i < TAIL; i++) {
+      kf |= (uint64_t)mm_ascii1((c >> (2 * i)) & 3) << (8 * i);                        // byte 16+i = base j+16+i
+      kr |= (uint64_t)mm_ascii1(3 - ((c >> (2 * (TAIL - 1 - i))) & 3)) << (8 * i);     // byte 16+i = comp(base j+TAIL-1-i)
+    }
+    T.tailF[c] = TAIL ? mm_mix_k1(kf) : 0ull;
+    T.tailR[c] = TAIL ? mm_mix_k1(kr) : 0ull;
+  }
+}
+
+// 2-bit code of base i (0..47) of the 48-base window w[0..2]
+#define MM_CODE(w, i) (((w)[(i) >> 4] >> (2 * ((i) & 15))) & 3u)
+
+// block part from the ASCII streams (as mm_murmur_kmer), tail mix supplied by the caller (TAIL <= 8 bytes: no k2 tail)
+template <int K>
+__device__ __forceinline__ uint64_t mm_murmur_kmer_tail(const uint32_t* A, int off, uint64_t tailMix) {
+  uint64_t h1 = MM_SEED, h2 = MM_SEED;
+  constexpr int NB = K / 16;
+#pragma unroll
+  for (int b = 0; b < NB; b++) {
+    const uint64_t k1 = mm_bytes<8>(A, off + 16 * b), k2 = mm_bytes<8>(A, off + 16 * b + 8);
+    h1 ^= mm_mix_k1(k1); h1 = mm_rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
+    h2 ^= mm_mix_k2(k2); h2 = mm_rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
+  }
+  h1 ^= tailMix;
+  h1 ^= (uint64_t)K; h2 ^= (uint64_t)K;
+  h1 += h2; h2 += h1;
+  h1 = mm_fmix64(h1); h2 = mm_fmix64(h2);
+  return h1 + h2;
+}
+
+// Hashes of the 16 k-mer positions of a strip on both strands; calls use(j, fwd, rc) for j = 0..15 in ascending order.
+template <int K, class Use>
+__device__ __forceinline__ void mm_strip_hashes(uint32_t w0, uint32_t w1, uint32_t w2, const MMTables& T, Use&& use) {
+  MMStrip st;
+  st.load(w0, w1, w2);
+  if constexpr (MMFastK<K>::value) {
+    constexpr int TAIL = K - 16;
+    const uint32_t w[3] = {w0, w1, w2};
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      uint32_t tf = 0, tr = 0;
+#pragma unroll
+      for (int i = 0; i < TAIL; i++) { tf |= MM_CODE(w, j + 16 + i) << (2 * i); tr |= MM_CODE(w, j + i) << (2 * i); }
+      use(j, mm_murmur_kmer_tail<K>(st.F, j, T.tailF[tf]), mm_murmur_kmer_tail<K>(st.R, 48 - K - j, T.tailR[tr]));
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 16; j++) use(j, mm_murmur_kmer<K>(st.F, j), mm_murmur_kmer<K>(st.R, 48 - K - j));
+  }
+}

@@ -29,26 +29,24 @@ template <int K>
 __global__ void __launch_bounds__(256)
 k_ref_hash(const uint32_t* __restrict__ bases2, const uint32_t* __restrict__ nmask, int64_t nPos, int hasN,
            uint64_t* __restrict__ outH, int8_t* __restrict__ outS) {
+  __shared__ MMTables tabs;
+  if (MMFastK<K>::value) mm_tables_init<K>(tabs, threadIdx.x, blockDim.x);
+  __syncthreads();
   const int64_t nStrips = (nPos + 15) >> 4;
   const uint64_t kmask = (1ull << K) - 1ull;
   for (int64_t strip = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; strip < nStrips; strip += (int64_t)gridDim.x * blockDim.x) {
-    MMStrip st;
-    st.load(bases2[strip], bases2[strip + 1], bases2[strip + 2]);
     uint64_t nm = 0;
     if (hasN) {
       const uint64_t m64 = (uint64_t)nmask[strip >> 1] | ((uint64_t)nmask[(strip >> 1) + 1] << 32);
       nm = m64 >> ((strip & 1) * 16);
     }
     uint64_t hs[16]; uint32_t sbits = 0;
-#pragma unroll
-    for (int j = 0; j < 16; j++) {
-      const uint64_t hf = mm_murmur_kmer<K>(st.F, j);
-      const uint64_t hr = mm_murmur_kmer<K>(st.R, 48 - K - j);
+    mm_strip_hashes<K>(bases2[strip], bases2[strip + 1], bases2[strip + 2], tabs, [&](int j, uint64_t hf, uint64_t hr) {
       bool ok = hf != hr;
       if (hasN) ok = ok & (((nm >> j) & kmask) == 0);
       hs[j] = ok ? (hf < hr ? hf : hr) : MM_HASH_MAX;
       sbits |= (hf < hr ? 1u : 0u) << j;
-    }
+    });
     const int64_t p0 = strip * 16;
 #pragma unroll
     for (int j = 0; j < 16; j++)

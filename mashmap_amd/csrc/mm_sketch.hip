@@ -98,6 +98,8 @@ k_sketch_fragments(const uint32_t* __restrict__ bases2, const uint32_t* __restri
   const int nW = (len + 15) / 16 + 3;               // code words incl. 2 words of run-off for the last strip
   const int nM = (len + 31) / 32 + 2;
   size_t off = 0;
+  MMTables* tabs = (MMTables*)(smem + off); off += sizeof(MMTables);
+  if (MMFastK<K>::value) mm_tables_init<K>(*tabs, tid, nthr);    // made visible by the first __syncthreads() below
   uint32_t* sW = (uint32_t*)(smem + off); off += (((size_t)nW * 4 + 15) / 16) * 16;
   uint32_t* sM = (uint32_t*)(smem + off); off += (((size_t)nM * 4 + 15) / 16) * 16;
   uint64_t* arrA = (uint64_t*)(smem + off); off += (size_t)HT * 8;     // queue hashes, later sort keys
@@ -145,18 +147,13 @@ k_sketch_fragments(const uint32_t* __restrict__ bases2, const uint32_t* __restri
 
     // ---- phase 1: hash both strands of every k-mer ----
     for (int strip = tid; strip < nStrips; strip += nthr) {
-      MMStrip st;
-      st.load(sW[strip], sW[strip + 1], sW[strip + 2]);
       uint64_t nm = 0;
       if (hasN) {
         const uint64_t m64 = (uint64_t)sM[strip >> 1] | ((uint64_t)sM[(strip >> 1) + 1] << 32);
         nm = m64 >> ((strip & 1) * 16);
       }
-#pragma unroll
-      for (int j = 0; j < 16; j++) {
+      mm_strip_hashes<K>(sW[strip], sW[strip + 1], sW[strip + 2], *tabs, [&](int j, uint64_t hf, uint64_t hr) {
         const int pos = strip * 16 + j;
-        const uint64_t hf = mm_murmur_kmer<K>(st.F, j);
-        const uint64_t hr = mm_murmur_kmer<K>(st.R, 48 - K - j);
         const uint64_t h = hf < hr ? hf : hr;
         bool pass = (pos < n) & (hf != hr) & (T == MM_HASH_MAX ? true : h < T);
         if (hasN) pass = pass & (((nm >> j) & kmask) == 0);
@@ -175,7 +172,7 @@ k_sketch_fragments(const uint32_t* __restrict__ bases2, const uint32_t* __restri
             }
           }
         }
-      }
+      });
     }
     __syncthreads();
 
@@ -248,7 +245,7 @@ k_sketch_fragments(const uint32_t* __restrict__ bases2, const uint32_t* __restri
 // ---------------------------------------------------------------------------------------------
 static size_t sketch_lds_bytes(int maxLen, int HT) {
   const size_t nW = (size_t)(maxLen + 15) / 16 + 3, nM = (size_t)(maxLen + 31) / 32 + 2;
-  return ((nW * 4 + 15) / 16) * 16 + ((nM * 4 + 15) / 16) * 16 + (size_t)HT * (8 + 4 + 8 + 4 + 4 + 4) + 16;
+  return sizeof(MMTables) + ((nW * 4 + 15) / 16) * 16 + ((nM * 4 + 15) / 16) * 16 + (size_t)HT * (8 + 4 + 8 + 4 + 4 + 4) + 16;
 }
 static int next_pow2(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 
