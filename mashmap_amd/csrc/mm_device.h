@@ -74,12 +74,15 @@ __device__ __forceinline__ uint64_t mm_murmur_kmer(const uint32_t* A, int off) {
 // The 16 k-mer positions of one strip: forward and reverse-complement ASCII streams of a 48-base window.
 //   F[m]  = ascii(code[m])            m = 0..47   forward k-mer j starts at byte j
 //   RC[m] = ascii(3 - code[47 - m])               reverse-complement of k-mer j starts at byte 48-K-j
+struct MMTables;
 struct MMStrip {
   uint32_t F[13], R[13];
   __device__ __forceinline__ void load(uint32_t w0, uint32_t w1, uint32_t w2) {
     mm_expand16(w0, F); mm_expand16(w1, F + 4); mm_expand16(w2, F + 8); F[12] = 0;
     mm_expand16(mm_rev2(~w2), R); mm_expand16(mm_rev2(~w1), R + 4); mm_expand16(mm_rev2(~w0), R + 8); R[12] = 0;
   }
+  // same streams from the 256-entry LDS table: code byte q of the window gives F[q] and R[11-q] with one 8-byte read
+  __device__ __forceinline__ void load(uint32_t w0, uint32_t w1, uint32_t w2, const MMTables& T);
 };
 
 __device__ __forceinline__ uint32_t mm_lane() { return threadIdx.x & 63u; }
@@ -97,6 +100,7 @@ __device__ __forceinline__ uint32_t mm_popc_below(uint64_t mask) {    // set bit
 // fewer instructions help; see DESIGN.md.)
 // ---------------------------------------------------------------------------------------------
 struct MMTables {            // lives in LDS; filled by mm_tables_init
+  uint2 ascii4[256];         // .x = ASCII of the 4 bases of a code byte; .y = ASCII of their reverse complement (both streams of MMStrip)
   uint64_t tailF[64];        // mix_k1 of the forward tail, indexed by the 2-bit codes of bases j+16.. (first base in the low bits)
   uint64_t tailR[64];        // mix_k1 of the reverse-complement tail, indexed by the codes of bases j..j+TAIL-1
 };
@@ -108,6 +112,15 @@ template <int K> struct MMFastK { static constexpr bool value = (K >= 17 && K <=
 template <int K>
 __device__ __forceinline__ void mm_tables_init(MMTables& T, int tid, int nthr) {
   constexpr int TAIL = MMFastK<K>::value ? K - 16 : 0;
+  for (int c = tid; c < 256; c += nthr) {
+    uint32_t f = 0, r = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      f |= mm_ascii1((c >> (2 * i)) & 3) << (8 * i);
+      r |= mm_ascii1(3 - ((c >> (2 * (3 - i))) & 3)) << (8 * i);
+    }
+    T.ascii4[c] = make_uint2(f, r);
+  }
   for (int c = tid; c < 64; c += nthr) {
     uint64_t kf = 0, kr = 0;
 #pragma unroll
@@ -145,7 +158,7 @@ __device__ __forceinline__ uint64_t mm_murmur_kmer_tail(const uint32_t* A, int o
 template <int K, class Use>
 __device__ __forceinline__ void mm_strip_hashes(uint32_t w0, uint32_t w1, uint32_t w2, const MMTables& T, Use&& use) {
   MMStrip st;
-  st.load(w0, w1, w2);
+  st.load(w0, w1, w2, T);
   if constexpr (MMFastK<K>::value) {
     constexpr int TAIL = K - 16;
     const uint32_t w[3] = {w0, w1, w2};
@@ -160,4 +173,14 @@ __device__ __forceinline__ void mm_strip_hashes(uint32_t w0, uint32_t w1, uint32
 #pragma unroll
     for (int j = 0; j < 16; j++) use(j, mm_murmur_kmer<K>(st.F, j), mm_murmur_kmer<K>(st.R, 48 - K - j));
   }
+}
+
+__device__ __forceinline__ void MMStrip::load(uint32_t w0, uint32_t w1, uint32_t w2, const MMTables& T) {
+  const uint32_t w[3] = {w0, w1, w2};
+#pragma unroll
+  for (int q = 0; q < 12; q++) {
+    const uint2 e = T.ascii4[(w[q >> 2] >> (8 * (q & 3))) & 0xFFu];
+    F[q] = e.x; R[11 - q] = e.y;
+  }
+  F[12] = 0; R[12] = 0;
 }

@@ -30,7 +30,7 @@ __global__ void __launch_bounds__(256)
 k_ref_hash(const uint32_t* __restrict__ bases2, const uint32_t* __restrict__ nmask, int64_t nPos, int hasN,
            uint64_t* __restrict__ outH, int8_t* __restrict__ outS) {
   __shared__ MMTables tabs;
-  if (MMFastK<K>::value) mm_tables_init<K>(tabs, threadIdx.x, blockDim.x);
+  mm_tables_init<K>(tabs, threadIdx.x, blockDim.x);
   __syncthreads();
   const int64_t nStrips = (nPos + 15) >> 4;
   const uint64_t kmask = (1ull << K) - 1ull;

@@ -47,6 +47,7 @@ struct DeviceIndex {
   DevBuf contigLen;            // int32[nContigs]
   DevBuf refGroup;             // int32[nContigs] (all 0 when unused)
   DevBuf htSlots;              // {uint64 key, uint64 val}[htCap]; val = offset<<24 | count<<1 | freq (one 16-byte slot per probe)
+  DevBuf filter; uint64_t filterMask = 0;   // presence bitmap in front of htSlots (bit (key>>32) & filterMask); mask 0 = disabled
   DevBuf ptKeys;               // uint64[nPoints]: seqId<<33 | pos<<1 | (side==OPEN)
   bool ready = false;
 };

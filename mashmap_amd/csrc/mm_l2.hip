@@ -355,12 +355,22 @@ k_l2_sweep(int nCand, int segLength, const mm_l1_candidate* __restrict__ l1, con
   }
   if (inRun) close_run(votes >= 0 ? 1 : -1);
 #undef CELL
-  const int total = nFlushed + (havePend ? 1 : 0);
-  if (slotOverflow) atomicOr(&counters[6], 1ull);
+  int total = nFlushed + (havePend ? 1 : 0);
+  if (slotOverflow) { atomicOr(&counters[6], 1ull); total = 0; }
   if (doubleOpen) atomicOr(&counters[6], 2ull);
-  if (total > 0 && !slotOverflow) {
-    const unsigned long long base = atomicAdd(&counters[4], (unsigned long long)total);
-    if (base + total > l2Cap) { atomicOr(&counters[5], 1ull); return; }
+  // one reservation per wave (64 candidates): exclusive scan of the lanes' counts, lane 63 of the active lanes asks
+  int incl = total;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(incl, o); if (lane >= o) incl += y; }
+  const uint64_t activeMask = __ballot(1);
+  const int lastLane = 63 - __builtin_clzll(activeMask);
+  const int waveTotal = __shfl(incl, lastLane);
+  unsigned long long wbase = 0;
+  if (lane == lastLane && waveTotal > 0) wbase = atomicAdd(&counters[4], (unsigned long long)waveTotal);
+  wbase = ((unsigned long long)(uint32_t)__shfl((int)(wbase >> 32), lastLane) << 32) | (uint32_t)__shfl((int)(uint32_t)wbase, lastLane);
+  if (waveTotal > 0 && wbase + (unsigned long long)waveTotal > l2Cap) { if (lane == lastLane) atomicOr(&counters[5], 1ull); return; }
+  if (total > 0) {
+    const unsigned long long base = wbase + (unsigned long long)(incl - total);
     const int candLocal = (int)(cIdx - l1Off[f]);
     for (int k = 0; k < total; k++) {
       const L2Tmp t = (k < nFlushed) ? mySlots[k] : pend;

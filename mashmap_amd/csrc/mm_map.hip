@@ -66,6 +66,14 @@ int mm_build_device_index(mm_ctx* c, const int32_t* contigLen, const int32_t* re
     while (hs[2 * slot] != MM_EMPTY) { if (hs[2 * slot] == key) { c->err = "mm_index_upload: duplicate key"; return MM_ERR_ARG; } slot = (slot + 1) & (cap - 1); }
     hs[2 * slot] = key; hs[2 * slot + 1] = (off << 24) | (cnt << 1) | (freq ? 1ull : 0ull);
   }
+  // presence filter in front of the table: one bit per key at (key >> 32) mod bits, >= 16 bits per key while that stays
+  // cache-sized (<= 64 MiB, Infinity Cache / L2 resident); most query seeds are absent from the index (sequencing errors),
+  // and an absent seed then costs a cached bit test instead of a random HBM sector.  Disabled (mask 0) for larger indexes.
+  uint64_t fbits = 1024; while (fbits < 16 * (uint64_t)nk) fbits <<= 1;
+  if (const char* e = getenv("MM_FILTER_BITS_PER_KEY")) { const uint64_t b = strtoull(e, nullptr, 10); fbits = 1024; while (b && fbits < b * (uint64_t)nk) fbits <<= 1; if (!b) fbits = 0; }
+  if (fbits / 8 > (64ull << 20)) fbits = 0;
+  std::vector<uint32_t> flt(fbits ? fbits / 32 : 1, 0u);
+  if (fbits) for (size_t i = 0; i < nk; i++) { const uint64_t b = (c->hKeys[i] >> 32) & (fbits - 1); flt[b >> 5] |= 1u << (b & 31); }
   std::vector<uint64_t> pk(np);
   for (size_t i = 0; i < np; i++) pk[i] = pack_point(c->hPoints[i].seqId, c->hPoints[i].pos, c->hPoints[i].side);
   std::vector<int32_t> grp(nContigs, 0);
@@ -73,7 +81,9 @@ int mm_build_device_index(mm_ctx* c, const int32_t* contigLen, const int32_t* re
 
   MM_HIP(c, I.recH.ensure(n * 8 + 64)); MM_HIP(c, I.recW.ensure(n * 8 + 64)); MM_HIP(c, I.recEh.ensure(n * 8 + 64)); MM_HIP(c, I.recEw.ensure(n * 4 + 64));
   MM_HIP(c, I.contigOff.ensure((nContigs + 1) * 8)); MM_HIP(c, I.contigLen.ensure(nContigs * 4)); MM_HIP(c, I.refGroup.ensure(nContigs * 4));
-  MM_HIP(c, I.htSlots.ensure(cap * 16)); MM_HIP(c, I.ptKeys.ensure(np * 8 + 64));
+  MM_HIP(c, I.htSlots.ensure(cap * 16)); MM_HIP(c, I.ptKeys.ensure(np * 8 + 64)); MM_HIP(c, I.filter.ensure(flt.size() * 4));
+  MM_HIP(c, hipMemcpyAsync(I.filter.p, flt.data(), flt.size() * 4, hipMemcpyHostToDevice, c->stream));
+  I.filterMask = fbits ? fbits - 1 : 0;
   if (n) { MM_HIP(c, hipMemcpyAsync(I.recH.p, rh.data(), n * 8, hipMemcpyHostToDevice, c->stream));
            MM_HIP(c, hipMemcpyAsync(I.recW.p, rw.data(), n * 8, hipMemcpyHostToDevice, c->stream));
            MM_HIP(c, hipMemcpyAsync(I.recEh.p, reh.data(), n * 8, hipMemcpyHostToDevice, c->stream));
@@ -304,10 +314,11 @@ __device__ __forceinline__ int mm_l1_fused(uint64_t (&k)[R], FuseScratch& sc, in
 //   * otherwise (many points, -Y groups, a position group spanning contigs, or keepPoints for the parity API): reserves
 //     slots in the global point buffer, gathers there and queues the fragment for k_sort_points_* + k_l1_sweep.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
+#define MM_LOOKUP_WPB 16            // waves (= fragments) per workgroup: one L1-cursor atomic per workgroup, not per fragment
+__global__ void __launch_bounds__(MM_LOOKUP_WPB * 64)
 k_lookup_l1(int nFrags, int s, const DFrag* __restrict__ frags,
             const uint64_t* __restrict__ skHash, const int8_t* __restrict__ skStrand, const uint32_t* __restrict__ skCount,
-            const HtSlot* __restrict__ ht, uint64_t htMask,
+            const HtSlot* __restrict__ ht, uint64_t htMask, const uint32_t* __restrict__ filter, uint64_t filterMask,
             const uint64_t* __restrict__ ptKeys, const int32_t* __restrict__ refGroup,
             const int32_t* __restrict__ readGroup, const int32_t* __restrict__ readSelf, int seqCounterBase, MapFlags fl, int keepPoints,
             uint64_t* __restrict__ qHash, int8_t* __restrict__ qStrand, uint64_t* __restrict__ seedVal,
@@ -315,46 +326,93 @@ k_lookup_l1(int nFrags, int s, const DFrag* __restrict__ frags,
             const int32_t* __restrict__ minHitsTab, const int32_t* __restrict__ cutoffs, int nCutoffs, int segLength,
             mm_l1_candidate* __restrict__ l1, unsigned long long l1Cap, int64_t* __restrict__ l1Off, int32_t* __restrict__ bigList,
             unsigned long long* __restrict__ counters /* [0] point cursor [1] pts overflow [2] l1 cursor [3] l1 overflow [7] big count */) {
-  __shared__ FuseScratch scratch[4];
-  const int f = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (f >= nFrags) return;
-  FuseScratch& sc = scratch[threadIdx.x >> 6];
+  __shared__ FuseScratch scratch[MM_LOOKUP_WPB];
+  __shared__ int wcnt[MM_LOOKUP_WPB];
+  __shared__ unsigned long long wbase;
+  const int wv = threadIdx.x >> 6;
+  const int f = blockIdx.x * MM_LOOKUP_WPB + wv;
+  const bool live = f < nFrags;
+  FuseScratch& sc = scratch[wv];
   const int lane = (int)mm_lane();
-  const int cnt = (int)skCount[f];
+  int nValid = 0, nOut = -1, outIdx = 0, P = 0, cnt = 0;
+  uint64_t lastHash = 0;
+  if (live) {
+  cnt = (int)skCount[f];
   const size_t fo = (size_t)f * s;
-  int outIdx = 0, P = 0;
-  for (int base = 0; base < cnt; base += 64) {
-    const int r = base + lane;
-    const bool act = r < cnt;
-    uint64_t h = 0, val = 0; bool found = false;
-    if (act) {
-      h = skHash[fo + r];
-      uint64_t slot = h & htMask;
-      while (true) {
-        const HtSlot sl = ht[slot];
-        if (sl.key == h) { found = true; val = sl.val; break; }
-        if (sl.key == MM_EMPTY) break;
-        slot = (slot + 1) & htMask;
-      }
-    }
-    const bool keep = act && !(found && (val & 1ull));
-    const uint64_t m = __ballot(keep);
-    if (keep) {
-      const int idx = outIdx + (int)mm_popc_below(m);
-      qHash[fo + idx] = h; qStrand[fo + idx] = skStrand[fo + r]; seedVal[fo + idx] = found ? val : 0ull;
-    }
-    P += mm_wave_sum(keep && found ? (int)((val >> 1) & 0x7fffffull) : 0);
-    outIdx += __popcll(m);
-  }
-  __threadfence_block();                                           // seedVal is re-read by the gather below
+  // per-read metadata early: nothing below depends on the probes to fetch it
   const int readId = frags[f].readId;
   const int rg = readGroup[readId], self = readSelf[readId], seqCounter = seqCounterBase + readId;
+  lastHash = cnt ? skHash[fo + cnt - 1] : 0ull;
+  // Phase 1: probe.  Four sub-rounds (256 sketch entries) are in flight together: their hash loads, filter tests and first
+  // table slots are independent, so one memory round trip serves all of them instead of four.
+  uint64_t pv[4] = {0, 0, 0, 0};                                   // table value of this lane's kept + found seeds, sub-round u
+  const bool oneBatch = cnt <= 256;
+  for (int base = 0; base < cnt; base += 256) {
+    uint64_t h[4], val[4]; bool act[4], found[4], open[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { const int r = base + u * 64 + lane; act[u] = r < cnt; h[u] = act[u] ? skHash[fo + r] : 0ull; }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      open[u] = act[u];
+      if (filterMask && act[u]) { const uint64_t bb = (h[u] >> 32) & filterMask; open[u] = (filter[bb >> 5] >> (bb & 31)) & 1u; }
+    }
+    HtSlot sl[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { sl[u].key = MM_EMPTY; sl[u].val = 0; if (open[u]) sl[u] = ht[h[u] & htMask]; }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      found[u] = false; val[u] = 0;
+      uint64_t slot = h[u] & htMask;
+      while (open[u]) {                                            // first slot already loaded; further slots are rare (load <= 0.5)
+        if (sl[u].key == h[u]) { found[u] = true; val[u] = sl[u].val; break; }
+        if (sl[u].key == MM_EMPTY) break;
+        slot = (slot + 1) & htMask;
+        sl[u] = ht[slot];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int r = base + u * 64 + lane;
+      const bool keep = act[u] && !(found[u] && (val[u] & 1ull));
+      const uint64_t m = __ballot(keep);
+      if (keep) {
+        const int idx = outIdx + (int)mm_popc_below(m);
+        qHash[fo + idx] = h[u]; qStrand[fo + idx] = skStrand[fo + r]; seedVal[fo + idx] = found[u] ? val[u] : 0ull;
+      }
+      const bool kf = keep && found[u];
+      pv[u] = kf ? val[u] : 0ull;
+      P += mm_wave_sum(kf ? (int)((val[u] >> 1) & 0x7fffffull) : 0);
+      outIdx += __popcll(m);
+    }
+  }
   const int minHits0 = outIdx > 0 ? minHitsTab[outIdx] : 0;
-  int nValid = 0, nOut = -1;
-  if (!keepPoints && !fl.skipPrefix && P <= MM_FUSE_MAXPTS && minHits0 > 0) {
+  if (!keepPoints && !fl.skipPrefix && oneBatch && P <= MM_FUSE_MAXPTS && minHits0 > 0) {
     if (P == 0) nOut = 0;
     else {
-      nValid = mm_gather_points(sc.a, outIdx, seedVal, fo, ptKeys, refGroup, rg, self, seqCounter, fl, lane);
+      // gather straight from the probing lanes' registers (the order of the points is irrelevant: they are sorted next)
+      int done = 0;
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int c = (int)((pv[u] >> 1) & 0x7fffffull);
+        const int my = done + mm_wave_excl_scan(c);
+        const uint64_t src = pv[u] >> 24;
+        uint64_t k0 = MM_EMPTY, k1 = MM_EMPTY;
+        if (c > 0) k0 = ptKeys[src];
+        if (c > 1) k1 = ptKeys[src + 1];
+        auto put = [&](int at, uint64_t key) {
+          const int seqId = (int)(key >> 33);
+          bool drop = false;
+          if (fl.skipSelf && seqId == self) drop = true;
+          if (fl.lowerTri && !(seqCounter > seqId)) drop = true;
+          if (drop) key = MM_EMPTY; else nValid++;
+          sc.a[at] = key;
+        };
+        if (c > 0) put(my, k0);
+        if (c > 1) put(my + 1, k1);
+        for (int j = 2; j < c; j++) put(my + j, ptKeys[src + j]);
+        done += mm_wave_sum(c);
+      }
+      nValid = mm_wave_sum(nValid);
       const int padTo = P <= 64 ? 64 : 128;
       for (int j = P + lane; j < padTo; j += 64) sc.a[j] = MM_EMPTY;
       __threadfence_block();
@@ -369,43 +427,52 @@ k_lookup_l1(int nFrags, int s, const DFrag* __restrict__ frags,
       }
     }
   }
-  mm_frag_stats st;
-  st.rawSketchSize = cnt; st.sketchSize = outIdx; st.maxHash = cnt ? skHash[fo + cnt - 1] : 0ull;
-  if (nOut >= 0) {                                                 // fast path complete: emit the candidates
-    unsigned long long base = 0;
-    if (nOut > 0) {
-      if (lane == 0) base = atomicAdd(&counters[2], (unsigned long long)nOut);
-      base = ((unsigned long long)(uint32_t)__shfl((int)(base >> 32), 0) << 32) | (uint32_t)__shfl((int)(uint32_t)base, 0);
-      if (base + (unsigned long long)nOut > l1Cap) { if (lane == 0) atomicOr(&counters[3], 1ull); nOut = 0; }
-      for (int i = lane; i < nOut; i += 64) {
-        const L1Run x = sc.run[i];
-        mm_l1_candidate o; o.frag = f; o.seqId = x.seq; o.rangeStartPos = x.start; o.rangeEndPos = x.end; o.intersectionSize = x.isize;
-        l1[base + i] = o;
-      }
+  __threadfence_block();                                           // seedVal is re-read by the slow-path gather below
+  if (nOut < 0) {
+    // slow path: points go to HBM, sorted and swept by the follow-up kernels (slots: a power of two above 64 for the sorters)
+    int slots = P;
+    if (P > 64) { slots = 128; while (slots < P) slots <<= 1; }
+    unsigned long long off = 0;
+    if (lane == 0 && slots > 0) off = atomicAdd(&counters[0], (unsigned long long)slots);
+    off = ((unsigned long long)(uint32_t)__shfl((int)(off >> 32), 0) << 32) | (uint32_t)__shfl((int)(uint32_t)off, 0);
+    bool ok = true;
+    if (slots > 0 && off + (unsigned long long)slots > ptsCap) { ok = false; if (lane == 0) atomicOr(&counters[1], 1ull); }
+    nValid = 0;
+    if (ok && slots > 0) {
+      nValid = mm_gather_points(pts + off, outIdx, seedVal, fo, ptKeys, refGroup, rg, self, seqCounter, fl, lane);
+      for (int j = P + lane; j < slots; j += 64) pts[off + j] = MM_EMPTY;
     }
     if (lane == 0) {
-      st.nPoints = nValid; st.nL1 = nOut; stats[f] = st;
+      mm_frag_stats st;
+      st.rawSketchSize = cnt; st.sketchSize = outIdx; st.maxHash = lastHash; st.nPoints = nValid; st.nL1 = 0; stats[f] = st;
+      ptOff[2 * f] = (int64_t)off; ptOff[2 * f + 1] = ok ? (int64_t)slots : 0; l1Off[f] = 0;
+      if (slots > 0 && ok) bigList[atomicAdd(&counters[7], 1ull)] = f;
+    }
+  }
+  }  // live
+  // one reservation of L1 slots for the whole workgroup (a same-address atomic costs ~10 ns on this part: 2 M of them, one per
+  // fragment, were 20 ms of a 25 ms kernel)
+  if (lane == 0) wcnt[wv] = nOut > 0 ? nOut : 0;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int tot = 0;
+    for (int w = 0; w < MM_LOOKUP_WPB; w++) { const int t = wcnt[w]; wcnt[w] = tot; tot += t; }
+    wbase = tot ? atomicAdd(&counters[2], (unsigned long long)tot) : 0ull;
+  }
+  __syncthreads();
+  if (live && nOut >= 0) {                                         // fast path complete: emit the candidates
+    const unsigned long long base = wbase + (unsigned long long)wcnt[wv];
+    if (nOut > 0 && base + (unsigned long long)nOut > l1Cap) { if (lane == 0) atomicOr(&counters[3], 1ull); nOut = 0; }
+    for (int i = lane; i < nOut; i += 64) {
+      const L1Run x = sc.run[i];
+      mm_l1_candidate o; o.frag = f; o.seqId = x.seq; o.rangeStartPos = x.start; o.rangeEndPos = x.end; o.intersectionSize = x.isize;
+      l1[base + i] = o;
+    }
+    if (lane == 0) {
+      mm_frag_stats st;
+      st.rawSketchSize = cnt; st.sketchSize = outIdx; st.maxHash = lastHash; st.nPoints = nValid; st.nL1 = nOut; stats[f] = st;
       ptOff[2 * f] = 0; ptOff[2 * f + 1] = 0; l1Off[f] = (int64_t)base;
     }
-    return;
-  }
-  // slow path: points go to HBM, sorted and swept by the follow-up kernels (slots: a power of two above 64 for the sorters)
-  int slots = P;
-  if (P > 64) { slots = 128; while (slots < P) slots <<= 1; }
-  unsigned long long off = 0;
-  if (lane == 0 && slots > 0) off = atomicAdd(&counters[0], (unsigned long long)slots);
-  off = ((unsigned long long)(uint32_t)__shfl((int)(off >> 32), 0) << 32) | (uint32_t)__shfl((int)(uint32_t)off, 0);
-  bool ok = true;
-  if (slots > 0 && off + (unsigned long long)slots > ptsCap) { ok = false; if (lane == 0) atomicOr(&counters[1], 1ull); }
-  nValid = 0;
-  if (ok && slots > 0) {
-    nValid = mm_gather_points(pts + off, outIdx, seedVal, fo, ptKeys, refGroup, rg, self, seqCounter, fl, lane);
-    for (int j = P + lane; j < slots; j += 64) pts[off + j] = MM_EMPTY;
-  }
-  if (lane == 0) {
-    st.nPoints = nValid; st.nL1 = 0; stats[f] = st;
-    ptOff[2 * f] = (int64_t)off; ptOff[2 * f + 1] = ok ? (int64_t)slots : 0; l1Off[f] = 0;
-    if (slots > 0 && ok) bigList[atomicAdd(&counters[7], 1ull)] = f;
   }
 }
 
@@ -618,9 +685,9 @@ int mm_launch_map(mm_ctx* c) {
     MM_HIP(c, hipMemsetAsync(c->dCounters.p, 0, 256, c->stream));
     {
       KernelTimer t(c, MM_K_LOOKUP);
-      hipLaunchKernelGGL(k_lookup_l1, dim3((nF + 3) / 4), dim3(256), 0, c->stream, nF, s, c->dFrags.as<DFrag>(),
+      hipLaunchKernelGGL(k_lookup_l1, dim3((nF + MM_LOOKUP_WPB - 1) / MM_LOOKUP_WPB), dim3(MM_LOOKUP_WPB * 64), 0, c->stream, nF, s, c->dFrags.as<DFrag>(),
                          c->dSkHash.as<uint64_t>(), c->dSkStrand.as<int8_t>(), c->dSkCount.as<uint32_t>(),
-                         I.htSlots.as<HtSlot>(), (uint64_t)(I.htCap - 1), I.ptKeys.as<uint64_t>(),
+                         I.htSlots.as<HtSlot>(), (uint64_t)(I.htCap - 1), I.filter.as<uint32_t>(), (uint64_t)I.filterMask, I.ptKeys.as<uint64_t>(),
                          I.refGroup.as<int32_t>(), c->dReadGroup.as<int32_t>(), c->dReadSelf.as<int32_t>(), c->seqCounterBase, fl,
                          c->keepPoints ? 1 : 0,
                          c->dQHash.as<uint64_t>(), c->dQStrand.as<int8_t>(), c->dSeedVal.as<uint64_t>(), c->dStats.as<mm_frag_stats>(),

@@ -99,7 +99,7 @@ k_sketch_fragments(const uint32_t* __restrict__ bases2, const uint32_t* __restri
   const int nM = (len + 31) / 32 + 2;
   size_t off = 0;
   MMTables* tabs = (MMTables*)(smem + off); off += sizeof(MMTables);
-  if (MMFastK<K>::value) mm_tables_init<K>(*tabs, tid, nthr);    // made visible by the first __syncthreads() below
+  mm_tables_init<K>(*tabs, tid, nthr);                           // made visible by the first __syncthreads() below
   uint32_t* sW = (uint32_t*)(smem + off); off += (((size_t)nW * 4 + 15) / 16) * 16;
   uint32_t* sM = (uint32_t*)(smem + off); off += (((size_t)nM * 4 + 15) / 16) * 16;
   uint64_t* arrA = (uint64_t*)(smem + off); off += (size_t)HT * 8;     // queue hashes, later sort keys
