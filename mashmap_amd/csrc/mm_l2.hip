@@ -256,40 +256,38 @@ k_l2_sweep(int nCand, int segLength, const mm_l1_candidate* __restrict__ l1, con
   int pivot = S, pivRank = S, shared = 0, votes = 0;
   bool doubleOpen = false;
 
-  auto insert = [&](uint32_t op) {                     // slidingMap.hpp:125-165
-    const int j = OP_J(op);
-    if (j == 0) return;
-    uint32_t cw = CELL(j);
-    if (OP_MATCH(op)) {
-      const int v = OP_QS(op) * OP_RSTRAND(op);        // a query hash has one open reference window at a time (windowLen == 0);
-      if (CELL_ACT(cw)) doubleOpen = true;             // the 2-bit vote relies on it, so a violation is reported, not absorbed
-      cw = (cw & 0xFFFu) | (1u << 12) | ((uint32_t)(v + 1) << 13);
-      CELL(j) = (uint16_t)cw;
-      if (j <= pivot) { shared++; votes += v; }
-    } else {
-      CELL(j) = (uint16_t)(cw + 1u);
-      if (j <= pivot) pivRank++;
-      if (pivRank > S) {
-        const uint32_t pw = (pivot == j) ? cw + 1u : (uint32_t)CELL(pivot);
-        shared -= CELL_ACT(pw); votes -= CELL_ACT(pw) ? CELL_VOTE(pw) : 0; pivRank -= CELL_CNT(pw); pivot--;
-      }
-    }
-  };
-  auto remove = [&](uint32_t op) {                     // slidingMap.hpp:171-211
-    const int j = OP_J(op);
-    if (j == 0) return;
-    const uint32_t cw = CELL(j);
-    if (OP_MATCH(op)) {
-      if (j <= pivot) { shared--; votes -= CELL_VOTE(cw); }
-      CELL(j) = (uint16_t)((cw & 0xFFFu) | (1u << 13));
-    } else {
-      CELL(j) = (uint16_t)(cw - 1u);
-      if (j <= pivot) pivRank--;
-      if (pivot + 1 <= S) {
-        const uint32_t nw = (pivot + 1 == j) ? cw - 1u : (uint32_t)CELL(pivot + 1);
-        if (pivRank + CELL_CNT(nw) <= S) { pivot++; shared += CELL_ACT(nw); votes += CELL_ACT(nw) ? CELL_VOTE(nw) : 0; pivRank += CELL_CNT(nw); }
-      }
-    }
+  // SlideMapper::insert_minmer / delete_minmer (slidingMap.hpp:125-211) as straight-line code: the four cases (insert or
+  // delete x hash matches a query hash or not) are selected arithmetically, because the 64 lanes of a wave are at different
+  // candidates and take different cases at every entry -- as branches they serialise (measured 5x slower).  The cell of the
+  // hash, of the pivot and of its right neighbour are read up front, independent of the case.
+  auto apply = [&](uint32_t op, bool isIns) {
+    const int j = OP_J(op);                            // 0: hash beyond the query sketch -> no effect (cell 0 is a dummy)
+    const bool valid = j != 0, match = OP_MATCH(op) != 0;
+    const int pn = pivot + 1 <= S ? pivot + 1 : S;
+    const uint32_t cw = CELL(j), pw = CELL(pivot), nw = CELL(pn);
+    const int v = OP_QS(op) * OP_RSTRAND(op);          // a query hash has one open reference window at a time (windowLen == 0);
+    const bool IM = valid & isIns & match, IN = valid & isIns & !match, DM = valid & !isIns & match, DN = valid & !isIns & !match;
+    doubleOpen |= IM & (CELL_ACT(cw) != 0);            // the 2-bit vote relies on it, so a violation is reported, not absorbed
+    uint32_t ncw = cw;
+    ncw = IM ? ((cw & 0xFFFu) | (1u << 12) | ((uint32_t)(v + 1) << 13)) : ncw;
+    ncw = IN ? cw + 1u : ncw;
+    ncw = DM ? ((cw & 0xFFFu) | (1u << 13)) : ncw;
+    ncw = DN ? cw - 1u : ncw;
+    CELL(j) = (uint16_t)ncw;
+    const int ip = j <= pivot ? 1 : 0;
+    shared += (IM ? ip : 0) - (DM ? ip : 0);
+    votes += ((IM & (ip != 0)) ? v : 0) - ((DM & (ip != 0)) ? CELL_VOTE(cw) : 0);
+    pivRank += (IN ? ip : 0) - (DN ? ip : 0);
+    // insert of a non-shared hash can push the pivot one cell left (:155-160)
+    const uint32_t pwp = (pivot == j) ? ncw : pw;
+    const bool left = IN & (pivRank > S);
+    // delete of a non-shared hash can let it move one cell right (:201-207)
+    const uint32_t nwp = (pn == j) ? ncw : nw;
+    const bool right = DN & (pivot + 1 <= S) & (pivRank + CELL_CNT(nwp) <= S);
+    shared += (right ? CELL_ACT(nwp) : 0) - (left ? CELL_ACT(pwp) : 0);
+    votes += (right ? CELL_VOTE(nwp) : 0) - (left ? CELL_VOTE(pwp) : 0);
+    pivRank += (right ? CELL_CNT(nwp) : 0) - (left ? CELL_CNT(pwp) : 0);
+    pivot += (right ? 1 : 0) - (left ? 1 : 0);
   };
 
   // best-position bookkeeping (:1376-1449)
@@ -340,15 +338,14 @@ k_l2_sweep(int nCand, int segLength, const mm_l1_candidate* __restrict__ l1, con
       const int wpos = (int)((k & 1) ? cur[k >> 1].w : cur[k >> 1].y);
       if (done) continue;
       const uint32_t type = OP_TYPE(lo);
-      if (type == E_DEL) remove(lo);
-      else if (type == E_PRE) { insert(lo); lastVotes = votes; }
-      else {
+      if (type == E_INS || type == E_END) {
         if (evalPending) { evaluate(wpos); evalPending = false; }
         if (type == E_END) { done = true; continue; }
-        evPrevVotes = lastVotes;
-        insert(lo);
-        evW = wpos; evShared = shared; lastVotes = votes; evalPending = true;
       }
+      evPrevVotes = (type == E_INS) ? lastVotes : evPrevVotes;
+      apply(lo, type != E_DEL);
+      lastVotes = (type != E_DEL) ? votes : lastVotes;
+      if (type == E_INS) { evW = wpos; evShared = shared; evalPending = true; }
     }
 #pragma unroll
     for (int k = 0; k < 4; k++) cur[k] = nxt[k];
@@ -426,7 +423,7 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt) {
                        c->dL2Info.as<L2Info>(), c->dL2Off.as<int64_t>(), c->dL2Ops.as<uint64_t>());
     MM_HIP(c, hipGetLastError());
   }
-  const size_t ldsL2 = (size_t)(s + 1) * 64 * 2;
+  const size_t ldsL2 = (size_t)(s + 1) * 64 * 2;          // cells 0..S
   if (ldsL2 > 160 * 1024) { c->err = "sketchSize too large for the LDS-resident L2 state"; return MM_ERR_ARG; }
   MM_HIP(c, hipFuncSetAttribute((const void*)k_l2_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsL2));
   if (c->l2Cap < c->nL1 * 2 + 1024) c->l2Cap = c->nL1 * 2 + 1024;
