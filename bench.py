@@ -172,7 +172,7 @@ def main():
     t0 = time.time()
     ctx.index_build(ref_np, kmerPct=0.001)
     ctx.set_tables_default(PI)
-    log("[rank %d] index build (device hash + host winnow): %.1f s" % (rank, time.time() - t0))
+    log("[rank %d] index build (device hash + winnow, host stitch + lookup map): %.1f s" % (rank, time.time() - t0))
     offs = np.arange(args.reads + 1, dtype=np.int64) * READ_LEN
     nF = ctx.reads_upload_device(reads_t.data_ptr(), reads_t.numel(), offs)
     reads_np = reads_t[:min(args.reads, args.cpu_sample) * READ_LEN].cpu().numpy() if rank == 0 else None

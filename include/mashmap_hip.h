@@ -191,7 +191,7 @@ int mm_index_download(mm_ctx* ctx, mm_minmer* minmers, uint64_t* keys, uint64_t*
                       uint64_t* freqSeeds);
 
 /* per-kernel device timing, measured with hipEvents on the ctx stream (bench.py roofline leg) */
-enum { MM_K_PACK = 0, MM_K_SKETCH, MM_K_SKETCH_HARD, MM_K_LOOKUP, MM_K_SORT, MM_K_L1, MM_K_L2, MM_K_REFHASH, MM_K_L2_LOCATE, MM_K_COUNT };
+enum { MM_K_PACK = 0, MM_K_SKETCH, MM_K_SKETCH_HARD, MM_K_LOOKUP, MM_K_SORT, MM_K_L1, MM_K_L2, MM_K_REFHASH, MM_K_L2_LOCATE, MM_K_WINNOW, MM_K_COUNT };
 int mm_profile_enable(mm_ctx* ctx, int on);
 /* ms[i] = accumulated milliseconds, launches[i] = launch count since the last reset */
 int mm_profile_read(mm_ctx* ctx, double* ms, uint64_t* launches, int reset);

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libmashmap_hip.so")
 
 MM_FLAG_HG_FILTER, MM_FLAG_SKIP_SELF, MM_FLAG_SKIP_PREFIX, MM_FLAG_LOWER_TRIANGULAR, MM_FLAG_NO_SPLIT = 1, 2, 4, 8, 16
-KERNELS = ["pack", "sketch", "sketch_hard", "lookup", "sort", "l1", "l2", "refhash", "l2_locate"]
+KERNELS = ["pack", "sketch", "sketch_hard", "lookup", "sort", "l1", "l2", "refhash", "l2_locate", "winnow"]
 
 
 class LibraryMissing(RuntimeError):

@@ -1,15 +1,16 @@
 // mashmap_amd/csrc/mm_index.hip -- reference-side index construction (mm_index_build).
 //
 //   k_ref_hash        both-strand MurmurHash3 of every reference k-mer        commonFunc.hpp:357-373
-//   winnow_contig     sliding bottom-s "minmer" intervals of one contig       commonFunc.hpp:302-570
+//   (mm_winnow.hip)   sliding bottom-s "minmer" intervals of one contig       commonFunc.hpp:302-521
+//   finish_contig     tail of addMinmers: drop empty runs, chunk, sort, unique commonFunc.hpp:523-568
 //   build_lookup      Sketch::index                                           winSketch.hpp:379-404
 //   frequency_filter  computeFreqHist / computeFreqSeedSet / dropFreqSeedSet  winSketch.hpp:410-504
 //
-// ROUND-1 STATUS: the hashing (all the integer-multiply work, ~95 % of the CPU cost of addMinmers)
-// runs on the device; the sliding-window bookkeeping that turns hashes into intervals still runs on
-// host threads inside this library and is the next kernel to move.
+// Hashing and winnowing run on the device; the host stitches the tiles' open runs together and applies the reference's own
+// tail (std::sort + std::unique on the emission order, which is what fixes the order of ties) and Sketch::index.
 #include "mm_internal.h"
 #include "mm_device.h"
+#include "mm_winnow.h"
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -78,74 +79,33 @@ static uint64_t host_murmur(const unsigned char* p, int len) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// host: hashes -> minmer intervals of one contig.  Event order per window W (= i + k - w for the
-// arriving k-mer i) follows the reference: departure of k-mer W-1, arrival of k-mer i, then
-// eviction / refill so that the sketch holds the s smallest distinct hashes of window W.
+// host: the device's records of one contig (reference emission order; runs that were open at a tile boundary still carry
+// WN_CARRY as their start) -> the contig's slice of minmerIndex.  Stitching, then the literal tail of addMinmers
+// (commonFunc.hpp:523-568): drop empty / negative runs, FWD for a zero strand sum, split runs longer than w, std::sort by
+// (wpos, wpos_end), std::unique on (wpos, hash).
 // ---------------------------------------------------------------------------------------------
-namespace {
-struct Pend { uint64_t h; int32_t pos; int8_t st; };
-struct PendWorse { bool operator()(const Pend& a, const Pend& b) const { return a.h != b.h ? a.h > b.h : a.pos > b.pos; } };
-struct Member { int32_t start; int32_t sum; std::deque<std::pair<int32_t, int8_t>> occ; };
-}
-
-static void winnow_contig(const uint64_t* H, const int8_t* ST, int64_t nPos, int len, int k, int w, int s, int seqId,
-                          std::vector<mm_minmer>& out) {
-  out.clear();
-  std::map<uint64_t, Member> sk;
-  std::vector<Pend> heap; PendWorse worse;
-  auto emit = [&](uint64_t h, const Member& m, int32_t end) { out.push_back(mm_minmer{h, m.start, end, seqId, (int16_t)m.sum, 0}); };
-  for (int64_t i = 0; i < nPos; i++) {
-    const int32_t W = (int32_t)(i + k - w);
-    if ((int64_t)heap.size() > 2 * (int64_t)w) {
-      heap.erase(std::remove_if(heap.begin(), heap.end(), [W](const Pend& p) { return p.pos < W; }), heap.end());
-      std::make_heap(heap.begin(), heap.end(), worse);
-    }
-    if (W >= 1 && H[W - 1] != MM_HASH_MAX && !sk.empty()) {            // departure
-      const uint64_t g = H[W - 1];
-      if (g <= std::prev(sk.end())->first) {
-        auto it = sk.find(g);
-        Member& m = it->second;
-        if (m.occ.size() == 1) { emit(g, m, W); sk.erase(it); }
-        else {
-          const int st = ST[W - 1];
-          if (m.sum - st == 0 || m.sum == 0) { emit(g, m, W); m.start = W; }
-          m.sum -= st; m.occ.pop_front();
-        }
+static void finish_contig(std::vector<mm_minmer>& out, const std::vector<int32_t>& tileCount, const std::vector<WnOpenRun>& openRuns,
+                          const std::vector<int32_t>& openCount, int s, int w, int seqId) {
+  {
+    std::vector<std::pair<uint64_t, int32_t>> prev, cur;                 // (hash, resolved start) of the runs open at the last boundary
+    auto lookup = [&prev](uint64_t h) {
+      auto it = std::lower_bound(prev.begin(), prev.end(), std::make_pair(h, (int32_t)0x80000000));
+      return (it != prev.end() && it->first == h) ? it->second : (int32_t)0;   // always found: both tiles hold the sketch of that window
+    };
+    size_t off = 0;
+    for (size_t t = 0; t < tileCount.size(); t++) {
+      for (size_t i = off; i < off + (size_t)tileCount[t]; i++) if (out[i].wpos == WN_CARRY) out[i].wpos = lookup(out[i].hash);
+      off += (size_t)tileCount[t];
+      cur.clear();
+      for (int j = 0; j < openCount[t]; j++) {
+        const WnOpenRun& o = openRuns[t * (size_t)s + j];
+        cur.emplace_back(o.hash, o.start == WN_CARRY ? lookup(o.hash) : o.start);
       }
-    }
-    const uint64_t h = H[i];
-    if (h != MM_HASH_MAX) {                                              // arrival
-      const int st = ST[i];
-      auto it = sk.find(h);
-      if (it != sk.end()) {
-        Member& m = it->second;
-        m.occ.emplace_back((int32_t)i, (int8_t)st);
-        if (m.sum + st == 0 || m.sum == 0) { emit(h, m, W); m.start = W; }
-        m.sum += st;
-      } else { heap.push_back(Pend{h, (int32_t)i, (int8_t)st}); std::push_heap(heap.begin(), heap.end(), worse); }
-    }
-    if (W >= 0) {                                                        // eviction / refill
-      while (!heap.empty() && heap.front().pos < W) { std::pop_heap(heap.begin(), heap.end(), worse); heap.pop_back(); }
-      if (!sk.empty() && !heap.empty() && (int)sk.size() == s && heap.front().h < std::prev(sk.end())->first) {
-        auto last = std::prev(sk.end());
-        emit(last->first, last->second, W);
-        for (auto& o : last->second.occ) if (o.first > W) { heap.push_back(Pend{last->first, o.first, o.second}); std::push_heap(heap.begin(), heap.end(), worse); }
-        sk.erase(last);
-      }
-      while (!heap.empty() && (int)sk.size() < s) {
-        while (!heap.empty() && heap.front().pos < W) { std::pop_heap(heap.begin(), heap.end(), worse); heap.pop_back(); }
-        if (heap.empty()) break;
-        const uint64_t nh = heap.front().h;
-        Member& m = sk[nh];
-        m.start = W; m.sum = 0; m.occ.clear();
-        while (!heap.empty() && heap.front().h == nh) {
-          m.occ.emplace_back(heap.front().pos, heap.front().st); m.sum += heap.front().st;
-          std::pop_heap(heap.begin(), heap.end(), worse); heap.pop_back();
-        }
-      }
+      std::sort(cur.begin(), cur.end());
+      prev.swap(cur);
     }
   }
-  { int rank = 1; for (auto it = sk.begin(); it != sk.end() && rank <= s; ++it, ++rank) emit(it->first, it->second, len - k + 1); }
+  for (auto& m : out) m.seqId = seqId;
   out.erase(std::remove_if(out.begin(), out.end(), [](const mm_minmer& m) { return m.wpos < 0 || m.wpos_end < 0 || m.wpos == m.wpos_end; }), out.end());
   std::vector<mm_minmer> pieces;
   for (auto& m : out) {
@@ -163,8 +123,7 @@ static void winnow_contig(const uint64_t* H, const int8_t* ST, int64_t nPos, int
 
 // ---------------------------------------------------------------------------------------------
 template <int K>
-static int hash_contig(mm_ctx* c, const char* seq, int len, DevBuf& dAscii, DevBuf& dB, DevBuf& dM, DevBuf& dMeta, DevBuf& dH, DevBuf& dS,
-                       std::vector<uint64_t>& H, std::vector<int8_t>& S) {
+static int hash_contig(mm_ctx* c, const char* seq, int len, DevBuf& dAscii, DevBuf& dB, DevBuf& dM, DevBuf& dMeta, DevBuf& dH, DevBuf& dS) {
   const int64_t nPos = (int64_t)len - K + 1;
   const int64_t packed = ((int64_t)len + 31) / 32 * 32;
   MM_HIP(c, dAscii.ensure((size_t)len + 64)); MM_HIP(c, dB.ensure((size_t)packed / 4 + 64)); MM_HIP(c, dM.ensure((size_t)packed / 8 + 64));
@@ -194,12 +153,9 @@ static int hash_contig(mm_ctx* c, const char* seq, int len, DevBuf& dAscii, DevB
                        dH.as<uint64_t>(), dS.as<int8_t>());
     MM_HIP(c, hipGetLastError());
   }
-  H.resize((size_t)nPos); S.resize((size_t)nPos);
-  MM_HIP(c, hipMemcpyAsync(H.data(), dH.p, (size_t)nPos * 8, hipMemcpyDeviceToHost, c->stream));
-  MM_HIP(c, hipMemcpyAsync(S.data(), dS.p, (size_t)nPos, hipMemcpyDeviceToHost, c->stream));
-  MM_HIP(c, hipStreamSynchronize(c->stream));
   // leading k-mers with an unnoticed N (see host_murmur): an N at position p < K-1 never starts the reference's
   // ambiguity countdown, so k-mers i <= p that have no N at a position >= K-1 are hashed with the 'N' byte in place.
+  // At most K-1 values per contig: computed here and patched into the device arrays.
   if (hasN) {
     std::vector<unsigned char> norm((size_t)std::min<int64_t>(len, 2 * K));
     for (size_t j = 0; j < norm.size(); j++) {
@@ -213,14 +169,17 @@ static int hash_contig(mm_ctx* c, const char* seq, int len, DevBuf& dAscii, DevB
         unsigned char rc[64];
         for (int p = 0; p < K; p++) { unsigned char ch = norm[i + p]; rc[K - 1 - p] = ch == 'A' ? 'T' : ch == 'C' ? 'G' : ch == 'G' ? 'C' : ch == 'T' ? 'A' : ch; }
         const uint64_t f = host_murmur(&norm[i], K), b = host_murmur(rc, K);
-        H[i] = f == b ? MM_HASH_MAX : std::min(f, b); S[i] = f < b ? 1 : -1;
+        const uint64_t hv = f == b ? MM_HASH_MAX : std::min(f, b); const int8_t sv = f < b ? 1 : -1;
+        MM_HIP(c, hipMemcpyAsync((uint64_t*)dH.p + i, &hv, 8, hipMemcpyHostToDevice, c->stream));
+        MM_HIP(c, hipMemcpyAsync((int8_t*)dS.p + i, &sv, 1, hipMemcpyHostToDevice, c->stream));
+        MM_HIP(c, hipStreamSynchronize(c->stream));
       }
     }
   }
   return MM_OK;
 }
 
-typedef int (*HashContigFn)(mm_ctx*, const char*, int, DevBuf&, DevBuf&, DevBuf&, DevBuf&, DevBuf&, DevBuf&, std::vector<uint64_t>&, std::vector<int8_t>&);
+typedef int (*HashContigFn)(mm_ctx*, const char*, int, DevBuf&, DevBuf&, DevBuf&, DevBuf&, DevBuf&, DevBuf&);
 static HashContigFn pick_hasher(int k) {
   switch (k) {
 #define MM_CASE(KK) case KK: return &hash_contig<KK>;
@@ -242,6 +201,7 @@ extern "C" int mm_index_build(mm_ctx* c, const char* bases, const int64_t* conti
   std::vector<std::vector<mm_minmer>> per(nContigs);
   std::deque<std::future<void>> inflight;
   DevBuf dAscii, dB, dM, dMeta, dH, dS;
+  WinnowBuffers wb;
   int rc = MM_OK;
   const unsigned maxJobs = std::max(1u, std::thread::hardware_concurrency());
   for (size_t ci = 0; ci < nContigs && rc == MM_OK; ci++) {
@@ -249,17 +209,21 @@ extern "C" int mm_index_build(mm_ctx* c, const char* bases, const int64_t* conti
     if (len64 < 0 || len64 > 0x7fffffff) { c->err = "mm_index_build: contig longer than int32 (offset_t)"; rc = MM_ERR_ARG; break; }
     const int len = (int)len64; clen[ci] = len;
     if (len < k || len < w) continue;            // winSketch.hpp:194; contigs shorter than a window yield no minmers
-    auto H = std::make_shared<std::vector<uint64_t>>(); auto S = std::make_shared<std::vector<int8_t>>();
-    rc = hasher(c, bases + contigOffsets[ci], len, dAscii, dB, dM, dMeta, dH, dS, *H, *S);
+    rc = hasher(c, bases + contigOffsets[ci], len, dAscii, dB, dM, dMeta, dH, dS);
+    if (rc != MM_OK) break;
+    auto rec = std::make_shared<std::vector<mm_minmer>>(); auto tc = std::make_shared<std::vector<int32_t>>();
+    auto runs = std::make_shared<std::vector<WnOpenRun>>(); auto oc = std::make_shared<std::vector<int32_t>>();
+    rc = mm_winnow_contig_device(c, wb, dH.as<uint64_t>(), dS.as<int8_t>(), (int64_t)len - k + 1, len, *rec, *tc, *runs, *oc);
     if (rc != MM_OK) break;
     while (inflight.size() >= maxJobs) { inflight.front().get(); inflight.pop_front(); }
     std::vector<mm_minmer>* dst = &per[ci];
-    inflight.push_back(std::async(std::launch::async, [H, S, len, k, w, s, ci, dst]() {
-      winnow_contig(H->data(), S->data(), (int64_t)H->size(), len, k, w, s, (int)ci, *dst);
+    inflight.push_back(std::async(std::launch::async, [rec, tc, runs, oc, w, s, ci, dst]() {
+      finish_contig(*rec, *tc, *runs, *oc, s, w, (int)ci);
+      dst->swap(*rec);
     }));
   }
   while (!inflight.empty()) { inflight.front().get(); inflight.pop_front(); }
-  dAscii.release(); dB.release(); dM.release(); dMeta.release(); dH.release(); dS.release();
+  dAscii.release(); dB.release(); dM.release(); dMeta.release(); dH.release(); dS.release(); wb.release();
   if (rc != MM_OK) return rc;
 
   // Sketch::index (winSketch.hpp:379-404): per-hash OPEN/CLOSE points in minmerIndex order, adjacent runs merged

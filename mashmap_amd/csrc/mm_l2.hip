@@ -380,7 +380,7 @@ k_l2_sweep(int nCand, int segLength, const mm_l1_candidate* __restrict__ l1, con
 }
 
 // ---------------------------------------------------------------------------------------------
-static int scan_i32_to_i64(mm_ctx* c, int64_t n, const int32_t* dIn, int64_t* dOut, int64_t* total) {
+int mm_scan_i32_to_i64(mm_ctx* c, int64_t n, const int32_t* dIn, int64_t* dOut, int64_t* total) {
   const int64_t nTiles = (n + SCAN_TILE - 1) / SCAN_TILE;
   MM_HIP(c, c->dScanTmp.ensure((size_t)(nTiles + 2) * 8));
   int64_t* tileSum = c->dScanTmp.as<int64_t>();
@@ -407,7 +407,7 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt) {
     hipLaunchKernelGGL(k_l2_extents, dim3((nC + 255) / 256), dim3(256), 0, c->stream, nC, c->P.segLength, c->dL1.as<mm_l1_candidate>(),
                        I.recW.as<int2>(), I.recEw.as<int32_t>(), I.contigOff.as<int64_t>(), c->dL2Info.as<L2Info>(), c->dL2Cnt.as<int32_t>());
     MM_HIP(c, hipGetLastError());
-    int rc = scan_i32_to_i64(c, nC, c->dL2Cnt.as<int32_t>(), c->dL2Off.as<int64_t>(), &totalOps);
+    int rc = mm_scan_i32_to_i64(c, nC, c->dL2Cnt.as<int32_t>(), c->dL2Off.as<int64_t>(), &totalOps);
     if (rc != MM_OK) return rc;
     MM_HIP(c, c->dL2Ops.ensure((size_t)totalOps * 8 + 256));
     // LDS for the two position arrays of a candidate: ~4x the sketch size covers the typical candidate (2 records per

@@ -1,0 +1,432 @@
+// mashmap_amd/csrc/mm_winnow.hip -- CommonFunc::addMinmers on the device (src/map/include/commonFunc.hpp:302-570):
+// the sliding bottom-s "minmer" intervals of one reference contig, from the per-position canonical hashes that
+// k_ref_hash (mm_index.hip) leaves in HBM.
+//
+// The reference slides a window of w - k + 1 k-mer positions one base at a time and keeps the s smallest distinct hashes
+// of the window in a std::map (the sketch), everything else in a heap.  A record [wpos, wpos_end) is emitted whenever a hash
+// stops being in the sketch or the sign of its strand sum passes through zero.  Two observations make this parallel:
+//   * only k-mers whose hash is below a small cut (2.5x the expected s-th smallest of a window, ~6 % of the positions) can ever
+//     be in a sketch: the contig is first compacted to that candidate list (k_cand_count / k_cand_write);
+//   * the state at a window W0 (sketch members and their strand sums) is a function of that window alone, so the contig is cut
+//     into tiles of TW windows that are simulated independently -- one wavefront per tile, cold-started at its first window,
+//     stepping only through the windows at which a candidate arrives or departs (k_winnow_tiles).  Runs that were open when
+//     the tile started get their true start from the previous tile's open list afterwards (stitching, host).
+// The simulation keeps the reference's event order inside a window step -- departure of k-mer W-1 (:376-410), arrival of
+// k-mer W+w-k (:412-438), eviction / refill (:440-505) -- so records come out in the reference's emission order, which is what
+// makes the final std::sort (:558) reproduce its tie order.
+// A tile whose candidate list cannot fill the sketch (fewer than s distinct candidates in some window: N-rich or low-complexity
+// sequence) is re-run in DENSE mode, where every valid k-mer position is a candidate.
+#include "mm_internal.h"
+#include "mm_device.h"
+#include "mm_winnow.h"
+#include <algorithm>
+
+#define WN_NONE 0xFFFFFFFFFFFFFFFFULL
+
+// ---------------------------------------------------------------------------------------------
+// candidate compaction: positions with H <= cap, in position order (block = 256 threads x 8 positions)
+// ---------------------------------------------------------------------------------------------
+#define CAND_ITEMS 8
+#define CAND_TILE (256 * CAND_ITEMS)
+__global__ void __launch_bounds__(256)
+k_cand_count(const uint64_t* __restrict__ H, int64_t nPos, uint64_t cap, int32_t* __restrict__ blockCnt) {
+  __shared__ int sm[4];
+  const int64_t base = (int64_t)blockIdx.x * CAND_TILE + (int64_t)threadIdx.x * CAND_ITEMS;
+  int c = 0;
+#pragma unroll
+  for (int i = 0; i < CAND_ITEMS; i++) if (base + i < nPos && H[base + i] <= cap) c++;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) blockCnt[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+__global__ void __launch_bounds__(256)
+k_cand_write(const uint64_t* __restrict__ H, const int8_t* __restrict__ ST, int64_t nPos, uint64_t cap, const int64_t* __restrict__ blockOff,
+             int32_t* __restrict__ cPos, uint64_t* __restrict__ cHash, int8_t* __restrict__ cSt) {
+  __shared__ int sm[256];
+  const int64_t base = (int64_t)blockIdx.x * CAND_TILE + (int64_t)threadIdx.x * CAND_ITEMS;
+  uint64_t h[CAND_ITEMS]; int c = 0;
+#pragma unroll
+  for (int i = 0; i < CAND_ITEMS; i++) { h[i] = base + i < nPos ? H[base + i] : WN_NONE; if (h[i] <= cap) c++; }
+  sm[threadIdx.x] = c;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {
+    const int t = (int)threadIdx.x >= o ? sm[threadIdx.x - o] : 0;
+    __syncthreads();
+    sm[threadIdx.x] += t;
+    __syncthreads();
+  }
+  int64_t at = blockOff[blockIdx.x] + sm[threadIdx.x] - c;
+#pragma unroll
+  for (int i = 0; i < CAND_ITEMS; i++)
+    if (h[i] <= cap) { cPos[at] = (int32_t)(base + i); cHash[at] = h[i]; cSt[at] = ST[base + i]; at++; }
+}
+
+// ---------------------------------------------------------------------------------------------
+// wave helpers
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int wn_sum(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ uint64_t wn_min64(uint64_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint64_t y = ((uint64_t)(uint32_t)__shfl_xor((int)(v >> 32), o) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)v, o);
+    v = y < v ? y : v;
+  }
+  return v;
+}
+
+// the sketch of the current window: n entries ascending by hash, in this wave's LDS
+struct WnSketch {
+  uint64_t* h; int32_t* start; int32_t* sum; int n;
+  __device__ __forceinline__ uint64_t maxHash() const { return n > 0 ? h[n - 1] : 0ull; }
+  __device__ __forceinline__ int find(uint64_t x, int lane) const {           // wave-uniform x; index or -1
+    for (int base = 0; base < n; base += 64) {
+      const int i = base + lane;
+      const uint64_t m = __ballot(i < n && h[i] == x);
+      if (m) return base + (int)__builtin_ctzll(m);
+    }
+    return -1;
+  }
+  __device__ __forceinline__ bool contains_lane(uint64_t x) const {           // per-lane x: binary search
+    int lo = 0, hi = n;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (h[mid] < x) lo = mid + 1; else hi = mid; }
+    return lo < n && h[lo] == x;
+  }
+  __device__ __forceinline__ void insert(uint64_t x, int st, int sm, int lane) {
+    int p = 0;
+    for (int base = 0; base < n; base += 64) { const int i = base + lane; p += __popcll(__ballot(i < n && h[i] < x)); }
+    for (int base = ((n > 0 ? n - 1 : 0) / 64) * 64; base >= 0; base -= 64) {  // shift [p, n) up by one, top chunk first
+      const int i = base + lane;
+      const bool mv = i >= p && i < n;
+      uint64_t a = 0; int32_t b = 0, c = 0;
+      if (mv) { a = h[i]; b = start[i]; c = sum[i]; }
+      __threadfence_block();
+      if (mv) { h[i + 1] = a; start[i + 1] = b; sum[i + 1] = c; }
+      __threadfence_block();
+    }
+    if (lane == 0) { h[p] = x; start[p] = st; sum[p] = sm; }
+    __threadfence_block();
+    n++;
+  }
+  __device__ __forceinline__ void remove(int p, int lane) {
+    for (int base = (p / 64) * 64; base < n; base += 64) {                     // shift (p, n) down by one, bottom chunk first
+      const int i = base + lane;
+      const bool mv = i > p && i < n;
+      uint64_t a = 0; int32_t b = 0, c = 0;
+      if (mv) { a = h[i]; b = start[i]; c = sum[i]; }
+      __threadfence_block();
+      if (mv) { h[i - 1] = a; start[i - 1] = b; sum[i - 1] = c; }
+      __threadfence_block();
+    }
+    n--;
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// k_winnow_tiles<DENSE>: one wavefront per tile.
+//   index space: DENSE -> k-mer positions (H[i] == NONE: not a k-mer);  sparse -> indices into the candidate list
+// ---------------------------------------------------------------------------------------------
+template <bool DENSE>
+__global__ void __launch_bounds__(64)
+k_winnow_tiles(const int32_t* __restrict__ tileList, int nTilesLaunch,
+               const int32_t* __restrict__ cPos, const uint64_t* __restrict__ cHash, const int8_t* __restrict__ cSt, int64_t nCand,
+               const uint64_t* __restrict__ H, const int8_t* __restrict__ ST,
+               int len, int k, int w, int s, int TW, int nW, int ldsCand,
+               mm_minmer* __restrict__ out, int outCap, int32_t* __restrict__ outCount,
+               WnOpenRun* __restrict__ open, int32_t* __restrict__ openCount, int32_t* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x;
+  const int slot = blockIdx.x;                                   // output slot (== position in tileList when there is one)
+  const int t = tileList ? tileList[blockIdx.x] : (int)blockIdx.x;
+  (void)nTilesLaunch;
+  const int wk = w - k + 1;                                      // k-mer positions per window
+  const int W0 = t * TW;
+  const int Wend = ((int64_t)(t + 1) * TW < (int64_t)nW - 1) ? (t + 1) * TW : nW - 1;
+  const bool lastTile = Wend == nW - 1;
+
+  WnSketch sk;
+  sk.h = (uint64_t*)smem;
+  sk.start = (int32_t*)(smem + (size_t)(s + 1) * 8);
+  sk.sum = sk.start + (s + 1);
+  sk.n = 0;
+  unsigned char* stage = smem + (size_t)(s + 1) * 16;
+
+  // candidate view (flat pointers: LDS when the tile's candidates were staged, HBM otherwise)
+  const int32_t* vPos = cPos; const uint64_t* vHash = DENSE ? H : cHash; const int8_t* vSt = DENSE ? ST : cSt;
+  int64_t cLo = 0, cHi = 0, vOff = 0;                            // sparse: candidate indices of positions [W0, Wend + wk - 1]
+  if (!DENSE) {
+    auto lower = [&](int pos) { int64_t lo = 0, hi = nCand; while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (cPos[mid] < pos) lo = mid + 1; else hi = mid; } return lo; };
+    cLo = lower(W0); cHi = lower(Wend + wk);
+    if (cHi - cLo <= (int64_t)ldsCand) {
+      const int m = (int)(cHi - cLo);
+      uint64_t* lH = (uint64_t*)stage; int32_t* lP = (int32_t*)(stage + (size_t)ldsCand * 8); int8_t* lS = (int8_t*)(stage + (size_t)ldsCand * 12);
+      for (int i = lane; i < m; i += 64) { lH[i] = cHash[cLo + i]; lP[i] = cPos[cLo + i]; lS[i] = cSt[cLo + i]; }
+      __threadfence_block();
+      vHash = lH; vPos = lP; vSt = lS; vOff = cLo;      // (no negative-offset pointer: an LDS address must stay inside its 32-bit aperture)
+    }
+  }
+  auto posOf = [&](int64_t i) -> int { return DENSE ? (int)i : vPos[i - vOff]; };
+  auto hashAt = [&](int64_t i) -> uint64_t { return vHash[i - vOff]; };
+  auto stAt = [&](int64_t i) -> int { return (int)vSt[i - vOff]; };
+  auto validAt = [&](int64_t i) -> bool { return DENSE ? hashAt(i) != WN_NONE : true; };
+
+  mm_minmer* myOut = out + (size_t)slot * outCap;
+  int nOut = 0; bool fail = false;
+  auto emit = [&](uint64_t hh, int st, int en, int sm) {
+    if (nOut < outCap) { if (lane == 0) myOut[nOut] = mm_minmer{hh, st, en, 0, (int16_t)sm, 0}; }
+    else fail = true;
+    nOut++;
+  };
+  // occurrences of g among the indices [a, b): count and strand sum
+  auto occ = [&](uint64_t g, int64_t a, int64_t b, int& cnt, int& sm) {
+    int c = 0, sgn = 0;
+    for (int64_t base = a; base < b; base += 64) {
+      const int64_t i = base + lane;
+      const bool hit = i < b && hashAt(i) == g;
+      c += __popcll(__ballot(hit));
+      sgn += hit ? stAt(i) : 0;
+    }
+    cnt = c; sm = wn_sum(sgn);
+  };
+  // smallest hash among [a, b) that is not in the sketch (the reference's heap front)
+  auto pendMin = [&](int64_t a, int64_t b) -> uint64_t {
+    uint64_t best = WN_NONE;
+    const uint64_t mx = sk.maxHash();
+    for (int64_t base = a; base < b; base += 64) {
+      const int64_t i = base + lane;
+      uint64_t hv = (i < b && validAt(i)) ? hashAt(i) : WN_NONE;
+      if (hv != WN_NONE && sk.n > 0 && hv <= mx && sk.contains_lane(hv)) hv = WN_NONE;
+      best = hv < best ? hv : best;
+    }
+    return wn_min64(best);
+  };
+  auto refill = [&](int W, int startVal, int64_t a, int64_t b) {          // :487-505
+    while (sk.n < s) {
+      const uint64_t pm = pendMin(a, b);
+      if (pm == WN_NONE) break;
+      int cnt, sm; occ(pm, a, b, cnt, sm);
+      sk.insert(pm, startVal, sm, lane);
+    }
+    (void)W;
+  };
+
+  // window [a, b) in index space
+  int64_t a, b;
+  if (DENSE) { a = W0; b = (int64_t)W0 + wk; }
+  else {
+    a = cLo;
+    int64_t lo = cLo, hi = cHi; const int lim = W0 + wk;                   // first candidate with pos >= W0 + wk
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (posOf(mid) < lim) lo = mid + 1; else hi = mid; }
+    b = lo;
+  }
+  // cold start: the sketch of window W0; runs that were already open get their start from the previous tile later
+  refill(W0, W0 == 0 ? 0 : WN_CARRY, a, b);
+  if (!DENSE && sk.n < s) fail = true;
+
+  int W = W0;
+  const int64_t idxEnd = DENSE ? (int64_t)Wend + wk : cHi;
+  while (!fail) {
+    int Wn;
+    if (DENSE) Wn = W + 1;
+    else {
+      const int dep = a < b ? posOf(a) + 1 : 0x7fffffff;                     // first candidate of the window leaves at pos + 1
+      const int arr = b < idxEnd ? posOf(b) - (wk - 1) : 0x7fffffff;         // next candidate enters when the window end reaches it
+      Wn = dep < arr ? dep : arr;
+    }
+    if (Wn > Wend) break;
+    W = Wn;
+    bool removed = false, newPending = false; uint64_t hArr = 0;
+    // (1) departure of k-mer W-1 (:376-410)
+    {
+      const bool depValid = DENSE ? validAt(W - 1) : (a < b && posOf(a) == W - 1);
+      if (depValid) {
+        const int64_t di = DENSE ? (int64_t)(W - 1) : a;
+        const uint64_t g = hashAt(di); const int st = stAt(di);
+        if (sk.n > 0 && g <= sk.maxHash()) {
+          const int p = sk.find(g, lane);
+          if (p >= 0) {
+            int cnt, sm; occ(g, a, b, cnt, sm);                               // old window: still contains the departing k-mer
+            const int cur = sk.sum[p];
+            if (cnt == 1) { emit(g, sk.start[p], W, cur); sk.remove(p, lane); removed = true; }
+            else {
+              if (cur - st == 0 || cur == 0) { emit(g, sk.start[p], W, cur); if (lane == 0) sk.start[p] = W; }
+              if (lane == 0) sk.sum[p] = cur - st;
+              __threadfence_block();
+            }
+          }
+        }
+      }
+      if (DENSE) a = W; else if (depValid) a++;
+    }
+    // (2) arrival of k-mer W+w-k (:412-438)
+    {
+      const int ap = W + wk - 1;
+      const bool arrValid = DENSE ? validAt(ap) : (b < idxEnd && posOf(b) == ap);
+      if (arrValid) {
+        const int64_t ai = DENSE ? (int64_t)ap : b;
+        const uint64_t hh = hashAt(ai); const int st = stAt(ai);
+        const int p = (sk.n > 0 && hh <= sk.maxHash()) ? sk.find(hh, lane) : -1;
+        if (p >= 0) {
+          const int cur = sk.sum[p];
+          if (cur + st == 0 || cur == 0) { emit(hh, sk.start[p], W, cur); if (lane == 0) sk.start[p] = W; }
+          if (lane == 0) sk.sum[p] = cur + st;
+          __threadfence_block();
+        } else { newPending = true; hArr = hh; }
+      }
+      if (DENSE) b = (int64_t)W + wk; else if (arrValid) b++;
+    }
+    // (3) eviction of the largest member by a smaller newcomer, then refill (:440-505)
+    if (sk.n == s && newPending && hArr < sk.maxHash()) {
+      emit(sk.h[sk.n - 1], sk.start[sk.n - 1], W, sk.sum[sk.n - 1]);
+      sk.n--; removed = true;
+    }
+    if (sk.n < s && (removed || newPending)) {
+      refill(W, W, a, b);
+      if (!DENSE && sk.n < s) fail = true;                                  // the cut may be hiding k-mers that belong in the sketch
+    }
+  }
+
+  if (!fail) {
+    if (lastTile) {                                                          // final flush in ascending hash (:509-520)
+      for (int p = 0; p < sk.n; p++) emit(sk.h[p], sk.start[p], len - k + 1, sk.sum[p]);
+      if (lane == 0) openCount[slot] = 0;
+    } else {
+      for (int p = lane; p < sk.n; p += 64) open[(size_t)slot * s + p] = WnOpenRun{sk.h[p], sk.start[p], sk.sum[p]};
+      if (lane == 0) openCount[slot] = sk.n;
+    }
+  }
+  if (lane == 0) { outCount[slot] = fail ? 0 : nOut; status[slot] = fail ? 1 : 0; }
+}
+
+// gathers the tiles' records into one dense array (block per tile)
+__global__ void __launch_bounds__(256)
+k_winnow_compact(const mm_minmer* __restrict__ out, int outCap, const int32_t* __restrict__ outCount, const int64_t* __restrict__ outOff,
+                 mm_minmer* __restrict__ dense) {
+  const int t = blockIdx.x;
+  const int n = outCount[t];
+  const mm_minmer* src = out + (size_t)t * outCap;
+  mm_minmer* dst = dense + outOff[t];
+  for (int i = threadIdx.x; i < n; i += 256) dst[i] = src[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// host orchestration for one contig whose hashes are resident (dH, dS)
+// ---------------------------------------------------------------------------------------------
+int mm_scan_i32_to_i64(mm_ctx* c, int64_t n, const int32_t* dIn, int64_t* dOut, int64_t* total);   // mm_l2.hip
+
+int mm_winnow_contig_device(mm_ctx* c, WinnowBuffers& B, const uint64_t* dH, const int8_t* dS, int64_t nPos, int len,
+                            std::vector<mm_minmer>& records, std::vector<int32_t>& tileCount, std::vector<WnOpenRun>& openRuns,
+                            std::vector<int32_t>& openCount) {
+  const int k = c->P.kmerSize, w = c->P.segLength, s = c->P.sketchSize;
+  const int nW = len - w + 1;
+  const int wk = w - k + 1;
+  const int TW = w;                                                          // windows per tile
+  const int nTiles = nW - 1 <= 0 ? 1 : (int)(((int64_t)nW - 1 + TW - 1) / TW);
+  // cut: the s-th smallest of wk canonical hashes (min of two uniforms) is ~ s / (2 wk) * 2^64; keep 2.5x that
+  uint64_t cap = ~0ull;
+  { const double frac = 2.5 * (double)s / (2.0 * (double)wk); if (frac < 0.45) cap = (uint64_t)(frac * 18446744073709551615.0); }
+  const bool sparse = cap != ~0ull;
+  // ---- candidates
+  int64_t nCand = 0;
+  if (sparse) {
+    const int64_t nBlocks = (nPos + CAND_TILE - 1) / CAND_TILE;
+    MM_HIP(c, B.blockCnt.ensure((size_t)nBlocks * 4 + 64)); MM_HIP(c, B.blockOff.ensure((size_t)nBlocks * 8 + 64));
+    hipLaunchKernelGGL(k_cand_count, dim3((unsigned)nBlocks), dim3(256), 0, c->stream, dH, nPos, cap, B.blockCnt.as<int32_t>());
+    MM_HIP(c, hipGetLastError());
+    int rc = mm_scan_i32_to_i64(c, nBlocks, B.blockCnt.as<int32_t>(), B.blockOff.as<int64_t>(), &nCand);
+    if (rc != MM_OK) return rc;
+    MM_HIP(c, B.cPos.ensure((size_t)nCand * 4 + 64)); MM_HIP(c, B.cHash.ensure((size_t)nCand * 8 + 64)); MM_HIP(c, B.cSt.ensure((size_t)nCand + 64));
+    hipLaunchKernelGGL(k_cand_write, dim3((unsigned)nBlocks), dim3(256), 0, c->stream, dH, dS, nPos, cap, B.blockOff.as<int64_t>(),
+                       B.cPos.as<int32_t>(), B.cHash.as<uint64_t>(), B.cSt.as<int8_t>());
+    MM_HIP(c, hipGetLastError());
+  }
+  // ---- tiles
+  const int outCap = std::max(1024, 8 * s);
+  MM_HIP(c, B.out.ensure((size_t)nTiles * outCap * sizeof(mm_minmer) + 64));
+  MM_HIP(c, B.outCount.ensure((size_t)nTiles * 4 + 64)); MM_HIP(c, B.openCount.ensure((size_t)nTiles * 4 + 64));
+  MM_HIP(c, B.status.ensure((size_t)nTiles * 4 + 64)); MM_HIP(c, B.open.ensure((size_t)nTiles * s * sizeof(WnOpenRun) + 64));
+  MM_HIP(c, B.outOff.ensure((size_t)nTiles * 8 + 64));
+  const size_t ldsSketch = (size_t)(s + 1) * 16;
+  int ldsCand = 1024; while ((size_t)ldsCand * 13 + ldsSketch > 60 * 1024 && ldsCand > 64) ldsCand >>= 1;
+  const size_t ldsSparse = ldsSketch + (size_t)ldsCand * 13 + 16;
+  MM_HIP(c, hipFuncSetAttribute((const void*)k_winnow_tiles<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsSparse));
+  MM_HIP(c, hipFuncSetAttribute((const void*)k_winnow_tiles<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsSketch + 16));
+  {
+    KernelTimer t(c, MM_K_WINNOW);
+    if (sparse)
+      hipLaunchKernelGGL((k_winnow_tiles<false>), dim3(nTiles), dim3(64), ldsSparse, c->stream, (const int32_t*)nullptr, nTiles,
+                         B.cPos.as<int32_t>(), B.cHash.as<uint64_t>(), B.cSt.as<int8_t>(), nCand, dH, dS, len, k, w, s, TW, nW, ldsCand,
+                         B.out.as<mm_minmer>(), outCap, B.outCount.as<int32_t>(), B.open.as<WnOpenRun>(), B.openCount.as<int32_t>(), B.status.as<int32_t>());
+    else
+      hipLaunchKernelGGL((k_winnow_tiles<true>), dim3(nTiles), dim3(64), ldsSketch + 16, c->stream, (const int32_t*)nullptr, nTiles,
+                         (const int32_t*)nullptr, (const uint64_t*)nullptr, (const int8_t*)nullptr, (int64_t)0, dH, dS, len, k, w, s, TW, nW, 0,
+                         B.out.as<mm_minmer>(), outCap, B.outCount.as<int32_t>(), B.open.as<WnOpenRun>(), B.openCount.as<int32_t>(), B.status.as<int32_t>());
+    MM_HIP(c, hipGetLastError());
+  }
+  std::vector<int32_t> status((size_t)nTiles);
+  MM_HIP(c, hipMemcpyAsync(status.data(), B.status.p, (size_t)nTiles * 4, hipMemcpyDeviceToHost, c->stream));
+  MM_HIP(c, hipStreamSynchronize(c->stream));
+  std::vector<int32_t> redo;
+  for (int t = 0; t < nTiles; t++) if (status[t]) redo.push_back(t);
+  int64_t total = 0;
+  { const int rc = mm_scan_i32_to_i64(c, nTiles, B.outCount.as<int32_t>(), B.outOff.as<int64_t>(), &total); if (rc != MM_OK) return rc; }
+  MM_HIP(c, B.dense.ensure((size_t)total * sizeof(mm_minmer) + 64));
+  hipLaunchKernelGGL(k_winnow_compact, dim3(nTiles), dim3(256), 0, c->stream, B.out.as<mm_minmer>(), outCap, B.outCount.as<int32_t>(),
+                     B.outOff.as<int64_t>(), B.dense.as<mm_minmer>());
+  MM_HIP(c, hipGetLastError());
+  std::vector<mm_minmer> first((size_t)total);
+  tileCount.assign((size_t)nTiles, 0); openCount.assign((size_t)nTiles, 0); openRuns.assign((size_t)nTiles * s, WnOpenRun{0, 0, 0});
+  if (total) MM_HIP(c, hipMemcpyAsync(first.data(), B.dense.p, (size_t)total * sizeof(mm_minmer), hipMemcpyDeviceToHost, c->stream));
+  MM_HIP(c, hipMemcpyAsync(tileCount.data(), B.outCount.p, (size_t)nTiles * 4, hipMemcpyDeviceToHost, c->stream));
+  MM_HIP(c, hipMemcpyAsync(openCount.data(), B.openCount.p, (size_t)nTiles * 4, hipMemcpyDeviceToHost, c->stream));
+  MM_HIP(c, hipMemcpyAsync(openRuns.data(), B.open.p, (size_t)nTiles * s * sizeof(WnOpenRun), hipMemcpyDeviceToHost, c->stream));
+  MM_HIP(c, hipStreamSynchronize(c->stream));
+  if (redo.empty()) { records.swap(first); return MM_OK; }
+
+  // ---- failed tiles again, every valid k-mer a candidate, room for the worst case (3 records per window step + flush)
+  const int nRedo = (int)redo.size();
+  const int bigCap = 3 * TW + s + 16;
+  MM_HIP(c, B.redoList.ensure((size_t)nRedo * 4 + 64));
+  MM_HIP(c, B.out2.ensure((size_t)nRedo * bigCap * sizeof(mm_minmer) + 64));
+  MM_HIP(c, B.outCount2.ensure((size_t)nRedo * 4 + 64)); MM_HIP(c, B.openCount2.ensure((size_t)nRedo * 4 + 64));
+  MM_HIP(c, B.status2.ensure((size_t)nRedo * 4 + 64)); MM_HIP(c, B.open2.ensure((size_t)nRedo * s * sizeof(WnOpenRun) + 64));
+  MM_HIP(c, hipMemcpyAsync(B.redoList.p, redo.data(), (size_t)nRedo * 4, hipMemcpyHostToDevice, c->stream));
+  {
+    KernelTimer t(c, MM_K_WINNOW);
+    hipLaunchKernelGGL((k_winnow_tiles<true>), dim3(nRedo), dim3(64), ldsSketch + 16, c->stream, B.redoList.as<int32_t>(), nRedo,
+                       (const int32_t*)nullptr, (const uint64_t*)nullptr, (const int8_t*)nullptr, (int64_t)0, dH, dS, len, k, w, s, TW, nW, 0,
+                       B.out2.as<mm_minmer>(), bigCap, B.outCount2.as<int32_t>(), B.open2.as<WnOpenRun>(), B.openCount2.as<int32_t>(), B.status2.as<int32_t>());
+    MM_HIP(c, hipGetLastError());
+  }
+  std::vector<int32_t> cnt2((size_t)nRedo), oc2((size_t)nRedo), st2((size_t)nRedo);
+  std::vector<WnOpenRun> or2((size_t)nRedo * s);
+  std::vector<mm_minmer> rec2((size_t)nRedo * bigCap);
+  MM_HIP(c, hipMemcpyAsync(cnt2.data(), B.outCount2.p, (size_t)nRedo * 4, hipMemcpyDeviceToHost, c->stream));
+  MM_HIP(c, hipMemcpyAsync(oc2.data(), B.openCount2.p, (size_t)nRedo * 4, hipMemcpyDeviceToHost, c->stream));
+  MM_HIP(c, hipMemcpyAsync(st2.data(), B.status2.p, (size_t)nRedo * 4, hipMemcpyDeviceToHost, c->stream));
+  MM_HIP(c, hipMemcpyAsync(or2.data(), B.open2.p, (size_t)nRedo * s * sizeof(WnOpenRun), hipMemcpyDeviceToHost, c->stream));
+  MM_HIP(c, hipMemcpyAsync(rec2.data(), B.out2.p, (size_t)nRedo * bigCap * sizeof(mm_minmer), hipMemcpyDeviceToHost, c->stream));
+  MM_HIP(c, hipStreamSynchronize(c->stream));
+  for (int r = 0; r < nRedo; r++) if (st2[r]) { c->err = "mm_index_build: winnowing tile overflowed its worst-case record buffer"; return MM_ERR_CAPACITY; }
+  // splice: tile order, redone tiles taken from the second launch
+  std::vector<int64_t> off((size_t)nTiles + 1, 0);
+  for (int t = 0; t < nTiles; t++) off[t + 1] = off[t] + tileCount[t];
+  records.clear();
+  size_t r = 0;
+  for (int t = 0; t < nTiles; t++) {
+    if (r < redo.size() && redo[r] == t) {
+      records.insert(records.end(), rec2.begin() + (size_t)r * bigCap, rec2.begin() + (size_t)r * bigCap + cnt2[r]);
+      tileCount[t] = cnt2[r]; openCount[t] = oc2[r];
+      std::copy(or2.begin() + (size_t)r * s, or2.begin() + (size_t)r * s + oc2[r], openRuns.begin() + (size_t)t * s);
+      r++;
+    } else {
+      records.insert(records.end(), first.begin() + off[t], first.begin() + off[t + 1]);
+    }
+  }
+  return MM_OK;
+}

@@ -101,3 +101,18 @@ def test_stats_mirror_vs_reference_golden(gold):
         s, pi = key.split("_")
         assert [lib.mm_stat_min_hits_relaxed(q, 19, int(pi) / 100.0) for q in range(1, int(s) + 1)] == tab
     assert list(capi.stat_sketch_cutoffs(130, 19, True)) == gold["session"]["cutoffs"]
+
+
+def test_minmers_vs_reference_golden():
+    """device winnowing (k_ref_hash -> candidate compaction -> k_winnow_tiles -> stitch) vs addMinmers of the real reference"""
+    from mashmap_amd import capi
+    z = np.load(os.path.join(GOLD, "minmers.npz"))
+    for name, k, w, s, seq in CS.minmer_cases():
+        ctx = capi.Context(k=k, segLength=w, sketchSize=s)
+        ctx.index_build([seq], kmerPct=0.0)              # threshold 0 %: no frequent-seed removal, minmerIndex == addMinmers output
+        got = ctx.index_download()["minmers"]
+        exp = z[name]
+        assert len(got) == len(exp), name
+        for f in ("hash", "wpos", "wpos_end", "strand"):
+            assert np.array_equal(got[f], exp[f]), (name, f)
+        ctx.close()
