@@ -108,18 +108,27 @@ def cpu_baseline(ref_np, reads_np, n_sample, read_len):
             with open(qp + ".fai", "w") as f:          # avoids the reference's extra pass over the query file
                 for i in range(n_sample):
                     f.write("read%d\t%d\t0\t100\t101\n" % (i, read_len))
-            t0 = time.time()
-            p = subprocess.run([ref_bin, "-r", rp, "-q", qp, "-o", op, "-t", str(ncores), "-s", str(SEG), "--pi", str(int(PI * 100)),
-                                "-k", str(K), "-J", str(SKETCH)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-            wall = time.time() - t0
-            tmap = None
-            for line in p.stderr.splitlines():
-                if "time spent mapping the query" in line:
-                    tmap = float(line.split(":")[-1].split()[0])
-            if p.returncode == 0 and tmap:
-                log("[cpu_baseline] reference binary: map %.2f s (total wall %.1f s) on %d threads" % (tmap, wall, ncores))
-                return {"value": n_sample * read_len / tmap / 1e9, "unit": "Gbp/s", "cores": ncores, "kind": "reference",
-                        "sample": desc + "; mashmap_ref -t %d, 'time spent mapping the query' (includes its FASTA reader)" % ncores}
+            # the reference's pthread pool stops scaling early (one reader thread feeds it; with hundreds of threads it thrashes):
+            # time a few thread counts on the same sample and report the best one
+            best = None
+            for nt in sorted({min(ncores, 8), min(ncores, 32), min(ncores, 64)}):
+                t0 = time.time()
+                p = subprocess.run([ref_bin, "-r", rp, "-q", qp, "-o", op, "-t", str(nt), "-s", str(SEG), "--pi", str(int(PI * 100)),
+                                    "-k", str(K), "-J", str(SKETCH)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+                wall = time.time() - t0
+                tmap = None
+                for line in p.stderr.splitlines():
+                    if "time spent mapping the query" in line:
+                        tmap = float(line.split(":")[-1].split()[0])
+                if p.returncode == 0 and tmap:
+                    log("[cpu_baseline] reference binary -t %d: map %.2f s (total wall %.1f s)" % (nt, tmap, wall))
+                    if best is None or tmap < best[0]:
+                        best = (tmap, nt)
+            if best:
+                tmap, nt = best
+                return {"value": n_sample * read_len / tmap / 1e9, "unit": "Gbp/s", "cores": nt, "kind": "reference",
+                        "sample": desc + "; mashmap_ref (built from the reference sources) best of -t 8/32/64 = -t %d of %d host cores, "
+                                         "'time spent mapping the query' (includes its single-threaded FASTA reader)" % (nt, ncores)}
             log("[cpu_baseline] reference binary failed, falling back to the port:", p.stderr[-300:])
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import mmutil as U

@@ -229,22 +229,54 @@ extern "C" int mm_index_build(mm_ctx* c, const char* bases, const int64_t* conti
   // Sketch::index (winSketch.hpp:379-404): per-hash OPEN/CLOSE points in minmerIndex order, adjacent runs merged
   std::vector<mm_minmer> all;
   { size_t tot = 0; for (auto& v : per) tot += v.size(); all.reserve(tot); for (auto& v : per) { all.insert(all.end(), v.begin(), v.end()); std::vector<mm_minmer>().swap(v); } }
-  std::unordered_map<uint64_t, std::vector<mm_interval_point>> lookup;
-  lookup.reserve(all.size() / 2 + 16);
-  for (const auto& mi : all) {
-    auto& v = lookup[mi.hash];
-    if (v.empty() || v.back().pos != mi.wpos) {
-      mm_interval_point a; std::memset(&a, 0, sizeof a); a.pos = mi.wpos; a.hash = mi.hash; a.seqId = mi.seqId; a.side = 1;
-      mm_interval_point b = a; b.pos = mi.wpos_end; b.side = -1;
-      v.push_back(a); v.push_back(b);
-    } else v.back().pos = mi.wpos_end;
+  // Grouping by hash with the records of a hash in minmerIndex order is a stable sort of (hash, index) pairs; the map's
+  // "previous point of this hash ends where this record starts" test (winSketch.hpp:388-396) then only looks at the
+  // neighbour.  Keys come out ascending, which is the order mm_index_download promises.
+  const size_t nAll = all.size();
+  std::vector<std::pair<uint64_t, uint32_t>> byHash(nAll);
+  {
+    const unsigned T = (unsigned)std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), std::max<size_t>(1, nAll / 65536));
+    std::vector<size_t> cut(T + 1);
+    for (unsigned t = 0; t <= T; t++) cut[t] = nAll * t / T;
+    std::vector<std::future<void>> jobs;
+    for (unsigned t = 0; t < T; t++)
+      jobs.push_back(std::async(std::launch::async, [&, t]() {
+        for (size_t i = cut[t]; i < cut[t + 1]; i++) byHash[i] = std::make_pair(all[i].hash, (uint32_t)i);
+        std::sort(byHash.begin() + cut[t], byHash.begin() + cut[t + 1]);
+      }));
+    for (auto& j : jobs) j.get();
+    for (unsigned width = 1; width < T; width *= 2) {                      // pairwise merges, each level in parallel
+      jobs.clear();
+      for (unsigned t = 0; t + width < T; t += 2 * width) {
+        const size_t lo = cut[t], mid = cut[t + width], hi = cut[std::min(T, t + 2 * width)];
+        jobs.push_back(std::async(std::launch::async, [&, lo, mid, hi]() { std::inplace_merge(byHash.begin() + lo, byHash.begin() + mid, byHash.begin() + hi); }));
+      }
+      for (auto& j : jobs) j.get();
+    }
   }
+  c->hKeys.clear(); c->hOffsets.clear(); c->hPoints.clear(); c->hFreq.clear();
+  c->hPoints.reserve(2 * nAll);
+  for (size_t i = 0; i < nAll;) {                                          // Sketch::index (winSketch.hpp:379-404)
+    const uint64_t key = byHash[i].first;
+    c->hKeys.push_back(key); c->hOffsets.push_back((uint64_t)c->hPoints.size());
+    for (; i < nAll && byHash[i].first == key; i++) {
+      const mm_minmer& mi = all[byHash[i].second];
+      if (c->hPoints.size() == c->hOffsets.back() || c->hPoints.back().pos != mi.wpos) {
+        mm_interval_point a2; std::memset(&a2, 0, sizeof a2); a2.pos = mi.wpos; a2.hash = mi.hash; a2.seqId = mi.seqId; a2.side = 1;
+        mm_interval_point b2 = a2; b2.pos = mi.wpos_end; b2.side = -1;
+        c->hPoints.push_back(a2); c->hPoints.push_back(b2);
+      } else c->hPoints.back().pos = mi.wpos_end;
+    }
+  }
+  c->hOffsets.push_back((uint64_t)c->hPoints.size());
+  std::vector<std::pair<uint64_t, uint32_t>>().swap(byHash);
   // frequency filter (winSketch.hpp:410-504)
   int32_t freqThreshold = 0x7fffffff;
-  if (!lookup.empty()) {
+  const size_t nKeysAll = c->hKeys.size();
+  if (nKeysAll) {
     std::map<int, int64_t> hist;
-    for (auto& e : lookup) hist[(int)e.second.size()] += 1;
-    const int64_t total = (int64_t)lookup.size();
+    for (size_t i = 0; i < nKeysAll; i++) hist[(int)(c->hOffsets[i + 1] - c->hOffsets[i])] += 1;
+    const int64_t total = (int64_t)nKeysAll;
     const int64_t toIgnore = (int64_t)(total * kmerPctThreshold / 100);      // int64 * float / int, as winSketch.hpp:425
     int64_t sum = 0;
     for (auto it = hist.rbegin(); it != hist.rend(); ++it) {
@@ -254,19 +286,8 @@ extern "C" int mm_index_build(mm_ctx* c, const char* bases, const int64_t* conti
       else break;
     }
   }
-  c->hKeys.clear(); c->hOffsets.clear(); c->hPoints.clear(); c->hFreq.clear();
-  c->hKeys.reserve(lookup.size());
-  for (auto& e : lookup) c->hKeys.push_back(e.first);
-  std::sort(c->hKeys.begin(), c->hKeys.end());
-  c->hOffsets.reserve(lookup.size() + 1);
-  uint64_t o = 0;
-  for (uint64_t key : c->hKeys) {
-    auto& v = lookup[key];
-    c->hOffsets.push_back(o); o += v.size();
-    c->hPoints.insert(c->hPoints.end(), v.begin(), v.end());
-    if ((int64_t)v.size() >= (int64_t)freqThreshold) c->hFreq.push_back(key);
-  }
-  c->hOffsets.push_back(o);
+  for (size_t i = 0; i < nKeysAll; i++)
+    if ((int64_t)(c->hOffsets[i + 1] - c->hOffsets[i]) >= (int64_t)freqThreshold) c->hFreq.push_back(c->hKeys[i]);
   if (!c->hFreq.empty())
     all.erase(std::remove_if(all.begin(), all.end(), [&](const mm_minmer& m) { return std::binary_search(c->hFreq.begin(), c->hFreq.end(), m.hash); }), all.end());
   c->hMinmers.swap(all);
