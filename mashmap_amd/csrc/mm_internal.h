@@ -38,12 +38,12 @@ struct DFrag {
 
 struct DeviceIndex {
   size_t nRec = 0, nKeys = 0, nPoints = 0, nContigs = 0, htCap = 0;
-  // minmerIndex as structure-of-arrays, in minmerIndex order ("insert stream"):
-  DevBuf recH;                 //   uint64 hash
-  DevBuf recW;                 //   int2 {wpos, wpos_end | REV<<31}
-  // the same records per contig ordered by wpos_end ("eviction stream", replaces the reference's heap):
-  DevBuf recEh, recEw;         //   uint64 hash ; int32 wpos_end
-  DevBuf contigOff;            // int64[nContigs+1] record offsets
+  // minmerIndex as the L2 event stream (see mm_build_device_index): per contig, one insert event per record at wpos and one
+  // eviction event at wpos_end, merged by position
+  DevBuf evKey;                // uint32 pos*2 + isInsert
+  DevBuf evAux;                // uint32 insert: wpos_end | REV<<31 ; eviction: 0
+  DevBuf evHash;               // uint64 hash of the record
+  DevBuf contigOff;            // int64[nContigs+1] event offsets
   DevBuf contigLen;            // int32[nContigs]
   DevBuf refGroup;             // int32[nContigs] (all 0 when unused)
   DevBuf htSlots;              // {uint64 key, uint64 val}[htCap]; val = offset<<24 | count<<1 | freq (one 16-byte slot per probe)

@@ -4,72 +4,70 @@
 //   SlideMapper              src/map/include/slidingMap.hpp:28-212
 //
 // The reference walks minmerIndex once per L1 candidate, keeps the open reference minmers in a heap ordered
-// by wpos_end and, for every record, binary-searches the query sketch twice (insert + eviction).  Here:
+// by wpos_end and, for every record, binary-searches the query sketch twice (insert + eviction).  Here the index already
+// holds, per contig, the merged stream of insert and eviction events (mm_build_device_index), so a candidate is a slice of it:
 //
-//   k_l2_extents   thread / candidate : the two record ranges a candidate touches
-//                                       (insert stream: minmerIndex order; eviction stream: same records ordered by wpos_end)
+//   k_l2_extents   thread / candidate : three binary searches give the slice [e0, eMid, ub) of the event stream
 //   scan           exclusive scan of the per-candidate entry counts
-//   k_l2_locate    wave / candidate   : merges the two streams into ONE time-ordered stream of 8-byte entries.  The query
-//                                       sketch and both position arrays are staged in LDS; every record is located in the
-//                                       sketch (LDS binary search) and its slot in the merged order is computed by counting
-//                                       (eviction e precedes insert i  <=>  wpos_end[e] <= wpos[i], computeMap.hpp:1344-1367)
-//   k_l2_sweep     lane / candidate   : the sequential SlideMapper sweep over the merged stream; 64 bytes (8 entries) per lane
+//   k_l2_locate    wave / candidate   : streams the slice (coalesced 16 B per event), locates every hash in the query sketch
+//                                       (LDS bucket table + short scan) and writes a compact 4-byte entry per event that can
+//                                       matter: pre-load inserts still open at rangeStart, inserts, evictions of hashes inside
+//                                       the sketch's range; positions are delta-coded against the previous insert
+//   k_l2_sweep     lane / candidate   : the sequential SlideMapper sweep over that stream; 64 bytes (16 entries) per lane
 //                                       are fetched per step and the next step is prefetched while the current one is
 //                                       consumed; per-lane SlideMapper state sits in LDS as 16-bit cells laid out so that a
-//                                       lane always hits its own bank
+//                                       lane always hits its own bank; the state update is branch-free
 //
 // so the latency-bound pointer chasing of the reference (two dependent 8-step searches per record plus a heap) becomes a
-// throughput-bound, coalesced pre-pass followed by a sweep whose only memory traffic is one sequential stream per lane.
+// streaming pre-pass followed by a sweep whose only memory traffic is one sequential stream per lane.
 #include "mm_internal.h"
 #include "mm_device.h"
 
 #define MM_LOCAP 8          // private L2 locus slots per candidate before the final compaction
 
-struct L2Info { int64_t it0; int64_t itE0; int32_t nIns; int32_t nDel; };
+struct L2Info { int64_t e0; int32_t nPre; int32_t nAll; };      // slice [e0, e0+nAll) of the contig's events, the first nPre before rangeStart
 struct L2Tmp { int32_t start, end, shared, strand; };
 
-// merged-stream entry (uint64):
+// stream entry (uint32):
 //   bits 0..10  1-based position j of the hash in the query sketch (0: beyond the sketch -> no effect on the state)
 //   bit  11     hash equals q[j]
 //   bits 12..13 query strand + 1
-//   bits 16..17 type: 0 eviction, 1 insert + evaluate, 2 end of stream, 3 pre-load insert (computeMap.hpp:1323-1338)
-//   bit  18     reference strand is REV
-//   bits 32..63 wpos of the record (insert), or of the record after the last one (end)
+//   bits 14..16 type: 0 eviction, 1 insert + evaluate, 2 end of stream, 3 pre-load insert (computeMap.hpp:1323-1338), 4 skip
+//   bit  17     reference strand is REV
+//   bits 18..31 insert / end: wpos minus the running position (previous insert's wpos, rangeStart at first)
+//   skip: adds ((e >> 17) << 14 | (e & 0x3FFF)) to the running position (a gap that does not fit 14 bits)
 #define E_DEL 0u
 #define E_INS 1u
 #define E_END 2u
 #define E_PRE 3u
+#define E_SKIP 4u
 #define OP_J(op) ((int)((op) & 0x7FFu))
 #define OP_MATCH(op) ((int)(((op) >> 11) & 1u))
 #define OP_QS(op) ((int)(((op) >> 12) & 3u) - 1)
-#define OP_TYPE(op) (((op) >> 16) & 3u)
-#define OP_RSTRAND(op) ((((op) >> 18) & 1u) ? -1 : 1)
+#define OP_TYPE(op) (((op) >> 14) & 7u)
+#define OP_RSTRAND(op) ((((op) >> 17) & 1u) ? -1 : 1)
+#define E_MAXDELTA 0x3FFFu
+#define E_STEP 16           // entries per 64-byte sweep step
 
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-k_l2_extents(int nCand, int segLength, const mm_l1_candidate* __restrict__ l1, const int2* __restrict__ recW,
-             const int32_t* __restrict__ recEw, const int64_t* __restrict__ contigOff, L2Info* __restrict__ info, int32_t* __restrict__ cnt) {
+k_l2_extents(int nCand, int segLength, const mm_l1_candidate* __restrict__ l1, const uint32_t* __restrict__ evKey,
+             const int64_t* __restrict__ contigOff, L2Info* __restrict__ info, int32_t* __restrict__ cnt) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= nCand) return;
   const mm_l1_candidate cand = l1[c];
   const int64_t cb = contigOff[cand.seqId], ce = contigOff[cand.seqId + 1];
-  // std::lower_bound(minmerIndex, (seqId, rangeStart - segLength - 1))  (computeMap.hpp:1290-1293)
+  auto lower = [&](int64_t lo, uint32_t key) { int64_t hi = ce; while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (evKey[mid] < key) lo = mid + 1; else hi = mid; } return lo; };
+  // std::lower_bound(minmerIndex, (seqId, rangeStart - segLength - 1))  (computeMap.hpp:1290-1293): inserts with wpos >= target
   const int target = cand.rangeStartPos - segLength - 1;
-  int64_t lo = cb, hi = ce;
-  while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (recW[mid].x < target) lo = mid + 1; else hi = mid; }
-  const int64_t it0 = lo;
-  hi = ce;                                             // records are visited while wpos <= rangeEnd (:1340)
-  while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (recW[mid].x <= cand.rangeEndPos) lo = mid + 1; else hi = mid; }
-  const int64_t itEnd = lo;
-  lo = cb; hi = ce;                                    // evictions: wpos_end > rangeStart (anything earlier is never opened, :1325)
-  while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (recEw[mid] <= cand.rangeStartPos) lo = mid + 1; else hi = mid; }
-  const int64_t itE0 = lo;
-  hi = ce;                                             // ... and wpos_end <= the last visited wpos <= rangeEnd
-  while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (recEw[mid] <= cand.rangeEndPos) lo = mid + 1; else hi = mid; }
-  L2Info o; o.it0 = it0; o.itE0 = itE0; o.nIns = (int32_t)(itEnd - it0); o.nDel = (int32_t)(lo - itE0);
+  const int64_t e0 = lower(cb, target > 0 ? (uint32_t)target * 2u : 0u);
+  const int64_t eMid = lower(e0, (uint32_t)cand.rangeStartPos * 2u + 1u);      // first event of the slide: insert at rangeStart or anything later
+  const int64_t ub = lower(eMid, (uint32_t)cand.rangeEndPos * 2u + 2u);        // records are visited while wpos <= rangeEnd (:1340)
+  L2Info o; o.e0 = e0; o.nPre = (int32_t)(eMid - e0); o.nAll = (int32_t)(ub - e0);
   info[c] = o;
-  // merged stream: every insert, every eviction, the end marker; padded to a whole number of 64-byte sweep steps
-  cnt[c] = (o.nIns + o.nDel + 1 + 7) & ~7;
+  // upper bound of the stream: every event, the end marker, one skip per 16 K of range, slack for the end marker's own skip
+  const int n = o.nAll + 1 + ((cand.rangeEndPos - cand.rangeStartPos) >> 14) + 4;
+  cnt[c] = (n + E_STEP - 1) & ~(E_STEP - 1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -128,101 +126,132 @@ k_scan_add(int64_t n, int64_t* __restrict__ out, const int64_t* __restrict__ til
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_l2_locate: one wave per candidate (4 per workgroup).  LDS per wave: the fragment's query sketch (9 B per entry) and,
-// when they fit (posCap int32 words), the wpos of the insert range and the wpos_end of the eviction range; candidates with
-// longer ranges search those two arrays in global memory instead (same code, X = pointer + stride).
+// k_l2_locate: one wave per candidate (4 per workgroup, no workgroup barrier).  LDS per wave: the fragment's query sketch
+// (hash + strand) and a 256-bucket table over [0, qmax] that turns the lower_bound of a hash into one table read plus a scan of
+// ~0.5 entries (the hashes of a sketch are uniform, so equal-width buckets are balanced).
 // ---------------------------------------------------------------------------------------------
-struct PosArr {            // int32 array with an element stride (LDS copy: stride 1; recW.x in global memory: stride 2)
-  const int32_t* p; int stride;
-  __device__ __forceinline__ int operator[](int i) const { return p[(size_t)i * stride]; }
-};
-// #{ i in [0,n) : a[i] < v }   /   #{ i : a[i] <= v }
-__device__ __forceinline__ int mm_count_lt(const PosArr a, int n, int v) {
-  int lo = 0, hi = n;
-  while (lo < hi) { const int mid = (lo + hi) >> 1; if (a[mid] < v) lo = mid + 1; else hi = mid; }
-  return lo;
-}
-__device__ __forceinline__ int mm_count_le(const PosArr a, int n, int v) {
-  int lo = 0, hi = n;
-  while (lo < hi) { const int mid = (lo + hi) >> 1; if (a[mid] <= v) lo = mid + 1; else hi = mid; }
-  return lo;
-}
-
 __global__ void __launch_bounds__(256)
-k_l2_locate(int nCand, int s, int posCap, const mm_l1_candidate* __restrict__ l1, const mm_frag_stats* __restrict__ stats,
-            const uint64_t* __restrict__ qHash, const int8_t* __restrict__ qStrand, const uint64_t* __restrict__ recH,
-            const int2* __restrict__ recW, const uint64_t* __restrict__ recEh, const int32_t* __restrict__ recEw,
+k_l2_locate(int nCand, int s, const mm_l1_candidate* __restrict__ l1, const mm_frag_stats* __restrict__ stats,
+            const uint64_t* __restrict__ qHash, const int8_t* __restrict__ qStrand,
+            const uint32_t* __restrict__ evKey, const uint32_t* __restrict__ evAux, const uint64_t* __restrict__ evHash,
             const int64_t* __restrict__ contigOff, const L2Info* __restrict__ info, const int64_t* __restrict__ opOff,
-            uint64_t* __restrict__ ops) {
+            const int32_t* __restrict__ opCnt, uint32_t* __restrict__ ops, unsigned long long* __restrict__ counters /* [6] |= 4: gap too wide */) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  // per-wave carve: q[s] u64 | pos[posCap] i32 | qs[s] i8
-  const size_t perWave = (size_t)s * 8 + (size_t)posCap * 4 + (((size_t)s + 15) & ~(size_t)15);
-  unsigned char* base = smem + (size_t)wave * perWave;
+  const size_t perWave = (size_t)s * 8 + 260 * 2 + (((size_t)s + 15) & ~(size_t)15);
+  unsigned char* base = smem + (size_t)wave * ((perWave + 15) & ~(size_t)15);
   uint64_t* q = (uint64_t*)base;
-  int32_t* posL = (int32_t*)(base + (size_t)s * 8);
-  int8_t* qs = (int8_t*)(base + (size_t)s * 8 + (size_t)posCap * 4);
-  for (int c = blockIdx.x * 4 + wave; c < nCand; c += gridDim.x * 4) {    // waves are independent: no workgroup barrier below
+  uint16_t* bkt = (uint16_t*)(base + (size_t)s * 8);               // bkt[b] = #query hashes whose bucket is < b, b = 0..256
+  int8_t* qs = (int8_t*)(base + (size_t)s * 8 + 260 * 2);
+  for (int c = blockIdx.x * 4 + wave; c < nCand; c += gridDim.x * 4) {
     const mm_l1_candidate cand = l1[c];
     const int f = cand.frag;
     const int S = stats[f].sketchSize;
     const L2Info in = info[c];
-    uint64_t* out = ops + opOff[c];
-    __threadfence_block();                                                 // previous candidate's LDS reads are done
+    uint32_t* out = ops + opOff[c];
+    const int cap = opCnt[c];
+    __threadfence_block();                                         // previous candidate's LDS reads are done
     for (int p = lane; p < S; p += 64) { q[p] = qHash[(size_t)f * s + p]; qs[p] = qStrand[(size_t)f * s + p]; }
-    const bool inLds = in.nIns + in.nDel <= posCap;
-    PosArr insX, delX;
-    if (inLds) {
-      for (int i = lane; i < in.nIns; i += 64) posL[i] = recW[in.it0 + i].x;
-      for (int e = lane; e < in.nDel; e += 64) posL[in.nIns + e] = recEw[in.itE0 + e];
-      insX.p = posL; insX.stride = 1; delX.p = posL + in.nIns; delX.stride = 1;
-    } else {
-      insX.p = (const int32_t*)(recW + in.it0); insX.stride = 2; delX.p = recEw + in.itE0; delX.stride = 1;
-    }
     __threadfence_block();
     const uint64_t qmax = q[S - 1];
+    // bucket(h): monotone map of [0, qmax] onto 0..255 from the top 24 significant bits (float keeps them exactly)
+    const int sh = qmax ? (int)__builtin_clzll(qmax) : 63;
+    const float scale = 256.0f / ((float)(uint32_t)((qmax << sh) >> 40) + 1.0f);
+    auto bucket = [&](uint64_t h) -> int { const int b = (int)((float)(uint32_t)((h << sh) >> 40) * scale); return b > 255 ? 255 : b; };
+    for (int b = lane; b <= 256; b += 64) {                        // bkt[b] = lower_bound over the (sorted) buckets of q
+      int lo = 0, hi = S;
+      while (lo < hi) { const int mid = (lo + hi) >> 1; if (bucket(q[mid]) < b) lo = mid + 1; else hi = mid; }
+      bkt[b] = (uint16_t)lo;
+    }
+    __threadfence_block();
     auto locate = [&](uint64_t h) -> uint32_t {
       if (h > qmax) return 0u;
-      int lo = 0, hi = S;
-      while (lo < hi) { const int mid = (lo + hi) >> 1; if (q[mid] < h) lo = mid + 1; else hi = mid; }
+      const int b = bucket(h);
+      int lo = bkt[b]; const int hi = bkt[b + 1];
+      while (lo < hi && q[lo] < h) lo++;
+      // lo == lower_bound(q, h): everything in earlier buckets is smaller, everything in later ones larger
       return (uint32_t)(lo + 1) | (q[lo] == h ? 0x800u : 0u) | ((uint32_t)((int)qs[lo] + 1) << 12);
     };
-    // records left of the range (wpos < rangeStart): only those still open at rangeStart are pre-loaded (:1323-1338)
-    const int nPreAll = mm_count_lt(insX, in.nIns, cand.rangeStartPos);
-    int nPre = 0;
-    for (int b0 = 0; b0 < nPreAll; b0 += 64) {
+    // the slide ends with the last insert at or before rangeEnd (evictions behind it are never reached, :1340)
+    int lastRel = -1;                                              // index of that insert relative to e0
+    for (int hiEnd = in.nAll; hiEnd > in.nPre && lastRel < 0; hiEnd -= 64) {
+      const int i = hiEnd - 64 + lane;
+      const uint64_t m = __ballot(i >= in.nPre && i < hiEnd && (evKey[in.e0 + i] & 1u));
+      if (m) lastRel = hiEnd - 64 + 63 - (int)__builtin_clzll(m);
+    }
+    // wpos of the record after it in the same contig, else its own (:1387-1390)
+    int nextW = 0;
+    if (lastRel >= 0) {
+      nextW = (int)(evKey[in.e0 + lastRel] >> 1);
+      const int64_t ce = contigOff[cand.seqId + 1];
+      for (int64_t e = in.e0 + lastRel + 1; e < ce; e += 64) {
+        const uint64_t m = __ballot(e + lane < ce && (evKey[e + lane] & 1u));
+        if (m) { nextW = (int)(evKey[e + (int)__builtin_ctzll(m)] >> 1); break; }
+      }
+    }
+    int outN = 0;                                                  // entries written so far (wave-uniform)
+    int posAcc = cand.rangeStartPos;                               // running position of the delta code (wave-uniform)
+    bool tooWide = false;
+    const int nEv = lastRel + 1;                                   // events [0, nEv) of the slice are streamed
+    for (int b0 = 0; b0 < (nEv > in.nPre ? nEv : in.nPre); b0 += 64) {
       const int i = b0 + lane;
-      bool keep = false; int2 w = make_int2(0, 0);
-      if (i < nPreAll) { w = recW[in.it0 + i]; keep = (int)((uint32_t)w.y & 0x7fffffffu) > cand.rangeStartPos; }
-      const uint64_t m = __ballot(keep);
-      if (keep) {
-        const uint32_t op = locate(recH[in.it0 + i]) | (E_PRE << 16) | (w.y < 0 ? (1u << 18) : 0u);
-        out[nPre + (int)mm_popc_below(m)] = ((uint64_t)(uint32_t)w.x << 32) | op;
+      const bool inPre = i < in.nPre;
+      const bool live = inPre ? true : i < nEv;
+      uint32_t key = 0, aux = 0; uint64_t h = 0;
+      if (live) { key = evKey[in.e0 + i]; aux = evAux[in.e0 + i]; h = evHash[in.e0 + i]; }
+      const bool isIns = (key & 1u) != 0;
+      const int pos = (int)(key >> 1);
+      uint32_t op = 0; bool keep = false, evalIns = false;
+      if (live) {
+        if (inPre) keep = isIns && (int)(aux & 0x7fffffffu) > cand.rangeStartPos;      // still open at rangeStart (:1323-1338)
+        else keep = isIns || h <= qmax;                                                 // an eviction outside the sketch's range changes nothing
+        if (keep) {
+          op = locate(h);
+          const uint32_t type = inPre ? E_PRE : (isIns ? E_INS : E_DEL);
+          op |= (type << 14) | ((isIns && (aux >> 31)) ? (1u << 17) : 0u);
+          evalIns = !inPre && isIns;
+        }
       }
-      nPre += __popcll(m);
-    }
-    const int nMain = in.nIns - nPreAll;
-    PosArr mainX = insX; mainX.p += (size_t)nPreAll * insX.stride;
-    for (int mi = lane; mi < nMain; mi += 64) {                            // inserts that are evaluated
-      const int2 w = recW[in.it0 + nPreAll + mi];
-      const uint32_t op = locate(recH[in.it0 + nPreAll + mi]) | (E_INS << 16) | (w.y < 0 ? (1u << 18) : 0u);
-      out[nPre + mi + mm_count_le(delX, in.nDel, w.x)] = ((uint64_t)(uint32_t)w.x << 32) | op;
-    }
-    for (int e = lane; e < in.nDel; e += 64) {                             // evictions that happen before some insert
-      const int ew = delX[e];
-      const int before = mm_count_lt(mainX, nMain, ew);                    // inserts with wpos < wpos_end[e] come first
-      if (before < nMain) out[nPre + e + before] = (uint64_t)(locate(recEh[in.itE0 + e]) | (E_DEL << 16));
-    }
-    if (lane == 0) {                                                       // end marker right behind the last insert
-      int endPos = nPre, nextW = 0;
-      if (nMain > 0) {
-        const int wl = mainX[nMain - 1];
-        endPos = nPre + nMain + mm_count_le(delX, in.nDel, wl);
-        // wpos of the next record of the same contig, or of the last one when it closes the contig (:1387-1390)
-        nextW = (in.it0 + in.nIns < contigOff[cand.seqId + 1]) ? recW[in.it0 + in.nIns].x : wl;
+      // delta against the previous evaluated insert (lower lanes of this chunk, else the carry)
+      const uint64_t mIns = __ballot(evalIns);
+      int prevPos = posAcc;
+      {
+        const uint64_t below = mIns & ((1ull << lane) - 1ull);
+        const int src = below ? 63 - (int)__builtin_clzll(below) : lane;
+        const int p2 = __shfl(pos, src);
+        if (below) prevPos = p2;
       }
-      out[endPos] = ((uint64_t)(uint32_t)nextW << 32) | (uint64_t)(E_END << 16);
+      const int delta = evalIns ? pos - prevPos : 0;
+      const bool needSkip = evalIns && delta > (int)E_MAXDELTA;
+      if (needSkip && (delta - (int)E_MAXDELTA) >= (1 << 29)) tooWide = true;
+      const int mine = keep ? (needSkip ? 2 : 1) : 0;
+      int incl = mine;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(incl, o); if (lane >= o) incl += y; }
+      const int at = outN + incl - mine;
+      if (keep && at + mine <= cap) {
+        if (needSkip) {
+          const uint32_t extra = (uint32_t)(delta - (int)E_MAXDELTA);
+          out[at] = (E_SKIP << 14) | (extra & 0x3FFFu) | ((extra >> 14) << 17);
+          out[at + 1] = op | (E_MAXDELTA << 18);
+        } else out[at] = op | ((uint32_t)delta << 18);
+      }
+      outN += __shfl(incl, 63);
+      if (mIns) posAcc = __shfl(pos, 63 - (int)__builtin_clzll(mIns));
     }
+    if (lane == 0) {                                               // end marker: carries the wpos behind the last insert
+      int at = outN;
+      int delta = lastRel >= 0 ? nextW - posAcc : 0;
+      if (delta > (int)E_MAXDELTA) {
+        const uint32_t extra = (uint32_t)(delta - (int)E_MAXDELTA);
+        if (extra >= (1u << 29)) tooWide = true;
+        if (at < cap) out[at] = (E_SKIP << 14) | (extra & 0x3FFFu) | ((extra >> 14) << 17);
+        at++; delta = (int)E_MAXDELTA;
+      }
+      if (at < cap) out[at] = (E_END << 14) | ((uint32_t)delta << 18);
+      else tooWide = true;                                         // cannot happen: the reservation covers every event + skips
+    }
+    if (__ballot(tooWide) && lane == 0) atomicOr(&counters[6], 4ull);
   }
 }
 
@@ -237,7 +266,7 @@ k_l2_locate(int nCand, int s, int posCap, const mm_l1_candidate* __restrict__ l1
 
 __global__ void __launch_bounds__(64)
 k_l2_sweep(int nCand, int segLength, const mm_l1_candidate* __restrict__ l1, const mm_frag_stats* __restrict__ stats,
-           const int64_t* __restrict__ opOff, const int32_t* __restrict__ opCnt, const uint64_t* __restrict__ ops,
+           const int64_t* __restrict__ opOff, const int32_t* __restrict__ opCnt, const uint32_t* __restrict__ ops,
            const int64_t* __restrict__ l1Off, L2Tmp* __restrict__ tmp, mm_l2_locus* __restrict__ l2, unsigned long long l2Cap,
            unsigned long long* __restrict__ counters /* [4] l2 cursor, [5] overflow, [6] locus-slot overflow */) {
   extern __shared__ __attribute__((aligned(16))) uint16_t cell[];
@@ -248,7 +277,8 @@ k_l2_sweep(int nCand, int segLength, const mm_l1_candidate* __restrict__ l1, con
   const int f = cand.frag;
   const int S = stats[f].sketchSize;
   const uint4* src = (const uint4*)(ops + opOff[cIdx]);
-  const int nSteps = opCnt[cIdx] >> 3;                 // 8 entries = 4 x 16 bytes per step
+  const int nSteps = opCnt[cIdx] / E_STEP;             // 16 entries = 4 x 16 bytes per step
+  int posAcc = cand.rangeStartPos;                     // running position of the delta code
   const int lbase = (lane & 31) * 2 + (lane >> 5);
 #define CELL(p) cell[(p) * 64 + lbase]
   CELL(0) = 0;
@@ -333,18 +363,21 @@ k_l2_sweep(int nCand, int segLength, const mm_l1_candidate* __restrict__ l1, con
       for (int k = 0; k < 4; k++) nxt[k] = src[(size_t)(step + 1) * 4 + k];
     }
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-      const uint32_t lo = (k & 1) ? cur[k >> 1].z : cur[k >> 1].x;
-      const int wpos = (int)((k & 1) ? cur[k >> 1].w : cur[k >> 1].y);
+    for (int k = 0; k < E_STEP; k++) {
+      const uint4 v = cur[k >> 2];
+      const uint32_t e = (k & 3) == 0 ? v.x : (k & 3) == 1 ? v.y : (k & 3) == 2 ? v.z : v.w;
       if (done) continue;
-      const uint32_t type = OP_TYPE(lo);
+      const uint32_t type = OP_TYPE(e);
+      posAcc += (type == E_SKIP) ? (int)(((e >> 17) << 14) | (e & 0x3FFFu)) : ((type == E_INS || type == E_END) ? (int)(e >> 18) : 0);
+      const int wpos = posAcc;
       if (type == E_INS || type == E_END) {
         if (evalPending) { evaluate(wpos); evalPending = false; }
         if (type == E_END) { done = true; continue; }
       }
+      const uint32_t lo = (type == E_SKIP) ? 0u : e;                // a skip carries no hash
       evPrevVotes = (type == E_INS) ? lastVotes : evPrevVotes;
       apply(lo, type != E_DEL);
-      lastVotes = (type != E_DEL) ? votes : lastVotes;
+      lastVotes = (type == E_INS || type == E_PRE) ? votes : lastVotes;
       if (type == E_INS) { evW = wpos; evShared = shared; evalPending = true; }
     }
 #pragma unroll
@@ -401,26 +434,24 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt) {
   MM_HIP(c, c->dL2Cnt.ensure((size_t)nC * 4 + 64));
   MM_HIP(c, c->dL2Off.ensure((size_t)nC * 8 + 64));
   MM_HIP(c, c->dL2Tmp.ensure((size_t)nC * MM_LOCAP * sizeof(L2Tmp) + 64));
+  MM_HIP(c, hipMemsetAsync(cnt + 4, 0, 24, c->stream));
   int64_t totalOps = 0;
   {
     KernelTimer t(c, MM_K_L2_LOCATE);
     hipLaunchKernelGGL(k_l2_extents, dim3((nC + 255) / 256), dim3(256), 0, c->stream, nC, c->P.segLength, c->dL1.as<mm_l1_candidate>(),
-                       I.recW.as<int2>(), I.recEw.as<int32_t>(), I.contigOff.as<int64_t>(), c->dL2Info.as<L2Info>(), c->dL2Cnt.as<int32_t>());
+                       I.evKey.as<uint32_t>(), I.contigOff.as<int64_t>(), c->dL2Info.as<L2Info>(), c->dL2Cnt.as<int32_t>());
     MM_HIP(c, hipGetLastError());
     int rc = mm_scan_i32_to_i64(c, nC, c->dL2Cnt.as<int32_t>(), c->dL2Off.as<int64_t>(), &totalOps);
     if (rc != MM_OK) return rc;
-    MM_HIP(c, c->dL2Ops.ensure((size_t)totalOps * 8 + 256));
-    // LDS for the two position arrays of a candidate: ~4x the sketch size covers the typical candidate (2 records per
-    // sketch entry per segLength of range, both streams); longer ones search global memory
-    int posCap = 16 * s; if (posCap < 2048) posCap = 2048; if (posCap > 8192) posCap = 8192;
-    const size_t perWave = (size_t)s * 8 + (size_t)posCap * 4 + (((size_t)s + 15) & ~(size_t)15);
+    MM_HIP(c, c->dL2Ops.ensure((size_t)totalOps * 4 + 256));
+    const size_t perWave = (((size_t)s * 8 + 260 * 2 + (((size_t)s + 15) & ~(size_t)15)) + 15) & ~(size_t)15;
     const size_t ldsLoc = perWave * 4;
     MM_HIP(c, hipFuncSetAttribute((const void*)k_l2_locate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsLoc));
     int blocks = (nC + 3) / 4; if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL(k_l2_locate, dim3(blocks), dim3(256), ldsLoc, c->stream, nC, s, posCap, c->dL1.as<mm_l1_candidate>(),
-                       c->dStats.as<mm_frag_stats>(), c->dQHash.as<uint64_t>(), c->dQStrand.as<int8_t>(), I.recH.as<uint64_t>(),
-                       I.recW.as<int2>(), I.recEh.as<uint64_t>(), I.recEw.as<int32_t>(), I.contigOff.as<int64_t>(),
-                       c->dL2Info.as<L2Info>(), c->dL2Off.as<int64_t>(), c->dL2Ops.as<uint64_t>());
+    hipLaunchKernelGGL(k_l2_locate, dim3(blocks), dim3(256), ldsLoc, c->stream, nC, s, c->dL1.as<mm_l1_candidate>(),
+                       c->dStats.as<mm_frag_stats>(), c->dQHash.as<uint64_t>(), c->dQStrand.as<int8_t>(), I.evKey.as<uint32_t>(),
+                       I.evAux.as<uint32_t>(), I.evHash.as<uint64_t>(), I.contigOff.as<int64_t>(),
+                       c->dL2Info.as<L2Info>(), c->dL2Off.as<int64_t>(), c->dL2Cnt.as<int32_t>(), c->dL2Ops.as<uint32_t>(), cnt);
     MM_HIP(c, hipGetLastError());
   }
   const size_t ldsL2 = (size_t)(s + 1) * 64 * 2;          // cells 0..S
@@ -430,11 +461,11 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt) {
   unsigned long long hc[8];
   for (int attempt = 0; attempt < 8; attempt++) {
     MM_HIP(c, c->dL2.ensure(c->l2Cap * sizeof(mm_l2_locus) + 64));
-    MM_HIP(c, hipMemsetAsync(cnt + 4, 0, 24, c->stream));
+    MM_HIP(c, hipMemsetAsync(cnt + 4, 0, 16, c->stream));                  // [4] cursor [5] overflow; [6] keeps the locate kernel's flags
     {
       KernelTimer t(c, MM_K_L2);
       hipLaunchKernelGGL(k_l2_sweep, dim3((unsigned)((nC + 63) / 64)), dim3(64), ldsL2, c->stream, nC, c->P.segLength, c->dL1.as<mm_l1_candidate>(),
-                         c->dStats.as<mm_frag_stats>(), c->dL2Off.as<int64_t>(), c->dL2Cnt.as<int32_t>(), c->dL2Ops.as<uint64_t>(),
+                         c->dStats.as<mm_frag_stats>(), c->dL2Off.as<int64_t>(), c->dL2Cnt.as<int32_t>(), c->dL2Ops.as<uint32_t>(),
                          c->dL1Off.as<int64_t>(), c->dL2Tmp.as<L2Tmp>(), c->dL2.as<mm_l2_locus>(), (unsigned long long)c->l2Cap, cnt);
       MM_HIP(c, hipGetLastError());
     }
@@ -443,6 +474,7 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt) {
     if (hc[5]) { c->l2Cap = (size_t)hc[4] + (size_t)hc[4] / 8 + 1024; continue; }
     break;
   }
+  if (hc[6] & 4ull) { c->err = "a gap of more than 2^29 bases between consecutive reference minmers is not representable in the L2 stream"; return MM_ERR_ARG; }
   if (hc[6] & 2ull) { c->err = "a query hash had two open reference windows at once (index intervals of one hash overlap)"; return MM_ERR_STATE; }
   if (hc[6]) { c->err = "more than MM_LOCAP tied L2 loci for one candidate"; return MM_ERR_CAPACITY; }
   if (hc[5]) { c->err = "L2 locus buffer overflow"; return MM_ERR_CAPACITY; }

@@ -27,31 +27,40 @@ int mm_build_device_index(mm_ctx* c, const int32_t* contigLen, const int32_t* re
   DeviceIndex& I = c->idx;
   I.ready = false;
   const size_t n = c->hMinmers.size(), nk = c->hKeys.size(), np = c->hPoints.size();
-  std::vector<uint64_t> rh(n), reh(n); std::vector<int2> rw(n); std::vector<int32_t> rew(n);
+  // L2 event stream of every contig: an insert event per record at wpos (minmerIndex order) and an eviction event at
+  // wpos_end (replaces the reference's per-candidate heap of open windows, computeMap.hpp:1344-1367), merged by position;
+  // an eviction sorts before an insert at the same position because the reference evicts while wpos_end <= wpos.
+  //   evKey = pos*2 + isInsert,  evAux = insert ? (wpos_end | REV<<31) : 0,  evHash = the record's hash
+  std::vector<uint32_t> evKey(2 * n), evAux(2 * n); std::vector<uint64_t> evHash(2 * n);
   std::vector<int64_t> coff(nContigs + 1, 0);
   {
-    int32_t prevSeq = 0; size_t i = 0;
+    size_t i = 0;
     for (size_t sId = 0; sId < nContigs; sId++) {
-      coff[sId] = (int64_t)i;
+      coff[sId] = (int64_t)(2 * i);
       while (i < n && c->hMinmers[i].seqId == (int32_t)sId) i++;
-      (void)prevSeq;
     }
-    coff[nContigs] = (int64_t)i;
+    coff[nContigs] = (int64_t)(2 * i);
     if (i != n) { c->err = "mm_index_upload: minmerIndex is not grouped by ascending seqId"; return MM_ERR_ARG; }
   }
   for (size_t i = 0; i < n; i++) {
     const mm_minmer& m = c->hMinmers[i];
     if (m.wpos < 0 || m.wpos_end < 0) { c->err = "mm_index_upload: negative minmer position"; return MM_ERR_ARG; }
-    rh[i] = m.hash; rw[i] = make_int2(m.wpos, (int)((uint32_t)m.wpos_end | (m.strand < 0 ? 0x80000000u : 0u)));
   }
   {
     std::vector<uint32_t> order;
     for (size_t sId = 0; sId < nContigs; sId++) {
-      const size_t b = (size_t)coff[sId], e = (size_t)coff[sId + 1];
-      order.resize(e - b);
+      const size_t b0 = (size_t)coff[sId] / 2, e0 = (size_t)coff[sId + 1] / 2;
+      order.resize(e0 - b0);
       std::iota(order.begin(), order.end(), 0u);
-      std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return c->hMinmers[b + x].wpos_end < c->hMinmers[b + y].wpos_end; });
-      for (size_t j = 0; j < order.size(); j++) { const mm_minmer& m = c->hMinmers[b + order[j]]; reh[b + j] = m.hash; rew[b + j] = m.wpos_end; }
+      std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return c->hMinmers[b0 + x].wpos_end < c->hMinmers[b0 + y].wpos_end; });
+      size_t ii = 0, dd = 0, o = (size_t)coff[sId];
+      const size_t cnt = e0 - b0;
+      while (ii < cnt || dd < cnt) {
+        const bool takeDel = dd < cnt && (ii >= cnt || (uint32_t)c->hMinmers[b0 + order[dd]].wpos_end * 2u < (uint32_t)c->hMinmers[b0 + ii].wpos * 2u + 1u);
+        if (takeDel) { const mm_minmer& m = c->hMinmers[b0 + order[dd]]; evKey[o] = (uint32_t)m.wpos_end * 2u; evAux[o] = 0; evHash[o] = m.hash; dd++; }
+        else { const mm_minmer& m = c->hMinmers[b0 + ii]; evKey[o] = (uint32_t)m.wpos * 2u + 1u; evAux[o] = (uint32_t)m.wpos_end | (m.strand < 0 ? 0x80000000u : 0u); evHash[o] = m.hash; ii++; }
+        o++;
+      }
     }
   }
   size_t cap = 16; while (cap < 2 * nk + 2) cap <<= 1;
@@ -79,15 +88,14 @@ int mm_build_device_index(mm_ctx* c, const int32_t* contigLen, const int32_t* re
   std::vector<int32_t> grp(nContigs, 0);
   if (refGroup) grp.assign(refGroup, refGroup + nContigs);
 
-  MM_HIP(c, I.recH.ensure(n * 8 + 64)); MM_HIP(c, I.recW.ensure(n * 8 + 64)); MM_HIP(c, I.recEh.ensure(n * 8 + 64)); MM_HIP(c, I.recEw.ensure(n * 4 + 64));
+  MM_HIP(c, I.evKey.ensure(2 * n * 4 + 256)); MM_HIP(c, I.evAux.ensure(2 * n * 4 + 256)); MM_HIP(c, I.evHash.ensure(2 * n * 8 + 512));
   MM_HIP(c, I.contigOff.ensure((nContigs + 1) * 8)); MM_HIP(c, I.contigLen.ensure(nContigs * 4)); MM_HIP(c, I.refGroup.ensure(nContigs * 4));
   MM_HIP(c, I.htSlots.ensure(cap * 16)); MM_HIP(c, I.ptKeys.ensure(np * 8 + 64)); MM_HIP(c, I.filter.ensure(flt.size() * 4));
   MM_HIP(c, hipMemcpyAsync(I.filter.p, flt.data(), flt.size() * 4, hipMemcpyHostToDevice, c->stream));
   I.filterMask = fbits ? fbits - 1 : 0;
-  if (n) { MM_HIP(c, hipMemcpyAsync(I.recH.p, rh.data(), n * 8, hipMemcpyHostToDevice, c->stream));
-           MM_HIP(c, hipMemcpyAsync(I.recW.p, rw.data(), n * 8, hipMemcpyHostToDevice, c->stream));
-           MM_HIP(c, hipMemcpyAsync(I.recEh.p, reh.data(), n * 8, hipMemcpyHostToDevice, c->stream));
-           MM_HIP(c, hipMemcpyAsync(I.recEw.p, rew.data(), n * 4, hipMemcpyHostToDevice, c->stream)); }
+  if (n) { MM_HIP(c, hipMemcpyAsync(I.evKey.p, evKey.data(), 2 * n * 4, hipMemcpyHostToDevice, c->stream));
+           MM_HIP(c, hipMemcpyAsync(I.evAux.p, evAux.data(), 2 * n * 4, hipMemcpyHostToDevice, c->stream));
+           MM_HIP(c, hipMemcpyAsync(I.evHash.p, evHash.data(), 2 * n * 8, hipMemcpyHostToDevice, c->stream)); }
   MM_HIP(c, hipMemcpyAsync(I.contigOff.p, coff.data(), (nContigs + 1) * 8, hipMemcpyHostToDevice, c->stream));
   MM_HIP(c, hipMemcpyAsync(I.contigLen.p, contigLen, nContigs * 4, hipMemcpyHostToDevice, c->stream));
   MM_HIP(c, hipMemcpyAsync(I.refGroup.p, grp.data(), nContigs * 4, hipMemcpyHostToDevice, c->stream));
