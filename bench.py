@@ -152,7 +152,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads", type=int, default=int(os.environ.get("MM_BENCH_READS", 1_000_000)), help="reads per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=10000)
+    ap.add_argument("--cpu-sample", type=int, default=30000)
     args = ap.parse_args()
 
     import torch
@@ -230,11 +230,16 @@ def main():
         sk_ms, sk_n = prof["sketch"]
         frag_bytes = SEG / 4.0 + 24.0 * SKETCH
         ach = frag_bytes * nF / (sk_ms / max(1, sk_n) / 1e3) / 1e9 if sk_ms > 0 else 0.0
+        # HBM bytes per launch of that kernel from the committed PMC passes (scripts/gpu_round.sh -> scripts/pmc_to_json.py);
+        # only meaningful for the default workload the passes were taken on
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_sketch_pmc.json")
-        if os.path.exists(pmc):
+        valu_per_launch = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc) and args.reads == 1_000_000:
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                ent = json.load(open(pmc)).get("k_sketch_fragments", {})
+                traffic = ent.get("hbm_bytes_per_launch")
+                valu_per_launch = ent.get("SQ_INSTS_VALU")
             except Exception:
                 traffic = None
         kernels = {k: {"ms_per_step": v[0] / args.steps, "launches_per_step": v[1] / args.steps} for k, v in prof.items() if v[1]}
@@ -251,8 +256,13 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_sketch_fragments", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_fragment": frag_bytes, "avg_launch_ms": round(sk_ms / max(1, sk_n), 3),
-                         "note": "integer-ALU bound kernel (2 x MurmurHash3_x64_128 per base, 12 64-bit multiplies each); "
-                                 "HBM fraction is expected to be small -- see DESIGN.md for the integer roofline"},
+                         "algorithmic_bytes_per_launch": frag_bytes * nF,
+                         "note": "VALU-issue bound kernel (2 x MurmurHash3_x64_128 per base = ~260 VALU instructions per k-mer position); "
+                                 "the HBM fraction is small by construction -- DESIGN.md section 3 gives the integer roofline",
+                         "valu": None if not valu_per_launch or sk_ms <= 0 else {
+                             "wave_instructions_per_launch": valu_per_launch,
+                             "issue_utilisation": round(valu_per_launch * 4.0 / (sk_ms / max(1, sk_n) * 1e-3 * 2.4e9 * 1024), 3),
+                             "model": "1024 SIMDs x 2.4 GHz, 4 cycles per wave64 VALU instruction"}},
             "kernels": kernels,
         }
         if world == 1 and not args.no_cpu_baseline:

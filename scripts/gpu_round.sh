@@ -18,7 +18,7 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -
 find $OUT/trace -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv
 rm -f $(find $OUT/trace -name '*kernel_trace.csv')
 head -12 $OUT/kernel_stats.csv | cut -c1-200 | tee -a $OUT/log.txt
-for C in FETCH_SIZE WRITE_SIZE; do
+for C in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU; do
   echo "== pmc $C" | tee -a $OUT/log.txt
   timeout 900 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$C -o pmc -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2> $OUT/pmc_$C.err
   python scripts/pmc_summary.py $OUT/pmc_$C $C > $OUT/pmc_$C.csv 2>> $OUT/log.txt
