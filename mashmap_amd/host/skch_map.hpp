@@ -16,12 +16,16 @@
 // spread over param.threads std::threads.  Output order == input order, as in the reference (ThreadPool.hpp:187-211).
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
 #include <cstdint>
+#include <deque>
 #include <cstdlib>
 #include <fstream>
 #include <functional>
 #include <iostream>
+#include <mutex>
 #include <numeric>
 #include <set>
 #include <sstream>
@@ -106,6 +110,20 @@ class Map {
   std::vector<int> refIdGroup;
   std::unordered_map<std::string, int> refNameToId;
   mm_ctx* ctx;
+  // nucIdentityUpperBound depends only on (sharedSketchSize, Q.sketchSize); md_lower_bound is a CDF search, so the few hundred
+  // pairs that occur are computed once (a benign race: two threads may compute the same value)
+  mutable std::vector<std::atomic<uint32_t>> ubCache;
+  float identityUpperBound(float mash_dist, int shared, int Qs) const {
+    const size_t at = (size_t)Qs * (size_t)(param.sketchSize + 1) + (size_t)shared;
+    uint32_t bits = ubCache[at].load(std::memory_order_relaxed);
+    if (bits == 0xFFFFFFFFu) {
+      const float v = 1 - mmhost::Stat::md_lower_bound(mash_dist, Qs, param.kmerSize, skch::fixed::confidence_interval);
+      std::memcpy(&bits, &v, 4);
+      ubCache[at].store(bits, std::memory_order_relaxed);
+    }
+    float out; std::memcpy(&out, &bits, 4);
+    return out;
+  }
 
   struct Batch {
     std::string bases;
@@ -132,7 +150,9 @@ class Map {
 
  public:
   Map(const skch::Parameters& p, const skch::Sketch& refsketch, PostProcessResultsFn_t f = nullptr)
-      : param(p), refSketch(refsketch), processMappingResults(f), refIdGroup(refsketch.metadata.size(), 0), ctx(refsketch.ctx()) {
+      : param(p), refSketch(refsketch), processMappingResults(f), refIdGroup(refsketch.metadata.size(), 0), ctx(refsketch.ctx()),
+        ubCache((size_t)(p.sketchSize + 1) * (size_t)(p.sketchSize + 1)) {
+    for (auto& e : ubCache) e.store(0xFFFFFFFFu, std::memory_order_relaxed);      // a NaN pattern no identity can have
     if (p.skip_prefix) refIdGroup = refsketch.refGroups();
     for (size_t i = 0; i < refsketch.metadata.size(); i++) refNameToId.emplace(refsketch.metadata[i].name, (int)i);
     // integer tables the kernels consume: estimateMinimumHitsRelaxed per Q.sketchSize (:1144) and sketchCutoffs (:178-258)
@@ -165,32 +185,54 @@ class Map {
     MappingResultsVector_t allReadMappings;
     const char* be = getenv("MASHMAP_HIP_BATCH_MBP");
     const size_t batchBases = (size_t)((be ? atof(be) : 512.0) * 1e6);
-    Batch batch;
-    auto flush = [&]() {
-      if (batch.size() == 0) return;
-      processBatch(batch, allReadMappings, totalReadsMapped, outstrm);
-      batch.clear(seqCounter);
-    };
-    for (const auto& fileName : param.querySequences) {
-      mmhost::for_each_seq_in_file(fileName, {}, "", [&](const std::string& name, std::string& seq) {
-        const offset_t len = (offset_t)seq.length();
-        totalBp += seq.length();
-        if (param.filterMode == filter::ONETOONE) qmetadata.push_back(ContigInfo{name, len});
-        if (len < param.kmerSize) {
-          std::cerr << std::endl << "WARNING, skch::Map::mapQuery, read " << name << " of " << len << "bp "
-                    << " is not long enough for mapping at segment length " << param.segLength << std::endl;
-        } else {
-          totalReadsPickedForMapping++;
-        }
-        // short reads travel too (they yield no fragment) so that seqCounter == firstSeqCounter + index inside the batch
-        batch.names.push_back(name);
-        batch.bases.append(seq);
-        batch.offs.push_back((int64_t)batch.bases.size());
-        seqCounter++;
-        if (batch.bases.size() >= batchBases) flush();
-      });
+    // reader thread: parses the query files into batches (at most two waiting) while this thread drives the device pass and
+    // the host post-processing of the previous batch
+    std::deque<Batch> ready; std::mutex mu; std::condition_variable cvFull, cvEmpty; bool readerDone = false;
+    std::thread reader([&]() {
+      Batch batch;
+      auto flush = [&]() {
+        if (batch.size() == 0) return;
+        std::unique_lock<std::mutex> lk(mu);
+        cvFull.wait(lk, [&] { return ready.size() < 2; });
+        ready.emplace_back(std::move(batch));
+        lk.unlock(); cvEmpty.notify_one();
+        batch = Batch(); batch.clear(seqCounter);
+      };
+      for (const auto& fileName : param.querySequences) {
+        mmhost::for_each_seq_in_file(fileName, {}, "", [&](const std::string& name, std::string& seq) {
+          const offset_t len = (offset_t)seq.length();
+          totalBp += seq.length();
+          if (param.filterMode == filter::ONETOONE) qmetadata.push_back(ContigInfo{name, len});
+          if (len < param.kmerSize) {
+            std::cerr << std::endl << "WARNING, skch::Map::mapQuery, read " << name << " of " << len << "bp "
+                      << " is not long enough for mapping at segment length " << param.segLength << std::endl;
+          } else {
+            totalReadsPickedForMapping++;
+          }
+          // short reads travel too (they yield no fragment) so that seqCounter == firstSeqCounter + index inside the batch
+          batch.names.push_back(name);
+          batch.bases.append(seq);
+          batch.offs.push_back((int64_t)batch.bases.size());
+          seqCounter++;
+          if (batch.bases.size() >= batchBases) flush();
+        });
+      }
+      flush();
+      { std::lock_guard<std::mutex> lk(mu); readerDone = true; }
+      cvEmpty.notify_one();
+    });
+    while (true) {
+      Batch cur;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cvEmpty.wait(lk, [&] { return !ready.empty() || readerDone; });
+        if (ready.empty()) break;
+        cur = std::move(ready.front()); ready.pop_front();
+      }
+      cvFull.notify_one();
+      processBatch(cur, allReadMappings, totalReadsMapped, outstrm);
     }
-    flush();
+    reader.join();
 
     if (param.filterMode == filter::ONETOONE) {            // :358-406
       const int n_mappings = (int)param.numMappingsForSegment - 1;
@@ -225,6 +267,14 @@ class Map {
   // one device pass + the per-read host post-processing of a batch
   void processBatch(const Batch& batch, MappingResultsVector_t& allReadMappings, seqno_t& totalReadsMapped, std::ofstream& outstrm) {
     const size_t nReads = batch.size();
+    const bool timing = getenv("MASHMAP_HIP_TIMING") != nullptr;
+    auto tick = skch::Time::now();
+    auto lap = [&](const char* what) {
+      if (!timing) return;
+      const auto now = skch::Time::now();
+      std::cerr << "[mashmap_hip::timing] " << what << ": " << std::chrono::duration<double>(now - tick).count() << " s" << std::endl;
+      tick = now;
+    };
     std::vector<int32_t> readGroup, readSelf;
     if (param.skip_prefix) { readGroup.resize(nReads); for (size_t r = 0; r < nReads; r++) readGroup[r] = getRefGroup(batch.names[r]); }
     if (param.skip_self) {
@@ -233,7 +283,9 @@ class Map {
     }
     if (mm_reads_upload(ctx, batch.bases.data(), batch.offs.data(), nReads, param.skip_prefix ? readGroup.data() : nullptr,
                         param.skip_self ? readSelf.data() : nullptr, batch.firstSeqCounter) != MM_OK) die("mm_reads_upload");
+    lap("upload + pack");
     if (mm_map_fragments(ctx) != MM_OK) die("mm_map_fragments");
+    lap("device pass");
     DeviceResults D;
     size_t n1 = 0, n2 = 0;
     if (mm_result_counts(ctx, &n1, &n2) != MM_OK) die("mm_result_counts");
@@ -248,6 +300,7 @@ class Map {
     D.l2Begin.assign(n1 + 1, n2);
     { size_t i = 0; for (size_t c = 0; c <= n1; c++) { while (i < n2 && (size_t)D.l2[i].cand < c) i++; D.l2Begin[c] = i; } }
 
+    lap("download");
     std::vector<MappingResultsVector_t> perRead(nReads);
     std::vector<std::string> text(nReads);
     const bool reportNow = param.filterMode != filter::ONETOONE;
@@ -266,6 +319,7 @@ class Map {
     work(0);
     for (auto& th : pool) th.join();
 
+    lap("host replay + chain + filter");
     for (size_t r = 0; r < nReads; r++) {                  // mapModuleHandleOutput (:724-752), input order
       if (!perRead[r].empty()) totalReadsMapped++;
       if (!reportNow) allReadMappings.insert(allReadMappings.end(), perRead[r].begin(), perRead[r].end());
@@ -296,7 +350,7 @@ class Map {
         const mm_l2_locus& l2 = D.l2[i];
         const float mash_dist = mmhost::Stat::j2md(1.0 * l2.sharedSketchSize / Qs, param.kmerSize);
         const float nucIdentity = (1 - mash_dist);
-        const float nucIdentityUpperBound = 1 - mmhost::Stat::md_lower_bound(mash_dist, Qs, param.kmerSize, skch::fixed::confidence_interval);
+        const float nucIdentityUpperBound = identityUpperBound(mash_dist, l2.sharedSketchSize, Qs);
         if ((param.keep_low_pct_id && nucIdentityUpperBound >= param.percentageIdentity) || nucIdentity >= param.percentageIdentity) {
           bestJaccardNumerator = std::max<double>(bestJaccardNumerator, l2.sharedSketchSize);
           MappingResult res{};                 // n_merged / splitMappingId / discard are indeterminate in the reference (:1227); zero is what its

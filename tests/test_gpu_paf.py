@@ -67,3 +67,30 @@ def test_paf_independent_of_batching_and_threads(tmp_path):
     finally:
         del os.environ["MASHMAP_HIP_BATCH_MBP"]
     assert a == b
+
+
+def test_paf_from_gzipped_fastq_queries(tmp_path):
+    """the host reader (mashmap_amd/host/seq_reader.hpp): FASTQ and gzip give the same PAF as the FASTA of the same reads"""
+    import gzip
+    _, refrec, qrec, extra = CASES["default"]
+    rf = str(tmp_path / "ref.fa.gz")
+    with gzip.open(rf, "wb") as f:
+        for n, a in refrec:
+            f.write(b">" + n.encode() + b" some description\n" + a.tobytes() + b"\n")
+    qf = str(tmp_path / "q.fq.gz")
+    with gzip.open(qf, "wb") as f:
+        for n, a in qrec:
+            f.write(b"@" + n.encode() + b" extra words\n" + a.tobytes() + b"\n+\n" + b"I" * len(a) + b"\n")
+    out = str(tmp_path / "o.paf")
+    # the reference derives the sketch size from the reference FILE size (compressed here): pin it to what the fixture used
+    p = subprocess.run([HIP_BIN, "-r", rf, "-q", qf, "-o", out, "-t", "3", "-J", str(_fixture_sketch_size())], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert open(out, "rb").read() == open(os.path.join(PAF_DIR, "default.paf"), "rb").read()
+
+
+def _fixture_sketch_size():
+    """sketch size mashmap derives for the uncompressed FASTA of the 'default' case (what produced tests/golden/paf/default.paf)"""
+    from mashmap_amd import capi
+    _, refrec, _, _ = CASES["default"]
+    nbytes = sum(len(n) + 2 + len(a) + (len(a) + 79) // 80 for n, a in refrec)        # U.write_fasta: 80 columns
+    return int(capi.load().mm_stat_recommended_sketch_size(19, 0.85, 5000, nbytes))
