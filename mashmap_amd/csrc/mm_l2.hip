@@ -23,7 +23,7 @@
 #include "mm_internal.h"
 #include "mm_device.h"
 
-#define MM_LOCAP 8          // private L2 locus slots per candidate before the final compaction
+#define MM_LOCAP0 8         // private L2 locus slots per candidate before the final compaction (doubled and re-run on overflow)
 
 struct L2Info { int64_t e0; int32_t nPre; int32_t nAll; };      // slice [e0, e0+nAll) of the contig's events, the first nPre before rangeStart
 struct L2Tmp { int32_t start, end, shared, strand; };
@@ -267,7 +267,7 @@ k_l2_locate(int nCand, int s, const mm_l1_candidate* __restrict__ l1, const mm_f
 __global__ void __launch_bounds__(64)
 k_l2_sweep(int nCand, int segLength, const mm_l1_candidate* __restrict__ l1, const mm_frag_stats* __restrict__ stats,
            const int64_t* __restrict__ opOff, const int32_t* __restrict__ opCnt, const uint32_t* __restrict__ ops,
-           const int64_t* __restrict__ l1Off, L2Tmp* __restrict__ tmp, mm_l2_locus* __restrict__ l2, unsigned long long l2Cap,
+           const int64_t* __restrict__ l1Off, L2Tmp* __restrict__ tmp, int locap, mm_l2_locus* __restrict__ l2, unsigned long long l2Cap,
            unsigned long long* __restrict__ counters /* [4] l2 cursor, [5] overflow, [6] locus-slot overflow */) {
   extern __shared__ __attribute__((aligned(16))) uint16_t cell[];
   const int lane = threadIdx.x;
@@ -324,11 +324,11 @@ k_l2_sweep(int nCand, int segLength, const mm_l1_candidate* __restrict__ l1, con
   int bestShared = 1; bool inRun = false;
   int curStart = 0, curEnd = 0, curShared = 0;
   int nFlushed = 0; bool havePend = false; L2Tmp pend{0, 0, 0, 0};
-  L2Tmp* mySlots = tmp + (size_t)cIdx * MM_LOCAP;
+  L2Tmp* mySlots = tmp + (size_t)cIdx * locap;
   bool slotOverflow = false;
   auto close_run = [&](int strand) {                   // :1417-1426 / :1440-1449
     if (!havePend || pend.end + segLength < curStart) {
-      if (havePend) { if (nFlushed < MM_LOCAP) mySlots[nFlushed] = pend; else slotOverflow = true; nFlushed++; }
+      if (havePend) { if (nFlushed < locap) mySlots[nFlushed] = pend; else slotOverflow = true; nFlushed++; }
       pend.start = curStart; pend.end = curEnd; pend.shared = curShared; pend.strand = strand; havePend = true;
     } else {
       pend.end = curEnd;
@@ -433,7 +433,6 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt) {
   MM_HIP(c, c->dL2Info.ensure((size_t)nC * sizeof(L2Info) + 64));
   MM_HIP(c, c->dL2Cnt.ensure((size_t)nC * 4 + 64));
   MM_HIP(c, c->dL2Off.ensure((size_t)nC * 8 + 64));
-  MM_HIP(c, c->dL2Tmp.ensure((size_t)nC * MM_LOCAP * sizeof(L2Tmp) + 64));
   MM_HIP(c, hipMemsetAsync(cnt + 4, 0, 24, c->stream));
   int64_t totalOps = 0;
   {
@@ -459,24 +458,35 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt) {
   MM_HIP(c, hipFuncSetAttribute((const void*)k_l2_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsL2));
   if (c->l2Cap < c->nL1 * 2 + 1024) c->l2Cap = c->nL1 * 2 + 1024;
   unsigned long long hc[8];
-  for (int attempt = 0; attempt < 8; attempt++) {
+  int locap = MM_LOCAP0;
+  for (int attempt = 0; attempt < 24; attempt++) {
     MM_HIP(c, c->dL2.ensure(c->l2Cap * sizeof(mm_l2_locus) + 64));
-    MM_HIP(c, hipMemsetAsync(cnt + 4, 0, 16, c->stream));                  // [4] cursor [5] overflow; [6] keeps the locate kernel's flags
+    MM_HIP(c, c->dL2Tmp.ensure((size_t)nC * locap * sizeof(L2Tmp) + 64));
+    const unsigned long long keep = 6ull;                                  // [6] bits 1,2 belong to this launch; bit 4 is the locate kernel's
+    MM_HIP(c, hipMemsetAsync(cnt + 4, 0, 16, c->stream));                  // [4] cursor [5] overflow
+    (void)keep;
     {
       KernelTimer t(c, MM_K_L2);
       hipLaunchKernelGGL(k_l2_sweep, dim3((unsigned)((nC + 63) / 64)), dim3(64), ldsL2, c->stream, nC, c->P.segLength, c->dL1.as<mm_l1_candidate>(),
                          c->dStats.as<mm_frag_stats>(), c->dL2Off.as<int64_t>(), c->dL2Cnt.as<int32_t>(), c->dL2Ops.as<uint32_t>(),
-                         c->dL1Off.as<int64_t>(), c->dL2Tmp.as<L2Tmp>(), c->dL2.as<mm_l2_locus>(), (unsigned long long)c->l2Cap, cnt);
+                         c->dL1Off.as<int64_t>(), c->dL2Tmp.as<L2Tmp>(), locap, c->dL2.as<mm_l2_locus>(), (unsigned long long)c->l2Cap, cnt);
       MM_HIP(c, hipGetLastError());
     }
     MM_HIP(c, hipMemcpyAsync(hc, cnt, 64, hipMemcpyDeviceToHost, c->stream));
     MM_HIP(c, hipStreamSynchronize(c->stream));
+    if (hc[6] & 1ull) {                                                    // a candidate with more tied loci than slots (tandem repeats): more slots, again
+      if ((size_t)nC * (size_t)locap * 2 * sizeof(L2Tmp) > ((size_t)64 << 30)) break;
+      locap *= 2;
+      const unsigned long long flags = hc[6] & ~1ull;
+      MM_HIP(c, hipMemcpyAsync(cnt + 6, &flags, 8, hipMemcpyHostToDevice, c->stream));
+      continue;
+    }
     if (hc[5]) { c->l2Cap = (size_t)hc[4] + (size_t)hc[4] / 8 + 1024; continue; }
     break;
   }
   if (hc[6] & 4ull) { c->err = "a gap of more than 2^29 bases between consecutive reference minmers is not representable in the L2 stream"; return MM_ERR_ARG; }
   if (hc[6] & 2ull) { c->err = "a query hash had two open reference windows at once (index intervals of one hash overlap)"; return MM_ERR_STATE; }
-  if (hc[6]) { c->err = "more than MM_LOCAP tied L2 loci for one candidate"; return MM_ERR_CAPACITY; }
+  if (hc[6] & 1ull) { c->err = "an L1 candidate with more tied L2 loci than 64 GiB of staging can hold"; return MM_ERR_CAPACITY; }
   if (hc[5]) { c->err = "L2 locus buffer overflow"; return MM_ERR_CAPACITY; }
   c->nL2 = (size_t)hc[4];
   return MM_OK;

@@ -96,3 +96,40 @@ def run_and_compare(oracle, contigs, reads, k=19, L=5000, s=130, pi=0.85, flags=
     oracle.free(h)
     assert not bad, "GPU vs oracle mismatches: %r over %d fragments" % (bad, nF)
     return nF, nloci
+
+
+def fuzz_scenario(seed0, it):
+    """a random but reproducible (k, segLength, sketchSize, pi, flags, error rate, genome shape) scenario for run_and_compare"""
+    r = U.splitmix64(seed0 * 7919 + it, 16)
+    pick = lambda i, xs: xs[int(r[i] % np.uint64(len(xs)))]
+    k = pick(0, [15, 16, 17, 19, 19, 19, 21, 24])
+    L = pick(1, [500, 1000, 2000, 5000, 5000, 10000])
+    s = pick(2, [10, 20, 40, 64, 65, 128, 130, 130, 200, 310, 498])
+    if s > (L - k) // 4: s = max(5, (L - k) // 8)
+    pi = pick(3, [0.80, 0.85, 0.85, 0.90, 0.95])
+    err = pick(4, [0.0, 0.02, 0.05, 0.10, 0.15])
+    flags = pick(5, [U.FLAG_HG, U.FLAG_HG, 0, U.FLAG_HG | U.FLAG_SKIP_SELF, U.FLAG_HG | U.FLAG_LOWER_TRI])
+    nct = pick(6, [1, 2, 3, 5])
+    shape = pick(7, ["random", "random", "repeat", "tandem", "nruns", "dup"])
+    kmerPct = pick(8, [0.001, 0.001, 0.0, 0.5])
+    sizes = [int(40 * L + (int(r[9 + i % 4]) % (60 * L))) for i in range(nct)]
+    cs = []
+    for i, n in enumerate(sizes):
+        a = U.random_dna(1000 * it + i + seed0 * 100000, n)
+        if shape == "repeat":
+            unit = a[:max(3 * L, n // 12)]
+            a = np.concatenate([U.mutate(unit, 50 + j, 0.01) for j in range(max(2, n // len(unit)))])[:n]
+        elif shape == "tandem" and i == 0:
+            a = U.tandem_repeat(it, n, int(r[13] % np.uint64(900)) + 5)
+        elif shape == "nruns":
+            a = U.with_n_runs(a, it, 6, int(L // 3) + 7); a[3] = ord("N")
+        cs.append(a)
+    if shape == "dup" and nct > 1:
+        blk = U.mutate(cs[0][:8 * L], 5, 0.03); cs[1][:len(blk)] = blk[:len(cs[1])][:len(blk)]
+    contigs = [("c%d" % i, a) for i, a in enumerate(cs)]
+    rl = pick(10, [L, 2 * L, 2 * L + 123, 3 * L + 1, L // 2 + 10])
+    reads = [(n_, a) for n_, a, _ in U.sample_reads(cs, it + 3, 40, min(rl, min(len(c) for c in cs)), err)]
+    if flags & (U.FLAG_SKIP_SELF | U.FLAG_LOWER_TRI):
+        reads = [(contigs[i % nct][0] if i % 3 == 0 else n_, a) for i, (n_, a) in enumerate(reads)]
+    desc = dict(it=it, k=k, L=L, s=s, pi=pi, err=err, flags=flags, nct=nct, shape=shape, kmerPct=kmerPct, rl=rl)
+    return contigs, reads, dict(k=k, L=L, s=s, pi=pi, flags=flags, kmerPct=kmerPct), desc

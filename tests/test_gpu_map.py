@@ -89,3 +89,12 @@ def test_map_repetitive_reference_many_points(oracle):
     contigs = [("rep", c0), ("uniq", U.random_dna(82, 200000))]
     reads = reads_for(contigs, 11, 30, 10000, 0.05)
     run_and_compare(oracle, contigs, reads, kmerPct=0.0)
+
+
+@pytest.mark.parametrize("seed0,it", [(1, 42), (1, 29), (1, 36), (1, 52)] + [(2, i) for i in range(8)])
+def test_map_fuzz_scenarios(oracle, seed0, it):
+    """reproducible random scenarios (scripts/fuzz_parity.py runs the long campaign); (1, 42) is a tandem-repeat reference whose
+    candidates have more tied L2 loci than the first slot allocation holds"""
+    from gpucheck import fuzz_scenario
+    contigs, reads, kw, desc = fuzz_scenario(seed0, it)
+    run_and_compare(oracle, contigs, reads, verbose=True, **kw)
