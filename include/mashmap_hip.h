@@ -167,8 +167,10 @@ int mm_query_sketch_download(mm_ctx* ctx, mm_minmer* out);
  * Options.  MM_OPT_KEEP_POINTS (default 0): by default the interval points of a fragment (getSeedIntervalPoints,
  * computeMap.hpp:857) live only in LDS/registers between the seed lookup and the L1 sweep; with 1 every fragment's sorted
  * point list is also kept in HBM so that mm_points_download can return it (parity tests).
+ * MM_OPT_KEEP_FULL_INDEX (default 0): keep minmerIndex as it is BEFORE dropFreqSeedSet (winSketch.hpp:497) on the host so that
+ * mm_index_download_full can return it -- that is what --saveIndex writes (winSketch.hpp:127-134 run before the drop).
  */
-enum { MM_OPT_KEEP_POINTS = 1 };
+enum { MM_OPT_KEEP_POINTS = 1, MM_OPT_KEEP_FULL_INDEX = 2 };
 int mm_set_option(mm_ctx* ctx, int option, int value);
 /* sorted, filtered interval points of fragment f (needs MM_OPT_KEEP_POINTS; (seqId,pos,side) only, hash = 0) */
 int mm_points_download(mm_ctx* ctx, size_t frag, mm_interval_point* out, size_t cap, size_t* n);
@@ -189,6 +191,17 @@ int mm_index_build(mm_ctx* ctx, const char* bases, const int64_t* contigOffsets,
 int mm_index_sizes(const mm_ctx* ctx, size_t* nMinmers, size_t* nKeys, size_t* nPoints, size_t* nFreq, int32_t* freqThreshold);
 int mm_index_download(mm_ctx* ctx, mm_minmer* minmers, uint64_t* keys, uint64_t* offsets, mm_interval_point* points,
                       uint64_t* freqSeeds);
+
+/*
+ * Index persistence (winSketch.hpp:284-374).  mm_index_download_full: the pre-drop minmerIndex (PREFIX.index); the lookup map of
+ * mm_index_download is already the full one (PREFIX.map).  mm_index_upload_full: what --loadIndex reads -- the pre-drop
+ * minmerIndex and the map, flattened as for mm_index_upload, keys in any order -- followed inside the library by
+ * computeFreqHist / computeFreqSeedSet / dropFreqSeedSet (:410-504), exactly the steps the reference runs after loading.
+ */
+int mm_index_download_full(mm_ctx* ctx, mm_minmer* out, size_t* n);
+int mm_index_upload_full(mm_ctx* ctx, const mm_minmer* minmersAll, size_t nMinmers, const uint64_t* keys, const uint64_t* offsets,
+                         size_t nKeys, const mm_interval_point* points, size_t nPoints, const int32_t* contigLen,
+                         const int32_t* refGroup, size_t nContigs, float kmerPctThreshold);
 
 /* per-kernel device timing, measured with hipEvents on the ctx stream (bench.py roofline leg) */
 enum { MM_K_PACK = 0, MM_K_SKETCH, MM_K_SKETCH_HARD, MM_K_LOOKUP, MM_K_SORT, MM_K_L1, MM_K_L2, MM_K_REFHASH, MM_K_L2_LOCATE, MM_K_WINNOW, MM_K_COUNT };

@@ -89,6 +89,8 @@ def load():
         "mm_index_sizes": (C.c_int, [vp, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz), C.POINTER(sz), C.POINTER(i32)]),
         "mm_index_download": (C.c_int, [vp, vp, vp, vp, vp, vp]),
         "mm_set_option": (C.c_int, [vp, C.c_int, C.c_int]),
+        "mm_index_download_full": (C.c_int, [vp, vp, C.POINTER(sz)]),
+        "mm_index_upload_full": (C.c_int, [vp, vp, sz, vp, vp, sz, vp, sz, vp, vp, sz, C.c_float]),
         "mm_profile_enable": (C.c_int, [vp, C.c_int]),
         "mm_profile_read": (C.c_int, [vp, vp, vp, C.c_int]),
         "mm_kernel_name": (C.c_char_p, [C.c_int]),
@@ -109,7 +111,7 @@ EXPORTS = ["mm_abi_version", "mm_create", "mm_destroy", "mm_last_error", "mm_ind
            "mm_reads_upload", "mm_reads_upload_device", "mm_num_fragments", "mm_fragments_download",
            "mm_sketch_fragments", "mm_sketch_download", "mm_map_fragments", "mm_result_counts",
            "mm_results_download", "mm_query_sketch_download", "mm_points_download", "mm_results_device",
-           "mm_index_build", "mm_index_sizes", "mm_index_download", "mm_set_option", "mm_profile_enable", "mm_profile_read",
+           "mm_index_build", "mm_index_sizes", "mm_index_download", "mm_set_option", "mm_index_download_full", "mm_index_upload_full", "mm_profile_enable", "mm_profile_read",
            "mm_kernel_name", "mm_synchronize", "mm_stream"]
 
 

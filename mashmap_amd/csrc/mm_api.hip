@@ -67,6 +67,7 @@ void* mm_stream(const mm_ctx* c) { return (void*)c->stream; }
 
 int mm_set_option(mm_ctx* c, int option, int value) {
   if (option == MM_OPT_KEEP_POINTS) { c->keepPoints = value != 0; c->ptsCap = 0; return MM_OK; }
+  if (option == MM_OPT_KEEP_FULL_INDEX) { c->keepFullIndex = value != 0; return MM_OK; }
   c->err = "mm_set_option: unknown option"; return MM_ERR_ARG;
 }
 

@@ -19,6 +19,7 @@
 #include <memory>
 #include <thread>
 #include <map>
+#include <numeric>
 #include <queue>
 #include <unordered_map>
 
@@ -190,6 +191,83 @@ static HashContigFn pick_hasher(int k) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Second half of the index build, shared by mm_index_build and mm_index_upload_full (--loadIndex):
+//   Sketch::index (winSketch.hpp:379-404) unless the lookup map is supplied, computeFreqHist / computeFreqSeedSet /
+//   dropFreqSeedSet (:410-504), then the flat device index.  `all` is minmerIndex BEFORE the frequent-seed drop.
+// ---------------------------------------------------------------------------------------------
+static int finalize_index(mm_ctx* c, std::vector<mm_minmer>& all, bool haveMap, float kmerPctThreshold, const int32_t* contigLen,
+                          const int32_t* refGroup, size_t nContigs) {
+  if (!haveMap) {
+    // Grouping by hash with the records of a hash in minmerIndex order is a stable sort of (hash, index) pairs; the map's
+    // "previous point of this hash ends where this record starts" test (winSketch.hpp:388-396) then only looks at the
+    // neighbour.  Keys come out ascending, which is the order mm_index_download promises.
+    const size_t nAll = all.size();
+    std::vector<std::pair<uint64_t, uint32_t>> byHash(nAll);
+    {
+      const unsigned T = (unsigned)std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), std::max<size_t>(1, nAll / 65536));
+      std::vector<size_t> cut(T + 1);
+      for (unsigned t = 0; t <= T; t++) cut[t] = nAll * t / T;
+      std::vector<std::future<void>> jobs;
+      for (unsigned t = 0; t < T; t++)
+        jobs.push_back(std::async(std::launch::async, [&, t]() {
+          for (size_t i = cut[t]; i < cut[t + 1]; i++) byHash[i] = std::make_pair(all[i].hash, (uint32_t)i);
+          std::sort(byHash.begin() + cut[t], byHash.begin() + cut[t + 1]);
+        }));
+      for (auto& j : jobs) j.get();
+      for (unsigned width = 1; width < T; width *= 2) {                      // pairwise merges, each level in parallel
+        jobs.clear();
+        for (unsigned t = 0; t + width < T; t += 2 * width) {
+          const size_t lo = cut[t], mid = cut[t + width], hi = cut[std::min(T, t + 2 * width)];
+          jobs.push_back(std::async(std::launch::async, [&, lo, mid, hi]() { std::inplace_merge(byHash.begin() + lo, byHash.begin() + mid, byHash.begin() + hi); }));
+        }
+        for (auto& j : jobs) j.get();
+      }
+    }
+    c->hKeys.clear(); c->hOffsets.clear(); c->hPoints.clear(); c->hFreq.clear();
+    c->hPoints.reserve(2 * nAll);
+    for (size_t i = 0; i < nAll;) {                                          // Sketch::index (winSketch.hpp:379-404)
+      const uint64_t key = byHash[i].first;
+      c->hKeys.push_back(key); c->hOffsets.push_back((uint64_t)c->hPoints.size());
+      for (; i < nAll && byHash[i].first == key; i++) {
+        const mm_minmer& mi = all[byHash[i].second];
+        if (c->hPoints.size() == c->hOffsets.back() || c->hPoints.back().pos != mi.wpos) {
+          mm_interval_point a2; std::memset(&a2, 0, sizeof a2); a2.pos = mi.wpos; a2.hash = mi.hash; a2.seqId = mi.seqId; a2.side = 1;
+          mm_interval_point b2 = a2; b2.pos = mi.wpos_end; b2.side = -1;
+          c->hPoints.push_back(a2); c->hPoints.push_back(b2);
+        } else c->hPoints.back().pos = mi.wpos_end;
+      }
+    }
+    c->hOffsets.push_back((uint64_t)c->hPoints.size());
+    std::vector<std::pair<uint64_t, uint32_t>>().swap(byHash);
+  }
+  // frequency filter (winSketch.hpp:410-504)
+  int32_t freqThreshold = 0x7fffffff;
+  const size_t nKeysAll = c->hKeys.size();
+  if (nKeysAll) {
+    std::map<int, int64_t> hist;
+    for (size_t i = 0; i < nKeysAll; i++) hist[(int)(c->hOffsets[i + 1] - c->hOffsets[i])] += 1;
+    const int64_t total = (int64_t)nKeysAll;
+    const int64_t toIgnore = (int64_t)(total * kmerPctThreshold / 100);      // int64 * float / int, as winSketch.hpp:425
+    int64_t sum = 0;
+    for (auto it = hist.rbegin(); it != hist.rend(); ++it) {
+      sum += it->second;
+      if (sum < toIgnore) freqThreshold = it->first;
+      else if (sum == toIgnore) { freqThreshold = it->first; break; }
+      else break;
+    }
+  }
+  for (size_t i = 0; i < nKeysAll; i++)
+    if ((int64_t)(c->hOffsets[i + 1] - c->hOffsets[i]) >= (int64_t)freqThreshold) c->hFreq.push_back(c->hKeys[i]);
+  if (c->keepFullIndex) c->hMinmersAll = all; else std::vector<mm_minmer>().swap(c->hMinmersAll);
+  if (!c->hFreq.empty())
+    all.erase(std::remove_if(all.begin(), all.end(), [&](const mm_minmer& m) { return std::binary_search(c->hFreq.begin(), c->hFreq.end(), m.hash); }), all.end());
+  c->hMinmers.swap(all);
+  c->freqThreshold = freqThreshold;
+  c->mapped = false;
+  return mm_build_device_index(c, contigLen, refGroup, nContigs);
+}
+
 extern "C" int mm_index_build(mm_ctx* c, const char* bases, const int64_t* contigOffsets, size_t nContigs, const int32_t* refGroup,
                               float kmerPctThreshold) {
   if (!bases || !contigOffsets || !nContigs) { c->err = "mm_index_build: null argument"; return MM_ERR_ARG; }
@@ -229,69 +307,38 @@ extern "C" int mm_index_build(mm_ctx* c, const char* bases, const int64_t* conti
   // Sketch::index (winSketch.hpp:379-404): per-hash OPEN/CLOSE points in minmerIndex order, adjacent runs merged
   std::vector<mm_minmer> all;
   { size_t tot = 0; for (auto& v : per) tot += v.size(); all.reserve(tot); for (auto& v : per) { all.insert(all.end(), v.begin(), v.end()); std::vector<mm_minmer>().swap(v); } }
-  // Grouping by hash with the records of a hash in minmerIndex order is a stable sort of (hash, index) pairs; the map's
-  // "previous point of this hash ends where this record starts" test (winSketch.hpp:388-396) then only looks at the
-  // neighbour.  Keys come out ascending, which is the order mm_index_download promises.
-  const size_t nAll = all.size();
-  std::vector<std::pair<uint64_t, uint32_t>> byHash(nAll);
-  {
-    const unsigned T = (unsigned)std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), std::max<size_t>(1, nAll / 65536));
-    std::vector<size_t> cut(T + 1);
-    for (unsigned t = 0; t <= T; t++) cut[t] = nAll * t / T;
-    std::vector<std::future<void>> jobs;
-    for (unsigned t = 0; t < T; t++)
-      jobs.push_back(std::async(std::launch::async, [&, t]() {
-        for (size_t i = cut[t]; i < cut[t + 1]; i++) byHash[i] = std::make_pair(all[i].hash, (uint32_t)i);
-        std::sort(byHash.begin() + cut[t], byHash.begin() + cut[t + 1]);
-      }));
-    for (auto& j : jobs) j.get();
-    for (unsigned width = 1; width < T; width *= 2) {                      // pairwise merges, each level in parallel
-      jobs.clear();
-      for (unsigned t = 0; t + width < T; t += 2 * width) {
-        const size_t lo = cut[t], mid = cut[t + width], hi = cut[std::min(T, t + 2 * width)];
-        jobs.push_back(std::async(std::launch::async, [&, lo, mid, hi]() { std::inplace_merge(byHash.begin() + lo, byHash.begin() + mid, byHash.begin() + hi); }));
-      }
-      for (auto& j : jobs) j.get();
-    }
+  return finalize_index(c, all, false, kmerPctThreshold, clen.data(), refGroup, nContigs);
+}
+
+extern "C" int mm_index_upload_full(mm_ctx* c, const mm_minmer* minmersAll, size_t nMinmers, const uint64_t* keys, const uint64_t* offsets,
+                                    size_t nKeys, const mm_interval_point* points, size_t nPoints, const int32_t* contigLen,
+                                    const int32_t* refGroup, size_t nContigs, float kmerPctThreshold) {
+  if ((nMinmers && !minmersAll) || (nKeys && (!keys || !offsets)) || (nPoints && !points) || !contigLen || !nContigs) {
+    c->err = "mm_index_upload_full: null argument"; return MM_ERR_ARG;
   }
+  if (nKeys && offsets[nKeys] != nPoints) { c->err = "mm_index_upload_full: offsets[nKeys] != nPoints"; return MM_ERR_ARG; }
+  MM_HIP(c, hipSetDevice(c->device));
+  std::vector<mm_minmer> all(minmersAll, minmersAll + nMinmers);
+  // the saved map comes in the saving program's iteration order: put the keys in ascending order (what mm_index_download promises)
+  std::vector<uint32_t> ord(nKeys);
+  std::iota(ord.begin(), ord.end(), 0u);
+  std::sort(ord.begin(), ord.end(), [&](uint32_t x, uint32_t y) { return keys[x] < keys[y]; });
   c->hKeys.clear(); c->hOffsets.clear(); c->hPoints.clear(); c->hFreq.clear();
-  c->hPoints.reserve(2 * nAll);
-  for (size_t i = 0; i < nAll;) {                                          // Sketch::index (winSketch.hpp:379-404)
-    const uint64_t key = byHash[i].first;
-    c->hKeys.push_back(key); c->hOffsets.push_back((uint64_t)c->hPoints.size());
-    for (; i < nAll && byHash[i].first == key; i++) {
-      const mm_minmer& mi = all[byHash[i].second];
-      if (c->hPoints.size() == c->hOffsets.back() || c->hPoints.back().pos != mi.wpos) {
-        mm_interval_point a2; std::memset(&a2, 0, sizeof a2); a2.pos = mi.wpos; a2.hash = mi.hash; a2.seqId = mi.seqId; a2.side = 1;
-        mm_interval_point b2 = a2; b2.pos = mi.wpos_end; b2.side = -1;
-        c->hPoints.push_back(a2); c->hPoints.push_back(b2);
-      } else c->hPoints.back().pos = mi.wpos_end;
-    }
+  c->hKeys.reserve(nKeys); c->hOffsets.reserve(nKeys + 1); c->hPoints.reserve(nPoints);
+  for (size_t i = 0; i < nKeys; i++) {
+    const uint32_t j = ord[i];
+    if (i && keys[j] == c->hKeys.back()) { c->err = "mm_index_upload_full: duplicate key"; return MM_ERR_ARG; }
+    c->hKeys.push_back(keys[j]); c->hOffsets.push_back((uint64_t)c->hPoints.size());
+    c->hPoints.insert(c->hPoints.end(), points + offsets[j], points + offsets[j + 1]);
   }
   c->hOffsets.push_back((uint64_t)c->hPoints.size());
-  std::vector<std::pair<uint64_t, uint32_t>>().swap(byHash);
-  // frequency filter (winSketch.hpp:410-504)
-  int32_t freqThreshold = 0x7fffffff;
-  const size_t nKeysAll = c->hKeys.size();
-  if (nKeysAll) {
-    std::map<int, int64_t> hist;
-    for (size_t i = 0; i < nKeysAll; i++) hist[(int)(c->hOffsets[i + 1] - c->hOffsets[i])] += 1;
-    const int64_t total = (int64_t)nKeysAll;
-    const int64_t toIgnore = (int64_t)(total * kmerPctThreshold / 100);      // int64 * float / int, as winSketch.hpp:425
-    int64_t sum = 0;
-    for (auto it = hist.rbegin(); it != hist.rend(); ++it) {
-      sum += it->second;
-      if (sum < toIgnore) freqThreshold = it->first;
-      else if (sum == toIgnore) { freqThreshold = it->first; break; }
-      else break;
-    }
-  }
-  for (size_t i = 0; i < nKeysAll; i++)
-    if ((int64_t)(c->hOffsets[i + 1] - c->hOffsets[i]) >= (int64_t)freqThreshold) c->hFreq.push_back(c->hKeys[i]);
-  if (!c->hFreq.empty())
-    all.erase(std::remove_if(all.begin(), all.end(), [&](const mm_minmer& m) { return std::binary_search(c->hFreq.begin(), c->hFreq.end(), m.hash); }), all.end());
-  c->hMinmers.swap(all);
-  c->freqThreshold = freqThreshold;
-  c->mapped = false;
-  return mm_build_device_index(c, clen.data(), refGroup, nContigs);
+  return finalize_index(c, all, true, kmerPctThreshold, contigLen, refGroup, nContigs);
 }
+
+extern "C" int mm_index_download_full(mm_ctx* c, mm_minmer* out, size_t* n) {
+  if (!c->idx.ready || !c->keepFullIndex) { c->err = "mm_index_download_full: needs MM_OPT_KEEP_FULL_INDEX before the index is built"; return MM_ERR_STATE; }
+  if (n) *n = c->hMinmersAll.size();
+  if (out && !c->hMinmersAll.empty()) std::memcpy(out, c->hMinmersAll.data(), c->hMinmersAll.size() * sizeof(mm_minmer));
+  return MM_OK;
+}
+

@@ -60,6 +60,8 @@ struct mm_ctx {
 
   // host mirrors needed for downloads in reference layout
   std::vector<mm_minmer> hMinmers;
+  std::vector<mm_minmer> hMinmersAll;                   // minmerIndex before dropFreqSeedSet (only with MM_OPT_KEEP_FULL_INDEX: --saveIndex)
+  bool keepFullIndex = false;
   std::vector<uint64_t> hKeys, hOffsets, hFreq;
   std::vector<mm_interval_point> hPoints;
   int32_t freqThreshold = 0x7fffffff;

@@ -12,8 +12,11 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdlib>
+#include <cstring>
+#include <filesystem>
 #include <fstream>
 #include <iostream>
+#include <sstream>
 #include <string>
 #include <unordered_map>
 #include <unordered_set>
@@ -52,10 +55,6 @@ class Sketch {
   explicit Sketch(const skch::Parameters& p) : param(p) {
     static_assert(sizeof(MinmerInfo) == sizeof(mm_minmer), "MinmerInfo layout");
     static_assert(sizeof(IntervalPoint) == sizeof(mm_interval_point), "IntervalPoint layout");
-    if (!p.saveIndexFilename.empty() || !p.loadIndexFilename.empty()) {
-      std::cerr << "[mashmap_hip::skch::Sketch] ERROR: --saveIndex/--loadIndex are not supported by the device index (SURVEY 8f.4)" << std::endl;
-      exit(1);
-    }
     mm_params mp;
     mp.kmerSize = p.kmerSize; mp.segLength = p.segLength; mp.sketchSize = p.sketchSize;
     mp.flags = (p.stage1_topANI_filter ? MM_FLAG_HG_FILTER : 0) | (p.skip_self ? MM_FLAG_SKIP_SELF : 0) |
@@ -65,7 +64,9 @@ class Sketch {
       std::cerr << "[mashmap_hip::skch::Sketch] ERROR: " << mm_last_error(nullptr) << std::endl;
       exit(1);
     }
+    if (!p.saveIndexFilename.empty()) mm_set_option(ctx_, MM_OPT_KEEP_FULL_INDEX, 1);
     this->build();
+    if (!p.saveIndexFilename.empty()) this->saveIndex();
   }
   ~Sketch() { mm_destroy(ctx_); }
   Sketch(const Sketch&) = delete;
@@ -110,6 +111,101 @@ class Sketch {
   }
 
  private:
+  // --saveIndex PREFIX (winSketch.hpp:127-134, 270-315): PREFIX.index = size_t n + raw MinmerInfo[n] of minmerIndex before the
+  // frequent-seed drop (or a TSV when PREFIX ends in .tsv), PREFIX.map = size_t keys, then per key: hash, size_t n, raw IntervalPoint[n].
+  // Keys are written in order of first appearance in minmerIndex, the iteration order of the reference's insertion-ordered map.
+  void saveIndex() {
+    size_t nAll = 0;
+    if (mm_index_download_full(ctx_, nullptr, &nAll) != MM_OK) die("mm_index_download_full");
+    std::vector<MinmerInfo> all(nAll);
+    if (mm_index_download_full(ctx_, reinterpret_cast<mm_minmer*>(all.data()), &nAll) != MM_OK) die("mm_index_download_full");
+    if (param.saveIndexFilename.extension() == ".tsv") {
+      std::ofstream out(param.saveIndexFilename);
+      out << "seqId" << "\t" << "strand" << "\t" << "start" << "\t" << "end" << "\t" << "hash\n";
+      for (const auto& mi : all) out << mi.seqId << "\t" << std::to_string(mi.strand) << "\t" << mi.wpos << "\t" << mi.wpos_end << "\t" << mi.hash << "\n";
+    } else {
+      std::filesystem::path fn = param.saveIndexFilename; fn += ".index";
+      std::ofstream out(fn, std::ios::binary);
+      const size_t n = all.size();
+      out.write((const char*)&n, sizeof n);
+      out.write((const char*)all.data(), (std::streamsize)(n * sizeof(MinmerInfo)));
+    }
+    size_t nM, nK, nP, nF; int32_t ft;
+    if (mm_index_sizes(ctx_, &nM, &nK, &nP, &nF, &ft) != MM_OK) die("mm_index_sizes");
+    std::vector<uint64_t> keys(nK), offs(nK + 1);
+    std::vector<mm_interval_point> pts(nP);
+    if (mm_index_download(ctx_, nullptr, keys.data(), offs.data(), pts.data(), nullptr) != MM_OK) die("mm_index_download");
+    std::vector<uint32_t> first(nK, 0xFFFFFFFFu), order;
+    order.reserve(nK);
+    for (const auto& mi : all) {
+      const size_t ki = (size_t)(std::lower_bound(keys.begin(), keys.end(), mi.hash) - keys.begin());
+      if (ki < nK && keys[ki] == mi.hash && first[ki] == 0xFFFFFFFFu) { first[ki] = 1; order.push_back((uint32_t)ki); }
+    }
+    std::filesystem::path fn = param.saveIndexFilename; fn += ".map";
+    std::ofstream out(fn, std::ios::binary);
+    const size_t nKeys = order.size();
+    out.write((const char*)&nKeys, sizeof nKeys);
+    std::vector<IntervalPoint> tmp;
+    for (uint32_t ki : order) {
+      const MinmerMapKeyType key = keys[ki];
+      const size_t n = (size_t)(offs[ki + 1] - offs[ki]);
+      tmp.clear();
+      for (uint64_t j = offs[ki]; j < offs[ki + 1]; j++) tmp.push_back(IntervalPoint{pts[j].pos, pts[j].hash, pts[j].seqId, pts[j].side});
+      out.write((const char*)&key, sizeof key);
+      out.write((const char*)&n, sizeof n);
+      out.write((const char*)tmp.data(), (std::streamsize)(n * sizeof(IntervalPoint)));
+    }
+  }
+
+  // --loadIndex PREFIX (winSketch.hpp:166-172, 320-374): minmerIndex and the lookup map from disk; the frequent-seed steps run
+  // afterwards, as in the reference's constructor (:135-137), inside mm_index_upload_full
+  void loadIndex(const std::vector<int>& groups) {
+    std::vector<MinmerInfo> all;
+    if (param.loadIndexFilename.extension() == ".tsv") {
+      std::ifstream in(param.loadIndexFilename);
+      std::string line;
+      std::getline(in, line);                                     // header
+      while (std::getline(in, line)) {
+        if (line.empty()) continue;
+        std::stringstream ls(line);
+        long long seqId, strand, start, end; unsigned long long hash;
+        ls >> seqId >> strand >> start >> end >> hash;
+        all.push_back(MinmerInfo{(hash_t)hash, (offset_t)start, (offset_t)end, (seqno_t)seqId, (strand_t)strand});
+      }
+    } else {
+      std::filesystem::path fn = param.loadIndexFilename; fn += ".index";
+      std::ifstream in(fn, std::ios::binary);
+      size_t n = 0;
+      in.read((char*)&n, sizeof n);
+      if (!in) { std::cerr << "[mashmap_hip::skch::Sketch] ERROR: cannot read " << fn << std::endl; exit(1); }
+      all.resize(n);
+      in.read((char*)all.data(), (std::streamsize)(n * sizeof(MinmerInfo)));
+    }
+    std::filesystem::path fn = param.loadIndexFilename; fn += ".map";
+    std::ifstream in(fn, std::ios::binary);
+    size_t nKeys = 0;
+    in.read((char*)&nKeys, sizeof nKeys);
+    if (!in) { std::cerr << "[mashmap_hip::skch::Sketch] ERROR: cannot read " << fn << std::endl; exit(1); }
+    std::vector<uint64_t> keys(nKeys), offs(nKeys + 1, 0);
+    std::vector<mm_interval_point> pts;
+    std::vector<IntervalPoint> tmp;
+    for (size_t i = 0; i < nKeys; i++) {
+      MinmerMapKeyType key = 0; size_t n = 0;
+      in.read((char*)&key, sizeof key);
+      in.read((char*)&n, sizeof n);
+      tmp.resize(n);
+      in.read((char*)tmp.data(), (std::streamsize)(n * sizeof(IntervalPoint)));
+      keys[i] = key; offs[i] = pts.size();
+      for (const auto& ip : tmp) { mm_interval_point q; std::memset(&q, 0, sizeof q); q.pos = ip.pos; q.hash = ip.hash; q.seqId = ip.seqId; q.side = ip.side; pts.push_back(q); }
+    }
+    offs[nKeys] = pts.size();
+    std::vector<int32_t> clen(metadata.size());
+    for (size_t i = 0; i < metadata.size(); i++) clen[i] = metadata[i].len;
+    if (mm_index_upload_full(ctx_, reinterpret_cast<const mm_minmer*>(all.data()), all.size(), keys.data(), offs.data(), nKeys, pts.data(), pts.size(),
+                             clen.data(), param.skip_prefix ? groups.data() : nullptr, metadata.size(), param.kmer_pct_threshold) != MM_OK)
+      die("mm_index_upload_full");
+  }
+
   void build() {      // winSketch.hpp:147-231 + :379-504, with the compute moved behind mm_index_build
     std::unordered_set<std::string> allowed;
     if (!param.target_list.empty()) {
@@ -123,7 +219,7 @@ class Sketch {
     for (const auto& fileName : param.refSequences) {
       mmhost::for_each_seq_in_file(fileName, allowed, param.target_prefix, [&](const std::string& name, std::string& seq) {
         metadata.push_back(ContigInfo{name, (offset_t)seq.length()});
-        bases.append(seq);
+        if (param.loadIndexFilename.empty()) bases.append(seq);        // --loadIndex still reads the FASTA for names and lengths (:181-211)
         offs.push_back((int64_t)bases.size());
         seqCounter++;
       });
@@ -135,8 +231,9 @@ class Sketch {
     }
     std::vector<int> groups;
     if (param.skip_prefix) groups = refGroups();
-    if (mm_index_build(ctx_, bases.data(), offs.data(), metadata.size(), param.skip_prefix ? groups.data() : nullptr,
-                       param.kmer_pct_threshold) != MM_OK) die("mm_index_build");
+    if (!param.loadIndexFilename.empty()) this->loadIndex(groups);
+    else if (mm_index_build(ctx_, bases.data(), offs.data(), metadata.size(), param.skip_prefix ? groups.data() : nullptr,
+                            param.kmer_pct_threshold) != MM_OK) die("mm_index_build");
     size_t nM, nK, nP, nF; int32_t ft;
     if (mm_index_sizes(ctx_, &nM, &nK, &nP, &nF, &ft) != MM_OK) die("mm_index_sizes");
     minmerIndex.resize(nM);

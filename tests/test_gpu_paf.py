@@ -94,3 +94,48 @@ def _fixture_sketch_size():
     _, refrec, _, _ = CASES["default"]
     nbytes = sum(len(n) + 2 + len(a) + (len(a) + 79) // 80 for n, a in refrec)        # U.write_fasta: 80 columns
     return int(capi.load().mm_stat_recommended_sketch_size(19, 0.85, 5000, nbytes))
+
+
+def _read_index_files(prefix):
+    import numpy as np
+    mdt = np.dtype([("hash", "<u8"), ("wpos", "<i4"), ("wpos_end", "<i4"), ("seqId", "<i4"), ("strand", "<i2"), ("pad", "<i2")])
+    pdt = np.dtype([("pos", "<i4"), ("pad0", "<i4"), ("hash", "<u8"), ("seqId", "<i4"), ("side", "i1"), ("pad1", "i1", (3,))])
+    raw = open(prefix + ".index", "rb").read()
+    n = int(np.frombuffer(raw[:8], dtype="<u8")[0])
+    mins = np.frombuffer(raw[8:], dtype=mdt, count=n)
+    raw = open(prefix + ".map", "rb").read()
+    nk = int(np.frombuffer(raw[:8], dtype="<u8")[0])
+    off, keys, lists = 8, [], []
+    for _ in range(nk):
+        key, cnt = np.frombuffer(raw[off:off + 16], dtype="<u8")
+        off += 16
+        pts = np.frombuffer(raw[off:off + 24 * int(cnt)], dtype=pdt)
+        off += 24 * int(cnt)
+        keys.append(int(key)); lists.append([(int(p["pos"]), int(p["hash"]), int(p["seqId"]), int(p["side"])) for p in pts])
+    assert off == len(raw)
+    return [tuple(int(m[f]) for f in ("hash", "wpos", "wpos_end", "seqId", "strand")) for m in mins], keys, lists
+
+
+def test_save_and_load_index_interoperate_with_the_reference(tmp_path):
+    """--saveIndex / --loadIndex in the reference's on-disk layout (winSketch.hpp:284-374): same records, same map, same key order;
+    each program maps from the other's files and still writes the golden PAF"""
+    _, refrec, qrec, extra = CASES["default"]
+    td = str(tmp_path)
+    exp = open(os.path.join(PAF_DIR, "default.paf"), "rb").read()
+    got = _run(HIP_BIN, td, "default", refrec, qrec, ["--saveIndex", td + "/hipidx"], "hsave")
+    assert got == exp
+    mine = _read_index_files(td + "/hipidx")
+    assert len(mine[0]) > 1000 and len(mine[1]) > 500
+    again = _run(HIP_BIN, td, "default", refrec, qrec, ["--loadIndex", td + "/hipidx"], "hload")
+    assert again == exp
+    tsv = _run(HIP_BIN, td, "default", refrec, qrec, ["--saveIndex", td + "/hip.tsv"], "htsv")
+    assert tsv == exp and open(td + "/hip.tsv").readline().split("\t")[0] == "seqId"
+    assert _run(HIP_BIN, td, "default", refrec, qrec, ["--loadIndex", td + "/hip.tsv"], "htsvload") == exp
+    if os.path.exists(U.REF_BIN):
+        assert _run(U.REF_BIN, td, "default", refrec, qrec, ["--saveIndex", td + "/refidx"], "rsave") == exp
+        theirs = _read_index_files(td + "/refidx")
+        assert mine[0] == theirs[0], "minmerIndex on disk differs"
+        assert mine[1] == theirs[1], "lookup keys (or their order) differ"
+        assert mine[2] == theirs[2], "interval point lists differ"
+        assert _run(HIP_BIN, td, "default", refrec, qrec, ["--loadIndex", td + "/refidx"], "hloadref") == exp
+        assert _run(U.REF_BIN, td, "default", refrec, qrec, ["--loadIndex", td + "/hipidx"], "rloadhip") == exp
