@@ -338,17 +338,17 @@ k_l2_sweep(int nCand, int segLength, const mm_l1_candidate* __restrict__ l1, con
   // lastVotes = strand_votes right after the most recent insert (pre-load included): the reference samples it before the
   // evictions that precede the next insert (:1342)
   bool evalPending = false; int evW = 0, evShared = 0, evPrevVotes = 0, lastVotes = 0;
-  auto evaluate = [&](int nextW) {
-    if (evShared > bestShared) {
-      nFlushed = 0; havePend = false;                  // l2_vec_out.clear()
-      inRun = true; bestShared = evShared; curShared = evShared; curStart = evW; curEnd = nextW;
-    } else if (evShared == bestShared) {
-      if (!inRun) { curShared = evShared; curStart = evW; }
-      inRun = true; curEnd = nextW;
-    } else {
-      if (inRun) { curEnd = nextW; close_run(evPrevVotes >= 0 ? 1 : -1); curStart = 0; curEnd = 0; curShared = 0; }
-      inRun = false;
-    }
+  // the three outcomes of an evaluation (:1376-1430) as selects; only the closing of a run -- rare -- is a branch
+  auto evaluate = [&](bool on, int nextW) {
+    const bool gt = on & (evShared > bestShared), eq = on & (evShared == bestShared), lt = on & (evShared < bestShared);
+    if (lt & inRun) { curEnd = nextW; close_run(evPrevVotes >= 0 ? 1 : -1); curStart = 0; curEnd = 0; curShared = 0; }
+    const bool startNew = gt | (eq & !inRun);
+    nFlushed = gt ? 0 : nFlushed; havePend = gt ? false : havePend;          // l2_vec_out.clear()
+    bestShared = gt ? evShared : bestShared;
+    curShared = startNew ? evShared : curShared;
+    curStart = startNew ? evW : curStart;
+    curEnd = (gt | eq) ? nextW : curEnd;
+    inRun = on ? (gt | eq) : inRun;
   };
 
   bool done = false;
@@ -366,19 +366,20 @@ k_l2_sweep(int nCand, int segLength, const mm_l1_candidate* __restrict__ l1, con
     for (int k = 0; k < E_STEP; k++) {
       const uint4 v = cur[k >> 2];
       const uint32_t e = (k & 3) == 0 ? v.x : (k & 3) == 1 ? v.y : (k & 3) == 2 ? v.z : v.w;
-      if (done) continue;
+      // straight-line per entry: a finished lane (done) and the entry kinds are masks, not branches
+      const bool act = !done;
       const uint32_t type = OP_TYPE(e);
-      posAcc += (type == E_SKIP) ? (int)(((e >> 17) << 14) | (e & 0x3FFFu)) : ((type == E_INS || type == E_END) ? (int)(e >> 18) : 0);
+      const bool isIns = act & (type == E_INS), isEnd = act & (type == E_END), isPre = act & (type == E_PRE), isDel = act & (type == E_DEL);
+      const int add = (type == E_SKIP) ? (int)(((e >> 17) << 14) | (e & 0x3FFFu)) : ((type == E_INS || type == E_END) ? (int)(e >> 18) : 0);
+      posAcc += act ? add : 0;
       const int wpos = posAcc;
-      if (type == E_INS || type == E_END) {
-        if (evalPending) { evaluate(wpos); evalPending = false; }
-        if (type == E_END) { done = true; continue; }
-      }
-      const uint32_t lo = (type == E_SKIP) ? 0u : e;                // a skip carries no hash
-      evPrevVotes = (type == E_INS) ? lastVotes : evPrevVotes;
-      apply(lo, type != E_DEL);
-      lastVotes = (type == E_INS || type == E_PRE) ? votes : lastVotes;
-      if (type == E_INS) { evW = wpos; evShared = shared; evalPending = true; }
+      evaluate((isIns | isEnd) & evalPending, wpos);
+      evalPending = (isIns | isEnd) ? false : evalPending;
+      done |= isEnd;
+      evPrevVotes = isIns ? lastVotes : evPrevVotes;
+      apply((isIns | isPre | isDel) ? e : 0u, !isDel);                 // anything else carries no hash: j = 0, no effect
+      lastVotes = (isIns | isPre) ? votes : lastVotes;
+      evW = isIns ? wpos : evW; evShared = isIns ? shared : evShared; evalPending = isIns ? true : evalPending;
     }
 #pragma unroll
     for (int k = 0; k < 4; k++) cur[k] = nxt[k];
