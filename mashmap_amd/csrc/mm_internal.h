@@ -82,7 +82,7 @@ struct mm_ctx {
   DevBuf dQHash, dQStrand, dSeedVal;                    // post-removal sketch + per-seed lookup value
   DevBuf dStats;                                        // mm_frag_stats[nFrags]
   DevBuf dPtOff, dPts; size_t ptsCap = 0;               // per-fragment offset (int64) + sorted keys
-  DevBuf dL1; size_t l1Cap = 0, nL1 = 0;
+  DevBuf dL1, dL1b, dL1Cursors; size_t l1Cap = 0, nL1 = 0;   // dL1b: the region-filled buffer k_l1_compact reads from
   DevBuf dL1Off;                                        // int64[nFrags] first candidate of a fragment
   DevBuf dL2; size_t l2Cap = 0, nL2 = 0;
   DevBuf dL2Info, dL2Cnt, dL2Off, dL2Ops, dScanTmp, dL2Tmp, dListB, dListC, dBigList;     // L2 staging: per-candidate stream extents, op counts/offsets, located ops

@@ -322,7 +322,9 @@ __device__ __forceinline__ int mm_l1_fused(uint64_t (&k)[R], FuseScratch& sc, in
 //   * otherwise (many points, -Y groups, a position group spanning contigs, or keepPoints for the parity API): reserves
 //     slots in the global point buffer, gathers there and queues the fragment for k_sort_points_* + k_l1_sweep.
 // ---------------------------------------------------------------------------------------------
-#define MM_LOOKUP_WPB 16            // waves (= fragments) per workgroup: one L1-cursor atomic per workgroup, not per fragment
+#define MM_LOOKUP_WPB 4             // waves (= fragments) per workgroup
+#define MM_L1_REGIONS 64            // L1 output cursors: a same-address atomic costs ~10 ns, so fragments spread over 64 of them
+#define MM_L1_CURSOR_STRIDE 32      // u64 words between cursors (256 bytes)
 __global__ void __launch_bounds__(MM_LOOKUP_WPB * 64)
 k_lookup_l1(int nFrags, int s, const DFrag* __restrict__ frags,
             const uint64_t* __restrict__ skHash, const int8_t* __restrict__ skStrand, const uint32_t* __restrict__ skCount,
@@ -332,11 +334,10 @@ k_lookup_l1(int nFrags, int s, const DFrag* __restrict__ frags,
             uint64_t* __restrict__ qHash, int8_t* __restrict__ qStrand, uint64_t* __restrict__ seedVal,
             mm_frag_stats* __restrict__ stats, int64_t* __restrict__ ptOff, uint64_t* __restrict__ pts, unsigned long long ptsCap,
             const int32_t* __restrict__ minHitsTab, const int32_t* __restrict__ cutoffs, int nCutoffs, int segLength,
-            mm_l1_candidate* __restrict__ l1, unsigned long long l1Cap, int64_t* __restrict__ l1Off, int32_t* __restrict__ bigList,
-            unsigned long long* __restrict__ counters /* [0] point cursor [1] pts overflow [2] l1 cursor [3] l1 overflow [7] big count */) {
+            mm_l1_candidate* __restrict__ l1, unsigned long long regionCap, unsigned long long* __restrict__ l1Cursors,
+            int64_t* __restrict__ l1Off, int32_t* __restrict__ bigList,
+            unsigned long long* __restrict__ counters /* [0] point cursor [1] pts overflow [3] l1 overflow [7] big count */) {
   __shared__ FuseScratch scratch[MM_LOOKUP_WPB];
-  __shared__ int wcnt[MM_LOOKUP_WPB];
-  __shared__ unsigned long long wbase;
   const int wv = threadIdx.x >> 6;
   const int f = blockIdx.x * MM_LOOKUP_WPB + wv;
   const bool live = f < nFrags;
@@ -458,19 +459,16 @@ k_lookup_l1(int nFrags, int s, const DFrag* __restrict__ frags,
     }
   }
   }  // live
-  // one reservation of L1 slots for the whole workgroup (a same-address atomic costs ~10 ns on this part: 2 M of them, one per
-  // fragment, were 20 ms of a 25 ms kernel)
-  if (lane == 0) wcnt[wv] = nOut > 0 ? nOut : 0;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int tot = 0;
-    for (int w = 0; w < MM_LOOKUP_WPB; w++) { const int t = wcnt[w]; wcnt[w] = tot; tot += t; }
-    wbase = tot ? atomicAdd(&counters[2], (unsigned long long)tot) : 0ull;
-  }
-  __syncthreads();
   if (live && nOut >= 0) {                                         // fast path complete: emit the candidates
-    const unsigned long long base = wbase + (unsigned long long)wcnt[wv];
-    if (nOut > 0 && base + (unsigned long long)nOut > l1Cap) { if (lane == 0) atomicOr(&counters[3], 1ull); nOut = 0; }
+    // region f mod 64 of the L1 buffer, filled from its own cursor; k_l1_compact closes the gaps afterwards
+    const int region = f & (MM_L1_REGIONS - 1);
+    unsigned long long at = 0;
+    if (nOut > 0) {
+      if (lane == 0) at = atomicAdd(&l1Cursors[(size_t)region * MM_L1_CURSOR_STRIDE], (unsigned long long)nOut);
+      at = ((unsigned long long)(uint32_t)__shfl((int)(at >> 32), 0) << 32) | (uint32_t)__shfl((int)(uint32_t)at, 0);
+      if (at + (unsigned long long)nOut > regionCap) { if (lane == 0) atomicOr(&counters[3], 1ull); nOut = 0; }
+    }
+    const unsigned long long base = (unsigned long long)region * regionCap + at;
     for (int i = lane; i < nOut; i += 64) {
       const L1Run x = sc.run[i];
       mm_l1_candidate o; o.frag = f; o.seqId = x.seq; o.rangeStartPos = x.start; o.rangeEndPos = x.end; o.intersectionSize = x.isize;
@@ -482,6 +480,23 @@ k_lookup_l1(int nFrags, int s, const DFrag* __restrict__ frags,
       ptOff[2 * f] = 0; ptOff[2 * f + 1] = 0; l1Off[f] = (int64_t)base;
     }
   }
+}
+
+// closes the gaps between the 64 regions of the L1 buffer: region r moves to its prefix position (into a second buffer), and
+// the fragments' first-candidate offsets follow
+struct L1Regions { unsigned long long prefix[MM_L1_REGIONS]; unsigned long long count[MM_L1_REGIONS]; };
+__global__ void __launch_bounds__(256)
+k_l1_compact(const mm_l1_candidate* __restrict__ src, mm_l1_candidate* __restrict__ dst, unsigned long long regionCap, L1Regions R) {
+  const int r = blockIdx.y;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < R.count[r]; i += (unsigned long long)gridDim.x * 256)
+    dst[R.prefix[r] + i] = src[(unsigned long long)r * regionCap + i];
+}
+__global__ void __launch_bounds__(256)
+k_l1_fix_offsets(int nFrags, const mm_frag_stats* __restrict__ stats, int64_t* __restrict__ l1Off, unsigned long long regionCap, L1Regions R) {
+  const int f = blockIdx.x * 256 + threadIdx.x;
+  if (f >= nFrags || stats[f].nL1 <= 0) return;
+  const int r = f & (MM_L1_REGIONS - 1);
+  l1Off[f] = l1Off[f] - (int64_t)((unsigned long long)r * regionCap) + (int64_t)R.prefix[r];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -687,10 +702,17 @@ int mm_launch_map(mm_ctx* c) {
   unsigned long long hc[8];
   unsigned long long* cnt = c->dCounters.as<unsigned long long>() + 8;   // [8..15]; [0..7] belong to the sketch launcher
 
+  unsigned long long hcur[MM_L1_REGIONS * MM_L1_CURSOR_STRIDE];
+  L1Regions R;
+  unsigned long long regionCap = 0;
   for (int attempt = 0; attempt < 10; attempt++) {          // grow-and-retry on capacity overflow (points or L1 candidates)
+    regionCap = (c->l1Cap + MM_L1_REGIONS - 1) / MM_L1_REGIONS + 64;
     MM_HIP(c, c->dPts.ensure(c->ptsCap * 8 + 64));
-    MM_HIP(c, c->dL1.ensure(c->l1Cap * sizeof(mm_l1_candidate) + 64));
+    MM_HIP(c, c->dL1.ensure(regionCap * MM_L1_REGIONS * sizeof(mm_l1_candidate) + 64));
+    MM_HIP(c, c->dL1b.ensure(regionCap * MM_L1_REGIONS * sizeof(mm_l1_candidate) + 64));
+    MM_HIP(c, c->dL1Cursors.ensure(sizeof hcur));
     MM_HIP(c, hipMemsetAsync(c->dCounters.p, 0, 256, c->stream));
+    MM_HIP(c, hipMemsetAsync(c->dL1Cursors.p, 0, sizeof hcur, c->stream));
     {
       KernelTimer t(c, MM_K_LOOKUP);
       hipLaunchKernelGGL(k_lookup_l1, dim3((nF + MM_LOOKUP_WPB - 1) / MM_LOOKUP_WPB), dim3(MM_LOOKUP_WPB * 64), 0, c->stream, nF, s, c->dFrags.as<DFrag>(),
@@ -701,17 +723,36 @@ int mm_launch_map(mm_ctx* c) {
                          c->dQHash.as<uint64_t>(), c->dQStrand.as<int8_t>(), c->dSeedVal.as<uint64_t>(), c->dStats.as<mm_frag_stats>(),
                          c->dPtOff.as<int64_t>(), c->dPts.as<uint64_t>(), (unsigned long long)c->ptsCap,
                          c->dMinHits.as<int32_t>(), c->dCutoffs.as<int32_t>(), (int)c->nCutoffs, c->P.segLength,
-                         c->dL1.as<mm_l1_candidate>(), (unsigned long long)c->l1Cap, c->dL1Off.as<int64_t>(), c->dBigList.as<int32_t>(), cnt);
+                         c->dL1.as<mm_l1_candidate>(), regionCap, c->dL1Cursors.as<unsigned long long>(), c->dL1Off.as<int64_t>(),
+                         c->dBigList.as<int32_t>(), cnt);
       MM_HIP(c, hipGetLastError());
     }
     MM_HIP(c, hipMemcpyAsync(hc, cnt, 64, hipMemcpyDeviceToHost, c->stream));
+    MM_HIP(c, hipMemcpyAsync(hcur, c->dL1Cursors.p, sizeof hcur, hipMemcpyDeviceToHost, c->stream));
     MM_HIP(c, hipStreamSynchronize(c->stream));
     if (hc[1]) { c->ptsCap = (size_t)hc[0] + (size_t)hc[0] / 8 + 4096; continue; }
-    if (hc[3]) { c->l1Cap = (size_t)hc[2] * 2 + 1024; continue; }
+    if (hc[3]) {                                              // some region overflowed: size for the largest one seen
+      unsigned long long mx = 0;
+      for (int r = 0; r < MM_L1_REGIONS; r++) mx = std::max(mx, hcur[(size_t)r * MM_L1_CURSOR_STRIDE]);
+      c->l1Cap = (size_t)(mx + mx / 4 + 256) * MM_L1_REGIONS; continue;
+    }
     break;
   }
   if (hc[1]) { c->err = "interval-point buffer overflow"; return MM_ERR_CAPACITY; }
   if (hc[3]) { c->err = "L1 candidate buffer overflow"; return MM_ERR_CAPACITY; }
+  {
+    unsigned long long tot = 0;
+    for (int r = 0; r < MM_L1_REGIONS; r++) { R.count[r] = hcur[(size_t)r * MM_L1_CURSOR_STRIDE]; R.prefix[r] = tot; tot += R.count[r]; }
+    hc[2] = tot;
+    if (tot) {
+      KernelTimer t(c, MM_K_L1);
+      hipLaunchKernelGGL(k_l1_compact, dim3(64, MM_L1_REGIONS), dim3(256), 0, c->stream, c->dL1.as<mm_l1_candidate>(), c->dL1b.as<mm_l1_candidate>(), regionCap, R);
+      hipLaunchKernelGGL(k_l1_fix_offsets, dim3((nF + 255) / 256), dim3(256), 0, c->stream, nF, c->dStats.as<mm_frag_stats>(), c->dL1Off.as<int64_t>(), regionCap, R);
+      MM_HIP(c, hipGetLastError());
+    }
+    std::swap(c->dL1, c->dL1b);                               // dL1 is the dense buffer from here on
+  }
+  size_t denseCap = c->dL1.bytes / sizeof(mm_l1_candidate) - 4;   // room behind the fused candidates for the sweep path's
   const int nBig = (int)hc[7];
   if (getenv("MM_DEBUG")) fprintf(stderr, "[mm] lookup+L1: %d fragments, %d to the sort+sweep path, %llu fused candidates\n", nF, nBig, hc[2]);
   if (nBig > 0) {
@@ -739,7 +780,7 @@ int mm_launch_map(mm_ctx* c) {
         hipLaunchKernelGGL(k_l1_sweep, dim3((nBig + 255) / 256), dim3(256), 0, c->stream, nBig, c->dBigList.as<int32_t>(), c->dPtOff.as<int64_t>(),
                            c->dPts.as<uint64_t>(), c->dStats.as<mm_frag_stats>(), c->dMinHits.as<int32_t>(), c->dCutoffs.as<int32_t>(),
                            (int)c->nCutoffs, s, c->P.segLength, fl, I.refGroup.as<int32_t>(), c->dL1.as<mm_l1_candidate>(),
-                           (unsigned long long)c->l1Cap, c->dL1Off.as<int64_t>(), cnt);
+                           (unsigned long long)denseCap, c->dL1Off.as<int64_t>(), cnt);
         MM_HIP(c, hipGetLastError());
       }
       unsigned long long h2[2];
@@ -751,7 +792,7 @@ int mm_launch_map(mm_ctx* c) {
         DevBuf nb; MM_HIP(c, nb.ensure(newCap * sizeof(mm_l1_candidate) + 64));
         if (fusedL1) MM_HIP(c, hipMemcpyAsync(nb.p, c->dL1.p, (size_t)fusedL1 * sizeof(mm_l1_candidate), hipMemcpyDeviceToDevice, c->stream));
         MM_HIP(c, hipStreamSynchronize(c->stream));
-        c->dL1.release(); c->dL1 = nb; c->l1Cap = newCap;
+        c->dL1.release(); c->dL1 = nb; denseCap = newCap;
         hc[3] = 1; continue;
       }
       hc[2] = h2[0]; hc[3] = 0;
