@@ -98,3 +98,35 @@ def test_map_fuzz_scenarios(oracle, seed0, it):
     from gpucheck import fuzz_scenario
     contigs, reads, kw, desc = fuzz_scenario(seed0, it)
     run_and_compare(oracle, contigs, reads, verbose=True, **kw)
+
+
+def test_map_empty_and_degenerate_inputs(oracle):
+    """nothing to do must mean nothing done, not a crash: no reads, reads shorter than k, an index without a single minmer"""
+    from mashmap_amd import capi
+    g = U.random_dna(5, 60000)
+    ctx = capi.Context(k=19, segLength=5000, sketchSize=130)
+    ctx.index_build([g], kmerPct=0.001)
+    ctx.set_tables_default(0.85)
+    assert ctx.reads_upload([]) == 0
+    ctx.map()
+    stats, l1, l2 = ctx.results()
+    assert len(stats) == 0 and len(l1) == 0 and len(l2) == 0
+    assert ctx.reads_upload([g[:10], g[:18], np.zeros(0, dtype=np.uint8)]) == 0       # all shorter than k: no fragment (computeMap.hpp:325)
+    ctx.map()
+    assert ctx.result_counts() == (0, 0)
+    nF = ctx.reads_upload([g[100:5100], np.frombuffer(b"N" * 6000, dtype=np.uint8).copy()])
+    assert nF == 3
+    ctx.map()
+    stats, l1, l2 = ctx.results()
+    assert int(stats[0]["nL1"]) >= 1 and int(stats[1]["sketchSize"]) == 0 and int(stats[2]["sketchSize"]) == 0
+    ctx.close()
+    # a reference whose contigs are all shorter than segLength has no minmers at all (commonFunc.hpp:341)
+    ctx = capi.Context(k=19, segLength=5000, sketchSize=130)
+    ctx.index_build([g[:3000], g[3000:7000]], kmerPct=0.001)
+    ix = ctx.index_download()
+    assert len(ix["minmers"]) == 0 and len(ix["keys"]) == 0
+    ctx.set_tables_default(0.85)
+    assert ctx.reads_upload([g[:12000]]) == 3
+    ctx.map()
+    assert ctx.result_counts() == (0, 0)
+    ctx.close()
