@@ -325,7 +325,7 @@ __device__ __forceinline__ int mm_l1_fused(uint64_t (&k)[R], FuseScratch& sc, in
 #define MM_LOOKUP_WPB 4             // waves (= fragments) per workgroup
 #define MM_L1_REGIONS 64            // L1 output cursors: a same-address atomic costs ~10 ns, so fragments spread over 64 of them
 #define MM_L1_CURSOR_STRIDE 32      // u64 words between cursors (256 bytes)
-__global__ void __launch_bounds__(MM_LOOKUP_WPB * 64)
+__global__ void __launch_bounds__(MM_LOOKUP_WPB * 64, 8)
 k_lookup_l1(int nFrags, int s, const DFrag* __restrict__ frags,
             const uint64_t* __restrict__ skHash, const int8_t* __restrict__ skStrand, const uint32_t* __restrict__ skCount,
             const HtSlot* __restrict__ ht, uint64_t htMask, const uint32_t* __restrict__ filter, uint64_t filterMask,
