@@ -463,9 +463,7 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt) {
   for (int attempt = 0; attempt < 24; attempt++) {
     MM_HIP(c, c->dL2.ensure(c->l2Cap * sizeof(mm_l2_locus) + 64));
     MM_HIP(c, c->dL2Tmp.ensure((size_t)nC * locap * sizeof(L2Tmp) + 64));
-    const unsigned long long keep = 6ull;                                  // [6] bits 1,2 belong to this launch; bit 4 is the locate kernel's
-    MM_HIP(c, hipMemsetAsync(cnt + 4, 0, 16, c->stream));                  // [4] cursor [5] overflow
-    (void)keep;
+    MM_HIP(c, hipMemsetAsync(cnt + 4, 0, 16, c->stream));                  // [4] cursor [5] overflow; [6] keeps the locate kernel's flag
     {
       KernelTimer t(c, MM_K_L2);
       hipLaunchKernelGGL(k_l2_sweep, dim3((unsigned)((nC + 63) / 64)), dim3(64), ldsL2, c->stream, nC, c->P.segLength, c->dL1.as<mm_l1_candidate>(),

@@ -133,7 +133,7 @@ struct WnSketch {
 // ---------------------------------------------------------------------------------------------
 template <bool DENSE>
 __global__ void __launch_bounds__(64)
-k_winnow_tiles(const int32_t* __restrict__ tileList, int nTilesLaunch,
+k_winnow_tiles(const int32_t* __restrict__ tileList,
                const int32_t* __restrict__ cPos, const uint64_t* __restrict__ cHash, const int8_t* __restrict__ cSt, int64_t nCand,
                const uint64_t* __restrict__ H, const int8_t* __restrict__ ST,
                int len, int k, int w, int s, int TW, int nW, int ldsCand,
@@ -143,7 +143,6 @@ k_winnow_tiles(const int32_t* __restrict__ tileList, int nTilesLaunch,
   const int lane = threadIdx.x;
   const int slot = blockIdx.x;                                   // output slot (== position in tileList when there is one)
   const int t = tileList ? tileList[blockIdx.x] : (int)blockIdx.x;
-  (void)nTilesLaunch;
   const int wk = w - k + 1;                                      // k-mer positions per window
   const int W0 = t * TW;
   const int Wend = ((int64_t)(t + 1) * TW < (int64_t)nW - 1) ? (t + 1) * TW : nW - 1;
@@ -205,14 +204,13 @@ k_winnow_tiles(const int32_t* __restrict__ tileList, int nTilesLaunch,
     }
     return wn_min64(best);
   };
-  auto refill = [&](int W, int startVal, int64_t a, int64_t b) {          // :487-505
+  auto refill = [&](int startVal, int64_t a, int64_t b) {                 // :487-505
     while (sk.n < s) {
       const uint64_t pm = pendMin(a, b);
       if (pm == WN_NONE) break;
       int cnt, sm; occ(pm, a, b, cnt, sm);
       sk.insert(pm, startVal, sm, lane);
     }
-    (void)W;
   };
 
   // window [a, b) in index space
@@ -225,7 +223,7 @@ k_winnow_tiles(const int32_t* __restrict__ tileList, int nTilesLaunch,
     b = lo;
   }
   // cold start: the sketch of window W0; runs that were already open get their start from the previous tile later
-  refill(W0, W0 == 0 ? 0 : WN_CARRY, a, b);
+  refill(W0 == 0 ? 0 : WN_CARRY, a, b);
   if (!DENSE && sk.n < s) fail = true;
 
   int W = W0;
@@ -286,7 +284,7 @@ k_winnow_tiles(const int32_t* __restrict__ tileList, int nTilesLaunch,
       sk.n--; removed = true;
     }
     if (sk.n < s && (removed || newPending)) {
-      refill(W, W, a, b);
+      refill(W, a, b);
       if (!DENSE && sk.n < s) fail = true;                                  // the cut may be hiding k-mers that belong in the sketch
     }
   }
@@ -359,11 +357,11 @@ int mm_winnow_contig_device(mm_ctx* c, WinnowBuffers& B, const uint64_t* dH, con
   {
     KernelTimer t(c, MM_K_WINNOW);
     if (sparse)
-      hipLaunchKernelGGL((k_winnow_tiles<false>), dim3(nTiles), dim3(64), ldsSparse, c->stream, (const int32_t*)nullptr, nTiles,
+      hipLaunchKernelGGL((k_winnow_tiles<false>), dim3(nTiles), dim3(64), ldsSparse, c->stream, (const int32_t*)nullptr,
                          B.cPos.as<int32_t>(), B.cHash.as<uint64_t>(), B.cSt.as<int8_t>(), nCand, dH, dS, len, k, w, s, TW, nW, ldsCand,
                          B.out.as<mm_minmer>(), outCap, B.outCount.as<int32_t>(), B.open.as<WnOpenRun>(), B.openCount.as<int32_t>(), B.status.as<int32_t>());
     else
-      hipLaunchKernelGGL((k_winnow_tiles<true>), dim3(nTiles), dim3(64), ldsSketch + 16, c->stream, (const int32_t*)nullptr, nTiles,
+      hipLaunchKernelGGL((k_winnow_tiles<true>), dim3(nTiles), dim3(64), ldsSketch + 16, c->stream, (const int32_t*)nullptr,
                          (const int32_t*)nullptr, (const uint64_t*)nullptr, (const int8_t*)nullptr, (int64_t)0, dH, dS, len, k, w, s, TW, nW, 0,
                          B.out.as<mm_minmer>(), outCap, B.outCount.as<int32_t>(), B.open.as<WnOpenRun>(), B.openCount.as<int32_t>(), B.status.as<int32_t>());
     MM_HIP(c, hipGetLastError());
@@ -398,7 +396,7 @@ int mm_winnow_contig_device(mm_ctx* c, WinnowBuffers& B, const uint64_t* dH, con
   MM_HIP(c, hipMemcpyAsync(B.redoList.p, redo.data(), (size_t)nRedo * 4, hipMemcpyHostToDevice, c->stream));
   {
     KernelTimer t(c, MM_K_WINNOW);
-    hipLaunchKernelGGL((k_winnow_tiles<true>), dim3(nRedo), dim3(64), ldsSketch + 16, c->stream, B.redoList.as<int32_t>(), nRedo,
+    hipLaunchKernelGGL((k_winnow_tiles<true>), dim3(nRedo), dim3(64), ldsSketch + 16, c->stream, B.redoList.as<int32_t>(),
                        (const int32_t*)nullptr, (const uint64_t*)nullptr, (const int8_t*)nullptr, (int64_t)0, dH, dS, len, k, w, s, TW, nW, 0,
                        B.out2.as<mm_minmer>(), bigCap, B.outCount2.as<int32_t>(), B.open2.as<WnOpenRun>(), B.openCount2.as<int32_t>(), B.status2.as<int32_t>());
     MM_HIP(c, hipGetLastError());
