@@ -85,7 +85,7 @@ struct mm_ctx {
   DevBuf dL1, dL1b, dL1Cursors; size_t l1Cap = 0, nL1 = 0;   // dL1b: the region-filled buffer k_l1_compact reads from
   DevBuf dL1Off;                                        // int64[nFrags] first candidate of a fragment
   DevBuf dL2; size_t l2Cap = 0, nL2 = 0;
-  DevBuf dL2Info, dL2Cnt, dL2Off, dL2Ops, dScanTmp, dL2Tmp, dListB, dListC, dBigList;     // L2 staging: per-candidate stream extents, op counts/offsets, located ops
+  DevBuf dL2Info, dL2Cnt, dL2Off, dL2Ops, dScanTmp, dL2Tmp, dL2Wide, dListB, dListC, dBigList;     // L2 staging: per-candidate stream extents, op counts/offsets, located ops
   bool sketched = false, mapped = false;
   bool keepPoints = false;                              // mm_set_option(MM_OPT_KEEP_POINTS): route every fragment through the HBM point list
 

@@ -22,6 +22,9 @@
 // streaming pre-pass followed by a sweep whose only memory traffic is one sequential stream per lane.
 #include "mm_internal.h"
 #include "mm_device.h"
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
 
 #define MM_LOCAP0 8         // private L2 locus slots per candidate before the final compaction (doubled and re-run on overflow)
 
@@ -256,35 +259,45 @@ k_l2_locate(int nCand, int s, const mm_l1_candidate* __restrict__ l1, const mm_f
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_l2_sweep: one lane per candidate.  Per-lane SlideMapper state in LDS, one 16-bit cell per query position p:
-//   bits 0..11 num_before_inc   bit 12 active   bits 13..14 strand_vote + 1
-// cell p of lane l lives in dword p*32 + (l & 31), half l >> 5: both 32-lane halves of a DS instruction see 32 distinct banks.
+// k_l2_sweep<WIDE>: one lane per candidate.  Per-lane SlideMapper state in LDS, one cell per query position p:
+//   num_before_inc (CB bits) | active (1 bit) | strand_vote + 1 (2 bits)
+// The LDS that 64 such states need is what limits the waves per CU, and the kernel is latency bound, so the first pass uses
+// 8-bit cells (CB = 5: 18 waves/CU at s = 130).  num_before_inc counts the open reference-only hashes between two neighbouring
+// query hashes -- about one on average; a candidate where one exceeds 31 is queued and redone with 16-bit cells (CB = 12).
+// Every lane owns an LDS bank: 8-bit cell p of lane l is byte p & 3 of dword (p >> 2) * 64 + l; 16-bit cell p of lane l is
+// half l >> 5 of dword p * 32 + (l & 31).  Both 32-lane halves of a DS instruction then see 32 distinct banks.
 // ---------------------------------------------------------------------------------------------
-#define CELL_CNT(x) ((int)((x) & 0xFFFu))
-#define CELL_ACT(x) ((int)(((x) >> 12) & 1u))
-#define CELL_VOTE(x) ((int)(((x) >> 13) & 3u) - 1)
-
+template <bool WIDE>
 __global__ void __launch_bounds__(64)
-k_l2_sweep(int nCand, int segLength, const mm_l1_candidate* __restrict__ l1, const mm_frag_stats* __restrict__ stats,
+k_l2_sweep(int nCand, const int32_t* __restrict__ candList, int segLength, const mm_l1_candidate* __restrict__ l1, const mm_frag_stats* __restrict__ stats,
            const int64_t* __restrict__ opOff, const int32_t* __restrict__ opCnt, const uint32_t* __restrict__ ops,
            const int64_t* __restrict__ l1Off, L2Tmp* __restrict__ tmp, int locap, mm_l2_locus* __restrict__ l2, unsigned long long l2Cap,
-           unsigned long long* __restrict__ counters /* [4] l2 cursor, [5] overflow, [6] locus-slot overflow */) {
-  extern __shared__ __attribute__((aligned(16))) uint16_t cell[];
+           int32_t* __restrict__ wideList,
+           unsigned long long* __restrict__ counters /* [4] l2 cursor, [5] overflow, [6] flags, [7] candidates queued for the wide pass */) {
+  typedef typename std::conditional<WIDE, uint16_t, uint8_t>::type CellT;
+  constexpr int CB = WIDE ? 12 : 5;
+  constexpr uint32_t CMASK = (1u << CB) - 1u;
+#define CELL_CNT(x) ((int)((x) & CMASK))
+#define CELL_ACT(x) ((int)(((x) >> CB) & 1u))
+#define CELL_VOTE(x) ((int)(((x) >> (CB + 1)) & 3u) - 1)
+  extern __shared__ __attribute__((aligned(16))) unsigned char cellRaw[];
+  CellT* cell = (CellT*)cellRaw;
   const int lane = threadIdx.x;
-  const int cIdx = blockIdx.x * 64 + lane;
-  if (cIdx >= nCand) return;
+  const int li = blockIdx.x * 64 + lane;
+  if (li >= nCand) return;
+  const int cIdx = candList ? candList[li] : li;
   const mm_l1_candidate cand = l1[cIdx];
   const int f = cand.frag;
   const int S = stats[f].sketchSize;
   const uint4* src = (const uint4*)(ops + opOff[cIdx]);
   const int nSteps = opCnt[cIdx] / E_STEP;             // 16 entries = 4 x 16 bytes per step
   int posAcc = cand.rangeStartPos;                     // running position of the delta code
-  const int lbase = (lane & 31) * 2 + (lane >> 5);
-#define CELL(p) cell[(p) * 64 + lbase]
+  const int lbase = WIDE ? (lane & 31) * 2 + (lane >> 5) : lane * 4;
+#define CELL(p) cell[WIDE ? (p) * 64 + lbase : ((p) >> 2) * 256 + lbase + ((p) & 3)]
   CELL(0) = 0;
-  for (int p = 1; p <= S; p++) CELL(p) = 1u | (1u << 13);       // num_before_inc = 1, inactive, vote 0
+  for (int p = 1; p <= S; p++) CELL(p) = (CellT)(1u | (1u << (CB + 1)));       // num_before_inc = 1, inactive, vote 0
   int pivot = S, pivRank = S, shared = 0, votes = 0;
-  bool doubleOpen = false;
+  bool doubleOpen = false, cntOverflow = false;
 
   // SlideMapper::insert_minmer / delete_minmer (slidingMap.hpp:125-211) as straight-line code: the four cases (insert or
   // delete x hash matches a query hash or not) are selected arithmetically, because the 64 lanes of a wave are at different
@@ -292,18 +305,19 @@ k_l2_sweep(int nCand, int segLength, const mm_l1_candidate* __restrict__ l1, con
   // hash, of the pivot and of its right neighbour are read up front, independent of the case.
   auto apply = [&](uint32_t op, bool isIns) {
     const int j = OP_J(op);                            // 0: hash beyond the query sketch -> no effect (cell 0 is a dummy)
-    const bool valid = j != 0, match = OP_MATCH(op) != 0;
+    const bool valid = (j != 0) & !cntOverflow, match = OP_MATCH(op) != 0;   // after a counter overflow the lane only idles to the end
     const int pn = pivot + 1 <= S ? pivot + 1 : S;
     const uint32_t cw = CELL(j), pw = CELL(pivot), nw = CELL(pn);
     const int v = OP_QS(op) * OP_RSTRAND(op);          // a query hash has one open reference window at a time (windowLen == 0);
     const bool IM = valid & isIns & match, IN = valid & isIns & !match, DM = valid & !isIns & match, DN = valid & !isIns & !match;
     doubleOpen |= IM & (CELL_ACT(cw) != 0);            // the 2-bit vote relies on it, so a violation is reported, not absorbed
     uint32_t ncw = cw;
-    ncw = IM ? ((cw & 0xFFFu) | (1u << 12) | ((uint32_t)(v + 1) << 13)) : ncw;
+    cntOverflow |= IN & (CELL_CNT(cw) == (int)CMASK);   // the counter of this cell is full: redo the candidate with wide cells
+    ncw = IM ? ((cw & CMASK) | (1u << CB) | ((uint32_t)(v + 1) << (CB + 1))) : ncw;
     ncw = IN ? cw + 1u : ncw;
-    ncw = DM ? ((cw & 0xFFFu) | (1u << 13)) : ncw;
+    ncw = DM ? ((cw & CMASK) | (1u << (CB + 1))) : ncw;
     ncw = DN ? cw - 1u : ncw;
-    CELL(j) = (uint16_t)ncw;
+    CELL(j) = (CellT)ncw;
     const int ip = j <= pivot ? 1 : 0;
     shared += (IM ? ip : 0) - (DM ? ip : 0);
     votes += ((IM & (ip != 0)) ? v : 0) - ((DM & (ip != 0)) ? CELL_VOTE(cw) : 0);
@@ -386,9 +400,17 @@ k_l2_sweep(int nCand, int segLength, const mm_l1_candidate* __restrict__ l1, con
   }
   if (inRun) close_run(votes >= 0 ? 1 : -1);
 #undef CELL
+#undef CELL_CNT
+#undef CELL_ACT
+#undef CELL_VOTE
   int total = nFlushed + (havePend ? 1 : 0);
-  if (slotOverflow) { atomicOr(&counters[6], 1ull); total = 0; }
-  if (doubleOpen) atomicOr(&counters[6], 2ull);
+  if (cntOverflow) {
+    total = 0;
+    if (WIDE) atomicOr(&counters[6], 8ull);            // cannot happen: 12 bits hold every open record of a sketch <= 1024
+    else wideList[atomicAdd(&counters[7], 1ull)] = cIdx;
+  }
+  if (slotOverflow && !cntOverflow) { atomicOr(&counters[6], 1ull); total = 0; }
+  if (doubleOpen && !cntOverflow) atomicOr(&counters[6], 2ull);
   // one reservation per wave (64 candidates): exclusive scan of the lanes' counts, lane 63 of the active lanes asks
   int incl = total;
 #pragma unroll
@@ -454,9 +476,12 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt) {
                        c->dL2Info.as<L2Info>(), c->dL2Off.as<int64_t>(), c->dL2Cnt.as<int32_t>(), c->dL2Ops.as<uint32_t>(), cnt);
     MM_HIP(c, hipGetLastError());
   }
-  const size_t ldsL2 = (size_t)(s + 1) * 64 * 2;          // cells 0..S
-  if (ldsL2 > 160 * 1024) { c->err = "sketchSize too large for the LDS-resident L2 state"; return MM_ERR_ARG; }
-  MM_HIP(c, hipFuncSetAttribute((const void*)k_l2_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsL2));
+  const size_t ldsWide = (size_t)(s + 1) * 64 * 2;                         // cells 0..S, 16 bit
+  const size_t ldsNarrow = (size_t)((s + 1 + 3) / 4) * 256;                 // 8 bit
+  if (ldsWide > 160 * 1024) { c->err = "sketchSize too large for the LDS-resident L2 state"; return MM_ERR_ARG; }
+  MM_HIP(c, hipFuncSetAttribute((const void*)k_l2_sweep<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsWide));
+  MM_HIP(c, hipFuncSetAttribute((const void*)k_l2_sweep<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsNarrow));
+  MM_HIP(c, c->dL2Wide.ensure((size_t)nC * 4 + 64));
   if (c->l2Cap < c->nL1 * 2 + 1024) c->l2Cap = c->nL1 * 2 + 1024;
   unsigned long long hc[8];
   int locap = MM_LOCAP0;
@@ -464,15 +489,29 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt) {
     MM_HIP(c, c->dL2.ensure(c->l2Cap * sizeof(mm_l2_locus) + 64));
     MM_HIP(c, c->dL2Tmp.ensure((size_t)nC * locap * sizeof(L2Tmp) + 64));
     MM_HIP(c, hipMemsetAsync(cnt + 4, 0, 16, c->stream));                  // [4] cursor [5] overflow; [6] keeps the locate kernel's flag
+    MM_HIP(c, hipMemsetAsync(cnt + 7, 0, 8, c->stream));                   // [7] candidates queued for the wide pass
     {
       KernelTimer t(c, MM_K_L2);
-      hipLaunchKernelGGL(k_l2_sweep, dim3((unsigned)((nC + 63) / 64)), dim3(64), ldsL2, c->stream, nC, c->P.segLength, c->dL1.as<mm_l1_candidate>(),
-                         c->dStats.as<mm_frag_stats>(), c->dL2Off.as<int64_t>(), c->dL2Cnt.as<int32_t>(), c->dL2Ops.as<uint32_t>(),
-                         c->dL1Off.as<int64_t>(), c->dL2Tmp.as<L2Tmp>(), locap, c->dL2.as<mm_l2_locus>(), (unsigned long long)c->l2Cap, cnt);
+      hipLaunchKernelGGL((k_l2_sweep<false>), dim3((unsigned)((nC + 63) / 64)), dim3(64), ldsNarrow, c->stream, nC, (const int32_t*)nullptr, c->P.segLength,
+                         c->dL1.as<mm_l1_candidate>(), c->dStats.as<mm_frag_stats>(), c->dL2Off.as<int64_t>(), c->dL2Cnt.as<int32_t>(), c->dL2Ops.as<uint32_t>(),
+                         c->dL1Off.as<int64_t>(), c->dL2Tmp.as<L2Tmp>(), locap, c->dL2.as<mm_l2_locus>(), (unsigned long long)c->l2Cap,
+                         c->dL2Wide.as<int32_t>(), cnt);
       MM_HIP(c, hipGetLastError());
     }
     MM_HIP(c, hipMemcpyAsync(hc, cnt, 64, hipMemcpyDeviceToHost, c->stream));
     MM_HIP(c, hipStreamSynchronize(c->stream));
+    if (hc[7] && !(hc[6] & 1ull) && !hc[5]) {                              // the few candidates whose 5-bit counters overflowed
+      const int nWide = (int)hc[7];
+      if (getenv("MM_DEBUG")) fprintf(stderr, "[mm] L2 sweep: %d of %d candidates redone with 16-bit cells\n", nWide, nC);
+      KernelTimer t(c, MM_K_L2);
+      hipLaunchKernelGGL((k_l2_sweep<true>), dim3((unsigned)((nWide + 63) / 64)), dim3(64), ldsWide, c->stream, nWide, c->dL2Wide.as<int32_t>(), c->P.segLength,
+                         c->dL1.as<mm_l1_candidate>(), c->dStats.as<mm_frag_stats>(), c->dL2Off.as<int64_t>(), c->dL2Cnt.as<int32_t>(), c->dL2Ops.as<uint32_t>(),
+                         c->dL1Off.as<int64_t>(), c->dL2Tmp.as<L2Tmp>(), locap, c->dL2.as<mm_l2_locus>(), (unsigned long long)c->l2Cap,
+                         (int32_t*)nullptr, cnt);
+      MM_HIP(c, hipGetLastError());
+      MM_HIP(c, hipMemcpyAsync(hc, cnt, 64, hipMemcpyDeviceToHost, c->stream));
+      MM_HIP(c, hipStreamSynchronize(c->stream));
+    }
     if (hc[6] & 1ull) {                                                    // a candidate with more tied loci than slots (tandem repeats): more slots, again
       if ((size_t)nC * (size_t)locap * 2 * sizeof(L2Tmp) > ((size_t)64 << 30)) break;
       locap *= 2;
@@ -484,6 +523,7 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt) {
     break;
   }
   if (hc[6] & 4ull) { c->err = "a gap of more than 2^29 bases between consecutive reference minmers is not representable in the L2 stream"; return MM_ERR_ARG; }
+  if (hc[6] & 8ull) { c->err = "L2 state counter overflow with 16-bit cells"; return MM_ERR_STATE; }
   if (hc[6] & 2ull) { c->err = "a query hash had two open reference windows at once (index intervals of one hash overlap)"; return MM_ERR_STATE; }
   if (hc[6] & 1ull) { c->err = "an L1 candidate with more tied L2 loci than 64 GiB of staging can hold"; return MM_ERR_CAPACITY; }
   if (hc[5]) { c->err = "L2 locus buffer overflow"; return MM_ERR_CAPACITY; }

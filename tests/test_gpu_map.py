@@ -130,3 +130,27 @@ def test_map_empty_and_degenerate_inputs(oracle):
     ctx.map()
     assert ctx.result_counts() == (0, 0)
     ctx.close()
+
+
+def test_map_short_reads_wide_l2_cells(oracle):
+    """reads much shorter than segLength: their sketch spans most of the hash range while a reference window's sketch sits at
+    the bottom of it, so over a hundred reference-only hashes pile up below the first query hashes -- more than the 5-bit
+    counters of the first L2 pass hold.  Those candidates must be redone with 16-bit cells and still match the reference."""
+    from mashmap_amd import capi
+    contigs = genome(91, [200000, 150000], repeats=False)
+    g0, g1 = contigs[0][1], contigs[1][1]
+    reads = [("s%d" % i, g0[10000 + 7000 * i:10000 + 7000 * i + 300 + 40 * i].copy()) for i in range(12)]
+    reads += [("t%d" % i, U.revcomp(g1[5000 + 9000 * i:5000 + 9000 * i + 450])) for i in range(8)]
+    nF, nl = run_and_compare(oracle, contigs, reads)
+    assert nl >= 10
+    h = oracle.session(contigs, 19, 5000, 130, 0.85)
+    ix = oracle.export_index(h)
+    ctx = capi.Context(k=19, segLength=5000, sketchSize=130)
+    ctx.index_upload(ix["minmers"], ix["keys"], ix["offsets"], ix["points"], ix["freq"], ix["contigLen"])
+    ctx.set_tables_default(0.85)
+    ctx.reads_upload([a for _, a in reads])
+    ctx.profile(True); ctx.profile_read(reset=True)
+    ctx.map()
+    launches = ctx.profile_read()["l2"][1]
+    assert launches == 2, "the wide-cell pass did not run (launches of the L2 sweep: %d)" % launches
+    ctx.close(); oracle.free(h)
