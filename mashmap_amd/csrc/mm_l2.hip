@@ -228,10 +228,8 @@ k_l2_locate(int nCand, int s, const mm_l1_candidate* __restrict__ l1, const mm_f
       const bool needSkip = evalIns && delta > (int)E_MAXDELTA;
       if (needSkip && (delta - (int)E_MAXDELTA) >= (1 << 29)) tooWide = true;
       const int mine = keep ? (needSkip ? 2 : 1) : 0;
-      int incl = mine;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(incl, o); if (lane >= o) incl += y; }
-      const int at = outN + incl - mine;
+      const uint64_t mKeep = __ballot(keep), mSkip = __ballot(needSkip);          // slots before this lane: one per kept event, one more per skip
+      const int at = outN + (int)mm_popc_below(mKeep) + (int)mm_popc_below(mSkip);
       if (keep && at + mine <= cap) {
         if (needSkip) {
           const uint32_t extra = (uint32_t)(delta - (int)E_MAXDELTA);
@@ -239,7 +237,7 @@ k_l2_locate(int nCand, int s, const mm_l1_candidate* __restrict__ l1, const mm_f
           out[at + 1] = op | (E_MAXDELTA << 18);
         } else out[at] = op | ((uint32_t)delta << 18);
       }
-      outN += __shfl(incl, 63);
+      outN += __popcll(mKeep) + __popcll(mSkip);
       if (mIns) posAcc = __shfl(pos, 63 - (int)__builtin_clzll(mIns));
     }
     if (lane == 0) {                                               // end marker: carries the wpos behind the last insert
