@@ -45,13 +45,31 @@ __global__ void k_pack2bit(const uint8_t* __restrict__ ascii, const int64_t* __r
 }
 
 // ---------------------------------------------------------------------------------------------
-// LDS hash table used to de-duplicate the survivors of the threshold filter
+// LDS table that de-duplicates the survivors of the threshold filter AND orders them.
+//   The home slot is a monotone function of the hash (hashes below the cut T are spread over
+//   [0, HT)), collisions probe linearly WITHOUT wrap-around into `pad` spare slots.  Then
+//     * every key of a cluster (maximal run of occupied slots) has its home inside the cluster,
+//     * keys of an earlier cluster have a strictly smaller home, hence a strictly smaller hash,
+//   so rank(key) = occupied slots before its cluster + keys of its own cluster that are smaller:
+//   the table scan replaces compaction + sort.
 // ---------------------------------------------------------------------------------------------
 struct SkTable {
-  uint64_t* key; int32_t* first; int32_t* last; int32_t* sum; uint32_t* counters;   // counters[0]=distinct, [1]=overflow
-  uint32_t mask, maxLoad;
+  uint64_t* key; int32_t* first; int32_t* last; int32_t* sum;
+  uint32_t* counters;            // [0] distinct keys  [1] overflow (table, spill or queue)
+  uint64_t* occW; uint32_t* occP; // occupancy bit words and their exclusive prefix counts
+  uint32_t nSlots, maxLoad, M; int sh;
+
+  // slots for hashes in [0, T): x = top 32 bits of h after normalising T to bit 63, home = x * M >> 32 with
+  // M <= 2^32 * HT / (x_max + 1)  (any smaller M keeps home < HT and monotone; the float estimate is shaded down)
+  __device__ __forceinline__ void set_cut(uint64_t T, uint32_t HT) {
+    sh = (T == MM_HASH_MAX) ? 0 : __clzll((long long)T);
+    const uint64_t t32 = ((T << sh) >> 32) + 1ull;
+    M = (uint32_t)((float)HT * 4294967296.0f / (float)t32 * 0.99999f);
+  }
+  __device__ __forceinline__ uint32_t home(uint64_t h) const { return __umulhi((uint32_t)((h << sh) >> 32), M); }
+
   __device__ __forceinline__ void insert(uint64_t h, int pos, int st) {
-    uint32_t slot = (uint32_t)h & mask;
+    uint32_t slot = home(h);
     while (true) {
       if (((volatile uint32_t*)counters)[1]) return;
       const unsigned long long prev = atomicCAS((unsigned long long*)&key[slot], (unsigned long long)MM_HASH_MAX,
@@ -63,18 +81,29 @@ struct SkTable {
         atomicMin(&first[slot], pos); atomicMax(&last[slot], pos); atomicAdd(&sum[slot], st);
         return;
       }
-      slot = (slot + 1) & mask;
+      if (++slot >= nSlots) { atomicOr(&counters[1], 1u); return; }
     }
   }
 };
 
+// OR of every K-wide window: bit j of the result = any of bits j..j+K-1 of x
+template <int K>
+__device__ __forceinline__ uint64_t mm_window_or(uint64_t x) {
+  constexpr int P = K >= 32 ? 32 : K >= 16 ? 16 : K >= 8 ? 8 : K >= 4 ? 4 : K >= 2 ? 2 : 1;
+  uint64_t w = x;
+#pragma unroll
+  for (int d = 1; d < P; d <<= 1) w |= w >> d;
+  return w | (w >> (K - P));
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_sketch_fragments<K, HARD>
 //   FAST (HARD=false): hash every k-mer on both strands, keep canonical hashes below a threshold
-//     T ~ 1.75 * s / (2n) * 2^64 in an LDS queue (wave ballot compaction), de-duplicate them in an LDS
-//     hash table (first / last position, strand sum), bitonic-sort the distinct ones, emit the s
-//     smallest.  If the queue or table overflows, or fewer than s distinct survive while T < max,
-//     the fragment is appended to the hard list instead.
+//     T ~ 1.75 * s / (2n) * 2^64 in per-wave LDS queues (ballot compaction, the queue head lives in an
+//     SGPR: no atomic, no LDS round trip inside the hash loop), de-duplicate them in the ordered LDS
+//     table above (first / last position, strand sum), rank the distinct ones, emit the s smallest.
+//     If a queue or the table overflows, or fewer than s distinct survive while T < max, the fragment
+//     is appended to the hard list instead.
 //   HARD: exact for any input (tandem repeats, low complexity, N-rich): survivors go straight into
 //     a larger table (duplicates collapse) and T is bisected until s <= distinct <= load limit.
 // ---------------------------------------------------------------------------------------------
@@ -82,7 +111,7 @@ template <int K, bool HARD>
 __global__ void __launch_bounds__(1024)
 k_sketch_fragments(const uint32_t* __restrict__ bases2, const uint32_t* __restrict__ nmask,
                    const DFrag* __restrict__ frags, const uint32_t* __restrict__ readHasN,
-                   const int32_t* __restrict__ fragList, int s, int HT,
+                   const int32_t* __restrict__ fragList, int s, int HT, int PAD,
                    uint64_t* __restrict__ skHash, int2* __restrict__ skPos, int8_t* __restrict__ skStrand,
                    uint32_t* __restrict__ skCount, int32_t* __restrict__ hardList, uint32_t* __restrict__ hardCount) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -97,20 +126,26 @@ k_sketch_fragments(const uint32_t* __restrict__ bases2, const uint32_t* __restri
   // ---- LDS carve (every offset a multiple of 16) ----
   const int nW = (len + 15) / 16 + 3;               // code words incl. 2 words of run-off for the last strip
   const int nM = (len + 31) / 32 + 2;
+  const int NS = HT + PAD;                          // table slots (multiple of 64)
+  const int nOcc = NS >> 6;
+  const int nWaves = nthr >> 6;
+  const uint32_t QC = HARD ? 0u : (uint32_t)HT / (uint32_t)nWaves;     // queue slots per wave
   size_t off = 0;
   MMTables* tabs = (MMTables*)(smem + off); off += sizeof(MMTables);
   mm_tables_init<K>(*tabs, tid, nthr);                           // made visible by the first __syncthreads() below
   uint32_t* sW = (uint32_t*)(smem + off); off += (((size_t)nW * 4 + 15) / 16) * 16;
   uint32_t* sM = (uint32_t*)(smem + off); off += (((size_t)nM * 4 + 15) / 16) * 16;
-  uint64_t* arrA = (uint64_t*)(smem + off); off += (size_t)HT * 8;     // queue hashes, later sort keys
-  uint32_t* arrB = (uint32_t*)(smem + off); off += (size_t)HT * 4;     // queue meta, later sort payload (slot)
+  uint64_t* qH = (uint64_t*)(smem + off); off += HARD ? 0 : (size_t)HT * 8;     // per-wave queues: hashes
+  uint32_t* qM = (uint32_t*)(smem + off); off += HARD ? 0 : (size_t)HT * 4;     //                  pos<<1 | (strand > 0)
   SkTable tab;
-  tab.key = (uint64_t*)(smem + off); off += (size_t)HT * 8;
-  tab.first = (int32_t*)(smem + off); off += (size_t)HT * 4;
-  tab.last = (int32_t*)(smem + off); off += (size_t)HT * 4;
-  tab.sum = (int32_t*)(smem + off); off += (size_t)HT * 4;
-  tab.counters = (uint32_t*)(smem + off); off += 16;                   // [0] distinct [1] overflow [2] queue count [3] compact count
-  tab.mask = (uint32_t)HT - 1u; tab.maxLoad = (uint32_t)HT * 5u / 8u;
+  tab.key = (uint64_t*)(smem + off); off += (size_t)NS * 8;
+  tab.occW = (uint64_t*)(smem + off); off += (size_t)nOcc * 8;
+  tab.first = (int32_t*)(smem + off); off += (size_t)NS * 4;
+  tab.last = (int32_t*)(smem + off); off += (size_t)NS * 4;
+  tab.sum = (int32_t*)(smem + off); off += (size_t)NS * 4;
+  tab.occP = (uint32_t*)(smem + off); off += (((size_t)nOcc * 4 + 15) / 16) * 16;
+  tab.counters = (uint32_t*)(smem + off); off += 16;
+  tab.nSlots = (uint32_t)NS; tab.maxLoad = (uint32_t)HT * 5u / 8u;
 
   // ---- stage the fragment, re-aligned so that LDS word j holds bases 16j..16j+15 ----
   {
@@ -137,58 +172,60 @@ k_sketch_fragments(const uint32_t* __restrict__ bases2, const uint32_t* __restri
   }
   uint64_t lo = 0, hi = MM_HASH_MAX; bool hiInf = true;   // HARD bisection state (uniform across the block)
   const int nStrips = (n + 15) >> 4;
-  const uint64_t kmask = (K >= 64) ? ~0ull : ((1ull << K) - 1ull);
   uint32_t D = 0;
 
   for (int attempt = 0;; attempt++) {
-    for (int i = tid; i < HT; i += nthr) { tab.key[i] = MM_HASH_MAX; tab.first[i] = 0x7fffffff; tab.last[i] = -1; tab.sum[i] = 0; }
+    tab.set_cut(T, (uint32_t)HT);
+    for (int i = tid; i < NS; i += nthr) { tab.key[i] = MM_HASH_MAX; tab.first[i] = 0x7fffffff; tab.last[i] = -1; tab.sum[i] = 0; }
     if (tid < 4) tab.counters[tid] = 0;
     __syncthreads();
 
     // ---- phase 1: hash both strands of every k-mer ----
+    const uint32_t qBase = (uint32_t)(tid >> 6) * QC, qEnd = qBase + QC;
+    uint32_t qHead = qBase;                         // wave-uniform (only ballots feed it)
+    const bool allPass = (T == MM_HASH_MAX);
     for (int strip = tid; strip < nStrips; strip += nthr) {
-      uint64_t nm = 0;
+      // bit j: position strip*16+j exists and its k-mer holds no N
+      const int rem = n - strip * 16;
+      uint32_t ok = rem >= 16 ? 0xFFFFu : ((1u << rem) - 1u);
       if (hasN) {
         const uint64_t m64 = (uint64_t)sM[strip >> 1] | ((uint64_t)sM[(strip >> 1) + 1] << 32);
-        nm = m64 >> ((strip & 1) * 16);
+        ok &= ~(uint32_t)mm_window_or<K>(m64 >> ((strip & 1) * 16));
       }
       mm_strip_hashes<K>(sW[strip], sW[strip + 1], sW[strip + 2], *tabs, [&](int j, uint64_t hf, uint64_t hr) {
         const int pos = strip * 16 + j;
         const uint64_t h = hf < hr ? hf : hr;
-        bool pass = (pos < n) & (hf != hr) & (T == MM_HASH_MAX ? true : h < T);
-        if (hasN) pass = pass & (((nm >> j) & kmask) == 0);
-        const int sgn = hf < hr ? 1 : -1;
+        bool pass = false;                          // nested ifs: the compiler keeps the three tests as exec masks
+        if ((ok & (1u << j)) != 0) { if (hf != hr) { if (allPass || h < T) pass = true; } }
         if (HARD) {
-          if (pass) tab.insert(h, pos, sgn);
+          if (pass) tab.insert(h, pos, hf < hr ? 1 : -1);
         } else {
-          const uint64_t m = __ballot(pass);
-          if (m) {
-            uint32_t base = 0;
-            if (mm_lane() == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(&tab.counters[2], (uint32_t)__popcll(m));
-            base = __shfl(base, __builtin_ctzll(m));
-            if (pass) {
-              const uint32_t idx = base + mm_popc_below(m);
-              if (idx < (uint32_t)HT) { arrA[idx] = h; arrB[idx] = ((uint32_t)pos << 1) | (sgn > 0 ? 1u : 0u); }
-            }
-          }
+          const uint64_t m = __builtin_amdgcn_ballot_w64(pass);
+          const uint32_t idx = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, qHead));
+          if (pass && idx < qEnd) { qH[idx] = h; qM[idx] = ((uint32_t)pos << 1) | (hf < hr ? 1u : 0u); }
+          qHead += (uint32_t)__popcll(m);
         }
       });
     }
+    uint32_t qCount = qHead - qBase;
+    if (!HARD) {
+      // every wave drains its own queue (LDS operations of one wave complete in order)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      // lanes that left the strip loop early (or never entered it) hold a stale count; lane 0 owns the smallest strip
+      qCount = (uint32_t)__builtin_amdgcn_readfirstlane((int)qCount);
+      if (qCount > QC) { if (mm_lane() == 0) atomicOr(&tab.counters[1], 1u); }
+      else {
+        for (uint32_t i = mm_lane(); i < qCount; i += 64) { const uint32_t m = qM[qBase + i]; tab.insert(qH[qBase + i], (int)(m >> 1), (m & 1u) ? 1 : -1); }
+      }
+    }
     __syncthreads();
 
-    bool fail = false;
-    if (!HARD) {
-      const uint32_t qn = tab.counters[2];
-      if (qn > (uint32_t)HT) fail = true;
-      else {
-        for (uint32_t i = tid; i < qn; i += nthr) { const uint32_t m = arrB[i]; tab.insert(arrA[i], (int)(m >> 1), (m & 1u) ? 1 : -1); }
-      }
-      __syncthreads();
-    }
     D = tab.counters[0];
     const bool overflow = tab.counters[1] != 0;
     if (!HARD) {
-      if (fail || overflow || (D < (uint32_t)s && T != MM_HASH_MAX)) {
+      if (overflow || (D < (uint32_t)s && T != MM_HASH_MAX)) {
         if (tid == 0) { const uint32_t at = atomicAdd(hardCount, 1u); hardList[at] = f; skCount[f] = 0; }
         return;
       }
@@ -204,48 +241,50 @@ k_sketch_fragments(const uint32_t* __restrict__ bases2, const uint32_t* __restri
     }
   }
 
-  // ---- compact distinct entries into (key, slot) pairs, pad to a power of two, bitonic sort ----
-  uint32_t n2 = 1; while (n2 < D) n2 <<= 1;
-  if (n2 > (uint32_t)HT) n2 = HT;
-  for (int i = tid; i < HT; i += nthr) {
-    const uint64_t kx = tab.key[i];
-    if (kx != MM_HASH_MAX) { const uint32_t at = atomicAdd(&tab.counters[3], 1u); arrA[at] = kx; arrB[at] = (uint32_t)i; }
-  }
-  __syncthreads();
-  for (uint32_t i = D + tid; i < n2; i += nthr) { arrA[i] = MM_HASH_MAX; arrB[i] = 0; }
-  __syncthreads();
-  for (uint32_t k2 = 2; k2 <= n2; k2 <<= 1) {
-    for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
-      for (uint32_t i = tid; i < n2; i += nthr) {
-        const uint32_t p = i ^ j;
-        if (p > i) {
-          const uint64_t a = arrA[i], b = arrA[p];
-          const bool up = (i & k2) == 0;
-          if ((a > b) == up) { arrA[i] = b; arrA[p] = a; const uint32_t t = arrB[i]; arrB[i] = arrB[p]; arrB[p] = t; }
-        }
-      }
-      __syncthreads();
+  // ---- occupancy words, their prefix counts ----
+  for (int base = 0; base < NS; base += nthr) {
+    const int slot = base + tid;                    // NS and nthr are multiples of 64: a wave is in or out as a whole
+    if (slot < NS) {
+      const uint64_t m = __ballot(tab.key[slot] != MM_HASH_MAX);
+      if (mm_lane() == 0) tab.occW[slot >> 6] = m;
     }
   }
-
-  // ---- emit the s smallest distinct hashes, ascending (commonFunc.hpp:278-286) ----
-  const uint32_t cnt = D < (uint32_t)s ? D : (uint32_t)s;
-  for (uint32_t r = tid; r < cnt; r += nthr) {
-    const uint32_t slot = arrB[r];
-    const size_t o = (size_t)f * s + r;
-    skHash[o] = arrA[r];
-    skPos[o] = make_int2(tab.first[slot], tab.last[slot]);
-    // the reference accumulates the strand in an int16 (base_types.hpp:24, commonFunc.hpp:268)
-    const int16_t acc = (int16_t)tab.sum[slot];
-    skStrand[o] = acc > 0 ? 1 : (acc == 0 ? 0 : -1);
+  __syncthreads();
+  for (int w = tid; w < nOcc; w += nthr) {
+    uint32_t acc = 0;
+    for (int q = 0; q < w; q++) acc += (uint32_t)__popcll(tab.occW[q]);
+    tab.occP[w] = acc;
   }
-  if (tid == 0) skCount[f] = cnt;
+  __syncthreads();
+
+  // ---- rank every key inside its cluster; emit the s smallest, ascending (commonFunc.hpp:278-286) ----
+  for (int slot = tid; slot < NS; slot += nthr) {
+    const uint64_t k = tab.key[slot];
+    if (k == MM_HASH_MAX) continue;
+    uint32_t smaller = 0;
+    int q = slot;                                   // -> first slot of the cluster
+    while (q > 0) { const uint64_t o = tab.key[q - 1]; if (o == MM_HASH_MAX) break; smaller += o < k ? 1u : 0u; q--; }
+    for (int r = slot + 1; r < NS; r++) { const uint64_t o = tab.key[r]; if (o == MM_HASH_MAX) break; smaller += o < k ? 1u : 0u; }
+    const uint64_t below = tab.occW[q >> 6] & ((1ull << (q & 63)) - 1ull);
+    const uint32_t rank = tab.occP[q >> 6] + (uint32_t)__popcll(below) + smaller;
+    if (rank < (uint32_t)s) {
+      const size_t o = (size_t)f * s + rank;
+      skHash[o] = k;
+      skPos[o] = make_int2(tab.first[slot], tab.last[slot]);
+      // the reference accumulates the strand in an int16 (base_types.hpp:24, commonFunc.hpp:268)
+      const int16_t acc = (int16_t)tab.sum[slot];
+      skStrand[o] = acc > 0 ? 1 : (acc == 0 ? 0 : -1);
+    }
+  }
+  if (tid == 0) skCount[f] = D < (uint32_t)s ? D : (uint32_t)s;
 }
 
 // ---------------------------------------------------------------------------------------------
-static size_t sketch_lds_bytes(int maxLen, int HT) {
+static size_t sketch_lds_bytes(int maxLen, int HT, int PAD, bool hard) {
   const size_t nW = (size_t)(maxLen + 15) / 16 + 3, nM = (size_t)(maxLen + 31) / 32 + 2;
-  return sizeof(MMTables) + ((nW * 4 + 15) / 16) * 16 + ((nM * 4 + 15) / 16) * 16 + (size_t)HT * (8 + 4 + 8 + 4 + 4 + 4) + 16;
+  const size_t NS = (size_t)HT + PAD, nOcc = NS / 64;
+  return sizeof(MMTables) + ((nW * 4 + 15) / 16) * 16 + ((nM * 4 + 15) / 16) * 16 + (hard ? 0 : (size_t)HT * 12) +
+         NS * (8 + 4 + 4 + 4) + nOcc * 8 + ((nOcc * 4 + 15) / 16) * 16 + 16;
 }
 static int next_pow2(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 
@@ -256,7 +295,8 @@ static int launch_sketch_k(mm_ctx* c) {
   const int HT = next_pow2(s * 3 < 256 ? 256 : s * 3);
   const int HTH = next_pow2(s * 4 < 4096 ? 4096 : s * 4);
   const int maxLen = c->maxFragLen;
-  const size_t ldsFast = sketch_lds_bytes(maxLen, HT), ldsHard = sketch_lds_bytes(maxLen, HTH);
+  const int PAD = 64, PADH = 256;                   // spill slots behind the ordered tables (no wrap-around)
+  const size_t ldsFast = sketch_lds_bytes(maxLen, HT, PAD, false), ldsHard = sketch_lds_bytes(maxLen, HTH, PADH, true);
   if (ldsHard > 160 * 1024) { c->err = "fragment too long / sketch too large for the LDS-resident sketch kernel"; return MM_ERR_ARG; }
   int nStrips = (maxLen - K + 1 + 15) / 16; if (nStrips < 1) nStrips = 1;
   int threads = ((nStrips + 63) / 64) * 64; if (threads > 1024) threads = 1024; if (threads < 64) threads = 64;
@@ -267,7 +307,7 @@ static int launch_sketch_k(mm_ctx* c) {
     KernelTimer t(c, MM_K_SKETCH);
     hipLaunchKernelGGL((k_sketch_fragments<K, false>), dim3(nF), dim3(threads), ldsFast, c->stream,
                        c->dBases2.as<uint32_t>(), c->dNmask.as<uint32_t>(), c->dFrags.as<DFrag>(), c->dReadHasN.as<uint32_t>(),
-                       (const int32_t*)nullptr, s, HT, c->dSkHash.as<uint64_t>(), c->dSkPos.as<int2>(), c->dSkStrand.as<int8_t>(),
+                       (const int32_t*)nullptr, s, HT, PAD, c->dSkHash.as<uint64_t>(), c->dSkPos.as<int2>(), c->dSkStrand.as<int8_t>(),
                        c->dSkCount.as<uint32_t>(), c->dHardList.as<int32_t>(), c->dCounters.as<uint32_t>());
     MM_HIP(c, hipGetLastError());
   }
@@ -279,7 +319,7 @@ static int launch_sketch_k(mm_ctx* c) {
     KernelTimer t(c, MM_K_SKETCH_HARD);
     hipLaunchKernelGGL((k_sketch_fragments<K, true>), dim3(nHard), dim3(threads), ldsHard, c->stream,
                        c->dBases2.as<uint32_t>(), c->dNmask.as<uint32_t>(), c->dFrags.as<DFrag>(), c->dReadHasN.as<uint32_t>(),
-                       c->dHardList.as<int32_t>(), s, HTH, c->dSkHash.as<uint64_t>(), c->dSkPos.as<int2>(), c->dSkStrand.as<int8_t>(),
+                       c->dHardList.as<int32_t>(), s, HTH, PADH, c->dSkHash.as<uint64_t>(), c->dSkPos.as<int2>(), c->dSkStrand.as<int8_t>(),
                        c->dSkCount.as<uint32_t>(), c->dHardList.as<int32_t>(), c->dCounters.as<uint32_t>() + 1);
     MM_HIP(c, hipGetLastError());
   }
