@@ -190,3 +190,96 @@ __device__ __forceinline__ void MMStrip::load(uint32_t w0, uint32_t w1, uint32_t
   }
   F[12] = 0; R[12] = 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Product-table strip hasher (K = 17..19).  The two block products of MurmurHash3 are linear in the key bytes:
+//   k1 * C1 = ascii4(bases j..j+3) * C1 + ((ascii4(bases j+4..j+7) * C1) << 32)      (mod 2^64)
+// and a group of 4 bases has only 256 values, so a 256-entry LDS table of 64-bit products per (strand, constant) replaces
+// the ASCII reconstruction and 4 of the 8 remaining 64-bit multiplies per position pair: one 8-byte read, one 4-byte read
+// (the low word of the entry of the next group) and one 32-bit add per product.  The look-ups depend only on the packed
+// words, not on the hash chain, so they are issued ahead of it.  The reverse strand reads the same 8-bit windows through
+// tables built from the reverse complement of the group.  Bit-exact with mm_murmur_kmer<K>.
+// ---------------------------------------------------------------------------------------------
+struct MMProdTables {        // lives in LDS (first thing in the dynamic segment); 9 KB
+  uint64_t pf1[256];         // ascii4(c) * C1            forward strand, block word k1
+  uint64_t pf2[256];         // ascii4(c) * C2            forward strand, block word k2
+  uint64_t pr1[256];         // ascii4(revcomp c) * C1    reverse strand, k1
+  uint64_t pr2[256];         // ascii4(revcomp c) * C2    reverse strand, k2
+  uint64_t tailF[64];        // as MMTables
+  uint64_t tailR[64];
+};
+
+template <int K>
+__device__ __forceinline__ void mm_tables_init(MMProdTables& T, int tid, int nthr) {
+  constexpr int TAIL = K - 16;
+  for (int c = tid; c < 256; c += nthr) {
+    uint32_t f = 0, r = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      f |= mm_ascii1((c >> (2 * i)) & 3) << (8 * i);
+      r |= mm_ascii1(3 - ((c >> (2 * (3 - i))) & 3)) << (8 * i);
+    }
+    T.pf1[c] = (uint64_t)f * MM_C1; T.pf2[c] = (uint64_t)f * MM_C2;
+    T.pr1[c] = (uint64_t)r * MM_C1; T.pr2[c] = (uint64_t)r * MM_C2;
+  }
+  for (int c = tid; c < 64; c += nthr) {
+    uint64_t kf = 0, kr = 0;
+#pragma unroll
+    for (int i = 0; i < TAIL; i++) {
+      kf |= (uint64_t)mm_ascii1((c >> (2 * i)) & 3) << (8 * i);
+      kr |= (uint64_t)mm_ascii1(3 - ((c >> (2 * (TAIL - 1 - i))) & 3)) << (8 * i);
+    }
+    T.tailF[c] = mm_mix_k1(kf);
+    T.tailR[c] = mm_mix_k1(kr);
+  }
+}
+
+// byte offset (index * 8) into a table of 8-byte entries of the NB-base window that starts at base p (compile-time) of w[0..2]
+template <int NB>
+__device__ __forceinline__ uint32_t mm_win_off8(const uint32_t* w, int p) {
+  const int word = p >> 4, bit = 2 * (p & 15);
+  constexpr uint32_t mask = ((1u << (2 * NB)) - 1u) << 3;
+  uint32_t x;
+  if (bit + 2 * NB <= 32) x = bit >= 3 ? (w[word] >> (bit - 3)) : (w[word] << (3 - bit));
+  else x = __builtin_amdgcn_alignbit(w[word + 1], w[word], bit - 3);
+  return x & mask;
+}
+__device__ __forceinline__ uint64_t mm_lds64(const uint64_t* tab, uint32_t byteOff) { return *(const uint64_t*)((const unsigned char*)tab + byteOff); }
+__device__ __forceinline__ uint32_t mm_lds32(const uint64_t* tab, uint32_t byteOff) { return *(const uint32_t*)((const unsigned char*)tab + byteOff); }
+
+// the hash from the two block products p1 = k1*C1, p2 = k2*C2 and the complete tail mix
+template <int K>
+__device__ __forceinline__ uint64_t mm_murmur_from_products(uint64_t p1, uint64_t p2, uint64_t tailMix) {
+  uint64_t h1 = MM_SEED, h2 = MM_SEED;
+  h1 ^= mm_rotl64(p1, 31) * MM_C2; h1 = mm_rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
+  h2 ^= mm_rotl64(p2, 33) * MM_C1; h2 = mm_rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
+  h1 ^= tailMix;
+  h1 ^= (uint64_t)K; h2 ^= (uint64_t)K;
+  h1 += h2; h2 += h1;
+  h1 = mm_fmix64(h1); h2 = mm_fmix64(h2);
+  return h1 + h2;
+}
+
+template <int K, class Use>
+__device__ __forceinline__ void mm_strip_hashes(uint32_t w0, uint32_t w1, uint32_t w2, const MMProdTables& T, Use&& use) {
+  static_assert(MMFastK<K>::value, "product tables need exactly one 16-byte block and a tail of 1..3 bases");
+  constexpr int TAIL = K - 16;
+  const uint32_t w[3] = {w0, w1, w2};
+  uint32_t a[32];                                   // a[p]: table offset of the 4-base group starting at base p (unused ones fold away)
+#pragma unroll
+  for (int p = 0; p < 31; p++) a[p] = mm_win_off8<4>(w, p);
+#pragma unroll
+  for (int j = 0; j < 16; j++) {
+    uint64_t f1 = mm_lds64(T.pf1, a[j]), f2 = mm_lds64(T.pf2, a[j + 8]);
+    f1 += (uint64_t)mm_lds32(T.pf1, a[j + 4]) << 32; f2 += (uint64_t)mm_lds32(T.pf2, a[j + 12]) << 32;
+    // reverse complement of k-mer j: byte i = comp(base j+K-1-i), so its 4-byte groups are the windows at j+K-4, j+K-8, ...
+    uint64_t r1 = mm_lds64(T.pr1, a[j + K - 4]), r2 = mm_lds64(T.pr2, a[j + K - 12]);
+    r1 += (uint64_t)mm_lds32(T.pr1, a[j + K - 8]) << 32; r2 += (uint64_t)mm_lds32(T.pr2, a[j + K - 16]) << 32;
+    const uint64_t tf = mm_lds64(T.tailF, mm_win_off8<TAIL>(w, j + 16)), tr = mm_lds64(T.tailR, mm_win_off8<TAIL>(w, j));
+    use(j, mm_murmur_from_products<K>(f1, f2, tf), mm_murmur_from_products<K>(r1, r2, tr));
+  }
+}
+
+// table type of the strip hasher for a given K
+template <int K, bool FAST = MMFastK<K>::value> struct MMTabsFor { using type = MMTables; };
+template <int K> struct MMTabsFor<K, true> { using type = MMProdTables; };

@@ -131,7 +131,8 @@ k_sketch_fragments(const uint32_t* __restrict__ bases2, const uint32_t* __restri
   const int nWaves = nthr >> 6;
   const uint32_t QC = HARD ? 0u : (uint32_t)HT / (uint32_t)nWaves;     // queue slots per wave
   size_t off = 0;
-  MMTables* tabs = (MMTables*)(smem + off); off += sizeof(MMTables);
+  using Tabs = typename MMTabsFor<K>::type;
+  Tabs* tabs = (Tabs*)(smem + off); off += sizeof(Tabs);
   mm_tables_init<K>(*tabs, tid, nthr);                           // made visible by the first __syncthreads() below
   uint32_t* sW = (uint32_t*)(smem + off); off += (((size_t)nW * 4 + 15) / 16) * 16;
   uint32_t* sM = (uint32_t*)(smem + off); off += (((size_t)nM * 4 + 15) / 16) * 16;
@@ -280,10 +281,10 @@ k_sketch_fragments(const uint32_t* __restrict__ bases2, const uint32_t* __restri
 }
 
 // ---------------------------------------------------------------------------------------------
-static size_t sketch_lds_bytes(int maxLen, int HT, int PAD, bool hard) {
+static size_t sketch_lds_bytes(size_t tabBytes, int maxLen, int HT, int PAD, bool hard) {
   const size_t nW = (size_t)(maxLen + 15) / 16 + 3, nM = (size_t)(maxLen + 31) / 32 + 2;
   const size_t NS = (size_t)HT + PAD, nOcc = NS / 64;
-  return sizeof(MMTables) + ((nW * 4 + 15) / 16) * 16 + ((nM * 4 + 15) / 16) * 16 + (hard ? 0 : (size_t)HT * 12) +
+  return tabBytes + ((nW * 4 + 15) / 16) * 16 + ((nM * 4 + 15) / 16) * 16 + (hard ? 0 : (size_t)HT * 12) +
          NS * (8 + 4 + 4 + 4) + nOcc * 8 + ((nOcc * 4 + 15) / 16) * 16 + 16;
 }
 static int next_pow2(int x) { int p = 1; while (p < x) p <<= 1; return p; }
@@ -296,7 +297,8 @@ static int launch_sketch_k(mm_ctx* c) {
   const int HTH = next_pow2(s * 4 < 4096 ? 4096 : s * 4);
   const int maxLen = c->maxFragLen;
   const int PAD = 64, PADH = 256;                   // spill slots behind the ordered tables (no wrap-around)
-  const size_t ldsFast = sketch_lds_bytes(maxLen, HT, PAD, false), ldsHard = sketch_lds_bytes(maxLen, HTH, PADH, true);
+  const size_t ldsFast = sketch_lds_bytes(sizeof(typename MMTabsFor<K>::type), maxLen, HT, PAD, false),
+               ldsHard = sketch_lds_bytes(sizeof(typename MMTabsFor<K>::type), maxLen, HTH, PADH, true);
   if (ldsHard > 160 * 1024) { c->err = "fragment too long / sketch too large for the LDS-resident sketch kernel"; return MM_ERR_ARG; }
   int nStrips = (maxLen - K + 1 + 15) / 16; if (nStrips < 1) nStrips = 1;
   int threads = ((nStrips + 63) / 64) * 64; if (threads > 1024) threads = 1024; if (threads < 64) threads = 64;
