@@ -205,7 +205,7 @@ struct MMProdTables {        // lives in LDS (first thing in the dynamic segment
   uint64_t pf2[256];         // ascii4(c) * C2            forward strand, block word k2
   uint64_t pr1[256];         // ascii4(revcomp c) * C1    reverse strand, k1
   uint64_t pr2[256];         // ascii4(revcomp c) * C2    reverse strand, k2
-  uint64_t tailF[64];        // as MMTables
+  uint64_t tailF[64];        // as MMTables, ^ K
   uint64_t tailR[64];
 };
 
@@ -229,8 +229,8 @@ __device__ __forceinline__ void mm_tables_init(MMProdTables& T, int tid, int nth
       kf |= (uint64_t)mm_ascii1((c >> (2 * i)) & 3) << (8 * i);
       kr |= (uint64_t)mm_ascii1(3 - ((c >> (2 * (TAIL - 1 - i))) & 3)) << (8 * i);
     }
-    T.tailF[c] = mm_mix_k1(kf);
-    T.tailR[c] = mm_mix_k1(kr);
+    T.tailF[c] = mm_mix_k1(kf) ^ (uint64_t)K;       // h1 ^= tail mix; h1 ^= len  in one xor
+    T.tailR[c] = mm_mix_k1(kr) ^ (uint64_t)K;
   }
 }
 
@@ -247,14 +247,21 @@ __device__ __forceinline__ uint32_t mm_win_off8(const uint32_t* w, int p) {
 __device__ __forceinline__ uint64_t mm_lds64(const uint64_t* tab, uint32_t byteOff) { return *(const uint64_t*)((const unsigned char*)tab + byteOff); }
 __device__ __forceinline__ uint32_t mm_lds32(const uint64_t* tab, uint32_t byteOff) { return *(const uint32_t*)((const unsigned char*)tab + byteOff); }
 
-// the hash from the two block products p1 = k1*C1, p2 = k2*C2 and the complete tail mix
+// h * 5 as one v_lshl_add_u64 ((h << 2) + h); hipcc's own choice is two v_mad_u64_u32 plus two moves to pair their operands
+__device__ __forceinline__ uint64_t mm_times5(uint64_t h) {
+  uint64_t r;
+  asm("v_lshl_add_u64 %0, %1, 2, %1" : "=v"(r) : "v"(h));
+  return r;
+}
+
+// the hash from the two block products p1 = k1*C1, p2 = k2*C2 and the complete tail mix with the key length folded in (tailMixK = mix ^ K)
 template <int K>
-__device__ __forceinline__ uint64_t mm_murmur_from_products(uint64_t p1, uint64_t p2, uint64_t tailMix) {
+__device__ __forceinline__ uint64_t mm_murmur_from_products(uint64_t p1, uint64_t p2, uint64_t tailMixK) {
   uint64_t h1 = MM_SEED, h2 = MM_SEED;
-  h1 ^= mm_rotl64(p1, 31) * MM_C2; h1 = mm_rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
-  h2 ^= mm_rotl64(p2, 33) * MM_C1; h2 = mm_rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
-  h1 ^= tailMix;
-  h1 ^= (uint64_t)K; h2 ^= (uint64_t)K;
+  h1 ^= mm_rotl64(p1, 31) * MM_C2; h1 = mm_rotl64(h1, 27); h1 += h2; h1 = mm_times5(h1) + 0x52dce729;
+  h2 ^= mm_rotl64(p2, 33) * MM_C1; h2 = mm_rotl64(h2, 31); h2 += h1; h2 = mm_times5(h2) + 0x38495ab5;
+  h1 ^= tailMixK;
+  h2 ^= (uint64_t)K;
   h1 += h2; h2 += h1;
   h1 = mm_fmix64(h1); h2 = mm_fmix64(h2);
   return h1 + h2;
