@@ -109,7 +109,7 @@ __device__ __forceinline__ uint64_t mm_window_or(uint64_t x) {
 // ---------------------------------------------------------------------------------------------
 template <int K, bool HARD>
 __global__ void __launch_bounds__(1024)
-k_sketch_fragments(const uint32_t* __restrict__ bases2, const uint32_t* __restrict__ nmask,
+k_sketch_fragments(const uint4* __restrict__ gTabs, const uint32_t* __restrict__ bases2, const uint32_t* __restrict__ nmask,
                    const DFrag* __restrict__ frags, const uint32_t* __restrict__ readHasN,
                    const int32_t* __restrict__ fragList, int s, int HT, int PAD,
                    uint64_t* __restrict__ skHash, int2* __restrict__ skPos, int8_t* __restrict__ skStrand,
@@ -133,7 +133,8 @@ k_sketch_fragments(const uint32_t* __restrict__ bases2, const uint32_t* __restri
   size_t off = 0;
   using Tabs = typename MMTabsFor<K>::type;
   Tabs* tabs = (Tabs*)(smem + off); off += sizeof(Tabs);
-  mm_tables_init<K>(*tabs, tid, nthr);                           // made visible by the first __syncthreads() below
+  static_assert(sizeof(Tabs) % 16 == 0, "tables are copied in 16-byte pieces");
+  for (int i = tid; i < (int)(sizeof(Tabs) / 16); i += nthr) ((uint4*)tabs)[i] = gTabs[i];   // visible after the first __syncthreads() below
   uint32_t* sW = (uint32_t*)(smem + off); off += (((size_t)nW * 4 + 15) / 16) * 16;
   uint32_t* sM = (uint32_t*)(smem + off); off += (((size_t)nM * 4 + 15) / 16) * 16;
   uint64_t* qH = (uint64_t*)(smem + off); off += HARD ? 0 : (size_t)HT * 8;     // per-wave queues: hashes
@@ -280,6 +281,10 @@ k_sketch_fragments(const uint32_t* __restrict__ bases2, const uint32_t* __restri
   if (tid == 0) skCount[f] = D < (uint32_t)s ? D : (uint32_t)s;
 }
 
+// strip-hasher tables, built once per context and k-mer size
+template <int K>
+__global__ void k_sketch_tables(typename MMTabsFor<K>::type* out) { mm_tables_init<K>(*out, (int)threadIdx.x, (int)blockDim.x); }
+
 // ---------------------------------------------------------------------------------------------
 static size_t sketch_lds_bytes(size_t tabBytes, int maxLen, int HT, int PAD, bool hard) {
   const size_t nW = (size_t)(maxLen + 15) / 16 + 3, nM = (size_t)(maxLen + 31) / 32 + 2;
@@ -302,13 +307,20 @@ static int launch_sketch_k(mm_ctx* c) {
   if (ldsHard > 160 * 1024) { c->err = "fragment too long / sketch too large for the LDS-resident sketch kernel"; return MM_ERR_ARG; }
   int nStrips = (maxLen - K + 1 + 15) / 16; if (nStrips < 1) nStrips = 1;
   int threads = ((nStrips + 63) / 64) * 64; if (threads > 1024) threads = 1024; if (threads < 64) threads = 64;
+  using Tabs = typename MMTabsFor<K>::type;
+  if (c->sketchTabsK != K) {
+    MM_HIP(c, c->dSketchTabs.ensure(sizeof(Tabs)));
+    hipLaunchKernelGGL((k_sketch_tables<K>), dim3(1), dim3(256), 0, c->stream, c->dSketchTabs.as<Tabs>());
+    MM_HIP(c, hipGetLastError());
+    c->sketchTabsK = K;
+  }
   MM_HIP(c, hipMemsetAsync(c->dCounters.p, 0, 64, c->stream));
   MM_HIP(c, hipFuncSetAttribute((const void*)k_sketch_fragments<K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsFast));
   MM_HIP(c, hipFuncSetAttribute((const void*)k_sketch_fragments<K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsHard));
   {
     KernelTimer t(c, MM_K_SKETCH);
     hipLaunchKernelGGL((k_sketch_fragments<K, false>), dim3(nF), dim3(threads), ldsFast, c->stream,
-                       c->dBases2.as<uint32_t>(), c->dNmask.as<uint32_t>(), c->dFrags.as<DFrag>(), c->dReadHasN.as<uint32_t>(),
+                       c->dSketchTabs.as<uint4>(), c->dBases2.as<uint32_t>(), c->dNmask.as<uint32_t>(), c->dFrags.as<DFrag>(), c->dReadHasN.as<uint32_t>(),
                        (const int32_t*)nullptr, s, HT, PAD, c->dSkHash.as<uint64_t>(), c->dSkPos.as<int2>(), c->dSkStrand.as<int8_t>(),
                        c->dSkCount.as<uint32_t>(), c->dHardList.as<int32_t>(), c->dCounters.as<uint32_t>());
     MM_HIP(c, hipGetLastError());
@@ -320,7 +332,7 @@ static int launch_sketch_k(mm_ctx* c) {
   if (nHard) {
     KernelTimer t(c, MM_K_SKETCH_HARD);
     hipLaunchKernelGGL((k_sketch_fragments<K, true>), dim3(nHard), dim3(threads), ldsHard, c->stream,
-                       c->dBases2.as<uint32_t>(), c->dNmask.as<uint32_t>(), c->dFrags.as<DFrag>(), c->dReadHasN.as<uint32_t>(),
+                       c->dSketchTabs.as<uint4>(), c->dBases2.as<uint32_t>(), c->dNmask.as<uint32_t>(), c->dFrags.as<DFrag>(), c->dReadHasN.as<uint32_t>(),
                        c->dHardList.as<int32_t>(), s, HTH, PADH, c->dSkHash.as<uint64_t>(), c->dSkPos.as<int2>(), c->dSkStrand.as<int8_t>(),
                        c->dSkCount.as<uint32_t>(), c->dHardList.as<int32_t>(), c->dCounters.as<uint32_t>() + 1);
     MM_HIP(c, hipGetLastError());
