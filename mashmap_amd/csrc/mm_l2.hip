@@ -161,10 +161,15 @@ k_l2_locate(int nCand, int s, const mm_l1_candidate* __restrict__ l1, const mm_f
     const int sh = qmax ? (int)__builtin_clzll(qmax) : 63;
     const float scale = 256.0f / ((float)(uint32_t)((qmax << sh) >> 40) + 1.0f);
     auto bucket = [&](uint64_t h) -> int { const int b = (int)((float)(uint32_t)((h << sh) >> 40) * scale); return b > 255 ? 255 : b; };
-    for (int b = lane; b <= 256; b += 64) {                        // bkt[b] = lower_bound over the (sorted) buckets of q
-      int lo = 0, hi = S;
-      while (lo < hi) { const int mid = (lo + hi) >> 1; if (bucket(q[mid]) < b) lo = mid + 1; else hi = mid; }
-      bkt[b] = (uint16_t)lo;
+    // bkt[b] = #{p : bucket(q[p]) < b}.  q is sorted, so entry p owns the buckets (bucket(q[p-1]), bucket(q[p])] and the
+    // sentinel p = S owns the rest up to 256: a scatter of ~2 stores per lane instead of 257 binary searches
+    for (int p0 = 0; p0 <= S; p0 += 64) {
+      const int p = p0 + lane;
+      if (p <= S) {
+        const int from = p == 0 ? 0 : bucket(q[p - 1]) + 1;
+        const int to = p == S ? 256 : bucket(q[p]);
+        for (int b = from; b <= to; b++) bkt[b] = (uint16_t)p;
+      }
     }
     __threadfence_block();
     auto locate = [&](uint64_t h) -> uint32_t {

@@ -7,6 +7,7 @@
 // packed input is only 0.25 B/bp (+0.125 B/bp N mask).  See DESIGN.md for the roofline terms.
 #include "mm_internal.h"
 #include "mm_device.h"
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 
@@ -111,7 +112,7 @@ template <int K, bool HARD>
 __global__ void __launch_bounds__(1024)
 k_sketch_fragments(const uint4* __restrict__ gTabs, const uint32_t* __restrict__ bases2, const uint32_t* __restrict__ nmask,
                    const DFrag* __restrict__ frags, const uint32_t* __restrict__ readHasN,
-                   const int32_t* __restrict__ fragList, int s, int HT, int PAD,
+                   const int32_t* __restrict__ fragList, int s, int wantFast, int HT, int PAD,
                    uint64_t* __restrict__ skHash, int2* __restrict__ skPos, int8_t* __restrict__ skStrand,
                    uint32_t* __restrict__ skCount, int32_t* __restrict__ hardList, uint32_t* __restrict__ hardCount) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -165,12 +166,13 @@ k_sketch_fragments(const uint4* __restrict__ gTabs, const uint32_t* __restrict__
     }
   }
 
-  // threshold: expected s-th smallest of n uniform hashes is s/n * 2^64; take 1.75x (fast) as the cut
+  // threshold: the canonical hash is the smaller of two uniform 64-bit values, so P[h < T] ~ 2T / 2^64; the cut is placed
+  // where `want` (> s) survivors are expected.  Any T gives the exact sketch as long as >= s distinct hashes survive
+  // (checked below), so a float estimate is enough.
   uint64_t T;
   {
-    // the canonical hash is the smaller of two uniform 64-bit values, so P[h < T] ~ 2T / 2^64
-    const uint64_t want = HARD ? (uint64_t)s * 2u : ((uint64_t)s * 7u + 3u) / 4u;
-    T = (want >= (uint64_t)n) ? MM_HASH_MAX : (MM_HASH_MAX / (2ull * (uint64_t)n)) * want;
+    const uint32_t want = HARD ? (uint32_t)s * 2u : (uint32_t)wantFast;
+    T = (want >= (uint32_t)n) ? MM_HASH_MAX : (uint64_t)((float)want / (float)(2 * n) * 18446744073709551616.0f);
   }
   uint64_t lo = 0, hi = MM_HASH_MAX; bool hiInf = true;   // HARD bisection state (uniform across the block)
   const int nStrips = (n + 15) >> 4;
@@ -298,6 +300,11 @@ template <int K>
 static int launch_sketch_k(mm_ctx* c) {
   const int s = c->P.sketchSize;
   const int nF = (int)c->nFrags;
+  // survivors the fast kernel aims for: s + max(s/2, 4 sqrt(s)) (their count is ~Poisson, so s stays >= 4 sigma away);
+  // fewer = less queue/table work, more fragments redone by the hard kernel (1 in 2 M at s = 130).  MM_SKETCH_CUT = factor on s.
+  double margin = s * 0.5; if (margin < 4.0 * sqrt((double)s)) margin = 4.0 * sqrt((double)s);
+  int wantFast = (int)(s + margin + 0.999);
+  if (const char* e = getenv("MM_SKETCH_CUT")) { double cut = atof(e); if (cut < 1.05) cut = 1.05; if (cut > 2.5) cut = 2.5; wantFast = (int)(s * cut + 0.999); }
   const int HT = next_pow2(s * 3 < 256 ? 256 : s * 3);
   const int HTH = next_pow2(s * 4 < 4096 ? 4096 : s * 4);
   const int maxLen = c->maxFragLen;
@@ -321,7 +328,7 @@ static int launch_sketch_k(mm_ctx* c) {
     KernelTimer t(c, MM_K_SKETCH);
     hipLaunchKernelGGL((k_sketch_fragments<K, false>), dim3(nF), dim3(threads), ldsFast, c->stream,
                        c->dSketchTabs.as<uint4>(), c->dBases2.as<uint32_t>(), c->dNmask.as<uint32_t>(), c->dFrags.as<DFrag>(), c->dReadHasN.as<uint32_t>(),
-                       (const int32_t*)nullptr, s, HT, PAD, c->dSkHash.as<uint64_t>(), c->dSkPos.as<int2>(), c->dSkStrand.as<int8_t>(),
+                       (const int32_t*)nullptr, s, wantFast, HT, PAD, c->dSkHash.as<uint64_t>(), c->dSkPos.as<int2>(), c->dSkStrand.as<int8_t>(),
                        c->dSkCount.as<uint32_t>(), c->dHardList.as<int32_t>(), c->dCounters.as<uint32_t>());
     MM_HIP(c, hipGetLastError());
   }
@@ -333,7 +340,7 @@ static int launch_sketch_k(mm_ctx* c) {
     KernelTimer t(c, MM_K_SKETCH_HARD);
     hipLaunchKernelGGL((k_sketch_fragments<K, true>), dim3(nHard), dim3(threads), ldsHard, c->stream,
                        c->dSketchTabs.as<uint4>(), c->dBases2.as<uint32_t>(), c->dNmask.as<uint32_t>(), c->dFrags.as<DFrag>(), c->dReadHasN.as<uint32_t>(),
-                       c->dHardList.as<int32_t>(), s, HTH, PADH, c->dSkHash.as<uint64_t>(), c->dSkPos.as<int2>(), c->dSkStrand.as<int8_t>(),
+                       c->dHardList.as<int32_t>(), s, wantFast, HTH, PADH, c->dSkHash.as<uint64_t>(), c->dSkPos.as<int2>(), c->dSkStrand.as<int8_t>(),
                        c->dSkCount.as<uint32_t>(), c->dHardList.as<int32_t>(), c->dCounters.as<uint32_t>() + 1);
     MM_HIP(c, hipGetLastError());
   }
