@@ -71,8 +71,10 @@ struct SkTable {
 
   __device__ __forceinline__ void insert(uint64_t h, int pos, int st) {
     uint32_t slot = home(h);
-    while (true) {
-      if (((volatile uint32_t*)counters)[1]) return;
+    for (uint32_t probes = 1;; probes++) {
+      // a flooded table (hard kernel, cut still too high) is abandoned early; looked at every 16th probe only, the
+      // volatile generic load is slow
+      if ((probes & 15u) == 0 && ((volatile uint32_t*)counters)[1]) return;
       const unsigned long long prev = atomicCAS((unsigned long long*)&key[slot], (unsigned long long)MM_HASH_MAX,
                                                 (unsigned long long)h);
       if (prev == MM_HASH_MAX) {
