@@ -137,14 +137,47 @@ __device__ __forceinline__ int mm_wave_excl_scan(int v) {      // exclusive pref
   const int off = row == 0 ? 0 : row == 1 ? r0 : row == 2 ? r0 + r1 : r0 + r1 + r2;
   return x + off - v;
 }
-__device__ __forceinline__ uint64_t mm_shfl_xor64(uint64_t v, int m) {
-  return ((uint64_t)(uint32_t)__shfl_xor((int)(v >> 32), m) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)v, m);
+// value of lane (lane ^ M), M a power of two, without the LDS crossbar: DPP inside a row of 16, v_permlane{16,32}_swap
+// (gfx950) across rows.  All 64 lanes must be active.
+template <int M>
+__device__ __forceinline__ uint32_t mm_lane_xor32(uint32_t v, int lane) {
+  if constexpr (M == 1) return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, MM_DPP_QUAD_1032, 0xf, 0xf, false);
+  else if constexpr (M == 2) return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, MM_DPP_QUAD_2301, 0xf, 0xf, false);
+  else if constexpr (M == 4) {                                   // banks 0,2 (lane bit 2 clear) read lane+4, banks 1,3 read lane-4
+    const int t = __builtin_amdgcn_update_dpp((int)v, (int)v, 0x104 /* row_shl:4 */, 0xf, 0x5, false);
+    return (uint32_t)__builtin_amdgcn_update_dpp(t, (int)v, 0x114 /* row_shr:4 */, 0xf, 0xa, false);
+  } else if constexpr (M == 8) return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x128 /* row_ror:8 */, 0xf, 0xf, false);
+  else if constexpr (M == 16) {                                  // first' = (r0,r0,r2,r2), second' = (r1,r1,r3,r3)
+    const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    return (lane & 16) ? r[0] : r[1];
+  } else {
+    static_assert(M == 32, "lane distance");
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);   // first' = (lo,lo), second' = (hi,hi)
+    return (lane & 32) ? r[0] : r[1];
+  }
 }
-__device__ __forceinline__ uint64_t mm_shfl_up64(uint64_t v, int d) {
-  return ((uint64_t)(uint32_t)__shfl_up((int)(v >> 32), d) << 32) | (uint32_t)__shfl_up((int)(uint32_t)v, d);
+template <int M>
+__device__ __forceinline__ uint64_t mm_lane_xor64(uint64_t v, int lane) {
+  return ((uint64_t)mm_lane_xor32<M>((uint32_t)(v >> 32), lane) << 32) | mm_lane_xor32<M>((uint32_t)v, lane);
 }
-__device__ __forceinline__ uint64_t mm_shfl_down64(uint64_t v, int d) {
-  return ((uint64_t)(uint32_t)__shfl_down((int)(v >> 32), d) << 32) | (uint32_t)__shfl_down((int)(uint32_t)v, d);
+__device__ __forceinline__ uint64_t mm_shfl_xor64(uint64_t v, int m, int lane) {   // m: a power of two known after unrolling
+  switch (m) {
+    case 1: return mm_lane_xor64<1>(v, lane);
+    case 2: return mm_lane_xor64<2>(v, lane);
+    case 4: return mm_lane_xor64<4>(v, lane);
+    case 8: return mm_lane_xor64<8>(v, lane);
+    case 16: return mm_lane_xor64<16>(v, lane);
+    default: return mm_lane_xor64<32>(v, lane);
+  }
+}
+// neighbour lanes (lane 0 / lane 63 keep their own value, as __shfl_up / __shfl_down do) through DPP wave shifts
+__device__ __forceinline__ int mm_shfl_up1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false); }
+__device__ __forceinline__ int mm_shfl_down1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false); }
+__device__ __forceinline__ uint64_t mm_shfl_up64(uint64_t v, int d) {      // d == 1
+  return ((uint64_t)(uint32_t)mm_shfl_up1((int)(v >> 32)) << 32) | (uint32_t)mm_shfl_up1((int)(uint32_t)v);
+}
+__device__ __forceinline__ uint64_t mm_shfl_down64(uint64_t v, int d) {    // d == 1
+  return ((uint64_t)(uint32_t)mm_shfl_down1((int)(v >> 32)) << 32) | (uint32_t)mm_shfl_down1((int)(uint32_t)v);
 }
 
 struct MapFlags { int hg, skipSelf, skipPrefix, lowerTri; };
@@ -168,7 +201,7 @@ __device__ __forceinline__ void mm_wave_bitonic(uint64_t (&k)[R], int lane) {
 #pragma unroll
         for (int r = 0; r < R; r++) {
           const int idx = lane * R + r;
-          const uint64_t other = mm_shfl_xor64(k[r], lj);
+          const uint64_t other = mm_shfl_xor64(k[r], lj, lane);
           const bool up = (idx & k2) == 0, lower = (idx & j) == 0;
           const uint64_t mn = k[r] < other ? k[r] : other, mx = k[r] < other ? other : k[r];
           k[r] = (lower == up) ? mn : mx;
@@ -189,15 +222,13 @@ struct FuseScratch {
 
 // Interval points of the fragment's surviving seeds -> dst[0..P) (skip_self / skip_prefix / lower_triangular applied,
 // computeMap.hpp:891-896; dropped points become MM_EMPTY and sort to the end).  Returns the wave-wide count of kept points.
-template <class Dst>
-__device__ __forceinline__ int mm_gather_points(Dst dst, int outIdx, const uint64_t* __restrict__ seedVal, size_t fo,
+template <class Dst, class ValAt>
+__device__ __forceinline__ int mm_gather_points(Dst dst, int nRounds, ValAt&& valAt,
                                                 const uint64_t* __restrict__ ptKeys, const int32_t* __restrict__ refGroup,
                                                 int rg, int self, int seqCounter, MapFlags fl, int lane) {
   int nValid = 0, done = 0;
-  for (int base = 0; base < outIdx; base += 64) {
-    const int i = base + lane;
-    uint64_t val = 0;
-    if (i < outIdx) val = seedVal[fo + i];
+  for (int rd = 0; rd < nRounds; rd++) {
+    const uint64_t val = valAt(rd);                // table value of this lane's seed in round rd (0: none)
     const int c = (int)((val >> 1) & 0x7fffffull);
     const int my = done + mm_wave_excl_scan(c);
     const uint64_t src = val >> 24;
@@ -276,8 +307,8 @@ __device__ __forceinline__ int mm_l1_fused(uint64_t (&k)[R], FuseScratch& sc, in
   }
   bool pflag[R], nflag[R]; uint32_t pseq[R], nseq[R];
   {
-    const int upf = __shfl_up((int)flag[R - 1], 1), dnf = __shfl_down((int)flag[0], 1);
-    const int ups = __shfl_up((int)(gk[R - 1] >> 32), 1), dns = __shfl_down((int)(gk[0] >> 32), 1);
+    const int upf = mm_shfl_up1((int)flag[R - 1]), dnf = mm_shfl_down1((int)flag[0]);
+    const int ups = mm_shfl_up1((int)(gk[R - 1] >> 32)), dns = mm_shfl_down1((int)(gk[0] >> 32));
     pflag[0] = lane != 0 && upf; pseq[0] = (uint32_t)ups;
     nflag[R - 1] = lane != 63 && dnf; nseq[R - 1] = (uint32_t)dns;
     if (R == 2) { pflag[R - 1] = flag[0]; pseq[R - 1] = (uint32_t)(gk[0] >> 32); nflag[0] = flag[R - 1]; nseq[0] = (uint32_t)(gk[R - 1] >> 32); }
@@ -398,7 +429,8 @@ k_lookup_l1(int nFrags, int s, const DFrag* __restrict__ frags,
       const uint64_t m = __ballot(keep);
       if (keep) {
         const int idx = outIdx + (int)mm_popc_below(m);
-        qHash[fo + idx] = h[u]; qStrand[fo + idx] = skStrand[fo + r]; seedVal[fo + idx] = found[u] ? val[u] : 0ull;
+        qHash[fo + idx] = h[u]; qStrand[fo + idx] = skStrand[fo + r];
+        if (!oneBatch) seedVal[fo + idx] = found[u] ? val[u] : 0ull;   // sketches of more than 256 entries: the slow path re-reads them
       }
       const bool kf = keep && found[u];
       pv[u] = kf ? val[u] : 0ull;
@@ -460,7 +492,11 @@ k_lookup_l1(int nFrags, int s, const DFrag* __restrict__ frags,
     if (slots > 0 && off + (unsigned long long)slots > ptsCap) { ok = false; if (lane == 0) atomicOr(&counters[1], 1ull); }
     nValid = 0;
     if (ok && slots > 0) {
-      nValid = mm_gather_points(pts + off, outIdx, seedVal, fo, ptKeys, refGroup, rg, self, seqCounter, fl, lane);
+      // the table values are still in the probing lanes' registers (the order of the points is irrelevant: they are sorted next)
+      if (oneBatch) nValid = mm_gather_points(pts + off, 4, [&](int rd) { return rd == 0 ? pv[0] : rd == 1 ? pv[1] : rd == 2 ? pv[2] : pv[3]; },
+                                              ptKeys, refGroup, rg, self, seqCounter, fl, lane);
+      else nValid = mm_gather_points(pts + off, (outIdx + 63) >> 6, [&](int rd) { const int i = rd * 64 + lane; return i < outIdx ? seedVal[fo + i] : 0ull; },
+                                     ptKeys, refGroup, rg, self, seqCounter, fl, lane);
       for (int j = P + lane; j < slots; j += 64) pts[off + j] = MM_EMPTY;
     }
     if (lane == 0) {
