@@ -28,7 +28,8 @@
 
 #define MM_LOCAP0 8         // private L2 locus slots per candidate before the final compaction (doubled and re-run on overflow)
 
-struct L2Info { int64_t e0; int32_t nPre; int32_t nAll; };      // slice [e0, e0+nAll) of the contig's events, the first nPre before rangeStart
+struct L2Info { int64_t e0; int32_t nPre; int32_t nAll;         // slice [e0, e0+nAll) of the contig's events, the first nPre before rangeStart
+                int32_t sketch; int32_t pad; };                 // the fragment's sketchSize, bit 31: no seed was removed (take the raw sketch)
 struct L2Tmp { int32_t start, end, shared, strand; };
 
 // stream entry (uint32):
@@ -54,11 +55,12 @@ struct L2Tmp { int32_t start, end, shared, strand; };
 
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-k_l2_extents(int nCand, int segLength, const mm_l1_candidate* __restrict__ l1, const uint32_t* __restrict__ evKey,
+k_l2_extents(int nCand, int segLength, const mm_l1_candidate* __restrict__ l1, const mm_frag_stats* __restrict__ stats, const uint32_t* __restrict__ evKey,
              const int64_t* __restrict__ contigOff, L2Info* __restrict__ info, int32_t* __restrict__ cnt) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= nCand) return;
   const mm_l1_candidate cand = l1[c];
+  const mm_frag_stats fst = stats[cand.frag];
   const int64_t cb = contigOff[cand.seqId], ce = contigOff[cand.seqId + 1];
   auto lower = [&](int64_t lo, uint32_t key) { int64_t hi = ce; while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (evKey[mid] < key) lo = mid + 1; else hi = mid; } return lo; };
   // std::lower_bound(minmerIndex, (seqId, rangeStart - segLength - 1))  (computeMap.hpp:1290-1293): inserts with wpos >= target
@@ -67,6 +69,7 @@ k_l2_extents(int nCand, int segLength, const mm_l1_candidate* __restrict__ l1, c
   const int64_t eMid = lower(e0, (uint32_t)cand.rangeStartPos * 2u + 1u);      // first event of the slide: insert at rangeStart or anything later
   const int64_t ub = lower(eMid, (uint32_t)cand.rangeEndPos * 2u + 2u);        // records are visited while wpos <= rangeEnd (:1340)
   L2Info o; o.e0 = e0; o.nPre = (int32_t)(eMid - e0); o.nAll = (int32_t)(ub - e0);
+  o.sketch = fst.sketchSize | (fst.rawSketchSize == fst.sketchSize ? (int32_t)0x80000000 : 0); o.pad = 0;
   info[c] = o;
   // upper bound of the stream: every event, the end marker, one skip per 16 K of range, slack for the end marker's own skip
   const int n = o.nAll + 1 + ((cand.rangeEndPos - cand.rangeStartPos) >> 14) + 4;
@@ -136,6 +139,7 @@ k_scan_add(int64_t n, int64_t* __restrict__ out, const int64_t* __restrict__ til
 __global__ void __launch_bounds__(256)
 k_l2_locate(int nCand, int s, const mm_l1_candidate* __restrict__ l1, const mm_frag_stats* __restrict__ stats,
             const uint64_t* __restrict__ qHash, const int8_t* __restrict__ qStrand,
+            const uint64_t* __restrict__ skHash, const int8_t* __restrict__ skStrand,
             const uint32_t* __restrict__ evKey, const uint32_t* __restrict__ evAux, const uint64_t* __restrict__ evHash,
             const int64_t* __restrict__ contigOff, const L2Info* __restrict__ info, const int64_t* __restrict__ opOff,
             const int32_t* __restrict__ opCnt, uint32_t* __restrict__ ops, unsigned long long* __restrict__ counters /* [6] |= 4: gap too wide */) {
@@ -149,12 +153,16 @@ k_l2_locate(int nCand, int s, const mm_l1_candidate* __restrict__ l1, const mm_f
   for (int c = blockIdx.x * 4 + wave; c < nCand; c += gridDim.x * 4) {
     const mm_l1_candidate cand = l1[c];
     const int f = cand.frag;
-    const int S = stats[f].sketchSize;
     const L2Info in = info[c];
+    const int S = in.sketch & 0x7fffffff;
     uint32_t* out = ops + opOff[c];
     const int cap = opCnt[c];
     __threadfence_block();                                         // previous candidate's LDS reads are done
-    for (int p = lane; p < S; p += 64) { q[p] = qHash[(size_t)f * s + p]; qs[p] = qStrand[(size_t)f * s + p]; }
+    // a fragment that lost no frequent seed has no copy in qHash/qStrand: its sketch is the raw one (k_lookup_l1)
+    const bool raw = in.sketch < 0;
+    const uint64_t* srcH = (raw ? skHash : qHash) + (size_t)f * s;
+    const int8_t* srcS = (raw ? skStrand : qStrand) + (size_t)f * s;
+    for (int p = lane; p < S; p += 64) { q[p] = srcH[p]; qs[p] = srcS[p]; }
     __threadfence_block();
     const uint64_t qmax = q[S - 1];
     // bucket(h): monotone map of [0, qmax] onto 0..255 from the top 24 significant bits (float keeps them exactly)
@@ -463,7 +471,7 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt) {
   int64_t totalOps = 0;
   {
     KernelTimer t(c, MM_K_L2_LOCATE);
-    hipLaunchKernelGGL(k_l2_extents, dim3((nC + 255) / 256), dim3(256), 0, c->stream, nC, c->P.segLength, c->dL1.as<mm_l1_candidate>(),
+    hipLaunchKernelGGL(k_l2_extents, dim3((nC + 255) / 256), dim3(256), 0, c->stream, nC, c->P.segLength, c->dL1.as<mm_l1_candidate>(), c->dStats.as<mm_frag_stats>(),
                        I.evKey.as<uint32_t>(), I.contigOff.as<int64_t>(), c->dL2Info.as<L2Info>(), c->dL2Cnt.as<int32_t>());
     MM_HIP(c, hipGetLastError());
     int rc = mm_scan_i32_to_i64(c, nC, c->dL2Cnt.as<int32_t>(), c->dL2Off.as<int64_t>(), &totalOps);
@@ -474,7 +482,8 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt) {
     MM_HIP(c, hipFuncSetAttribute((const void*)k_l2_locate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsLoc));
     int blocks = (nC + 3) / 4; if (blocks > 256 * 32) blocks = 256 * 32;
     hipLaunchKernelGGL(k_l2_locate, dim3(blocks), dim3(256), ldsLoc, c->stream, nC, s, c->dL1.as<mm_l1_candidate>(),
-                       c->dStats.as<mm_frag_stats>(), c->dQHash.as<uint64_t>(), c->dQStrand.as<int8_t>(), I.evKey.as<uint32_t>(),
+                       c->dStats.as<mm_frag_stats>(), c->dQHash.as<uint64_t>(), c->dQStrand.as<int8_t>(), c->dSkHash.as<uint64_t>(), c->dSkStrand.as<int8_t>(),
+                       I.evKey.as<uint32_t>(),
                        I.evAux.as<uint32_t>(), I.evHash.as<uint64_t>(), I.contigOff.as<int64_t>(),
                        c->dL2Info.as<L2Info>(), c->dL2Off.as<int64_t>(), c->dL2Cnt.as<int32_t>(), c->dL2Ops.as<uint32_t>(), cnt);
     MM_HIP(c, hipGetLastError());

@@ -422,12 +422,22 @@ k_lookup_l1(int nFrags, int s, const DFrag* __restrict__ frags,
         sl[u] = ht[slot];
       }
     }
+    // The sketch after frequent-seed removal goes to qHash/qStrand only if a seed was removed (or the sketch spans several
+    // batches): otherwise it equals the raw sketch, and readers (k_l2_locate, mm_query_sketch_download) take that instead
+    // (rawSketchSize == sketchSize in the fragment's stats).
+    bool writeQ = !oneBatch;
+    if (oneBatch) {
+      bool drop = false;
+#pragma unroll
+      for (int u = 0; u < 4; u++) drop |= act[u] && found[u] && (val[u] & 1ull);
+      writeQ = __ballot(drop) != 0;
+    }
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       const int r = base + u * 64 + lane;
       const bool keep = act[u] && !(found[u] && (val[u] & 1ull));
       const uint64_t m = __ballot(keep);
-      if (keep) {
+      if (keep && writeQ) {
         const int idx = outIdx + (int)mm_popc_below(m);
         qHash[fo + idx] = h[u]; qStrand[fo + idx] = skStrand[fo + r];
         if (!oneBatch) seedVal[fo + idx] = found[u] ? val[u] : 0ull;   // sketches of more than 256 entries: the slow path re-reads them
@@ -903,12 +913,18 @@ int mm_query_sketch_download(mm_ctx* c, mm_minmer* out) {
   MM_HIP(c, hipMemcpyAsync(h.data(), c->dQHash.p, nF * s * 8, hipMemcpyDeviceToHost, c->stream));
   MM_HIP(c, hipMemcpyAsync(st.data(), c->dQStrand.p, nF * s, hipMemcpyDeviceToHost, c->stream));
   MM_HIP(c, hipMemcpyAsync(fs.data(), c->dStats.p, nF * sizeof(mm_frag_stats), hipMemcpyDeviceToHost, c->stream));
+  // fragments that lost no seed were not copied to dQHash/dQStrand: their sketch is the raw one (k_lookup_l1)
+  std::vector<uint64_t> rh(nF * s); std::vector<int8_t> rst(nF * s);
+  MM_HIP(c, hipMemcpyAsync(rh.data(), c->dSkHash.p, nF * s * 8, hipMemcpyDeviceToHost, c->stream));
+  MM_HIP(c, hipMemcpyAsync(rst.data(), c->dSkStrand.p, nF * s, hipMemcpyDeviceToHost, c->stream));
   MM_HIP(c, hipStreamSynchronize(c->stream));
-  for (size_t f = 0; f < nF; f++)
+  for (size_t f = 0; f < nF; f++) {
+    const bool raw = fs[f].rawSketchSize == fs[f].sketchSize;
     for (int r = 0; r < fs[f].sketchSize; r++) {
       const size_t o = f * s + r;
-      out[o] = mm_minmer{h[o], 0, 0, c->hFrags[f].readId + c->seqCounterBase, (int16_t)st[o], 0};
+      out[o] = mm_minmer{raw ? rh[o] : h[o], 0, 0, c->hFrags[f].readId + c->seqCounterBase, (int16_t)(raw ? rst[o] : st[o]), 0};
     }
+  }
   return MM_OK;
 }
 
