@@ -257,12 +257,13 @@ def main():
                          "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_fragment": frag_bytes, "avg_launch_ms": round(sk_ms / max(1, sk_n), 3),
                          "algorithmic_bytes_per_launch": frag_bytes * nF,
-                         "note": "VALU-issue bound kernel (2 x MurmurHash3_x64_128 per base = ~260 VALU instructions per k-mer position); "
+                         "note": "VALU-issue bound kernel (2 x MurmurHash3_x64_128 per base = ~150 VALU instructions per k-mer position); "
                                  "the HBM fraction is small by construction -- DESIGN.md section 3 gives the integer roofline",
                          "valu": None if not valu_per_launch or sk_ms <= 0 else {
                              "wave_instructions_per_launch": valu_per_launch,
                              "issue_utilisation": round(valu_per_launch * 4.0 / (sk_ms / max(1, sk_n) * 1e-3 * 2.4e9 * 1024), 3),
-                             "model": "1024 SIMDs x 2.4 GHz, 4 cycles per wave64 VALU instruction"}},
+                             "model": "1024 SIMDs x 2.4 GHz, 4 cycles per wave64 VALU instruction (measured with scripts/probes/valu_rate.hip: "
+                                      "4.2 cycles for the VOP3 integer ops incl. 32-bit multiplies, 2.3 for simple VOP2 add/xor/shift/mov)"}},
             "kernels": kernels,
         }
         if world == 1 and not args.no_cpu_baseline:
