@@ -152,6 +152,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads", type=int, default=int(os.environ.get("MM_BENCH_READS", 1_000_000)), help="reads per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ref-contigs", type=int, default=REF_CONTIGS, help="contigs of the synthetic reference (default: configs[1], 10 x 10 Mbp)")
+    ap.add_argument("--ref-contig-len", type=int, default=REF_CONTIG_LEN)
     ap.add_argument("--cpu-sample", type=int, default=30000)
     args = ap.parse_args()
 
@@ -171,7 +173,7 @@ def main():
     dev = torch.device("cuda", local)
 
     t0 = time.time()
-    contigs = make_reference(torch, dev, REF_CONTIGS, REF_CONTIG_LEN)
+    contigs = make_reference(torch, dev, args.ref_contigs, args.ref_contig_len)
     ref_np = [c.cpu().numpy() for c in contigs]
     reads_t = make_reads(torch, dev, contigs, args.reads, READ_LEN, ERR, seed=1000 + rank)
     torch.cuda.synchronize()
@@ -197,6 +199,7 @@ def main():
             mine = torch.empty((n2, shard.L2_WORDS), dtype=torch.int32, device=dev)
             ctx.results_copy_device(mine.data_ptr(), n2)
             shard.allgatherv_records(mine, dist, device=dev)
+            torch.cuda.current_stream().synchronize()   # the gather is part of the step; `mine` is rewritten from the library's stream next step
 
     def fence():
         if world > 1:
@@ -235,7 +238,7 @@ def main():
         traffic = None
         valu_per_launch = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc) and args.reads == 1_000_000:
+        if os.path.exists(pmc) and args.reads == 1_000_000 and (args.ref_contigs, args.ref_contig_len) == (REF_CONTIGS, REF_CONTIG_LEN):
             try:
                 ent = json.load(open(pmc)).get("k_sketch_fragments", {})
                 traffic = ent.get("hbm_bytes_per_launch")
@@ -248,8 +251,8 @@ def main():
             "metric": "query Gbp/s sketch+L1/L2 map (pi=85, s=5000)", "value": round(value, 4), "unit": "Gbp/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "configs[1]: %d x %d bp reads/GPU (%.0f%% ONT-like error) vs 100 Mbp synthetic reference (10 contigs)"
-                                   % (args.reads, READ_LEN, ERR * 100), "k": K, "segLength": SEG, "sketchSize": SKETCH,
+            "config": {"workload": "configs[1]: %d x %d bp reads/GPU (%.0f%% ONT-like error) vs %.0f Mbp synthetic reference (%d contigs)"
+                                   % (args.reads, READ_LEN, ERR * 100, args.ref_contigs * args.ref_contig_len / 1e6, args.ref_contigs), "k": K, "segLength": SEG, "sketchSize": SKETCH,
                        "percentageIdentity": PI, "fragments_per_gpu": nF, "parallelism": "reads sharded, index replicated, RCCL all-gatherv of L2 loci"
                        if world > 1 else "single GPU", "mean_interval_points_per_fragment": round(P, 1),
                        "l1_candidates_per_gpu": n1, "l2_loci_per_gpu": n2},
