@@ -35,22 +35,19 @@ struct L2Tmp { int32_t start, end, shared, strand; };
 // stream entry (uint32):
 //   bits 0..10  1-based position j of the hash in the query sketch (0: beyond the sketch -> no effect on the state)
 //   bit  11     hash equals q[j]
-//   bits 12..13 query strand + 1
-//   bits 14..16 type: 0 eviction, 1 insert + evaluate, 2 end of stream, 3 pre-load insert (computeMap.hpp:1323-1338), 4 skip
-//   bit  17     reference strand is REV
-//   bits 18..31 insert / end: wpos minus the running position (previous insert's wpos, rangeStart at first)
-//   skip: adds ((e >> 17) << 14 | (e & 0x3FFF)) to the running position (a gap that does not fit 14 bits)
-#define E_DEL 0u
-#define E_INS 1u
-#define E_END 2u
-#define E_PRE 3u
-#define E_SKIP 4u
-#define OP_J(op) ((int)((op) & 0x7FFu))
-#define OP_MATCH(op) ((int)(((op) >> 11) & 1u))
-#define OP_QS(op) ((int)(((op) >> 12) & 3u) - 1)
-#define OP_TYPE(op) (((op) >> 14) & 7u)
-#define OP_RSTRAND(op) ((((op) >> 17) & 1u) ? -1 : 1)
-#define E_MAXDELTA 0x3FFFu
+//   bits 12..13 strand vote of a matching insert + 1 (query strand x reference strand)
+//   bits 14..26 insert / end: wpos minus the running position (previous insert's wpos, rangeStart at first)
+//   bits 27..31 kind, one bit each (the sweep turns a bit into a lane mask with one v_bfe_i32):
+//               insert + evaluate, eviction, pre-load insert (computeMap.hpp:1323-1338), end of stream, skip
+//   skip: adds its low 27 bits to the running position (a gap that does not fit 13 bits)
+#define E_INS_BIT 27
+#define E_DEL_BIT 28
+#define E_PRE_BIT 29
+#define E_END_BIT 30
+#define E_SKIP_BIT 31
+#define E_MAXDELTA 0x1FFFu
+#define E_DELTA_SHIFT 14
+#define E_SKIP_MAX ((1u << 27) - 1u)
 #define E_STEP 16           // entries per 64-byte sweep step
 
 // ---------------------------------------------------------------------------------------------
@@ -71,8 +68,9 @@ k_l2_extents(int nCand, int segLength, const mm_l1_candidate* __restrict__ l1, c
   L2Info o; o.e0 = e0; o.nPre = (int32_t)(eMid - e0); o.nAll = (int32_t)(ub - e0);
   o.sketch = fst.sketchSize | (fst.rawSketchSize == fst.sketchSize ? (int32_t)0x80000000 : 0); o.pad = 0;
   info[c] = o;
-  // upper bound of the stream: every event, the end marker, one skip per 16 K of range, slack for the end marker's own skip
-  const int n = o.nAll + 1 + ((cand.rangeEndPos - cand.rangeStartPos) >> 14) + 4;
+  // upper bound of the stream: every event, the end marker, one skip per 8 K of range, slack for the end marker's own skips
+  // (the record behind the last insert may be anywhere in the contig: up to 2^31 / 2^27 of them)
+  const int n = o.nAll + 1 + ((cand.rangeEndPos - cand.rangeStartPos) >> 13) + 20;
   cnt[c] = (n + E_STEP - 1) & ~(E_STEP - 1);
 }
 
@@ -186,7 +184,7 @@ k_l2_locate(int nCand, int s, const mm_l1_candidate* __restrict__ l1, const mm_f
       int lo = bkt[b]; const int hi = bkt[b + 1];
       while (lo < hi && q[lo] < h) lo++;
       // lo == lower_bound(q, h): everything in earlier buckets is smaller, everything in later ones larger
-      return (uint32_t)(lo + 1) | (q[lo] == h ? 0x800u : 0u) | ((uint32_t)((int)qs[lo] + 1) << 12);
+      return (uint32_t)(lo + 1) | (q[lo] == h ? 0x800u : 0u) | ((uint32_t)((int)qs[lo] + 1) << 12);   // bits 12..13: query strand + 1
     };
     // the slide ends with the last insert at or before rangeEnd (evictions behind it are never reached, :1340)
     int lastRel = -1;                                              // index of that insert relative to e0
@@ -223,8 +221,9 @@ k_l2_locate(int nCand, int s, const mm_l1_candidate* __restrict__ l1, const mm_f
         else keep = isIns || h <= qmax;                                                 // an eviction outside the sketch's range changes nothing
         if (keep) {
           op = locate(h);
-          const uint32_t type = inPre ? E_PRE : (isIns ? E_INS : E_DEL);
-          op |= (type << 14) | ((isIns && (aux >> 31)) ? (1u << 17) : 0u);
+          // vote of a matching insert = query strand x reference strand: a REV record (aux bit 31) mirrors the field around 1
+          if (isIns && (aux >> 31)) op = (op & ~0x3000u) | ((2u - ((op >> 12) & 3u)) << 12);
+          op |= 1u << (inPre ? E_PRE_BIT : (isIns ? E_INS_BIT : E_DEL_BIT));
           evalIns = !inPre && isIns;
         }
       }
@@ -239,30 +238,29 @@ k_l2_locate(int nCand, int s, const mm_l1_candidate* __restrict__ l1, const mm_f
       }
       const int delta = evalIns ? pos - prevPos : 0;
       const bool needSkip = evalIns && delta > (int)E_MAXDELTA;
-      if (needSkip && (delta - (int)E_MAXDELTA) >= (1 << 29)) tooWide = true;
+      if (needSkip && (uint32_t)(delta - (int)E_MAXDELTA) > E_SKIP_MAX) tooWide = true;
       const int mine = keep ? (needSkip ? 2 : 1) : 0;
       const uint64_t mKeep = __ballot(keep), mSkip = __ballot(needSkip);          // slots before this lane: one per kept event, one more per skip
       const int at = outN + (int)mm_popc_below(mKeep) + (int)mm_popc_below(mSkip);
       if (keep && at + mine <= cap) {
         if (needSkip) {
           const uint32_t extra = (uint32_t)(delta - (int)E_MAXDELTA);
-          out[at] = (E_SKIP << 14) | (extra & 0x3FFFu) | ((extra >> 14) << 17);
-          out[at + 1] = op | (E_MAXDELTA << 18);
-        } else out[at] = op | ((uint32_t)delta << 18);
+          out[at] = (1u << E_SKIP_BIT) | (extra & E_SKIP_MAX);
+          out[at + 1] = op | (E_MAXDELTA << E_DELTA_SHIFT);
+        } else out[at] = op | ((uint32_t)delta << E_DELTA_SHIFT);
       }
       outN += __popcll(mKeep) + __popcll(mSkip);
       if (mIns) posAcc = __shfl(pos, 63 - (int)__builtin_clzll(mIns));
     }
     if (lane == 0) {                                               // end marker: carries the wpos behind the last insert
       int at = outN;
-      int delta = lastRel >= 0 ? nextW - posAcc : 0;
-      if (delta > (int)E_MAXDELTA) {
-        const uint32_t extra = (uint32_t)(delta - (int)E_MAXDELTA);
-        if (extra >= (1u << 29)) tooWide = true;
-        if (at < cap) out[at] = (E_SKIP << 14) | (extra & 0x3FFFu) | ((extra >> 14) << 17);
-        at++; delta = (int)E_MAXDELTA;
+      uint32_t delta = lastRel >= 0 ? (uint32_t)(nextW - posAcc) : 0u;
+      while (delta > E_MAXDELTA) {                                 // that record may be far away: as many skips as it takes
+        const uint32_t extra = delta - E_MAXDELTA > E_SKIP_MAX ? E_SKIP_MAX : delta - E_MAXDELTA;
+        if (at < cap) out[at] = (1u << E_SKIP_BIT) | extra;
+        at++; delta -= extra;
       }
-      if (at < cap) out[at] = (E_END << 14) | ((uint32_t)delta << 18);
+      if (at < cap) out[at] = (1u << E_END_BIT) | (delta << E_DELTA_SHIFT);
       else tooWide = true;                                         // cannot happen: the reservation covers every event + skips
     }
     if (__ballot(tooWide) && lane == 0) atomicOr(&counters[6], 4ull);
@@ -270,6 +268,9 @@ k_l2_locate(int nCand, int s, const mm_l1_candidate* __restrict__ l1, const mm_f
 }
 
 // ---------------------------------------------------------------------------------------------
+// bit B of x as a lane mask (all ones / zero): one v_bfe_i32, opaque to the optimiser (see k_l2_sweep)
+template <int B> __device__ __forceinline__ int mm_bit_mask(uint32_t x) { int m; asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(x), "n"(B)); return m; }
+
 // k_l2_sweep<WIDE>: one lane per candidate.  Per-lane SlideMapper state in LDS, one cell per query position p:
 //   num_before_inc (CB bits) | active (1 bit) | strand_vote + 1 (2 bits)
 // The LDS that 64 such states need is what limits the waves per CU, and the kernel is latency bound, so the first pass uses
@@ -308,53 +309,63 @@ k_l2_sweep(int nCand, const int32_t* __restrict__ candList, int segLength, const
   CELL(0) = 0;
   for (int p = 1; p <= S; p++) CELL(p) = (CellT)(1u | (1u << (CB + 1)));       // num_before_inc = 1, inactive, vote 0
   int pivot = S, pivRank = S, shared = 0, votes = 0;
-  bool doubleOpen = false, cntOverflow = false;
 
-  // SlideMapper::insert_minmer / delete_minmer (slidingMap.hpp:125-211) as straight-line code: the four cases (insert or
-  // delete x hash matches a query hash or not) are selected arithmetically, because the 64 lanes of a wave are at different
-  // candidates and take different cases at every entry -- as branches they serialise (measured 5x slower).  The cell of the
-  // hash, of the pivot and of its right neighbour are read up front, independent of the case.
-  auto apply = [&](uint32_t op, bool isIns) {
-    const int j = OP_J(op);                            // 0: hash beyond the query sketch -> no effect (cell 0 is a dummy)
-    const bool valid = (j != 0) & !cntOverflow, match = OP_MATCH(op) != 0;   // after a counter overflow the lane only idles to the end
-    const int pn = pivot + 1 <= S ? pivot + 1 : S;
+  // Lane masks.  The 64 lanes of a wave are at different candidates and take different cases at every entry, so the cases are
+  // not branches (measured 5x slower) but all-ones / zero integers combined with and/or/add: a kind bit of the entry becomes
+  // a mask with one v_bfe_i32, a comparison of two small non-negative numbers with a subtract and an arithmetic shift, and
+  // "x += c ? a : 0" is "x += a & m".  These are 32-bit-encoded VALU instructions, which issue about twice as fast on this
+  // part as the v_cmp + v_cndmask pairs (64-bit encodings) the bool form compiles to.  The mask
+  // producers are inline asm so that the optimiser does not turn "mask & value" back into compare + select.
+#define BITM(x, b) mm_bit_mask<b>((uint32_t)(x))
+  auto neg = [](int x) -> int { int m; asm("v_ashrrev_i32 %0, 31, %1" : "=v"(m) : "v"(x)); return m; };   // x < 0 ? ~0 : 0
+  auto sel = [](int m, int a, int b2) -> int { return (a & m) | (b2 & ~m); };                               // v_bfi_b32
+
+  // SlideMapper::insert_minmer / delete_minmer (slidingMap.hpp:125-211): the four cases (insert or delete x hash matches a
+  // query hash or not) as masks IM, IN, DM, DN.  The cell of the hash, of the pivot and of its right neighbour are read up
+  // front, independent of the case.  insM: the entry inserts (insert or pre-load), delM: it evicts.
+  int doubleOpen = 0, cntOverflow = 0;
+  auto apply = [&](uint32_t e, int insM, int delM) {
+    const int j = (int)(e & 0x7FFu) & (insM | delM);   // 0: no hash / hash beyond the query sketch -> no effect (cell 0 is a dummy)
+    const int valid = neg(-j) & ~cntOverflow;          // after a counter overflow the lane only idles to the end
+    const int mt = BITM(e, 11);
+    const int ltS = neg(pivot - S);                    // pivot + 1 <= S
+    const int pn = pivot - ltS;                        // min(pivot + 1, S)
     const uint32_t cw = CELL(j), pw = CELL(pivot), nw = CELL(pn);
-    const int v = OP_QS(op) * OP_RSTRAND(op);          // a query hash has one open reference window at a time (windowLen == 0);
-    const bool IM = valid & isIns & match, IN = valid & isIns & !match, DM = valid & !isIns & match, DN = valid & !isIns & !match;
-    doubleOpen |= IM & (CELL_ACT(cw) != 0);            // the 2-bit vote relies on it, so a violation is reported, not absorbed
-    uint32_t ncw = cw;
-    cntOverflow |= IN & (CELL_CNT(cw) == (int)CMASK);   // the counter of this cell is full: redo the candidate with wide cells
-    ncw = IM ? ((cw & CMASK) | (1u << CB) | ((uint32_t)(v + 1) << (CB + 1))) : ncw;
-    ncw = IN ? cw + 1u : ncw;
-    ncw = DM ? ((cw & CMASK) | (1u << (CB + 1))) : ncw;
-    ncw = DN ? cw - 1u : ncw;
+    const int vi = valid & insM, vd = valid & delM;
+    const int IM = vi & mt, IN = vi & ~mt, DM = vd & mt, DN = vd & ~mt;
+    const int vf = (int)((e >> 12) & 3u);              // vote + 1; a query hash has one open reference window at a time (windowLen == 0),
+    doubleOpen |= IM & BITM(cw, CB);                   // the 2-bit vote relies on it, so a violation is reported, not absorbed
+    cntOverflow |= IN & neg((int)(CMASK - 1u) - (int)(cw & CMASK));   // the counter of this cell is full: redo the candidate with wide cells
+    const int repl = (int)(cw & CMASK) | sel(IM, (int)((1u << CB) | ((uint32_t)vf << (CB + 1))), (int)(1u << (CB + 1)));
+    const int ncw = sel(IM | DM, repl, (int)cw - IN + DN);            // IN: count + 1, DN: count - 1 (the masks are -1)
     CELL(j) = (CellT)ncw;
-    const int ip = j <= pivot ? 1 : 0;
-    shared += (IM ? ip : 0) - (DM ? ip : 0);
-    votes += ((IM & (ip != 0)) ? v : 0) - ((DM & (ip != 0)) ? CELL_VOTE(cw) : 0);
-    pivRank += (IN ? ip : 0) - (DN ? ip : 0);
+    const int ip = ~neg(pivot - j);                    // j <= pivot
+    const int IMp = IM & ip, DMp = DM & ip;
+    shared += DMp - IMp;
+    votes += ((vf - 1) & IMp) - (CELL_VOTE(cw) & DMp);
+    pivRank += (DN & ip) - (IN & ip);
     // insert of a non-shared hash can push the pivot one cell left (:155-160)
-    const uint32_t pwp = (pivot == j) ? ncw : pw;
-    const bool left = IN & (pivRank > S);
+    const int pwp = sel(neg((pivot ^ j) - 1), ncw, (int)pw);          // pivot == j: the cell just written
+    const int left = IN & neg(S - pivRank);                           // pivRank > S
     // delete of a non-shared hash can let it move one cell right (:201-207)
-    const uint32_t nwp = (pn == j) ? ncw : nw;
-    const bool right = DN & (pivot + 1 <= S) & (pivRank + CELL_CNT(nwp) <= S);
-    shared += (right ? CELL_ACT(nwp) : 0) - (left ? CELL_ACT(pwp) : 0);
-    votes += (right ? CELL_VOTE(nwp) : 0) - (left ? CELL_VOTE(pwp) : 0);
-    pivRank += (right ? CELL_CNT(nwp) : 0) - (left ? CELL_CNT(pwp) : 0);
-    pivot += (right ? 1 : 0) - (left ? 1 : 0);
+    const int nwp = sel(neg((pn ^ j) - 1), ncw, (int)nw);
+    const int right = DN & ltS & ~neg(S - pivRank - CELL_CNT(nwp));   // pivRank + count(next) <= S
+    shared += (CELL_ACT(nwp) & right) - (CELL_ACT(pwp) & left);
+    votes += (CELL_VOTE(nwp) & right) - (CELL_VOTE(pwp) & left);
+    pivRank += (CELL_CNT(nwp) & right) - (CELL_CNT(pwp) & left);
+    pivot += left - right;
   };
 
   // best-position bookkeeping (:1376-1449)
-  int bestShared = 1; bool inRun = false;
+  int bestShared = 1, inRun = 0;
   int curStart = 0, curEnd = 0, curShared = 0;
-  int nFlushed = 0; bool havePend = false; L2Tmp pend{0, 0, 0, 0};
+  int nFlushed = 0, havePend = 0; L2Tmp pend{0, 0, 0, 0};
   L2Tmp* mySlots = tmp + (size_t)cIdx * locap;
   bool slotOverflow = false;
   auto close_run = [&](int strand) {                   // :1417-1426 / :1440-1449
     if (!havePend || pend.end + segLength < curStart) {
       if (havePend) { if (nFlushed < locap) mySlots[nFlushed] = pend; else slotOverflow = true; nFlushed++; }
-      pend.start = curStart; pend.end = curEnd; pend.shared = curShared; pend.strand = strand; havePend = true;
+      pend.start = curStart; pend.end = curEnd; pend.shared = curShared; pend.strand = strand; havePend = -1;
     } else {
       pend.end = curEnd;
     }
@@ -362,21 +373,21 @@ k_l2_sweep(int nCand, const int32_t* __restrict__ candList, int segLength, const
   // the evaluation of insert i needs the wpos of record i+1, so it is carried until the next insert / end entry arrives
   // lastVotes = strand_votes right after the most recent insert (pre-load included): the reference samples it before the
   // evictions that precede the next insert (:1342)
-  bool evalPending = false; int evW = 0, evShared = 0, evPrevVotes = 0, lastVotes = 0;
-  // the three outcomes of an evaluation (:1376-1430) as selects; only the closing of a run -- rare -- is a branch
-  auto evaluate = [&](bool on, int nextW) {
-    const bool gt = on & (evShared > bestShared), eq = on & (evShared == bestShared), lt = on & (evShared < bestShared);
+  int evalPending = 0, evW = 0, evShared = 0, evPrevVotes = 0, lastVotes = 0;
+  // the three outcomes of an evaluation (:1376-1430) as masks; only the closing of a run -- rare -- is a branch
+  auto evaluate = [&](int on, int nextW) {
+    const int gt = on & neg(bestShared - evShared), lt = on & neg(evShared - bestShared), ge = on & ~lt;
     if (lt & inRun) { curEnd = nextW; close_run(evPrevVotes >= 0 ? 1 : -1); curStart = 0; curEnd = 0; curShared = 0; }
-    const bool startNew = gt | (eq & !inRun);
-    nFlushed = gt ? 0 : nFlushed; havePend = gt ? false : havePend;          // l2_vec_out.clear()
-    bestShared = gt ? evShared : bestShared;
-    curShared = startNew ? evShared : curShared;
-    curStart = startNew ? evW : curStart;
-    curEnd = (gt | eq) ? nextW : curEnd;
-    inRun = on ? (gt | eq) : inRun;
+    const int startNew = gt | (ge & ~inRun);
+    nFlushed &= ~gt; havePend &= ~gt;                  // l2_vec_out.clear()
+    bestShared = sel(gt, evShared, bestShared);
+    curShared = sel(startNew, evShared, curShared);
+    curStart = sel(startNew, evW, curStart);
+    curEnd = sel(ge, nextW, curEnd);
+    inRun = sel(on, ge, inRun);
   };
 
-  bool done = false;
+  int done = 0;
   uint4 cur[4], nxt[4];
   if (nSteps > 0) {
 #pragma unroll
@@ -392,19 +403,19 @@ k_l2_sweep(int nCand, const int32_t* __restrict__ candList, int segLength, const
       const uint4 v = cur[k >> 2];
       const uint32_t e = (k & 3) == 0 ? v.x : (k & 3) == 1 ? v.y : (k & 3) == 2 ? v.z : v.w;
       // straight-line per entry: a finished lane (done) and the entry kinds are masks, not branches
-      const bool act = !done;
-      const uint32_t type = OP_TYPE(e);
-      const bool isIns = act & (type == E_INS), isEnd = act & (type == E_END), isPre = act & (type == E_PRE), isDel = act & (type == E_DEL);
-      const int add = (type == E_SKIP) ? (int)(((e >> 17) << 14) | (e & 0x3FFFu)) : ((type == E_INS || type == E_END) ? (int)(e >> 18) : 0);
-      posAcc += act ? add : 0;
+      const int act = ~done;
+      const int mIns = BITM(e, 27) & act, mDel = BITM(e, 28) & act, mPre = BITM(e, 29) & act, mEnd = BITM(e, 30) & act;
+      const int mSkip = neg((int)e) & act;
+      const int ie = mIns | mEnd;
+      posAcc += ((int)((e >> E_DELTA_SHIFT) & E_MAXDELTA) & ie) | ((int)(e & E_SKIP_MAX) & mSkip);
       const int wpos = posAcc;
-      evaluate((isIns | isEnd) & evalPending, wpos);
-      evalPending = (isIns | isEnd) ? false : evalPending;
-      done |= isEnd;
-      evPrevVotes = isIns ? lastVotes : evPrevVotes;
-      apply((isIns | isPre | isDel) ? e : 0u, !isDel);                 // anything else carries no hash: j = 0, no effect
-      lastVotes = (isIns | isPre) ? votes : lastVotes;
-      evW = isIns ? wpos : evW; evShared = isIns ? shared : evShared; evalPending = isIns ? true : evalPending;
+      evaluate(ie & evalPending, wpos);
+      evalPending = (evalPending & ~ie) | mIns;
+      done |= mEnd;
+      evPrevVotes = sel(mIns, lastVotes, evPrevVotes);
+      apply(e, mIns | mPre, mDel);
+      lastVotes = sel(mIns | mPre, votes, lastVotes);
+      evW = sel(mIns, wpos, evW); evShared = sel(mIns, shared, evShared);
     }
 #pragma unroll
     for (int k = 0; k < 4; k++) cur[k] = nxt[k];
@@ -534,7 +545,7 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt) {
     if (hc[5]) { c->l2Cap = (size_t)hc[4] + (size_t)hc[4] / 8 + 1024; continue; }
     break;
   }
-  if (hc[6] & 4ull) { c->err = "a gap of more than 2^29 bases between consecutive reference minmers is not representable in the L2 stream"; return MM_ERR_ARG; }
+  if (hc[6] & 4ull) { c->err = "a gap of more than 2^27 bases between consecutive reference minmers inside an L1 candidate is not representable in the L2 stream"; return MM_ERR_ARG; }
   if (hc[6] & 8ull) { c->err = "L2 state counter overflow with 16-bit cells"; return MM_ERR_STATE; }
   if (hc[6] & 2ull) { c->err = "a query hash had two open reference windows at once (index intervals of one hash overlap)"; return MM_ERR_STATE; }
   if (hc[6] & 1ull) { c->err = "an L1 candidate with more tied L2 loci than 64 GiB of staging can hold"; return MM_ERR_CAPACITY; }
