@@ -258,7 +258,8 @@ __device__ __forceinline__ uint64_t mm_times5(uint64_t h) {
 template <int K>
 __device__ __forceinline__ uint64_t mm_murmur_from_products(uint64_t p1, uint64_t p2, uint64_t tailMixK) {
   uint64_t h1 = MM_SEED, h2 = MM_SEED;
-  h1 ^= mm_rotl64(p1, 31) * MM_C2; h1 = mm_rotl64(h1, 27); h1 += h2; h1 = mm_times5(h1) + 0x52dce729;
+  // (rotl(h1, 27) + seed) * 5 + c  =  rotl(h1, 27) * 5 + (5 * seed + c): one 64-bit add less
+  h1 ^= mm_rotl64(p1, 31) * MM_C2; h1 = mm_rotl64(h1, 27); h1 = mm_times5(h1) + (0x52dce729ull + 5ull * MM_SEED);
   h2 ^= mm_rotl64(p2, 33) * MM_C1; h2 = mm_rotl64(h2, 31); h2 += h1; h2 = mm_times5(h2) + 0x38495ab5;
   h1 ^= tailMixK;
   h2 ^= (uint64_t)K;
