@@ -315,7 +315,12 @@ static int launch_sketch_k(mm_ctx* c) {
                ldsHard = sketch_lds_bytes(sizeof(typename MMTabsFor<K>::type), maxLen, HTH, PADH, true);
   if (ldsHard > 160 * 1024) { c->err = "fragment too long / sketch too large for the LDS-resident sketch kernel"; return MM_ERR_ARG; }
   int nStrips = (maxLen - K + 1 + 15) / 16; if (nStrips < 1) nStrips = 1;
-  int threads = ((nStrips + 63) / 64) * 64; if (threads > 1024) threads = 1024; if (threads < 64) threads = 64;
+  // one strip per thread; a last, partly filled wave is folded into a second pass of wave 0 instead (same number of
+  // wave-passes over the hash loop, one wave less running the per-workgroup phases) as long as 4 waves remain
+  int threads = ((nStrips + 63) / 64) * 64;
+  if ((nStrips & 63) && (nStrips / 64) * 64 >= 256) threads = (nStrips / 64) * 64;
+  if (threads > 1024) threads = 1024; if (threads < 64) threads = 64;
+  if (const char* e = getenv("MM_SKETCH_THREADS")) { const int t = atoi(e); if (t >= 64 && t <= 1024 && t % 64 == 0) threads = t; }
   using Tabs = typename MMTabsFor<K>::type;
   if (c->sketchTabsK != K) {
     MM_HIP(c, c->dSketchTabs.ensure(sizeof(Tabs)));
