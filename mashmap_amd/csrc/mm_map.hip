@@ -191,20 +191,21 @@ __device__ __forceinline__ void mm_wave_bitonic(uint64_t (&k)[R], int lane) {
   for (int k2 = 2; k2 <= N; k2 <<= 1) {
 #pragma unroll
     for (int j = k2 >> 1; j > 0; j >>= 1) {
+      // one compare per exchange: the lane keeps its key or takes the partner's (equal keys: either)
       if (R == 2 && j == 1) {
         const bool up = ((lane * 2) & k2) == 0;
         const uint64_t a = k[0], b = k[R - 1];
-        const uint64_t mn = a < b ? a : b, mx = a < b ? b : a;
-        k[0] = up ? mn : mx; k[R - 1] = up ? mx : mn;
+        const bool swap = (a < b) != up;
+        k[0] = swap ? b : a; k[R - 1] = swap ? a : b;
       } else {
         const int lj = (R == 2) ? (j >> 1) : j;
 #pragma unroll
         for (int r = 0; r < R; r++) {
           const int idx = lane * R + r;
           const uint64_t other = mm_shfl_xor64(k[r], lj, lane);
-          const bool up = (idx & k2) == 0, lower = (idx & j) == 0;
-          const uint64_t mn = k[r] < other ? k[r] : other, mx = k[r] < other ? other : k[r];
-          k[r] = (lower == up) ? mn : mx;
+          const bool keepMin = ((idx & k2) == 0) == ((idx & j) == 0);
+          const bool lt = k[r] < other;
+          k[r] = (lt != keepMin) ? other : k[r];
         }
       }
     }
