@@ -36,6 +36,8 @@ struct DFrag {
 
 // device index (see DESIGN.md "data layout in HBM")
 
+#define MM_OPEN_BLOCK_SHIFT 10
+
 struct DeviceIndex {
   size_t nRec = 0, nKeys = 0, nPoints = 0, nContigs = 0, htCap = 0;
   // minmerIndex as the L2 event stream (see mm_build_device_index): per contig, one insert event per record at wpos and one
@@ -44,6 +46,11 @@ struct DeviceIndex {
   DevBuf evAux;                // uint32 insert: wpos_end | REV<<31 ; eviction: 0
   DevBuf evHash;               // uint64 hash of the record
   DevBuf contigOff;            // int64[nContigs+1] event offsets
+  // records still open at every MM_OPEN_BLOCK-th position (wpos < B < wpos_end, index order), as insert events: the L2 pre-load of a
+  // candidate starts from the list of its block instead of streaming a whole segLength of events (computeMap.hpp:1323-1338)
+  DevBuf opKey, opAux, opHash; // as evKey / evAux / evHash
+  DevBuf blockOff;             // int64[nBlocks+1] offsets into op*
+  DevBuf contigBlock;          // int64[nContigs+1] first block of every contig
   DevBuf contigLen;            // int32[nContigs]
   DevBuf refGroup;             // int32[nContigs] (all 0 when unused)
   DevBuf htSlots;              // {uint64 key, uint64 val}[htCap]; val = offset<<24 | count<<1 | freq (one 16-byte slot per probe)

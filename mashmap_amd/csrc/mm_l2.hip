@@ -29,7 +29,9 @@
 #define MM_LOCAP0 8         // private L2 locus slots per candidate before the final compaction (doubled and re-run on overflow)
 
 struct L2Info { int64_t e0; int32_t nPre; int32_t nAll;         // slice [e0, e0+nAll) of the contig's events, the first nPre before rangeStart
-                int32_t sketch; int32_t pad; };                 // the fragment's sketchSize, bit 31: no seed was removed (take the raw sketch)
+                int32_t sketch;                                 // the fragment's sketchSize, bit 31: no seed was removed (take the raw sketch)
+                int32_t nOpen; int64_t open0;                   // records open at the block boundary before rangeStart: op*[open0, open0+nOpen)
+                int32_t target; int32_t pad; };                 // pre-load takes records with wpos >= target = rangeStart - segLength - 1 (:1290)
 struct L2Tmp { int32_t start, end, shared, strand; };
 
 // stream entry (uint32):
@@ -53,24 +55,32 @@ struct L2Tmp { int32_t start, end, shared, strand; };
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_l2_extents(int nCand, int segLength, const mm_l1_candidate* __restrict__ l1, const mm_frag_stats* __restrict__ stats, const uint32_t* __restrict__ evKey,
-             const int64_t* __restrict__ contigOff, L2Info* __restrict__ info, int32_t* __restrict__ cnt) {
+             const int64_t* __restrict__ contigOff, const int64_t* __restrict__ contigBlock, const int64_t* __restrict__ blockOff,
+             L2Info* __restrict__ info, int32_t* __restrict__ cnt) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= nCand) return;
   const mm_l1_candidate cand = l1[c];
   const mm_frag_stats fst = stats[cand.frag];
   const int64_t cb = contigOff[cand.seqId], ce = contigOff[cand.seqId + 1];
   auto lower = [&](int64_t lo, uint32_t key) { int64_t hi = ce; while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (evKey[mid] < key) lo = mid + 1; else hi = mid; } return lo; };
-  // std::lower_bound(minmerIndex, (seqId, rangeStart - segLength - 1))  (computeMap.hpp:1290-1293): inserts with wpos >= target
+  // std::lower_bound(minmerIndex, (seqId, rangeStart - segLength - 1))  (computeMap.hpp:1290-1293): inserts with wpos >= target are
+  // pre-loaded if still open at rangeStart.  Those that start before the block boundary B <= rangeStart come from the block's
+  // list of open records, the rest from the events in [max(B, target), rangeStart).
   const int target = cand.rangeStartPos - segLength - 1;
-  const int64_t e0 = lower(cb, target > 0 ? (uint32_t)target * 2u : 0u);
+  const int64_t blk = contigBlock[cand.seqId] + (cand.rangeStartPos >> MM_OPEN_BLOCK_SHIFT);
+  const int64_t ob = blockOff[blk], oe = blockOff[blk + 1];
+  const int B = (cand.rangeStartPos >> MM_OPEN_BLOCK_SHIFT) << MM_OPEN_BLOCK_SHIFT;
+  const int from = target > B ? target : B;
+  const int64_t e0 = lower(cb, from > 0 ? (uint32_t)from * 2u : 0u);
   const int64_t eMid = lower(e0, (uint32_t)cand.rangeStartPos * 2u + 1u);      // first event of the slide: insert at rangeStart or anything later
   const int64_t ub = lower(eMid, (uint32_t)cand.rangeEndPos * 2u + 2u);        // records are visited while wpos <= rangeEnd (:1340)
   L2Info o; o.e0 = e0; o.nPre = (int32_t)(eMid - e0); o.nAll = (int32_t)(ub - e0);
+  o.open0 = ob; o.nOpen = (int32_t)(oe - ob); o.target = target;
   o.sketch = fst.sketchSize | (fst.rawSketchSize == fst.sketchSize ? (int32_t)0x80000000 : 0); o.pad = 0;
   info[c] = o;
   // upper bound of the stream: every event, the end marker, one skip per 8 K of range, slack for the end marker's own skips
   // (the record behind the last insert may be anywhere in the contig: up to 2^31 / 2^27 of them)
-  const int n = o.nAll + 1 + ((cand.rangeEndPos - cand.rangeStartPos) >> 13) + 20;
+  const int n = o.nAll + o.nOpen + 1 + ((cand.rangeEndPos - cand.rangeStartPos) >> 13) + 20;
   cnt[c] = (n + E_STEP - 1) & ~(E_STEP - 1);
 }
 
@@ -139,6 +149,7 @@ k_l2_locate(int nCand, int s, const mm_l1_candidate* __restrict__ l1, const mm_f
             const uint64_t* __restrict__ qHash, const int8_t* __restrict__ qStrand,
             const uint64_t* __restrict__ skHash, const int8_t* __restrict__ skStrand,
             const uint32_t* __restrict__ evKey, const uint32_t* __restrict__ evAux, const uint64_t* __restrict__ evHash,
+            const uint32_t* __restrict__ opKey, const uint32_t* __restrict__ opAux, const uint64_t* __restrict__ opHash,
             const int64_t* __restrict__ contigOff, const L2Info* __restrict__ info, const int64_t* __restrict__ opOff,
             const int32_t* __restrict__ opCnt, uint32_t* __restrict__ ops, unsigned long long* __restrict__ counters /* [6] |= 4: gap too wide */) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -207,17 +218,25 @@ k_l2_locate(int nCand, int s, const mm_l1_candidate* __restrict__ l1, const mm_f
     int posAcc = cand.rangeStartPos;                               // running position of the delta code (wave-uniform)
     bool tooWide = false;
     const int nEv = lastRel + 1;                                   // events [0, nEv) of the slice are streamed
-    for (int b0 = 0; b0 < (nEv > in.nPre ? nEv : in.nPre); b0 += 64) {
-      const int i = b0 + lane;
-      const bool inPre = i < in.nPre;
+    // the stream: first the block's open records (all inserts), then the events [e0, e0 + nEv) of which the first nPre lie
+    // before rangeStart
+    const int nOpen = in.nOpen;
+    for (int b0 = 0; b0 < nOpen + (nEv > in.nPre ? nEv : in.nPre); b0 += 64) {
+      const int iAll = b0 + lane;
+      const bool inOpen = iAll < nOpen;
+      const int i = iAll - nOpen;
+      const bool inPre = inOpen || i < in.nPre;
       const bool live = inPre ? true : i < nEv;
       uint32_t key = 0, aux = 0; uint64_t h = 0;
-      if (live) { key = evKey[in.e0 + i]; aux = evAux[in.e0 + i]; h = evHash[in.e0 + i]; }
+      if (live) {
+        if (inOpen) { key = opKey[in.open0 + iAll]; aux = opAux[in.open0 + iAll]; h = opHash[in.open0 + iAll]; }
+        else { key = evKey[in.e0 + i]; aux = evAux[in.e0 + i]; h = evHash[in.e0 + i]; }
+      }
       const bool isIns = (key & 1u) != 0;
       const int pos = (int)(key >> 1);
       uint32_t op = 0; bool keep = false, evalIns = false;
       if (live) {
-        if (inPre) keep = isIns && (int)(aux & 0x7fffffffu) > cand.rangeStartPos;      // still open at rangeStart (:1323-1338)
+        if (inPre) keep = isIns && (int)(aux & 0x7fffffffu) > cand.rangeStartPos && pos >= in.target;   // still open at rangeStart (:1323-1338)
         else keep = isIns || h <= qmax;                                                 // an eviction outside the sketch's range changes nothing
         if (keep) {
           op = locate(h);
@@ -483,7 +502,8 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt) {
   {
     KernelTimer t(c, MM_K_L2_LOCATE);
     hipLaunchKernelGGL(k_l2_extents, dim3((nC + 255) / 256), dim3(256), 0, c->stream, nC, c->P.segLength, c->dL1.as<mm_l1_candidate>(), c->dStats.as<mm_frag_stats>(),
-                       I.evKey.as<uint32_t>(), I.contigOff.as<int64_t>(), c->dL2Info.as<L2Info>(), c->dL2Cnt.as<int32_t>());
+                       I.evKey.as<uint32_t>(), I.contigOff.as<int64_t>(), I.contigBlock.as<int64_t>(), I.blockOff.as<int64_t>(),
+                       c->dL2Info.as<L2Info>(), c->dL2Cnt.as<int32_t>());
     MM_HIP(c, hipGetLastError());
     int rc = mm_scan_i32_to_i64(c, nC, c->dL2Cnt.as<int32_t>(), c->dL2Off.as<int64_t>(), &totalOps);
     if (rc != MM_OK) return rc;
@@ -495,7 +515,8 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt) {
     hipLaunchKernelGGL(k_l2_locate, dim3(blocks), dim3(256), ldsLoc, c->stream, nC, s, c->dL1.as<mm_l1_candidate>(),
                        c->dStats.as<mm_frag_stats>(), c->dQHash.as<uint64_t>(), c->dQStrand.as<int8_t>(), c->dSkHash.as<uint64_t>(), c->dSkStrand.as<int8_t>(),
                        I.evKey.as<uint32_t>(),
-                       I.evAux.as<uint32_t>(), I.evHash.as<uint64_t>(), I.contigOff.as<int64_t>(),
+                       I.evAux.as<uint32_t>(), I.evHash.as<uint64_t>(), I.opKey.as<uint32_t>(), I.opAux.as<uint32_t>(), I.opHash.as<uint64_t>(),
+                       I.contigOff.as<int64_t>(),
                        c->dL2Info.as<L2Info>(), c->dL2Off.as<int64_t>(), c->dL2Cnt.as<int32_t>(), c->dL2Ops.as<uint32_t>(), cnt);
     MM_HIP(c, hipGetLastError());
   }

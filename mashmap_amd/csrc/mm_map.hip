@@ -63,6 +63,35 @@ int mm_build_device_index(mm_ctx* c, const int32_t* contigLen, const int32_t* re
       }
     }
   }
+  // records open at every block boundary B = b << MM_OPEN_BLOCK_SHIFT: wpos < B < wpos_end, in index order.  A record is at most
+  // maxLen positions long, so the candidates for B are the records with wpos in [B - maxLen, B).
+  std::vector<uint32_t> opKey, opAux; std::vector<uint64_t> opHash;
+  std::vector<int64_t> blockOff(1, 0), contigBlock(nContigs + 1, 0);
+  {
+    int64_t maxLen = 0;
+    for (size_t i = 0; i < n; i++) maxLen = std::max<int64_t>(maxLen, (int64_t)c->hMinmers[i].wpos_end - c->hMinmers[i].wpos);
+    for (size_t sId = 0; sId < nContigs; sId++) {
+      contigBlock[sId] = (int64_t)blockOff.size() - 1;
+      const size_t b0 = (size_t)coff[sId] / 2, e0 = (size_t)coff[sId + 1] / 2;
+      int64_t lastPos = contigLen[sId];
+      if (e0 > b0) lastPos = std::max<int64_t>(lastPos, c->hMinmers[e0 - 1].wpos);
+      const int64_t nBlk = (lastPos >> MM_OPEN_BLOCK_SHIFT) + 1;
+      size_t lo = b0, hi = b0;
+      for (int64_t b = 0; b < nBlk; b++) {
+        const int64_t B = b << MM_OPEN_BLOCK_SHIFT;
+        while (hi < e0 && c->hMinmers[hi].wpos < B) hi++;
+        while (lo < hi && c->hMinmers[lo].wpos < B - maxLen) lo++;
+        for (size_t i = lo; i < hi; i++) {
+          const mm_minmer& m = c->hMinmers[i];
+          if ((int64_t)m.wpos_end > B) {
+            opKey.push_back((uint32_t)m.wpos * 2u + 1u); opAux.push_back((uint32_t)m.wpos_end | (m.strand < 0 ? 0x80000000u : 0u)); opHash.push_back(m.hash);
+          }
+        }
+        blockOff.push_back((int64_t)opKey.size());
+      }
+    }
+    contigBlock[nContigs] = (int64_t)blockOff.size() - 1;
+  }
   size_t cap = 16; while (cap < 2 * nk + 2) cap <<= 1;
   std::vector<uint64_t> hs(2 * cap, 0);                 // interleaved {key, val} slots
   for (size_t i = 0; i < cap; i++) hs[2 * i] = MM_EMPTY;
@@ -97,6 +126,16 @@ int mm_build_device_index(mm_ctx* c, const int32_t* contigLen, const int32_t* re
            MM_HIP(c, hipMemcpyAsync(I.evAux.p, evAux.data(), 2 * n * 4, hipMemcpyHostToDevice, c->stream));
            MM_HIP(c, hipMemcpyAsync(I.evHash.p, evHash.data(), 2 * n * 8, hipMemcpyHostToDevice, c->stream)); }
   MM_HIP(c, hipMemcpyAsync(I.contigOff.p, coff.data(), (nContigs + 1) * 8, hipMemcpyHostToDevice, c->stream));
+  {
+    const size_t no = opKey.size();
+    MM_HIP(c, I.opKey.ensure(no * 4 + 256)); MM_HIP(c, I.opAux.ensure(no * 4 + 256)); MM_HIP(c, I.opHash.ensure(no * 8 + 512));
+    MM_HIP(c, I.blockOff.ensure(blockOff.size() * 8)); MM_HIP(c, I.contigBlock.ensure((nContigs + 1) * 8));
+    if (no) { MM_HIP(c, hipMemcpyAsync(I.opKey.p, opKey.data(), no * 4, hipMemcpyHostToDevice, c->stream));
+              MM_HIP(c, hipMemcpyAsync(I.opAux.p, opAux.data(), no * 4, hipMemcpyHostToDevice, c->stream));
+              MM_HIP(c, hipMemcpyAsync(I.opHash.p, opHash.data(), no * 8, hipMemcpyHostToDevice, c->stream)); }
+    MM_HIP(c, hipMemcpyAsync(I.blockOff.p, blockOff.data(), blockOff.size() * 8, hipMemcpyHostToDevice, c->stream));
+    MM_HIP(c, hipMemcpyAsync(I.contigBlock.p, contigBlock.data(), (nContigs + 1) * 8, hipMemcpyHostToDevice, c->stream));
+  }
   MM_HIP(c, hipMemcpyAsync(I.contigLen.p, contigLen, nContigs * 4, hipMemcpyHostToDevice, c->stream));
   MM_HIP(c, hipMemcpyAsync(I.refGroup.p, grp.data(), nContigs * 4, hipMemcpyHostToDevice, c->stream));
   MM_HIP(c, hipMemcpyAsync(I.htSlots.p, hs.data(), cap * 16, hipMemcpyHostToDevice, c->stream));
