@@ -174,10 +174,11 @@ k_l2_locate(int nCand, int s, const mm_l1_candidate* __restrict__ l1, const mm_f
     for (int p = lane; p < S; p += 64) { q[p] = srcH[p]; qs[p] = srcS[p]; }
     __threadfence_block();
     const uint64_t qmax = q[S - 1];
-    // bucket(h): monotone map of [0, qmax] onto 0..255 from the top 24 significant bits (float keeps them exactly)
+    // bucket(h): monotone map of [0, qmax] onto 0..255: the top 24 significant bits times M >> 32, M <= 2^32 * 256 / (top24(qmax) + 1)
+    // (any smaller M stays monotone and below 256; the float estimate is shaded down)
     const int sh = qmax ? (int)__builtin_clzll(qmax) : 63;
-    const float scale = 256.0f / ((float)(uint32_t)((qmax << sh) >> 40) + 1.0f);
-    auto bucket = [&](uint64_t h) -> int { const int b = (int)((float)(uint32_t)((h << sh) >> 40) * scale); return b > 255 ? 255 : b; };
+    const uint32_t bM = (uint32_t)(256.0f * 4294967296.0f / ((float)(uint32_t)((qmax << sh) >> 40) + 1.0f) * 0.99999f);
+    auto bucket = [&](uint64_t h) -> int { return (int)__umulhi((uint32_t)((h << sh) >> 40), bM); };
     // bkt[b] = #{p : bucket(q[p]) < b}.  q is sorted, so entry p owns the buckets (bucket(q[p-1]), bucket(q[p])] and the
     // sentinel p = S owns the rest up to 256: a scatter of ~2 stores per lane instead of 257 binary searches
     for (int p0 = 0; p0 <= S; p0 += 64) {
