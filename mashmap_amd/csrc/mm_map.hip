@@ -687,7 +687,15 @@ struct L1Emit {
     }
     firstOfGroup = false;
   }
-  __device__ __forceinline__ void flush() { if (have) { if (write) out[count] = pend; count++; have = false; } }
+  mm_l1_candidate b0, b1;                             // the first two candidates of a counting pass: most fragments need no second pass
+  __device__ __forceinline__ void flush() {
+    if (have) {
+      if (write) out[count] = pend;
+      else if (count == 0) b0 = pend;
+      else if (count == 1) b1 = pend;
+      count++; have = false;
+    }
+  }
 };
 
 __device__ void l1_sweep_fragment(const uint64_t* __restrict__ p, int nPts, int sketchSizeQ, int minHits0, const int32_t* __restrict__ cutoffs,
@@ -767,6 +775,7 @@ k_l1_sweep(int nList, const int32_t* __restrict__ list, const int64_t* __restric
     if (nOut > 0) {
       base = (long long)atomicAdd(&counters[2], (unsigned long long)nOut);
       if ((unsigned long long)base + nOut > l1Cap) { atomicOr(&counters[3], 1ull); nOut = 0; }
+      else if (nOut <= 2) { l1[base] = em.b0; if (nOut == 2) l1[base + 1] = em.b1; }
       else {
         L1Emit ew; ew.out = l1 + base; ew.frag = f; ew.count = 0; ew.write = true; ew.have = false;
         l1_sweep_fragment(p, nPts, S, minHits0, cutoffs, nCutoffs, sParam, segLength, fl, refGroup, ew);
