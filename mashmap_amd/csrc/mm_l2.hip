@@ -62,7 +62,14 @@ k_l2_extents(int nCand, int segLength, const mm_l1_candidate* __restrict__ l1, c
   const mm_l1_candidate cand = l1[c];
   const mm_frag_stats fst = stats[cand.frag];
   const int64_t cb = contigOff[cand.seqId], ce = contigOff[cand.seqId + 1];
-  auto lower = [&](int64_t lo, uint32_t key) { int64_t hi = ce; while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (evKey[mid] < key) lo = mid + 1; else hi = mid; } return lo; };
+  auto lowerIn = [&](int64_t lo, int64_t hi, uint32_t key) { while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (evKey[mid] < key) lo = mid + 1; else hi = mid; } return lo; };
+  auto lower = [&](int64_t lo, uint32_t key) { return lowerIn(lo, ce, key); };
+  // the same when the answer is known to be close behind lo: gallop to bracket it, then bisect the bracket
+  auto lowerNear = [&](int64_t lo, uint32_t key) {
+    int64_t step = 32, hi;
+    while (true) { hi = lo + step; if (hi >= ce) { hi = ce; break; } if (evKey[hi] < key) { lo = hi + 1; step <<= 1; } else break; }
+    return lowerIn(lo, hi, key);
+  };
   // std::lower_bound(minmerIndex, (seqId, rangeStart - segLength - 1))  (computeMap.hpp:1290-1293): inserts with wpos >= target are
   // pre-loaded if still open at rangeStart.  Those that start before the block boundary B <= rangeStart come from the block's
   // list of open records, the rest from the events in [max(B, target), rangeStart).
@@ -72,8 +79,8 @@ k_l2_extents(int nCand, int segLength, const mm_l1_candidate* __restrict__ l1, c
   const int B = (cand.rangeStartPos >> MM_OPEN_BLOCK_SHIFT) << MM_OPEN_BLOCK_SHIFT;
   const int from = target > B ? target : B;
   const int64_t e0 = lower(cb, from > 0 ? (uint32_t)from * 2u : 0u);
-  const int64_t eMid = lower(e0, (uint32_t)cand.rangeStartPos * 2u + 1u);      // first event of the slide: insert at rangeStart or anything later
-  const int64_t ub = lower(eMid, (uint32_t)cand.rangeEndPos * 2u + 2u);        // records are visited while wpos <= rangeEnd (:1340)
+  const int64_t eMid = lowerNear(e0, (uint32_t)cand.rangeStartPos * 2u + 1u);  // first event of the slide: insert at rangeStart or anything later
+  const int64_t ub = lowerNear(eMid, (uint32_t)cand.rangeEndPos * 2u + 2u);        // records are visited while wpos <= rangeEnd (:1340)
   L2Info o; o.e0 = e0; o.nPre = (int32_t)(eMid - e0); o.nAll = (int32_t)(ub - e0);
   o.open0 = ob; o.nOpen = (int32_t)(oe - ob); o.target = target;
   o.sketch = fst.sketchSize | (fst.rawSketchSize == fst.sketchSize ? (int32_t)0x80000000 : 0); o.pad = 0;
