@@ -51,7 +51,7 @@ void mm_destroy(mm_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
-  DevBuf* bufs[] = {&c->idx.evKey, &c->idx.evAux, &c->idx.evHash, &c->idx.contigOff, &c->idx.opKey, &c->idx.opAux, &c->idx.opHash, &c->idx.blockOff, &c->idx.contigBlock, &c->idx.contigLen, &c->idx.refGroup, &c->idx.htSlots, &c->idx.filter, &c->idx.ptKeys, &c->dMinHits, &c->dCutoffs, &c->dAscii, &c->dReadSrcOff, &c->dReadPackOff,
+  DevBuf* bufs[] = {&c->idx.evKey, &c->idx.evAux, &c->idx.evHash, &c->idx.contigOff, &c->idx.opKey, &c->idx.opAux, &c->idx.opHash, &c->idx.blockOff, &c->idx.evBlock, &c->idx.contigBlock, &c->idx.contigLen, &c->idx.refGroup, &c->idx.htSlots, &c->idx.filter, &c->idx.ptKeys, &c->dMinHits, &c->dCutoffs, &c->dAscii, &c->dReadSrcOff, &c->dReadPackOff,
                     &c->dReadLen, &c->dReadGroup, &c->dReadSelf, &c->dReadHasN, &c->dBases2, &c->dNmask, &c->dFrags, &c->dSkHash,
                     &c->dSkPos, &c->dSkStrand, &c->dSkCount, &c->dHardList, &c->dCounters, &c->dSketchTabs, &c->dQHash, &c->dQStrand, &c->dSeedVal,
                     &c->dStats, &c->dPtOff, &c->dPts, &c->dL1, &c->dL1b, &c->dL1Cursors, &c->dL1Off, &c->dL2, &c->dL2Info, &c->dL2Cnt, &c->dL2Off, &c->dL2Ops, &c->dScanTmp, &c->dL2Tmp, &c->dL2Wide, &c->dListB, &c->dListC, &c->dBigList};

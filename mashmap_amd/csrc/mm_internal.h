@@ -50,6 +50,7 @@ struct DeviceIndex {
   // candidate starts from the list of its block instead of streaming a whole segLength of events (computeMap.hpp:1323-1338)
   DevBuf opKey, opAux, opHash; // as evKey / evAux / evHash
   DevBuf blockOff;             // int64[nBlocks+1] offsets into op*
+  DevBuf evBlock;              // int64[nBlocks+1] first event at or behind the block start (block b of a contig: pos >= b << MM_OPEN_BLOCK_SHIFT)
   DevBuf contigBlock;          // int64[nContigs+1] first block of every contig
   DevBuf contigLen;            // int32[nContigs]
   DevBuf refGroup;             // int32[nContigs] (all 0 when unused)

@@ -56,31 +56,26 @@ struct L2Tmp { int32_t start, end, shared, strand; };
 __global__ void __launch_bounds__(256)
 k_l2_extents(int nCand, int segLength, const mm_l1_candidate* __restrict__ l1, const mm_frag_stats* __restrict__ stats, const uint32_t* __restrict__ evKey,
              const int64_t* __restrict__ contigOff, const int64_t* __restrict__ contigBlock, const int64_t* __restrict__ blockOff,
-             L2Info* __restrict__ info, int32_t* __restrict__ cnt) {
+             const int64_t* __restrict__ evBlock, L2Info* __restrict__ info, int32_t* __restrict__ cnt) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= nCand) return;
   const mm_l1_candidate cand = l1[c];
   const mm_frag_stats fst = stats[cand.frag];
-  const int64_t cb = contigOff[cand.seqId], ce = contigOff[cand.seqId + 1];
   auto lowerIn = [&](int64_t lo, int64_t hi, uint32_t key) { while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (evKey[mid] < key) lo = mid + 1; else hi = mid; } return lo; };
-  auto lower = [&](int64_t lo, uint32_t key) { return lowerIn(lo, ce, key); };
-  // the same when the answer is known to be close behind lo: gallop to bracket it, then bisect the bracket
-  auto lowerNear = [&](int64_t lo, uint32_t key) {
-    int64_t step = 32, hi;
-    while (true) { hi = lo + step; if (hi >= ce) { hi = ce; break; } if (evKey[hi] < key) { lo = hi + 1; step <<= 1; } else break; }
-    return lowerIn(lo, hi, key);
-  };
   // std::lower_bound(minmerIndex, (seqId, rangeStart - segLength - 1))  (computeMap.hpp:1290-1293): inserts with wpos >= target are
   // pre-loaded if still open at rangeStart.  Those that start before the block boundary B <= rangeStart come from the block's
-  // list of open records, the rest from the events in [max(B, target), rangeStart).
+  // list of open records, the rest from the events in [max(B, target), rangeStart).  evBlock brackets every search to one block.
   const int target = cand.rangeStartPos - segLength - 1;
-  const int64_t blk = contigBlock[cand.seqId] + (cand.rangeStartPos >> MM_OPEN_BLOCK_SHIFT);
+  const int64_t blk0 = contigBlock[cand.seqId], nBlk = contigBlock[cand.seqId + 1] - blk0;
+  const int64_t blk = blk0 + (cand.rangeStartPos >> MM_OPEN_BLOCK_SHIFT);
   const int64_t ob = blockOff[blk], oe = blockOff[blk + 1];
+  const int64_t evB = evBlock[blk], evN = evBlock[blk + 1];
   const int B = (cand.rangeStartPos >> MM_OPEN_BLOCK_SHIFT) << MM_OPEN_BLOCK_SHIFT;
-  const int from = target > B ? target : B;
-  const int64_t e0 = lower(cb, from > 0 ? (uint32_t)from * 2u : 0u);
-  const int64_t eMid = lowerNear(e0, (uint32_t)cand.rangeStartPos * 2u + 1u);  // first event of the slide: insert at rangeStart or anything later
-  const int64_t ub = lowerNear(eMid, (uint32_t)cand.rangeEndPos * 2u + 2u);        // records are visited while wpos <= rangeEnd (:1340)
+  const int64_t e0 = target > B ? lowerIn(evB, evN, (uint32_t)target * 2u) : evB;
+  const int64_t eMid = lowerIn(e0, evN, (uint32_t)cand.rangeStartPos * 2u + 1u);   // first event of the slide: insert at rangeStart or anything later
+  int64_t bE = cand.rangeEndPos >> MM_OPEN_BLOCK_SHIFT; if (bE > nBlk - 1) bE = nBlk - 1;
+  const int64_t evE = evBlock[blk0 + bE], evEn = evBlock[blk0 + bE + 1];
+  const int64_t ub = lowerIn(evE > eMid ? evE : eMid, evEn, (uint32_t)cand.rangeEndPos * 2u + 2u);   // records are visited while wpos <= rangeEnd (:1340)
   L2Info o; o.e0 = e0; o.nPre = (int32_t)(eMid - e0); o.nAll = (int32_t)(ub - e0);
   o.open0 = ob; o.nOpen = (int32_t)(oe - ob); o.target = target;
   o.sketch = fst.sketchSize | (fst.rawSketchSize == fst.sketchSize ? (int32_t)0x80000000 : 0); o.pad = 0;
@@ -510,7 +505,7 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt) {
   {
     KernelTimer t(c, MM_K_L2_LOCATE);
     hipLaunchKernelGGL(k_l2_extents, dim3((nC + 255) / 256), dim3(256), 0, c->stream, nC, c->P.segLength, c->dL1.as<mm_l1_candidate>(), c->dStats.as<mm_frag_stats>(),
-                       I.evKey.as<uint32_t>(), I.contigOff.as<int64_t>(), I.contigBlock.as<int64_t>(), I.blockOff.as<int64_t>(),
+                       I.evKey.as<uint32_t>(), I.contigOff.as<int64_t>(), I.contigBlock.as<int64_t>(), I.blockOff.as<int64_t>(), I.evBlock.as<int64_t>(),
                        c->dL2Info.as<L2Info>(), c->dL2Cnt.as<int32_t>());
     MM_HIP(c, hipGetLastError());
     int rc = mm_scan_i32_to_i64(c, nC, c->dL2Cnt.as<int32_t>(), c->dL2Off.as<int64_t>(), &totalOps);

@@ -67,6 +67,7 @@ int mm_build_device_index(mm_ctx* c, const int32_t* contigLen, const int32_t* re
   // maxLen positions long, so the candidates for B are the records with wpos in [B - maxLen, B).
   std::vector<uint32_t> opKey, opAux; std::vector<uint64_t> opHash;
   std::vector<int64_t> blockOff(1, 0), contigBlock(nContigs + 1, 0);
+  std::vector<int64_t> evBlock;                          // first event of every block (pos >= B), + one sentinel per contig
   {
     int64_t maxLen = 0;
     for (size_t i = 0; i < n; i++) maxLen = std::max<int64_t>(maxLen, (int64_t)c->hMinmers[i].wpos_end - c->hMinmers[i].wpos);
@@ -77,8 +78,11 @@ int mm_build_device_index(mm_ctx* c, const int32_t* contigLen, const int32_t* re
       if (e0 > b0) lastPos = std::max<int64_t>(lastPos, c->hMinmers[e0 - 1].wpos);
       const int64_t nBlk = (lastPos >> MM_OPEN_BLOCK_SHIFT) + 1;
       size_t lo = b0, hi = b0;
+      int64_t ev = coff[sId];
       for (int64_t b = 0; b < nBlk; b++) {
         const int64_t B = b << MM_OPEN_BLOCK_SHIFT;
+        while (ev < coff[sId + 1] && (int64_t)(evKey[(size_t)ev] >> 1) < B) ev++;
+        evBlock.push_back(ev);
         while (hi < e0 && c->hMinmers[hi].wpos < B) hi++;
         while (lo < hi && c->hMinmers[lo].wpos < B - maxLen) lo++;
         for (size_t i = lo; i < hi; i++) {
@@ -91,6 +95,7 @@ int mm_build_device_index(mm_ctx* c, const int32_t* contigLen, const int32_t* re
       }
     }
     contigBlock[nContigs] = (int64_t)blockOff.size() - 1;
+    evBlock.push_back(coff[nContigs]);
   }
   size_t cap = 16; while (cap < 2 * nk + 2) cap <<= 1;
   std::vector<uint64_t> hs(2 * cap, 0);                 // interleaved {key, val} slots
@@ -134,6 +139,8 @@ int mm_build_device_index(mm_ctx* c, const int32_t* contigLen, const int32_t* re
               MM_HIP(c, hipMemcpyAsync(I.opAux.p, opAux.data(), no * 4, hipMemcpyHostToDevice, c->stream));
               MM_HIP(c, hipMemcpyAsync(I.opHash.p, opHash.data(), no * 8, hipMemcpyHostToDevice, c->stream)); }
     MM_HIP(c, hipMemcpyAsync(I.blockOff.p, blockOff.data(), blockOff.size() * 8, hipMemcpyHostToDevice, c->stream));
+    MM_HIP(c, I.evBlock.ensure(evBlock.size() * 8));
+    MM_HIP(c, hipMemcpyAsync(I.evBlock.p, evBlock.data(), evBlock.size() * 8, hipMemcpyHostToDevice, c->stream));
     MM_HIP(c, hipMemcpyAsync(I.contigBlock.p, contigBlock.data(), (nContigs + 1) * 8, hipMemcpyHostToDevice, c->stream));
   }
   MM_HIP(c, hipMemcpyAsync(I.contigLen.p, contigLen, nContigs * 4, hipMemcpyHostToDevice, c->stream));
