@@ -7,16 +7,18 @@
 // by wpos_end and, for every record, binary-searches the query sketch twice (insert + eviction).  Here the index already
 // holds, per contig, the merged stream of insert and eviction events (mm_build_device_index), so a candidate is a slice of it:
 //
-//   k_l2_extents   thread / candidate : three binary searches give the slice [e0, eMid, ub) of the event stream
+//   k_l2_extents   thread / candidate : the slice [e0, eMid, ub) of the event stream (three searches, each bracketed to one block of
+//                                       positions by evBlock) and the block's list of records open at its start
 //   scan           exclusive scan of the per-candidate entry counts
-//   k_l2_locate    wave / candidate   : streams the slice (coalesced 16 B per event), locates every hash in the query sketch
-//                                       (LDS bucket table + short scan) and writes a compact 4-byte entry per event that can
-//                                       matter: pre-load inserts still open at rangeStart, inserts, evictions of hashes inside
+//   k_l2_locate    wave / candidate   : streams the open-record list and the slice (coalesced 16 B per event), locates every hash in
+//                                       the query sketch (LDS bucket table + short scan) and writes a compact 4-byte entry per event
+//                                       that can matter: pre-load inserts still open at rangeStart, inserts, evictions of hashes inside
 //                                       the sketch's range; positions are delta-coded against the previous insert
 //   k_l2_sweep     lane / candidate   : the sequential SlideMapper sweep over that stream; 64 bytes (16 entries) per lane
 //                                       are fetched per step and the next step is prefetched while the current one is
-//                                       consumed; per-lane SlideMapper state sits in LDS as 16-bit cells laid out so that a
-//                                       lane always hits its own bank; the state update is branch-free
+//                                       consumed; per-lane SlideMapper state sits in LDS as 8-bit cells (16-bit for the rare
+//                                       candidate that overflows them) laid out so that a lane always hits its own bank; the state
+//                                       update runs on integer lane masks, without branches
 //
 // so the latency-bound pointer chasing of the reference (two dependent 8-step searches per record plus a heap) becomes a
 // streaming pre-pass followed by a sweep whose only memory traffic is one sequential stream per lane.
@@ -55,7 +57,7 @@ struct L2Tmp { int32_t start, end, shared, strand; };
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_l2_extents(int nCand, int segLength, const mm_l1_candidate* __restrict__ l1, const mm_frag_stats* __restrict__ stats, const uint32_t* __restrict__ evKey,
-             const int64_t* __restrict__ contigOff, const int64_t* __restrict__ contigBlock, const int64_t* __restrict__ blockOff,
+             const int64_t* __restrict__ contigBlock, const int64_t* __restrict__ blockOff,
              const int64_t* __restrict__ evBlock, L2Info* __restrict__ info, int32_t* __restrict__ cnt) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= nCand) return;
@@ -505,7 +507,7 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt) {
   {
     KernelTimer t(c, MM_K_L2_LOCATE);
     hipLaunchKernelGGL(k_l2_extents, dim3((nC + 255) / 256), dim3(256), 0, c->stream, nC, c->P.segLength, c->dL1.as<mm_l1_candidate>(), c->dStats.as<mm_frag_stats>(),
-                       I.evKey.as<uint32_t>(), I.contigOff.as<int64_t>(), I.contigBlock.as<int64_t>(), I.blockOff.as<int64_t>(), I.evBlock.as<int64_t>(),
+                       I.evKey.as<uint32_t>(), I.contigBlock.as<int64_t>(), I.blockOff.as<int64_t>(), I.evBlock.as<int64_t>(),
                        c->dL2Info.as<L2Info>(), c->dL2Cnt.as<int32_t>());
     MM_HIP(c, hipGetLastError());
     int rc = mm_scan_i32_to_i64(c, nC, c->dL2Cnt.as<int32_t>(), c->dL2Off.as<int64_t>(), &totalOps);

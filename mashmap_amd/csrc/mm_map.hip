@@ -800,7 +800,8 @@ int mm_launch_map(mm_ctx* c) {
   const int nF = (int)c->nFrags, s = c->P.sketchSize;
   const DeviceIndex& I = c->idx;
   MM_HIP(c, c->dQHash.ensure((size_t)nF * s * 8 + 64)); MM_HIP(c, c->dQStrand.ensure((size_t)nF * s + 64));
-  MM_HIP(c, c->dSeedVal.ensure((size_t)nF * s * 8 + 64)); MM_HIP(c, c->dStats.ensure((size_t)nF * sizeof(mm_frag_stats) + 64));
+  // per-seed table values go through HBM only for sketches of more than 256 entries (k_lookup_l1 keeps them in registers otherwise)
+  MM_HIP(c, c->dSeedVal.ensure((s > 256 ? (size_t)nF * s * 8 : 0) + 64)); MM_HIP(c, c->dStats.ensure((size_t)nF * sizeof(mm_frag_stats) + 64));
   MM_HIP(c, c->dPtOff.ensure((size_t)nF * 16 + 64)); MM_HIP(c, c->dL1Off.ensure((size_t)nF * 8 + 64));
   MM_HIP(c, c->dCounters.ensure(256));
   c->nL1 = c->nL2 = 0;
