@@ -154,6 +154,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ref-contigs", type=int, default=REF_CONTIGS, help="contigs of the synthetic reference (default: configs[1], 10 x 10 Mbp)")
     ap.add_argument("--ref-contig-len", type=int, default=REF_CONTIG_LEN)
+    ap.add_argument("--kmer", type=int, default=K, help="k-mer size (default: the reference's 19; other sizes are not the BASELINE configuration)")
     ap.add_argument("--cpu-sample", type=int, default=30000)
     args = ap.parse_args()
 
@@ -179,7 +180,7 @@ def main():
     torch.cuda.synchronize()
     log("[rank %d] synthetic data: %.1f s" % (rank, time.time() - t0))
 
-    ctx = capi.Context(k=K, segLength=SEG, sketchSize=SKETCH, flags=capi.MM_FLAG_HG_FILTER, device=local)
+    ctx = capi.Context(k=args.kmer, segLength=SEG, sketchSize=SKETCH, flags=capi.MM_FLAG_HG_FILTER, device=local)
     t0 = time.time()
     ctx.index_build(ref_np, kmerPct=0.001)
     ctx.set_tables_default(PI)
@@ -238,7 +239,7 @@ def main():
         traffic = None
         valu_per_launch = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc) and args.reads == 1_000_000 and (args.ref_contigs, args.ref_contig_len) == (REF_CONTIGS, REF_CONTIG_LEN):
+        if os.path.exists(pmc) and args.reads == 1_000_000 and (args.ref_contigs, args.ref_contig_len, args.kmer) == (REF_CONTIGS, REF_CONTIG_LEN, K):
             try:
                 ent = json.load(open(pmc)).get("k_sketch_fragments", {})
                 traffic = ent.get("hbm_bytes_per_launch")
@@ -252,7 +253,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": "configs[1]: %d x %d bp reads/GPU (%.0f%% ONT-like error) vs %.0f Mbp synthetic reference (%d contigs)"
-                                   % (args.reads, READ_LEN, ERR * 100, args.ref_contigs * args.ref_contig_len / 1e6, args.ref_contigs), "k": K, "segLength": SEG, "sketchSize": SKETCH,
+                                   % (args.reads, READ_LEN, ERR * 100, args.ref_contigs * args.ref_contig_len / 1e6, args.ref_contigs), "k": args.kmer, "segLength": SEG, "sketchSize": SKETCH,
                        "percentageIdentity": PI, "fragments_per_gpu": nF, "parallelism": "reads sharded, index replicated, RCCL all-gatherv of L2 loci"
                        if world > 1 else "single GPU", "mean_interval_points_per_fragment": round(P, 1),
                        "l1_candidates_per_gpu": n1, "l2_loci_per_gpu": n2},

@@ -205,13 +205,21 @@ struct MMProdTables {        // lives in LDS (first thing in the dynamic segment
   uint64_t pf2[256];         // ascii4(c) * C2            forward strand, block word k2
   uint64_t pr1[256];         // ascii4(revcomp c) * C1    reverse strand, k1
   uint64_t pr2[256];         // ascii4(revcomp c) * C2    reverse strand, k2
-  uint64_t tailF[64];        // as MMTables, ^ K
+  uint64_t tailF[64];        // K = 17..19: complete mix of the tail ^ K; otherwise: products of the one group shorter than 4 bases
   uint64_t tailR[64];
+};
+
+// Word layout of MurmurHash3_x64_128 over K bytes, 16 <= K <= 32: K/16 blocks (k1, k2 of 8 bytes each), then tail words of
+// T1 = min(K%16, 8) bytes (mixed like k1) and T2 = K%16 - T1 bytes (mixed like k2).  Every word is a sum of 4-byte groups; at most
+// one group of the key is shorter than 4 bytes (PM bytes, in the k1 tail unless that tail is exactly 8 bytes).
+template <int K> struct MMKeyLayout {
+  static constexpr int NB = K / 16, T = K % 16, T1 = T > 8 ? 8 : T, T2 = T > 8 ? T - 8 : 0;
+  static constexpr int PM = (T1 % 4) ? (T1 % 4) : (T2 % 4);
+  static constexpr bool PART_IN_K2 = (T1 % 4) == 0 && (T2 % 4) != 0;
 };
 
 template <int K>
 __device__ __forceinline__ void mm_tables_init(MMProdTables& T, int tid, int nthr) {
-  constexpr int TAIL = K - 16;
   for (int c = tid; c < 256; c += nthr) {
     uint32_t f = 0, r = 0;
 #pragma unroll
@@ -222,15 +230,33 @@ __device__ __forceinline__ void mm_tables_init(MMProdTables& T, int tid, int nth
     T.pf1[c] = (uint64_t)f * MM_C1; T.pf2[c] = (uint64_t)f * MM_C2;
     T.pr1[c] = (uint64_t)r * MM_C1; T.pr2[c] = (uint64_t)r * MM_C2;
   }
-  for (int c = tid; c < 64; c += nthr) {
-    uint64_t kf = 0, kr = 0;
+  if constexpr (MMFastK<K>::value) {
+    // K = 17..19: the tail is the short group alone, so its complete mix (with the key length folded in) comes from the table
+    constexpr int TAIL = K - 16;
+    for (int c = tid; c < 64; c += nthr) {
+      uint64_t kf = 0, kr = 0;
 #pragma unroll
-    for (int i = 0; i < TAIL; i++) {
-      kf |= (uint64_t)mm_ascii1((c >> (2 * i)) & 3) << (8 * i);
-      kr |= (uint64_t)mm_ascii1(3 - ((c >> (2 * (TAIL - 1 - i))) & 3)) << (8 * i);
+      for (int i = 0; i < TAIL; i++) {
+        kf |= (uint64_t)mm_ascii1((c >> (2 * i)) & 3) << (8 * i);
+        kr |= (uint64_t)mm_ascii1(3 - ((c >> (2 * (TAIL - 1 - i))) & 3)) << (8 * i);
+      }
+      T.tailF[c] = mm_mix_k1(kf) ^ (uint64_t)K;       // h1 ^= tail mix; h1 ^= len  in one xor
+      T.tailR[c] = mm_mix_k1(kr) ^ (uint64_t)K;
     }
-    T.tailF[c] = mm_mix_k1(kf) ^ (uint64_t)K;       // h1 ^= tail mix; h1 ^= len  in one xor
-    T.tailR[c] = mm_mix_k1(kr) ^ (uint64_t)K;
+  } else {
+    // otherwise: the products of the short group (PM bases) with the constant of the word it sits in
+    constexpr int PM = MMKeyLayout<K>::PM;
+    constexpr uint64_t CP = MMKeyLayout<K>::PART_IN_K2 ? MM_C2 : MM_C1;
+    for (int c = tid; c < 64; c += nthr) {
+      uint64_t kf = 0, kr = 0;
+#pragma unroll
+      for (int i = 0; i < PM; i++) {
+        kf |= (uint64_t)mm_ascii1((c >> (2 * i)) & 3) << (8 * i);
+        kr |= (uint64_t)mm_ascii1(3 - ((c >> (2 * (PM - 1 - i))) & 3)) << (8 * i);
+      }
+      T.tailF[c] = kf * CP;
+      T.tailR[c] = kr * CP;
+    }
   }
 }
 
@@ -268,26 +294,71 @@ __device__ __forceinline__ uint64_t mm_murmur_from_products(uint64_t p1, uint64_
   return h1 + h2;
 }
 
+// product of the NBYTES-byte key word at byte offset BYTEOFF of k-mer j with C1 (CI == 1) or C2, forward or reverse-complement
+// strand: the 4-byte group at byte b of the forward key is the window of bases j+b.., of the reverse key (byte i = complement of
+// base j+K-1-i) the window that ends at base j+K-1-b.
+template <int K, bool RC, int CI, int BYTEOFF, int NBYTES>
+__device__ __forceinline__ uint64_t mm_word_product(const uint32_t* w, int j, const MMProdTables& T) {
+  constexpr int M0 = NBYTES < 4 ? NBYTES : 4, M1 = NBYTES - M0;
+  const uint64_t* full = CI == 1 ? (RC ? T.pr1 : T.pf1) : (RC ? T.pr2 : T.pf2);
+  const uint64_t* part = RC ? T.tailR : T.tailF;
+  const int p0 = RC ? j + K - BYTEOFF - M0 : j + BYTEOFF;
+  uint64_t P = mm_lds64(M0 == 4 ? full : part, mm_win_off8<M0>(w, p0));
+  if constexpr (M1 > 0) {
+    const int p1 = RC ? j + K - (BYTEOFF + 4) - M1 : j + BYTEOFF + 4;
+    P += (uint64_t)mm_lds32(M1 == 4 ? full : part, mm_win_off8<M1>(w, p1)) << 32;
+  }
+  return P;
+}
+
+// the hash of k-mer j on one strand, every first-level product from the tables (16 <= K <= 32, K not in 17..19)
+template <int K, bool RC>
+__device__ __forceinline__ uint64_t mm_murmur_prod_general(const uint32_t* w, int j, const MMProdTables& T) {
+  using L = MMKeyLayout<K>;
+  uint64_t h1, h2;
+  {
+    const uint64_t p1 = mm_word_product<K, RC, 1, 0, 8>(w, j, T), p2 = mm_word_product<K, RC, 2, 8, 8>(w, j, T);
+    h1 = MM_SEED ^ (mm_rotl64(p1, 31) * MM_C2); h1 = mm_rotl64(h1, 27); h1 = mm_times5(h1) + (0x52dce729ull + 5ull * MM_SEED);
+    h2 = MM_SEED ^ (mm_rotl64(p2, 33) * MM_C1); h2 = mm_rotl64(h2, 31); h2 += h1; h2 = mm_times5(h2) + 0x38495ab5;
+  }
+  if constexpr (L::NB == 2) {
+    const uint64_t p1 = mm_word_product<K, RC, 1, 16, 8>(w, j, T), p2 = mm_word_product<K, RC, 2, 24, 8>(w, j, T);
+    h1 ^= mm_rotl64(p1, 31) * MM_C2; h1 = mm_rotl64(h1, 27); h1 += h2; h1 = mm_times5(h1) + 0x52dce729;
+    h2 ^= mm_rotl64(p2, 33) * MM_C1; h2 = mm_rotl64(h2, 31); h2 += h1; h2 = mm_times5(h2) + 0x38495ab5;
+  }
+  if constexpr (L::T2 > 0) h2 ^= mm_rotl64(mm_word_product<K, RC, 2, 16 * L::NB + 8, (L::T2 > 0 ? L::T2 : 1)>(w, j, T), 33) * MM_C1;
+  if constexpr (L::T1 > 0) h1 ^= mm_rotl64(mm_word_product<K, RC, 1, 16 * L::NB, (L::T1 > 0 ? L::T1 : 1)>(w, j, T), 31) * MM_C2;
+  h1 ^= (uint64_t)K; h2 ^= (uint64_t)K;
+  h1 += h2; h2 += h1;
+  h1 = mm_fmix64(h1); h2 = mm_fmix64(h2);
+  return h1 + h2;
+}
+
 template <int K, class Use>
 __device__ __forceinline__ void mm_strip_hashes(uint32_t w0, uint32_t w1, uint32_t w2, const MMProdTables& T, Use&& use) {
-  static_assert(MMFastK<K>::value, "product tables need exactly one 16-byte block and a tail of 1..3 bases");
-  constexpr int TAIL = K - 16;
+  static_assert(K >= 16 && K <= 32, "product tables need at least one 16-byte block");
   const uint32_t w[3] = {w0, w1, w2};
-  uint32_t a[32];                                   // a[p]: table offset of the 4-base group starting at base p (unused ones fold away)
+  if constexpr (MMFastK<K>::value) {
+    constexpr int TAIL = K - 16;
+    uint32_t a[32];                                 // a[p]: table offset of the 4-base group starting at base p (unused ones fold away)
 #pragma unroll
-  for (int p = 0; p < 31; p++) a[p] = mm_win_off8<4>(w, p);
+    for (int p = 0; p < 31; p++) a[p] = mm_win_off8<4>(w, p);
 #pragma unroll
-  for (int j = 0; j < 16; j++) {
-    uint64_t f1 = mm_lds64(T.pf1, a[j]), f2 = mm_lds64(T.pf2, a[j + 8]);
-    f1 += (uint64_t)mm_lds32(T.pf1, a[j + 4]) << 32; f2 += (uint64_t)mm_lds32(T.pf2, a[j + 12]) << 32;
-    // reverse complement of k-mer j: byte i = comp(base j+K-1-i), so its 4-byte groups are the windows at j+K-4, j+K-8, ...
-    uint64_t r1 = mm_lds64(T.pr1, a[j + K - 4]), r2 = mm_lds64(T.pr2, a[j + K - 12]);
-    r1 += (uint64_t)mm_lds32(T.pr1, a[j + K - 8]) << 32; r2 += (uint64_t)mm_lds32(T.pr2, a[j + K - 16]) << 32;
-    const uint64_t tf = mm_lds64(T.tailF, mm_win_off8<TAIL>(w, j + 16)), tr = mm_lds64(T.tailR, mm_win_off8<TAIL>(w, j));
-    use(j, mm_murmur_from_products<K>(f1, f2, tf), mm_murmur_from_products<K>(r1, r2, tr));
+    for (int j = 0; j < 16; j++) {
+      uint64_t f1 = mm_lds64(T.pf1, a[j]), f2 = mm_lds64(T.pf2, a[j + 8]);
+      f1 += (uint64_t)mm_lds32(T.pf1, a[j + 4]) << 32; f2 += (uint64_t)mm_lds32(T.pf2, a[j + 12]) << 32;
+      // reverse complement of k-mer j: byte i = comp(base j+K-1-i), so its 4-byte groups are the windows at j+K-4, j+K-8, ...
+      uint64_t r1 = mm_lds64(T.pr1, a[j + K - 4]), r2 = mm_lds64(T.pr2, a[j + K - 12]);
+      r1 += (uint64_t)mm_lds32(T.pr1, a[j + K - 8]) << 32; r2 += (uint64_t)mm_lds32(T.pr2, a[j + K - 16]) << 32;
+      const uint64_t tf = mm_lds64(T.tailF, mm_win_off8<TAIL>(w, j + 16)), tr = mm_lds64(T.tailR, mm_win_off8<TAIL>(w, j));
+      use(j, mm_murmur_from_products<K>(f1, f2, tf), mm_murmur_from_products<K>(r1, r2, tr));
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 16; j++) use(j, mm_murmur_prod_general<K, false>(w, j, T), mm_murmur_prod_general<K, true>(w, j, T));
   }
 }
 
 // table type of the strip hasher for a given K
-template <int K, bool FAST = MMFastK<K>::value> struct MMTabsFor { using type = MMTables; };
+template <int K, bool FAST = (K >= 16 && K <= 32)> struct MMTabsFor { using type = MMTables; };
 template <int K> struct MMTabsFor<K, true> { using type = MMProdTables; };

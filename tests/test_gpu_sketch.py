@@ -68,7 +68,11 @@ def test_sketch_adversarial(oracle):
     _check(oracle, reads)
 
 
-@pytest.mark.parametrize("k,s,L", [(16, 60, 1000), (19, 498, 5000), (19, 40, 10000), (15, 200, 3000), (21, 130, 5000), (32, 100, 2500), (11, 30, 500)])
+# every k-mer size the kernels are compiled for beyond the default: the word layout of the hash (blocks, 8-byte and shorter tail
+# words, the one group shorter than 4 bases) differs for each of them
+@pytest.mark.parametrize("k,s,L", [(16, 60, 1000), (19, 498, 5000), (19, 40, 10000), (15, 200, 3000), (21, 130, 5000), (32, 100, 2500), (11, 30, 500),
+                                   (17, 70, 1200), (18, 90, 2000), (20, 80, 2000), (22, 64, 1500), (23, 75, 2500), (24, 100, 4000), (25, 50, 1000),
+                                   (27, 130, 5000), (29, 40, 800), (31, 100, 3000), (12, 25, 600), (13, 40, 900), (14, 33, 700)])
 def test_sketch_parameter_grid(oracle, k, s, L):
     g = U.random_dna(11, 200000)
     reads = [a for _, a, _ in U.sample_reads([g], 5 + k, 12, 2 * L + 123, 0.08)]
