@@ -1,20 +1,28 @@
 #!/usr/bin/env python3
 """bench.py -- query Gbp/s of the sketch + L1/L2 hot path on N MI355X (one process per GPU).
 
-Workload (BASELINE.json configs[1]): 10 kbp ONT-error reads vs a 100 Mbp synthetic reference,
-pi = 85, segLength 5000, k = 19, sketchSize 130 (pinned: it is what the reference derives for this
-reference size).  Weak scaling: every GPU gets `--reads` reads (default 1 M) of its own.
+  python bench.py --gpus N --steps K --warmup W [--workload configs1|configs3|configs4]
 
-A "step" = one pass of the hot path (sketch -> seed lookup -> L1 sweep -> L2 slide) over the resident
-batch; inputs (2-bit packed bases + N mask) are already in HBM when the timed region starts; for N > 1
-the step ends with the all-gatherv (RCCL) of the L2 locus records.
+With N > 1 and no torch.distributed environment the script starts its own N ranks (torch.distributed.run, 127.0.0.1); started by
+a launcher it checks that WORLD_SIZE == N.  It never prints an `n_gpus` other than the N it was asked for.
 
-  python bench.py --gpus N --steps K --warmup W
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+A "step" = one pass of the hot path (sketch -> seed lookup -> L1 -> L2 slide -> doL2Mapping's best-first selection) over the
+resident batch; inputs (2-bit packed bases + N mask) are already in HBM when the timed region starts.  For N > 1 every rank maps
+its own reads (weak scaling: `reads` per GPU, index replicated) and the step ends with the RCCL all-gatherv of the candidate
+mappings (mm_allgatherv_mappings, mashmap_amd/csrc/mm_comm.hip) -- the product's own exchange step, not a Python stand-in.
+
+Workloads (BASELINE.json `configs`; the default is configs[1], the configuration the metric is quoted on):
+  configs1  1 M x 10 kbp reads (10 % ONT-like error) vs 100 Mbp, pi 85, segLength 5000, sketchSize 130
+  configs3  per-GPU share of configs[3]: 1.25 M x 15 kbp reads vs 3 Gbp (24 x 125 Mbp), sketchSize 310 (the stock binary's value:
+            its int32 referenceSize overflows for a 3 GB file; 220 mathematically -- SURVEY App. C)
+  configs4  per-GPU share of configs[4]: 625 k x 20 kbp reads at 15-20 % error vs 10 x 300 Mbp (the --rl list shares one seqId
+            space, winSketch.hpp:174-214), --dense --pi 80 => sketchSize 498
+--reads / --ref-contigs / --ref-contig-len scale a workload down; the JSON line names what actually ran.
 """
 import argparse
 import json
 import os
+import socket
 import subprocess
 import sys
 import tempfile
@@ -25,10 +33,20 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-K, SEG, SKETCH, PI = 19, 5000, 130, 0.85
-READ_LEN, ERR = 10000, 0.10
-REF_CONTIGS, REF_CONTIG_LEN = 10, 10_000_000
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
+SIMDS, CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs, max clock (MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    "configs1": dict(label="configs[1]", k=19, seg=5000, sketch=130, pi=0.85, read_len=10000, err=(0.10, 0.10), reads=1_000_000,
+                     ref_contigs=10, ref_contig_len=10_000_000,
+                     sketch_note="130 = recommendedSketchSize for a 100 Mbp reference file (SURVEY App. C)"),
+    "configs3": dict(label="configs[3] (per-GPU share of 10 M reads / 8 GPUs)", k=19, seg=5000, sketch=310, pi=0.85, read_len=15000,
+                     err=(0.10, 0.10), reads=1_250_000, ref_contigs=24, ref_contig_len=125_000_000,
+                     sketch_note="310 = what the stock binary derives for a 3 GB reference file (int32 referenceSize overflow); 220 mathematically (SURVEY App. C)"),
+    "configs4": dict(label="configs[4] (per-GPU share of 5 M reads / 8 GPUs)", k=19, seg=5000, sketch=498, pi=0.80, read_len=20000,
+                     err=(0.15, 0.20), reads=625_000, ref_contigs=10, ref_contig_len=300_000_000,
+                     sketch_note="498 = --dense at pi 80: 0.02 (1 + 0.2 / 0.05) (5000 - 19) (parseCmdArgs.hpp:620-641); the 10 --rl files are 10 contigs of one index"),
+}
 
 
 def log(*a):
@@ -38,11 +56,17 @@ def log(*a):
 def make_reference(torch, dev, ncontigs, clen, seed=1):
     g = torch.Generator(device=dev); g.manual_seed(seed)
     lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
-    return [lut[torch.randint(0, 4, (clen,), generator=g, device=dev)] for _ in range(ncontigs)]
+    out = []
+    for _ in range(ncontigs):
+        out.append(lut[torch.randint(0, 4, (clen,), generator=g, device=dev, dtype=torch.int32).long()] if clen <= (1 << 27)
+                   else torch.cat([lut[torch.randint(0, 4, (min(1 << 27, clen - o),), generator=g, device=dev, dtype=torch.int32).long()]
+                                   for o in range(0, clen, 1 << 27)]))
+    return out
 
 
-def make_reads(torch, dev, contigs, nreads, read_len, err, seed, chunk=16384):
-    """ONT-like reads on the device: uniform start/strand, i.i.d. err/3 sub + err/3 ins + err/3 del."""
+def make_reads(torch, dev, contigs, nreads, read_len, err, seed, chunk=8192):
+    """ONT-like reads on the device: uniform start/strand, i.i.d. e/3 sub + e/3 ins + e/3 del with the read's error rate e drawn
+    uniformly from err = (lo, hi)."""
     g = torch.Generator(device=dev); g.manual_seed(seed)
     ref = torch.cat(contigs)
     coff = torch.tensor(np.cumsum([0] + [len(c) for c in contigs[:-1]]), device=dev)
@@ -51,7 +75,7 @@ def make_reads(torch, dev, contigs, nreads, read_len, err, seed, chunk=16384):
     comp = torch.zeros(256, dtype=torch.uint8, device=dev)
     for a, b in zip(b"ACGT", b"TGCA"):
         comp[a] = b
-    src_len = int(read_len * (1 + err)) + 200
+    src_len = int(read_len * (1 + err[1])) + 300
     out = torch.empty(nreads * read_len, dtype=torch.uint8, device=dev)
     ar = torch.arange(src_len, device=dev)
     for r0 in range(0, nreads, chunk):
@@ -59,13 +83,14 @@ def make_reads(torch, dev, contigs, nreads, read_len, err, seed, chunk=16384):
         ci = torch.randint(0, len(contigs), (R,), generator=g, device=dev)
         st = (torch.rand(R, generator=g, device=dev, dtype=torch.float64) * (clen[ci] - src_len).double()).long()
         rev = torch.rand(R, generator=g, device=dev) < 0.5
+        e = (err[0] + (err[1] - err[0]) * torch.rand(R, generator=g, device=dev))[:, None]
         seg = ref[(coff[ci] + st)[:, None] + ar[None, :]]
         seg = torch.where(rev[:, None], comp[seg.flip(1).long()], seg)
         u = torch.rand(R, src_len, generator=g, device=dev)
         rb = lut[torch.randint(0, 4, (R, src_len), generator=g, device=dev)]
-        is_sub = u < err / 3
-        is_ins = (u >= err / 3) & (u < 2 * err / 3)
-        is_del = (u >= 2 * err / 3) & (u < err)
+        is_sub = u < e / 3
+        is_ins = (u >= e / 3) & (u < 2 * e / 3)
+        is_del = (u >= 2 * e / 3) & (u < e)
         cnt = (~is_del).int() + is_ins.int()
         pos = torch.cumsum(cnt, dim=1) - cnt                     # output slot of the (possibly inserted) first symbol
         base = torch.where(is_sub & (rb != seg), rb, seg)
@@ -93,13 +118,15 @@ def write_fasta(path, names, arrays, width=100):
                 f.write(a[full:].tobytes() + b"\n")
 
 
-def cpu_baseline(ref_np, reads_np, n_sample, read_len):
-    """the reference's own CPU path (oracle/_ref/mashmap_ref, built from /root/reference with the GSL stand-in) or,
-    if that binary did not travel, our CPU port (oracle/liboracle.so); timed on this box's host cores."""
+def cpu_baseline(W, ref_np, reads_np, n_sample):
+    """the reference's own CPU path (oracle/_ref/mashmap_ref, built from /root/reference with the GSL stand-in) or, if that binary
+    did not travel, our CPU port (oracle/liboracle.so); timed on this box's host cores on a bounded sample of the same workload."""
     ncores = os.cpu_count() or 1
+    read_len = W["read_len"]
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "mashmap_ref")
+    prof_bin = os.path.join(ROOT, "oracle", "_ref", "mashmap_ref_prof")
     sample = reads_np[:n_sample * read_len].reshape(n_sample, read_len)
-    desc = "%d of the benchmark reads (%.0f Mbp) vs the same 100 Mbp reference" % (n_sample, n_sample * read_len / 1e6)
+    desc = "%d of the benchmark reads (%.0f Mbp) vs the same %.0f Mbp reference" % (n_sample, n_sample * read_len / 1e6, sum(len(a) for a in ref_np) / 1e6)
     if os.path.exists(ref_bin):
         with tempfile.TemporaryDirectory() as td:
             rp, qp, op = os.path.join(td, "ref.fa"), os.path.join(td, "q.fa"), os.path.join(td, "o.paf")
@@ -108,13 +135,13 @@ def cpu_baseline(ref_np, reads_np, n_sample, read_len):
             with open(qp + ".fai", "w") as f:          # avoids the reference's extra pass over the query file
                 for i in range(n_sample):
                     f.write("read%d\t%d\t0\t100\t101\n" % (i, read_len))
+            common = ["-r", rp, "-q", qp, "-o", op, "-s", str(W["seg"]), "--pi", str(int(round(W["pi"] * 100))), "-k", str(W["k"]), "-J", str(W["sketch"])]
             # the reference's pthread pool stops scaling early (one reader thread feeds it; with hundreds of threads it thrashes):
             # time a few thread counts on the same sample and report the best one
             best = None
             for nt in sorted({min(ncores, 8), min(ncores, 32), min(ncores, 64)}):
                 t0 = time.time()
-                p = subprocess.run([ref_bin, "-r", rp, "-q", qp, "-o", op, "-t", str(nt), "-s", str(SEG), "--pi", str(int(PI * 100)),
-                                    "-k", str(K), "-J", str(SKETCH)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+                p = subprocess.run([ref_bin] + common + ["-t", str(nt)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
                 wall = time.time() - t0
                 tmap = None
                 for line in p.stderr.splitlines():
@@ -124,25 +151,103 @@ def cpu_baseline(ref_np, reads_np, n_sample, read_len):
                     log("[cpu_baseline] reference binary -t %d: map %.2f s (total wall %.1f s)" % (nt, tmap, wall))
                     if best is None or tmap < best[0]:
                         best = (tmap, nt)
+            # sum of the per-fragment compute times of the -DENABLE_TIME_PROFILE_L1_L2 build (no reader, no
+            # pool overhead) / threads = the rate an ideally fed pool of that many cores would reach
+            compute = None
+            if best and os.path.exists(prof_bin):
+                p = subprocess.run([prof_bin] + common + ["-t", str(best[1])], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+                tot = 0.0; nfr = 0
+                for line in p.stderr.splitlines():
+                    f = line.split()
+                    if len(f) == 5 and f[0].isdigit() and f[1].isdigit():
+                        try:
+                            tot += float(f[4]); nfr += 1
+                        except ValueError:
+                            pass
+                if p.returncode == 0 and nfr:
+                    compute = {"fragments": nfr, "sum_fragment_seconds": round(tot, 3),
+                               "gbps_per_core": round(n_sample * read_len / tot / 1e9, 5),
+                               "gbps_all_cores_ideal": round(n_sample * read_len / tot / 1e9 * ncores, 3)}
             if best:
                 tmap, nt = best
                 return {"value": n_sample * read_len / tmap / 1e9, "unit": "Gbp/s", "cores": nt, "kind": "reference",
                         "sample": desc + "; mashmap_ref (built from the reference sources) best of -t 8/32/64 = -t %d of %d host cores, "
-                                         "'time spent mapping the query' (includes its single-threaded FASTA reader)" % (nt, ncores)}
+                                         "'time spent mapping the query' (includes its single-threaded FASTA reader)" % (nt, ncores),
+                        "fragment_compute": compute}
             log("[cpu_baseline] reference binary failed, falling back to the port:", p.stderr[-300:])
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import mmutil as U
     orc = U.Oracle()
-    h = orc.session([("chr%d" % i, a) for i, a in enumerate(ref_np[:1])], K, SEG, SKETCH, PI)
+    h = orc.session([("chr%d" % i, a) for i, a in enumerate(ref_np[:1])], W["k"], W["seg"], W["sketch"], W["pi"])
     n = min(n_sample, 200)
     t0 = time.time()
     for i in range(n):
-        for off in range(0, read_len - SEG + 1, SEG):
-            orc.map_fragment(h, sample[i, off:off + SEG], i, b"r", read_len, SKETCH)
+        for off in range(0, read_len - W["seg"] + 1, W["seg"]):
+            orc.map_fragment(h, sample[i, off:off + W["seg"]], i, b"r", read_len, W["sketch"])
     dt = time.time() - t0
     orc.free(h)
     return {"value": n * read_len / dt / 1e9 * 0.5, "unit": "Gbp/s", "cores": 1, "kind": "port",
-            "sample": "%d reads vs the first 10 Mbp contig; scalar port, diagnostic entry runs the path twice (halved)" % n}
+            "sample": "%d reads vs the first contig; scalar port, diagnostic entry runs the path twice (halved)" % n}
+
+
+def host_path(ctx, W, nreads, ref_lens, steps_ms):
+    """packed bases -> MappingResult rows: the device pass + download of the candidate mappings + the host stage of skch::Map
+    (chaining, plane-sweep filter, sanity checks; libmashmap_host.so = MapPost) on every host core."""
+    import ctypes as C
+    from mashmap_amd import capi
+    lib_path = os.path.join(ROOT, "mashmap_amd", "lib", "libmashmap_host.so")
+    if not os.path.exists(lib_path):
+        return None
+    lib = C.CDLL(lib_path)
+    lib.mmh_post_batch.restype = C.c_int64
+    lib.mmh_post_batch.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t,
+                                   C.c_void_p, C.c_size_t, C.c_int32, C.c_int, C.POINTER(C.c_double), C.c_void_p, C.c_size_t]
+    t0 = time.perf_counter()
+    recs = ctx.mappings()
+    t_dl = time.perf_counter() - t0
+    clens = np.ascontiguousarray(ref_lens, dtype=np.int32)
+    rl = np.full(nreads, W["read_len"], dtype=np.int32)
+    threads = os.cpu_count() or 1
+    best = None
+    for nt in sorted({min(threads, 32), min(threads, 64), min(threads, 128), threads}):
+        sec = C.c_double()
+        rows = lib.mmh_post_batch(W["k"], W["seg"], W["sketch"], W["pi"], 1, 1, 1, len(clens), clens.ctypes.data, recs.ctypes.data, len(recs),
+                                  rl.ctypes.data, nreads, 0, nt, C.byref(sec), None, 0)
+        if best is None or sec.value < best[0]:
+            best = (sec.value, nt, int(rows))
+    post_s, nt, rows = best
+    bases = nreads * W["read_len"]
+    dev_s = steps_ms / 1e3
+    return {"what": "packed bases -> reported MappingResult rows on one GPU + host: device pass, D2H of the candidate mappings (48 B each), "
+                    "then per read mergeMappingsInRange + filterByGroup + sanity checks (MapPost, the code skch::Map runs) on host threads",
+            "candidate_mappings": int(len(recs)), "rows": rows, "device_ms": round(dev_s * 1e3, 3), "download_ms": round(t_dl * 1e3, 3),
+            "host_ms": round(post_s * 1e3, 3), "host_threads": nt, "host_cores": threads,
+            "gbps_serial": round(bases / (dev_s + t_dl + post_s) / 1e9, 3),
+            "gbps_pipelined": round(bases / max(dev_s, t_dl + post_s) / 1e9, 3),
+            "note": "skch::Map overlaps the host stage of batch i with the device stage of batch i+1 (pipelined); serial = no overlap"}
+
+
+class StubContext:
+    """CPU stand-in used ONLY by tests/test_bench_spawn.py (--stub): lets the launcher / rank plumbing of this script run where there
+    is no GPU.  It maps nothing; a line produced with it says "data": "stub"."""
+
+    def __init__(self, rank):
+        self.rank = rank
+
+    def map(self):
+        time.sleep(0.002)
+
+    def allgatherv(self, dist):
+        import torch
+        from mashmap_amd import shard
+        mine = torch.full((3 + self.rank, shard.L2_WORDS), self.rank, dtype=torch.int32)
+        got, counts = shard.allgatherv_records(mine, dist)
+        assert got.shape[0] == sum(counts)
+
+
+def free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
 
 
 def main():
@@ -150,57 +255,111 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=int, default=int(os.environ.get("MM_BENCH_READS", 1_000_000)), help="reads per GPU")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="configs1")
+    ap.add_argument("--reads", type=int, default=int(os.environ.get("MM_BENCH_READS", 0)), help="reads per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--ref-contigs", type=int, default=REF_CONTIGS, help="contigs of the synthetic reference (default: configs[1], 10 x 10 Mbp)")
-    ap.add_argument("--ref-contig-len", type=int, default=REF_CONTIG_LEN)
-    ap.add_argument("--kmer", type=int, default=K, help="k-mer size (default: the reference's 19; other sizes are not the BASELINE configuration)")
+    ap.add_argument("--no-host-path", action="store_true")
+    ap.add_argument("--ref-contigs", type=int, default=0, help="contigs of the synthetic reference (default: the workload's)")
+    ap.add_argument("--ref-contig-len", type=int, default=0)
+    ap.add_argument("--kmer", type=int, default=0, help="k-mer size (default: the reference's 19; other sizes are not the BASELINE configuration)")
     ap.add_argument("--cpu-sample", type=int, default=30000)
+    ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
-    from mashmap_amd import capi
-
+    # ---- N ranks: start them ourselves unless a launcher already did
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        log("[bench] starting %d ranks: %s" % (args.gpus, " ".join(cmd[2:9])))
+        raise SystemExit(subprocess.run(cmd).returncode)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks; refusing to report a number for a different GPU count" % (args.gpus, world))
+
+    import torch
+    import torch.distributed as dist
+    W = dict(WORKLOADS[args.workload])
+    scaled = []
+    if args.reads: W["reads"] = args.reads; scaled.append("reads")
+    if args.ref_contigs: W["ref_contigs"] = args.ref_contigs; scaled.append("ref-contigs")
+    if args.ref_contig_len: W["ref_contig_len"] = args.ref_contig_len; scaled.append("ref-contig-len")
+    if args.kmer: W["k"] = args.kmer; scaled.append("kmer")
+    is_default = args.workload == "configs1" and not scaled
+
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("gloo" if args.stub else "nccl", rank=rank, world_size=world)
+
+    if args.stub:
+        ctx = StubContext(rank)
+        for _ in range(args.warmup):
+            ctx.map(); world > 1 and ctx.allgatherv(dist)
+        if world > 1: dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            ctx.map(); world > 1 and ctx.allgatherv(dist)
+        if world > 1: dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tm = torch.tensor([dt], dtype=torch.float64); dist.all_reduce(tm, op=dist.ReduceOp.MAX); dt = float(tm.item())
+        if rank == 0:
+            print(json.dumps({"metric": "query Gbp/s sketch+L1/L2 map (pi=85, s=5000)", "value": 0.0, "unit": "Gbp/s", "n_gpus": world, "steps": args.steps,
+                              "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+                              "vs_baseline": None, "dtype": "u64", "data": "stub", "config": {"workload": "STUB: no kernels ran (launcher test)"}}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    from mashmap_amd import capi
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if torch.cuda.device_count() < world:
+        raise SystemExit("bench.py: --gpus %d but only %d GPU(s) are visible" % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    K, SEG, SKETCH, PI, READ_LEN = W["k"], W["seg"], W["sketch"], W["pi"], W["read_len"]
+    nreads = W["reads"]
 
     t0 = time.time()
-    contigs = make_reference(torch, dev, args.ref_contigs, args.ref_contig_len)
+    contigs = make_reference(torch, dev, W["ref_contigs"], W["ref_contig_len"])
     ref_np = [c.cpu().numpy() for c in contigs]
-    reads_t = make_reads(torch, dev, contigs, args.reads, READ_LEN, ERR, seed=1000 + rank)
+    reads_t = make_reads(torch, dev, contigs, nreads, READ_LEN, W["err"], seed=1000 + rank)
     torch.cuda.synchronize()
     log("[rank %d] synthetic data: %.1f s" % (rank, time.time() - t0))
-
-    ctx = capi.Context(k=args.kmer, segLength=SEG, sketchSize=SKETCH, flags=capi.MM_FLAG_HG_FILTER, device=local)
-    t0 = time.time()
-    ctx.index_build(ref_np, kmerPct=0.001)
-    ctx.set_tables_default(PI)
-    log("[rank %d] index build (device hash + winnow, host stitch + lookup map): %.1f s" % (rank, time.time() - t0))
-    offs = np.arange(args.reads + 1, dtype=np.int64) * READ_LEN
-    nF = ctx.reads_upload_device(reads_t.data_ptr(), reads_t.numel(), offs)
-    reads_np = reads_t[:min(args.reads, args.cpu_sample) * READ_LEN].cpu().numpy() if rank == 0 else None
-    del reads_t, contigs
+    del contigs
     torch.cuda.empty_cache()
 
-    from mashmap_amd import shard
+    ctx = capi.Context(k=K, segLength=SEG, sketchSize=SKETCH, flags=capi.MM_FLAG_HG_FILTER, device=local)
+    t0 = time.time()
+    ctx.index_build(ref_np, kmerPct=0.001)
+    index_s = time.time() - t0
+    t0 = time.time()
+    ctx.set_tables_default(PI)
+    log("[rank %d] index build: %.1f s; integer tables: %.2f s" % (rank, index_s, time.time() - t0))
+    offs = np.arange(nreads + 1, dtype=np.int64) * READ_LEN
+    nF = ctx.reads_upload_device(reads_t.data_ptr(), reads_t.numel(), offs, seqCounterBase=rank * nreads)
+    # the CPU leg indexes the reference with the stock binary: minutes beyond a few hundred Mbp, so it rides on the default workload only
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline and sum(len(a) for a in ref_np) <= 400e6
+    reads_np = reads_t[:min(nreads, args.cpu_sample) * READ_LEN].cpu().numpy() if want_cpu else None
+    ref_lens = [len(a) for a in ref_np]
+    if not want_cpu:
+        ref_np = None
+    del reads_t
+    torch.cuda.empty_cache()
+
+    if world > 1:                                       # the product's RCCL communicator: the id travels through torch's store
+        box = [capi.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        ctx.comm_init_rank(box[0], rank, world)
 
     def step():
         ctx.map()
-        if world > 1:                                   # all-gatherv of the L2 locus records over RCCL/xGMI (mashmap_amd/shard.py)
-            n1, n2 = ctx.result_counts()
-            mine = torch.empty((n2, shard.L2_WORDS), dtype=torch.int32, device=dev)
-            ctx.results_copy_device(mine.data_ptr(), n2)
-            shard.allgatherv_records(mine, dist, device=dev)
-            torch.cuda.current_stream().synchronize()   # the gather is part of the step; `mine` is rewritten from the library's stream next step
+        if world > 1:
+            ctx.allgatherv_mappings()                   # all-gatherv of the candidate mappings over RCCL/xGMI, on the library's stream
 
     def fence():
         if world > 1:
@@ -224,54 +383,83 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     n1, n2 = ctx.result_counts()
-    stats, _, _ = ctx.results() if rank == 0 else (None, None, None)
 
     if rank == 0:
-        bases_step = args.reads * READ_LEN * world
+        stats, _, _ = ctx.results()
+        nmap = len(ctx.mappings())
+        bases_step = nreads * READ_LEN * world
         value = bases_step * args.steps / dt / 1e9
+        step_ms = dt / args.steps * 1e3
         # roofline of the dominant kernel (k_sketch_fragments): algorithmic bytes per fragment = L/4 packed bases in
         # + 24 B per sketch entry out, divided by its average HIP-event duration in the timed region
         sk_ms, sk_n = prof["sketch"]
+        sk_avg = sk_ms / max(1, sk_n)
         frag_bytes = SEG / 4.0 + 24.0 * SKETCH
-        ach = frag_bytes * nF / (sk_ms / max(1, sk_n) / 1e3) / 1e9 if sk_ms > 0 else 0.0
-        # HBM bytes per launch of that kernel from the committed PMC passes (scripts/gpu_round.sh -> scripts/pmc_to_json.py);
-        # only meaningful for the default workload the passes were taken on
+        ach = frag_bytes * nF / (sk_avg / 1e3) / 1e9 if sk_ms > 0 else 0.0
+        # integer roofline: the same fragments through a kernel that only hashes (2 x MurmurHash3_x64_128 per base)
+        integer = None
+        try:
+            hms = ctx.bench_hash_only(3)
+            integer = {"hash_only_ms": round(hms, 3), "hash_only_gbps": round(nF * SEG / hms / 1e6, 2),
+                       "sketch_kernel_frac": round(hms / sk_avg, 4) if sk_avg > 0 else None, "step_frac": round(hms / step_ms, 4),
+                       "note": "k_hash_only: same decomposition, staging and tables as k_sketch_fragments, nothing but the two hashes per position; "
+                               "frac = its time / the kernel's (step's) time = share of the integer floor reached"}
+        except capi.MashmapError as e:
+            log("[bench] hash-only microbenchmark unavailable:", e)
+        # HBM bytes / VALU instructions per launch of that kernel from the committed PMC passes; only meaningful for the workload
+        # the passes were taken on (profiles/pmc_traffic.json names it)
         traffic = None
-        valu_per_launch = None
+        valu = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc) and args.reads == 1_000_000 and (args.ref_contigs, args.ref_contig_len, args.kmer) == (REF_CONTIGS, REF_CONTIG_LEN, K):
+        if os.path.exists(pmc) and is_default:
             try:
                 ent = json.load(open(pmc)).get("k_sketch_fragments", {})
                 traffic = ent.get("hbm_bytes_per_launch")
-                valu_per_launch = ent.get("SQ_INSTS_VALU")
+                ninst = ent.get("SQ_INSTS_VALU")
+                if ninst and sk_avg > 0:
+                    per_s = ninst / (sk_avg * 1e-3)
+                    mix = 3.4                           # cycles per wave-instruction of this kernel's VOP3/VOP2 mix (profiles/r02_valu_rate.txt)
+                    valu = {"wave_instructions_per_launch": ninst,
+                            "util_vs_2_cycles_per_instr": round(per_s / (SIMDS * CLOCK_HZ / 2.0), 3),
+                            "util_vs_measured_mix": round(per_s / (SIMDS * CLOCK_HZ / mix), 3),
+                            "util_vs_4_cycles_per_instr": round(per_s / (SIMDS * CLOCK_HZ / 4.0), 3),
+                            "model": "1024 SIMDs x 2.4 GHz; three issue peaks: 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md nominal, SIMD-32), "
+                                     "%.1f cycles (this kernel's mix of VOP3 integer ops at ~4.2 and VOP2 ops at ~2.3 cycles measured by "
+                                     "scripts/probes/valu_rate.hip, output in profiles/), 4 cycles (every instruction at the VOP3 rate)" % mix}
             except Exception:
                 traffic = None
         kernels = {k: {"ms_per_step": v[0] / args.steps, "launches_per_step": v[1] / args.steps} for k, v in prof.items() if v[1]}
-        P = float(stats["nPoints"].mean()); S = float(stats["sketchSize"].mean())
+        P = float(stats["nPoints"].mean())
+        ref_mbp = sum(ref_lens) / 1e6
         out = {
             "metric": "query Gbp/s sketch+L1/L2 map (pi=85, s=5000)", "value": round(value, 4), "unit": "Gbp/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "configs[1]: %d x %d bp reads/GPU (%.0f%% ONT-like error) vs %.0f Mbp synthetic reference (%d contigs)"
-                                   % (args.reads, READ_LEN, ERR * 100, args.ref_contigs * args.ref_contig_len / 1e6, args.ref_contigs), "k": args.kmer, "segLength": SEG, "sketchSize": SKETCH,
-                       "percentageIdentity": PI, "fragments_per_gpu": nF, "parallelism": "reads sharded, index replicated, RCCL all-gatherv of L2 loci"
+            "config": {"workload": "%s%s: %d x %d bp reads/GPU (%s ONT-like error) vs %.0f Mbp synthetic reference (%d contigs)"
+                                   % (W["label"], " SCALED (%s)" % ", ".join(scaled) if scaled else "", nreads, READ_LEN,
+                                      "%.0f%%" % (W["err"][0] * 100) if W["err"][0] == W["err"][1] else "%.0f-%.0f%%" % (W["err"][0] * 100, W["err"][1] * 100),
+                                      ref_mbp, len(ref_lens)),
+                       "k": K, "segLength": SEG, "sketchSize": SKETCH, "sketchSize_note": W["sketch_note"],
+                       "percentageIdentity": PI, "fragments_per_gpu": nF,
+                       "parallelism": "reads sharded, index replicated, RCCL all-gatherv of candidate mappings (libmashmap_hip: mm_allgatherv_mappings)"
                        if world > 1 else "single GPU", "mean_interval_points_per_fragment": round(P, 1),
-                       "l1_candidates_per_gpu": n1, "l2_loci_per_gpu": n2},
+                       "l1_candidates_per_gpu": n1, "l2_loci_per_gpu": n2, "candidate_mappings_per_gpu": nmap,
+                       "index_build_s": round(index_s, 2),
+                       "identity_tables": "minimumHits / sketchCutoffs / acceptance from mm_stats.hpp's re-derivation of GSL's binomial and hypergeometric "
+                                          "CDFs (GSL is not in the image; SURVEY section 8c: the one unpinned boundary)"},
             "roofline": {"bound": "hbm", "kernel": "k_sketch_fragments", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "algorithmic_bytes_per_fragment": frag_bytes, "avg_launch_ms": round(sk_ms / max(1, sk_n), 3),
+                         "algorithmic_bytes_per_fragment": frag_bytes, "avg_launch_ms": round(sk_avg, 3),
                          "algorithmic_bytes_per_launch": frag_bytes * nF,
-                         "note": "VALU-issue bound kernel (2 x MurmurHash3_x64_128 per base = ~150 VALU instructions per k-mer position); "
-                                 "the HBM fraction is small by construction -- DESIGN.md section 3 gives the integer roofline",
-                         "valu": None if not valu_per_launch or sk_ms <= 0 else {
-                             "wave_instructions_per_launch": valu_per_launch,
-                             "issue_utilisation": round(valu_per_launch * 4.0 / (sk_ms / max(1, sk_n) * 1e-3 * 2.4e9 * 1024), 3),
-                             "model": "1024 SIMDs x 2.4 GHz, 4 cycles per wave64 VALU instruction (measured with scripts/probes/valu_rate.hip: "
-                                      "4.2 cycles for the VOP3 integer ops incl. 32-bit multiplies, 2.3 for simple VOP2 add/xor/shift/mov)"}},
+                         "note": "integer-issue bound kernel (2 x MurmurHash3_x64_128 per base); the HBM fraction is small by construction -- "
+                                 "`int` (hash-only yardstick) and `valu` (issue peaks) are the rooflines that bind, DESIGN.md section 3",
+                         "int": integer, "valu": valu},
             "kernels": kernels,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(ref_np, reads_np, min(args.cpu_sample, args.reads), READ_LEN)
+        if world == 1 and not args.no_host_path:
+            out["host_path"] = host_path(ctx, W, nreads, ref_lens, step_ms)
+        if want_cpu:
+            out["cpu_baseline"] = cpu_baseline(W, ref_np, reads_np, min(args.cpu_sample, nreads))
         print(json.dumps(out), flush=True)
     ctx.close()
     if world > 1:

@@ -38,13 +38,14 @@ enum {
   MM_FLAG_SKIP_SELF = 2,        /* skip_self              (parseCmdArgs.hpp:341) */
   MM_FLAG_SKIP_PREFIX = 4,      /* skip_prefix            (parseCmdArgs.hpp:349) */
   MM_FLAG_LOWER_TRIANGULAR = 8, /* lower_triangular       (parseCmdArgs.hpp:334) */
-  MM_FLAG_NO_SPLIT = 16         /* !split                 (parseCmdArgs.hpp:427) */
+  MM_FLAG_NO_SPLIT = 16         /* !split                 (parseCmdArgs.hpp:427); reads longer than segLength are then refused by
+                                   mm_reads_upload (windowLen != 0, computeMap.hpp:933, is not built) */
 };
 
 typedef struct {
   int32_t kmerSize;       /* Parameters::kmerSize   (1..32) */
   int32_t segLength;      /* Parameters::segLength  */
-  int32_t sketchSize;     /* Parameters::sketchSize (1..1024) */
+  int32_t sketchSize;     /* Parameters::sketchSize (1..1279: the L2 state of 64 candidates must fit one CU's LDS; mm_create checks) */
   int32_t flags;          /* MM_FLAG_* */
 } mm_params;
 
@@ -72,11 +73,30 @@ typedef struct {
 
 /* Map::L1_candidateLocus_t (computeMap.hpp:58) + owning fragment */
 typedef struct { int32_t frag; int32_t seqId, rangeStartPos, rangeEndPos, intersectionSize; } mm_l1_candidate;
-/* Map::L2_mapLocus_t (computeMap.hpp:76) + owning fragment / candidate (index into the L1 array) */
+/* Map::L2_mapLocus_t (computeMap.hpp:76) + owning fragment / candidate.  `cand` as returned by mm_results_download is the index
+ * into the L1 array downloaded with it.  In the DEVICE-resident records (mm_results_device / mm_results_copy_device) `cand` is the
+ * candidate's rank among the candidates of its own fragment (0 .. stats[frag].nL1-1), and records are grouped by candidate but
+ * not sorted by fragment. */
 typedef struct {
   int32_t frag, cand;
   int32_t seqId, meanOptimalPos, optimalStart, optimalEnd, sharedSketchSize, strand;
 } mm_l2_locus;
+
+/*
+ * A candidate mapping: one L2 locus that doL2Mapping reports for a fragment (computeMap.hpp:1221-1250), in integers.  The floats of
+ * MappingResult (base_types.hpp:154) are functions of these: nucIdentity / nucIdentityUpperBound of (conservedSketches, sketchSize, k)
+ * (map_stats.hpp:45,81), kmerComplexity of (rawSketchSize, maxHash, fragLen, k) (computeMap.hpp:830-831).  This is the record the
+ * host side chains and filters, and the record multi-GPU runs exchange (mm_allgatherv_mappings).  48 bytes.
+ */
+typedef struct {
+  int32_t querySeqId;          /* MappingResult::querySeqId == seqCounterBase + index of the read in the batch */
+  int32_t fragStart, fragLen;  /* offset of the fragment in the read (queryStartPos after :632-636), Q.len */
+  int32_t refSeqId, refStartPos;          /* L2_mapLocus_t::seqId, meanOptimalPos */
+  int32_t conservedSketches, sketchSize;  /* sharedSketchSize, Q.sketchSize */
+  int32_t strand;
+  int32_t rawSketchSize, pad_;
+  uint64_t maxHash;
+} mm_mapping;
 
 typedef struct mm_ctx mm_ctx;
 
@@ -111,7 +131,19 @@ int mm_index_upload(mm_ctx* ctx,
  */
 int mm_set_tables(mm_ctx* ctx, const int32_t* minHits, size_t nMinHits, const int32_t* sketchCutoffs, size_t nCutoffs);
 
-/* same tables computed inside the library (mashmap_amd/host/mm_stats.hpp mirrors skch::Stat and Map::setProbs) and uploaded */
+/*
+ * Integer tables for the best-first walk of doL2Mapping (computeMap.hpp:1182-1267) on the device, stride = sketchSize + 1:
+ *   accept[Qs*stride + shared] = 1 iff a locus sharing `shared` of Qs sketch elements is reported  (:1221: identity or, with
+ *                                keep_low_pct_id, its upper bound reaches percentageIdentity)
+ *   minIsz[Qs*stride + best]   = smallest L1 intersectionSize that passes the ANI cut-off (:1192-1202) when the best reported
+ *                                locus so far shares `best` elements
+ * (mashmap_amd/host/mm_stats.hpp: mmhost::replayTables fills them with the reference's own float expressions.)  Without them
+ * mm_map_fragments stops at the L2 loci and the mm_mappings_* calls fail with MM_ERR_STATE.
+ */
+int mm_set_replay_tables(mm_ctx* ctx, const uint8_t* accept, const int16_t* minIsz, size_t stride);
+
+/* all three tables computed inside the library (mashmap_amd/host/mm_stats.hpp mirrors skch::Stat and Map::setProbs) with the
+ * reference's defaults (ANIDiff 0, ANIDiffConf 0.999, keep_low_pct_id on) and uploaded */
 int mm_set_tables_default(mm_ctx* ctx, float percentageIdentity);
 
 /*
@@ -126,6 +158,8 @@ float   mm_stat_md_lower_bound(float d, int s, int k, float ci);
 int     mm_stat_min_hits_relaxed(int s, int k, float percentageIdentity);
 int64_t mm_stat_recommended_sketch_size(int k, float percentageIdentity, int64_t segLength, uint64_t referenceSize);
 int     mm_stat_sketch_cutoffs(int sketchSize, int k, int hgFilter, int32_t* out, size_t cap);   /* returns entries written */
+/* the tables of mm_set_replay_tables, (sketchSize+1)^2 entries each, from the reference's own float expressions (computeMap.hpp:1192-1222) */
+int     mm_stat_replay_tables(int sketchSize, int k, float percentageIdentity, float ANIDiff, int keepLowPctId, uint8_t* accept, int16_t* minIsz);
 
 /*
  * A batch of query reads -> device.  Replaces the `char* seq` handed to sketchSequence
@@ -161,6 +195,14 @@ int mm_map_fragments(mm_ctx* ctx);
 int mm_result_counts(const mm_ctx* ctx, size_t* nL1, size_t* nL2);
 /* any pointer may be NULL.  l1/l2 are sorted by (frag, emission order of the reference) */
 int mm_results_download(mm_ctx* ctx, mm_frag_stats* stats, mm_l1_candidate* l1, mm_l2_locus* l2);
+/*
+ * The candidate mappings of the batch (needs the replay tables): what mapSingleQueryFrag leaves in l2Mappings for every fragment
+ * before its final std::sort (computeMap.hpp:774-800), fragment-major, inside a fragment in doL2Mapping's push order.
+ */
+int mm_mappings_count(const mm_ctx* ctx, size_t* n);
+int mm_mappings_download(mm_ctx* ctx, mm_mapping* out, size_t cap, size_t* n);
+/* device address of the same records; valid until the next map call */
+int mm_mappings_device(const mm_ctx* ctx, const mm_mapping** dMappings, size_t* n);
 /* post-removal sketches Q.minmerTableQuery: out[f*sketchSize + r] (valid r < stats[f].sketchSize) */
 int mm_query_sketch_download(mm_ctx* ctx, mm_minmer* out);
 /*
@@ -203,12 +245,39 @@ int mm_index_upload_full(mm_ctx* ctx, const mm_minmer* minmersAll, size_t nMinme
                          size_t nKeys, const mm_interval_point* points, size_t nPoints, const int32_t* contigLen,
                          const int32_t* refGroup, size_t nContigs, float kmerPctThreshold);
 
+/*
+ * Multi-GPU: reads are sharded over GPUs in contiguous blocks, the index is replicated, and the one exchange
+ * step is an all-gatherv of the candidate mappings over RCCL / xGMI -- what a multi-GPU skch::Map needs before the one-to-one
+ * filter (computeMap.hpp:358-405) and to write one output stream in input order.  One mm_ctx per GPU.
+ *   one process per GPU:  rank 0 calls mm_comm_unique_id and ships the MM_COMM_ID_BYTES to the others (MPI, a file, torch.distributed's
+ *                         store ...); every rank calls mm_comm_init_rank; after each mm_map_fragments every rank calls mm_allgatherv_mappings.
+ *   one process, n GPUs:  mm_comm_init_local(ctxs, n), then mm_allgatherv_mappings_local(ctxs, n) after all n contexts have mapped their
+ *                         batch (contexts that share a device exchange by device copies: RCCL wants distinct GPUs).
+ * Afterwards every context holds all ranks' records, rank-major (= input order with contiguous read blocks): mm_gathered_*.
+ * mm_index_replicate copies a resident index GPU to GPU (xGMI) instead of building it once per GPU; the replica serves
+ * mm_map_fragments but not the mm_index_download calls (the host mirrors stay with the source context).
+ */
+#define MM_COMM_ID_BYTES 128
+int mm_comm_unique_id(void* id);
+int mm_comm_init_rank(mm_ctx* ctx, const void* id, int rank, int world);
+int mm_comm_init_local(mm_ctx** ctxs, int n);
+int mm_comm_world(const mm_ctx* ctx, int* rank, int* world);
+int mm_allgatherv_mappings(mm_ctx* ctx);
+int mm_allgatherv_mappings_local(mm_ctx** ctxs, int n);
+int mm_gathered_counts(const mm_ctx* ctx, size_t* perRank, size_t* total);
+int mm_gathered_download(mm_ctx* ctx, mm_mapping* out, size_t cap);
+int mm_gathered_device(const mm_ctx* ctx, const mm_mapping** dMappings, size_t* total);
+int mm_index_replicate(mm_ctx* dst, mm_ctx* src);
+
 /* per-kernel device timing, measured with hipEvents on the ctx stream (bench.py roofline leg) */
-enum { MM_K_PACK = 0, MM_K_SKETCH, MM_K_SKETCH_HARD, MM_K_LOOKUP, MM_K_SORT, MM_K_L1, MM_K_L2, MM_K_REFHASH, MM_K_L2_LOCATE, MM_K_WINNOW, MM_K_COUNT };
+enum { MM_K_PACK = 0, MM_K_SKETCH, MM_K_SKETCH_HARD, MM_K_LOOKUP, MM_K_SORT, MM_K_L1, MM_K_L2, MM_K_REFHASH, MM_K_L2_LOCATE, MM_K_WINNOW, MM_K_SELECT, MM_K_COUNT };
 int mm_profile_enable(mm_ctx* ctx, int on);
 /* ms[i] = accumulated milliseconds, launches[i] = launch count since the last reset */
 int mm_profile_read(mm_ctx* ctx, double* ms, uint64_t* launches, int reset);
 const char* mm_kernel_name(int which);
+/* integer-roofline yardstick: a kernel that does nothing but the 2 x MurmurHash3_x64_128 per position of
+ * every resident fragment (both strands, same tables and staging as the sketch kernel); *msAvg = average of `reps` launches */
+int mm_bench_hash_only(mm_ctx* ctx, int reps, double* msAvg);
 int mm_synchronize(mm_ctx* ctx);
 /* the HIP stream all work of this ctx is ordered on (a hipStream_t) */
 void* mm_stream(const mm_ctx* ctx);

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libmashmap_hip.so")
 
 MM_FLAG_HG_FILTER, MM_FLAG_SKIP_SELF, MM_FLAG_SKIP_PREFIX, MM_FLAG_LOWER_TRIANGULAR, MM_FLAG_NO_SPLIT = 1, 2, 4, 8, 16
-KERNELS = ["pack", "sketch", "sketch_hard", "lookup", "sort", "l1", "l2", "refhash", "l2_locate", "winnow"]
+KERNELS = ["pack", "sketch", "sketch_hard", "lookup", "sort", "l1", "l2", "refhash", "l2_locate", "winnow", "select"]
 
 
 class LibraryMissing(RuntimeError):
@@ -37,9 +37,13 @@ STATS_DT = np.dtype([("rawSketchSize", "<i4"), ("sketchSize", "<i4"), ("maxHash"
                      ("nL1", "<i4")])
 L1_DT = np.dtype([("frag", "<i4"), ("seqId", "<i4"), ("rangeStartPos", "<i4"), ("rangeEndPos", "<i4"),
                   ("intersectionSize", "<i4")])
+MAPPING_DT = np.dtype([("querySeqId", "<i4"), ("fragStart", "<i4"), ("fragLen", "<i4"), ("refSeqId", "<i4"), ("refStartPos", "<i4"),
+                       ("conservedSketches", "<i4"), ("sketchSize", "<i4"), ("strand", "<i4"), ("rawSketchSize", "<i4"), ("pad", "<i4"),
+                       ("maxHash", "<u8")])
+COMM_ID_BYTES = 128
 L2_DT = np.dtype([("frag", "<i4"), ("cand", "<i4"), ("seqId", "<i4"), ("meanOptimalPos", "<i4"),
                   ("optimalStart", "<i4"), ("optimalEnd", "<i4"), ("sharedSketchSize", "<i4"), ("strand", "<i4")])
-assert MINMER_DT.itemsize == 24 and POINT_DT.itemsize == 24 and STATS_DT.itemsize == 24 and L2_DT.itemsize == 32
+assert MAPPING_DT.itemsize == 48 and MINMER_DT.itemsize == 24 and POINT_DT.itemsize == 24 and STATS_DT.itemsize == 24 and L2_DT.itemsize == 32
 
 _lib = None
 
@@ -72,6 +76,7 @@ def load():
         "mm_stat_min_hits_relaxed": (C.c_int, [C.c_int, C.c_int, C.c_float]),
         "mm_stat_recommended_sketch_size": (i64, [C.c_int, C.c_float, i64, C.c_uint64]),
         "mm_stat_sketch_cutoffs": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, sz]),
+        "mm_stat_replay_tables": (C.c_int, [C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, vp, vp]),
         "mm_results_copy_device": (C.c_int, [vp, vp, sz, C.POINTER(sz)]),
         "mm_reads_upload": (C.c_int, [vp, vp, vp, sz, vp, vp, i32]),
         "mm_reads_upload_device": (C.c_int, [vp, vp, sz, vp, sz, vp, vp, i32]),
@@ -94,6 +99,21 @@ def load():
         "mm_profile_enable": (C.c_int, [vp, C.c_int]),
         "mm_profile_read": (C.c_int, [vp, vp, vp, C.c_int]),
         "mm_kernel_name": (C.c_char_p, [C.c_int]),
+        "mm_bench_hash_only": (C.c_int, [vp, C.c_int, C.POINTER(C.c_double)]),
+        "mm_set_replay_tables": (C.c_int, [vp, vp, vp, sz]),
+        "mm_mappings_count": (C.c_int, [vp, C.POINTER(sz)]),
+        "mm_mappings_download": (C.c_int, [vp, vp, sz, C.POINTER(sz)]),
+        "mm_mappings_device": (C.c_int, [vp, C.POINTER(vp), C.POINTER(sz)]),
+        "mm_comm_unique_id": (C.c_int, [vp]),
+        "mm_comm_init_rank": (C.c_int, [vp, vp, C.c_int, C.c_int]),
+        "mm_comm_init_local": (C.c_int, [C.POINTER(vp), C.c_int]),
+        "mm_comm_world": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+        "mm_allgatherv_mappings": (C.c_int, [vp]),
+        "mm_allgatherv_mappings_local": (C.c_int, [C.POINTER(vp), C.c_int]),
+        "mm_gathered_counts": (C.c_int, [vp, vp, C.POINTER(sz)]),
+        "mm_gathered_download": (C.c_int, [vp, vp, sz]),
+        "mm_gathered_device": (C.c_int, [vp, C.POINTER(vp), C.POINTER(sz)]),
+        "mm_index_replicate": (C.c_int, [vp, vp]),
         "mm_synchronize": (C.c_int, [vp]),
         "mm_stream": (vp, [vp]),
     }
@@ -112,7 +132,10 @@ EXPORTS = ["mm_abi_version", "mm_create", "mm_destroy", "mm_last_error", "mm_ind
            "mm_sketch_fragments", "mm_sketch_download", "mm_map_fragments", "mm_result_counts",
            "mm_results_download", "mm_query_sketch_download", "mm_points_download", "mm_results_device",
            "mm_index_build", "mm_index_sizes", "mm_index_download", "mm_set_option", "mm_index_download_full", "mm_index_upload_full", "mm_profile_enable", "mm_profile_read",
-           "mm_kernel_name", "mm_synchronize", "mm_stream"]
+           "mm_kernel_name", "mm_synchronize", "mm_stream", "mm_bench_hash_only",
+           "mm_set_replay_tables", "mm_mappings_count", "mm_mappings_download", "mm_mappings_device", "mm_comm_unique_id",
+           "mm_comm_init_rank", "mm_comm_init_local", "mm_comm_world", "mm_allgatherv_mappings", "mm_allgatherv_mappings_local",
+           "mm_gathered_counts", "mm_gathered_download", "mm_gathered_device", "mm_index_replicate", "mm_stat_replay_tables"]
 
 
 def stat_sketch_cutoffs(sketchSize, k, hg=True):
@@ -121,6 +144,33 @@ def stat_sketch_cutoffs(sketchSize, k, hg=True):
     out = np.zeros(n, dtype=np.int32)
     lib.mm_stat_sketch_cutoffs(sketchSize, k, 1 if hg else 0, _ptr(out), n)
     return out
+
+
+def comm_unique_id():
+    buf = (C.c_char * COMM_ID_BYTES)()
+    if load().mm_comm_unique_id(C.cast(buf, C.c_void_p)) != 0:
+        raise MashmapError("mm_comm_unique_id failed (RCCL not loadable?)")
+    return bytes(buf)
+
+
+def comm_init_local(ctxs):
+    arr = (C.c_void_p * len(ctxs))(*[c.h for c in ctxs])
+    if load().mm_comm_init_local(arr, len(ctxs)) != 0:
+        raise MashmapError("mm_comm_init_local failed: " + load().mm_last_error(ctxs[0].h).decode())
+
+
+def allgatherv_mappings_local(ctxs):
+    arr = (C.c_void_p * len(ctxs))(*[c.h for c in ctxs])
+    if load().mm_allgatherv_mappings_local(arr, len(ctxs)) != 0:
+        raise MashmapError("mm_allgatherv_mappings_local failed: " + load().mm_last_error(ctxs[0].h).decode())
+
+
+def stat_replay_tables(sketchSize, k, pi, aniDiff=0.0, keepLow=True):
+    n = (sketchSize + 1) ** 2
+    acc = np.zeros(n, dtype=np.uint8); mi = np.zeros(n, dtype=np.int16)
+    if load().mm_stat_replay_tables(sketchSize, k, pi, aniDiff, 1 if keepLow else 0, _ptr(acc), _ptr(mi)) != 0:
+        raise MashmapError("mm_stat_replay_tables failed")
+    return acc, mi
 
 
 class Context:
@@ -277,6 +327,40 @@ class Context:
         ms = np.zeros(len(KERNELS), dtype=np.float64); ln = np.zeros(len(KERNELS), dtype=np.uint64)
         self.lib.mm_profile_read(self.h, _ptr(ms), _ptr(ln), 1 if reset else 0)
         return {KERNELS[i]: (float(ms[i]), int(ln[i])) for i in range(len(KERNELS))}
+
+    # ---- candidate mappings + multi-GPU exchange
+    def set_replay_tables(self, accept, minIsz):
+        a = np.ascontiguousarray(accept, dtype=np.uint8); b = np.ascontiguousarray(minIsz, dtype=np.int16)
+        self._ck(self.lib.mm_set_replay_tables(self.h, _ptr(a), _ptr(b), self.s + 1), "mm_set_replay_tables")
+
+    def mappings(self):
+        n = C.c_size_t()
+        self._ck(self.lib.mm_mappings_count(self.h, C.byref(n)), "mm_mappings_count")
+        out = np.zeros(n.value, dtype=MAPPING_DT)
+        self._ck(self.lib.mm_mappings_download(self.h, _ptr(out), n.value, C.byref(n)), "mm_mappings_download")
+        return out
+
+    def comm_init_rank(self, comm_id, rank, world):
+        buf = (C.c_char * COMM_ID_BYTES).from_buffer_copy(bytes(comm_id))
+        self._ck(self.lib.mm_comm_init_rank(self.h, C.cast(buf, C.c_void_p), rank, world), "mm_comm_init_rank")
+
+    def allgatherv_mappings(self):
+        self._ck(self.lib.mm_allgatherv_mappings(self.h), "mm_allgatherv_mappings")
+
+    def gathered(self, world):
+        counts = np.zeros(world, dtype=np.uint64); tot = C.c_size_t()
+        self._ck(self.lib.mm_gathered_counts(self.h, _ptr(counts), C.byref(tot)), "mm_gathered_counts")
+        out = np.zeros(tot.value, dtype=MAPPING_DT)
+        self._ck(self.lib.mm_gathered_download(self.h, _ptr(out), tot.value), "mm_gathered_download")
+        return out, counts.astype(np.int64)
+
+    def index_replicate_from(self, src):
+        self._ck(self.lib.mm_index_replicate(self.h, src.h), "mm_index_replicate")
+
+    def bench_hash_only(self, reps=3):
+        ms = C.c_double()
+        self._ck(self.lib.mm_bench_hash_only(self.h, reps, C.byref(ms)), "mm_bench_hash_only")
+        return ms.value
 
     def synchronize(self):
         self._ck(self.lib.mm_synchronize(self.h), "mm_synchronize")

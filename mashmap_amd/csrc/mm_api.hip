@@ -2,13 +2,23 @@
 #include "mm_internal.h"
 #include <algorithm>
 #include <cstring>
+#include <thread>
 #include "../host/mm_stats.hpp"
 
 static thread_local std::string g_createErr;
 
 static const char* kKernelNames[MM_K_COUNT] = {
   "k_pack2bit", "k_sketch_fragments", "k_sketch_fragments(hard)", "k_seed_lookup", "k_sort_points",
-  "k_l1_sweep", "k_l2_sweep", "k_ref_hash", "k_l2_locate", "k_winnow_tiles"};
+  "k_l1_sweep", "k_l2_sweep", "k_ref_hash", "k_l2_locate", "k_winnow_tiles", "k_l2_select"};
+
+std::vector<DevBuf*> mm_ctx::allBufs() {
+  DeviceIndex& I = idx;
+  return {&I.evKey, &I.evAux, &I.evHash, &I.contigOff, &I.opKey, &I.opAux, &I.opHash, &I.blockOff, &I.evBlock, &I.contigBlock, &I.contigLen, &I.refGroup,
+          &I.htSlots, &I.filter, &I.ptKeys, &dMinHits, &dCutoffs, &dAscii, &dReadSrcOff, &dReadPackOff, &dReadLen, &dReadGroup, &dReadSelf, &dReadHasN,
+          &dBases2, &dNmask, &dFrags, &dSkHash, &dSkPos, &dSkStrand, &dSkCount, &dHardList, &dCounters, &dSketchTabs, &dQHash, &dQStrand, &dSeedVal,
+          &dStats, &dPtOff, &dPts, &dL1, &dL1b, &dL1Cursors, &dL1Off, &dL2, &dL2Info, &dL2Cnt, &dL2Off, &dL2Ops, &dScanTmp, &dL2Tmp, &dL2Wide,
+          &dListB, &dListC, &dBigList, &dL2First, &dL2Num, &dAccept, &dMinIsz, &dSelCnt, &dSelOff, &dSelHeap, &dFragTab, &dMappings, &dCommCounts, &dGathered};
+}
 
 extern "C" {
 
@@ -20,10 +30,11 @@ const char* mm_last_error(const mm_ctx* ctx) { return ctx ? ctx->err.c_str() : g
 int mm_create(mm_ctx** out, int device, const mm_params* p) {
   if (!out || !p) { g_createErr = "mm_create: null argument"; return MM_ERR_ARG; }
   *out = nullptr;
-  if (p->kmerSize < 1 || p->kmerSize > 32 || p->sketchSize < 1 || p->sketchSize > 1024 || p->segLength < p->kmerSize) {
-    g_createErr = "mm_create: unsupported parameters (need 1<=k<=32, 1<=sketchSize<=1024, segLength>=k)";
+  if (p->kmerSize < 1 || p->kmerSize > 32 || p->sketchSize < 1 || p->segLength < p->kmerSize) {
+    g_createErr = "mm_create: unsupported parameters (need 1 <= kmerSize <= 32, sketchSize >= 1, segLength >= kmerSize)";
     return MM_ERR_ARG;
   }
+  if (mm_check_params(p, g_createErr) != MM_OK) return MM_ERR_ARG;
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
@@ -51,11 +62,8 @@ void mm_destroy(mm_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
-  DevBuf* bufs[] = {&c->idx.evKey, &c->idx.evAux, &c->idx.evHash, &c->idx.contigOff, &c->idx.opKey, &c->idx.opAux, &c->idx.opHash, &c->idx.blockOff, &c->idx.evBlock, &c->idx.contigBlock, &c->idx.contigLen, &c->idx.refGroup, &c->idx.htSlots, &c->idx.filter, &c->idx.ptKeys, &c->dMinHits, &c->dCutoffs, &c->dAscii, &c->dReadSrcOff, &c->dReadPackOff,
-                    &c->dReadLen, &c->dReadGroup, &c->dReadSelf, &c->dReadHasN, &c->dBases2, &c->dNmask, &c->dFrags, &c->dSkHash,
-                    &c->dSkPos, &c->dSkStrand, &c->dSkCount, &c->dHardList, &c->dCounters, &c->dSketchTabs, &c->dQHash, &c->dQStrand, &c->dSeedVal,
-                    &c->dStats, &c->dPtOff, &c->dPts, &c->dL1, &c->dL1b, &c->dL1Cursors, &c->dL1Off, &c->dL2, &c->dL2Info, &c->dL2Cnt, &c->dL2Off, &c->dL2Ops, &c->dScanTmp, &c->dL2Tmp, &c->dL2Wide, &c->dListB, &c->dListC, &c->dBigList};
-  for (DevBuf* b : bufs) b->release();
+  mm_comm_release(c);
+  for (DevBuf* b : c->allBufs()) b->release();
   if (c->evA) (void)hipEventDestroy(c->evA);
   if (c->evB) (void)hipEventDestroy(c->evB);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -120,7 +128,11 @@ int mm_set_tables_default(mm_ctx* c, float pi) {
   for (int q = 1; q <= s; q++) mh[q] = mmhost::Stat::estimateMinimumHitsRelaxed(q, k, pi, mmhost::fixed::confidence_interval);
   std::vector<int> cut = mmhost::sketchCutoffs(s, k, mmhost::fixed::ANIDiff, mmhost::fixed::ANIDiffConf, (c->P.flags & MM_FLAG_HG_FILTER) != 0);
   std::vector<int32_t> cut32(cut.begin(), cut.end());
-  return mm_set_tables(c, mh.data(), mh.size(), cut32.data(), cut32.size());
+  int rc = mm_set_tables(c, mh.data(), mh.size(), cut32.data(), cut32.size());
+  if (rc != MM_OK) return rc;
+  std::vector<uint8_t> accept; std::vector<int16_t> minIsz;
+  mmhost::replayTables(s, k, pi, mmhost::fixed::ANIDiff, true, std::max(1u, std::thread::hardware_concurrency()), accept, minIsz);
+  return mm_set_replay_tables(c, accept.data(), minIsz.data(), (size_t)s + 1);
 }
 
 float mm_stat_j2md(float j, int k) { return mmhost::Stat::j2md(j, k); }
@@ -129,6 +141,13 @@ float mm_stat_md_lower_bound(float d, int s, int k, float ci) { return mmhost::S
 int mm_stat_min_hits_relaxed(int s, int k, float pi) { return mmhost::Stat::estimateMinimumHitsRelaxed(s, k, pi, mmhost::fixed::confidence_interval); }
 int64_t mm_stat_recommended_sketch_size(int k, float pi, int64_t segLength, uint64_t referenceSize) {
   return mmhost::Stat::recommendedSketchSize(mmhost::fixed::pval_cutoff, mmhost::fixed::confidence_interval, k, 4, pi, segLength, referenceSize);
+}
+int mm_stat_replay_tables(int sketchSize, int k, float percentageIdentity, float ANIDiff, int keepLowPctId, uint8_t* accept, int16_t* minIsz) {
+  if (sketchSize < 1 || !accept || !minIsz) return MM_ERR_ARG;
+  std::vector<uint8_t> a; std::vector<int16_t> m;
+  mmhost::replayTables(sketchSize, k, percentageIdentity, ANIDiff, keepLowPctId != 0, std::max(1u, std::thread::hardware_concurrency()), a, m);
+  std::memcpy(accept, a.data(), a.size()); std::memcpy(minIsz, m.data(), m.size() * 2);
+  return MM_OK;
 }
 int mm_stat_sketch_cutoffs(int sketchSize, int k, int hgFilter, int32_t* out, size_t cap) {
   std::vector<int> cut = mmhost::sketchCutoffs(sketchSize, k, mmhost::fixed::ANIDiff, mmhost::fixed::ANIDiffConf, hgFilter != 0);
@@ -179,7 +198,7 @@ static int upload_reads_common(mm_ctx* c, const void* src, bool srcOnDevice, siz
   }
   srcOff[nReads] = readOffsets[nReads]; packOff[nReads] = pk;
   c->nReads = nReads; c->nFrags = dfr.size(); c->nPackedBases = (size_t)pk; c->seqCounterBase = seqCounterBase; c->maxFragLen = maxLen;
-  c->sketched = false; c->mapped = false;
+  c->sketched = false; c->mapped = false; c->fragTabStale = true; c->gathered = false;
 
   const size_t srcBase = (size_t)readOffsets[0];
   const size_t nSrc = (size_t)(readOffsets[nReads] - readOffsets[0]);

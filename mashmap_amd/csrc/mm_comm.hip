@@ -1,0 +1,270 @@
+// mashmap_amd/csrc/mm_comm.hip -- the one exchange step of a multi-GPU run: all-gatherv of the candidate mappings over RCCL (xGMI).
+//
+// The reference maps every read in one address space; chaining and the per-read filters need only that read's fragments
+// (computeMap.hpp:679-697), but the one-to-one filter (:358-405) and the single output stream need every read's mappings in one
+// place.  Here reads are sharded over GPUs in contiguous blocks with the index replicated, fragments never
+// interact before the CPU filters, so the data path has exactly one collective: after mm_map_fragments every rank contributes its
+// batch's mm_mapping records (48 bytes per reported locus, ~1 per 5 kbp of reads) and receives everybody's, rank-major -- which, with
+// contiguous read blocks, is input order.
+//
+//   one process per GPU :  mm_comm_unique_id (rank 0) -> ship the 128 bytes -> mm_comm_init_rank on every rank -> mm_allgatherv_mappings
+//   one process, n GPUs :  mm_comm_init_local(ctxs, n) -> mm_allgatherv_mappings_local(ctxs, n)     (skch::Map, MASHMAP_HIP_DEVICES)
+//
+// The all-gatherv is one RCCL group of `world` broadcasts (root r sends its count[r] records into everybody's slot r): no padding,
+// no staging copy.  Counts travel first (ncclAllGather of one uint64 per rank; the host needs them to size and place the slots).
+// RCCL is opened with dlopen on first use: single-GPU users of libmashmap_hip.so never load it.  Contexts of a local group that
+// share a device (two contexts on one GPU) cannot form an RCCL communicator; they exchange by device-to-device copies instead.
+#include "mm_internal.h"
+#include <rccl/rccl.h>
+#include <dlfcn.h>
+#include <algorithm>
+#include <cstring>
+#include <mutex>
+
+namespace {
+
+struct Rccl {
+  void* h = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommInitAll) CommInitAll = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclBroadcast) Broadcast = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  std::string err;
+};
+Rccl g_rccl;
+std::mutex g_rcclMu;
+
+Rccl* rccl_open(std::string& err) {
+  std::lock_guard<std::mutex> lk(g_rcclMu);
+  if (g_rccl.h) return &g_rccl;
+  if (!g_rccl.err.empty()) { err = g_rccl.err; return nullptr; }
+  const char* names[] = {getenv("MASHMAP_HIP_RCCL"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  void* h = nullptr;
+  for (const char* n : names) { if (n && *n && (h = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break; }
+  if (!h) { g_rccl.err = std::string("cannot load RCCL (librccl.so.1): ") + (dlerror() ? dlerror() : "not found"); err = g_rccl.err; return nullptr; }
+  bool ok = true;
+  auto sym = [&](const char* n) { void* p = dlsym(h, n); if (!p) ok = false; return p; };
+  g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))sym("ncclGetUniqueId");
+  g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))sym("ncclCommInitRank");
+  g_rccl.CommInitAll = (decltype(g_rccl.CommInitAll))sym("ncclCommInitAll");
+  g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))sym("ncclCommDestroy");
+  g_rccl.AllGather = (decltype(g_rccl.AllGather))sym("ncclAllGather");
+  g_rccl.Broadcast = (decltype(g_rccl.Broadcast))sym("ncclBroadcast");
+  g_rccl.GroupStart = (decltype(g_rccl.GroupStart))sym("ncclGroupStart");
+  g_rccl.GroupEnd = (decltype(g_rccl.GroupEnd))sym("ncclGroupEnd");
+  g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))sym("ncclGetErrorString");
+  if (!ok) { g_rccl.err = "RCCL library lacks a required entry point"; err = g_rccl.err; dlclose(h); return nullptr; }
+  g_rccl.h = h;
+  return &g_rccl;
+}
+
+#define MM_NCCL(ctx, R, call)                                                                    \
+  do {                                                                                           \
+    ncclResult_t r__ = (call);                                                                   \
+    if (r__ != ncclSuccess) { (ctx)->err = std::string(#call) + ": " + (R)->GetErrorString(r__); return MM_ERR_DEVICE; } \
+  } while (0)
+
+// slots of the gathered buffer from the per-rank counts
+void place(mm_ctx* c) {
+  c->gatherDisp.assign(c->gatherCounts.size() + 1, 0);
+  for (size_t r = 0; r < c->gatherCounts.size(); r++) c->gatherDisp[r + 1] = c->gatherDisp[r] + c->gatherCounts[r];
+  c->nGathered = c->gatherDisp.back();
+}
+
+// the `world` broadcasts of one rank (to be called between GroupStart / GroupEnd)
+int issue_broadcasts(mm_ctx* c, Rccl* R) {
+  const int world = c->commWorld;
+  for (int r = 0; r < world; r++) {
+    const size_t bytes = c->gatherCounts[r] * sizeof(mm_mapping);
+    if (!bytes) continue;
+    char* slot = (char*)c->dGathered.p + c->gatherDisp[r] * sizeof(mm_mapping);
+    MM_NCCL(c, R, R->Broadcast(r == c->commRank ? c->dMappings.p : (const void*)slot, slot, bytes, ncclChar, r, (ncclComm_t)c->comm, c->stream));
+  }
+  return MM_OK;
+}
+
+}  // namespace
+
+void mm_comm_release(mm_ctx* c) {
+  if (c->comm && g_rccl.h) (void)g_rccl.CommDestroy((ncclComm_t)c->comm);
+  c->comm = nullptr; c->commWorld = 0; c->commRank = 0; c->commCopy = false;
+}
+
+extern "C" {
+
+int mm_comm_unique_id(void* id) {
+  std::string err;
+  Rccl* R = rccl_open(err);
+  if (!R || !id) return MM_ERR_DEVICE;
+  ncclUniqueId u;
+  if (R->GetUniqueId(&u) != ncclSuccess) return MM_ERR_DEVICE;
+  static_assert(sizeof(ncclUniqueId) == MM_COMM_ID_BYTES, "ncclUniqueId size");
+  std::memcpy(id, &u, sizeof u);
+  return MM_OK;
+}
+
+int mm_comm_init_rank(mm_ctx* c, const void* id, int rank, int world) {
+  if (!id || world < 1 || rank < 0 || rank >= world) { c->err = "mm_comm_init_rank: bad argument"; return MM_ERR_ARG; }
+  Rccl* R = rccl_open(c->err);
+  if (!R) return MM_ERR_DEVICE;
+  MM_HIP(c, hipSetDevice(c->device));
+  mm_comm_release(c);
+  ncclUniqueId u; std::memcpy(&u, id, sizeof u);
+  ncclComm_t comm = nullptr;
+  MM_NCCL(c, R, R->CommInitRank(&comm, world, u, rank));
+  c->comm = comm; c->commRank = rank; c->commWorld = world; c->commCopy = false;
+  MM_HIP(c, c->dCommCounts.ensure((size_t)(world + 1) * 8));
+  return MM_OK;
+}
+
+int mm_comm_init_local(mm_ctx** ctxs, int n) {
+  if (!ctxs || n < 1) return MM_ERR_ARG;
+  mm_ctx* c0 = ctxs[0];
+  std::vector<int> devs(n);
+  bool distinct = true;
+  for (int i = 0; i < n; i++) { devs[i] = ctxs[i]->device; for (int j = 0; j < i; j++) if (devs[j] == devs[i]) distinct = false; }
+  for (int i = 0; i < n; i++) { mm_comm_release(ctxs[i]); ctxs[i]->commRank = i; ctxs[i]->commWorld = n; ctxs[i]->commCopy = true; }
+  if (distinct && n > 1) {
+    Rccl* R = rccl_open(c0->err);
+    if (!R) return MM_ERR_DEVICE;
+    std::vector<ncclComm_t> comms(n, nullptr);
+    MM_NCCL(c0, R, R->CommInitAll(comms.data(), n, devs.data()));
+    for (int i = 0; i < n; i++) { ctxs[i]->comm = comms[i]; ctxs[i]->commCopy = false; }
+  }
+  return MM_OK;
+}
+
+int mm_comm_world(const mm_ctx* c, int* rank, int* world) {
+  if (rank) *rank = c->commRank;
+  if (world) *world = c->commWorld;
+  return c->commWorld ? MM_OK : MM_ERR_STATE;
+}
+
+int mm_allgatherv_mappings(mm_ctx* c) {
+  if (!c->comm || c->commCopy) { c->err = "mm_allgatherv_mappings: mm_comm_init_rank first"; return MM_ERR_STATE; }
+  if (!c->mapped || !c->haveReplayTables) { c->err = "mm_allgatherv_mappings: no candidate mappings resident"; return MM_ERR_STATE; }
+  Rccl* R = rccl_open(c->err);
+  if (!R) return MM_ERR_DEVICE;
+  MM_HIP(c, hipSetDevice(c->device));
+  const int world = c->commWorld;
+  unsigned long long mine = c->nMappings;
+  unsigned long long* dC = c->dCommCounts.as<unsigned long long>();
+  MM_HIP(c, hipMemcpyAsync(dC + world, &mine, 8, hipMemcpyHostToDevice, c->stream));
+  MM_NCCL(c, R, R->AllGather(dC + world, dC, 1, ncclUint64, (ncclComm_t)c->comm, c->stream));
+  std::vector<unsigned long long> h(world);
+  MM_HIP(c, hipMemcpyAsync(h.data(), dC, (size_t)world * 8, hipMemcpyDeviceToHost, c->stream));
+  MM_HIP(c, hipStreamSynchronize(c->stream));
+  c->gatherCounts.assign(h.begin(), h.end());
+  place(c);
+  MM_HIP(c, c->dGathered.ensure(c->nGathered * sizeof(mm_mapping) + 64));
+  MM_NCCL(c, R, R->GroupStart());
+  const int rc = issue_broadcasts(c, R);
+  MM_NCCL(c, R, R->GroupEnd());
+  if (rc != MM_OK) return rc;
+  MM_HIP(c, hipStreamSynchronize(c->stream));
+  c->gathered = true;
+  return MM_OK;
+}
+
+int mm_allgatherv_mappings_local(mm_ctx** ctxs, int n) {
+  if (!ctxs || n < 1) return MM_ERR_ARG;
+  mm_ctx* c0 = ctxs[0];
+  for (int i = 0; i < n; i++) {
+    mm_ctx* c = ctxs[i];
+    if (c->commWorld != n || c->commRank != i) { c0->err = "mm_allgatherv_mappings_local: contexts are not the group of mm_comm_init_local"; return MM_ERR_STATE; }
+    if (!c->mapped || !c->haveReplayTables) { c0->err = "mm_allgatherv_mappings_local: a context has no candidate mappings resident"; return MM_ERR_STATE; }
+  }
+  for (int i = 0; i < n; i++) {
+    mm_ctx* c = ctxs[i];
+    c->gatherCounts.resize(n);
+    for (int r = 0; r < n; r++) c->gatherCounts[r] = ctxs[r]->nMappings;
+    place(c);
+    MM_HIP(c, hipSetDevice(c->device));
+    MM_HIP(c, c->dGathered.ensure(c->nGathered * sizeof(mm_mapping) + 64));
+  }
+  if (!c0->commCopy) {
+    Rccl* R = rccl_open(c0->err);
+    if (!R) return MM_ERR_DEVICE;
+    MM_NCCL(c0, R, R->GroupStart());
+    int rc = MM_OK;
+    for (int i = 0; i < n && rc == MM_OK; i++) { (void)hipSetDevice(ctxs[i]->device); rc = issue_broadcasts(ctxs[i], R); if (rc != MM_OK) c0->err = ctxs[i]->err; }
+    MM_NCCL(c0, R, R->GroupEnd());
+    if (rc != MM_OK) return rc;
+  } else {
+    // contexts sharing a device: slot r of every context is a device copy of context r's records (mm_map_fragments has synchronised
+    // every source stream)
+    for (int i = 0; i < n; i++) {
+      mm_ctx* c = ctxs[i];
+      MM_HIP(c, hipSetDevice(c->device));
+      for (int r = 0; r < n; r++) {
+        const size_t bytes = c->gatherCounts[r] * sizeof(mm_mapping);
+        if (!bytes) continue;
+        char* slot = (char*)c->dGathered.p + c->gatherDisp[r] * sizeof(mm_mapping);
+        if (ctxs[r]->device == c->device) MM_HIP(c, hipMemcpyAsync(slot, ctxs[r]->dMappings.p, bytes, hipMemcpyDeviceToDevice, c->stream));
+        else MM_HIP(c, hipMemcpyPeerAsync(slot, c->device, ctxs[r]->dMappings.p, ctxs[r]->device, bytes, c->stream));
+      }
+    }
+  }
+  for (int i = 0; i < n; i++) { mm_ctx* c = ctxs[i]; MM_HIP(c, hipSetDevice(c->device)); MM_HIP(c, hipStreamSynchronize(c->stream)); c->gathered = true; }
+  return MM_OK;
+}
+
+int mm_gathered_counts(const mm_ctx* c, size_t* perRank, size_t* total) {
+  if (!c->gathered) return MM_ERR_STATE;
+  if (perRank) for (size_t r = 0; r < c->gatherCounts.size(); r++) perRank[r] = c->gatherCounts[r];
+  if (total) *total = c->nGathered;
+  return MM_OK;
+}
+
+int mm_gathered_download(mm_ctx* c, mm_mapping* out, size_t cap) {
+  if (!c->gathered) { c->err = "mm_gathered_download: nothing gathered"; return MM_ERR_STATE; }
+  if (c->nGathered > cap) { c->err = "mm_gathered_download: destination too small"; return MM_ERR_ARG; }
+  MM_HIP(c, hipSetDevice(c->device));
+  if (c->nGathered) {
+    MM_HIP(c, hipMemcpyAsync(out, c->dGathered.p, c->nGathered * sizeof(mm_mapping), hipMemcpyDeviceToHost, c->stream));
+    MM_HIP(c, hipStreamSynchronize(c->stream));
+  }
+  return MM_OK;
+}
+
+int mm_gathered_device(const mm_ctx* c, const mm_mapping** d, size_t* total) {
+  if (!c->gathered) return MM_ERR_STATE;
+  if (d) *d = c->dGathered.as<mm_mapping>();
+  if (total) *total = c->nGathered;
+  return MM_OK;
+}
+
+// replica of src's resident index on dst's GPU (device-to-device over xGMI; no second build, no host round trip).  dst gets the
+// device index only: the host mirrors behind mm_index_download stay with src.
+int mm_index_replicate(mm_ctx* dst, mm_ctx* src) {
+  if (!src->idx.ready) { dst->err = "mm_index_replicate: the source context has no index"; return MM_ERR_STATE; }
+  if (dst->P.kmerSize != src->P.kmerSize || dst->P.segLength != src->P.segLength || dst->P.sketchSize != src->P.sketchSize) {
+    dst->err = "mm_index_replicate: contexts differ in kmerSize / segLength / sketchSize"; return MM_ERR_ARG;
+  }
+  MM_HIP(dst, hipSetDevice(src->device));
+  MM_HIP(dst, hipStreamSynchronize(src->stream));
+  MM_HIP(dst, hipSetDevice(dst->device));
+  DeviceIndex& D = dst->idx; DeviceIndex& S = src->idx;
+  D.ready = false;
+  DevBuf* d[] = {&D.evKey, &D.evAux, &D.evHash, &D.contigOff, &D.opKey, &D.opAux, &D.opHash, &D.blockOff, &D.evBlock, &D.contigBlock, &D.contigLen, &D.refGroup, &D.htSlots, &D.filter, &D.ptKeys};
+  DevBuf* s[] = {&S.evKey, &S.evAux, &S.evHash, &S.contigOff, &S.opKey, &S.opAux, &S.opHash, &S.blockOff, &S.evBlock, &S.contigBlock, &S.contigLen, &S.refGroup, &S.htSlots, &S.filter, &S.ptKeys};
+  for (size_t i = 0; i < sizeof d / sizeof d[0]; i++) {
+    if (!s[i]->bytes) continue;
+    MM_HIP(dst, d[i]->ensure(s[i]->bytes));
+    if (dst->device == src->device) MM_HIP(dst, hipMemcpyAsync(d[i]->p, s[i]->p, s[i]->bytes, hipMemcpyDeviceToDevice, dst->stream));
+    else MM_HIP(dst, hipMemcpyPeerAsync(d[i]->p, dst->device, s[i]->p, src->device, s[i]->bytes, dst->stream));
+  }
+  MM_HIP(dst, hipStreamSynchronize(dst->stream));
+  D.nRec = S.nRec; D.nKeys = S.nKeys; D.nPoints = S.nPoints; D.nContigs = S.nContigs; D.htCap = S.htCap; D.filterMask = S.filterMask;
+  D.ready = true;
+  dst->freqThreshold = src->freqThreshold;
+  dst->mapped = false;
+  return MM_OK;
+}
+
+}  // extern "C"

@@ -184,8 +184,7 @@ typedef int (*HashContigFn)(mm_ctx*, const char*, int, DevBuf&, DevBuf&, DevBuf&
 static HashContigFn pick_hasher(int k) {
   switch (k) {
 #define MM_CASE(KK) case KK: return &hash_contig<KK>;
-    MM_CASE(11) MM_CASE(12) MM_CASE(13) MM_CASE(14) MM_CASE(15) MM_CASE(16) MM_CASE(17) MM_CASE(18) MM_CASE(19)
-    MM_CASE(20) MM_CASE(21) MM_CASE(22) MM_CASE(23) MM_CASE(24) MM_CASE(25) MM_CASE(27) MM_CASE(29) MM_CASE(31) MM_CASE(32)
+    MM_CASE(1) MM_CASE(2) MM_CASE(3) MM_CASE(4) MM_CASE(5) MM_CASE(6) MM_CASE(7) MM_CASE(8) MM_CASE(9) MM_CASE(10) MM_CASE(11) MM_CASE(12) MM_CASE(13) MM_CASE(14) MM_CASE(15) MM_CASE(16) MM_CASE(17) MM_CASE(18) MM_CASE(19) MM_CASE(20) MM_CASE(21) MM_CASE(22) MM_CASE(23) MM_CASE(24) MM_CASE(25) MM_CASE(26) MM_CASE(27) MM_CASE(28) MM_CASE(29) MM_CASE(30) MM_CASE(31) MM_CASE(32)
 #undef MM_CASE
     default: return nullptr;
   }

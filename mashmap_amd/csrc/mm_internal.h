@@ -94,6 +94,14 @@ struct mm_ctx {
   DevBuf dL1, dL1b, dL1Cursors; size_t l1Cap = 0, nL1 = 0;   // dL1b: the region-filled buffer k_l1_compact reads from
   DevBuf dL1Off;                                        // int64[nFrags] first candidate of a fragment
   DevBuf dL2; size_t l2Cap = 0, nL2 = 0;
+  DevBuf dL2First, dL2Num;                              // per L1 candidate: first locus in dL2 (int64) and count (int32)
+  // candidate mappings (mm_select.hip)
+  DevBuf dAccept, dMinIsz; bool haveReplayTables = false;
+  DevBuf dSelCnt, dSelOff, dSelHeap, dFragTab, dMappings; size_t nMappings = 0; bool fragTabStale = true;
+  // multi-GPU exchange (mm_comm.hip)
+  void* comm = nullptr; int commRank = 0, commWorld = 0; bool commCopy = false;   // commCopy: local group whose contexts share a device
+  DevBuf dCommCounts, dGathered; std::vector<size_t> gatherCounts, gatherDisp; size_t nGathered = 0; bool gathered = false;
+  std::vector<DevBuf*> allBufs();
   DevBuf dL2Info, dL2Cnt, dL2Off, dL2Ops, dScanTmp, dL2Tmp, dL2Wide, dListB, dListC, dBigList;     // L2 staging: per-candidate stream extents, op counts/offsets, located ops
   bool sketched = false, mapped = false;
   bool keepPoints = false;                              // mm_set_option(MM_OPT_KEEP_POINTS): route every fragment through the HBM point list
@@ -127,10 +135,13 @@ struct KernelTimer {   // RAII hipEvent bracket on the ctx stream
 };
 
 // launchers implemented in the .hip files
+int mm_check_params(const mm_params* p, std::string& err);
 int mm_launch_pack(mm_ctx* c);
 int mm_launch_pack_raw(mm_ctx* c, const uint8_t* dAscii, const int64_t* dSrcOff, const int64_t* dPackOff, const int32_t* dLen, int nReads,
                        int64_t nChunks, uint32_t* dB, uint32_t* dM, uint32_t* dHasN);
 int mm_launch_sketch(mm_ctx* c);
 int mm_launch_map(mm_ctx* c);
+int mm_launch_select(mm_ctx* c);
+void mm_comm_release(mm_ctx* c);
 int mm_launch_l2(mm_ctx* c, unsigned long long* cnt);   // cnt: device counters [4] cursor [5] overflow [6] slot overflow
 int mm_build_device_index(mm_ctx* c, const int32_t* contigLen, const int32_t* refGroup, size_t nContigs);

@@ -308,7 +308,7 @@ __global__ void __launch_bounds__(64)
 k_l2_sweep(int nCand, const int32_t* __restrict__ candList, int segLength, const mm_l1_candidate* __restrict__ l1, const mm_frag_stats* __restrict__ stats,
            const int64_t* __restrict__ opOff, const int32_t* __restrict__ opCnt, const uint32_t* __restrict__ ops,
            const int64_t* __restrict__ l1Off, L2Tmp* __restrict__ tmp, int locap, mm_l2_locus* __restrict__ l2, unsigned long long l2Cap,
-           int32_t* __restrict__ wideList,
+           int32_t* __restrict__ wideList, int64_t* __restrict__ l2First, int32_t* __restrict__ l2Num,
            unsigned long long* __restrict__ counters /* [4] l2 cursor, [5] overflow, [6] flags, [7] candidates queued for the wide pass */) {
   typedef typename std::conditional<WIDE, uint16_t, uint8_t>::type CellT;
   constexpr int CB = WIDE ? 12 : 5;
@@ -468,6 +468,7 @@ k_l2_sweep(int nCand, const int32_t* __restrict__ candList, int segLength, const
   if (lane == lastLane && waveTotal > 0) wbase = atomicAdd(&counters[4], (unsigned long long)waveTotal);
   wbase = ((unsigned long long)(uint32_t)__shfl((int)(wbase >> 32), lastLane) << 32) | (uint32_t)__shfl((int)(uint32_t)wbase, lastLane);
   if (waveTotal > 0 && wbase + (unsigned long long)waveTotal > l2Cap) { if (lane == lastLane) atomicOr(&counters[5], 1ull); return; }
+  l2First[cIdx] = (int64_t)(wbase + (unsigned long long)(incl - total)); l2Num[cIdx] = total;   // where k_l2_select finds this candidate's loci
   if (total > 0) {
     const unsigned long long base = wbase + (unsigned long long)(incl - total);
     const int candLocal = (int)(cIdx - l1Off[f]);
@@ -531,6 +532,7 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt) {
   MM_HIP(c, hipFuncSetAttribute((const void*)k_l2_sweep<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsWide));
   MM_HIP(c, hipFuncSetAttribute((const void*)k_l2_sweep<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsNarrow));
   MM_HIP(c, c->dL2Wide.ensure((size_t)nC * 4 + 64));
+  MM_HIP(c, c->dL2First.ensure((size_t)nC * 8 + 64)); MM_HIP(c, c->dL2Num.ensure((size_t)nC * 4 + 64));
   if (c->l2Cap < c->nL1 * 2 + 1024) c->l2Cap = c->nL1 * 2 + 1024;
   unsigned long long hc[8];
   int locap = MM_LOCAP0;
@@ -544,7 +546,7 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt) {
       hipLaunchKernelGGL((k_l2_sweep<false>), dim3((unsigned)((nC + 63) / 64)), dim3(64), ldsNarrow, c->stream, nC, (const int32_t*)nullptr, c->P.segLength,
                          c->dL1.as<mm_l1_candidate>(), c->dStats.as<mm_frag_stats>(), c->dL2Off.as<int64_t>(), c->dL2Cnt.as<int32_t>(), c->dL2Ops.as<uint32_t>(),
                          c->dL1Off.as<int64_t>(), c->dL2Tmp.as<L2Tmp>(), locap, c->dL2.as<mm_l2_locus>(), (unsigned long long)c->l2Cap,
-                         c->dL2Wide.as<int32_t>(), cnt);
+                         c->dL2Wide.as<int32_t>(), c->dL2First.as<int64_t>(), c->dL2Num.as<int32_t>(), cnt);
       MM_HIP(c, hipGetLastError());
     }
     MM_HIP(c, hipMemcpyAsync(hc, cnt, 64, hipMemcpyDeviceToHost, c->stream));
@@ -556,7 +558,7 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt) {
       hipLaunchKernelGGL((k_l2_sweep<true>), dim3((unsigned)((nWide + 63) / 64)), dim3(64), ldsWide, c->stream, nWide, c->dL2Wide.as<int32_t>(), c->P.segLength,
                          c->dL1.as<mm_l1_candidate>(), c->dStats.as<mm_frag_stats>(), c->dL2Off.as<int64_t>(), c->dL2Cnt.as<int32_t>(), c->dL2Ops.as<uint32_t>(),
                          c->dL1Off.as<int64_t>(), c->dL2Tmp.as<L2Tmp>(), locap, c->dL2.as<mm_l2_locus>(), (unsigned long long)c->l2Cap,
-                         (int32_t*)nullptr, cnt);
+                         (int32_t*)nullptr, c->dL2First.as<int64_t>(), c->dL2Num.as<int32_t>(), cnt);
       MM_HIP(c, hipGetLastError());
       MM_HIP(c, hipMemcpyAsync(hc, cnt, 64, hipMemcpyDeviceToHost, c->stream));
       MM_HIP(c, hipStreamSynchronize(c->stream));

@@ -102,9 +102,12 @@ int mm_build_device_index(mm_ctx* c, const int32_t* contigLen, const int32_t* re
   for (size_t i = 0; i < cap; i++) hs[2 * i] = MM_EMPTY;
   for (size_t i = 0; i < nk; i++) {
     const uint64_t key = c->hKeys[i];
-    const uint64_t off = c->hOffsets[i], cnt = c->hOffsets[i + 1] - c->hOffsets[i];
-    if (cnt >= (1ull << 23) || off >= (1ull << 40)) { c->err = "mm_index_upload: lookup list too large for the packed table value"; return MM_ERR_ARG; }
+    uint64_t off = c->hOffsets[i], cnt = c->hOffsets[i + 1] - c->hOffsets[i];
     const bool freq = std::binary_search(c->hFreq.begin(), c->hFreq.end(), key);
+    // a frequent seed is removed from the query sketch before any lookup (getSeedHits, computeMap.hpp:834-837): its point list is
+    // never read on the device, so however long it is (satellite arrays) it needs no room in the packed value
+    if (freq) { off = 0; cnt = 0; }
+    if (cnt >= (1ull << 23) || off >= (1ull << 40)) { c->err = "mm_index_upload: a non-frequent seed with 2^23 or more interval points (or 2^40 points in total) does not fit the packed table value"; return MM_ERR_ARG; }
     size_t slot = (size_t)key & (cap - 1);
     while (hs[2 * slot] != MM_EMPTY) { if (hs[2 * slot] == key) { c->err = "mm_index_upload: duplicate key"; return MM_ERR_ARG; } slot = (slot + 1) & (cap - 1); }
     hs[2 * slot] = key; hs[2 * slot + 1] = (off << 24) | (cnt << 1) | (freq ? 1ull : 0ull);
@@ -804,7 +807,7 @@ int mm_launch_map(mm_ctx* c) {
   MM_HIP(c, c->dSeedVal.ensure((s > 256 ? (size_t)nF * s * 8 : 0) + 64)); MM_HIP(c, c->dStats.ensure((size_t)nF * sizeof(mm_frag_stats) + 64));
   MM_HIP(c, c->dPtOff.ensure((size_t)nF * 16 + 64)); MM_HIP(c, c->dL1Off.ensure((size_t)nF * 8 + 64));
   MM_HIP(c, c->dCounters.ensure(256));
-  c->nL1 = c->nL2 = 0;
+  c->nL1 = c->nL2 = 0; c->nMappings = 0;
   if (nF == 0) return MM_OK;
   MapFlags fl{(c->P.flags & MM_FLAG_HG_FILTER) ? 1 : 0, (c->P.flags & MM_FLAG_SKIP_SELF) ? 1 : 0,
               (c->P.flags & MM_FLAG_SKIP_PREFIX) ? 1 : 0, (c->P.flags & MM_FLAG_LOWER_TRIANGULAR) ? 1 : 0};
@@ -919,7 +922,8 @@ int mm_launch_map(mm_ctx* c) {
   if (c->nL1 == 0) { c->nL2 = 0; return rc; }
 
   rc = mm_launch_l2(c, cnt);
-  return rc;
+  if (rc != MM_OK) return rc;
+  return mm_launch_select(c);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -111,14 +111,11 @@ __device__ __forceinline__ uint64_t mm_window_or(uint64_t x) {
 //     a larger table (duplicates collapse) and T is bisected until s <= distinct <= load limit.
 // ---------------------------------------------------------------------------------------------
 template <int K, bool HARD>
-__global__ void __launch_bounds__(1024)
-k_sketch_fragments(const uint4* __restrict__ gTabs, const uint32_t* __restrict__ bases2, const uint32_t* __restrict__ nmask,
-                   const DFrag* __restrict__ frags, const uint32_t* __restrict__ readHasN,
-                   const int32_t* __restrict__ fragList, int s, int wantFast, int HT, int PAD,
+__device__ __forceinline__ void
+mm_sketch_fragment(unsigned char* smem, const int f, const uint4* __restrict__ gTabs, const uint32_t* __restrict__ bases2, const uint32_t* __restrict__ nmask,
+                   const DFrag* __restrict__ frags, const uint32_t* __restrict__ readHasN, int s, int wantFast, int HT, int PAD,
                    uint64_t* __restrict__ skHash, int2* __restrict__ skPos, int8_t* __restrict__ skStrand,
                    uint32_t* __restrict__ skCount, int32_t* __restrict__ hardList, uint32_t* __restrict__ hardCount) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int f = HARD ? fragList[blockIdx.x] : (int)blockIdx.x;
   const DFrag fr = frags[f];
   const int len = fr.len;
   const int n = len - K + 1;                        // k-mer positions
@@ -285,6 +282,60 @@ k_sketch_fragments(const uint4* __restrict__ gTabs, const uint32_t* __restrict__
   if (tid == 0) skCount[f] = D < (uint32_t)s ? D : (uint32_t)s;
 }
 
+template <int K, bool HARD>
+__global__ void __launch_bounds__(1024)
+k_sketch_fragments(const uint4* __restrict__ gTabs, const uint32_t* __restrict__ bases2, const uint32_t* __restrict__ nmask,
+                   const DFrag* __restrict__ frags, const uint32_t* __restrict__ readHasN,
+                   const int32_t* __restrict__ fragList, const uint32_t* __restrict__ fragListCount, int s, int wantFast, int HT, int PAD,
+                   uint64_t* __restrict__ skHash, int2* __restrict__ skPos, int8_t* __restrict__ skStrand,
+                   uint32_t* __restrict__ skCount, int32_t* __restrict__ hardList, uint32_t* __restrict__ hardCount) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if (!HARD) {
+    mm_sketch_fragment<K, false>(smem, (int)blockIdx.x, gTabs, bases2, nmask, frags, readHasN, s, wantFast, HT, PAD, skHash, skPos, skStrand, skCount, hardList, hardCount);
+  } else {
+    // the hard list's length stays on the device (no host round trip between the two kernels): a fixed grid walks it
+    const uint32_t nList = *fragListCount;
+    for (uint32_t i = blockIdx.x; i < nList; i += gridDim.x) {
+      mm_sketch_fragment<K, true>(smem, fragList[i], gTabs, bases2, nmask, frags, readHasN, s, wantFast, HT, PAD, skHash, skPos, skStrand, skCount, hardList, hardCount);
+      __syncthreads();                              // the next fragment reuses the LDS
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_hash_only<K>: the integer roofline's yardstick.  Same decomposition and staging as the fast sketch
+// kernel -- workgroup per fragment, thread per 16-position strip, packed words and hasher tables in LDS -- but nothing besides
+// the 2 x MurmurHash3_x64_128 per position: no N mask, no cut, no queues, no table.  The canonical hashes are folded into one
+// value per thread that is stored only if it equals an impossible constant, so the hashes stay live and nothing is written.
+// ---------------------------------------------------------------------------------------------
+template <int K>
+__global__ void __launch_bounds__(1024)
+k_hash_only(const uint4* __restrict__ gTabs, const uint32_t* __restrict__ bases2, const DFrag* __restrict__ frags, uint64_t* __restrict__ sink) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const DFrag fr = frags[blockIdx.x];
+  const int len = fr.len, n = len - K + 1;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  if (n <= 0) return;
+  using Tabs = typename MMTabsFor<K>::type;
+  Tabs* tabs = (Tabs*)smem;
+  for (int i = tid; i < (int)(sizeof(Tabs) / 16); i += nthr) ((uint4*)tabs)[i] = gTabs[i];
+  uint32_t* sW = (uint32_t*)(smem + sizeof(Tabs));
+  const int nW = (len + 15) / 16 + 3;
+  {
+    const int64_t w0 = fr.base >> 4; const int sh = (int)(fr.base & 15) * 2;
+    for (int j = tid; j < nW; j += nthr) {
+      const uint32_t a = bases2[w0 + j], b = bases2[w0 + j + 1];
+      sW[j] = sh ? __builtin_amdgcn_alignbit(b, a, sh) : a;
+    }
+  }
+  __syncthreads();
+  const int nStrips = (n + 15) >> 4;
+  uint64_t acc = 0;
+  for (int strip = tid; strip < nStrips; strip += nthr)
+    mm_strip_hashes<K>(sW[strip], sW[strip + 1], sW[strip + 2], *tabs, [&](int j, uint64_t hf, uint64_t hr) { acc += hf < hr ? hf : hr; });
+  if (acc == 0x9E3779B97F4A7C15ull) sink[0] = acc;
+}
+
 // strip-hasher tables, built once per context and k-mer size
 template <int K>
 __global__ void k_sketch_tables(typename MMTabsFor<K>::type* out) { mm_tables_init<K>(*out, (int)threadIdx.x, (int)blockDim.x); }
@@ -297,6 +348,27 @@ static size_t sketch_lds_bytes(size_t tabBytes, int maxLen, int HT, int PAD, boo
          NS * (8 + 4 + 4 + 4) + nOcc * 8 + ((nOcc * 4 + 15) / 16) * 16 + 16;
 }
 static int next_pow2(int x) { int p = 1; while (p < x) p <<= 1; return p; }
+#define MM_SK_PAD 64
+#define MM_SK_PADH 256
+static int sketch_ht_fast(int s) { return next_pow2(s * 3 < 256 ? 256 : s * 3); }
+static int sketch_ht_hard(int s) { return next_pow2(s * 3 < 4096 ? 4096 : s * 3); }   // load limit 5/8 of it stays >= 2 s
+
+// Parameter combinations the LDS-resident kernels cannot hold are refused when the context is created (not after the reference
+// index has been built): the sketch tables + a staged fragment of segLength bases, and the 16-bit L2 state cells of k_l2_sweep.
+int mm_check_params(const mm_params* p, std::string& err) {
+  const int s = p->sketchSize, L = p->segLength;
+  const size_t tabBytes = p->kmerSize >= 16 ? sizeof(MMProdTables) : sizeof(MMTables);
+  const size_t ldsFast = sketch_lds_bytes(tabBytes, L, sketch_ht_fast(s), MM_SK_PAD, false), ldsHard = sketch_lds_bytes(tabBytes, L, sketch_ht_hard(s), MM_SK_PADH, true);
+  const size_t ldsL2 = (size_t)(s + 1) * 64 * 2;
+  const size_t lim = 160 * 1024;
+  if (ldsFast > lim || ldsHard > lim || ldsL2 > lim) {
+    char b[320];
+    snprintf(b, sizeof b, "mm_create: segLength %d with sketchSize %d needs %zu / %zu bytes of LDS in the sketch kernels and %zu in the L2 sweep; a CU has %zu "
+             "(sketchSize <= 1279; segLength up to ~150 kbp at sketchSize 1024)", L, s, ldsFast, ldsHard, ldsL2, lim);
+    err = b; return MM_ERR_ARG;
+  }
+  return MM_OK;
+}
 
 template <int K>
 static int launch_sketch_k(mm_ctx* c) {
@@ -307,10 +379,9 @@ static int launch_sketch_k(mm_ctx* c) {
   double margin = s * 0.5; if (margin < 4.0 * sqrt((double)s)) margin = 4.0 * sqrt((double)s);
   int wantFast = (int)(s + margin + 0.999);
   if (const char* e = getenv("MM_SKETCH_CUT")) { double cut = atof(e); if (cut < 1.05) cut = 1.05; if (cut > 2.5) cut = 2.5; wantFast = (int)(s * cut + 0.999); }
-  const int HT = next_pow2(s * 3 < 256 ? 256 : s * 3);
-  const int HTH = next_pow2(s * 4 < 4096 ? 4096 : s * 4);
+  const int HT = sketch_ht_fast(s), HTH = sketch_ht_hard(s);
   const int maxLen = c->maxFragLen;
-  const int PAD = 64, PADH = 256;                   // spill slots behind the ordered tables (no wrap-around)
+  const int PAD = MM_SK_PAD, PADH = MM_SK_PADH;     // spill slots behind the ordered tables (no wrap-around)
   const size_t ldsFast = sketch_lds_bytes(sizeof(typename MMTabsFor<K>::type), maxLen, HT, PAD, false),
                ldsHard = sketch_lds_bytes(sizeof(typename MMTabsFor<K>::type), maxLen, HTH, PADH, true);
   if (ldsHard > 160 * 1024) { c->err = "fragment too long / sketch too large for the LDS-resident sketch kernel"; return MM_ERR_ARG; }
@@ -335,23 +406,69 @@ static int launch_sketch_k(mm_ctx* c) {
     KernelTimer t(c, MM_K_SKETCH);
     hipLaunchKernelGGL((k_sketch_fragments<K, false>), dim3(nF), dim3(threads), ldsFast, c->stream,
                        c->dSketchTabs.as<uint4>(), c->dBases2.as<uint32_t>(), c->dNmask.as<uint32_t>(), c->dFrags.as<DFrag>(), c->dReadHasN.as<uint32_t>(),
-                       (const int32_t*)nullptr, s, wantFast, HT, PAD, c->dSkHash.as<uint64_t>(), c->dSkPos.as<int2>(), c->dSkStrand.as<int8_t>(),
+                       (const int32_t*)nullptr, (const uint32_t*)nullptr, s, wantFast, HT, PAD, c->dSkHash.as<uint64_t>(), c->dSkPos.as<int2>(), c->dSkStrand.as<int8_t>(),
                        c->dSkCount.as<uint32_t>(), c->dHardList.as<int32_t>(), c->dCounters.as<uint32_t>());
     MM_HIP(c, hipGetLastError());
   }
-  uint32_t nHard = 0;
-  MM_HIP(c, hipMemcpyAsync(&nHard, c->dCounters.p, 4, hipMemcpyDeviceToHost, c->stream));
-  MM_HIP(c, hipStreamSynchronize(c->stream));
-  if (getenv("MM_DEBUG")) fprintf(stderr, "[mm] sketch: %d fragments, %u to the hard path, threads %d, HT %d, lds %zu/%zu\n", nF, nHard, threads, HT, ldsFast, ldsHard);
-  if (nHard) {
+  if (getenv("MM_DEBUG")) {
+    uint32_t nHard = 0;
+    MM_HIP(c, hipMemcpyAsync(&nHard, c->dCounters.p, 4, hipMemcpyDeviceToHost, c->stream));
+    MM_HIP(c, hipStreamSynchronize(c->stream));
+    fprintf(stderr, "[mm] sketch: %d fragments, %u to the hard path, threads %d, HT %d, lds %zu/%zu\n", nF, nHard, threads, HT, ldsFast, ldsHard);
+  }
+  {
+    // fixed grid over the device-resident hard list (its workgroups leave at once when the list is empty or short)
     KernelTimer t(c, MM_K_SKETCH_HARD);
-    hipLaunchKernelGGL((k_sketch_fragments<K, true>), dim3(nHard), dim3(threads), ldsHard, c->stream,
+    const int grid = nF < 1024 ? nF : 1024;
+    hipLaunchKernelGGL((k_sketch_fragments<K, true>), dim3(grid), dim3(threads), ldsHard, c->stream,
                        c->dSketchTabs.as<uint4>(), c->dBases2.as<uint32_t>(), c->dNmask.as<uint32_t>(), c->dFrags.as<DFrag>(), c->dReadHasN.as<uint32_t>(),
-                       c->dHardList.as<int32_t>(), s, wantFast, HTH, PADH, c->dSkHash.as<uint64_t>(), c->dSkPos.as<int2>(), c->dSkStrand.as<int8_t>(),
+                       c->dHardList.as<int32_t>(), c->dCounters.as<uint32_t>(), s, wantFast, HTH, PADH, c->dSkHash.as<uint64_t>(), c->dSkPos.as<int2>(), c->dSkStrand.as<int8_t>(),
                        c->dSkCount.as<uint32_t>(), c->dHardList.as<int32_t>(), c->dCounters.as<uint32_t>() + 1);
     MM_HIP(c, hipGetLastError());
   }
   return MM_OK;
+}
+
+template <int K>
+static int launch_hash_only_k(mm_ctx* c, int reps, double* msAvg) {
+  using Tabs = typename MMTabsFor<K>::type;
+  const int nF = (int)c->nFrags;
+  const int maxLen = c->maxFragLen;
+  int nStrips = (maxLen - K + 1 + 15) / 16; if (nStrips < 1) nStrips = 1;
+  int threads = ((nStrips + 63) / 64) * 64; if (threads > 1024) threads = 1024;
+  const size_t lds = sizeof(Tabs) + (((size_t)(maxLen + 15) / 16 + 3) * 4 + 15) / 16 * 16;
+  if (c->sketchTabsK != K) {
+    MM_HIP(c, c->dSketchTabs.ensure(sizeof(Tabs)));
+    hipLaunchKernelGGL((k_sketch_tables<K>), dim3(1), dim3(256), 0, c->stream, c->dSketchTabs.as<Tabs>());
+    MM_HIP(c, hipGetLastError());
+    c->sketchTabsK = K;
+  }
+  MM_HIP(c, c->dCounters.ensure(256));
+  MM_HIP(c, hipFuncSetAttribute((const void*)k_hash_only<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  float total = 0;
+  for (int r = 0; r <= reps; r++) {                 // launch 0 is a warm-up
+    MM_HIP(c, hipEventRecord(c->evA, c->stream));
+    hipLaunchKernelGGL((k_hash_only<K>), dim3(nF), dim3(threads), lds, c->stream, c->dSketchTabs.as<uint4>(), c->dBases2.as<uint32_t>(), c->dFrags.as<DFrag>(),
+                       c->dCounters.as<uint64_t>() + 24);
+    MM_HIP(c, hipGetLastError());
+    MM_HIP(c, hipEventRecord(c->evB, c->stream));
+    MM_HIP(c, hipEventSynchronize(c->evB));
+    float ms = 0; MM_HIP(c, hipEventElapsedTime(&ms, c->evA, c->evB));
+    if (r) total += ms;
+  }
+  *msAvg = total / reps;
+  return MM_OK;
+}
+
+extern "C" int mm_bench_hash_only(mm_ctx* c, int reps, double* msAvg) {
+  if (!c->nFrags || reps < 1 || !msAvg) { c->err = "mm_bench_hash_only: needs resident reads and reps >= 1"; return MM_ERR_ARG; }
+  MM_HIP(c, hipSetDevice(c->device));
+  switch (c->P.kmerSize) {
+#define MM_CASE(KK) case KK: return launch_hash_only_k<KK>(c, reps, msAvg);
+    MM_CASE(16) MM_CASE(19) MM_CASE(21)
+#undef MM_CASE
+    default: c->err = "mm_bench_hash_only: built for k = 16, 19, 21"; return MM_ERR_ARG;
+  }
 }
 
 int mm_launch_sketch(mm_ctx* c) {
@@ -365,10 +482,9 @@ int mm_launch_sketch(mm_ctx* c) {
   if (nF == 0) return MM_OK;
   switch (c->P.kmerSize) {
 #define MM_CASE(KK) case KK: return launch_sketch_k<KK>(c);
-    MM_CASE(11) MM_CASE(12) MM_CASE(13) MM_CASE(14) MM_CASE(15) MM_CASE(16) MM_CASE(17) MM_CASE(18) MM_CASE(19)
-    MM_CASE(20) MM_CASE(21) MM_CASE(22) MM_CASE(23) MM_CASE(24) MM_CASE(25) MM_CASE(27) MM_CASE(29) MM_CASE(31) MM_CASE(32)
+    MM_CASE(1) MM_CASE(2) MM_CASE(3) MM_CASE(4) MM_CASE(5) MM_CASE(6) MM_CASE(7) MM_CASE(8) MM_CASE(9) MM_CASE(10) MM_CASE(11) MM_CASE(12) MM_CASE(13) MM_CASE(14) MM_CASE(15) MM_CASE(16) MM_CASE(17) MM_CASE(18) MM_CASE(19) MM_CASE(20) MM_CASE(21) MM_CASE(22) MM_CASE(23) MM_CASE(24) MM_CASE(25) MM_CASE(26) MM_CASE(27) MM_CASE(28) MM_CASE(29) MM_CASE(30) MM_CASE(31) MM_CASE(32)
 #undef MM_CASE
-    default: c->err = "kmerSize not compiled into the sketch kernel (supported: 11-25, 27, 29, 31, 32)"; return MM_ERR_ARG;
+    default: c->err = "kmerSize outside 1..32"; return MM_ERR_ARG;
   }
 }
 

@@ -11,7 +11,9 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <atomic>
 #include <numeric>
+#include <thread>
 #include <vector>
 
 namespace mmhost {
@@ -149,6 +151,46 @@ inline std::vector<int> sketchCutoffs(int sketchSize, int kmerSize, float ANIDif
     cut[cmax] = lo == 0 ? 1 : lo;
   }
   return cut;
+}
+
+// Integer tables that let doL2Mapping's best-first walk (computeMap.hpp:1182-1267) run without floating point:
+//   accept[Qs * stride + shared]  = 1 when an L2 locus with `shared` of Qs sketch elements is reported (:1221-1222)
+//   minIsz[Qs * stride + best]    = smallest L1 intersectionSize that survives the ANI cut-off (:1192-1202) once the best reported
+//                                   locus so far shares `best` elements (Qs + 1: none does)
+// Both are evaluated with the reference's own expressions (same float/double mixing), for every pair that can occur; rows are
+// independent, so they are filled by `threads` host threads.  stride = sketchSize + 1.
+inline void replayTables(int sketchSize, int k, float percentageIdentity, float ANIDiff, bool keep_low_pct_id, unsigned threads,
+                         std::vector<uint8_t>& accept, std::vector<int16_t>& minIsz) {
+  const size_t stride = (size_t)sketchSize + 1;
+  accept.assign(stride * stride, 0); minIsz.assign(stride * stride, 0);
+  if (threads < 1) threads = 1;
+  std::atomic<int> next(1);
+  auto work = [&]() {
+    for (int Qs = next.fetch_add(1); Qs <= sketchSize; Qs = next.fetch_add(1)) {
+      for (int shared = 0; shared <= Qs; shared++) {
+        const float mash_dist = Stat::j2md(1.0 * shared / Qs, k);
+        const float nucIdentity = (1 - mash_dist);
+        bool ok = nucIdentity >= percentageIdentity;
+        if (!ok && keep_low_pct_id) {
+          const float ub = 1 - Stat::md_lower_bound(mash_dist, Qs, k, fixed::confidence_interval);
+          ok = ub >= percentageIdentity;
+        }
+        accept[(size_t)Qs * stride + shared] = ok ? 1 : 0;
+      }
+      for (int best = 0; best <= Qs; best++) {
+        const double bestJaccardNumerator = best;
+        const double cutoff_ani = std::max(0.0, double((1 - Stat::j2md(bestJaccardNumerator / Qs, k)) - ANIDiff));
+        const double cutoff_j = Stat::md2j(1 - cutoff_ani, k);
+        int isz = 0;
+        while (isz <= Qs && double(isz) / Qs < cutoff_j) isz++;
+        minIsz[(size_t)Qs * stride + best] = (int16_t)isz;
+      }
+    }
+  };
+  std::vector<std::thread> pool;
+  for (unsigned t = 1; t < threads; t++) pool.emplace_back(work);
+  work();
+  for (auto& th : pool) th.join();
 }
 
 }  // namespace mmhost

@@ -11,9 +11,15 @@
 //   * chaining (mergeMappingsInRange :1580-1702), filterWeakMappings :423, the plane-sweep filters
 //     (filter.hpp:103-160 query axis, :334-396 reference axis), filterFalseHighIdentity :441,
 //     mappingBoundarySanityCheck :1714, sparsifyMappings :481 and the PAF writer.
-// The reference runs one pthread task per read (ThreadPool.hpp); here the reader accumulates reads into batches
-// (MASHMAP_HIP_BATCH_MBP, default 512 Mbp), one batch is one device pass, and the per-read host work of a batch is
-// spread over param.threads std::threads.  Output order == input order, as in the reference (ThreadPool.hpp:187-211).
+// The reference runs one pthread task per read (ThreadPool.hpp); here three stages run concurrently on successive batches
+// (MASHMAP_HIP_BATCH_MBP, default 512 Mbp): the reader thread parses batch i+2, the device stage maps batch i+1, the post stage
+// chains / filters / prints batch i on param.threads std::threads.  Output order == input order (ThreadPool.hpp:187-211).
+//
+// Device stage.  The kernels report, per fragment, the candidate mappings doL2Mapping would have pushed (mm_mapping, k_l2_select);
+// with several contexts (MASHMAP_HIP_DEVICES, one per GPU, index replicated by Sketch) a batch's reads are cut into contiguous
+// blocks of about equal bases, every context maps its block, and the blocks' candidate mappings are exchanged with one RCCL
+// all-gatherv (mm_allgatherv_mappings_local) -- rank-major == input order -- before the CPU filters, the one-to-one filter
+// (:358-405) included, see them.
 #pragma once
 #include <algorithm>
 #include <atomic>
@@ -57,35 +63,59 @@ class Map {
   std::vector<ContigInfo> qmetadata;             // only filled for one-to-one filtering (:105)
   std::vector<int> refIdGroup;
   std::unordered_map<std::string, int> refNameToId;
-  mm_ctx* ctx;
+  std::vector<mm_ctx*> ctxs;                     // one per GPU (Sketch::contexts)
+  mm_ctx* ctx;                                   // ctxs[0]
   MapPost post;                                  // everything downstream of the device integers (skch_map_post.hpp)
   struct Batch {
     std::string bases;
     std::vector<int64_t> offs{0};
     std::vector<std::string> names;
     seqno_t firstSeqCounter = 0;
-    void clear(seqno_t next) { bases.clear(); offs.assign(1, 0); names.clear(); firstSeqCounter = next; }
+    std::vector<mm_mapping> recs;                // candidate mappings of the batch, read-major (filled by the device stage)
+    void clear(seqno_t next) { bases.clear(); offs.assign(1, 0); names.clear(); firstSeqCounter = next; recs.clear(); }
     size_t size() const { return names.size(); }
   };
-  [[noreturn]] void die(const char* what) const {
-    std::cerr << "[mashmap_hip::skch::Map] ERROR: " << what << ": " << mm_last_error(ctx) << std::endl;
+  [[noreturn]] void die(const char* what, mm_ctx* c = nullptr) const {
+    std::cerr << "[mashmap_hip::skch::Map] ERROR: " << what << ": " << mm_last_error(c ? c : ctx) << std::endl;
     exit(1);
   }
+  // hand-over between two stages: at most `cap` batches waiting
+  struct Channel {
+    std::deque<Batch> q; std::mutex mu; std::condition_variable cvFull, cvEmpty; bool done = false; size_t cap;
+    explicit Channel(size_t c) : cap(c) {}
+    void put(Batch&& b) { std::unique_lock<std::mutex> lk(mu); cvFull.wait(lk, [&] { return q.size() < cap; }); q.emplace_back(std::move(b)); lk.unlock(); cvEmpty.notify_one(); }
+    bool get(Batch& b) {
+      std::unique_lock<std::mutex> lk(mu);
+      cvEmpty.wait(lk, [&] { return !q.empty() || done; });
+      if (q.empty()) return false;
+      b = std::move(q.front()); q.pop_front();
+      lk.unlock(); cvFull.notify_one();
+      return true;
+    }
+    void close() { { std::lock_guard<std::mutex> lk(mu); done = true; } cvEmpty.notify_all(); }
+  };
 
  public:
   Map(const skch::Parameters& p, const skch::Sketch& refsketch, PostProcessResultsFn_t f = nullptr)
       : param(p), refSketch(refsketch), processMappingResults(f),
-        refIdGroup(p.skip_prefix ? refsketch.refGroups() : std::vector<int>(refsketch.metadata.size(), 0)), ctx(refsketch.ctx()),
-        post(p, refsketch.metadata, refIdGroup) {
+        refIdGroup(p.skip_prefix ? refsketch.refGroups() : std::vector<int>(refsketch.metadata.size(), 0)), ctxs(refsketch.contexts()),
+        ctx(refsketch.ctx()), post(p, refsketch.metadata, refIdGroup) {
     post.qmetadata = &qmetadata;
     for (size_t i = 0; i < refsketch.metadata.size(); i++) refNameToId.emplace(refsketch.metadata[i].name, (int)i);
-    // integer tables the kernels consume: estimateMinimumHitsRelaxed per Q.sketchSize (:1144) and sketchCutoffs (:178-258)
+    // integer tables the kernels consume: estimateMinimumHitsRelaxed per Q.sketchSize (:1144), sketchCutoffs (:178-258), and the two
+    // tables of doL2Mapping's walk (acceptance :1221, ANI cut-off :1192-1202)
     std::vector<int32_t> minHits((size_t)p.sketchSize + 1, 0);
     for (int q = 1; q <= p.sketchSize; q++)
       minHits[q] = mmhost::Stat::estimateMinimumHitsRelaxed(q, p.kmerSize, p.percentageIdentity, skch::fixed::confidence_interval);
     std::vector<int> cut = mmhost::sketchCutoffs(p.sketchSize, p.kmerSize, p.ANIDiff, p.ANIDiffConf, p.stage1_topANI_filter);
     std::vector<int32_t> cut32(cut.begin(), cut.end());
-    if (mm_set_tables(ctx, minHits.data(), minHits.size(), cut32.data(), cut32.size()) != MM_OK) die("mm_set_tables");
+    std::vector<uint8_t> accept; std::vector<int16_t> minIsz;
+    mmhost::replayTables(p.sketchSize, p.kmerSize, p.percentageIdentity, p.ANIDiff, p.keep_low_pct_id,
+                         std::max(1u, std::max((unsigned)std::max(1, p.threads), std::thread::hardware_concurrency())), accept, minIsz);
+    for (mm_ctx* c : ctxs) {
+      if (mm_set_tables(c, minHits.data(), minHits.size(), cut32.data(), cut32.size()) != MM_OK) die("mm_set_tables", c);
+      if (mm_set_replay_tables(c, accept.data(), minIsz.data(), (size_t)p.sketchSize + 1) != MM_OK) die("mm_set_replay_tables", c);
+    }
     this->mapQuery();
   }
 
@@ -109,17 +139,12 @@ class Map {
     MappingResultsVector_t allReadMappings;
     const char* be = getenv("MASHMAP_HIP_BATCH_MBP");
     const size_t batchBases = (size_t)((be ? atof(be) : 512.0) * 1e6);
-    // reader thread: parses the query files into batches (at most two waiting) while this thread drives the device pass and
-    // the host post-processing of the previous batch
-    std::deque<Batch> ready; std::mutex mu; std::condition_variable cvFull, cvEmpty; bool readerDone = false;
+    Channel parsed(2), mapped(2);
     std::thread reader([&]() {
       Batch batch;
       auto flush = [&]() {
         if (batch.size() == 0) return;
-        std::unique_lock<std::mutex> lk(mu);
-        cvFull.wait(lk, [&] { return ready.size() < 2; });
-        ready.emplace_back(std::move(batch));
-        lk.unlock(); cvEmpty.notify_one();
+        parsed.put(std::move(batch));
         batch = Batch(); batch.clear(seqCounter);
       };
       for (const auto& fileName : param.querySequences) {
@@ -142,21 +167,19 @@ class Map {
         });
       }
       flush();
-      { std::lock_guard<std::mutex> lk(mu); readerDone = true; }
-      cvEmpty.notify_one();
+      parsed.close();
     });
-    while (true) {
+    std::thread poster([&]() {
       Batch cur;
-      {
-        std::unique_lock<std::mutex> lk(mu);
-        cvEmpty.wait(lk, [&] { return !ready.empty() || readerDone; });
-        if (ready.empty()) break;
-        cur = std::move(ready.front()); ready.pop_front();
-      }
-      cvFull.notify_one();
-      processBatch(cur, allReadMappings, totalReadsMapped, outstrm);
+      while (mapped.get(cur)) postStage(cur, allReadMappings, totalReadsMapped, outstrm);
+    });
+    {
+      Batch cur;
+      while (parsed.get(cur)) { deviceStage(cur); mapped.put(std::move(cur)); cur = Batch(); }
+      mapped.close();
     }
     reader.join();
+    poster.join();
 
     if (param.filterMode == filter::ONETOONE) {            // :358-406
       const int n_mappings = (int)param.numMappingsForSegment - 1;
@@ -188,62 +211,94 @@ class Map {
   }
 
   // ------------------------------------------------------------------------------------------------------------------
-  // one device pass + the per-read host post-processing of a batch
-  void processBatch(const Batch& batch, MappingResultsVector_t& allReadMappings, seqno_t& totalReadsMapped, std::ofstream& outstrm) {
+  // device stage: the batch's reads -> candidate mappings (batch.recs), on one GPU or sharded over all contexts
+  void deviceStage(Batch& batch) {
     const size_t nReads = batch.size();
+    const size_t nCtx = ctxs.size();
     const bool timing = getenv("MASHMAP_HIP_TIMING") != nullptr;
-    auto tick = skch::Time::now();
-    auto lap = [&](const char* what) {
-      if (!timing) return;
-      const auto now = skch::Time::now();
-      std::cerr << "[mashmap_hip::timing] " << what << ": " << std::chrono::duration<double>(now - tick).count() << " s" << std::endl;
-      tick = now;
-    };
+    const auto t0 = skch::Time::now();
     std::vector<int32_t> readGroup, readSelf;
     if (param.skip_prefix) { readGroup.resize(nReads); for (size_t r = 0; r < nReads; r++) readGroup[r] = getRefGroup(batch.names[r]); }
     if (param.skip_self) {
       readSelf.resize(nReads);
       for (size_t r = 0; r < nReads; r++) { auto it = refNameToId.find(batch.names[r]); readSelf[r] = it == refNameToId.end() ? -1 : it->second; }
     }
-    if (mm_reads_upload(ctx, batch.bases.data(), batch.offs.data(), nReads, param.skip_prefix ? readGroup.data() : nullptr,
-                        param.skip_self ? readSelf.data() : nullptr, batch.firstSeqCounter) != MM_OK) die("mm_reads_upload");
-    lap("upload + pack");
-    if (mm_map_fragments(ctx) != MM_OK) die("mm_map_fragments");
-    lap("device pass");
-    DeviceResults D;
-    size_t n1 = 0, n2 = 0;
-    if (mm_result_counts(ctx, &n1, &n2) != MM_OK) die("mm_result_counts");
-    const size_t nF = mm_num_fragments(ctx);
-    D.frags.resize(nF); D.stats.resize(nF); D.l1.resize(n1); D.l2.resize(n2);
-    if (mm_fragments_download(ctx, D.frags.data()) != MM_OK) die("mm_fragments_download");
-    if (mm_results_download(ctx, D.stats.data(), D.l1.data(), D.l2.data()) != MM_OK) die("mm_results_download");
-    D.fragBegin.assign(nReads + 1, nF);
-    { size_t f = 0; for (size_t r = 0; r <= nReads; r++) { while (f < nF && (size_t)D.frags[f].readId < r) f++; D.fragBegin[r] = f; } }
-    D.l1Begin.resize(nF + 1);
-    { size_t o = 0; for (size_t f = 0; f < nF; f++) { D.l1Begin[f] = o; o += (size_t)D.stats[f].nL1; } D.l1Begin[nF] = o; }
-    D.l2Begin.assign(n1 + 1, n2);
-    { size_t i = 0; for (size_t c = 0; c <= n1; c++) { while (i < n2 && (size_t)D.l2[i].cand < c) i++; D.l2Begin[c] = i; } }
+    // contiguous blocks of about equal bases, one per context (a block may be empty)
+    std::vector<size_t> cutAt(nCtx + 1, nReads);
+    cutAt[0] = 0;
+    {
+      const int64_t total = batch.offs[nReads];
+      size_t r = 0;
+      for (size_t i = 1; i < nCtx; i++) {
+        const int64_t want = total * (int64_t)i / (int64_t)nCtx;
+        while (r < nReads && batch.offs[r] < want) r++;
+        cutAt[i] = r;
+      }
+    }
+    auto runBlock = [&](size_t i) {
+      mm_ctx* c = ctxs[i];
+      const size_t b = cutAt[i], e = cutAt[i + 1];
+      if (mm_reads_upload(c, batch.bases.data(), batch.offs.data() + b, e - b, param.skip_prefix ? readGroup.data() + b : nullptr,
+                          param.skip_self ? readSelf.data() + b : nullptr, batch.firstSeqCounter + (seqno_t)b) != MM_OK) die("mm_reads_upload", c);
+      if (mm_map_fragments(c) != MM_OK) die("mm_map_fragments", c);
+    };
+    if (nCtx == 1) runBlock(0);
+    else {
+      std::vector<std::thread> th;
+      for (size_t i = 1; i < nCtx; i++) th.emplace_back(runBlock, i);
+      runBlock(0);
+      for (auto& t : th) t.join();
+    }
+    size_t n = 0;
+    if (nCtx == 1) {
+      if (mm_mappings_count(ctx, &n) != MM_OK) die("mm_mappings_count");
+      batch.recs.resize(n);
+      if (mm_mappings_download(ctx, batch.recs.data(), n, &n) != MM_OK) die("mm_mappings_download");
+    } else {
+      if (mm_allgatherv_mappings_local(ctxs.data(), (int)nCtx) != MM_OK) die("mm_allgatherv_mappings_local");
+      if (mm_gathered_counts(ctx, nullptr, &n) != MM_OK) die("mm_gathered_counts");
+      batch.recs.resize(n);
+      if (mm_gathered_download(ctx, batch.recs.data(), n) != MM_OK) die("mm_gathered_download");
+    }
+    if (timing) std::cerr << "[mashmap_hip::timing] device stage (upload + pack + kernels" << (nCtx > 1 ? " + all-gatherv" : "") << " + download of " << n
+                          << " candidate mappings): " << std::chrono::duration<double>(skch::Time::now() - t0).count() << " s" << std::endl;
+  }
 
-    lap("download");
+  // post stage: per read, chaining + filters + PAF text on param.threads threads; then output in input order
+  void postStage(Batch& batch, MappingResultsVector_t& allReadMappings, seqno_t& totalReadsMapped, std::ofstream& outstrm) {
+    const size_t nReads = batch.size();
+    const bool timing = getenv("MASHMAP_HIP_TIMING") != nullptr;
+    const auto t0 = skch::Time::now();
+    // the records are read-major: first record of every read
+    std::vector<size_t> recBegin(nReads + 1, batch.recs.size());
+    {
+      size_t i = 0;
+      for (size_t r = 0; r <= nReads; r++) {
+        while (i < batch.recs.size() && (size_t)(batch.recs[i].querySeqId - batch.firstSeqCounter) < r) i++;
+        recBegin[r] = i;
+      }
+    }
     std::vector<MappingResultsVector_t> perRead(nReads);
     std::vector<std::string> text(nReads);
     const bool reportNow = param.filterMode != filter::ONETOONE;
     const unsigned nThreads = (unsigned)std::max(1, param.threads);
-    auto work = [&](unsigned t) {
+    std::atomic<size_t> next(0);
+    auto work = [&]() {
       std::ostringstream os;
-      for (size_t r = t; r < nReads; r += nThreads) {
-        const offset_t len = (offset_t)(batch.offs[r + 1] - batch.offs[r]);
-        if (len < param.kmerSize) continue;
-        post.mapModule(D, r, batch.names[r], len, batch.firstSeqCounter + (seqno_t)r, perRead[r]);
-        if (reportNow && !perRead[r].empty()) { os.str(std::string()); post.reportReadMappings(perRead[r], batch.names[r], os); text[r] = os.str(); }
-      }
+      const size_t chunk = 64;
+      for (size_t r0 = next.fetch_add(chunk); r0 < nReads; r0 = next.fetch_add(chunk))
+        for (size_t r = r0; r < std::min(nReads, r0 + chunk); r++) {
+          const offset_t len = (offset_t)(batch.offs[r + 1] - batch.offs[r]);
+          if (len < param.kmerSize || recBegin[r] == recBegin[r + 1]) continue;
+          post.mapModuleFromRecords(batch.recs.data() + recBegin[r], batch.recs.data() + recBegin[r + 1], len, perRead[r]);
+          if (reportNow && !perRead[r].empty()) { os.str(std::string()); post.reportReadMappings(perRead[r], batch.names[r], os); text[r] = os.str(); }
+        }
     };
     std::vector<std::thread> pool;
-    for (unsigned t = 1; t < nThreads; t++) pool.emplace_back(work, t);
-    work(0);
+    for (unsigned t = 1; t < nThreads; t++) pool.emplace_back(work);
+    work();
     for (auto& th : pool) th.join();
-
-    lap("host replay + chain + filter");
+    const auto t1 = skch::Time::now();
     for (size_t r = 0; r < nReads; r++) {                  // mapModuleHandleOutput (:724-752), input order
       if (!perRead[r].empty()) totalReadsMapped++;
       if (!reportNow) allReadMappings.insert(allReadMappings.end(), perRead[r].begin(), perRead[r].end());
@@ -252,6 +307,8 @@ class Map {
         if (processMappingResults) for (const auto& e : perRead[r]) processMappingResults(e);
       }
     }
+    if (timing) std::cerr << "[mashmap_hip::timing] post stage: chain + filter + format " << std::chrono::duration<double>(t1 - t0).count()
+                          << " s, output " << std::chrono::duration<double>(skch::Time::now() - t1).count() << " s" << std::endl;
   }
 
 };

@@ -212,6 +212,11 @@ class MapPost {
         unfiltered.insert(unfiltered.end(), l2Mappings.begin(), l2Mappings.end());
       }
     }
+    finishRead(unfiltered, len, split_mapping, out);
+  }
+
+  // the tail of mapModule (:679-714): chaining, weak-chain filter, plane-sweep filter, sanity checks
+  void finishRead(MappingResultsVector_t& unfiltered, offset_t len, bool split_mapping, MappingResultsVector_t& out) const {
     const int n_mappings = (int)(len < param.segLength ? param.numMappingsForShortSequence : param.numMappingsForSegment) - 1;
     if (split_mapping && param.mergeMappings) {
       mergeMappingsInRange(unfiltered, param.chain_gap);
@@ -226,6 +231,58 @@ class MapPost {
     if (param.filterLengthMismatches) filterFalseHighIdentity(out);
     mappingBoundarySanityCheck(len, out);
     sparsifyMappings(out);
+  }
+
+  // identity of a locus sharing `shared` of Qs sketch elements (:1211-1213); a function of two small integers, cached like the bound
+  float identityOf(int shared, int Qs, float* mashDist) const {
+    const float mash_dist = mmhost::Stat::j2md(1.0 * shared / Qs, param.kmerSize);
+    *mashDist = mash_dist;
+    return 1 - mash_dist;
+  }
+
+  // mapModule (:570-714) for one read from the device's candidate mappings [b, e) (include/mashmap_hip.h: mm_mapping): the read's
+  // records, fragment-major, inside a fragment in doL2Mapping's push order -- i.e. l2Mappings of mapSingleQueryFrag before its sort
+  void mapModuleFromRecords(const mm_mapping* b, const mm_mapping* e, offset_t len, MappingResultsVector_t& out) const {
+    MappingResultsVector_t unfiltered, l2Mappings;
+    const bool split_mapping = param.split && len > param.segLength;
+    for (const mm_mapping* p = b; p != e;) {
+      const mm_mapping* q = p;
+      while (q != e && q->fragStart == p->fragStart) q++;
+      const offset_t Qlen = p->fragLen;
+      // getSeedHits (:830-831): long double ratio -> double -> float
+      const double max_hash_01 = (long double)(p->maxHash) / std::numeric_limits<hash_t>::max();
+      const float kmerComplexity = (double(p->rawSketchSize) / max_hash_01) / ((Qlen - param.kmerSize + 1) * 2);
+      if (!(kmerComplexity < param.kmerComplexityThreshold)) {          // :1137
+        l2Mappings.clear();
+        for (const mm_mapping* m = p; m != q; ++m) {
+          float mash_dist;
+          MappingResult res{};                 // see doL2MappingReplay for the zero-initialised tail
+          res.nucIdentity = identityOf(m->conservedSketches, m->sketchSize, &mash_dist);
+          res.nucIdentityUpperBound = identityUpperBound(mash_dist, m->conservedSketches, m->sketchSize);
+          res.queryLen = Qlen;
+          res.refStartPos = m->refStartPos;
+          res.refEndPos = m->refStartPos + Qlen;
+          res.queryStartPos = 0;
+          res.queryEndPos = Qlen;
+          res.refSeqId = m->refSeqId;
+          res.querySeqId = m->querySeqId;
+          res.sketchSize = m->sketchSize;
+          res.conservedSketches = m->conservedSketches;
+          res.blockLength = std::max(res.refEndPos - res.refStartPos, res.queryEndPos - res.queryStartPos);
+          res.approxMatches = std::round(res.nucIdentity * res.blockLength / 100.0);
+          res.strand = (strand_t)m->strand;
+          res.kmerComplexity = kmerComplexity;
+          l2Mappings.push_back(res);
+        }
+        std::sort(l2Mappings.begin(), l2Mappings.end(), [](const MappingResult& a, const MappingResult& b2) {
+          return std::tie(a.refSeqId, a.refStartPos) < std::tie(b2.refSeqId, b2.refStartPos); });       // :799-800
+        if (split_mapping)
+          for (auto& x : l2Mappings) { x.queryLen = len; x.queryStartPos = p->fragStart; x.queryEndPos = p->fragStart + p->fragLen; }   // :632-636
+        unfiltered.insert(unfiltered.end(), l2Mappings.begin(), l2Mappings.end());
+      }
+      p = q;
+    }
+    finishRead(unfiltered, len, split_mapping, out);
   }
 
   // ------------------------------------------------------------------------------------------------------------------

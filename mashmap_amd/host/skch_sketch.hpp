@@ -32,7 +32,8 @@ class Sketch {
   const skch::Parameters& param;
   int freqThreshold = std::numeric_limits<int>::max();
   std::vector<hash_t> frequentSeeds;               // ascending
-  mm_ctx* ctx_ = nullptr;
+  mm_ctx* ctx_ = nullptr;                          // the context the index is built on (first device of the list)
+  std::vector<mm_ctx*> ctxs_;                      // one per entry of MASHMAP_HIP_DEVICES; ctxs_[0] == ctx_
   Sketch();
 
   [[noreturn]] void die(const char* what) const {
@@ -50,7 +51,17 @@ class Sketch {
   MI_Map_t minmerPosLookupIndex;                   // see materializeLookupIndex()
   MI_Type minmerIndex;
 
-  static int deviceFromEnv() { const char* e = getenv("MASHMAP_HIP_DEVICE"); return e ? atoi(e) : 0; }
+  // MASHMAP_HIP_DEVICES=0,1,... : the GPUs query batches are sharded over (index replicated);
+  // MASHMAP_HIP_DEVICE=n : a single one (default 0).  A device may be listed twice (two contexts on one GPU).
+  static std::vector<int> devicesFromEnv() {
+    std::vector<int> d;
+    if (const char* e = getenv("MASHMAP_HIP_DEVICES")) {
+      std::stringstream ss(e); std::string tok;
+      while (std::getline(ss, tok, ',')) if (!tok.empty()) d.push_back(atoi(tok.c_str()));
+    }
+    if (d.empty()) { const char* e = getenv("MASHMAP_HIP_DEVICE"); d.push_back(e ? atoi(e) : 0); }
+    return d;
+  }
 
   explicit Sketch(const skch::Parameters& p) : param(p) {
     static_assert(sizeof(MinmerInfo) == sizeof(mm_minmer), "MinmerInfo layout");
@@ -60,19 +71,30 @@ class Sketch {
     mp.flags = (p.stage1_topANI_filter ? MM_FLAG_HG_FILTER : 0) | (p.skip_self ? MM_FLAG_SKIP_SELF : 0) |
                (p.skip_prefix ? MM_FLAG_SKIP_PREFIX : 0) | (p.lower_triangular ? MM_FLAG_LOWER_TRIANGULAR : 0) |
                (p.split ? 0 : MM_FLAG_NO_SPLIT);
-    if (mm_create(&ctx_, deviceFromEnv(), &mp) != MM_OK) {
-      std::cerr << "[mashmap_hip::skch::Sketch] ERROR: " << mm_last_error(nullptr) << std::endl;
-      exit(1);
+    for (int dev : devicesFromEnv()) {
+      mm_ctx* c = nullptr;
+      if (mm_create(&c, dev, &mp) != MM_OK) {
+        std::cerr << "[mashmap_hip::skch::Sketch] ERROR: " << mm_last_error(nullptr) << std::endl;
+        exit(1);
+      }
+      ctxs_.push_back(c);
     }
+    ctx_ = ctxs_[0];
     if (!p.saveIndexFilename.empty()) mm_set_option(ctx_, MM_OPT_KEEP_FULL_INDEX, 1);
     this->build();
     if (!p.saveIndexFilename.empty()) this->saveIndex();
+    for (size_t i = 1; i < ctxs_.size(); i++)        // replicas of the resident index, GPU to GPU
+      if (mm_index_replicate(ctxs_[i], ctx_) != MM_OK) { std::cerr << "[mashmap_hip::skch::Sketch] ERROR: mm_index_replicate: " << mm_last_error(ctxs_[i]) << std::endl; exit(1); }
+    if (ctxs_.size() > 1 && mm_comm_init_local(ctxs_.data(), (int)ctxs_.size()) != MM_OK) {
+      std::cerr << "[mashmap_hip::skch::Sketch] ERROR: mm_comm_init_local: " << mm_last_error(ctx_) << std::endl; exit(1);
+    }
   }
-  ~Sketch() { mm_destroy(ctx_); }
+  ~Sketch() { for (mm_ctx* c : ctxs_) mm_destroy(c); }
   Sketch(const Sketch&) = delete;
   Sketch& operator=(const Sketch&) = delete;
 
   mm_ctx* ctx() const { return ctx_; }
+  const std::vector<mm_ctx*>& contexts() const { return ctxs_; }
 
   // Map::setRefGroups (computeMap.hpp:144): consecutive contigs with equal name prefix share a group
   std::vector<int> refGroups() const {

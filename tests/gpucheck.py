@@ -39,6 +39,7 @@ def run_and_compare(oracle, contigs, reads, k=19, L=5000, s=130, pi=0.85, flags=
     selfId = [cnames.index(n) if n in cnames else -1 for n, _ in reads]
     ctx.index_upload(ix["minmers"], ix["keys"], ix["offsets"], ix["points"], ix["freq"], ix["contigLen"], refGroup)
     ctx.set_tables(oracle.min_hits_table(s, k, pi), oracle.cutoffs(h))
+    ctx.set_replay_tables(*capi.stat_replay_tables(s, k, pi, 0.0, not (flags & U.FLAG_DROP_LOW_ID)))
     nF = ctx.reads_upload([a for _, a in reads], readGroup, selfId, seqCounterBase)
     # first the default path (interval points stay in LDS/registers: fused lookup + sort + L1), then again with the point lists
     # kept in HBM (sort + literal sweep kernels); both must reproduce the reference, and agree with each other
@@ -51,6 +52,14 @@ def run_and_compare(oracle, contigs, reads, k=19, L=5000, s=130, pi=0.85, flags=
         assert len(a) == len(b) and a.tobytes() == b.tobytes(), "fused and HBM point paths disagree on " + what
     qsk = ctx.query_sketches()
     frs = ctx.fragments()
+    # candidate mappings (k_l2_select: doL2Mapping's best-first walk on the device), fragment-major
+    recs = ctx.mappings()
+    recs_by_f, f_at = {}, 0
+    for m in recs:
+        key = (int(m["querySeqId"]) - seqCounterBase, int(m["fragStart"]))
+        while (int(frs[f_at]["readId"]), int(frs[f_at]["fragStart"])) != key:
+            f_at += 1                                    # records follow the fragment order
+        recs_by_f.setdefault(f_at, []).append(m)
     l1_by_f = {}
     for i, c in enumerate(l1):
         l1_by_f.setdefault(int(c["frag"]), []).append((i, c))
@@ -92,6 +101,16 @@ def run_and_compare(oracle, contigs, reads, k=19, L=5000, s=130, pi=0.85, flags=
                                int(x["sharedSketchSize"]), int(x["strand"])))
             nloci += len(g2)
             if g2 != e["l2"]: note("l2", f, g2[:4], e["l2"][:4])
+            else:
+                # what mapSingleQueryFrag leaves in l2Mappings (computeMap.hpp:774-800), as integers; the oracle's list is sorted by
+                # (refSeqId, refStartPos), the device's is in push order: compare as sorted lists
+                ql = int(fr["len"])
+                gm = sorted((ql, int(m["refStartPos"]), int(m["refStartPos"]) + ql, 0, ql, int(m["refSeqId"]), int(m["querySeqId"]), ql,
+                             int(m["sketchSize"]), int(m["conservedSketches"]), int(m["strand"])) for m in recs_by_f.get(f, []))
+                em = sorted(x[:11] for x in e["maps_i"])
+                if gm != em: note("mappings", f, gm[:3], em[:3])
+                for m in recs_by_f.get(f, []):
+                    if int(m["rawSketchSize"]) != e["rawSketchSize"] or int(m["fragLen"]) != ql: note("mapping.meta", f, m, e["rawSketchSize"])
     ctx.close()
     oracle.free(h)
     assert not bad, "GPU vs oracle mismatches: %r over %d fragments" % (bad, nF)

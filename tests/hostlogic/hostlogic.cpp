@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "../../mashmap_amd/host/skch_map_post.hpp"
+#include "../../mashmap_amd/csrc/mm_select_core.h"
 
 extern "C" {
 
@@ -45,6 +46,42 @@ int hl_map_read(int k, int segLength, int sketchSize, float pi, int filterMode, 
   { size_t i = 0; for (int c = 0; c <= nL1; c++) { while (i < (size_t)nL2 && D.l2[i].cand < c) i++; D.l2Begin[c] = i; } }
   skch::MappingResultsVector_t res;
   post.mapModule(D, 0, readName, readLen, seqCounter, res);
+  // The same read through the path the GPU run takes: doL2Mapping's walk in integers (mm_select_core.h: the code of k_l2_select,
+  // with the host tables of mmhost::replayTables) -> mm_mapping records -> MapPost::mapModuleFromRecords.  Must give the same rows,
+  // floats bit for bit; -2 reports a difference.
+  {
+    std::vector<uint8_t> accept; std::vector<int16_t> minIsz;
+    mmhost::replayTables(sketchSize, k, pi, p.ANIDiff, p.keep_low_pct_id, 4, accept, minIsz);
+    const size_t stride = (size_t)sketchSize + 1;
+    std::vector<int64_t> l2First((size_t)nL1, 0); std::vector<int32_t> l2Num((size_t)nL1, 0);
+    for (int c = 0; c < nL1; c++) { l2First[c] = (int64_t)D.l2Begin[c]; l2Num[c] = (int32_t)(D.l2Begin[c + 1] - D.l2Begin[c]); }
+    std::vector<int32_t> heap((size_t)nL1 + 1);
+    std::vector<int32_t> rg(grp.begin(), grp.end());
+    if (rg.empty()) rg.assign((size_t)nContigs, 0);
+    std::vector<mm_mapping> recs;
+    for (int f = 0; f < nFrags; f++) {
+      const int Qs = stats[f].sketchSize, nC = stats[f].nL1;
+      if (Qs <= 0 || nC <= 0) continue;
+      const size_t b = D.l1Begin[f];
+      mm_mapping rec; std::memset(&rec, 0, sizeof rec);
+      rec.querySeqId = seqCounter; rec.fragStart = frags[f].fragStart; rec.fragLen = frags[f].len; rec.sketchSize = Qs;
+      rec.rawSketchSize = stats[f].rawSketchSize; rec.maxHash = stats[f].maxHash;
+      mm_select_fragment(nC, D.l1.data() + b, heap.data(), l2First.data() + b, l2Num.data() + b, D.l2.data(), rg.data(), p.skip_prefix ? 1 : 0,
+                         p.stage1_topANI_filter ? 1 : 0, Qs, accept.data() + (size_t)Qs * stride, minIsz.data() + (size_t)Qs * stride,
+                         [&](const mm_l2_locus& L) { rec.refSeqId = L.seqId; rec.refStartPos = L.meanOptimalPos; rec.conservedSketches = L.sharedSketchSize; rec.strand = L.strand; recs.push_back(rec); });
+    }
+    skch::MappingResultsVector_t res2;
+    if (readLen >= k) post.mapModuleFromRecords(recs.data(), recs.data() + recs.size(), readLen, res2);
+    if (res2.size() != res.size()) return -2;
+    for (size_t i = 0; i < res.size(); i++) {
+      const auto& a = res[i]; const auto& b2 = res2[i];
+      if (a.queryLen != b2.queryLen || a.refStartPos != b2.refStartPos || a.refEndPos != b2.refEndPos || a.queryStartPos != b2.queryStartPos ||
+          a.queryEndPos != b2.queryEndPos || a.refSeqId != b2.refSeqId || a.querySeqId != b2.querySeqId || a.blockLength != b2.blockLength ||
+          a.sketchSize != b2.sketchSize || a.conservedSketches != b2.conservedSketches || a.strand != b2.strand || a.approxMatches != b2.approxMatches ||
+          a.n_merged != b2.n_merged || std::memcmp(&a.nucIdentity, &b2.nucIdentity, 4) || std::memcmp(&a.nucIdentityUpperBound, &b2.nucIdentityUpperBound, 4) ||
+          a.kmerComplexity != b2.kmerComplexity) return -2;
+    }
+  }
   std::ostringstream os;
   post.reportReadMappings(res, readName, os);
   const std::string txt = os.str();

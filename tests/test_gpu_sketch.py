@@ -68,11 +68,15 @@ def test_sketch_adversarial(oracle):
     _check(oracle, reads)
 
 
-# every k-mer size the kernels are compiled for beyond the default: the word layout of the hash (blocks, 8-byte and shorter tail
+# every k-mer size 1..32 (the kernels are compiled for all of them): the word layout of the hash (blocks, 8-byte and shorter tail
 # words, the one group shorter than 4 bases) differs for each of them
 @pytest.mark.parametrize("k,s,L", [(16, 60, 1000), (19, 498, 5000), (19, 40, 10000), (15, 200, 3000), (21, 130, 5000), (32, 100, 2500), (11, 30, 500),
                                    (17, 70, 1200), (18, 90, 2000), (20, 80, 2000), (22, 64, 1500), (23, 75, 2500), (24, 100, 4000), (25, 50, 1000),
-                                   (27, 130, 5000), (29, 40, 800), (31, 100, 3000), (12, 25, 600), (13, 40, 900), (14, 33, 700)])
+                                   (27, 130, 5000), (29, 40, 800), (31, 100, 3000), (12, 25, 600), (13, 40, 900), (14, 33, 700),
+                                   (26, 90, 3000), (28, 120, 4000), (30, 77, 2000),                    # even sizes above 25
+                                   (10, 20, 400), (9, 16, 300), (8, 12, 300), (7, 10, 200), (6, 8, 200), (5, 6, 150), (4, 5, 100), (3, 4, 100),
+                                   (2, 3, 64), (1, 2, 64),                                             # the reference takes any -k (parseCmdArgs.hpp:435)
+                                   (19, 1100, 10000), (19, 1279, 12000)])                              # sketches beyond 1024 entries
 def test_sketch_parameter_grid(oracle, k, s, L):
     g = U.random_dna(11, 200000)
     reads = [a for _, a, _ in U.sample_reads([g], 5 + k, 12, 2 * L + 123, 0.08)]

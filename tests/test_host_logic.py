@@ -30,6 +30,7 @@ def hl():
     so = os.path.join(HL_DIR, "libhostlogic.so")
     src = os.path.join(HL_DIR, "hostlogic.cpp")
     hdrs = [os.path.join(ROOT, "mashmap_amd", "host", f) for f in ("skch_map_post.hpp", "skch_types.hpp", "mm_stats.hpp")]
+    hdrs += [os.path.join(ROOT, "mashmap_amd", "csrc", f) for f in ("mm_select_core.h", "mm_heap.h")]
     if not os.path.exists(so) or any(os.path.getmtime(x) > os.path.getmtime(so) for x in [src] + hdrs):
         subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-Wno-sign-compare", "-o", so, src])
     lib = C.CDLL(so)
@@ -62,6 +63,7 @@ def run_host_logic(lib, P, contigs, groups, name, read_len, seq_counter, frag_ro
                         grp.ctypes.data_as(vp) if grp is not None else None, name.encode(), C.c_int(read_len), C.c_int(seq_counter),
                         C.c_int(nF), frags.ctypes.data_as(vp), stats.ctypes.data_as(vp), C.c_int(len(l1)), l1.ctypes.data_as(vp),
                         C.c_int(len(l2)), l2.ctypes.data_as(vp), out, C.c_int(256), paf, C.c_int(1 << 16))
+    assert n != -2, "the integer walk of k_l2_select + MapPost::mapModuleFromRecords disagree with the float replay"
     assert 0 <= n <= 256
     return [out[i].ikey() for i in range(n)], [out[i].fkey() for i in range(n)], paf.value.decode()
 
