@@ -156,16 +156,23 @@ def cpu_baseline(W, ref_np, reads_np, n_sample):
             compute = None
             if best and os.path.exists(prof_bin):
                 p = subprocess.run([prof_bin] + common + ["-t", str(best[1])], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+                # lines "seqCounter len tL1 tL2 tFragment" (computeMap.hpp:802-811); the pool's threads write them unsynchronised, so only
+                # lines that parse cleanly are used and their mean is scaled to the number of fragments of the sample
                 tot = 0.0; nfr = 0
                 for line in p.stderr.splitlines():
                     f = line.split()
-                    if len(f) == 5 and f[0].isdigit() and f[1].isdigit():
+                    if len(f) == 5 and f[0].isdigit() and f[1] == str(W["seg"]):
                         try:
-                            tot += float(f[4]); nfr += 1
+                            t = [float(x) for x in f[2:]]
                         except ValueError:
-                            pass
+                            continue
+                        if all(0 <= x < 10 for x in t) and abs(t[0] + t[1] - t[2]) < 1e-3:
+                            tot += t[2]; nfr += 1
+                if nfr:
+                    tot = tot / nfr * (n_sample * (read_len // W["seg"] + (1 if read_len % W["seg"] else 0)))
                 if p.returncode == 0 and nfr:
-                    compute = {"fragments": nfr, "sum_fragment_seconds": round(tot, 3),
+                    compute = {"what": "-DENABLE_TIME_PROFILE_L1_L2 build of the reference: per-fragment sketch+L1+L2 seconds, no reader, no pool overhead "
+                                       "(SURVEY section 8d(b)); per core, and x host cores as the ideally fed pool", "fragments_parsed": nfr, "sum_fragment_seconds": round(tot, 3),
                                "gbps_per_core": round(n_sample * read_len / tot / 1e9, 5),
                                "gbps_all_cores_ideal": round(n_sample * read_len / tot / 1e9 * ncores, 3)}
             if best:

@@ -1,0 +1,45 @@
+#!/bin/bash
+# One GPU-box visit.  usage: scripts/gpu_visit.sh TAG [steps...]   steps: tests probe bench small34 trace pmc
+TAG=${1:-r02x}; shift
+STEPS=${@:-tests bench}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || true
+for S in $STEPS; do
+case $S in
+tests)
+  echo "== pytest -m gpu" | tee -a $OUT/log.txt
+  timeout 1500 python -m pytest tests -m gpu -q --maxfail=12 --timeout 900 2>&1 | tail -60 | tee -a $OUT/log.txt ;;
+smoke)
+  timeout 300 python __graft_entry__.py smoke 2>&1 | tail -3 | tee -a $OUT/log.txt ;;
+probe)
+  echo "== valu_rate probe" | tee -a $OUT/log.txt
+  timeout 300 scripts/probes/valu_rate.bin > $OUT/valu_rate.txt 2>&1; tail -60 $OUT/valu_rate.txt | tee -a $OUT/log.txt ;;
+bench)
+  echo "== bench" | tee -a $OUT/log.txt
+  MM_DEBUG=1 timeout 900 python bench.py --steps 5 --warmup 2 > $OUT/bench.json 2> $OUT/bench.err
+  grep -v "^\[mm\] sketch" $OUT/bench.err | tail -12 | tee -a $OUT/log.txt; cat $OUT/bench.json | tee -a $OUT/log.txt ;;
+small34)
+  echo "== configs3 / configs4 scaled down" | tee -a $OUT/log.txt
+  timeout 900 python bench.py --steps 3 --warmup 1 --workload configs3 --reads 100000 --ref-contigs 3 --no-cpu-baseline > $OUT/bench_c3s.json 2> $OUT/bench_c3s.err
+  tail -4 $OUT/bench_c3s.err | tee -a $OUT/log.txt; cat $OUT/bench_c3s.json | tee -a $OUT/log.txt
+  timeout 900 python bench.py --steps 3 --warmup 1 --workload configs4 --reads 60000 --ref-contigs 2 --ref-contig-len 150000000 --no-cpu-baseline > $OUT/bench_c4s.json 2> $OUT/bench_c4s.err
+  tail -4 $OUT/bench_c4s.err | tee -a $OUT/log.txt; cat $OUT/bench_c4s.json | tee -a $OUT/log.txt ;;
+trace)
+  echo "== rocprofv3 kernel trace" | tee -a $OUT/log.txt
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-path > $OUT/trace_bench.json 2> $OUT/trace.err
+  find $OUT/trace -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv
+  rm -rf $OUT/trace
+  head -14 $OUT/kernel_stats.csv | cut -c1-200 | tee -a $OUT/log.txt ;;
+pmc)
+  for C in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU; do
+    echo "== pmc $C" | tee -a $OUT/log.txt
+    timeout 900 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$C -o pmc -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-host-path > /dev/null 2> $OUT/pmc_$C.err
+    python scripts/pmc_summary.py $OUT/pmc_$C $C > $OUT/pmc_$C.csv 2>> $OUT/log.txt
+    rm -rf $OUT/pmc_$C
+    cat $OUT/pmc_$C.csv | tee -a $OUT/log.txt
+  done ;;
+esac
+done
+echo "== done" | tee -a $OUT/log.txt

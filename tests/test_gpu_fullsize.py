@@ -46,9 +46,10 @@ def test_configs1_full_size(oracle):
     from mashmap_amd import capi
 
     dev = torch.device("cuda", 0)
-    contigs_t = B.make_reference(torch, dev, B.REF_CONTIGS, B.REF_CONTIG_LEN)
+    W1 = B.WORKLOADS["configs1"]
+    contigs_t = B.make_reference(torch, dev, W1["ref_contigs"], W1["ref_contig_len"])
     ref_np = [c.cpu().numpy() for c in contigs_t]
-    reads_t = B.make_reads(torch, dev, contigs_t, N_READS, READ_LEN, B.ERR, seed=1000)
+    reads_t = B.make_reads(torch, dev, contigs_t, N_READS, READ_LEN, W1["err"], seed=1000)
     torch.cuda.synchronize()
 
     # ---- the index, full size, against the oracle ----
