@@ -14,7 +14,7 @@ static const char* kKernelNames[MM_K_COUNT] = {
 std::vector<DevBuf*> mm_ctx::allBufs() {
   DeviceIndex& I = idx;
   return {&I.evKey, &I.evAux, &I.evHash, &I.contigOff, &I.opKey, &I.opAux, &I.opHash, &I.blockOff, &I.evBlock, &I.contigBlock, &I.contigLen, &I.refGroup,
-          &I.htSlots, &I.filter, &I.ptKeys, &dMinHits, &dCutoffs, &dAscii, &dReadSrcOff, &dReadPackOff, &dReadLen, &dReadGroup, &dReadSelf, &dReadHasN,
+          &I.htSlots, &I.filter, &I.ptKeys, &I.keys, &I.keyOff, &I.keyFreq, &dMinHits, &dCutoffs, &dAscii, &dReadSrcOff, &dReadPackOff, &dReadLen, &dReadGroup, &dReadSelf, &dReadHasN,
           &dBases2, &dNmask, &dFrags, &dSkHash, &dSkPos, &dSkStrand, &dSkCount, &dHardList, &dCounters, &dSketchTabs, &dQHash, &dQStrand, &dSeedVal,
           &dStats, &dPtOff, &dPts, &dL1, &dL1b, &dL1Cursors, &dL1Off, &dL2, &dL2Info, &dL2Cnt, &dL2Off, &dL2Ops, &dScanTmp, &dL2Tmp, &dL2Wide,
           &dListB, &dListC, &dBigList, &dL2First, &dL2Num, &dAccept, &dMinIsz, &dSelCnt, &dSelOff, &dSelHeap, &dFragTab, &dMappings, &dCommCounts, &dGathered};
@@ -96,6 +96,7 @@ int mm_index_upload(mm_ctx* c, const mm_minmer* minmers, size_t nMinmers, const 
     c->err = "mm_index_upload: null argument"; return MM_ERR_ARG;
   }
   MM_HIP(c, hipSetDevice(c->device));
+  c->mirrorMinmers = c->mirrorMap = false;
   c->hMinmers.assign(minmers, minmers + nMinmers);
   c->hKeys.assign(keys, keys + nKeys);
   c->hOffsets.assign(offsets, offsets + nKeys + (nKeys ? 1 : 0));
@@ -321,9 +322,9 @@ int mm_results_copy_device(mm_ctx* c, mm_l2_locus* dDst, size_t cap, size_t* n) 
 
 int mm_index_sizes(const mm_ctx* c, size_t* nMinmers, size_t* nKeys, size_t* nPoints, size_t* nFreq, int32_t* freqThreshold) {
   if (!c->idx.ready) return MM_ERR_STATE;
-  if (nMinmers) *nMinmers = c->hMinmers.size();
-  if (nKeys) *nKeys = c->hKeys.size();
-  if (nPoints) *nPoints = c->hPoints.size();
+  if (nMinmers) *nMinmers = c->idx.nRec;
+  if (nKeys) *nKeys = c->idx.nKeys;
+  if (nPoints) *nPoints = c->idx.nPoints;
   if (nFreq) *nFreq = c->hFreq.size();
   if (freqThreshold) *freqThreshold = c->freqThreshold;
   return MM_OK;
@@ -331,6 +332,10 @@ int mm_index_sizes(const mm_ctx* c, size_t* nMinmers, size_t* nKeys, size_t* nPo
 
 int mm_index_download(mm_ctx* c, mm_minmer* minmers, uint64_t* keys, uint64_t* offsets, mm_interval_point* points, uint64_t* freqSeeds) {
   if (!c->idx.ready) { c->err = "mm_index_download: no index resident"; return MM_ERR_STATE; }
+  if (c->idx.keys.bytes == 0 && c->idx.nKeys) { c->err = "mm_index_download: this context holds a replica (mm_index_replicate); ask the context the index was built on"; return MM_ERR_STATE; }
+  MM_HIP(c, hipSetDevice(c->device));
+  if (minmers) { const int rc = mm_mirror_minmers(c); if (rc != MM_OK) return rc; }
+  if (keys || offsets || points) { const int rc = mm_mirror_map(c); if (rc != MM_OK) return rc; }
   if (minmers && !c->hMinmers.empty()) std::memcpy(minmers, c->hMinmers.data(), c->hMinmers.size() * sizeof(mm_minmer));
   if (keys && !c->hKeys.empty()) std::memcpy(keys, c->hKeys.data(), c->hKeys.size() * 8);
   if (offsets) std::memcpy(offsets, c->hOffsets.data(), c->hOffsets.size() * 8);

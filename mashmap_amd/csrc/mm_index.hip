@@ -12,7 +12,10 @@
 #include "mm_device.h"
 #include "mm_winnow.h"
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <deque>
 #include <future>
@@ -198,49 +201,16 @@ static HashContigFn pick_hasher(int k) {
 static int finalize_index(mm_ctx* c, std::vector<mm_minmer>& all, bool haveMap, float kmerPctThreshold, const int32_t* contigLen,
                           const int32_t* refGroup, size_t nContigs) {
   if (!haveMap) {
-    // Grouping by hash with the records of a hash in minmerIndex order is a stable sort of (hash, index) pairs; the map's
-    // "previous point of this hash ends where this record starts" test (winSketch.hpp:388-396) then only looks at the
-    // neighbour.  Keys come out ascending, which is the order mm_index_download promises.
-    const size_t nAll = all.size();
-    std::vector<std::pair<uint64_t, uint32_t>> byHash(nAll);
-    {
-      const unsigned T = (unsigned)std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), std::max<size_t>(1, nAll / 65536));
-      std::vector<size_t> cut(T + 1);
-      for (unsigned t = 0; t <= T; t++) cut[t] = nAll * t / T;
-      std::vector<std::future<void>> jobs;
-      for (unsigned t = 0; t < T; t++)
-        jobs.push_back(std::async(std::launch::async, [&, t]() {
-          for (size_t i = cut[t]; i < cut[t + 1]; i++) byHash[i] = std::make_pair(all[i].hash, (uint32_t)i);
-          std::sort(byHash.begin() + cut[t], byHash.begin() + cut[t + 1]);
-        }));
-      for (auto& j : jobs) j.get();
-      for (unsigned width = 1; width < T; width *= 2) {                      // pairwise merges, each level in parallel
-        jobs.clear();
-        for (unsigned t = 0; t + width < T; t += 2 * width) {
-          const size_t lo = cut[t], mid = cut[t + width], hi = cut[std::min(T, t + 2 * width)];
-          jobs.push_back(std::async(std::launch::async, [&, lo, mid, hi]() { std::inplace_merge(byHash.begin() + lo, byHash.begin() + mid, byHash.begin() + hi); }));
-        }
-        for (auto& j : jobs) j.get();
-      }
-    }
-    c->hKeys.clear(); c->hOffsets.clear(); c->hPoints.clear(); c->hFreq.clear();
-    c->hPoints.reserve(2 * nAll);
-    for (size_t i = 0; i < nAll;) {                                          // Sketch::index (winSketch.hpp:379-404)
-      const uint64_t key = byHash[i].first;
-      c->hKeys.push_back(key); c->hOffsets.push_back((uint64_t)c->hPoints.size());
-      for (; i < nAll && byHash[i].first == key; i++) {
-        const mm_minmer& mi = all[byHash[i].second];
-        if (c->hPoints.size() == c->hOffsets.back() || c->hPoints.back().pos != mi.wpos) {
-          mm_interval_point a2; std::memset(&a2, 0, sizeof a2); a2.pos = mi.wpos; a2.hash = mi.hash; a2.seqId = mi.seqId; a2.side = 1;
-          mm_interval_point b2 = a2; b2.pos = mi.wpos_end; b2.side = -1;
-          c->hPoints.push_back(a2); c->hPoints.push_back(b2);
-        } else c->hPoints.back().pos = mi.wpos_end;
-      }
-    }
-    c->hOffsets.push_back((uint64_t)c->hPoints.size());
-    std::vector<std::pair<uint64_t, uint32_t>>().swap(byHash);
+    // mm_index_build: Sketch::index, the frequency filter and the flat index on the device (mm_index_dev.hip); the host copies behind
+    // mm_index_download are filled from the device on request
+    c->hKeys.clear(); c->hOffsets.clear(); c->hPoints.clear(); c->hFreq.clear(); c->hMinmers.clear();
+    c->mirrorMinmers = c->mirrorMap = false;
+    const int rc = mm_finalize_index_device(c, all.data(), all.size(), kmerPctThreshold, contigLen, refGroup, nContigs);
+    if (c->keepFullIndex) c->hMinmersAll.swap(all); else std::vector<mm_minmer>().swap(c->hMinmersAll);
+    return rc;
   }
-  // frequency filter (winSketch.hpp:410-504)
+  // --loadIndex: the lookup map comes from the file (it is not re-derived), so the threshold is taken from it here, as
+  // computeFreqHist / computeFreqSeedSet / dropFreqSeedSet do (winSketch.hpp:410-504)
   int32_t freqThreshold = 0x7fffffff;
   const size_t nKeysAll = c->hKeys.size();
   if (nKeysAll) {
@@ -274,6 +244,9 @@ extern "C" int mm_index_build(mm_ctx* c, const char* bases, const int64_t* conti
   const int k = c->P.kmerSize, w = c->P.segLength, s = c->P.sketchSize;
   HashContigFn hasher = pick_hasher(k);
   if (!hasher) { c->err = "mm_index_build: kmerSize not compiled in"; return MM_ERR_ARG; }
+  const bool dbg = getenv("MM_DEBUG") != nullptr;
+  const auto tStart = std::chrono::steady_clock::now();
+  auto since = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - tStart).count(); };
   std::vector<int32_t> clen(nContigs);
   std::vector<std::vector<mm_minmer>> per(nContigs);
   std::deque<std::future<void>> inflight;
@@ -299,14 +272,29 @@ extern "C" int mm_index_build(mm_ctx* c, const char* bases, const int64_t* conti
       dst->swap(*rec);
     }));
   }
+  if (dbg) fprintf(stderr, "[mm] index: hash + winnow of %zu contigs issued at %.2f s\n", nContigs, since());
   while (!inflight.empty()) { inflight.front().get(); inflight.pop_front(); }
+  if (dbg) fprintf(stderr, "[mm] index: host tails (stitch, sort, unique) done at %.2f s\n", since());
   dAscii.release(); dB.release(); dM.release(); dMeta.release(); dH.release(); dS.release(); wb.release();
   if (rc != MM_OK) return rc;
 
   // Sketch::index (winSketch.hpp:379-404): per-hash OPEN/CLOSE points in minmerIndex order, adjacent runs merged
   std::vector<mm_minmer> all;
-  { size_t tot = 0; for (auto& v : per) tot += v.size(); all.reserve(tot); for (auto& v : per) { all.insert(all.end(), v.begin(), v.end()); std::vector<mm_minmer>().swap(v); } }
-  return finalize_index(c, all, false, kmerPctThreshold, clen.data(), refGroup, nContigs);
+  {
+    std::vector<size_t> at(nContigs + 1, 0);
+    for (size_t ci = 0; ci < nContigs; ci++) at[ci + 1] = at[ci] + per[ci].size();
+    all.resize(at[nContigs]);
+    std::atomic<size_t> next(0);
+    auto copy = [&]() { for (size_t ci = next.fetch_add(1); ci < nContigs; ci = next.fetch_add(1)) { if (!per[ci].empty()) std::memcpy(all.data() + at[ci], per[ci].data(), per[ci].size() * sizeof(mm_minmer)); std::vector<mm_minmer>().swap(per[ci]); } };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < std::min<unsigned>(maxJobs, 16); t++) th.emplace_back(copy);
+    copy();
+    for (auto& t : th) t.join();
+  }
+  if (dbg) fprintf(stderr, "[mm] index: %zu records concatenated at %.2f s\n", all.size(), since());
+  const int frc = finalize_index(c, all, false, kmerPctThreshold, clen.data(), refGroup, nContigs);
+  if (dbg) fprintf(stderr, "[mm] index: Sketch::index + frequency filter + flat index on the device done at %.2f s (%zu keys, %zu points)\n", since(), c->idx.nKeys, c->idx.nPoints);
+  return frc;
 }
 
 extern "C" int mm_index_upload_full(mm_ctx* c, const mm_minmer* minmersAll, size_t nMinmers, const uint64_t* keys, const uint64_t* offsets,

@@ -57,6 +57,7 @@ struct DeviceIndex {
   DevBuf htSlots;              // {uint64 key, uint64 val}[htCap]; val = offset<<24 | count<<1 | freq (one 16-byte slot per probe)
   DevBuf filter; uint64_t filterMask = 0;   // presence bitmap in front of htSlots (bit (key>>32) & filterMask); mask 0 = disabled
   DevBuf ptKeys;               // uint64[nPoints]: seqId<<33 | pos<<1 | (side==OPEN)
+  DevBuf keys, keyOff, keyFreq; // the lookup map's key table in the order of ptKeys: uint64 key, uint64 first point (nKeys + 1), uint8 isFrequent
   bool ready = false;
 };
 
@@ -72,6 +73,7 @@ struct mm_ctx {
   bool keepFullIndex = false;
   std::vector<uint64_t> hKeys, hOffsets, hFreq;
   std::vector<mm_interval_point> hPoints;
+  bool mirrorMinmers = false, mirrorMap = false;        // the host copies above are filled (a device-built index fills them on request)
   int32_t freqThreshold = 0x7fffffff;
 
   DeviceIndex idx;
@@ -144,4 +146,9 @@ int mm_launch_map(mm_ctx* c);
 int mm_launch_select(mm_ctx* c);
 void mm_comm_release(mm_ctx* c);
 int mm_launch_l2(mm_ctx* c, unsigned long long* cnt);   // cnt: device counters [4] cursor [5] overflow [6] slot overflow
-int mm_build_device_index(mm_ctx* c, const int32_t* contigLen, const int32_t* refGroup, size_t nContigs);
+int mm_build_device_index(mm_ctx* c, const int32_t* contigLen, const int32_t* refGroup, size_t nContigs);   // from the host mirrors
+int mm_flatten_device_index(mm_ctx* c, const mm_minmer* dRec, size_t n, size_t nk, size_t np, const int32_t* contigLen, const int32_t* refGroup, size_t nContigs);
+int mm_finalize_index_device(mm_ctx* c, const mm_minmer* hAll, size_t nAll, float kmerPctThreshold, const int32_t* contigLen, const int32_t* refGroup, size_t nContigs);
+int mm_mirror_minmers(mm_ctx* c);
+int mm_mirror_map(mm_ctx* c);
+int mm_scan_i32_to_i64(mm_ctx* c, int64_t n, const int32_t* dIn, int64_t* dOut, int64_t* total);

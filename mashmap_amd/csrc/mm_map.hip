@@ -23,136 +23,30 @@ static inline uint64_t pack_point(int32_t seqId, int32_t pos, int side) {
   return ((uint64_t)(uint32_t)seqId << 33) | ((uint64_t)(uint32_t)pos << 1) | (side == 1 ? 1ull : 0ull);
 }
 
+// The index as the reference holds it (host mirrors: minmerIndex after dropFreqSeedSet, the lookup map flattened, the frequent seeds)
+// -> device arrays -> mm_flatten_device_index (mm_index_dev.hip), which builds everything Map reads on the GPU.
 int mm_build_device_index(mm_ctx* c, const int32_t* contigLen, const int32_t* refGroup, size_t nContigs) {
   DeviceIndex& I = c->idx;
   I.ready = false;
   const size_t n = c->hMinmers.size(), nk = c->hKeys.size(), np = c->hPoints.size();
-  // L2 event stream of every contig: an insert event per record at wpos (minmerIndex order) and an eviction event at
-  // wpos_end (replaces the reference's per-candidate heap of open windows, computeMap.hpp:1344-1367), merged by position;
-  // an eviction sorts before an insert at the same position because the reference evicts while wpos_end <= wpos.
-  //   evKey = pos*2 + isInsert,  evAux = insert ? (wpos_end | REV<<31) : 0,  evHash = the record's hash
-  std::vector<uint32_t> evKey(2 * n), evAux(2 * n); std::vector<uint64_t> evHash(2 * n);
-  std::vector<int64_t> coff(nContigs + 1, 0);
-  {
-    size_t i = 0;
-    for (size_t sId = 0; sId < nContigs; sId++) {
-      coff[sId] = (int64_t)(2 * i);
-      while (i < n && c->hMinmers[i].seqId == (int32_t)sId) i++;
-    }
-    coff[nContigs] = (int64_t)(2 * i);
-    if (i != n) { c->err = "mm_index_upload: minmerIndex is not grouped by ascending seqId"; return MM_ERR_ARG; }
-  }
-  for (size_t i = 0; i < n; i++) {
-    const mm_minmer& m = c->hMinmers[i];
-    if (m.wpos < 0 || m.wpos_end < 0) { c->err = "mm_index_upload: negative minmer position"; return MM_ERR_ARG; }
-  }
-  {
-    std::vector<uint32_t> order;
-    for (size_t sId = 0; sId < nContigs; sId++) {
-      const size_t b0 = (size_t)coff[sId] / 2, e0 = (size_t)coff[sId + 1] / 2;
-      order.resize(e0 - b0);
-      std::iota(order.begin(), order.end(), 0u);
-      std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return c->hMinmers[b0 + x].wpos_end < c->hMinmers[b0 + y].wpos_end; });
-      size_t ii = 0, dd = 0, o = (size_t)coff[sId];
-      const size_t cnt = e0 - b0;
-      while (ii < cnt || dd < cnt) {
-        const bool takeDel = dd < cnt && (ii >= cnt || (uint32_t)c->hMinmers[b0 + order[dd]].wpos_end * 2u < (uint32_t)c->hMinmers[b0 + ii].wpos * 2u + 1u);
-        if (takeDel) { const mm_minmer& m = c->hMinmers[b0 + order[dd]]; evKey[o] = (uint32_t)m.wpos_end * 2u; evAux[o] = 0; evHash[o] = m.hash; dd++; }
-        else { const mm_minmer& m = c->hMinmers[b0 + ii]; evKey[o] = (uint32_t)m.wpos * 2u + 1u; evAux[o] = (uint32_t)m.wpos_end | (m.strand < 0 ? 0x80000000u : 0u); evHash[o] = m.hash; ii++; }
-        o++;
-      }
-    }
-  }
-  // records open at every block boundary B = b << MM_OPEN_BLOCK_SHIFT: wpos < B < wpos_end, in index order.  A record is at most
-  // maxLen positions long, so the candidates for B are the records with wpos in [B - maxLen, B).
-  std::vector<uint32_t> opKey, opAux; std::vector<uint64_t> opHash;
-  std::vector<int64_t> blockOff(1, 0), contigBlock(nContigs + 1, 0);
-  std::vector<int64_t> evBlock;                          // first event of every block (pos >= B), + one sentinel per contig
-  {
-    int64_t maxLen = 0;
-    for (size_t i = 0; i < n; i++) maxLen = std::max<int64_t>(maxLen, (int64_t)c->hMinmers[i].wpos_end - c->hMinmers[i].wpos);
-    for (size_t sId = 0; sId < nContigs; sId++) {
-      contigBlock[sId] = (int64_t)blockOff.size() - 1;
-      const size_t b0 = (size_t)coff[sId] / 2, e0 = (size_t)coff[sId + 1] / 2;
-      int64_t lastPos = contigLen[sId];
-      if (e0 > b0) lastPos = std::max<int64_t>(lastPos, c->hMinmers[e0 - 1].wpos);
-      const int64_t nBlk = (lastPos >> MM_OPEN_BLOCK_SHIFT) + 1;
-      size_t lo = b0, hi = b0;
-      int64_t ev = coff[sId];
-      for (int64_t b = 0; b < nBlk; b++) {
-        const int64_t B = b << MM_OPEN_BLOCK_SHIFT;
-        while (ev < coff[sId + 1] && (int64_t)(evKey[(size_t)ev] >> 1) < B) ev++;
-        evBlock.push_back(ev);
-        while (hi < e0 && c->hMinmers[hi].wpos < B) hi++;
-        while (lo < hi && c->hMinmers[lo].wpos < B - maxLen) lo++;
-        for (size_t i = lo; i < hi; i++) {
-          const mm_minmer& m = c->hMinmers[i];
-          if ((int64_t)m.wpos_end > B) {
-            opKey.push_back((uint32_t)m.wpos * 2u + 1u); opAux.push_back((uint32_t)m.wpos_end | (m.strand < 0 ? 0x80000000u : 0u)); opHash.push_back(m.hash);
-          }
-        }
-        blockOff.push_back((int64_t)opKey.size());
-      }
-    }
-    contigBlock[nContigs] = (int64_t)blockOff.size() - 1;
-    evBlock.push_back(coff[nContigs]);
-  }
-  size_t cap = 16; while (cap < 2 * nk + 2) cap <<= 1;
-  std::vector<uint64_t> hs(2 * cap, 0);                 // interleaved {key, val} slots
-  for (size_t i = 0; i < cap; i++) hs[2 * i] = MM_EMPTY;
-  for (size_t i = 0; i < nk; i++) {
-    const uint64_t key = c->hKeys[i];
-    uint64_t off = c->hOffsets[i], cnt = c->hOffsets[i + 1] - c->hOffsets[i];
-    const bool freq = std::binary_search(c->hFreq.begin(), c->hFreq.end(), key);
-    // a frequent seed is removed from the query sketch before any lookup (getSeedHits, computeMap.hpp:834-837): its point list is
-    // never read on the device, so however long it is (satellite arrays) it needs no room in the packed value
-    if (freq) { off = 0; cnt = 0; }
-    if (cnt >= (1ull << 23) || off >= (1ull << 40)) { c->err = "mm_index_upload: a non-frequent seed with 2^23 or more interval points (or 2^40 points in total) does not fit the packed table value"; return MM_ERR_ARG; }
-    size_t slot = (size_t)key & (cap - 1);
-    while (hs[2 * slot] != MM_EMPTY) { if (hs[2 * slot] == key) { c->err = "mm_index_upload: duplicate key"; return MM_ERR_ARG; } slot = (slot + 1) & (cap - 1); }
-    hs[2 * slot] = key; hs[2 * slot + 1] = (off << 24) | (cnt << 1) | (freq ? 1ull : 0ull);
-  }
-  // presence filter in front of the table: one bit per key at (key >> 32) mod bits, >= 16 bits per key while that stays
-  // cache-sized (<= 64 MiB, Infinity Cache / L2 resident); most query seeds are absent from the index (sequencing errors),
-  // and an absent seed then costs a cached bit test instead of a random HBM sector.  Disabled (mask 0) for larger indexes.
-  uint64_t fbits = 1024; while (fbits < 16 * (uint64_t)nk) fbits <<= 1;
-  if (const char* e = getenv("MM_FILTER_BITS_PER_KEY")) { const uint64_t b = strtoull(e, nullptr, 10); fbits = 1024; while (b && fbits < b * (uint64_t)nk) fbits <<= 1; if (!b) fbits = 0; }
-  if (fbits / 8 > (64ull << 20)) fbits = 0;
-  std::vector<uint32_t> flt(fbits ? fbits / 32 : 1, 0u);
-  if (fbits) for (size_t i = 0; i < nk; i++) { const uint64_t b = (c->hKeys[i] >> 32) & (fbits - 1); flt[b >> 5] |= 1u << (b & 31); }
+  MM_HIP(c, c->dCounters.ensure(256));
   std::vector<uint64_t> pk(np);
   for (size_t i = 0; i < np; i++) pk[i] = pack_point(c->hPoints[i].seqId, c->hPoints[i].pos, c->hPoints[i].side);
-  std::vector<int32_t> grp(nContigs, 0);
-  if (refGroup) grp.assign(refGroup, refGroup + nContigs);
-
-  MM_HIP(c, I.evKey.ensure(2 * n * 4 + 256)); MM_HIP(c, I.evAux.ensure(2 * n * 4 + 256)); MM_HIP(c, I.evHash.ensure(2 * n * 8 + 512));
-  MM_HIP(c, I.contigOff.ensure((nContigs + 1) * 8)); MM_HIP(c, I.contigLen.ensure(nContigs * 4)); MM_HIP(c, I.refGroup.ensure(nContigs * 4));
-  MM_HIP(c, I.htSlots.ensure(cap * 16)); MM_HIP(c, I.ptKeys.ensure(np * 8 + 64)); MM_HIP(c, I.filter.ensure(flt.size() * 4));
-  MM_HIP(c, hipMemcpyAsync(I.filter.p, flt.data(), flt.size() * 4, hipMemcpyHostToDevice, c->stream));
-  I.filterMask = fbits ? fbits - 1 : 0;
-  if (n) { MM_HIP(c, hipMemcpyAsync(I.evKey.p, evKey.data(), 2 * n * 4, hipMemcpyHostToDevice, c->stream));
-           MM_HIP(c, hipMemcpyAsync(I.evAux.p, evAux.data(), 2 * n * 4, hipMemcpyHostToDevice, c->stream));
-           MM_HIP(c, hipMemcpyAsync(I.evHash.p, evHash.data(), 2 * n * 8, hipMemcpyHostToDevice, c->stream)); }
-  MM_HIP(c, hipMemcpyAsync(I.contigOff.p, coff.data(), (nContigs + 1) * 8, hipMemcpyHostToDevice, c->stream));
-  {
-    const size_t no = opKey.size();
-    MM_HIP(c, I.opKey.ensure(no * 4 + 256)); MM_HIP(c, I.opAux.ensure(no * 4 + 256)); MM_HIP(c, I.opHash.ensure(no * 8 + 512));
-    MM_HIP(c, I.blockOff.ensure(blockOff.size() * 8)); MM_HIP(c, I.contigBlock.ensure((nContigs + 1) * 8));
-    if (no) { MM_HIP(c, hipMemcpyAsync(I.opKey.p, opKey.data(), no * 4, hipMemcpyHostToDevice, c->stream));
-              MM_HIP(c, hipMemcpyAsync(I.opAux.p, opAux.data(), no * 4, hipMemcpyHostToDevice, c->stream));
-              MM_HIP(c, hipMemcpyAsync(I.opHash.p, opHash.data(), no * 8, hipMemcpyHostToDevice, c->stream)); }
-    MM_HIP(c, hipMemcpyAsync(I.blockOff.p, blockOff.data(), blockOff.size() * 8, hipMemcpyHostToDevice, c->stream));
-    MM_HIP(c, I.evBlock.ensure(evBlock.size() * 8));
-    MM_HIP(c, hipMemcpyAsync(I.evBlock.p, evBlock.data(), evBlock.size() * 8, hipMemcpyHostToDevice, c->stream));
-    MM_HIP(c, hipMemcpyAsync(I.contigBlock.p, contigBlock.data(), (nContigs + 1) * 8, hipMemcpyHostToDevice, c->stream));
-  }
-  MM_HIP(c, hipMemcpyAsync(I.contigLen.p, contigLen, nContigs * 4, hipMemcpyHostToDevice, c->stream));
-  MM_HIP(c, hipMemcpyAsync(I.refGroup.p, grp.data(), nContigs * 4, hipMemcpyHostToDevice, c->stream));
-  MM_HIP(c, hipMemcpyAsync(I.htSlots.p, hs.data(), cap * 16, hipMemcpyHostToDevice, c->stream));
+  std::vector<uint8_t> fq(nk, 0);
+  for (size_t i = 0; i < nk; i++) fq[i] = std::binary_search(c->hFreq.begin(), c->hFreq.end(), c->hKeys[i]) ? 1 : 0;
+  DevBuf dRec;
+  MM_HIP(c, dRec.ensure(n * sizeof(mm_minmer) + 64));
+  MM_HIP(c, I.keys.ensure(nk * 8 + 64)); MM_HIP(c, I.keyOff.ensure((nk + 1) * 8 + 64)); MM_HIP(c, I.keyFreq.ensure(nk + 64)); MM_HIP(c, I.ptKeys.ensure(np * 8 + 64));
+  if (n) MM_HIP(c, hipMemcpyAsync(dRec.p, c->hMinmers.data(), n * sizeof(mm_minmer), hipMemcpyHostToDevice, c->stream));
+  if (nk) { MM_HIP(c, hipMemcpyAsync(I.keys.p, c->hKeys.data(), nk * 8, hipMemcpyHostToDevice, c->stream));
+            MM_HIP(c, hipMemcpyAsync(I.keyFreq.p, fq.data(), nk, hipMemcpyHostToDevice, c->stream)); }
+  MM_HIP(c, hipMemcpyAsync(I.keyOff.p, c->hOffsets.data(), (nk + 1) * 8, hipMemcpyHostToDevice, c->stream));
   if (np) MM_HIP(c, hipMemcpyAsync(I.ptKeys.p, pk.data(), np * 8, hipMemcpyHostToDevice, c->stream));
   MM_HIP(c, hipStreamSynchronize(c->stream));
-  I.nRec = n; I.nKeys = nk; I.nPoints = np; I.nContigs = nContigs; I.htCap = cap; I.ready = true;
-  return MM_OK;
+  const int rc = mm_flatten_device_index(c, dRec.as<mm_minmer>(), n, nk, np, contigLen, refGroup, nContigs);
+  dRec.release();
+  c->mirrorMinmers = c->mirrorMap = true;
+  return rc;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -232,7 +126,7 @@ __device__ __forceinline__ uint64_t mm_shfl_down64(uint64_t v, int d) {    // d 
 struct MapFlags { int hg, skipSelf, skipPrefix, lowerTri; };
 struct HtSlot { uint64_t key, val; };                          // one 16-byte slot: a probe costs one memory sector
 
-// ascending bitonic sort of 64*R keys held R per lane, element index = lane*R + r
+// ascending bitonic sort of 64*R keys held R per lane (R a power of two), element index = lane*R + r
 template <int R>
 __device__ __forceinline__ void mm_wave_bitonic(uint64_t (&k)[R], int lane) {
   constexpr int N = 64 * R;
@@ -240,14 +134,18 @@ __device__ __forceinline__ void mm_wave_bitonic(uint64_t (&k)[R], int lane) {
   for (int k2 = 2; k2 <= N; k2 <<= 1) {
 #pragma unroll
     for (int j = k2 >> 1; j > 0; j >>= 1) {
-      // one compare per exchange: the lane keeps its key or takes the partner's (equal keys: either)
-      if (R == 2 && j == 1) {
-        const bool up = ((lane * 2) & k2) == 0;
-        const uint64_t a = k[0], b = k[R - 1];
-        const bool swap = (a < b) != up;
-        k[0] = swap ? b : a; k[R - 1] = swap ? a : b;
-      } else {
-        const int lj = (R == 2) ? (j >> 1) : j;
+      // one compare per exchange: the element keeps its key or takes the partner's (equal keys: either)
+      if (j < R) {                                   // partner inside the lane
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+          if (r & j) continue;
+          const bool up = (((lane * R + r) & k2) == 0);
+          const uint64_t a = k[r], b = k[r | j];
+          const bool swap = (a < b) != up;
+          k[r] = swap ? b : a; k[r | j] = swap ? a : b;
+        }
+      } else {                                       // partner in lane ^ (j / R), same register
+        const int lj = j / R;
 #pragma unroll
         for (int r = 0; r < R; r++) {
           const int idx = lane * R + r;
@@ -262,12 +160,12 @@ __device__ __forceinline__ void mm_wave_bitonic(uint64_t (&k)[R], int lane) {
 }
 
 // per-wave LDS scratch of the fused kernel
-#define MM_FUSE_MAXPTS 128
 struct L1Run { int32_t seq, start, end, isize; };
-struct FuseScratch {
-  uint64_t a[MM_FUSE_MAXPTS];        // gathered points, later (seqId<<32 | pos) of every position group
-  int32_t v[MM_FUSE_MAXPTS];         // overlap count after every position group
-  L1Run run[MM_FUSE_MAXPTS];
+template <int MAXPTS>
+struct FuseScratchT {
+  uint64_t a[MAXPTS];                // gathered points, later (seqId<<32 | pos) of every position group
+  int32_t v[MAXPTS];                 // overlap count after every position group
+  L1Run run[MAXPTS];
 };
 
 // Interval points of the fragment's surviving seeds -> dst[0..P) (skip_self / skip_prefix / lower_triangular applied,
@@ -303,7 +201,7 @@ __device__ __forceinline__ int mm_gather_points(Dst dst, int nRounds, ValAt&& va
 // change; runs closer than segLength joined.  Returns -1 when the list needs the literal sweep instead (a position group that
 // spans two contigs: there the reference's trailing pointer, which compares (seqId,pos), lags its leading pointer, which
 // compares pos only); otherwise the number of candidates, which have been stored at sc.run[0..n).
-template <int R>
+template <int R, class FuseScratch>
 __device__ __forceinline__ int mm_l1_fused(uint64_t (&k)[R], FuseScratch& sc, int sketchSizeQ, int minHits, int hg,
                                            const int32_t* __restrict__ cutoffs, int nCutoffs, int sParam, int segLength, int lane) {
   bool valid[R]; uint64_t prv[R], nxt[R];
@@ -313,7 +211,8 @@ __device__ __forceinline__ int mm_l1_fused(uint64_t (&k)[R], FuseScratch& sc, in
     const uint64_t up = mm_shfl_up64(k[R - 1], 1), dn = mm_shfl_down64(k[0], 1);
     prv[0] = lane == 0 ? MM_EMPTY : up;
     nxt[R - 1] = lane == 63 ? MM_EMPTY : dn;
-    if (R == 2) { prv[R - 1] = k[0]; nxt[0] = k[R - 1]; }
+#pragma unroll
+    for (int e = 1; e < R; e++) { prv[e] = k[e - 1]; nxt[e - 1] = k[e]; }
   }
   bool mixed = false; int delta[R]; bool gLast[R];
 #pragma unroll
@@ -361,7 +260,8 @@ __device__ __forceinline__ int mm_l1_fused(uint64_t (&k)[R], FuseScratch& sc, in
     const int ups = mm_shfl_up1((int)(gk[R - 1] >> 32)), dns = mm_shfl_down1((int)(gk[0] >> 32));
     pflag[0] = lane != 0 && upf; pseq[0] = (uint32_t)ups;
     nflag[R - 1] = lane != 63 && dnf; nseq[R - 1] = (uint32_t)dns;
-    if (R == 2) { pflag[R - 1] = flag[0]; pseq[R - 1] = (uint32_t)(gk[0] >> 32); nflag[0] = flag[R - 1]; nseq[0] = (uint32_t)(gk[R - 1] >> 32); }
+#pragma unroll
+    for (int e = 1; e < R; e++) { pflag[e] = flag[e - 1]; pseq[e] = (uint32_t)(gk[e - 1] >> 32); nflag[e - 1] = flag[e]; nseq[e - 1] = (uint32_t)(gk[e] >> 32); }
   }
   bool rStart[R], rEnd[R]; int laneStarts = 0;
 #pragma unroll
@@ -418,7 +318,8 @@ __device__ __forceinline__ int mm_l1_fused(uint64_t (&k)[R], FuseScratch& sc, in
 #define MM_LOOKUP_WPB 4             // waves (= fragments) per workgroup
 #define MM_L1_REGIONS 64            // L1 output cursors: a same-address atomic costs ~10 ns, so fragments spread over 64 of them
 #define MM_L1_CURSOR_STRIDE 32      // u64 words between cursors (256 bytes)
-__global__ void __launch_bounds__(MM_LOOKUP_WPB * 64, 8)
+template <int MAXPTS>
+__global__ void __launch_bounds__(MM_LOOKUP_WPB * 64, MAXPTS <= 128 ? 8 : 5)
 k_lookup_l1(int nFrags, int s, const DFrag* __restrict__ frags,
             const uint64_t* __restrict__ skHash, const int8_t* __restrict__ skStrand, const uint32_t* __restrict__ skCount,
             const HtSlot* __restrict__ ht, uint64_t htMask, const uint32_t* __restrict__ filter, uint64_t filterMask,
@@ -430,6 +331,7 @@ k_lookup_l1(int nFrags, int s, const DFrag* __restrict__ frags,
             mm_l1_candidate* __restrict__ l1, unsigned long long regionCap, unsigned long long* __restrict__ l1Cursors,
             int64_t* __restrict__ l1Off, int32_t* __restrict__ bigList,
             unsigned long long* __restrict__ counters /* [0] point cursor [1] pts overflow [3] l1 overflow [7] big count */) {
+  typedef FuseScratchT<MAXPTS> FuseScratch;
   __shared__ FuseScratch scratch[MM_LOOKUP_WPB];
   const int wv = threadIdx.x >> 6;
   const int f = blockIdx.x * MM_LOOKUP_WPB + wv;
@@ -499,7 +401,7 @@ k_lookup_l1(int nFrags, int s, const DFrag* __restrict__ frags,
     }
   }
   const int minHits0 = outIdx > 0 ? minHitsTab[outIdx] : 0;
-  if (!keepPoints && !fl.skipPrefix && oneBatch && P <= MM_FUSE_MAXPTS && minHits0 > 0) {
+  if (!keepPoints && !fl.skipPrefix && oneBatch && P <= MAXPTS && minHits0 > 0) {
     if (P == 0) nOut = 0;
     else {
       // gather straight from the probing lanes' registers (the order of the points is irrelevant: they are sorted next)
@@ -526,17 +428,21 @@ k_lookup_l1(int nFrags, int s, const DFrag* __restrict__ frags,
         done += mm_wave_sum(c);
       }
       nValid = mm_wave_sum(nValid);
-      const int padTo = P <= 64 ? 64 : 128;
+      const int padTo = P <= 64 ? 64 : P <= 128 ? 128 : 256;
       for (int j = P + lane; j < padTo; j += 64) sc.a[j] = MM_EMPTY;
       __threadfence_block();
       if (P <= 64) {
         uint64_t k[1] = {sc.a[lane]};
         mm_wave_bitonic<1>(k, lane);
         nOut = mm_l1_fused<1>(k, sc, outIdx, minHits0, fl.hg, cutoffs, nCutoffs, s, segLength, lane);
-      } else {
+      } else if (P <= 128) {
         uint64_t k[2] = {sc.a[lane * 2], sc.a[lane * 2 + 1]};
         mm_wave_bitonic<2>(k, lane);
         nOut = mm_l1_fused<2>(k, sc, outIdx, minHits0, fl.hg, cutoffs, nCutoffs, s, segLength, lane);
+      } else if constexpr (MAXPTS >= 256) {
+        uint64_t k[4] = {sc.a[lane * 4], sc.a[lane * 4 + 1], sc.a[lane * 4 + 2], sc.a[lane * 4 + 3]};
+        mm_wave_bitonic<4>(k, lane);
+        nOut = mm_l1_fused<4>(k, sc, outIdx, minHits0, fl.hg, cutoffs, nCutoffs, s, segLength, lane);
       }
     }
   }
@@ -833,7 +739,12 @@ int mm_launch_map(mm_ctx* c) {
     MM_HIP(c, hipMemsetAsync(c->dL1Cursors.p, 0, sizeof hcur, c->stream));
     {
       KernelTimer t(c, MM_K_LOOKUP);
-      hipLaunchKernelGGL(k_lookup_l1, dim3((nF + MM_LOOKUP_WPB - 1) / MM_LOOKUP_WPB), dim3(MM_LOOKUP_WPB * 64), 0, c->stream, nF, s, c->dFrags.as<DFrag>(),
+      // the fused path holds a fragment's interval points in LDS + registers: 128 of them at 8 waves per SIMD, or 256 at 5 (larger
+      // sketches bring proportionally more points: s = 310 averages ~160 per fragment)
+      int fuse = s > 160 ? 256 : 128;
+      if (const char* e = getenv("MM_FUSE_MAXPTS")) fuse = atoi(e) >= 256 ? 256 : 128;
+      auto kern = fuse == 256 ? k_lookup_l1<256> : k_lookup_l1<128>;
+      hipLaunchKernelGGL(kern, dim3((nF + MM_LOOKUP_WPB - 1) / MM_LOOKUP_WPB), dim3(MM_LOOKUP_WPB * 64), 0, c->stream, nF, s, c->dFrags.as<DFrag>(),
                          c->dSkHash.as<uint64_t>(), c->dSkStrand.as<int8_t>(), c->dSkCount.as<uint32_t>(),
                          I.htSlots.as<HtSlot>(), (uint64_t)(I.htCap - 1), I.filter.as<uint32_t>(), (uint64_t)I.filterMask, I.ptKeys.as<uint64_t>(),
                          I.refGroup.as<int32_t>(), c->dReadGroup.as<int32_t>(), c->dReadSelf.as<int32_t>(), c->seqCounterBase, fl,

@@ -26,6 +26,14 @@ small34)
   tail -4 $OUT/bench_c3s.err | tee -a $OUT/log.txt; cat $OUT/bench_c3s.json | tee -a $OUT/log.txt
   timeout 900 python bench.py --steps 3 --warmup 1 --workload configs4 --reads 60000 --ref-contigs 2 --ref-contig-len 150000000 --no-cpu-baseline > $OUT/bench_c4s.json 2> $OUT/bench_c4s.err
   tail -4 $OUT/bench_c4s.err | tee -a $OUT/log.txt; cat $OUT/bench_c4s.json | tee -a $OUT/log.txt ;;
+c3)
+  echo "== configs3 full" | tee -a $OUT/log.txt
+  MM_DEBUG=1 timeout 1500 python bench.py --steps 3 --warmup 1 --workload configs3 > $OUT/bench_c3.json 2> $OUT/bench_c3.err
+  grep -v "^\[mm\] sketch\|lookup+L1" $OUT/bench_c3.err | tail -12 | tee -a $OUT/log.txt; cat $OUT/bench_c3.json | tee -a $OUT/log.txt ;;
+c4)
+  echo "== configs4 full" | tee -a $OUT/log.txt
+  MM_DEBUG=1 timeout 1500 python bench.py --steps 3 --warmup 1 --workload configs4 > $OUT/bench_c4.json 2> $OUT/bench_c4.err
+  grep -v "^\[mm\] sketch\|lookup+L1" $OUT/bench_c4.err | tail -12 | tee -a $OUT/log.txt; cat $OUT/bench_c4.json | tee -a $OUT/log.txt ;;
 trace)
   echo "== rocprofv3 kernel trace" | tee -a $OUT/log.txt
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-path > $OUT/trace_bench.json 2> $OUT/trace.err

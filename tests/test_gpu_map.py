@@ -154,3 +154,63 @@ def test_map_short_reads_wide_l2_cells(oracle):
     launches = ctx.profile_read()["l2"][1]
     assert launches == 2, "the wide-cell pass did not run (launches of the L2 sweep: %d)" % launches
     ctx.close(); oracle.free(h)
+
+
+# ---- the other BASELINE.json shapes (configs[3], configs[4]) at sizes the oracle finishes in seconds -------------------------------
+def test_map_configs3_shape_15kbp_reads_sketch_310(oracle):
+    """configs[3]: 15 kbp reads (3 full fragments), 10 % ONT-like error, sketchSize 310 (what the stock binary derives for a 3 GB
+    reference file): ~160 interval points per fragment -> the 256-point fused path, LDS tables sized for s = 310"""
+    contigs = genome(301, [600000, 500000, 400000])
+    reads = reads_for(contigs, 31, 60, 15000, 0.10) + reads_for(contigs, 32, 12, 15000 + 777, 0.10)      # + overlapping tail fragment
+    nF, nl = run_and_compare(oracle, contigs, reads, s=310, pi=0.85)
+    assert nF >= 3 * 60 + 4 * 12 and nl > 200
+
+
+def test_map_configs4_shape_20kbp_noisy_reads_dense_pi80_many_files(oracle):
+    """configs[4]: --dense --pi 80 (sketchSize 498), 20 kbp reads at 15-20 % error, a reference given as a list of files (--rl): the
+    files' contigs share one seqId space (winSketch.hpp:174-214), so at this level they are ten contigs"""
+    sizes = [180000, 150000, 120000, 200000, 90000, 110000, 130000, 100000, 160000, 140000]
+    contigs = genome(401, sizes, names=["file%d_chr" % i for i in range(10)], repeats=False)
+    reads = []
+    for i, err in enumerate((0.15, 0.17, 0.20)):
+        reads += [("e%d_%s" % (i, n), a) for n, a in reads_for(contigs, 41 + i, 16, 20000, err)]
+    nF, nl = run_and_compare(oracle, contigs, reads, s=498, pi=0.80)
+    assert nF == 4 * 48 and nl > 100
+
+
+def test_map_sketch_beyond_1024(oracle):
+    """sketchSize 1100 (> 256 entries per probing batch, > 1024): the multi-batch lookup, seed values through HBM, 16-bit L2 cells"""
+    contigs = genome(501, [400000, 300000], repeats=False)
+    reads = reads_for(contigs, 51, 20, 20000, 0.12)
+    run_and_compare(oracle, contigs, reads, L=10000, s=1100, pi=0.80)
+
+
+def test_index_with_a_hyper_frequent_seed():
+    """a frequent seed's point list is never read on the device (getSeedHits drops the seed first): a list of 2^23 points and more
+    (a satellite array in a real genome) must not be refused.  Synthetic index: the resident one plus one such key."""
+    from mashmap_amd import capi
+    g = U.random_dna(77, 300000)
+    ctx = capi.Context(k=19, segLength=5000, sketchSize=130)
+    ctx.index_build([g], kmerPct=0.001)
+    ix = ctx.index_download()
+    ctx.set_tables_default(0.85)
+    reads = [a for _, a, _ in U.sample_reads([g], 5, 16, 10000, 0.08)]
+    ctx.reads_upload(reads); ctx.map()
+    base = ctx.results()
+    big = (1 << 23) + 10
+    key = np.uint64(0x7fff000000000123)
+    assert key not in ix["keys"]
+    pts = np.zeros(big, dtype=capi.POINT_DT)
+    pts["pos"] = np.arange(big, dtype=np.int64) % 250000; pts["hash"] = key; pts["seqId"] = 0; pts["side"] = np.where(np.arange(big) % 2 == 0, 1, -1)
+    keys = np.concatenate([ix["keys"], [key]])
+    offs = np.concatenate([ix["offsets"], [ix["offsets"][-1] + big]]).astype(np.uint64)
+    points = np.concatenate([ix["points"], pts])
+    freq = np.concatenate([ix["freq"], [key]])
+    ctx2 = capi.Context(k=19, segLength=5000, sketchSize=130)
+    ctx2.index_upload(ix["minmers"], keys, offs, points, freq, np.array([len(g)], dtype=np.int32))
+    ctx2.set_tables_default(0.85)
+    ctx2.reads_upload(reads); ctx2.map()
+    got = ctx2.results()
+    for a, b in zip(base, got):
+        assert a.tobytes() == b.tobytes()
+    ctx.close(); ctx2.close()
