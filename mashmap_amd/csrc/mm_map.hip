@@ -351,6 +351,18 @@ k_lookup_l1(int nFrags, int s, const DFrag* __restrict__ frags,
   // table slots are independent, so one memory round trip serves all of them instead of four.
   uint64_t pv[4] = {0, 0, 0, 0};                                   // table value of this lane's kept + found seeds, sub-round u
   const bool oneBatch = cnt <= 256;
+  // The interval points are gathered into LDS batch by batch, as long as they fit (MAXPTS): a sketch of more than 256 entries
+  // (several probing batches) stays on the fused path too.  The order of the points is irrelevant: they are sorted next.
+  bool fuseOk = !keepPoints && !fl.skipPrefix;                     // wave-uniform
+  int done = 0;                                                    // points in sc.a so far
+  auto put = [&](int at, uint64_t key) {
+    const int seqId = (int)(key >> 33);
+    bool drop = false;
+    if (fl.skipSelf && seqId == self) drop = true;
+    if (fl.lowerTri && !(seqCounter > seqId)) drop = true;
+    if (drop) key = MM_EMPTY; else nValid++;
+    sc.a[at] = key;
+  };
   for (int base = 0; base < cnt; base += 256) {
     uint64_t h[4], val[4]; bool act[4], found[4], open[4];
 #pragma unroll
@@ -384,6 +396,7 @@ k_lookup_l1(int nFrags, int s, const DFrag* __restrict__ frags,
       for (int u = 0; u < 4; u++) drop |= act[u] && found[u] && (val[u] & 1ull);
       writeQ = __ballot(drop) != 0;
     }
+    int cU[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       const int r = base + u * 64 + lane;
@@ -396,37 +409,34 @@ k_lookup_l1(int nFrags, int s, const DFrag* __restrict__ frags,
       }
       const bool kf = keep && found[u];
       pv[u] = kf ? val[u] : 0ull;
-      P += mm_wave_sum(kf ? (int)((val[u] >> 1) & 0x7fffffull) : 0);
+      cU[u] = kf ? (int)((val[u] >> 1) & 0x7fffffull) : 0;
       outIdx += __popcll(m);
+    }
+    const int Pb = mm_wave_sum(cU[0] + cU[1] + cU[2] + cU[3]);
+    P += Pb;
+    if (fuseOk && Pb > 0) {
+      if (done + Pb > MAXPTS) fuseOk = false;
+      else {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int c = cU[u];
+          const int my = done + mm_wave_excl_scan(c);
+          const uint64_t src = pv[u] >> 24;
+          uint64_t k0 = MM_EMPTY, k1 = MM_EMPTY;
+          if (c > 0) k0 = ptKeys[src];
+          if (c > 1) k1 = ptKeys[src + 1];
+          if (c > 0) put(my, k0);
+          if (c > 1) put(my + 1, k1);
+          for (int j = 2; j < c; j++) put(my + j, ptKeys[src + j]);
+          done += mm_wave_sum(c);
+        }
+      }
     }
   }
   const int minHits0 = outIdx > 0 ? minHitsTab[outIdx] : 0;
-  if (!keepPoints && !fl.skipPrefix && oneBatch && P <= MAXPTS && minHits0 > 0) {
+  if (fuseOk && minHits0 > 0) {
     if (P == 0) nOut = 0;
     else {
-      // gather straight from the probing lanes' registers (the order of the points is irrelevant: they are sorted next)
-      int done = 0;
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int c = (int)((pv[u] >> 1) & 0x7fffffull);
-        const int my = done + mm_wave_excl_scan(c);
-        const uint64_t src = pv[u] >> 24;
-        uint64_t k0 = MM_EMPTY, k1 = MM_EMPTY;
-        if (c > 0) k0 = ptKeys[src];
-        if (c > 1) k1 = ptKeys[src + 1];
-        auto put = [&](int at, uint64_t key) {
-          const int seqId = (int)(key >> 33);
-          bool drop = false;
-          if (fl.skipSelf && seqId == self) drop = true;
-          if (fl.lowerTri && !(seqCounter > seqId)) drop = true;
-          if (drop) key = MM_EMPTY; else nValid++;
-          sc.a[at] = key;
-        };
-        if (c > 0) put(my, k0);
-        if (c > 1) put(my + 1, k1);
-        for (int j = 2; j < c; j++) put(my + j, ptKeys[src + j]);
-        done += mm_wave_sum(c);
-      }
       nValid = mm_wave_sum(nValid);
       const int padTo = P <= 64 ? 64 : P <= 128 ? 128 : 256;
       for (int j = P + lane; j < padTo; j += 64) sc.a[j] = MM_EMPTY;

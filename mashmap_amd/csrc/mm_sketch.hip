@@ -436,7 +436,10 @@ static int launch_hash_only_k(mm_ctx* c, int reps, double* msAvg) {
   const int maxLen = c->maxFragLen;
   int nStrips = (maxLen - K + 1 + 15) / 16; if (nStrips < 1) nStrips = 1;
   int threads = ((nStrips + 63) / 64) * 64; if (threads > 1024) threads = 1024;
-  const size_t lds = sizeof(Tabs) + (((size_t)(maxLen + 15) / 16 + 3) * 4 + 15) / 16 * 16;
+  size_t lds = sizeof(Tabs) + (((size_t)(maxLen + 15) / 16 + 3) * 4 + 15) / 16 * 16;
+  // MM_HASH_ONLY_LDS=bytes: claim that much LDS per workgroup (occupancy experiment: how the hash loop fares at the resident-wave
+  // count the sketch kernel's tables leave it)
+  if (const char* e = getenv("MM_HASH_ONLY_LDS")) { const size_t want = (size_t)atol(e); if (want > lds && want <= 160 * 1024) lds = want; }
   if (c->sketchTabsK != K) {
     MM_HIP(c, c->dSketchTabs.ensure(sizeof(Tabs)));
     hipLaunchKernelGGL((k_sketch_tables<K>), dim3(1), dim3(256), 0, c->stream, c->dSketchTabs.as<Tabs>());

@@ -34,6 +34,17 @@ c4)
   echo "== configs4 full" | tee -a $OUT/log.txt
   MM_DEBUG=1 timeout 1500 python bench.py --steps 3 --warmup 1 --workload configs4 > $OUT/bench_c4.json 2> $OUT/bench_c4.err
   grep -v "^\[mm\] sketch\|lookup+L1" $OUT/bench_c4.err | tail -12 | tee -a $OUT/log.txt; cat $OUT/bench_c4.json | tee -a $OUT/log.txt ;;
+occ)
+  echo "== hash-only kernel vs LDS claimed per workgroup (occupancy)" | tee -a $OUT/log.txt
+  for L in 0 27000 45000 78000; do
+    MM_HASH_ONLY_LDS=$L timeout 600 python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-host-path --reads 500000 2> /dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('lds', $L, 'hash_only_ms', d['roofline']['int']['hash_only_ms'], 'sketch_ms', d['kernels']['sketch']['ms_per_step'])" | tee -a $OUT/log.txt
+  done ;;
+filt)
+  echo "== presence filter vs 3 Gbp index (configs1 reads)" | tee -a $OUT/log.txt
+  for CFG in "64 16" "160 4" "200 6" "250 8"; do
+    set -- $CFG
+    MM_FILTER_MAX_MIB=$1 MM_FILTER_BITS_PER_KEY=$2 timeout 900 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-path --reads 500000 --ref-contigs 30 --ref-contig-len 100000000 2> /dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('filter max MiB $1 bits/key $2:', d['value'], 'Gbp/s; lookup', d['kernels']['lookup']['ms_per_step'], 'ms; index', d['config']['index_build_s'], 's')" | tee -a $OUT/log.txt
+  done ;;
 trace)
   echo "== rocprofv3 kernel trace" | tee -a $OUT/log.txt
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-path > $OUT/trace_bench.json 2> $OUT/trace.err
