@@ -96,6 +96,35 @@ __device__ __forceinline__ uint32_t mm_popc_below(uint64_t mask) {    // set bit
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
+// Wave reductions / scans on the VALU's DPP lanes (no LDS round trip per step as with ds_bpermute shuffles).  All 64 lanes
+// must be active.  quad_perm / row_half_mirror / row_mirror leave every lane with the result of its row of 16; the four
+// rows are combined through v_readlane, so the result is wave-uniform (an SGPR).
+template <int CTRL> __device__ __forceinline__ int mm_dpp0(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+#define MM_DPP_QUAD_1032 0xB1
+#define MM_DPP_QUAD_2301 0x4E
+#define MM_DPP_ROW_HALF_MIRROR 0x141
+#define MM_DPP_ROW_MIRROR 0x140
+#define MM_DPP_ROW_SHR(n) (0x110 + (n))
+__device__ __forceinline__ int mm_wave_sum(int v) {
+  v += mm_dpp0<MM_DPP_QUAD_1032>(v); v += mm_dpp0<MM_DPP_QUAD_2301>(v);
+  v += mm_dpp0<MM_DPP_ROW_HALF_MIRROR>(v); v += mm_dpp0<MM_DPP_ROW_MIRROR>(v);
+  return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
+}
+__device__ __forceinline__ int mm_wave_max(int v) {              // values >= 0 (the fill of a masked DPP lane is 0)
+  auto mx = [](int a, int b) { return a > b ? a : b; };
+  v = mx(v, mm_dpp0<MM_DPP_QUAD_1032>(v)); v = mx(v, mm_dpp0<MM_DPP_QUAD_2301>(v));
+  v = mx(v, mm_dpp0<MM_DPP_ROW_HALF_MIRROR>(v)); v = mx(v, mm_dpp0<MM_DPP_ROW_MIRROR>(v));
+  return mx(mx(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), mx(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+__device__ __forceinline__ int mm_wave_excl_scan(int v) {      // exclusive prefix sum across the 64 lanes
+  int x = v;                                                     // inclusive scan inside each row of 16 (row_shr fills with 0)
+  x += mm_dpp0<MM_DPP_ROW_SHR(1)>(x); x += mm_dpp0<MM_DPP_ROW_SHR(2)>(x); x += mm_dpp0<MM_DPP_ROW_SHR(4)>(x); x += mm_dpp0<MM_DPP_ROW_SHR(8)>(x);
+  const int r0 = __builtin_amdgcn_readlane(x, 15), r1 = __builtin_amdgcn_readlane(x, 31), r2 = __builtin_amdgcn_readlane(x, 47);
+  const int row = (int)mm_lane() >> 4;
+  const int off = row == 0 ? 0 : row == 1 ? r0 : row == 2 ? r0 + r1 : r0 + r1 + r2;
+  return x + off - v;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Strip hasher.  For K = 17..19 (one 16-byte block + a tail of K-16 <= 3 bytes; K = 19 is MashMap's default) the tail has
 // at most 64 values, so its complete mix (k1*C1, rotl 31, *C2) comes from a 64-entry LDS table indexed by the 2-bit codes:
@@ -161,8 +190,9 @@ __device__ __forceinline__ uint64_t mm_murmur_kmer_tail(const uint32_t* A, int o
 }
 
 // Hashes of the 16 k-mer positions of a strip on both strands; calls use(j, fwd, rc) for j = 0..15 in ascending order.
-template <int K, class Use>
+template <int K, int SL = 16, class Use>
 __device__ __forceinline__ void mm_strip_hashes(uint32_t w0, uint32_t w1, uint32_t w2, const MMTables& T, Use&& use) {
+  static_assert(SL == 16, "the ASCII-stream hasher works on strips of 16 positions");
   MMStrip st;
   st.load(w0, w1, w2, T);
   if constexpr (MMFastK<K>::value) {
@@ -334,17 +364,19 @@ __device__ __forceinline__ uint64_t mm_murmur_prod_general(const uint32_t* w, in
   return h1 + h2;
 }
 
-template <int K, class Use>
+// SL k-mer positions per strip (16, or more while the last k-mer still ends inside the 48-base window: SL + K - 1 <= 48)
+template <int K, int SL = 16, class Use>
 __device__ __forceinline__ void mm_strip_hashes(uint32_t w0, uint32_t w1, uint32_t w2, const MMProdTables& T, Use&& use) {
   static_assert(K >= 16 && K <= 32, "product tables need at least one 16-byte block");
+  static_assert(SL >= 1 && SL + K - 1 <= 48, "a strip's k-mers must fit the 48-base window");
   const uint32_t w[3] = {w0, w1, w2};
   if constexpr (MMFastK<K>::value) {
     constexpr int TAIL = K - 16;
-    uint32_t a[32];                                 // a[p]: table offset of the 4-base group starting at base p (unused ones fold away)
+    uint32_t a[SL + K - 4];                         // a[p]: table offset of the 4-base group starting at base p (unused ones fold away)
 #pragma unroll
-    for (int p = 0; p < 31; p++) a[p] = mm_win_off8<4>(w, p);
+    for (int p = 0; p < SL + K - 4; p++) a[p] = mm_win_off8<4>(w, p);
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
+    for (int j = 0; j < SL; j++) {
       uint64_t f1 = mm_lds64(T.pf1, a[j]), f2 = mm_lds64(T.pf2, a[j + 8]);
       f1 += (uint64_t)mm_lds32(T.pf1, a[j + 4]) << 32; f2 += (uint64_t)mm_lds32(T.pf2, a[j + 12]) << 32;
       // reverse complement of k-mer j: byte i = comp(base j+K-1-i), so its 4-byte groups are the windows at j+K-4, j+K-8, ...
@@ -355,7 +387,7 @@ __device__ __forceinline__ void mm_strip_hashes(uint32_t w0, uint32_t w1, uint32
     }
   } else {
 #pragma unroll
-    for (int j = 0; j < 16; j++) use(j, mm_murmur_prod_general<K, false>(w, j, T), mm_murmur_prod_general<K, true>(w, j, T));
+    for (int j = 0; j < SL; j++) use(j, mm_murmur_prod_general<K, false>(w, j, T), mm_murmur_prod_general<K, true>(w, j, T));
   }
 }
 

@@ -52,34 +52,6 @@ int mm_build_device_index(mm_ctx* c, const int32_t* contigLen, const int32_t* re
 // ---------------------------------------------------------------------------------------------
 // device helpers
 // ---------------------------------------------------------------------------------------------
-// Wave reductions / scans on the VALU's DPP lanes (no LDS round trip per step as with ds_bpermute shuffles).  All 64 lanes
-// must be active.  quad_perm / row_half_mirror / row_mirror leave every lane with the result of its row of 16; the four
-// rows are combined through v_readlane, so the result is wave-uniform (an SGPR).
-template <int CTRL> __device__ __forceinline__ int mm_dpp0(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
-#define MM_DPP_QUAD_1032 0xB1
-#define MM_DPP_QUAD_2301 0x4E
-#define MM_DPP_ROW_HALF_MIRROR 0x141
-#define MM_DPP_ROW_MIRROR 0x140
-#define MM_DPP_ROW_SHR(n) (0x110 + (n))
-__device__ __forceinline__ int mm_wave_sum(int v) {
-  v += mm_dpp0<MM_DPP_QUAD_1032>(v); v += mm_dpp0<MM_DPP_QUAD_2301>(v);
-  v += mm_dpp0<MM_DPP_ROW_HALF_MIRROR>(v); v += mm_dpp0<MM_DPP_ROW_MIRROR>(v);
-  return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
-}
-__device__ __forceinline__ int mm_wave_max(int v) {              // values >= 0 (the fill of a masked DPP lane is 0)
-  auto mx = [](int a, int b) { return a > b ? a : b; };
-  v = mx(v, mm_dpp0<MM_DPP_QUAD_1032>(v)); v = mx(v, mm_dpp0<MM_DPP_QUAD_2301>(v));
-  v = mx(v, mm_dpp0<MM_DPP_ROW_HALF_MIRROR>(v)); v = mx(v, mm_dpp0<MM_DPP_ROW_MIRROR>(v));
-  return mx(mx(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), mx(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
-}
-__device__ __forceinline__ int mm_wave_excl_scan(int v) {      // exclusive prefix sum across the 64 lanes
-  int x = v;                                                     // inclusive scan inside each row of 16 (row_shr fills with 0)
-  x += mm_dpp0<MM_DPP_ROW_SHR(1)>(x); x += mm_dpp0<MM_DPP_ROW_SHR(2)>(x); x += mm_dpp0<MM_DPP_ROW_SHR(4)>(x); x += mm_dpp0<MM_DPP_ROW_SHR(8)>(x);
-  const int r0 = __builtin_amdgcn_readlane(x, 15), r1 = __builtin_amdgcn_readlane(x, 31), r2 = __builtin_amdgcn_readlane(x, 47);
-  const int row = (int)mm_lane() >> 4;
-  const int off = row == 0 ? 0 : row == 1 ? r0 : row == 2 ? r0 + r1 : r0 + r1 + r2;
-  return x + off - v;
-}
 // value of lane (lane ^ M), M a power of two, without the LDS crossbar: DPP inside a row of 16, v_permlane{16,32}_swap
 // (gfx950) across rows.  All 64 lanes must be active.
 template <int M>

@@ -54,9 +54,14 @@ __global__ void k_pack2bit(const uint8_t* __restrict__ ascii, const int64_t* __r
 //   so rank(key) = occupied slots before its cluster + keys of its own cluster that are smaller:
 //   the table scan replaces compaction + sort.
 // ---------------------------------------------------------------------------------------------
+#define MM_SK_PAD 64               // spill slots behind the ordered tables (no wrap-around): fast kernel
+#define MM_SK_PADH 256             // hard kernel
+#define MM_SK_DUPCAP 256          // repeat occurrences a fast-kernel fragment may defer (more: the hard kernel takes the fragment)
+#define MM_SK_GUARD 4             // always-empty slots on either side of the table: the ranking reads windows of that many neighbours
 struct SkTable {
   uint64_t* key; int32_t* first; int32_t* last; int32_t* sum;
-  uint32_t* counters;            // [0] distinct keys  [1] overflow (table, spill or queue)
+  uint32_t* counters;            // [0] distinct keys (hard kernel)  [1] overflow (table, spill, queue, duplicate list)  [2] occupied slots  [3] duplicates
+  uint32_t* dup;                 // fast kernel: deferred repeat occurrences, slot | (pos << 1 | strand bit) << 13
   uint64_t* occW; uint32_t* occP; // occupancy bit words and their exclusive prefix counts
   uint32_t nSlots, maxLoad, M; int sh;
 
@@ -69,6 +74,35 @@ struct SkTable {
   }
   __device__ __forceinline__ uint32_t home(uint64_t h) const { return __umulhi((uint32_t)((h << sh) >> 32), M); }
 
+  // Fast kernel.  A survivor that claims an empty slot owns it: first / last / strand sum are written with plain stores (an unclaimed
+  // slot is never read, so those arrays are not even initialised).  A repeat occurrence of a resident hash -- rare outside repeats --
+  // is put on a short list and folded in with atomics after the workgroup barrier, when every owner's stores are visible.  One
+  // returning LDS atomic per survivor instead of five: the LDS atomic pipeline, not the VALU, paced this phase at large sketches.
+  __device__ __forceinline__ void insert_fast(uint64_t h, uint32_t meta) {
+    uint32_t slot = home(h);
+    for (;;) {
+      const unsigned long long prev = atomicCAS((unsigned long long*)&key[slot], (unsigned long long)MM_HASH_MAX, (unsigned long long)h);
+      if (prev == MM_HASH_MAX) { const int pos = (int)(meta >> 1); first[slot] = pos; last[slot] = pos; sum[slot] = (meta & 1u) ? 1 : -1; return; }
+      if (prev == h) {
+        const uint32_t at = atomicAdd(&counters[3], 1u);
+        if (at < MM_SK_DUPCAP) dup[at] = slot | (meta << 13); else atomicOr(&counters[1], 1u);
+        return;
+      }
+      if (++slot >= nSlots) { atomicOr(&counters[1], 1u); return; }
+    }
+  }
+  __device__ __forceinline__ void fold_duplicates(int tid, int nthr) {
+    const uint32_t n = counters[3] < MM_SK_DUPCAP ? counters[3] : MM_SK_DUPCAP;
+    for (uint32_t i = (uint32_t)tid; i < n; i += (uint32_t)nthr) {
+      const uint32_t d = dup[i], slot = d & 0x1FFFu, meta = d >> 13;
+      const int pos = (int)(meta >> 1);
+      atomicMin(&first[slot], pos); atomicMax(&last[slot], pos); atomicAdd(&sum[slot], (meta & 1u) ? 1 : -1);
+    }
+  }
+  // COUNT: keep the number of distinct keys in counters[0] and flag the load limit as it is passed (the hard kernel, which inserts
+  // straight from the hash loop and must notice a flooded table early); the fast kernel counts occupied slots afterwards instead --
+  // one returning LDS atomic less on the dependency chain of every new key
+  template <bool COUNT>
   __device__ __forceinline__ void insert(uint64_t h, int pos, int st) {
     uint32_t slot = home(h);
     for (uint32_t probes = 1;; probes++) {
@@ -77,7 +111,7 @@ struct SkTable {
       if ((probes & 15u) == 0 && ((volatile uint32_t*)counters)[1]) return;
       const unsigned long long prev = atomicCAS((unsigned long long*)&key[slot], (unsigned long long)MM_HASH_MAX,
                                                 (unsigned long long)h);
-      if (prev == MM_HASH_MAX) {
+      if (COUNT && prev == MM_HASH_MAX) {
         if (atomicAdd(&counters[0], 1u) >= maxLoad) atomicOr(&counters[1], 1u);
       }
       if (prev == MM_HASH_MAX || prev == h) {
@@ -88,6 +122,9 @@ struct SkTable {
     }
   }
 };
+
+// words of the fast kernel's position queue: the per-wave queues, but at least the table's load limit (the memory lists the occupied slots later)
+__host__ __device__ static inline int sketch_fast_queue_total(int QC, int nWaves, int HT) { const int a = QC * nWaves, b = HT * 5 / 8 + 1; return ((a > b ? a : b) + 3) & ~3; }
 
 // OR of every K-wide window: bit j of the result = any of bits j..j+K-1 of x
 template <int K>
@@ -115,7 +152,13 @@ __device__ __forceinline__ void
 mm_sketch_fragment(unsigned char* smem, const int f, const uint4* __restrict__ gTabs, const uint32_t* __restrict__ bases2, const uint32_t* __restrict__ nmask,
                    const DFrag* __restrict__ frags, const uint32_t* __restrict__ readHasN, int s, int wantFast, int HT, int PAD,
                    uint64_t* __restrict__ skHash, int2* __restrict__ skPos, int8_t* __restrict__ skStrand,
-                   uint32_t* __restrict__ skCount, int32_t* __restrict__ hardList, uint32_t* __restrict__ hardCount) {
+                   uint32_t* __restrict__ skCount, int32_t* __restrict__ hardList, uint32_t* __restrict__ hardCount,
+                   unsigned long long* __restrict__ phaseStats = nullptr) {
+  // MM_SKETCH_STATS: shader-clock cycles thread 0 spends up to each phase boundary, summed over workgroups (diagnostics only)
+  unsigned long long tPrev = phaseStats ? __builtin_amdgcn_s_memtime() : 0ull;
+  auto mark = [&](int ph) {
+    if (phaseStats && threadIdx.x == 0) { const unsigned long long t = __builtin_amdgcn_s_memtime(); atomicAdd(&phaseStats[ph], t - tPrev); tPrev = t; }
+  };
   const DFrag fr = frags[f];
   const int len = fr.len;
   const int n = len - K + 1;                        // k-mer positions
@@ -140,7 +183,9 @@ mm_sketch_fragment(unsigned char* smem, const int f, const uint4* __restrict__ g
   uint64_t* qH = (uint64_t*)(smem + off); off += HARD ? 0 : (size_t)HT * 8;     // per-wave queues: hashes
   uint32_t* qM = (uint32_t*)(smem + off); off += HARD ? 0 : (size_t)HT * 4;     //                  pos<<1 | (strand > 0)
   SkTable tab;
-  tab.key = (uint64_t*)(smem + off); off += (size_t)NS * 8;
+  tab.key = (uint64_t*)(smem + off) + MM_SK_GUARD; off += (size_t)(NS + 2 * MM_SK_GUARD) * 8;   // MM_SK_GUARD always-empty slots on either side: the ranking reads windows
+  uint32_t* qCnt = (uint32_t*)(smem + off); off += 64;
+  tab.dup = (uint32_t*)(smem + off); off += HARD ? 0 : (size_t)MM_SK_DUPCAP * 4;                                           // survivors queued by every wave
   tab.occW = (uint64_t*)(smem + off); off += (size_t)nOcc * 8;
   tab.first = (int32_t*)(smem + off); off += (size_t)NS * 4;
   tab.last = (int32_t*)(smem + off); off += (size_t)NS * 4;
@@ -179,9 +224,12 @@ mm_sketch_fragment(unsigned char* smem, const int f, const uint4* __restrict__ g
 
   for (int attempt = 0;; attempt++) {
     tab.set_cut(T, (uint32_t)HT);
-    for (int i = tid; i < NS; i += nthr) { tab.key[i] = MM_HASH_MAX; tab.first[i] = 0x7fffffff; tab.last[i] = -1; tab.sum[i] = 0; }
+    if (HARD) for (int i = tid; i < NS; i += nthr) { tab.key[i] = MM_HASH_MAX; tab.first[i] = 0x7fffffff; tab.last[i] = -1; tab.sum[i] = 0; }
+    else for (int i = tid; i < NS; i += nthr) tab.key[i] = MM_HASH_MAX;
+    if (tid < MM_SK_GUARD) { tab.key[-1 - tid] = MM_HASH_MAX; tab.key[NS + tid] = MM_HASH_MAX; }
     if (tid < 4) tab.counters[tid] = 0;
     __syncthreads();
+    mark(0);                                          // staging + table init
 
     // ---- phase 1: hash both strands of every k-mer ----
     const uint32_t qBase = (uint32_t)(tid >> 6) * QC, qEnd = qBase + QC;
@@ -201,7 +249,7 @@ mm_sketch_fragment(unsigned char* smem, const int f, const uint4* __restrict__ g
         bool pass = false;                          // nested ifs: the compiler keeps the three tests as exec masks
         if ((ok & (1u << j)) != 0) { if (hf != hr) { if (allPass || h < T) pass = true; } }
         if (HARD) {
-          if (pass) tab.insert(h, pos, hf < hr ? 1 : -1);
+          if (pass) tab.template insert<true>(h, pos, hf < hr ? 1 : -1);
         } else {
           const uint64_t m = __builtin_amdgcn_ballot_w64(pass);
           const uint32_t idx = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, qHead));
@@ -211,21 +259,57 @@ mm_sketch_fragment(unsigned char* smem, const int f, const uint4* __restrict__ g
       });
     }
     uint32_t qCount = qHead - qBase;
+    mark(1);                                          // hash loop of wave 0 (its two passes when the last wave was folded in)
     if (!HARD) {
-      // every wave drains its own queue (LDS operations of one wave complete in order)
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       // lanes that left the strip loop early (or never entered it) hold a stale count; lane 0 owns the smallest strip
       qCount = (uint32_t)__builtin_amdgcn_readfirstlane((int)qCount);
-      if (qCount > QC) { if (mm_lane() == 0) atomicOr(&tab.counters[1], 1u); }
-      else {
-        for (uint32_t i = mm_lane(); i < qCount; i += 64) { const uint32_t m = qM[qBase + i]; tab.insert(qH[qBase + i], (int)(m >> 1), (m & 1u) ? 1 : -1); }
+      if (mm_lane() == 0) { qCnt[tid >> 6] = qCount; if (qCount > QC) atomicOr(&tab.counters[1], 1u); }
+    }
+    __syncthreads();
+    if (!HARD && tab.counters[1] == 0) {
+      // all threads drain all queues: entry g of the concatenated queues goes to thread g mod nthr, so every round of inserts is full
+      // (the queues themselves are uneven: wave 0 may have hashed twice as many strips)
+      uint32_t pre[17]; pre[0] = 0;
+#pragma unroll
+      for (int w = 0; w < 16; w++) pre[w + 1] = pre[w] + (w < nWaves ? qCnt[w] : 0u);
+      const uint32_t total = pre[16];
+      for (uint32_t g = (uint32_t)tid; g < total; g += (uint32_t)nthr) {
+        uint32_t w = 0, start = 0;                  // the queue entry g falls into, and where that queue starts in the concatenation
+#pragma unroll
+        for (int x = 1; x < 16; x++) if (g >= pre[x]) { w = (uint32_t)x; start = pre[x]; }
+        const uint32_t at = w * QC + (g - start);
+        tab.insert_fast(qH[at], qM[at]);
+      }
+    }
+    mark(2);                                          // thread 0's share of the drain
+    __syncthreads();
+    mark(3);                                          // waiting for the other waves
+    if (!HARD) tab.fold_duplicates(tid, nthr);        // owners' stores are visible now
+
+    // ---- occupancy words, their prefix counts (wave 0: one DPP scan per 64 words), number of distinct keys ----
+    for (int base = 0; base < NS; base += nthr) {
+      const int slot = base + tid;                  // NS and nthr are multiples of 64: a wave is in or out as a whole
+      if (slot < NS) {
+        const uint64_t m = __ballot(tab.key[slot] != MM_HASH_MAX);
+        if (mm_lane() == 0) tab.occW[slot >> 6] = m;
       }
     }
     __syncthreads();
+    if (tid < 64) {
+      int carry = 0;
+      for (int w0 = 0; w0 < nOcc; w0 += 64) {
+        const int w = w0 + tid;
+        const int v = w < nOcc ? (int)__popcll(tab.occW[w]) : 0;
+        const int ex = mm_wave_excl_scan(v);
+        if (w < nOcc) tab.occP[w] = (uint32_t)(carry + ex);
+        carry += mm_wave_sum(v);
+      }
+      if (tid == 0) { tab.counters[2] = (uint32_t)carry; if (!HARD && (uint32_t)carry > tab.maxLoad) tab.counters[1] = 1u; }
+    }
+    __syncthreads();
+    mark(4);                                          // occupancy words + prefix counts
 
-    D = tab.counters[0];
+    D = tab.counters[2];
     const bool overflow = tab.counters[1] != 0;
     if (!HARD) {
       if (overflow || (D < (uint32_t)s && T != MM_HASH_MAX)) {
@@ -244,32 +328,45 @@ mm_sketch_fragment(unsigned char* smem, const int f, const uint4* __restrict__ g
     }
   }
 
-  // ---- occupancy words, their prefix counts ----
-  for (int base = 0; base < NS; base += nthr) {
-    const int slot = base + tid;                    // NS and nthr are multiples of 64: a wave is in or out as a whole
-    if (slot < NS) {
-      const uint64_t m = __ballot(tab.key[slot] != MM_HASH_MAX);
-      if (mm_lane() == 0) tab.occW[slot >> 6] = m;
-    }
-  }
-  __syncthreads();
-  for (int w = tid; w < nOcc; w += nthr) {
-    uint32_t acc = 0;
-    for (int q = 0; q < w; q++) acc += (uint32_t)__popcll(tab.occW[q]);
-    tab.occP[w] = acc;
-  }
-  __syncthreads();
-
   // ---- rank every key inside its cluster; emit the s smallest, ascending (commonFunc.hpp:278-286) ----
-  for (int slot = tid; slot < NS; slot += nthr) {
+  // Fast kernel: the occupied slots are first listed in slot order (the queue memory is free again), so that every thread ranks
+  // D / nthr keys instead of visiting NS / nthr slots of which two thirds are empty; a key's position in that list is the number of
+  // occupied slots before it.  Hard kernel: straight over the slots.
+  uint32_t* occList = qM;
+  if (!HARD) {
+    for (int slot = tid; slot < NS; slot += nthr) {
+      const uint64_t m = tab.occW[slot >> 6];
+      if ((m >> (slot & 63)) & 1ull) occList[tab.occP[slot >> 6] + (uint32_t)__popcll(m & ((1ull << (slot & 63)) - 1ull))] = (uint32_t)slot;
+    }
+    __syncthreads();
+  }
+  const int nIter = HARD ? NS : (int)D;
+  for (int it = tid; it < nIter; it += nthr) {
+    const int slot = HARD ? it : (int)occList[it];
     const uint64_t k = tab.key[slot];
     if (k == MM_HASH_MAX) continue;
+    // the cluster around the slot: MM_SK_GUARD neighbours on either side are fetched at once (independent LDS reads, one latency);
+    // only a cluster that reaches further is walked slot by slot.  The guard slots beyond the table are always empty.
+    uint64_t L[MM_SK_GUARD], Rr[MM_SK_GUARD];
+#pragma unroll
+    for (int i = 0; i < MM_SK_GUARD; i++) { L[i] = tab.key[slot - 1 - i]; Rr[i] = tab.key[slot + 1 + i]; }
     uint32_t smaller = 0;
     int q = slot;                                   // -> first slot of the cluster
-    while (q > 0) { const uint64_t o = tab.key[q - 1]; if (o == MM_HASH_MAX) break; smaller += o < k ? 1u : 0u; q--; }
-    for (int r = slot + 1; r < NS; r++) { const uint64_t o = tab.key[r]; if (o == MM_HASH_MAX) break; smaller += o < k ? 1u : 0u; }
-    const uint64_t below = tab.occW[q >> 6] & ((1ull << (q & 63)) - 1ull);
-    const uint32_t rank = tab.occP[q >> 6] + (uint32_t)__popcll(below) + smaller;
+    bool openL = true, openR = true;
+#pragma unroll
+    for (int i = 0; i < MM_SK_GUARD; i++) {
+      openL = openL && L[i] != MM_HASH_MAX;
+      openR = openR && Rr[i] != MM_HASH_MAX;
+      if (openL) { smaller += L[i] < k ? 1u : 0u; q = slot - 1 - i; }
+      if (openR) smaller += Rr[i] < k ? 1u : 0u;
+    }
+    if (openL) { while (q > 0) { const uint64_t o = tab.key[q - 1]; if (o == MM_HASH_MAX) break; smaller += o < k ? 1u : 0u; q--; } }
+    if (openR) { for (int r = slot + 1 + MM_SK_GUARD; r < NS; r++) { const uint64_t o = tab.key[r]; if (o == MM_HASH_MAX) break; smaller += o < k ? 1u : 0u; } }
+    uint32_t rank;
+    if (HARD) {
+      const uint64_t below = tab.occW[q >> 6] & ((1ull << (q & 63)) - 1ull);
+      rank = tab.occP[q >> 6] + (uint32_t)__popcll(below) + smaller;
+    } else rank = (uint32_t)(it - (slot - q)) + smaller;      // every slot of [q, slot) is occupied
     if (rank < (uint32_t)s) {
       const size_t o = (size_t)f * s + rank;
       skHash[o] = k;
@@ -280,6 +377,7 @@ mm_sketch_fragment(unsigned char* smem, const int f, const uint4* __restrict__ g
     }
   }
   if (tid == 0) skCount[f] = D < (uint32_t)s ? D : (uint32_t)s;
+  mark(5);                                            // ranking + output (thread 0's share)
 }
 
 template <int K, bool HARD>
@@ -288,11 +386,11 @@ k_sketch_fragments(const uint4* __restrict__ gTabs, const uint32_t* __restrict__
                    const DFrag* __restrict__ frags, const uint32_t* __restrict__ readHasN,
                    const int32_t* __restrict__ fragList, const uint32_t* __restrict__ fragListCount, int s, int wantFast, int HT, int PAD,
                    uint64_t* __restrict__ skHash, int2* __restrict__ skPos, int8_t* __restrict__ skStrand,
-                   uint32_t* __restrict__ skCount, int32_t* __restrict__ hardList, uint32_t* __restrict__ hardCount) {
+                   uint32_t* __restrict__ skCount, int32_t* __restrict__ hardList, uint32_t* __restrict__ hardCount,
+                   unsigned long long* __restrict__ phaseStats) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  if (!HARD) {
-    mm_sketch_fragment<K, false>(smem, (int)blockIdx.x, gTabs, bases2, nmask, frags, readHasN, s, wantFast, HT, PAD, skHash, skPos, skStrand, skCount, hardList, hardCount);
-  } else {
+  static_assert(HARD, "the fast path is k_sketch_fast");
+  {
     // the hard list's length stays on the device (no host round trip between the two kernels): a fixed grid walks it
     const uint32_t nList = *fragListCount;
     for (uint32_t i = blockIdx.x; i < nList; i += gridDim.x) {
@@ -300,6 +398,270 @@ k_sketch_fragments(const uint4* __restrict__ gTabs, const uint32_t* __restrict__
       __syncthreads();                              // the next fragment reuses the LDS
     }
   }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Fast sketch kernel, per fragment (one workgroup).  What paces it besides the hash loop is how many workgroups share a CU -- the
+// table phases are LDS-latency bound and leave the VALU to whoever else is resident -- so the LDS footprint is kept small:
+//   * a table slot is the 64-bit key plus ONE 32-bit word, the (position, strand) of the occurrence that claimed the slot.  Repeat
+//     occurrences of a resident hash are rare outside repeats: they go on a short list, the slot gets a flag after the barrier, and
+//     only flagged slots fold their list entries into first / last / strand sum when the sketch is written;
+//   * the per-wave survivor queues hold the expected share of a wave plus six standard deviations, not a whole table's worth;
+//   * SL positions per thread are chosen so that the threads fill whole waves (4 982 k-mers: 250 threads x 20 positions = 4 waves,
+//     one per SIMD, instead of 312 x 16 = 5 waves of which two share a SIMD).
+// A fragment that overflows any of it (queue, table, duplicate list) or keeps fewer than s distinct survivors goes to the hard list.
+// ---------------------------------------------------------------------------------------------
+#define MM_SKF_FLAG 0x80000000u
+struct SkFast {
+  uint64_t* key; uint32_t* meta;      // meta: bit 31 = has entries on the duplicate list, low bits = pos << 1 | (strand > 0) of the owner
+  uint32_t* dup; uint32_t* counters;  // counters: [1] overflow  [2] occupied slots  [3] duplicates
+  uint64_t* occW; uint32_t* occP;
+  uint32_t nSlots, maxLoad, M; int sh;
+  __device__ __forceinline__ void set_cut(uint64_t T, uint32_t HT) {
+    sh = (T == MM_HASH_MAX) ? 0 : __clzll((long long)T);
+    const uint64_t t32 = ((T << sh) >> 32) + 1ull;
+    M = (uint32_t)((float)HT * 4294967296.0f / (float)t32 * 0.99999f);
+  }
+  __device__ __forceinline__ uint32_t home(uint64_t h) const { return __umulhi((uint32_t)((h << sh) >> 32), M); }
+  __device__ __forceinline__ void insert(uint64_t h, uint32_t m) {
+    uint32_t slot = home(h);
+    for (;;) {
+      const unsigned long long prev = atomicCAS((unsigned long long*)&key[slot], (unsigned long long)MM_HASH_MAX, (unsigned long long)h);
+      if (prev == MM_HASH_MAX) { meta[slot] = m; return; }                     // the owner: a plain store, nobody reads it before the barrier
+      if (prev == h) {
+        const uint32_t at = atomicAdd(&counters[3], 1u);
+        if (at < MM_SK_DUPCAP) dup[at] = slot | (m << 13); else atomicOr(&counters[1], 1u);
+        return;
+      }
+      if (++slot >= nSlots) { atomicOr(&counters[1], 1u); return; }
+    }
+  }
+};
+
+template <int K, int SL>
+__device__ __forceinline__ void
+mm_sketch_fast(unsigned char* smem, const int f, const uint4* __restrict__ gTabs, const uint32_t* __restrict__ bases2, const uint32_t* __restrict__ nmask,
+               const DFrag* __restrict__ frags, const uint32_t* __restrict__ readHasN, int s, int wantFast, int HT, int PAD, int QC,
+               uint64_t* __restrict__ skHash, int2* __restrict__ skPos, int8_t* __restrict__ skStrand,
+               uint32_t* __restrict__ skCount, int32_t* __restrict__ hardList, uint32_t* __restrict__ hardCount,
+               unsigned long long* __restrict__ phaseStats) {
+  // MM_SKETCH_STATS: shader-clock cycles thread 0 spends up to each phase boundary, summed over workgroups (diagnostics only)
+  unsigned long long tPrev = phaseStats ? __builtin_amdgcn_s_memtime() : 0ull;
+  auto mark = [&](int ph) {
+    if (phaseStats && threadIdx.x == 0) { const unsigned long long t = __builtin_amdgcn_s_memtime(); atomicAdd(&phaseStats[ph], t - tPrev); tPrev = t; }
+  };
+  const DFrag fr = frags[f];
+  const int len = fr.len;
+  const int n = len - K + 1;                        // k-mer positions
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  if (n <= 0) { if (tid == 0) skCount[f] = 0; return; }
+  const bool hasN = readHasN[fr.readId] != 0;
+
+  // ---- LDS carve (every offset a multiple of 16) ----
+  const int nW = (len + 15) / 16 + 4;               // code words incl. run-off for the last strip's window
+  const int nM = (len + 31) / 32 + 3;
+  const int NS = HT + PAD;                          // table slots (multiple of 64)
+  const int nOcc = NS >> 6;
+  const int nWaves = nthr >> 6;
+  const int QTOT = sketch_fast_queue_total(QC, nWaves, HT);   // >= the table's load limit: the memory serves as the list of occupied slots later
+  size_t off = 0;
+  using Tabs = typename MMTabsFor<K>::type;
+  Tabs* tabs = (Tabs*)(smem + off); off += sizeof(Tabs);
+  for (int i = tid; i < (int)(sizeof(Tabs) / 16); i += nthr) ((uint4*)tabs)[i] = gTabs[i];   // visible after the first __syncthreads() below
+  uint32_t* sW = (uint32_t*)(smem + off); off += (((size_t)nW * 4 + 15) / 16) * 16;
+  uint32_t* sM = (uint32_t*)(smem + off); off += (((size_t)nM * 4 + 15) / 16) * 16;
+  uint64_t* qH = (uint64_t*)(smem + off); off += (size_t)QC * nWaves * 8;        // per-wave queues: hashes
+  uint32_t* qM = (uint32_t*)(smem + off); off += (size_t)QTOT * 4;               //                  pos<<1 | (strand > 0)
+  SkFast tab;
+  tab.key = (uint64_t*)(smem + off) + MM_SK_GUARD; off += (size_t)(NS + 2 * MM_SK_GUARD) * 8;
+  tab.occW = (uint64_t*)(smem + off); off += (size_t)nOcc * 8;
+  tab.meta = (uint32_t*)(smem + off); off += (size_t)NS * 4;
+  tab.occP = (uint32_t*)(smem + off); off += (((size_t)nOcc * 4 + 15) / 16) * 16;
+  uint32_t* qCnt = (uint32_t*)(smem + off); off += 64;
+  tab.dup = (uint32_t*)(smem + off); off += (size_t)MM_SK_DUPCAP * 4;
+  tab.counters = (uint32_t*)(smem + off); off += 16;
+  tab.nSlots = (uint32_t)NS; tab.maxLoad = (uint32_t)HT * 5u / 8u;
+
+  // ---- stage the fragment, re-aligned so that LDS word j holds bases 16j..16j+15 ----
+  {
+    const int64_t w0 = fr.base >> 4; const int sh = (int)(fr.base & 15) * 2;
+    for (int j = tid; j < nW; j += nthr) {
+      const uint32_t a = bases2[w0 + j], b = bases2[w0 + j + 1];
+      sW[j] = sh ? __builtin_amdgcn_alignbit(b, a, sh) : a;
+    }
+    if (hasN) {
+      const int64_t m0 = fr.base >> 5; const int msh = (int)(fr.base & 31);
+      for (int j = tid; j < nM; j += nthr) {
+        const uint32_t a = nmask[m0 + j], b = nmask[m0 + j + 1];
+        sM[j] = msh ? __builtin_amdgcn_alignbit(b, a, msh) : a;
+      }
+    }
+  }
+  // threshold: the canonical hash is the smaller of two uniform 64-bit values, so P[h < T] ~ 2T / 2^64; the cut is placed where
+  // `wantFast` (> s) survivors are expected.  Any T gives the exact sketch as long as >= s distinct hashes survive (checked below).
+  const uint64_t T = ((uint32_t)wantFast >= (uint32_t)n) ? MM_HASH_MAX : (uint64_t)((float)wantFast / (float)(2 * n) * 18446744073709551616.0f);
+  const int nStrips = (n + SL - 1) / SL;
+  tab.set_cut(T, (uint32_t)HT);
+  for (int i = tid; i < NS; i += nthr) tab.key[i] = MM_HASH_MAX;
+  if (tid < MM_SK_GUARD) { tab.key[-1 - tid] = MM_HASH_MAX; tab.key[NS + tid] = MM_HASH_MAX; }
+  if (tid < 4) tab.counters[tid] = 0;
+  __syncthreads();
+  mark(0);                                          // staging + table init
+
+  // ---- phase 1: hash both strands of every k-mer ----
+  const uint32_t qBase = (uint32_t)(tid >> 6) * (uint32_t)QC, qEnd = qBase + (uint32_t)QC;
+  uint32_t qHead = qBase;                           // wave-uniform (only ballots feed it)
+  const bool allPass = (T == MM_HASH_MAX);
+  for (int strip = tid; strip < nStrips; strip += nthr) {
+    const int b0 = strip * SL;                      // first base of the strip: the 48-base window is cut out of four LDS words
+    const int wi = b0 >> 4, bsh = (b0 & 15) * 2;
+    uint32_t w0 = sW[wi], w1 = sW[wi + 1], w2 = sW[wi + 2];
+    if (SL % 16 != 0) {
+      const uint32_t w3 = sW[wi + 3];
+      if (bsh) { w0 = __builtin_amdgcn_alignbit(w1, w0, bsh); w1 = __builtin_amdgcn_alignbit(w2, w1, bsh); w2 = __builtin_amdgcn_alignbit(w3, w2, bsh); }
+    }
+    // bit j: position b0 + j exists and its k-mer holds no N
+    const int rem = n - b0;
+    uint32_t ok = rem >= SL ? (uint32_t)((1ull << SL) - 1ull) : ((1u << rem) - 1u);
+    if (hasN) {
+      const int mi = b0 >> 5, msh = b0 & 31;
+      const uint64_t lo64 = (uint64_t)sM[mi] | ((uint64_t)sM[mi + 1] << 32);
+      const uint64_t m64 = msh ? ((lo64 >> msh) | ((uint64_t)sM[mi + 2] << (64 - msh))) : lo64;
+      ok &= ~(uint32_t)mm_window_or<K>(m64);
+    }
+    mm_strip_hashes<K, SL>(w0, w1, w2, *tabs, [&](int j, uint64_t hf, uint64_t hr) {
+      const int pos = b0 + j;
+      const uint64_t h = hf < hr ? hf : hr;
+      bool pass = false;                            // nested ifs: the compiler keeps the three tests as exec masks
+      if ((ok & (1u << j)) != 0) { if (hf != hr) { if (allPass || h < T) pass = true; } }
+      const uint64_t m = __builtin_amdgcn_ballot_w64(pass);
+      const uint32_t idx = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, qHead));
+      if (pass && idx < qEnd) { qH[idx] = h; qM[idx] = ((uint32_t)pos << 1) | (hf < hr ? 1u : 0u); }
+      qHead += (uint32_t)__popcll(m);
+    });
+  }
+  mark(1);                                          // thread 0's hash loop
+  {
+    // lanes that left the strip loop early (or never entered it) hold a stale count; lane 0 owns the smallest strip
+    const uint32_t qCount = (uint32_t)__builtin_amdgcn_readfirstlane((int)(qHead - qBase));
+    if (mm_lane() == 0) { qCnt[tid >> 6] = qCount; if (qCount > (uint32_t)QC) atomicOr(&tab.counters[1], 1u); }
+  }
+  __syncthreads();
+  mark(2);                                          // waiting for the other waves' hash loops
+  if (tab.counters[1] == 0) {
+    // all threads drain all queues: entry g of the concatenated queues goes to thread g mod nthr, so every round of inserts is full
+    uint32_t pre[17]; pre[0] = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) pre[w + 1] = pre[w] + (w < nWaves ? qCnt[w] : 0u);
+    const uint32_t total = pre[16];
+    for (uint32_t g = (uint32_t)tid; g < total; g += (uint32_t)nthr) {
+      uint32_t w = 0, start = 0;                    // the queue entry g falls into, and where that queue starts in the concatenation
+#pragma unroll
+      for (int x = 1; x < 16; x++) if (g >= pre[x]) { w = (uint32_t)x; start = pre[x]; }
+      const uint32_t at = w * (uint32_t)QC + (g - start);
+      tab.insert(qH[at], qM[at]);
+    }
+  }
+  __syncthreads();
+  mark(3);                                          // queues drained into the table
+  {
+    // owners' stores are visible now: flag the slots that have entries on the duplicate list
+    const uint32_t nd = tab.counters[3] < MM_SK_DUPCAP ? tab.counters[3] : MM_SK_DUPCAP;
+    for (uint32_t i = (uint32_t)tid; i < nd; i += (uint32_t)nthr) atomicOr(&tab.meta[tab.dup[i] & 0x1FFFu], MM_SKF_FLAG);
+  }
+  // ---- occupancy words, their prefix counts (wave 0: one DPP scan per 64 words), number of distinct keys ----
+  for (int base = 0; base < NS; base += nthr) {
+    const int slot = base + tid;                    // NS and nthr are multiples of 64: a wave is in or out as a whole
+    if (slot < NS) {
+      const uint64_t m = __ballot(tab.key[slot] != MM_HASH_MAX);
+      if (mm_lane() == 0) tab.occW[slot >> 6] = m;
+    }
+  }
+  __syncthreads();
+  if (tid < 64) {
+    int carry = 0;
+    for (int w0 = 0; w0 < nOcc; w0 += 64) {
+      const int w = w0 + tid;
+      const int v = w < nOcc ? (int)__popcll(tab.occW[w]) : 0;
+      const int ex = mm_wave_excl_scan(v);
+      if (w < nOcc) tab.occP[w] = (uint32_t)(carry + ex);
+      carry += mm_wave_sum(v);
+    }
+    if (tid == 0) { tab.counters[2] = (uint32_t)carry; if ((uint32_t)carry > tab.maxLoad) tab.counters[1] = 1u; }
+  }
+  __syncthreads();
+  const uint32_t D = tab.counters[2];
+  if (tab.counters[1] != 0 || (D < (uint32_t)s && T != MM_HASH_MAX)) {
+    if (tid == 0) { const uint32_t at = atomicAdd(hardCount, 1u); hardList[at] = f; skCount[f] = 0; }
+    return;
+  }
+  // the occupied slots in slot order (the queue memory is free again): every thread then ranks D / nthr keys instead of visiting
+  // NS / nthr slots of which two thirds are empty; a key's position in that list is the number of occupied slots before it
+  uint32_t* occList = qM;
+  for (int slot = tid; slot < NS; slot += nthr) {
+    const uint64_t m = tab.occW[slot >> 6];
+    if ((m >> (slot & 63)) & 1ull) occList[tab.occP[slot >> 6] + (uint32_t)__popcll(m & ((1ull << (slot & 63)) - 1ull))] = (uint32_t)slot;
+  }
+  __syncthreads();
+  mark(4);                                          // duplicate flags, occupancy, prefix counts, list of occupied slots
+
+  // ---- rank every key inside its cluster; emit the s smallest, ascending (commonFunc.hpp:278-286) ----
+  const uint32_t nDup = tab.counters[3];
+  for (int it = tid; it < (int)D; it += nthr) {
+    const int slot = (int)occList[it];
+    const uint64_t k = tab.key[slot];
+    // the cluster around the slot: MM_SK_GUARD neighbours on either side are fetched at once (independent LDS reads, one latency);
+    // only a cluster that reaches further is walked slot by slot.  The guard slots beyond the table are always empty.
+    uint64_t L[MM_SK_GUARD], Rr[MM_SK_GUARD];
+#pragma unroll
+    for (int i = 0; i < MM_SK_GUARD; i++) { L[i] = tab.key[slot - 1 - i]; Rr[i] = tab.key[slot + 1 + i]; }
+    uint32_t smaller = 0;
+    int q = slot;                                   // -> first slot of the cluster
+    bool openL = true, openR = true;
+#pragma unroll
+    for (int i = 0; i < MM_SK_GUARD; i++) {
+      openL = openL && L[i] != MM_HASH_MAX;
+      openR = openR && Rr[i] != MM_HASH_MAX;
+      if (openL) { smaller += L[i] < k ? 1u : 0u; q = slot - 1 - i; }
+      if (openR) smaller += Rr[i] < k ? 1u : 0u;
+    }
+    if (openL) { while (q > 0) { const uint64_t o = tab.key[q - 1]; if (o == MM_HASH_MAX) break; smaller += o < k ? 1u : 0u; q--; } }
+    if (openR) { for (int r = slot + 1 + MM_SK_GUARD; r < NS; r++) { const uint64_t o = tab.key[r]; if (o == MM_HASH_MAX) break; smaller += o < k ? 1u : 0u; } }
+    const uint32_t rank = (uint32_t)(it - (slot - q)) + smaller;               // every slot of [q, slot) is occupied
+    if (rank < (uint32_t)s) {
+      const uint32_t m = tab.meta[slot];
+      int first = (int)((m & ~MM_SKF_FLAG) >> 1), last = first, sum = (m & 1u) ? 1 : -1;
+      if (m & MM_SKF_FLAG) {                                                   // repeat occurrences: first / last position, strand sum (commonFunc.hpp:242-270)
+        for (uint32_t i = 0; i < nDup; i++) {
+          const uint32_t d = tab.dup[i];
+          if ((int)(d & 0x1FFFu) != slot) continue;
+          const int pos = (int)(d >> 14);
+          first = pos < first ? pos : first; last = pos > last ? pos : last; sum += ((d >> 13) & 1u) ? 1 : -1;
+        }
+      }
+      const size_t o = (size_t)f * s + rank;
+      skHash[o] = k;
+      skPos[o] = make_int2(first, last);
+      // the reference accumulates the strand in an int16 (base_types.hpp:24, commonFunc.hpp:268)
+      const int16_t acc = (int16_t)sum;
+      skStrand[o] = acc > 0 ? 1 : (acc == 0 ? 0 : -1);
+    }
+  }
+  if (tid == 0) skCount[f] = D < (uint32_t)s ? D : (uint32_t)s;
+  mark(5);                                          // ranking + output (thread 0's share)
+}
+
+template <int K, int SL>
+__global__ void __launch_bounds__(1024)
+k_sketch_fast(const uint4* __restrict__ gTabs, const uint32_t* __restrict__ bases2, const uint32_t* __restrict__ nmask,
+              const DFrag* __restrict__ frags, const uint32_t* __restrict__ readHasN, int s, int wantFast, int HT, int PAD, int QC,
+              uint64_t* __restrict__ skHash, int2* __restrict__ skPos, int8_t* __restrict__ skStrand,
+              uint32_t* __restrict__ skCount, int32_t* __restrict__ hardList, uint32_t* __restrict__ hardCount,
+              unsigned long long* __restrict__ phaseStats) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  mm_sketch_fast<K, SL>(smem, (int)blockIdx.x, gTabs, bases2, nmask, frags, readHasN, s, wantFast, HT, PAD, QC, skHash, skPos, skStrand, skCount,
+                        hardList, hardCount, phaseStats);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -345,12 +707,48 @@ static size_t sketch_lds_bytes(size_t tabBytes, int maxLen, int HT, int PAD, boo
   const size_t nW = (size_t)(maxLen + 15) / 16 + 3, nM = (size_t)(maxLen + 31) / 32 + 2;
   const size_t NS = (size_t)HT + PAD, nOcc = NS / 64;
   return tabBytes + ((nW * 4 + 15) / 16) * 16 + ((nM * 4 + 15) / 16) * 16 + (hard ? 0 : (size_t)HT * 12) +
-         NS * (8 + 4 + 4 + 4) + nOcc * 8 + ((nOcc * 4 + 15) / 16) * 16 + 16;
+         NS * (8 + 4 + 4 + 4) + 2 * MM_SK_GUARD * 8 + 64 + (hard ? 0 : (size_t)MM_SK_DUPCAP * 4) + nOcc * 8 + ((nOcc * 4 + 15) / 16) * 16 + 16;
 }
 static int next_pow2(int x) { int p = 1; while (p < x) p <<= 1; return p; }
-#define MM_SK_PAD 64
-#define MM_SK_PADH 256
-static int sketch_ht_fast(int s) { return next_pow2(s * 3 < 256 ? 256 : s * 3); }
+
+// geometry of the fast kernel for fragments of up to maxLen bases: positions per thread, threads, table and queue sizes
+struct FastGeom { int SL, threads, HT, QC, wantFast; size_t lds; };
+static size_t sketch_fast_lds(size_t tabBytes, int maxLen, int HT, int PAD, int QC, int nWaves) {
+  const size_t nW = (size_t)(maxLen + 15) / 16 + 4, nM = (size_t)(maxLen + 31) / 32 + 3;
+  const size_t NS = (size_t)HT + PAD, nOcc = NS / 64;
+  return tabBytes + ((nW * 4 + 15) / 16) * 16 + ((nM * 4 + 15) / 16) * 16 + (size_t)QC * nWaves * 8 + (size_t)sketch_fast_queue_total(QC, nWaves, HT) * 4 +
+         (NS + 2 * MM_SK_GUARD) * 8 + nOcc * 8 + NS * 4 + ((nOcc * 4 + 15) / 16) * 16 + 64 + (size_t)MM_SK_DUPCAP * 4 + 16;
+}
+static FastGeom sketch_fast_geom(int K, int s, int maxLen, size_t tabBytes, bool sl20Built) {
+  FastGeom g;
+  // survivors the fast kernel aims for: s + max(s/2, 4 sqrt(s)) (their count is ~Poisson, so s stays >= 4 sigma away);
+  // fewer = less queue/table work, more fragments redone by the hard kernel (1 in 2 M at s = 130).  MM_SKETCH_CUT = factor on s.
+  double margin = s * 0.5; if (margin < 4.0 * sqrt((double)s)) margin = 4.0 * sqrt((double)s);
+  g.wantFast = (int)(s + margin + 0.999);
+  if (const char* e = getenv("MM_SKETCH_CUT")) { double cut = atof(e); if (cut < 1.05) cut = 1.05; if (cut > 2.5) cut = 2.5; g.wantFast = (int)(s * cut + 0.999); }
+  int n = maxLen - K + 1; if (n < 1) n = 1;
+  // positions per thread: 16, or 20 where that fills whole waves better (the workgroup's critical path is ceil(waves / 4 SIMDs) strips)
+  auto wavesFor = [&](int SL) { int st = (n + SL - 1) / SL; int w = (st + 63) / 64; return w < 1 ? 1 : (w > 16 ? 16 : w); };
+  g.SL = 16;
+  if (sl20Built && 20 + K - 1 <= 48) {
+    const int w16 = wavesFor(16), w20 = wavesFor(20);
+    const int c16 = ((w16 + 3) / 4) * 16, c20 = ((w20 + 3) / 4) * 20;
+    if (c20 < c16 || (c20 == c16 && w20 < w16)) g.SL = 20;
+  }
+  if (const char* e = getenv("MM_SKETCH_SL")) { const int v = atoi(e); if (v == 16 || (v == 20 && sl20Built && 20 + K - 1 <= 48)) g.SL = v; }
+  g.threads = wavesFor(g.SL) * 64;
+  if (const char* e = getenv("MM_SKETCH_THREADS")) { const int t = atoi(e); if (t >= 64 && t <= 1024 && t % 64 == 0) g.threads = t; }
+  const int nWaves = g.threads / 64;
+  int HT = (int)(2.4 * g.wantFast + 63) / 64 * 64; if (HT < 256) HT = 256;
+  g.HT = HT;
+  // a wave queues the survivors of its 64 threads' strips: their expectation + 6 standard deviations
+  int nStrips = (n + g.SL - 1) / g.SL; if (nStrips < 1) nStrips = 1;
+  const int passes = (nStrips + g.threads - 1) / g.threads;
+  double ex = 64.0 * passes * g.SL * (double)g.wantFast / (double)n; if (ex > g.wantFast) ex = g.wantFast;
+  g.QC = ((int)(ex + 6.0 * sqrt(ex) + 8.0) + 3) & ~3;
+  g.lds = sketch_fast_lds(tabBytes, maxLen, g.HT, MM_SK_PAD, g.QC, nWaves);
+  return g;
+}
 static int sketch_ht_hard(int s) { return next_pow2(s * 3 < 4096 ? 4096 : s * 3); }   // load limit 5/8 of it stays >= 2 s
 
 // Parameter combinations the LDS-resident kernels cannot hold are refused when the context is created (not after the reference
@@ -358,7 +756,7 @@ static int sketch_ht_hard(int s) { return next_pow2(s * 3 < 4096 ? 4096 : s * 3)
 int mm_check_params(const mm_params* p, std::string& err) {
   const int s = p->sketchSize, L = p->segLength;
   const size_t tabBytes = p->kmerSize >= 16 ? sizeof(MMProdTables) : sizeof(MMTables);
-  const size_t ldsFast = sketch_lds_bytes(tabBytes, L, sketch_ht_fast(s), MM_SK_PAD, false), ldsHard = sketch_lds_bytes(tabBytes, L, sketch_ht_hard(s), MM_SK_PADH, true);
+  const size_t ldsFast = sketch_fast_geom(p->kmerSize, s, L, tabBytes, false).lds, ldsHard = sketch_lds_bytes(tabBytes, L, sketch_ht_hard(s), MM_SK_PADH, true);
   const size_t ldsL2 = (size_t)(s + 1) * 64 * 2;
   const size_t lim = 160 * 1024;
   if (ldsFast > lim || ldsHard > lim || ldsL2 > lim) {
@@ -370,29 +768,21 @@ int mm_check_params(const mm_params* p, std::string& err) {
   return MM_OK;
 }
 
+template <int K> struct MMHasSL20 { static constexpr bool value = (K >= 16 && K <= 21); };   // strips of 20 positions are built for these k-mer sizes
+
 template <int K>
 static int launch_sketch_k(mm_ctx* c) {
   const int s = c->P.sketchSize;
   const int nF = (int)c->nFrags;
-  // survivors the fast kernel aims for: s + max(s/2, 4 sqrt(s)) (their count is ~Poisson, so s stays >= 4 sigma away);
-  // fewer = less queue/table work, more fragments redone by the hard kernel (1 in 2 M at s = 130).  MM_SKETCH_CUT = factor on s.
-  double margin = s * 0.5; if (margin < 4.0 * sqrt((double)s)) margin = 4.0 * sqrt((double)s);
-  int wantFast = (int)(s + margin + 0.999);
-  if (const char* e = getenv("MM_SKETCH_CUT")) { double cut = atof(e); if (cut < 1.05) cut = 1.05; if (cut > 2.5) cut = 2.5; wantFast = (int)(s * cut + 0.999); }
-  const int HT = sketch_ht_fast(s), HTH = sketch_ht_hard(s);
-  const int maxLen = c->maxFragLen;
-  const int PAD = MM_SK_PAD, PADH = MM_SK_PADH;     // spill slots behind the ordered tables (no wrap-around)
-  const size_t ldsFast = sketch_lds_bytes(sizeof(typename MMTabsFor<K>::type), maxLen, HT, PAD, false),
-               ldsHard = sketch_lds_bytes(sizeof(typename MMTabsFor<K>::type), maxLen, HTH, PADH, true);
-  if (ldsHard > 160 * 1024) { c->err = "fragment too long / sketch too large for the LDS-resident sketch kernel"; return MM_ERR_ARG; }
-  int nStrips = (maxLen - K + 1 + 15) / 16; if (nStrips < 1) nStrips = 1;
-  // one strip per thread; a last, partly filled wave is folded into a second pass of wave 0 instead (same number of
-  // wave-passes over the hash loop, one wave less running the per-workgroup phases) as long as 4 waves remain
-  int threads = ((nStrips + 63) / 64) * 64;
-  if ((nStrips & 63) && (nStrips / 64) * 64 >= 256) threads = (nStrips / 64) * 64;
-  if (threads > 1024) threads = 1024; if (threads < 64) threads = 64;
-  if (const char* e = getenv("MM_SKETCH_THREADS")) { const int t = atoi(e); if (t >= 64 && t <= 1024 && t % 64 == 0) threads = t; }
   using Tabs = typename MMTabsFor<K>::type;
+  const int maxLen = c->maxFragLen;
+  const FastGeom g = sketch_fast_geom(K, s, maxLen, sizeof(Tabs), MMHasSL20<K>::value);
+  const int HTH = sketch_ht_hard(s);
+  const int PAD = MM_SK_PAD, PADH = MM_SK_PADH;     // spill slots behind the ordered tables (no wrap-around)
+  const size_t ldsFast = g.lds, ldsHard = sketch_lds_bytes(sizeof(Tabs), maxLen, HTH, PADH, true);
+  if (ldsHard > 160 * 1024 || ldsFast > 160 * 1024) { c->err = "fragment too long / sketch too large for the LDS-resident sketch kernel"; return MM_ERR_ARG; }
+  int nStrips = (maxLen - K + 1 + 15) / 16; if (nStrips < 1) nStrips = 1;
+  int threadsHard = ((nStrips + 63) / 64) * 64; if (threadsHard > 1024) threadsHard = 1024;
   if (c->sketchTabsK != K) {
     MM_HIP(c, c->dSketchTabs.ensure(sizeof(Tabs)));
     hipLaunchKernelGGL((k_sketch_tables<K>), dim3(1), dim3(256), 0, c->stream, c->dSketchTabs.as<Tabs>());
@@ -400,30 +790,43 @@ static int launch_sketch_k(mm_ctx* c) {
     c->sketchTabsK = K;
   }
   MM_HIP(c, hipMemsetAsync(c->dCounters.p, 0, 64, c->stream));
-  MM_HIP(c, hipFuncSetAttribute((const void*)k_sketch_fragments<K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsFast));
+  unsigned long long* phaseStats = nullptr;
+  if (getenv("MM_SKETCH_STATS")) { phaseStats = c->dCounters.as<unsigned long long>() + 24; MM_HIP(c, hipMemsetAsync(phaseStats, 0, 64, c->stream)); }
   MM_HIP(c, hipFuncSetAttribute((const void*)k_sketch_fragments<K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsHard));
   {
     KernelTimer t(c, MM_K_SKETCH);
-    hipLaunchKernelGGL((k_sketch_fragments<K, false>), dim3(nF), dim3(threads), ldsFast, c->stream,
-                       c->dSketchTabs.as<uint4>(), c->dBases2.as<uint32_t>(), c->dNmask.as<uint32_t>(), c->dFrags.as<DFrag>(), c->dReadHasN.as<uint32_t>(),
-                       (const int32_t*)nullptr, (const uint32_t*)nullptr, s, wantFast, HT, PAD, c->dSkHash.as<uint64_t>(), c->dSkPos.as<int2>(), c->dSkStrand.as<int8_t>(),
-                       c->dSkCount.as<uint32_t>(), c->dHardList.as<int32_t>(), c->dCounters.as<uint32_t>());
+    auto launch = [&](auto kern) {
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsFast);
+      hipLaunchKernelGGL(kern, dim3(nF), dim3(g.threads), ldsFast, c->stream,
+                         c->dSketchTabs.as<uint4>(), c->dBases2.as<uint32_t>(), c->dNmask.as<uint32_t>(), c->dFrags.as<DFrag>(), c->dReadHasN.as<uint32_t>(),
+                         s, g.wantFast, g.HT, PAD, g.QC, c->dSkHash.as<uint64_t>(), c->dSkPos.as<int2>(), c->dSkStrand.as<int8_t>(),
+                         c->dSkCount.as<uint32_t>(), c->dHardList.as<int32_t>(), c->dCounters.as<uint32_t>(), phaseStats);
+    };
+    if constexpr (MMHasSL20<K>::value) { if (g.SL == 20) launch(k_sketch_fast<K, 20>); else launch(k_sketch_fast<K, 16>); }
+    else launch(k_sketch_fast<K, 16>);
     MM_HIP(c, hipGetLastError());
+  }
+  if (phaseStats) {
+    unsigned long long h[8];
+    MM_HIP(c, hipMemcpyAsync(h, phaseStats, 64, hipMemcpyDeviceToHost, c->stream));
+    MM_HIP(c, hipStreamSynchronize(c->stream));
+    fprintf(stderr, "[mm] sketch phases, shader-clock cycles per workgroup (thread 0), %d fragments, %d threads x %d positions, HT %d, queue %d/wave, lds %zu: stage+init %.0f | hash %.0f | wait %.0f | drain %.0f | occupancy+list %.0f | rank+emit %.0f\n",
+            nF, g.threads, g.SL, g.HT, g.QC, ldsFast, (double)h[0] / nF, (double)h[1] / nF, (double)h[2] / nF, (double)h[3] / nF, (double)h[4] / nF, (double)h[5] / nF);
   }
   if (getenv("MM_DEBUG")) {
     uint32_t nHard = 0;
     MM_HIP(c, hipMemcpyAsync(&nHard, c->dCounters.p, 4, hipMemcpyDeviceToHost, c->stream));
     MM_HIP(c, hipStreamSynchronize(c->stream));
-    fprintf(stderr, "[mm] sketch: %d fragments, %u to the hard path, threads %d, HT %d, lds %zu/%zu\n", nF, nHard, threads, HT, ldsFast, ldsHard);
+    fprintf(stderr, "[mm] sketch: %d fragments, %u to the hard path, threads %d x %d positions, HT %d, lds %zu/%zu\n", nF, nHard, g.threads, g.SL, g.HT, ldsFast, ldsHard);
   }
   {
     // fixed grid over the device-resident hard list (its workgroups leave at once when the list is empty or short)
     KernelTimer t(c, MM_K_SKETCH_HARD);
     const int grid = nF < 1024 ? nF : 1024;
-    hipLaunchKernelGGL((k_sketch_fragments<K, true>), dim3(grid), dim3(threads), ldsHard, c->stream,
+    hipLaunchKernelGGL((k_sketch_fragments<K, true>), dim3(grid), dim3(threadsHard), ldsHard, c->stream,
                        c->dSketchTabs.as<uint4>(), c->dBases2.as<uint32_t>(), c->dNmask.as<uint32_t>(), c->dFrags.as<DFrag>(), c->dReadHasN.as<uint32_t>(),
-                       c->dHardList.as<int32_t>(), c->dCounters.as<uint32_t>(), s, wantFast, HTH, PADH, c->dSkHash.as<uint64_t>(), c->dSkPos.as<int2>(), c->dSkStrand.as<int8_t>(),
-                       c->dSkCount.as<uint32_t>(), c->dHardList.as<int32_t>(), c->dCounters.as<uint32_t>() + 1);
+                       c->dHardList.as<int32_t>(), c->dCounters.as<uint32_t>(), s, g.wantFast, HTH, PADH, c->dSkHash.as<uint64_t>(), c->dSkPos.as<int2>(), c->dSkStrand.as<int8_t>(),
+                       c->dSkCount.as<uint32_t>(), c->dHardList.as<int32_t>(), c->dCounters.as<uint32_t>() + 1, (unsigned long long*)nullptr);
     MM_HIP(c, hipGetLastError());
   }
   return MM_OK;
