@@ -173,6 +173,10 @@ int     mm_stat_replay_tables(int sketchSize, int k, float percentageIdentity, f
  */
 int mm_reads_upload(mm_ctx* ctx, const char* bases, const int64_t* readOffsets, size_t nReads,
                     const int32_t* readRefGroup, const int32_t* readSelfSeqId, int32_t seqCounterBase);
+/* page-locked host memory for the `bases` of mm_reads_upload / mm_index_build: the copy to the GPU is then a single DMA at PCIe rate
+ * (pageable memory is staged through a bounce buffer at a fraction of it).  Optional: any host pointer works. */
+void* mm_host_alloc(size_t bytes);
+void  mm_host_free(void* p);
 /* same, from already device-resident ASCII (hipMalloc'ed by the caller, e.g. a torch tensor) */
 int mm_reads_upload_device(mm_ctx* ctx, const void* dBases, size_t nBases, const int64_t* readOffsets, size_t nReads,
                            const int32_t* readRefGroup, const int32_t* readSelfSeqId, int32_t seqCounterBase);

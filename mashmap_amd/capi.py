@@ -81,6 +81,8 @@ def load():
         "mm_reads_upload": (C.c_int, [vp, vp, vp, sz, vp, vp, i32]),
         "mm_reads_upload_device": (C.c_int, [vp, vp, sz, vp, sz, vp, vp, i32]),
         "mm_num_fragments": (sz, [vp]),
+        "mm_host_alloc": (vp, [sz]),
+        "mm_host_free": (None, [vp]),
         "mm_fragments_download": (C.c_int, [vp, vp]),
         "mm_sketch_fragments": (C.c_int, [vp]),
         "mm_sketch_download": (C.c_int, [vp, vp, vp]),
@@ -135,7 +137,7 @@ EXPORTS = ["mm_abi_version", "mm_create", "mm_destroy", "mm_last_error", "mm_ind
            "mm_kernel_name", "mm_synchronize", "mm_stream", "mm_bench_hash_only",
            "mm_set_replay_tables", "mm_mappings_count", "mm_mappings_download", "mm_mappings_device", "mm_comm_unique_id",
            "mm_comm_init_rank", "mm_comm_init_local", "mm_comm_world", "mm_allgatherv_mappings", "mm_allgatherv_mappings_local",
-           "mm_gathered_counts", "mm_gathered_download", "mm_gathered_device", "mm_index_replicate", "mm_stat_replay_tables"]
+           "mm_gathered_counts", "mm_gathered_download", "mm_gathered_device", "mm_index_replicate", "mm_stat_replay_tables", "mm_host_alloc", "mm_host_free"]
 
 
 def stat_sketch_cutoffs(sketchSize, k, hg=True):

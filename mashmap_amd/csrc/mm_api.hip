@@ -239,6 +239,13 @@ int mm_reads_upload_device(mm_ctx* c, const void* dBases, size_t nBases, const i
   return upload_reads_common(c, dBases, true, nBases, readOffsets, nReads, g, s, base);
 }
 
+void* mm_host_alloc(size_t bytes) {
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+  return p;
+}
+void mm_host_free(void* p) { if (p) (void)hipHostFree(p); }
+
 size_t mm_num_fragments(const mm_ctx* c) { return c->nFrags; }
 int mm_fragments_download(mm_ctx* c, mm_fragment* out) {
   if (c->nFrags) std::memcpy(out, c->hFrags.data(), c->nFrags * sizeof(mm_fragment));

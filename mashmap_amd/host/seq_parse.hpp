@@ -1,0 +1,343 @@
+// mashmap_amd/host/seq_parse.hpp -- multi-threaded FASTA / FASTQ (optionally gzip / BGZF) ingest into flat batches.
+//
+// Same record semantics as seqiter::for_each_seq_in_file (src/common/seqiter.hpp:20-111, the non-htslib path):
+//   * the first byte of the file decides the format ('>' FASTA, '@' FASTQ), anything else is fatal;
+//   * name = header without its first character, cut at the first ' ' (:82);
+//   * FASTA sequence = concatenation of the following lines up to the next line starting with '>';
+//   * FASTQ: one sequence line, then two lines skipped (:104-107);
+//   * records failing the keep_prefix / keep_seq filters are still reported, with an empty sequence (:84-97).
+// What differs is the mechanics.  The reference pulls records one at a time through a 303-byte igzstream (src/common/gzstream.h:50)
+// on one thread (~37 Mbp/s).  Here a file is taken in windows of raw bytes that end on a record boundary; a window
+// is cut at record boundaries into one piece per thread; every thread finds its records (memchr over lines) and their sequence
+// lengths, a prefix sum places them, and the threads copy the sequence bytes -- without the line breaks -- straight into the batch
+// buffer (pinned host memory when the caller provides an allocator, so that the upload to the GPU is one DMA).  Plain files are
+// mmap'ed; BGZF files (bgzip: independent <= 64 KiB deflate blocks, htslib's format -- the reference's data directory ships .gzi
+// indexes of such files) are inflated block-parallel; any other gzip stream is inflated by one thread ahead of the parsers.
+#pragma once
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <iostream>
+#include <string>
+#include <thread>
+#include <unordered_set>
+#include <vector>
+
+namespace mmhost {
+
+struct ParsedBatch {
+  std::vector<std::string> names;
+  std::vector<int64_t> offs{0};      // record r owns bases[offs[r], offs[r+1])
+  char* bases = nullptr;             // buffer from the reader's allocator
+  size_t cap = 0;
+  size_t size() const { return names.size(); }
+  int64_t totalBases() const { return offs.back(); }
+};
+
+namespace detail {
+
+inline void run_parallel(unsigned threads, const std::function<void(unsigned)>& fn) {
+  if (threads <= 1) { fn(0); return; }
+  std::vector<std::thread> th;
+  for (unsigned t = 1; t < threads; t++) th.emplace_back(fn, t);
+  fn(0);
+  for (auto& x : th) x.join();
+}
+
+// start of the next line at or after p (one past the next '\n'), or e
+inline const char* next_line(const char* p, const char* e) {
+  const char* nl = (const char*)memchr(p, '\n', (size_t)(e - p));
+  return nl ? nl + 1 : e;
+}
+// is `p` (a line start) the first byte of a record?
+inline bool record_starts_at(const char* p, const char* e, bool fasta) {
+  if (p >= e) return false;
+  if (fasta) return *p == '>';
+  if (*p != '@') return false;
+  const char* l2 = next_line(next_line(p, e), e);            // FASTQ: '@' header, and the line two below starts with '+' (a quality
+  return l2 < e && *l2 == '+';                               // line that starts with '@' is followed, two lines on, by a sequence line)
+}
+// first record start at or after p (p need not be a line start), or e
+inline const char* next_record(const char* base, const char* p, const char* e, bool fasta) {
+  const char* q = (p == base || p[-1] == '\n') ? p : next_line(p, e);
+  while (q < e && !record_starts_at(q, e, fasta)) q = next_line(q, e);
+  return q;
+}
+
+struct Rec { const char* hdr; const char* body; const char* end; int64_t seqLen; bool keep; };
+
+// source of raw (decompressed) bytes, window by window; every window ends on a record boundary
+class RawSource {
+ public:
+  virtual ~RawSource() {}
+  virtual bool next(const char*& p, size_t& n, bool fasta, bool first) = 0;   // false: exhausted
+  virtual char first_byte() = 0;
+};
+
+class MmapSource : public RawSource {
+  int fd_ = -1; const char* data_ = nullptr; size_t size_ = 0, pos_ = 0, window_;
+ public:
+  MmapSource(const std::string& path, size_t window) : window_(window) {
+    fd_ = open(path.c_str(), O_RDONLY);
+    if (fd_ < 0) return;
+    struct stat st; if (fstat(fd_, &st) != 0) return;
+    size_ = (size_t)st.st_size;
+    if (size_) { void* m = mmap(nullptr, size_, PROT_READ, MAP_PRIVATE, fd_, 0); if (m == MAP_FAILED) { size_ = 0; return; } data_ = (const char*)m; madvise((void*)data_, size_, MADV_SEQUENTIAL); }
+  }
+  ~MmapSource() override { if (data_) munmap((void*)data_, size_); if (fd_ >= 0) close(fd_); }
+  bool ok() const { return fd_ >= 0; }
+  char first_byte() override { return size_ ? data_[0] : 0; }
+  bool next(const char*& p, size_t& n, bool fasta, bool) override {
+    if (pos_ >= size_) return false;
+    const char* b = data_ + pos_; const char* e = data_ + size_;
+    const char* cut = e;
+    if ((size_t)(e - b) > window_) {
+      cut = next_record(data_, b + window_, e, fasta);           // the window grows to the next record boundary (a record is never split)
+    }
+    p = b; n = (size_t)(cut - b); pos_ += n;
+    return true;
+  }
+};
+
+// gzip / BGZF: inflated into an internal buffer; the tail behind the last record boundary is carried into the next window
+class GzSource : public RawSource {
+  std::string path_; size_t window_; unsigned threads_;
+  FILE* raw_ = nullptr; bool bgzf_ = false; gzFile gz_ = nullptr;
+  std::vector<char> buf_; size_t carry_ = 0; bool eof_ = false;
+  std::vector<unsigned char> comp_;
+
+  bool fill_stream(size_t want) {
+    while (buf_.size() < want && !eof_) {
+      const size_t at = buf_.size(); buf_.resize(at + (8u << 20));
+      const int got = gzread(gz_, buf_.data() + at, 8u << 20);
+      buf_.resize(at + (got > 0 ? (size_t)got : 0));
+      if (got <= 0) eof_ = true;
+    }
+    return !buf_.empty();
+  }
+  // BGZF (SAM spec 4.1): gzip member with extra subfield 'B','C' holding BSIZE = block size - 1; payload = raw deflate; trailer CRC32 + ISIZE
+  bool fill_bgzf(size_t want) {
+    struct Blk { size_t cOff, cLen, uOff, uLen; };
+    while (buf_.size() < want && !eof_) {
+      std::vector<Blk> blks; comp_.clear();
+      size_t uTot = 0;
+      while (uTot < (64u << 20)) {
+        unsigned char h[18];
+        if (fread(h, 1, 18, raw_) != 18) { eof_ = true; break; }
+        if (h[0] != 31 || h[1] != 139 || !(h[3] & 4) || h[12] != 'B' || h[13] != 'C') { std::cerr << "[mashmap_hip] malformed BGZF block in " << path_ << std::endl; exit(1); }
+        const size_t bsize = (size_t)h[16] + ((size_t)h[17] << 8) + 1;
+        const size_t at = comp_.size(); comp_.resize(at + bsize - 18);
+        if (fread(comp_.data() + at, 1, bsize - 18, raw_) != bsize - 18) { std::cerr << "[mashmap_hip] truncated BGZF file " << path_ << std::endl; exit(1); }
+        const unsigned char* t = comp_.data() + at + bsize - 18 - 4;
+        const size_t isize = (size_t)t[0] | ((size_t)t[1] << 8) | ((size_t)t[2] << 16) | ((size_t)t[3] << 24);
+        blks.push_back(Blk{at, bsize - 18 - 8, uTot, isize});
+        uTot += isize;
+      }
+      const size_t base = buf_.size(); buf_.resize(base + uTot);
+      std::atomic<size_t> nextB(0); std::atomic<int> bad(0);
+      run_parallel(std::max(1u, std::min<unsigned>(threads_, (unsigned)blks.size())), [&](unsigned) {
+        z_stream zs;
+        for (size_t i = nextB.fetch_add(1); i < blks.size(); i = nextB.fetch_add(1)) {
+          if (!blks[i].uLen) continue;
+          std::memset(&zs, 0, sizeof zs);
+          if (inflateInit2(&zs, -15) != Z_OK) { bad = 1; return; }
+          zs.next_in = comp_.data() + blks[i].cOff; zs.avail_in = (uInt)blks[i].cLen;
+          zs.next_out = (Bytef*)(buf_.data() + base + blks[i].uOff); zs.avail_out = (uInt)blks[i].uLen;
+          const int rc = inflate(&zs, Z_FINISH);
+          inflateEnd(&zs);
+          if (rc != Z_STREAM_END) bad = 1;
+        }
+      });
+      if (bad) { std::cerr << "[mashmap_hip] corrupt BGZF block in " << path_ << std::endl; exit(1); }
+    }
+    return !buf_.empty();
+  }
+
+ public:
+  GzSource(const std::string& path, size_t window, unsigned threads) : path_(path), window_(window), threads_(threads) {
+    raw_ = fopen(path.c_str(), "rb");
+    if (!raw_) return;
+    unsigned char h[18] = {0};
+    const size_t got = fread(h, 1, 18, raw_);
+    bgzf_ = got == 18 && h[0] == 31 && h[1] == 139 && (h[3] & 4) && h[10] == 6 && h[11] == 0 && h[12] == 'B' && h[13] == 'C';
+    if (bgzf_) fseek(raw_, 0, SEEK_SET);
+    else { fclose(raw_); raw_ = nullptr; gz_ = gzopen(path.c_str(), "rb"); if (gz_) gzbuffer(gz_, 1u << 20); }
+  }
+  ~GzSource() override { if (raw_) fclose(raw_); if (gz_) gzclose(gz_); }
+  bool ok() const { return raw_ || gz_; }
+  char first_byte() override { if (buf_.empty()) { if (bgzf_) fill_bgzf(1); else fill_stream(1); } return buf_.empty() ? 0 : buf_[0]; }
+  bool next(const char*& p, size_t& n, bool fasta, bool) override {
+    if (carry_) { buf_.erase(buf_.begin(), buf_.begin() + (std::ptrdiff_t)carry_); carry_ = 0; }
+    size_t want = window_;
+    while (true) {
+      if (bgzf_) fill_bgzf(want); else fill_stream(want);
+      if (buf_.empty()) return false;
+      const char* b = buf_.data(); const char* e = b + buf_.size();
+      if (eof_) { p = b; n = buf_.size(); carry_ = n; return true; }
+      // last record boundary inside the buffer (not at its start): everything before it is complete
+      const char* cut = nullptr; const char* q = e;
+      while (q > b + 1) {
+        const char* nl = (const char*)memrchr(b, '\n', (size_t)(q - 1 - b));
+        if (!nl) break;
+        if (nl + 1 < e && record_starts_at(nl + 1, e, fasta) && (fasta || next_line(next_line(nl + 1, e), e) < e)) { cut = nl + 1; break; }
+        q = nl + 1;
+      }
+      if (cut && cut > b) { p = b; n = (size_t)(cut - b); carry_ = n; return true; }
+      want = buf_.size() + window_;                              // one record longer than the buffer: read on
+    }
+  }
+};
+
+}  // namespace detail
+
+// Batches of records from a list of files.  Not thread-safe; next() itself runs `threads` workers.
+class BatchReader {
+ public:
+  typedef std::function<char*(size_t)> Alloc;
+  typedef std::function<void(char*)> Free;
+
+  BatchReader(std::vector<std::string> files, size_t windowBytes, unsigned threads, std::unordered_set<std::string> keepSeq = {},
+              std::string keepPrefix = "", Alloc a = nullptr, Free f = nullptr)
+      : files_(std::move(files)), window_(std::max<size_t>(windowBytes, 1u << 16)), threads_(std::max(1u, threads)), keepSeq_(std::move(keepSeq)),
+        keepPrefix_(std::move(keepPrefix)), alloc_(a ? a : [](size_t n) { return (char*)malloc(n); }), free_(f ? f : [](char* p) { free(p); }) {}
+  ~BatchReader() { delete src_; }
+
+  // index of the file the batch returned last came from, and whether it was that file's last batch
+  size_t fileIndex() const { return curFile_; }
+  bool fileDone() const { return fileDone_; }
+  void release(ParsedBatch& b) { if (b.bases) free_(b.bases); b.bases = nullptr; b.cap = 0; }
+
+  bool next(ParsedBatch& out) {
+    out.names.clear(); out.offs.assign(1, 0);
+    while (true) {
+      if (!src_) {
+        if (nextFile_ >= files_.size()) return false;
+        openFile(files_[nextFile_]); curFile_ = nextFile_++; firstWindow_ = true;
+      }
+      const char* p = nullptr; size_t n = 0;
+      if (!src_->next(p, n, fasta_, firstWindow_)) { delete src_; src_ = nullptr; continue; }
+      firstWindow_ = false;
+      parseWindow(p, n, out);
+      // peek: is this file exhausted?  (cheap for mmap; for gz the next call finds out)
+      fileDone_ = false;
+      return true;
+    }
+  }
+
+ private:
+  std::vector<std::string> files_; size_t window_; unsigned threads_;
+  std::unordered_set<std::string> keepSeq_; std::string keepPrefix_;
+  Alloc alloc_; Free free_;
+  detail::RawSource* src_ = nullptr; size_t nextFile_ = 0, curFile_ = 0; bool fasta_ = true, firstWindow_ = true, fileDone_ = false;
+
+  void openFile(const std::string& path) {
+    bool gz = false;
+    { FILE* f = fopen(path.c_str(), "rb"); if (f) { unsigned char m[2] = {0, 0}; if (fread(m, 1, 2, f) == 2) gz = m[0] == 31 && m[1] == 139; fclose(f); } }
+    bool ok = false;
+    if (gz) { auto* s = new detail::GzSource(path, window_, threads_); ok = s->ok(); src_ = s; }
+    else { auto* s = new detail::MmapSource(path, window_); ok = s->ok(); src_ = s; }
+    const char c = ok ? src_->first_byte() : 0;
+    if (!ok || (c != '>' && c != '@')) {
+      std::cerr << "[mashmap_hip::for_each_seq_in_file] unknown file format given to the sequence reader: " << path << std::endl;
+      exit(1);
+    }
+    fasta_ = c == '>';
+  }
+
+  void parseWindow(const char* p, size_t n, ParsedBatch& out) {
+    using detail::Rec;
+    const char* b = p; const char* e = p + n;
+    const unsigned T = (unsigned)std::min<size_t>(threads_, std::max<size_t>(1, n >> 16));
+    // piece t = records that start in [cut[t], cut[t+1])
+    std::vector<const char*> cut(T + 1, e);
+    cut[0] = b;
+    const bool fasta = fasta_;
+    detail::run_parallel(T, [&](unsigned t) { if (t) cut[t] = detail::next_record(b, b + n / T * t, e, fasta); });   // may scan a long record: in parallel
+    for (unsigned t = 1; t <= T; t++) if (cut[t] < cut[t - 1]) cut[t] = cut[t - 1];
+    std::vector<std::vector<Rec>> recs(T);
+    detail::run_parallel(T, [&](unsigned t) {
+      const char* q = cut[t]; const char* pe = cut[t + 1];
+      auto& R = recs[t];
+      while (q < pe) {
+        Rec r; r.hdr = q; r.keep = true;
+        const char* body = detail::next_line(q, e);
+        r.body = body;
+        if (fasta) {
+          int64_t len = 0; const char* l = body;
+          while (l < e && *l != '>') {
+            const char* nl = (const char*)memchr(l, '\n', (size_t)(e - l));
+            const char* le = nl ? nl : e;
+            len += le - l;
+            l = nl ? nl + 1 : e;
+          }
+          r.seqLen = len; r.end = l;
+        } else {
+          const char* nl = (const char*)memchr(body, '\n', (size_t)(e - body));
+          const char* le = nl ? nl : e;
+          r.seqLen = body < e ? le - body : 0;
+          r.end = detail::next_line(detail::next_line(nl ? nl + 1 : e, e), e);   // '+' line and quality line skipped
+        }
+        R.push_back(r);
+        q = r.end;
+      }
+    });
+    size_t nRec = 0;
+    std::vector<size_t> first(T + 1, 0);
+    for (unsigned t = 0; t < T; t++) { first[t] = nRec; nRec += recs[t].size(); }
+    first[T] = nRec;
+    const size_t base = out.names.size();
+    out.names.resize(base + nRec); out.offs.resize(base + nRec + 1);
+    // names + filters (per thread), then lengths -> offsets
+    detail::run_parallel(T, [&](unsigned t) {
+      for (size_t i = 0; i < recs[t].size(); i++) {
+        Rec& r = recs[t][i];
+        const char* hb = r.hdr + 1; const char* he = r.body > r.hdr && r.body[-1] == '\n' ? r.body - 1 : r.body;   // header line without its '\n'
+        if (he < hb) he = hb;
+        const char* sp = (const char*)memchr(hb, ' ', (size_t)(he - hb));
+        std::string& name = out.names[base + first[t] + i];
+        name.assign(hb, sp ? sp : he);
+        r.keep = (keepPrefix_.empty() || name.compare(0, keepPrefix_.size(), keepPrefix_) == 0) && (keepSeq_.empty() || keepSeq_.count(name));
+        if (!r.keep) r.seqLen = 0;
+      }
+    });
+    int64_t at = out.offs[base];
+    for (unsigned t = 0; t < T; t++) for (size_t i = 0; i < recs[t].size(); i++) { out.offs[base + first[t] + i] = at; at += recs[t][i].seqLen; }
+    out.offs[base + nRec] = at;
+    if ((size_t)at + 64 > out.cap) {
+      char* nb = alloc_((size_t)at + ((size_t)at >> 4) + 4096);
+      if (!nb) { std::cerr << "[mashmap_hip] out of host memory for a batch of " << at << " bases" << std::endl; exit(1); }
+      if (out.bases) { if (out.offs[base]) std::memcpy(nb, out.bases, (size_t)out.offs[base]); free_(out.bases); }
+      out.bases = nb; out.cap = (size_t)at + ((size_t)at >> 4) + 4096;
+    }
+    // sequence bytes, line breaks dropped
+    char* dst0 = out.bases;
+    detail::run_parallel(T, [&](unsigned t) {
+      for (size_t i = 0; i < recs[t].size(); i++) {
+        const Rec& r = recs[t][i];
+        if (!r.keep || !r.seqLen) continue;
+        char* d = dst0 + out.offs[base + first[t] + i];
+        if (fasta) {
+          const char* l = r.body;
+          while (l < r.end) {
+            const char* nl = (const char*)memchr(l, '\n', (size_t)(r.end - l));
+            const char* le = nl ? nl : r.end;
+            std::memcpy(d, l, (size_t)(le - l)); d += le - l;
+            l = nl ? nl + 1 : r.end;
+          }
+        } else std::memcpy(d, r.body, (size_t)r.seqLen);
+      }
+    });
+  }
+};
+
+}  // namespace mmhost

@@ -43,7 +43,7 @@
 
 #include "../../include/mashmap_hip.h"
 #include "mm_stats.hpp"
-#include "seq_reader.hpp"
+#include "seq_parse.hpp"
 #include "skch_map_post.hpp"
 #include "skch_sketch.hpp"
 #include "skch_types.hpp"
@@ -67,14 +67,13 @@ class Map {
   mm_ctx* ctx;                                   // ctxs[0]
   MapPost post;                                  // everything downstream of the device integers (skch_map_post.hpp)
   struct Batch {
-    std::string bases;
-    std::vector<int64_t> offs{0};
-    std::vector<std::string> names;
+    mmhost::ParsedBatch in;                      // names, offsets, bases (page-locked buffer, recycled through bufferPool)
     seqno_t firstSeqCounter = 0;
     std::vector<mm_mapping> recs;                // candidate mappings of the batch, read-major (filled by the device stage)
-    void clear(seqno_t next) { bases.clear(); offs.assign(1, 0); names.clear(); firstSeqCounter = next; recs.clear(); }
-    size_t size() const { return names.size(); }
+    size_t size() const { return in.names.size(); }
   };
+  // page-locked batch buffers are expensive to allocate: the post stage hands them back to the reader
+  std::mutex poolMu; std::vector<std::pair<char*, size_t>> bufferPool;
   [[noreturn]] void die(const char* what, mm_ctx* c = nullptr) const {
     std::cerr << "[mashmap_hip::skch::Map] ERROR: " << what << ": " << mm_last_error(c ? c : ctx) << std::endl;
     exit(1);
@@ -141,37 +140,42 @@ class Map {
     const size_t batchBases = (size_t)((be ? atof(be) : 512.0) * 1e6);
     Channel parsed(2), mapped(2);
     std::thread reader([&]() {
-      Batch batch;
-      auto flush = [&]() {
-        if (batch.size() == 0) return;
-        parsed.put(std::move(batch));
-        batch = Batch(); batch.clear(seqCounter);
-      };
-      for (const auto& fileName : param.querySequences) {
-        mmhost::for_each_seq_in_file(fileName, {}, "", [&](const std::string& name, std::string& seq) {
-          const offset_t len = (offset_t)seq.length();
-          totalBp += seq.length();
-          if (param.filterMode == filter::ONETOONE) qmetadata.push_back(ContigInfo{name, len});
+      // multi-threaded ingest (seq_parse.hpp): a window of the file per batch, parsed by param.threads workers straight into a
+      // page-locked buffer
+      mmhost::BatchReader rd(param.querySequences, batchBases, (unsigned)std::max(1, param.threads), {}, "",
+                             [](size_t n) { return (char*)mm_host_alloc(n); }, [](char* p) { mm_host_free(p); });
+      while (true) {
+        Batch batch;
+        { std::lock_guard<std::mutex> lk(poolMu); if (!bufferPool.empty()) { batch.in.bases = bufferPool.back().first; batch.in.cap = bufferPool.back().second; bufferPool.pop_back(); } }
+        const auto tr0 = skch::Time::now();
+        const bool more = rd.next(batch.in);
+        if (more && getenv("MASHMAP_HIP_TIMING")) std::cerr << "[mashmap_hip::timing] reader: parsed " << batch.size() << " records, " << batch.in.totalBases() << " bases in "
+                                                            << std::chrono::duration<double>(skch::Time::now() - tr0).count() << " s" << std::endl;
+        if (!more) { if (batch.in.bases) { std::lock_guard<std::mutex> lk(poolMu); bufferPool.emplace_back(batch.in.bases, batch.in.cap); } break; }
+        batch.firstSeqCounter = seqCounter;
+        for (size_t r = 0; r < batch.size(); r++) {
+          const offset_t len = (offset_t)(batch.in.offs[r + 1] - batch.in.offs[r]);
+          totalBp += (uint64_t)len;
+          if (param.filterMode == filter::ONETOONE) qmetadata.push_back(ContigInfo{batch.in.names[r], len});
           if (len < param.kmerSize) {
-            std::cerr << std::endl << "WARNING, skch::Map::mapQuery, read " << name << " of " << len << "bp "
+            std::cerr << std::endl << "WARNING, skch::Map::mapQuery, read " << batch.in.names[r] << " of " << len << "bp "
                       << " is not long enough for mapping at segment length " << param.segLength << std::endl;
           } else {
             totalReadsPickedForMapping++;
           }
           // short reads travel too (they yield no fragment) so that seqCounter == firstSeqCounter + index inside the batch
-          batch.names.push_back(name);
-          batch.bases.append(seq);
-          batch.offs.push_back((int64_t)batch.bases.size());
           seqCounter++;
-          if (batch.bases.size() >= batchBases) flush();
-        });
+        }
+        if (batch.size()) parsed.put(std::move(batch));
       }
-      flush();
       parsed.close();
     });
     std::thread poster([&]() {
       Batch cur;
-      while (mapped.get(cur)) postStage(cur, allReadMappings, totalReadsMapped, outstrm);
+      while (mapped.get(cur)) {
+        postStage(cur, allReadMappings, totalReadsMapped, outstrm);
+        if (cur.in.bases) { std::lock_guard<std::mutex> lk(poolMu); bufferPool.emplace_back(cur.in.bases, cur.in.cap); cur.in.bases = nullptr; }
+      }
     });
     {
       Batch cur;
@@ -180,6 +184,8 @@ class Map {
     }
     reader.join();
     poster.join();
+    for (auto& b : bufferPool) mm_host_free(b.first);
+    bufferPool.clear();
 
     if (param.filterMode == filter::ONETOONE) {            // :358-406
       const int n_mappings = (int)param.numMappingsForSegment - 1;
@@ -218,27 +224,27 @@ class Map {
     const bool timing = getenv("MASHMAP_HIP_TIMING") != nullptr;
     const auto t0 = skch::Time::now();
     std::vector<int32_t> readGroup, readSelf;
-    if (param.skip_prefix) { readGroup.resize(nReads); for (size_t r = 0; r < nReads; r++) readGroup[r] = getRefGroup(batch.names[r]); }
+    if (param.skip_prefix) { readGroup.resize(nReads); for (size_t r = 0; r < nReads; r++) readGroup[r] = getRefGroup(batch.in.names[r]); }
     if (param.skip_self) {
       readSelf.resize(nReads);
-      for (size_t r = 0; r < nReads; r++) { auto it = refNameToId.find(batch.names[r]); readSelf[r] = it == refNameToId.end() ? -1 : it->second; }
+      for (size_t r = 0; r < nReads; r++) { auto it = refNameToId.find(batch.in.names[r]); readSelf[r] = it == refNameToId.end() ? -1 : it->second; }
     }
     // contiguous blocks of about equal bases, one per context (a block may be empty)
     std::vector<size_t> cutAt(nCtx + 1, nReads);
     cutAt[0] = 0;
     {
-      const int64_t total = batch.offs[nReads];
+      const int64_t total = batch.in.offs[nReads];
       size_t r = 0;
       for (size_t i = 1; i < nCtx; i++) {
         const int64_t want = total * (int64_t)i / (int64_t)nCtx;
-        while (r < nReads && batch.offs[r] < want) r++;
+        while (r < nReads && batch.in.offs[r] < want) r++;
         cutAt[i] = r;
       }
     }
     auto runBlock = [&](size_t i) {
       mm_ctx* c = ctxs[i];
       const size_t b = cutAt[i], e = cutAt[i + 1];
-      if (mm_reads_upload(c, batch.bases.data(), batch.offs.data() + b, e - b, param.skip_prefix ? readGroup.data() + b : nullptr,
+      if (mm_reads_upload(c, batch.in.bases, batch.in.offs.data() + b, e - b, param.skip_prefix ? readGroup.data() + b : nullptr,
                           param.skip_self ? readSelf.data() + b : nullptr, batch.firstSeqCounter + (seqno_t)b) != MM_OK) die("mm_reads_upload", c);
       if (mm_map_fragments(c) != MM_OK) die("mm_map_fragments", c);
     };
@@ -288,10 +294,10 @@ class Map {
       const size_t chunk = 64;
       for (size_t r0 = next.fetch_add(chunk); r0 < nReads; r0 = next.fetch_add(chunk))
         for (size_t r = r0; r < std::min(nReads, r0 + chunk); r++) {
-          const offset_t len = (offset_t)(batch.offs[r + 1] - batch.offs[r]);
+          const offset_t len = (offset_t)(batch.in.offs[r + 1] - batch.in.offs[r]);
           if (len < param.kmerSize || recBegin[r] == recBegin[r + 1]) continue;
           post.mapModuleFromRecords(batch.recs.data() + recBegin[r], batch.recs.data() + recBegin[r + 1], len, perRead[r]);
-          if (reportNow && !perRead[r].empty()) { os.str(std::string()); post.reportReadMappings(perRead[r], batch.names[r], os); text[r] = os.str(); }
+          if (reportNow && !perRead[r].empty()) { os.str(std::string()); post.reportReadMappings(perRead[r], batch.in.names[r], os); text[r] = os.str(); }
         }
     };
     std::vector<std::thread> pool;

@@ -4,7 +4,7 @@
 // (builds + indexes the reference in the ctor, :122-138), same public members (metadata :79, sequencesByFileInfo :88,
 // minmerPosLookupIndex :101, minmerIndex :102) and accessors (isFreqSeed :506, getFreqThreshold :483,
 // isMinmerIndexEnd / getMinmerIndexEnd :470-481).  What differs is where the work happens: the FASTA text is read on the
-// host (seq_reader.hpp), everything from the k-mer hashes on is done by mm_index_build (a5-a7), and the index that
+// host (seq_parse.hpp, multi-threaded), everything from the k-mer hashes on is done by mm_index_build (a5-a7), and the index that
 // Map reads lives in HBM behind the mm_ctx this object owns.  The host copies of minmerIndex / minmerPosLookupIndex
 // are materialised from the library (mm_index_download) -- minmerIndex eagerly (one memcpy), the hash map only on
 // request (materializeLookupIndex), because nothing in the device path reads it.
@@ -23,7 +23,7 @@
 #include <vector>
 
 #include "../../include/mashmap_hip.h"
-#include "seq_reader.hpp"
+#include "seq_parse.hpp"
 #include "skch_types.hpp"
 
 namespace skch {
@@ -235,27 +235,51 @@ class Sketch {
       std::string name;
       while (std::getline(fl, name)) allowed.insert(name);
     }
-    std::string bases;
+    // the reference FASTA files, parsed by param.threads workers (seq_parse.hpp) into one page-locked buffer per file; --loadIndex
+    // still reads them for names and lengths (:181-211)
     std::vector<int64_t> offs(1, 0);
     seqno_t seqCounter = 0;
+    std::vector<mmhost::ParsedBatch> parts;
+    const bool needBases = param.loadIndexFilename.empty();
     for (const auto& fileName : param.refSequences) {
-      mmhost::for_each_seq_in_file(fileName, allowed, param.target_prefix, [&](const std::string& name, std::string& seq) {
-        metadata.push_back(ContigInfo{name, (offset_t)seq.length()});
-        if (param.loadIndexFilename.empty()) bases.append(seq);        // --loadIndex still reads the FASTA for names and lengths (:181-211)
-        offs.push_back((int64_t)bases.size());
-        seqCounter++;
-      });
+      mmhost::BatchReader rd({fileName}, (size_t)-1 >> 1, (unsigned)std::max(1, param.threads), allowed, param.target_prefix,
+                             [](size_t n) { return (char*)mm_host_alloc(n); }, [](char* p) { mm_host_free(p); });
+      mmhost::ParsedBatch b;
+      while (rd.next(b)) {
+        for (size_t r = 0; r < b.size(); r++) {
+          metadata.push_back(ContigInfo{b.names[r], (offset_t)(b.offs[r + 1] - b.offs[r])});
+          seqCounter++;
+        }
+        parts.push_back(std::move(b));
+        b = mmhost::ParsedBatch();
+      }
       sequencesByFileInfo.push_back(seqCounter);
     }
+    // one contiguous buffer for mm_index_build (a single part is used as it is)
+    char* bases = nullptr; bool ownBases = false;
+    if (needBases) {
+      int64_t total = 0;
+      for (auto& p : parts) total += p.totalBases();
+      if (parts.size() == 1) bases = parts[0].bases;
+      else { bases = (char*)mm_host_alloc((size_t)total + 64); ownBases = true; if (!bases) { std::cerr << "[mashmap_hip::skch::Sketch] ERROR: out of page-locked host memory" << std::endl; exit(1); } }
+      int64_t at = 0;
+      for (auto& p : parts) {
+        if (ownBases && p.totalBases()) std::memcpy(bases + at, p.bases, (size_t)p.totalBases());
+        for (size_t r = 0; r < p.size(); r++) offs.push_back(at + p.offs[r + 1]);
+        at += p.totalBases();
+      }
+    } else for (size_t i = 0; i < metadata.size(); i++) offs.push_back(0);
+    auto releaseParts = [&]() { for (auto& p : parts) if (p.bases) { mm_host_free(p.bases); p.bases = nullptr; } if (ownBases && bases) mm_host_free(bases); bases = nullptr; };
     if (seqCounter == 0) {
       std::cerr << "[mashmap::skch::Sketch::build] ERROR: No sequences indexed!" << std::endl;
       exit(1);
     }
     std::vector<int> groups;
     if (param.skip_prefix) groups = refGroups();
-    if (!param.loadIndexFilename.empty()) this->loadIndex(groups);
-    else if (mm_index_build(ctx_, bases.data(), offs.data(), metadata.size(), param.skip_prefix ? groups.data() : nullptr,
+    if (!param.loadIndexFilename.empty()) { this->loadIndex(groups); releaseParts(); }
+    else if (mm_index_build(ctx_, bases ? bases : "", offs.data(), metadata.size(), param.skip_prefix ? groups.data() : nullptr,
                             param.kmer_pct_threshold) != MM_OK) die("mm_index_build");
+    releaseParts();
     size_t nM, nK, nP, nF; int32_t ft;
     if (mm_index_sizes(ctx_, &nM, &nK, &nP, &nF, &ft) != MM_OK) die("mm_index_sizes");
     minmerIndex.resize(nM);

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""FASTA -> PAF end to end with the mashmap_hip command line on BASELINE configs[1] (synthetic 10 kbp reads vs 100 Mbp): the path a
+user runs, file parsing and PAF text included.  Prints one JSON line with the mapping-phase rate and the stage breakdown
+(MASHMAP_HIP_TIMING).  usage: e2e_fasta_paf.py [--reads N] [--threads T] [--gz]"""
+import argparse
+import json
+import os
+import re
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench as B  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reads", type=int, default=1_000_000)
+    ap.add_argument("--threads", type=int, default=min(128, os.cpu_count() or 1))
+    ap.add_argument("--dir", default="/tmp/mm_e2e")
+    ap.add_argument("--batch-mbp", type=float, default=512.0)
+    args = ap.parse_args()
+    import torch
+    os.makedirs(args.dir, exist_ok=True)
+    W = B.WORKLOADS["configs1"]
+    dev = torch.device("cuda", 0)
+    contigs = B.make_reference(torch, dev, W["ref_contigs"], W["ref_contig_len"])
+    rp, qp, op = os.path.join(args.dir, "ref.fa"), os.path.join(args.dir, "reads.fa"), os.path.join(args.dir, "out.paf")
+    B.write_fasta(rp, ["chr%d" % i for i in range(len(contigs))], [c.cpu().numpy() for c in contigs])
+    t0 = time.time()
+    L = W["read_len"]
+    with open(qp, "wb") as f:
+        chunk = 100_000
+        for r0 in range(0, args.reads, chunk):
+            n = min(chunk, args.reads - r0)
+            rd = B.make_reads(torch, dev, contigs, n, L, W["err"], seed=1000 + r0).cpu().numpy().reshape(n, L)
+            hdr = np.frombuffer(b"".join(b">read%07d\n" % (r0 + i) for i in range(n)), dtype=np.uint8).reshape(n, 13)      # fixed-width names
+            f.write(np.concatenate([hdr, rd, np.full((n, 1), 10, dtype=np.uint8)], axis=1).tobytes())
+    del contigs
+    torch.cuda.empty_cache()
+    log = "[e2e] wrote %.2f GB of FASTA in %.1f s" % (os.path.getsize(qp) / 1e9, time.time() - t0)
+    print(log, file=sys.stderr)
+    env = dict(os.environ, MASHMAP_HIP_TIMING="1", MASHMAP_HIP_BATCH_MBP=str(args.batch_mbp))
+    exe = os.path.join(ROOT, "mashmap_amd", "lib", "mashmap_hip")
+    best = None
+    for rep in range(2):                                   # second run: page cache warm for both programs' sake
+        t0 = time.time()
+        p = subprocess.run([exe, "-r", rp, "-q", qp, "-o", op, "-t", str(args.threads), "-s", str(W["seg"]), "--pi", "85", "-J", str(W["sketch"])],
+                           capture_output=True, text=True, env=env)
+        wall = time.time() - t0
+        if p.returncode != 0:
+            print(p.stderr[-2000:], file=sys.stderr); raise SystemExit(1)
+        tmap = float(re.search(r"time spent mapping the query: ([0-9.eE+-]+)", p.stderr).group(1))
+        tidx = float(re.search(r"time spent computing the reference index: ([0-9.eE+-]+)", p.stderr).group(1))
+        dev_s = sum(float(x) for x in re.findall(r"device stage.*?: ([0-9.eE+-]+) s", p.stderr))
+        post_s = sum(float(x) for x in re.findall(r"post stage: chain \+ filter \+ format ([0-9.eE+-]+) s", p.stderr))
+        out_s = sum(float(x) for x in re.findall(r", output ([0-9.eE+-]+) s", p.stderr))
+        read_s = sum(float(x) for x in re.findall(r"reader: parsed .*? in ([0-9.eE+-]+) s", p.stderr))
+        cur = dict(map_s=tmap, index_s=tidx, wall_s=wall, device_stage_s=dev_s, post_stage_s=post_s, output_s=out_s, reader_s=read_s)
+        if best is None or tmap < best["map_s"]:
+            best = cur
+    nlines = sum(1 for _ in open(op, "rb"))
+    bases = args.reads * L
+    out = {"what": "mashmap_hip -r ref.fa -q reads.fa (FASTA -> PAF), BASELINE configs[1]: %d x %d bp reads vs 100 Mbp, -t %d; 'time spent mapping the query' "
+                   "(parse + upload + kernels + chain/filter + PAF text), stages overlap (reader | device | post)" % (args.reads, L, args.threads),
+           "gbps_fasta_to_paf": round(bases / best["map_s"] / 1e9, 3), "paf_lines": nlines, "fasta_bytes": os.path.getsize(qp), **{k: round(v, 3) for k, v in best.items()}}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

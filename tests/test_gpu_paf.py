@@ -70,7 +70,7 @@ def test_paf_independent_of_batching_and_threads(tmp_path):
 
 
 def test_paf_from_gzipped_fastq_queries(tmp_path):
-    """the host reader (mashmap_amd/host/seq_reader.hpp): FASTQ and gzip give the same PAF as the FASTA of the same reads"""
+    """the host reader (mashmap_amd/host/seq_parse.hpp): FASTQ and gzip give the same PAF as the FASTA of the same reads"""
     import gzip
     _, refrec, qrec, extra = CASES["default"]
     rf = str(tmp_path / "ref.fa.gz")

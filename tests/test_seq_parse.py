@@ -1,0 +1,111 @@
+"""mashmap_amd/host/seq_parse.hpp (multi-threaded FASTA / FASTQ / gzip / BGZF ingest) against a plain Python restatement of
+seqiter::for_each_seq_in_file's record semantics (src/common/seqiter.hpp:20-111).  CPU only."""
+import gzip
+import os
+import struct
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+import mmutil as U
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def exe(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("parse") / "parse_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-o", out, os.path.join(ROOT, "tests", "hostlogic", "parse_check.cpp"), "-lz", "-lpthread"])
+    return out
+
+
+def fnv(b):
+    h = 1469598103934665603
+    for x in b:
+        h = ((h ^ x) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def records():
+    rs = []
+    rng = np.random.default_rng(5)
+    for i in range(400):
+        n = int(rng.choice([0, 1, 17, 300, 5000, 12345, 70000]))
+        a = U.random_dna(1000 + i, max(n, 1))[:n]
+        if i % 7 == 0 and n:
+            a = U.lowercase_some(a, i)
+        hdr = "rec%d" % i + (" description words" if i % 3 == 0 else "") + ("\tTAB" if i % 11 == 0 else "")
+        rs.append((hdr, a.tobytes()))
+    rs.append(("big_one", U.random_dna(77, 900000).tobytes()))
+    rs.append(("@looks_like_fastq", b"ACGT" * 10))
+    return rs
+
+
+def fasta_bytes(rs, width):
+    out = bytearray()
+    for hdr, seq in rs:
+        out += b">" + hdr.encode() + b"\n"
+        if width:
+            for i in range(0, len(seq), width):
+                out += seq[i:i + width] + b"\n"
+        else:
+            out += seq + b"\n"
+    return bytes(out)
+
+
+def fastq_bytes(rs):
+    out = bytearray()
+    for i, (hdr, seq) in enumerate(rs):
+        q = (b"@" if i % 5 == 0 else b"I") + b"+" * max(0, len(seq) - 1) if seq else b""     # quality lines that start with '@' / hold '+'
+        out += b"@" + hdr.encode() + b"\n" + seq + b"\n+\n" + q[:len(seq)] + b"\n"
+    return bytes(out)
+
+
+def bgzf_bytes(raw, block=60000):
+    out = bytearray()
+    for i in list(range(0, len(raw), block)) + [None]:
+        chunk = b"" if i is None else raw[i:i + block]
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        data = c.compress(chunk) + c.flush()
+        bsize = len(data) + 25
+        out += struct.pack("<BBBBIBBHBBHH", 31, 139, 8, 4, 0, 0, 255, 6, 66, 67, 2, bsize) + data + struct.pack("<II", zlib.crc32(chunk), len(chunk))
+    return bytes(out)
+
+
+def expect(rs, prefix=""):
+    lines = []
+    for hdr, seq in rs:
+        name = hdr.split(" ")[0]
+        keep = name.startswith(prefix)
+        s = seq if keep else b""
+        lines.append("%s\t%d\t%d" % (name, len(s), fnv(s)))
+    return lines
+
+
+@pytest.mark.parametrize("kind", ["fasta1", "fasta60", "fastq", "fasta60.gz", "fastq.gz", "fasta60.bgzf", "fastq.bgzf"])
+def test_parallel_reader_matches_the_serial_semantics(exe, tmp_path, kind):
+    rs = records()
+    raw = fastq_bytes(rs) if kind.startswith("fastq") else fasta_bytes(rs, 60 if "60" in kind else 0)
+    path = str(tmp_path / ("in." + kind))
+    if kind.endswith(".gz"):
+        with gzip.open(path, "wb") as f:
+            f.write(raw)
+    elif kind.endswith(".bgzf"):
+        open(path, "wb").write(bgzf_bytes(raw))
+    else:
+        open(path, "wb").write(raw)
+    want = expect(rs)
+    for window, threads in ((1 << 40, 1), (70000, 3), (65536, 8), (300000, 5)):
+        p = subprocess.run([exe, str(window), str(threads), path], capture_output=True, text=True)
+        assert p.returncode == 0, p.stderr
+        got = p.stdout.splitlines()
+        assert got == want, (kind, window, threads, len(got), len(want), [x for x in zip(got, want) if x[0] != x[1]][:3])
+    if kind == "fasta60":
+        p = subprocess.run([exe, "100000", "4", "--prefix", "rec1", path], capture_output=True, text=True)
+        assert p.stdout.splitlines() == expect(rs, "rec1")                    # filtered records are still reported, empty (seqiter.hpp:84-97)
+        # a file without a final line break, and two files in a row
+        open(path + ".nonl", "wb").write(raw.rstrip(b"\n"))
+        p = subprocess.run([exe, "90000", "3", path + ".nonl", path], capture_output=True, text=True)
+        assert p.stdout.splitlines() == want + want
