@@ -409,7 +409,7 @@ def main():
             hms = ctx.bench_hash_only(3)
             integer = {"hash_only_ms": round(hms, 3), "hash_only_gbps": round(nF * SEG / hms / 1e6, 2),
                        "sketch_kernel_frac": round(hms / sk_avg, 4) if sk_avg > 0 else None, "step_frac": round(hms / step_ms, 4),
-                       "note": "k_hash_only: same decomposition, staging and tables as k_sketch_fragments, nothing but the two hashes per position; "
+                       "note": "k_hash_only: same decomposition, staging and tables as k_sketch_fast, nothing but the two hashes per position; "
                                "frac = its time / the kernel's (step's) time = share of the integer floor reached"}
         except capi.MashmapError as e:
             log("[bench] hash-only microbenchmark unavailable:", e)
@@ -420,18 +420,18 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc) and is_default:
             try:
-                ent = json.load(open(pmc)).get("k_sketch_fragments", {})
+                ent = json.load(open(pmc)).get("k_sketch_fast", {})
                 traffic = ent.get("hbm_bytes_per_launch")
                 ninst = ent.get("SQ_INSTS_VALU")
                 if ninst and sk_avg > 0:
                     per_s = ninst / (sk_avg * 1e-3)
-                    mix = 3.4                           # cycles per wave-instruction of this kernel's VOP3/VOP2 mix (profiles/r02_valu_rate.txt)
+                    mix = 3.35                          # cycles per wave-instruction of this kernel's VOP3/VOP2 mix (profiles/r02_valu_rate.txt, r02_sketch_instruction_mix.txt)
                     valu = {"wave_instructions_per_launch": ninst,
                             "util_vs_2_cycles_per_instr": round(per_s / (SIMDS * CLOCK_HZ / 2.0), 3),
                             "util_vs_measured_mix": round(per_s / (SIMDS * CLOCK_HZ / mix), 3),
                             "util_vs_4_cycles_per_instr": round(per_s / (SIMDS * CLOCK_HZ / 4.0), 3),
                             "model": "1024 SIMDs x 2.4 GHz; three issue peaks: 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md nominal, SIMD-32), "
-                                     "%.1f cycles (this kernel's mix of VOP3 integer ops at ~4.2 and VOP2 ops at ~2.3 cycles measured by "
+                                     "%.2f cycles (this kernel's mix of VOP3 integer ops at ~4.2 and VOP2 ops at ~2.3 cycles measured by "
                                      "scripts/probes/valu_rate.hip, output in profiles/), 4 cycles (every instruction at the VOP3 rate)" % mix}
             except Exception:
                 traffic = None
@@ -454,7 +454,7 @@ def main():
                        "index_build_s": round(index_s, 2),
                        "identity_tables": "minimumHits / sketchCutoffs / acceptance from mm_stats.hpp's re-derivation of GSL's binomial and hypergeometric "
                                           "CDFs (GSL is not in the image; SURVEY section 8c: the one unpinned boundary)"},
-            "roofline": {"bound": "hbm", "kernel": "k_sketch_fragments", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "k_sketch_fast", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_fragment": frag_bytes, "avg_launch_ms": round(sk_avg, 3),
                          "algorithmic_bytes_per_launch": frag_bytes * nF,

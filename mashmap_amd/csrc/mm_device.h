@@ -125,6 +125,14 @@ __device__ __forceinline__ int mm_wave_excl_scan(int v) {      // exclusive pref
   return x + off - v;
 }
 
+// Presence filter in front of the seed table: 64-bit words, three bits per key inside ONE word (a word-blocked Bloom filter: one
+// 8-byte load per query seed).  Word = bits 32.. of the hash, the three bit positions from its low 18 bits.  Sized so that it stays
+// resident in an XCD's 4 MB L2 for indexes of a few hundred Mbp.
+__host__ __device__ __forceinline__ uint64_t mm_filter_bits(uint64_t h) {
+  return (1ull << (h & 63)) | (1ull << ((h >> 6) & 63)) | (1ull << ((h >> 12) & 63));
+}
+__host__ __device__ __forceinline__ uint64_t mm_filter_word(uint64_t h, uint64_t wordMask) { return (h >> 32) & wordMask; }
+
 // ---------------------------------------------------------------------------------------------
 // Strip hasher.  For K = 17..19 (one 16-byte block + a tail of K-16 <= 3 bytes; K = 19 is MashMap's default) the tail has
 // at most 64 values, so its complete mix (k1*C1, rotl 31, *C2) comes from a 64-entry LDS table indexed by the 2-bit codes:

@@ -16,6 +16,7 @@
 // one wave per 1024-position block scanning the <= segLength positions of records before the boundary.
 // Host work left: copying records in, a handful of scalars out.
 #include "mm_internal.h"
+#include "mm_device.h"
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 #include <algorithm>
@@ -236,7 +237,7 @@ k_ht_clear(size_t cap, HtSlot* __restrict__ ht) {
 }
 __global__ void __launch_bounds__(256)
 k_ht_insert(size_t nk, const uint64_t* __restrict__ keys, const uint64_t* __restrict__ keyOff, const uint8_t* __restrict__ freq, HtSlot* __restrict__ ht,
-            uint64_t mask, uint32_t* __restrict__ filter, uint64_t filterMask, unsigned long long* __restrict__ diag /* [3] |= 1 value overflow, |= 2 duplicate key */) {
+            uint64_t mask, unsigned long long* __restrict__ filter, uint64_t filterMask, unsigned long long* __restrict__ diag /* [3] |= 1 value overflow, |= 2 duplicate key */) {
   const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (k >= nk) return;
   const uint64_t key = keys[k];
@@ -254,7 +255,7 @@ k_ht_insert(size_t nk, const uint64_t* __restrict__ keys, const uint64_t* __rest
     if (prev == key) { atomicOr(&diag[3], 2ull); break; }
     slot = (slot + 1) & mask;
   }
-  if (filterMask) { const uint64_t b = (key >> 32) & filterMask; atomicOr(&filter[b >> 5], 1u << (b & 31)); }
+  if (filterMask) atomicOr(&filter[mm_filter_word(key, filterMask)], (unsigned long long)mm_filter_bits(key));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -354,10 +355,14 @@ int mm_flatten_device_index(mm_ctx* c, const mm_minmer* dRec, size_t n, size_t n
   }
   // ---- seed table + presence bitmap
   size_t cap = 16; while (cap < 2 * nk + 2) cap <<= 1;
-  // presence filter in front of the table: one bit per key at (key >> 32) mod bits, >= 16 bits per key while that stays cache-sized
-  // (<= 64 MiB); most query seeds are absent from the index (sequencing errors)
-  uint64_t fbits = 1024; while (fbits < 16 * (uint64_t)nk) fbits <<= 1;
-  if (const char* e = getenv("MM_FILTER_BITS_PER_KEY")) { const uint64_t b = strtoull(e, nullptr, 10); fbits = 1024; while (b && fbits < b * (uint64_t)nk) fbits <<= 1; if (!b) fbits = 0; }
+  // presence filter in front of the table (mm_filter_bits: 3 bits per key inside one 64-bit word): 4..8 bits per key, i.e. 2 MB for the
+  // ~3 M keys of a 100 Mbp index -- resident in an XCD's L2, ~7 % false positives.  Most query seeds are absent from the index
+  // (sequencing errors): they cost one cached 8-byte load instead of a table slot fetched over the fabric.  Beyond MM_FILTER_MAX_MIB
+  // (default 64) the filter is off: against a 3 Gbp index no size of it paid (profiles/r02c_log_occupancy_filter.txt).
+  uint64_t bitsPerKey = 4;
+  if (const char* e = getenv("MM_FILTER_BITS_PER_KEY")) bitsPerKey = strtoull(e, nullptr, 10);
+  uint64_t fbits = 4096; while (bitsPerKey && fbits < bitsPerKey * (uint64_t)nk) fbits <<= 1;
+  if (!bitsPerKey) fbits = 0;
   uint64_t maxMiB = 64;
   if (const char* e = getenv("MM_FILTER_MAX_MIB")) maxMiB = strtoull(e, nullptr, 10);
   if (fbits / 8 > (maxMiB << 20)) fbits = 0;
@@ -365,7 +370,7 @@ int mm_flatten_device_index(mm_ctx* c, const mm_minmer* dRec, size_t n, size_t n
   K_LAUNCH(k_ht_clear, cap, cap, I.htSlots.as<HtSlot>());
   MM_HIP(c, hipMemsetAsync(I.filter.p, 0, (fbits ? fbits / 8 : 4), c->stream));
   if (nk) K_LAUNCH(k_ht_insert, nk, nk, I.keys.as<uint64_t>(), I.keyOff.as<uint64_t>(), I.keyFreq.as<uint8_t>(), I.htSlots.as<HtSlot>(), (uint64_t)(cap - 1),
-                   I.filter.as<uint32_t>(), fbits ? fbits - 1 : 0ull, diag);
+                   I.filter.as<unsigned long long>(), fbits ? fbits / 64 - 1 : 0ull, diag);
   MM_HIP(c, hipGetLastError());
   std::vector<int32_t> grp(nContigs, 0);
   if (refGroup) grp.assign(refGroup, refGroup + nContigs);
@@ -376,7 +381,7 @@ int mm_flatten_device_index(mm_ctx* c, const mm_minmer* dRec, size_t n, size_t n
   MM_HIP(c, hipStreamSynchronize(c->stream));
   if (hd[3] & 1ull) { c->err = "mm_index_upload: a non-frequent seed with 2^23 or more interval points (or 2^40 points in total) does not fit the packed table value"; return MM_ERR_ARG; }
   if (hd[3] & 2ull) { c->err = "mm_index_upload: duplicate key"; return MM_ERR_ARG; }
-  I.filterMask = fbits ? fbits - 1 : 0;
+  I.filterMask = fbits ? fbits / 64 - 1 : 0;                                   // word mask
   I.nRec = n; I.nKeys = nk; I.nPoints = np; I.nContigs = nContigs; I.htCap = cap; I.ready = true;
   return MM_OK;
 }

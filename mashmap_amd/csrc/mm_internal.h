@@ -55,7 +55,7 @@ struct DeviceIndex {
   DevBuf contigLen;            // int32[nContigs]
   DevBuf refGroup;             // int32[nContigs] (all 0 when unused)
   DevBuf htSlots;              // {uint64 key, uint64 val}[htCap]; val = offset<<24 | count<<1 | freq (one 16-byte slot per probe)
-  DevBuf filter; uint64_t filterMask = 0;   // presence bitmap in front of htSlots (bit (key>>32) & filterMask); mask 0 = disabled
+  DevBuf filter; uint64_t filterMask = 0;   // presence filter in front of htSlots: uint64 words, mm_filter_word / mm_filter_bits (mm_device.h); word mask, 0 = disabled
   DevBuf ptKeys;               // uint64[nPoints]: seqId<<33 | pos<<1 | (side==OPEN)
   DevBuf keys, keyOff, keyFreq; // the lookup map's key table in the order of ptKeys: uint64 key, uint64 first point (nKeys + 1), uint8 isFrequent
   bool ready = false;

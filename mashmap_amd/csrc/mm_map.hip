@@ -294,7 +294,7 @@ template <int MAXPTS>
 __global__ void __launch_bounds__(MM_LOOKUP_WPB * 64, MAXPTS <= 128 ? 8 : 5)
 k_lookup_l1(int nFrags, int s, const DFrag* __restrict__ frags,
             const uint64_t* __restrict__ skHash, const int8_t* __restrict__ skStrand, const uint32_t* __restrict__ skCount,
-            const HtSlot* __restrict__ ht, uint64_t htMask, const uint32_t* __restrict__ filter, uint64_t filterMask,
+            const HtSlot* __restrict__ ht, uint64_t htMask, const uint64_t* __restrict__ filter, uint64_t filterMask,
             const uint64_t* __restrict__ ptKeys, const int32_t* __restrict__ refGroup,
             const int32_t* __restrict__ readGroup, const int32_t* __restrict__ readSelf, int seqCounterBase, MapFlags fl, int keepPoints,
             uint64_t* __restrict__ qHash, int8_t* __restrict__ qStrand, uint64_t* __restrict__ seedVal,
@@ -342,7 +342,7 @@ k_lookup_l1(int nFrags, int s, const DFrag* __restrict__ frags,
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       open[u] = act[u];
-      if (filterMask && act[u]) { const uint64_t bb = (h[u] >> 32) & filterMask; open[u] = (filter[bb >> 5] >> (bb & 31)) & 1u; }
+      if (filterMask && act[u]) { const uint64_t fb = mm_filter_bits(h[u]); open[u] = (filter[mm_filter_word(h[u], filterMask)] & fb) == fb; }
     }
     HtSlot sl[4];
 #pragma unroll
@@ -728,7 +728,7 @@ int mm_launch_map(mm_ctx* c) {
       auto kern = fuse == 256 ? k_lookup_l1<256> : k_lookup_l1<128>;
       hipLaunchKernelGGL(kern, dim3((nF + MM_LOOKUP_WPB - 1) / MM_LOOKUP_WPB), dim3(MM_LOOKUP_WPB * 64), 0, c->stream, nF, s, c->dFrags.as<DFrag>(),
                          c->dSkHash.as<uint64_t>(), c->dSkStrand.as<int8_t>(), c->dSkCount.as<uint32_t>(),
-                         I.htSlots.as<HtSlot>(), (uint64_t)(I.htCap - 1), I.filter.as<uint32_t>(), (uint64_t)I.filterMask, I.ptKeys.as<uint64_t>(),
+                         I.htSlots.as<HtSlot>(), (uint64_t)(I.htCap - 1), I.filter.as<uint64_t>(), (uint64_t)I.filterMask, I.ptKeys.as<uint64_t>(),
                          I.refGroup.as<int32_t>(), c->dReadGroup.as<int32_t>(), c->dReadSelf.as<int32_t>(), c->seqCounterBase, fl,
                          c->keepPoints ? 1 : 0,
                          c->dQHash.as<uint64_t>(), c->dQStrand.as<int8_t>(), c->dSeedVal.as<uint64_t>(), c->dStats.as<mm_frag_stats>(),

@@ -72,8 +72,7 @@ class Map {
     std::vector<mm_mapping> recs;                // candidate mappings of the batch, read-major (filled by the device stage)
     size_t size() const { return in.names.size(); }
   };
-  // page-locked batch buffers are expensive to allocate: the post stage hands them back to the reader
-  std::mutex poolMu; std::vector<std::pair<char*, size_t>> bufferPool;
+  // page-locked batch buffers come from skch::HostBufferPool (allocated while the index was being built) and are recycled
   [[noreturn]] void die(const char* what, mm_ctx* c = nullptr) const {
     std::cerr << "[mashmap_hip::skch::Map] ERROR: " << what << ": " << mm_last_error(c ? c : ctx) << std::endl;
     exit(1);
@@ -142,16 +141,19 @@ class Map {
     std::thread reader([&]() {
       // multi-threaded ingest (seq_parse.hpp): a window of the file per batch, parsed by param.threads workers straight into a
       // page-locked buffer
-      mmhost::BatchReader rd(param.querySequences, batchBases, (unsigned)std::max(1, param.threads), {}, "",
+      // (memchr + memcpy saturate the memory system with a few dozen threads; more only adds thread start-up per window)
+      const char* rte = getenv("MASHMAP_HIP_READER_THREADS");
+      const unsigned readerThreads = rte ? (unsigned)std::max(1, atoi(rte)) : (unsigned)std::min(32, std::max(1, param.threads));
+      mmhost::BatchReader rd(param.querySequences, batchBases, readerThreads, {}, "",
                              [](size_t n) { return (char*)mm_host_alloc(n); }, [](char* p) { mm_host_free(p); });
       while (true) {
         Batch batch;
-        { std::lock_guard<std::mutex> lk(poolMu); if (!bufferPool.empty()) { batch.in.bases = bufferPool.back().first; batch.in.cap = bufferPool.back().second; bufferPool.pop_back(); } }
+        { auto b = HostBufferPool::instance().take(0); batch.in.bases = b.first; batch.in.cap = b.second; }
         const auto tr0 = skch::Time::now();
         const bool more = rd.next(batch.in);
         if (more && getenv("MASHMAP_HIP_TIMING")) std::cerr << "[mashmap_hip::timing] reader: parsed " << batch.size() << " records, " << batch.in.totalBases() << " bases in "
                                                             << std::chrono::duration<double>(skch::Time::now() - tr0).count() << " s" << std::endl;
-        if (!more) { if (batch.in.bases) { std::lock_guard<std::mutex> lk(poolMu); bufferPool.emplace_back(batch.in.bases, batch.in.cap); } break; }
+        if (!more) { HostBufferPool::instance().give(batch.in.bases, batch.in.cap); break; }
         batch.firstSeqCounter = seqCounter;
         for (size_t r = 0; r < batch.size(); r++) {
           const offset_t len = (offset_t)(batch.in.offs[r + 1] - batch.in.offs[r]);
@@ -174,7 +176,7 @@ class Map {
       Batch cur;
       while (mapped.get(cur)) {
         postStage(cur, allReadMappings, totalReadsMapped, outstrm);
-        if (cur.in.bases) { std::lock_guard<std::mutex> lk(poolMu); bufferPool.emplace_back(cur.in.bases, cur.in.cap); cur.in.bases = nullptr; }
+        HostBufferPool::instance().give(cur.in.bases, cur.in.cap); cur.in.bases = nullptr;
       }
     });
     {
@@ -184,8 +186,6 @@ class Map {
     }
     reader.join();
     poster.join();
-    for (auto& b : bufferPool) mm_host_free(b.first);
-    bufferPool.clear();
 
     if (param.filterMode == filter::ONETOONE) {            // :358-406
       const int n_mappings = (int)param.numMappingsForSegment - 1;

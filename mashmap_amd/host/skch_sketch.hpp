@@ -80,6 +80,12 @@ class Sketch {
       ctxs_.push_back(c);
     }
     ctx_ = ctxs_[0];
+    {
+      // page-locked buffers for the query batches skch::Map will read: locked in the background while the index is built
+      const char* be = getenv("MASHMAP_HIP_BATCH_MBP");
+      const size_t batchBytes = (size_t)((be ? atof(be) : 512.0) * 1e6);
+      HostBufferPool::instance().prefetch(6, batchBytes + batchBytes / 8 + (1u << 20));
+    }
     if (!p.saveIndexFilename.empty()) mm_set_option(ctx_, MM_OPT_KEEP_FULL_INDEX, 1);
     this->build();
     if (!p.saveIndexFilename.empty()) this->saveIndex();

@@ -129,3 +129,42 @@ static const std::string VERSION = "3.1.3";
 
 }  // namespace skch
 #endif
+
+// Page-locked batch buffers for the query reader (skch::Map).  Locking pages costs about a second per few GB, so the buffers are
+// allocated by a background thread while skch::Sketch builds the reference index, and recycled between batches afterwards.
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+#include <utility>
+extern "C" { void* mm_host_alloc(size_t bytes); void mm_host_free(void* p); }
+namespace skch {
+class HostBufferPool {
+  std::mutex mu_; std::condition_variable cv_; std::vector<std::pair<char*, size_t>> free_; std::thread bg_; size_t pending_ = 0;
+ public:
+  static HostBufferPool& instance() { static HostBufferPool p; return p; }
+  ~HostBufferPool() { if (bg_.joinable()) bg_.join(); for (auto& b : free_) mm_host_free(b.first); }
+  void prefetch(size_t n, size_t bytes) {
+    if (bg_.joinable()) bg_.join();
+    { std::lock_guard<std::mutex> lk(mu_); pending_ = n; }
+    bg_ = std::thread([this, n, bytes]() {
+      for (size_t i = 0; i < n; i++) {
+        char* p = (char*)mm_host_alloc(bytes);
+        std::lock_guard<std::mutex> lk(mu_);
+        if (p) free_.emplace_back(p, bytes);
+        pending_--; cv_.notify_all();
+      }
+    });
+  }
+  // a buffer of at least `bytes` if one is ready (or about to be); {nullptr, 0} when the caller should allocate itself
+  std::pair<char*, size_t> take(size_t bytes) {
+    std::unique_lock<std::mutex> lk(mu_);
+    while (true) {
+      for (size_t i = 0; i < free_.size(); i++) if (free_[i].second >= bytes) { auto b = free_[i]; free_.erase(free_.begin() + (std::ptrdiff_t)i); return b; }
+      if (!pending_) return {nullptr, 0};
+      cv_.wait(lk);
+    }
+  }
+  void give(char* p, size_t bytes) { if (!p) return; std::lock_guard<std::mutex> lk(mu_); free_.emplace_back(p, bytes); cv_.notify_all(); }
+};
+}  // namespace skch
+

@@ -45,6 +45,22 @@ filt)
     set -- $CFG
     MM_FILTER_MAX_MIB=$1 MM_FILTER_BITS_PER_KEY=$2 timeout 900 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-path --reads 500000 --ref-contigs 30 --ref-contig-len 100000000 2> /dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('filter max MiB $1 bits/key $2:', d['value'], 'Gbp/s; lookup', d['kernels']['lookup']['ms_per_step'], 'ms; index', d['config']['index_build_s'], 's')" | tee -a $OUT/log.txt
   done ;;
+prof3|prof4)
+  WL=configs${S#prof}
+  echo "== $WL: kernel trace + PMC passes" | tee -a $OUT/log.txt
+  timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$WL -o trace -- python bench.py --steps 2 --warmup 1 --workload $WL --no-cpu-baseline --no-host-path > $OUT/trace_$WL.json 2> $OUT/trace_$WL.err
+  find $OUT/trace_$WL -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} $OUT/kernel_stats_$WL.csv
+  rm -rf $OUT/trace_$WL
+  grep -E '^"(void )?k_' $OUT/kernel_stats_$WL.csv | head -10 | cut -c1-150 | tee -a $OUT/log.txt
+  for C in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU; do
+    timeout 1500 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_${WL}_$C -o pmc -- python bench.py --steps 1 --warmup 0 --workload $WL --no-cpu-baseline --no-host-path > /dev/null 2> $OUT/pmc_${WL}_$C.err
+    python scripts/pmc_summary.py $OUT/pmc_${WL}_$C $C > $OUT/pmc_${WL}_$C.csv 2>> $OUT/log.txt
+    rm -rf $OUT/pmc_${WL}_$C
+    head -8 $OUT/pmc_${WL}_$C.csv | tee -a $OUT/log.txt
+  done ;;
+scale)
+  echo "== configs[2]: 3 Gbp assembly vs 3 Gbp reference, one-to-one, PAF vs the stock binary" | tee -a $OUT/log.txt
+  NC=24 CL=125000000 THREADS=64 timeout 2400 python scripts/scale_probe.py 2>&1 | tail -25 | tee $OUT/scale_probe.txt | tee -a $OUT/log.txt ;;
 trace)
   echo "== rocprofv3 kernel trace" | tee -a $OUT/log.txt
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-path > $OUT/trace_bench.json 2> $OUT/trace.err

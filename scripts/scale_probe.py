@@ -23,7 +23,8 @@ for i in range(NC):
 rp, qp = td + '/ref.fa', td + '/qry.fa'
 B.write_fasta(rp, ['chr%d' % i for i in range(NC)], ref)
 B.write_fasta(qp, ['ctg%d' % i for i in range(NC)], qry)
-args = ['--pi', '95', '-s', '10000', '-f', 'one-to-one', '-J', '40', '-t', '16']
+args = ['--pi', '95', '-s', '10000', '-f', 'one-to-one', '-J', '40', '-t', os.environ.get('THREADS', '32')]
+print('scale probe: %d contigs x %d bp, mashmap %s' % (NC, CL, ' '.join(args)))
 out = {}
 for name, exe in (('hip', 'mashmap_amd/lib/mashmap_hip'), ('ref', 'oracle/_ref/mashmap_ref')):
     if not os.path.exists(exe): continue
