@@ -132,12 +132,13 @@ __device__ __forceinline__ void mm_wave_bitonic(uint64_t (&k)[R], int lane) {
 }
 
 // per-wave LDS scratch of the fused kernel
+#define MM_FUSE_MAXRUNS 64
 struct L1Run { int32_t seq, start, end, isize; };
 template <int MAXPTS>
 struct FuseScratchT {
   uint64_t a[MAXPTS];                // gathered points, later (seqId<<32 | pos) of every position group
   int32_t v[MAXPTS];                 // overlap count after every position group
-  L1Run run[MAXPTS];
+  L1Run run[MM_FUSE_MAXRUNS];        // candidate runs before joining (a fragment with more goes to the literal sweep)
 };
 
 // Interval points of the fragment's surviving seeds -> dst[0..P) (skip_self / skip_prefix / lower_triangular applied,
@@ -246,6 +247,7 @@ __device__ __forceinline__ int mm_l1_fused(uint64_t (&k)[R], FuseScratch& sc, in
   int ridx = mm_wave_excl_scan(laneStarts);                       // runs that started before this lane
   const int nRuns = mm_wave_sum(laneStarts);
   if (nRuns == 0) return 0;
+  if (nRuns > MM_FUSE_MAXRUNS) return -1;
   int myRun[R];
 #pragma unroll
   for (int e = 0; e < R; e++) {
@@ -291,7 +293,7 @@ __device__ __forceinline__ int mm_l1_fused(uint64_t (&k)[R], FuseScratch& sc, in
 #define MM_L1_REGIONS 64            // L1 output cursors: a same-address atomic costs ~10 ns, so fragments spread over 64 of them
 #define MM_L1_CURSOR_STRIDE 32      // u64 words between cursors (256 bytes)
 template <int MAXPTS>
-__global__ void __launch_bounds__(MM_LOOKUP_WPB * 64, MAXPTS <= 128 ? 8 : 5)
+__global__ void __launch_bounds__(MM_LOOKUP_WPB * 64, MAXPTS <= 128 ? 8 : MAXPTS <= 256 ? 6 : 5)
 k_lookup_l1(int nFrags, int s, const DFrag* __restrict__ frags,
             const uint64_t* __restrict__ skHash, const int8_t* __restrict__ skStrand, const uint32_t* __restrict__ skCount,
             const HtSlot* __restrict__ ht, uint64_t htMask, const uint64_t* __restrict__ filter, uint64_t filterMask,
@@ -410,7 +412,7 @@ k_lookup_l1(int nFrags, int s, const DFrag* __restrict__ frags,
     if (P == 0) nOut = 0;
     else {
       nValid = mm_wave_sum(nValid);
-      const int padTo = P <= 64 ? 64 : P <= 128 ? 128 : 256;
+      const int padTo = P <= 64 ? 64 : P <= 128 ? 128 : P <= 256 ? 256 : 512;
       for (int j = P + lane; j < padTo; j += 64) sc.a[j] = MM_EMPTY;
       __threadfence_block();
       if (P <= 64) {
@@ -422,9 +424,17 @@ k_lookup_l1(int nFrags, int s, const DFrag* __restrict__ frags,
         mm_wave_bitonic<2>(k, lane);
         nOut = mm_l1_fused<2>(k, sc, outIdx, minHits0, fl.hg, cutoffs, nCutoffs, s, segLength, lane);
       } else if constexpr (MAXPTS >= 256) {
-        uint64_t k[4] = {sc.a[lane * 4], sc.a[lane * 4 + 1], sc.a[lane * 4 + 2], sc.a[lane * 4 + 3]};
-        mm_wave_bitonic<4>(k, lane);
-        nOut = mm_l1_fused<4>(k, sc, outIdx, minHits0, fl.hg, cutoffs, nCutoffs, s, segLength, lane);
+        if (P <= 256) {
+          uint64_t k[4] = {sc.a[lane * 4], sc.a[lane * 4 + 1], sc.a[lane * 4 + 2], sc.a[lane * 4 + 3]};
+          mm_wave_bitonic<4>(k, lane);
+          nOut = mm_l1_fused<4>(k, sc, outIdx, minHits0, fl.hg, cutoffs, nCutoffs, s, segLength, lane);
+        } else if constexpr (MAXPTS >= 512) {
+          uint64_t k[8];
+#pragma unroll
+          for (int e = 0; e < 8; e++) k[e] = sc.a[lane * 8 + e];
+          mm_wave_bitonic<8>(k, lane);
+          nOut = mm_l1_fused<8>(k, sc, outIdx, minHits0, fl.hg, cutoffs, nCutoffs, s, segLength, lane);
+        }
       }
     }
   }
@@ -721,11 +731,11 @@ int mm_launch_map(mm_ctx* c) {
     MM_HIP(c, hipMemsetAsync(c->dL1Cursors.p, 0, sizeof hcur, c->stream));
     {
       KernelTimer t(c, MM_K_LOOKUP);
-      // the fused path holds a fragment's interval points in LDS + registers: 128 of them at 8 waves per SIMD, or 256 at 5 (larger
-      // sketches bring proportionally more points: s = 310 averages ~160 per fragment)
-      int fuse = s > 160 ? 256 : 128;
-      if (const char* e = getenv("MM_FUSE_MAXPTS")) fuse = atoi(e) >= 256 ? 256 : 128;
-      auto kern = fuse == 256 ? k_lookup_l1<256> : k_lookup_l1<128>;
+      // the fused path holds a fragment's interval points in LDS + registers: up to 128 of them for the default sketch, 256 / 512 for
+      // larger ones (points come in proportion to the sketch: s = 310 averages ~176 per fragment with a long tail)
+      int fuse = s > 256 ? 512 : s > 160 ? 256 : 128;
+      if (const char* e = getenv("MM_FUSE_MAXPTS")) { const int v = atoi(e); fuse = v >= 512 ? 512 : v >= 256 ? 256 : 128; }
+      auto kern = fuse == 512 ? k_lookup_l1<512> : fuse == 256 ? k_lookup_l1<256> : k_lookup_l1<128>;
       hipLaunchKernelGGL(kern, dim3((nF + MM_LOOKUP_WPB - 1) / MM_LOOKUP_WPB), dim3(MM_LOOKUP_WPB * 64), 0, c->stream, nF, s, c->dFrags.as<DFrag>(),
                          c->dSkHash.as<uint64_t>(), c->dSkStrand.as<int8_t>(), c->dSkCount.as<uint32_t>(),
                          I.htSlots.as<HtSlot>(), (uint64_t)(I.htCap - 1), I.filter.as<uint64_t>(), (uint64_t)I.filterMask, I.ptKeys.as<uint64_t>(),

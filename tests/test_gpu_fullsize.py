@@ -22,11 +22,11 @@ K, SEG, SKETCH, PI = 19, 5000, 130, 0.85
 N_READS, READ_LEN, N_SAMPLE = 1_000_000, 10_000, 1000
 
 
-def _rows_by_fragment(l1, l2, reads=None):
+def _rows_by_fragment(l1, l2, reads=None, per=2):
     """{fragment: [(seqId, start, end, isize)]}, {fragment: [(candidate rank in fragment, seqId, mean, start, end, shared, strand)]};
-    only the fragments of the given (sorted) read ids if any"""
-    i1 = np.arange(len(l1)) if reads is None else np.nonzero(np.isin(l1["frag"] // 2, reads))[0]
-    i2 = np.arange(len(l2)) if reads is None else np.nonzero(np.isin(l2["frag"] // 2, reads))[0]
+    only the fragments of the given (sorted) read ids if any (`per` fragments per read)"""
+    i1 = np.arange(len(l1)) if reads is None else np.nonzero(np.isin(l1["frag"] // per, reads))[0]
+    i2 = np.arange(len(l2)) if reads is None else np.nonzero(np.isin(l2["frag"] // per, reads))[0]
     first, c1, c2 = {}, {}, {}
     for i in i1:
         c = l1[i]; f = int(c["frag"])
@@ -131,3 +131,68 @@ def test_configs1_full_size(oracle):
     ctx.close()
     oracle.free(h)
     assert bad == 0, "%d of %d sampled fragments differ from the oracle" % (bad, 2 * N_SAMPLE)
+
+
+@pytest.mark.parametrize("wl,n_reads,ref_len", [("configs3", 20000, 20_000_000), ("configs4", 12000, 15_000_000)])
+def test_other_baseline_shapes_midsize_sampled_parity(oracle, wl, n_reads, ref_len):
+    """configs[3] / configs[4] at their read length, error model and sketch size (15 kbp, s = 310; 20 kbp at 15-20 % error, s = 498, pi 80,
+    several reference contigs = the --rl list), the reference scaled to what the oracle indexes in seconds: batch invariants on every
+    fragment, and >= 1 % of the reads -- re-mapped as a small batch, which must reproduce their rows of the big batch -- equal the oracle
+    integer for integer (sketch, Q.sketchSize, L1 candidates, L2 loci)."""
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench as B
+    from mashmap_amd import capi
+    W = B.WORKLOADS[wl]
+    k, seg, s, pi, rl = W["k"], W["seg"], W["sketch"], W["pi"], W["read_len"]
+    dev = torch.device("cuda", 0)
+    contigs_t = B.make_reference(torch, dev, 4, ref_len // 4)
+    ref_np = [c.cpu().numpy() for c in contigs_t]
+    reads_t = B.make_reads(torch, dev, contigs_t, n_reads, rl, W["err"], seed=77)
+    torch.cuda.synchronize()
+    named = [("f%d_c" % i, a) for i, a in enumerate(ref_np)]
+    h = oracle.session(named, k, seg, s, pi, U.FILTER_MAP, U.FLAG_HG, b"\0", 0.001)
+    ctx = capi.Context(k=k, segLength=seg, sketchSize=s, flags=capi.MM_FLAG_HG_FILTER)
+    ctx.index_build(ref_np, kmerPct=0.001)
+    g, e = ctx.index_download(), oracle.export_index(h)
+    assert len(g["minmers"]) == len(e["minmers"]) and (g["minmers"]["hash"] == e["minmers"]["hash"]).all() and (g["minmers"]["wpos"] == e["minmers"]["wpos"]).all()
+    assert (g["keys"] == e["keys"]).all() and (g["offsets"] == e["offsets"]).all()
+    del g, e
+    ctx.set_tables(oracle.min_hits_table(s, k, pi), oracle.cutoffs(h))
+    ctx.set_replay_tables(*capi.stat_replay_tables(s, k, pi))
+    offs = np.arange(n_reads + 1, dtype=np.int64) * rl
+    nF = ctx.reads_upload_device(reads_t.data_ptr(), reads_t.numel(), offs)
+    per = rl // seg
+    assert nF == per * n_reads
+    ctx.map()
+    stats, l1, l2 = ctx.results()
+    recs = ctx.mappings()
+    assert (stats["rawSketchSize"] == s).all() and (stats["sketchSize"] > 0).all()
+    assert int(stats["nL1"].sum()) == len(l1) and (np.diff(l2["frag"].astype(np.int64)) >= 0).all()
+    assert (l2["sharedSketchSize"] <= stats["sketchSize"][l2["frag"]]).all()
+    mapped = np.zeros(nF, dtype=bool); mapped[l2["frag"]] = True
+    assert mapped.mean() > (0.97 if wl == "configs3" else 0.80)
+    assert (np.diff(recs["querySeqId"].astype(np.int64)) >= 0).all() and len(recs) >= 0.8 * mapped.sum()
+    n_sample = max(200, n_reads // 100)
+    rng = np.random.default_rng(4321)
+    pick = np.sort(rng.choice(n_reads, n_sample, replace=False))
+    sample = reads_t.view(n_reads, rl)[torch.from_numpy(pick).to(dev)].cpu().numpy()
+    full1, full2 = _rows_by_fragment(l1, l2, pick, per)
+    del reads_t, contigs_t
+    assert ctx.reads_upload([sample[i] for i in range(n_sample)]) == per * n_sample
+    ctx.map()
+    sst, sl1, sl2 = ctx.results()
+    qsk = ctx.query_sketches()
+    small1, small2 = _rows_by_fragment(sl1, sl2)
+    bad = 0
+    for i in range(n_sample):
+        for j in range(per):
+            fs, ff = per * i + j, per * int(pick[i]) + j
+            assert small1.get(fs, []) == full1.get(ff, []) and small2.get(fs, []) == full2.get(ff, []), "batch-size dependence at read %d" % pick[i]
+            ex = oracle.map_fragment(h, sample[i][j * seg:(j + 1) * seg], i, b"r", rl, s)
+            g_sk = [(int(x["hash"]), int(x["strand"])) for x in qsk[fs, :int(sst[fs]["sketchSize"])]]
+            if not (int(sst[fs]["rawSketchSize"]) == ex["rawSketchSize"] and g_sk == [(x[0], x[4]) for x in ex["sketch"]]
+                    and small1.get(fs, []) == ex["l1"] and small2.get(fs, []) == ex["l2"]):
+                bad += 1
+    ctx.close(); oracle.free(h)
+    assert bad == 0, "%d of %d sampled fragments differ from the oracle" % (bad, per * n_sample)
