@@ -104,7 +104,7 @@ struct mm_ctx {
   void* comm = nullptr; int commRank = 0, commWorld = 0; bool commCopy = false;   // commCopy: local group whose contexts share a device
   DevBuf dCommCounts, dGathered; std::vector<size_t> gatherCounts, gatherDisp; size_t nGathered = 0; bool gathered = false;
   std::vector<DevBuf*> allBufs();
-  DevBuf dL2Info, dL2Cnt, dL2Off, dL2Ops, dScanTmp, dL2Tmp, dL2Wide, dListB, dListC, dBigList;     // L2 staging: per-candidate stream extents, op counts/offsets, located ops
+  DevBuf dL2Info, dL2Cnt, dL2Off, dL2Ops, dScanTmp, dL2Tmp, dL2Wide, dL2Exact, dL2Cells, dListB, dListC, dBigList;     // L2 staging: per-candidate stream extents, op counts/offsets, located ops
   bool sketched = false, mapped = false;
   bool keepPoints = false;                              // mm_set_option(MM_OPT_KEEP_POINTS): route every fragment through the HBM point list
 

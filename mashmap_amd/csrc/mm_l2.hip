@@ -308,8 +308,8 @@ __global__ void __launch_bounds__(64)
 k_l2_sweep(int nCand, const int32_t* __restrict__ candList, int segLength, const mm_l1_candidate* __restrict__ l1, const mm_frag_stats* __restrict__ stats,
            const int64_t* __restrict__ opOff, const int32_t* __restrict__ opCnt, const uint32_t* __restrict__ ops,
            const int64_t* __restrict__ l1Off, L2Tmp* __restrict__ tmp, int locap, mm_l2_locus* __restrict__ l2, unsigned long long l2Cap,
-           int32_t* __restrict__ wideList, int64_t* __restrict__ l2First, int32_t* __restrict__ l2Num,
-           unsigned long long* __restrict__ counters /* [4] l2 cursor, [5] overflow, [6] flags, [7] candidates queued for the wide pass */) {
+           int32_t* __restrict__ wideList, int32_t* __restrict__ exactList, int64_t* __restrict__ l2First, int32_t* __restrict__ l2Num,
+           unsigned long long* __restrict__ counters /* [0] candidates queued for the exact pass, [4] l2 cursor, [5] overflow, [6] flags, [7] queued for the wide pass */) {
   typedef typename std::conditional<WIDE, uint16_t, uint8_t>::type CellT;
   constexpr int CB = WIDE ? 12 : 5;
   constexpr uint32_t CMASK = (1u << CB) - 1u;
@@ -357,8 +357,8 @@ k_l2_sweep(int nCand, const int32_t* __restrict__ candList, int segLength, const
     const uint32_t cw = CELL(j), pw = CELL(pivot), nw = CELL(pn);
     const int vi = valid & insM, vd = valid & delM;
     const int IM = vi & mt, IN = vi & ~mt, DM = vd & mt, DN = vd & ~mt;
-    const int vf = (int)((e >> 12) & 3u);              // vote + 1; a query hash has one open reference window at a time (windowLen == 0),
-    doubleOpen |= IM & BITM(cw, CB);                   // the 2-bit vote relies on it, so a violation is reported, not absorbed
+    const int vf = (int)((e >> 12) & 3u);              // vote + 1; a query hash normally has one open reference window at a time (windowLen == 0):
+    doubleOpen |= IM & BITM(cw, CB);                   // the 2-bit vote relies on it; a candidate that violates it is handed to k_l2_sweep_exact
     cntOverflow |= IN & neg((int)(CMASK - 1u) - (int)(cw & CMASK));   // the counter of this cell is full: redo the candidate with wide cells
     const int repl = (int)(cw & CMASK) | sel(IM, (int)((1u << CB) | ((uint32_t)vf << (CB + 1))), (int)(1u << (CB + 1)));
     const int ncw = sel(IM | DM, repl, (int)cw - IN + DN);            // IN: count + 1, DN: count - 1 (the masks are -1)
@@ -455,8 +455,11 @@ k_l2_sweep(int nCand, const int32_t* __restrict__ candList, int segLength, const
     if (WIDE) atomicOr(&counters[6], 8ull);            // cannot happen: 12 bits hold every open record of a sketch <= 1024
     else wideList[atomicAdd(&counters[7], 1ull)] = cIdx;
   }
+  if (doubleOpen && !cntOverflow) {                    // a query hash with two reference windows open at once: the 2-bit vote cell cannot hold it;
+    total = 0; slotOverflow = false;                   // the candidate is redone by k_l2_sweep_exact
+    exactList[atomicAdd(&counters[0], 1ull)] = cIdx;
+  }
   if (slotOverflow && !cntOverflow) { atomicOr(&counters[6], 1ull); total = 0; }
-  if (doubleOpen && !cntOverflow) atomicOr(&counters[6], 2ull);
   // one reservation per wave (64 candidates): exclusive scan of the lanes' counts, lane 63 of the active lanes asks
   int incl = total;
 #pragma unroll
@@ -479,6 +482,114 @@ k_l2_sweep(int nCand, const int32_t* __restrict__ candList, int segLength, const
       o.meanOptimalPos = (t.start + t.end) / 2; o.sharedSketchSize = t.shared; o.strand = t.strand;
       l2[base + k] = o;                                // a candidate's loci are contiguous and in emission order
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_l2_sweep_exact: the SlideMapper sweep of one candidate per thread, literally (slidingMap.hpp:125-211), for the candidates the fast
+// kernels hand over: an index in which two windows of one hash overlap (addMinmers only removes ADJACENT duplicates,
+// commonFunc.hpp:560; an index written by another program may hold anything) makes a query hash active twice.  The reference's state
+// then keeps `active` a boolean, accumulates strand_vote, and counts sharedSketchElements once per insert and once per delete -- which
+// is what this kernel does, cell by cell, with the state in global memory (count, active, accumulated vote per query position).
+// Rare by construction, so nothing here is tuned.
+// ---------------------------------------------------------------------------------------------
+struct ExactCell { int32_t cnt; int16_t vote; int16_t active; };
+__global__ void __launch_bounds__(64)
+k_l2_sweep_exact(int nList, const int32_t* __restrict__ list, int segLength, const mm_l1_candidate* __restrict__ l1, const mm_frag_stats* __restrict__ stats,
+                 const int64_t* __restrict__ opOff, const int32_t* __restrict__ opCnt, const uint32_t* __restrict__ ops,
+                 const int64_t* __restrict__ l1Off, ExactCell* __restrict__ cells, int cellStride, L2Tmp* __restrict__ tmp, int locap,
+                 mm_l2_locus* __restrict__ l2, unsigned long long l2Cap, int64_t* __restrict__ l2First, int32_t* __restrict__ l2Num,
+                 unsigned long long* __restrict__ counters) {
+  const int li = blockIdx.x * 64 + threadIdx.x;
+  if (li >= nList) return;
+  const int cIdx = list[li];
+  const mm_l1_candidate cand = l1[cIdx];
+  const int f = cand.frag;
+  const int S = stats[f].sketchSize;
+  ExactCell* cell = cells + (size_t)li * cellStride;
+  cell[0] = ExactCell{0, 0, 0};
+  for (int p = 1; p <= S; p++) cell[p] = ExactCell{1, 0, 0};                   // SlideMapper::init (:103-121)
+  int pivot = S, pivRank = S, shared = 0, votes = 0;
+  const uint32_t* src = ops + opOff[cIdx];
+  const int nEnt = opCnt[cIdx];
+  int posAcc = cand.rangeStartPos;
+  int bestShared = 1; bool inRun = false;
+  int curStart = 0, curEnd = 0, curShared = 0;
+  int nFlushed = 0; bool havePend = false; L2Tmp pend{0, 0, 0, 0};
+  L2Tmp* mySlots = tmp + (size_t)cIdx * locap;
+  bool slotOverflow = false;
+  auto close_run = [&](int strand) {                                             // computeMap.hpp:1417-1426 / :1440-1449
+    if (!havePend || pend.end + segLength < curStart) {
+      if (havePend) { if (nFlushed < locap) mySlots[nFlushed] = pend; else slotOverflow = true; nFlushed++; }
+      pend.start = curStart; pend.end = curEnd; pend.shared = curShared; pend.strand = strand; havePend = true;
+    } else pend.end = curEnd;
+  };
+  bool evalPending = false; int evW = 0, evShared = 0, evPrevVotes = 0, lastVotes = 0;
+  for (int i = 0; i < nEnt; i++) {
+    const uint32_t e = src[i];
+    const bool isIns = (e >> E_INS_BIT) & 1u, isDel = (e >> E_DEL_BIT) & 1u, isPre = (e >> E_PRE_BIT) & 1u, isEnd = (e >> E_END_BIT) & 1u, isSkip = (e >> E_SKIP_BIT) & 1u;
+    if (isSkip) { posAcc += (int)(e & E_SKIP_MAX); continue; }
+    if (isIns || isEnd) posAcc += (int)((e >> E_DELTA_SHIFT) & E_MAXDELTA);
+    const int wpos = posAcc;
+    if ((isIns || isEnd) && evalPending) {                                       // the evaluation behind the previous insert (:1376-1430): it needed this wpos
+      if (evShared > bestShared) {
+        nFlushed = 0; havePend = false; bestShared = evShared;
+        curShared = evShared; curStart = evW; curEnd = wpos; inRun = true;
+      } else if (evShared == bestShared) {
+        if (!inRun) { curShared = evShared; curStart = evW; }
+        curEnd = wpos; inRun = true;
+      } else {
+        if (inRun) { curEnd = wpos; close_run(evPrevVotes >= 0 ? 1 : -1); curStart = curEnd = curShared = 0; }
+        inRun = false;
+      }
+      evalPending = false;
+    }
+    if (isEnd) break;
+    if (isIns) { evalPending = true; evPrevVotes = lastVotes; }
+    const int j = (int)(e & 0x7FFu);
+    if (j > 0 && (isIns || isPre || isDel)) {
+      const bool match = (e >> 11) & 1u;
+      ExactCell c = cell[j];
+      if (isIns || isPre) {                                                      // insert_minmer (:125-165)
+        if (match) {
+          c.active = 1; c.vote = (int16_t)(c.vote + ((int)((e >> 12) & 3u) - 1));
+          if (j <= pivot) { shared++; votes += c.vote; }
+          cell[j] = c;
+        } else {
+          c.cnt++; cell[j] = c;
+          if (j <= pivot) pivRank++;
+          if (pivRank > S) { const ExactCell pc = cell[pivot]; shared -= pc.active; votes -= pc.vote; pivRank -= pc.cnt; pivot--; }
+        }
+      } else {                                                                   // delete_minmer (:171-211)
+        if (match) {
+          if (j <= pivot) { shared--; votes -= c.vote; }
+          c.active = 0; c.vote = 0; cell[j] = c;
+        } else {
+          c.cnt--; cell[j] = c;
+          if (j <= pivot) pivRank--;
+          if (pivot + 1 <= S && pivRank + cell[pivot + 1].cnt <= S) { pivot++; const ExactCell pc = cell[pivot]; shared += pc.active; votes += pc.vote; pivRank += pc.cnt; }
+        }
+      }
+    }
+    if (isIns || isPre) lastVotes = votes;
+    if (isIns) { evW = wpos; evShared = shared; }
+  }
+  if (inRun) close_run(votes >= 0 ? 1 : -1);
+  int total = nFlushed + (havePend ? 1 : 0);
+  if (slotOverflow) { atomicOr(&counters[6], 1ull); total = 0; }
+  unsigned long long base = 0;
+  if (total > 0) {
+    base = atomicAdd(&counters[4], (unsigned long long)total);
+    if (base + (unsigned long long)total > l2Cap) { atomicOr(&counters[5], 1ull); return; }
+  }
+  l2First[cIdx] = (int64_t)base; l2Num[cIdx] = total;
+  const int candLocal = (int)(cIdx - l1Off[f]);
+  for (int k = 0; k < total; k++) {
+    const L2Tmp t = (k < nFlushed) ? mySlots[k] : pend;
+    mm_l2_locus o;
+    o.frag = f; o.cand = candLocal; o.seqId = cand.seqId; o.optimalStart = t.start; o.optimalEnd = t.end;
+    o.meanOptimalPos = (t.start + t.end) / 2; o.sharedSketchSize = t.shared; o.strand = t.strand;
+    l2[base + k] = o;
   }
 }
 
@@ -531,7 +642,7 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt) {
   if (ldsWide > 160 * 1024) { c->err = "sketchSize too large for the LDS-resident L2 state"; return MM_ERR_ARG; }
   MM_HIP(c, hipFuncSetAttribute((const void*)k_l2_sweep<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsWide));
   MM_HIP(c, hipFuncSetAttribute((const void*)k_l2_sweep<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsNarrow));
-  MM_HIP(c, c->dL2Wide.ensure((size_t)nC * 4 + 64));
+  MM_HIP(c, c->dL2Wide.ensure((size_t)nC * 4 + 64)); MM_HIP(c, c->dL2Exact.ensure((size_t)nC * 4 + 64));
   MM_HIP(c, c->dL2First.ensure((size_t)nC * 8 + 64)); MM_HIP(c, c->dL2Num.ensure((size_t)nC * 4 + 64));
   if (c->l2Cap < c->nL1 * 2 + 1024) c->l2Cap = c->nL1 * 2 + 1024;
   unsigned long long hc[8];
@@ -541,12 +652,13 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt) {
     MM_HIP(c, c->dL2Tmp.ensure((size_t)nC * locap * sizeof(L2Tmp) + 64));
     MM_HIP(c, hipMemsetAsync(cnt + 4, 0, 16, c->stream));                  // [4] cursor [5] overflow; [6] keeps the locate kernel's flag
     MM_HIP(c, hipMemsetAsync(cnt + 7, 0, 8, c->stream));                   // [7] candidates queued for the wide pass
+    MM_HIP(c, hipMemsetAsync(cnt, 0, 8, c->stream));                       // [0] candidates queued for the exact pass (the lookup stage is done with it)
     {
       KernelTimer t(c, MM_K_L2);
       hipLaunchKernelGGL((k_l2_sweep<false>), dim3((unsigned)((nC + 63) / 64)), dim3(64), ldsNarrow, c->stream, nC, (const int32_t*)nullptr, c->P.segLength,
                          c->dL1.as<mm_l1_candidate>(), c->dStats.as<mm_frag_stats>(), c->dL2Off.as<int64_t>(), c->dL2Cnt.as<int32_t>(), c->dL2Ops.as<uint32_t>(),
                          c->dL1Off.as<int64_t>(), c->dL2Tmp.as<L2Tmp>(), locap, c->dL2.as<mm_l2_locus>(), (unsigned long long)c->l2Cap,
-                         c->dL2Wide.as<int32_t>(), c->dL2First.as<int64_t>(), c->dL2Num.as<int32_t>(), cnt);
+                         c->dL2Wide.as<int32_t>(), c->dL2Exact.as<int32_t>(), c->dL2First.as<int64_t>(), c->dL2Num.as<int32_t>(), cnt);
       MM_HIP(c, hipGetLastError());
     }
     MM_HIP(c, hipMemcpyAsync(hc, cnt, 64, hipMemcpyDeviceToHost, c->stream));
@@ -558,7 +670,20 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt) {
       hipLaunchKernelGGL((k_l2_sweep<true>), dim3((unsigned)((nWide + 63) / 64)), dim3(64), ldsWide, c->stream, nWide, c->dL2Wide.as<int32_t>(), c->P.segLength,
                          c->dL1.as<mm_l1_candidate>(), c->dStats.as<mm_frag_stats>(), c->dL2Off.as<int64_t>(), c->dL2Cnt.as<int32_t>(), c->dL2Ops.as<uint32_t>(),
                          c->dL1Off.as<int64_t>(), c->dL2Tmp.as<L2Tmp>(), locap, c->dL2.as<mm_l2_locus>(), (unsigned long long)c->l2Cap,
-                         (int32_t*)nullptr, c->dL2First.as<int64_t>(), c->dL2Num.as<int32_t>(), cnt);
+                         (int32_t*)nullptr, c->dL2Exact.as<int32_t>(), c->dL2First.as<int64_t>(), c->dL2Num.as<int32_t>(), cnt);
+      MM_HIP(c, hipGetLastError());
+      MM_HIP(c, hipMemcpyAsync(hc, cnt, 64, hipMemcpyDeviceToHost, c->stream));
+      MM_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    if (hc[0] && !(hc[6] & 1ull) && !hc[5]) {                              // candidates with a doubly open query hash: the literal sweep
+      const int nExact = (int)hc[0];
+      if (getenv("MM_DEBUG")) fprintf(stderr, "[mm] L2 sweep: %d of %d candidates redone by the exact kernel (overlapping windows of one hash)\n", nExact, nC);
+      MM_HIP(c, c->dL2Cells.ensure((size_t)nExact * (size_t)(s + 1) * sizeof(ExactCell) + 64));
+      KernelTimer t(c, MM_K_L2);
+      hipLaunchKernelGGL(k_l2_sweep_exact, dim3((unsigned)((nExact + 63) / 64)), dim3(64), 0, c->stream, nExact, c->dL2Exact.as<int32_t>(), c->P.segLength,
+                         c->dL1.as<mm_l1_candidate>(), c->dStats.as<mm_frag_stats>(), c->dL2Off.as<int64_t>(), c->dL2Cnt.as<int32_t>(), c->dL2Ops.as<uint32_t>(),
+                         c->dL1Off.as<int64_t>(), c->dL2Cells.as<ExactCell>(), s + 1, c->dL2Tmp.as<L2Tmp>(), locap, c->dL2.as<mm_l2_locus>(),
+                         (unsigned long long)c->l2Cap, c->dL2First.as<int64_t>(), c->dL2Num.as<int32_t>(), cnt);
       MM_HIP(c, hipGetLastError());
       MM_HIP(c, hipMemcpyAsync(hc, cnt, 64, hipMemcpyDeviceToHost, c->stream));
       MM_HIP(c, hipStreamSynchronize(c->stream));
@@ -575,7 +700,6 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt) {
   }
   if (hc[6] & 4ull) { c->err = "a gap of more than 2^27 bases between consecutive reference minmers inside an L1 candidate is not representable in the L2 stream"; return MM_ERR_ARG; }
   if (hc[6] & 8ull) { c->err = "L2 state counter overflow with 16-bit cells"; return MM_ERR_STATE; }
-  if (hc[6] & 2ull) { c->err = "a query hash had two open reference windows at once (index intervals of one hash overlap)"; return MM_ERR_STATE; }
   if (hc[6] & 1ull) { c->err = "an L1 candidate with more tied L2 loci than 64 GiB of staging can hold"; return MM_ERR_CAPACITY; }
   if (hc[5]) { c->err = "L2 locus buffer overflow"; return MM_ERR_CAPACITY; }
   c->nL2 = (size_t)hc[4];

@@ -812,6 +812,12 @@ void orc_session_add_contig(void* h, const char* name, const char* seq, int len)
   auto v = add_minmers(std::string(seq, seq + len), S->k, S->segLength, S->sketchSize, seqId);
   S->index.insert(S->index.end(), v.begin(), v.end());
 }
+/* replaces minmerIndex before orc_session_finalize: lets a test model an index as another program might have written it
+   (--loadIndex), e.g. with overlapping windows of one hash */
+void orc_session_set_index(void* h, const orc_minmer* recs, int64_t n) {
+  auto* S = (Session*)h;
+  S->index.assign(recs, recs + n);
+}
 void orc_session_finalize(void* h) {
   auto* S = (Session*)h;
   build_lookup(*S);

@@ -59,6 +59,8 @@ void* orc_session_new(int k, int segLength, int sketchSize, float pi, int filter
                       char prefixDelim, float kmerPctThreshold, int numMappings);
 /* contigs must be added in file order; name is the FASTA header up to the first space */
 void orc_session_add_contig(void* h, const char* name, const char* seq, int len);
+/* replaces minmerIndex (sorted by (seqId, wpos)) before orc_session_finalize */
+void orc_session_set_index(void* h, const orc_minmer* recs, int64_t n);
 /* runs Sketch::index + frequency filter (winSketch.hpp:379-504) and Map::setProbs (computeMap.hpp:178) */
 void orc_session_finalize(void* h);
 void orc_session_free(void* h);

@@ -17,10 +17,10 @@ def prefix_groups(names, delim):
 
 
 def run_and_compare(oracle, contigs, reads, k=19, L=5000, s=130, pi=0.85, flags=U.FLAG_HG, delim="\0", kmerPct=0.001,
-                    seqCounterBase=0, check_points=True, verbose=True):
+                    seqCounterBase=0, check_points=True, verbose=True, mutate_index=None):
     """contigs: [(name, uint8 array)], reads: [(name, uint8 array)].  Returns (nFragments, nMappedLoci)."""
     from mashmap_amd import capi
-    h = oracle.session(contigs, k, L, s, pi, U.FILTER_MAP, flags, delim.encode() if delim != "\0" else b"\0", kmerPct)
+    h = oracle.session(contigs, k, L, s, pi, U.FILTER_MAP, flags, delim.encode() if delim != "\0" else b"\0", kmerPct, mutate_index=mutate_index)
     ix = oracle.export_index(h)
     cflags = 0
     if flags & U.FLAG_HG: cflags |= capi.MM_FLAG_HG_FILTER

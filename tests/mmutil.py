@@ -318,11 +318,17 @@ class Oracle(_Side):
         lib.orc_normalise.argtypes = [C.c_char_p, C.c_int64]
 
     def session(self, contigs, k=19, segLength=5000, sketchSize=130, pi=0.85, filterMode=FILTER_MAP, flags=FLAG_HG,
-                delim=b"\0", kmerPct=0.001, numMappings=1):
+                delim=b"\0", kmerPct=0.001, numMappings=1, mutate_index=None):
+        """mutate_index(records) -> records: replaces minmerIndex before Sketch::index runs (an index as another program might
+        have written it)"""
         h = self.lib.orc_session_new(k, segLength, sketchSize, pi, filterMode, flags, delim, kmerPct, numMappings)
         for name, a in contigs:
             b = bytes(a)
             self.lib.orc_session_add_contig(h, name.encode(), b, len(b))
+        if mutate_index is not None:
+            recs = np.ascontiguousarray(mutate_index(self.index_array(h)), dtype=MINMER_DT)
+            self.lib.orc_session_set_index.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+            self.lib.orc_session_set_index(h, recs.ctypes.data, len(recs))
         self.lib.orc_session_finalize(h)
         return h
 

@@ -214,3 +214,40 @@ def test_index_with_a_hyper_frequent_seed():
     for a, b in zip(base, got):
         assert a.tobytes() == b.tobytes()
     ctx.close(); ctx2.close()
+
+
+def test_map_overlapping_windows_of_one_hash(oracle):
+    """An index in which two windows of one hash overlap (addMinmers only removes adjacent duplicates, commonFunc.hpp:560, and a
+    loaded index may come from anywhere): a query hash is then open twice during the L2 slide, which the reference's SlideMapper
+    absorbs in its own way (boolean `active`, accumulated votes, a count per insert and per delete, slidingMap.hpp:139-145,185-192).
+    The fast L2 kernels hand such candidates to k_l2_sweep_exact; every locus must still equal the oracle's."""
+    from mashmap_amd import capi
+    contigs = genome(601, [300000, 200000], repeats=False)
+    reads = reads_for(contigs, 61, 40, 10000, 0.06)
+
+    def overlap(recs):
+        extra = []
+        for i in range(0, len(recs), 5):
+            r = recs[i].copy()
+            d = 13 if i % 2 else 37
+            r["wpos"] += d; r["wpos_end"] += d
+            if i % 3 == 0:
+                r["strand"] = -r["strand"]
+            extra.append(r)
+        allr = np.concatenate([recs, np.array(extra, dtype=recs.dtype)])
+        order = np.lexsort((np.arange(len(allr)), allr["wpos"], allr["seqId"]))      # (seqId, wpos), originals first among equals
+        return allr[order]
+
+    nF, nl = run_and_compare(oracle, contigs, reads, mutate_index=overlap)
+    assert nl > 50
+    # the exact kernel really ran
+    h = oracle.session(contigs, 19, 5000, 130, 0.85, mutate_index=overlap)
+    ix = oracle.export_index(h)
+    ctx = capi.Context(k=19, segLength=5000, sketchSize=130)
+    ctx.index_upload(ix["minmers"], ix["keys"], ix["offsets"], ix["points"], ix["freq"], ix["contigLen"])
+    ctx.set_tables_default(0.85)
+    ctx.reads_upload([a for _, a in reads])
+    ctx.profile(True); ctx.profile_read(reset=True)
+    ctx.map()
+    assert ctx.profile_read()["l2"][1] >= 2, "no candidate reached the exact sweep"
+    ctx.close(); oracle.free(h)
