@@ -15,6 +15,7 @@ Workloads (BASELINE.json `configs`; the default is configs[1], the configuration
   configs1  1 M x 10 kbp reads (10 % ONT-like error) vs 100 Mbp, pi 85, segLength 5000, sketchSize 130
   configs3  per-GPU share of configs[3]: 1.25 M x 15 kbp reads vs 3 Gbp (24 x 125 Mbp), sketchSize 310 (the stock binary's value:
             its int32 referenceSize overflows for a 3 GB file; 220 mathematically -- SURVEY App. C)
+  northstar the north_star target sentence: 1 M x 10 kbp reads, pi 85, against the 3 Gbp index (sketchSize 310 as for configs3)
   configs4  per-GPU share of configs[4]: 625 k x 20 kbp reads at 15-20 % error vs 10 x 300 Mbp (the --rl list shares one seqId
             space, winSketch.hpp:174-214), --dense --pi 80 => sketchSize 498
 --reads / --ref-contigs / --ref-contig-len scale a workload down; the JSON line names what actually ran.
@@ -43,6 +44,9 @@ WORKLOADS = {
     "configs3": dict(label="configs[3] (per-GPU share of 10 M reads / 8 GPUs)", k=19, seg=5000, sketch=310, pi=0.85, read_len=15000,
                      err=(0.10, 0.10), reads=1_250_000, ref_contigs=24, ref_contig_len=125_000_000,
                      sketch_note="310 = what the stock binary derives for a 3 GB reference file (int32 referenceSize overflow); 220 mathematically (SURVEY App. C)"),
+    "northstar": dict(label="north_star target (10 kbp reads, pi 85, human-scale index)", k=19, seg=5000, sketch=310, pi=0.85, read_len=10000,
+                      err=(0.10, 0.10), reads=1_000_000, ref_contigs=24, ref_contig_len=125_000_000,
+                      sketch_note="310 = what the stock binary derives for a 3 GB reference file (int32 referenceSize overflow); 220 mathematically (SURVEY App. C)"),
     "configs4": dict(label="configs[4] (per-GPU share of 5 M reads / 8 GPUs)", k=19, seg=5000, sketch=498, pi=0.80, read_len=20000,
                      err=(0.15, 0.20), reads=625_000, ref_contigs=10, ref_contig_len=300_000_000,
                      sketch_note="498 = --dense at pi 80: 0.02 (1 + 0.2 / 0.05) (5000 - 19) (parseCmdArgs.hpp:620-641); the 10 --rl files are 10 contigs of one index"),

@@ -198,17 +198,24 @@ static HashContigFn pick_hasher(int k) {
 //   Sketch::index (winSketch.hpp:379-404) unless the lookup map is supplied, computeFreqHist / computeFreqSeedSet /
 //   dropFreqSeedSet (:410-504), then the flat device index.  `all` is minmerIndex BEFORE the frequent-seed drop.
 // ---------------------------------------------------------------------------------------------
+// mm_index_build: Sketch::index, the frequency filter and the flat index on the device (mm_index_dev.hip), from the contigs' record
+// arrays as they are; the host copies behind mm_index_download are filled from the device on request
+static int finalize_built_index(mm_ctx* c, std::vector<std::vector<mm_minmer>>& per, float kmerPctThreshold, const int32_t* contigLen,
+                                const int32_t* refGroup, size_t nContigs) {
+  c->hKeys.clear(); c->hOffsets.clear(); c->hPoints.clear(); c->hFreq.clear(); c->hMinmers.clear();
+  c->mirrorMinmers = c->mirrorMap = false;
+  std::vector<std::pair<const mm_minmer*, size_t>> parts;
+  for (const auto& v : per) parts.emplace_back(v.data(), v.size());
+  const int rc = mm_finalize_index_device(c, parts, kmerPctThreshold, contigLen, refGroup, nContigs);
+  std::vector<mm_minmer>().swap(c->hMinmersAll);
+  if (c->keepFullIndex) for (const auto& v : per) c->hMinmersAll.insert(c->hMinmersAll.end(), v.begin(), v.end());   // --saveIndex wants minmerIndex before the drop
+  return rc;
+}
+
+// --loadIndex: second half of the index build from host arrays in reference layout
 static int finalize_index(mm_ctx* c, std::vector<mm_minmer>& all, bool haveMap, float kmerPctThreshold, const int32_t* contigLen,
                           const int32_t* refGroup, size_t nContigs) {
-  if (!haveMap) {
-    // mm_index_build: Sketch::index, the frequency filter and the flat index on the device (mm_index_dev.hip); the host copies behind
-    // mm_index_download are filled from the device on request
-    c->hKeys.clear(); c->hOffsets.clear(); c->hPoints.clear(); c->hFreq.clear(); c->hMinmers.clear();
-    c->mirrorMinmers = c->mirrorMap = false;
-    const int rc = mm_finalize_index_device(c, all.data(), all.size(), kmerPctThreshold, contigLen, refGroup, nContigs);
-    if (c->keepFullIndex) c->hMinmersAll.swap(all); else std::vector<mm_minmer>().swap(c->hMinmersAll);
-    return rc;
-  }
+  (void)haveMap;
   // --loadIndex: the lookup map comes from the file (it is not re-derived), so the threshold is taken from it here, as
   // computeFreqHist / computeFreqSeedSet / dropFreqSeedSet do (winSketch.hpp:410-504)
   int32_t freqThreshold = 0x7fffffff;
@@ -278,21 +285,9 @@ extern "C" int mm_index_build(mm_ctx* c, const char* bases, const int64_t* conti
   dAscii.release(); dB.release(); dM.release(); dMeta.release(); dH.release(); dS.release(); wb.release();
   if (rc != MM_OK) return rc;
 
-  // Sketch::index (winSketch.hpp:379-404): per-hash OPEN/CLOSE points in minmerIndex order, adjacent runs merged
-  std::vector<mm_minmer> all;
-  {
-    std::vector<size_t> at(nContigs + 1, 0);
-    for (size_t ci = 0; ci < nContigs; ci++) at[ci + 1] = at[ci] + per[ci].size();
-    all.resize(at[nContigs]);
-    std::atomic<size_t> next(0);
-    auto copy = [&]() { for (size_t ci = next.fetch_add(1); ci < nContigs; ci = next.fetch_add(1)) { if (!per[ci].empty()) std::memcpy(all.data() + at[ci], per[ci].data(), per[ci].size() * sizeof(mm_minmer)); std::vector<mm_minmer>().swap(per[ci]); } };
-    std::vector<std::thread> th;
-    for (unsigned t = 1; t < std::min<unsigned>(maxJobs, 16); t++) th.emplace_back(copy);
-    copy();
-    for (auto& t : th) t.join();
-  }
-  if (dbg) fprintf(stderr, "[mm] index: %zu records concatenated at %.2f s\n", all.size(), since());
-  const int frc = finalize_index(c, all, false, kmerPctThreshold, clen.data(), refGroup, nContigs);
+  size_t nRecords = 0; for (const auto& v : per) nRecords += v.size();
+  if (dbg) fprintf(stderr, "[mm] index: %zu records in %zu per-contig arrays at %.2f s\n", nRecords, nContigs, since());
+  const int frc = finalize_built_index(c, per, kmerPctThreshold, clen.data(), refGroup, nContigs);
   if (dbg) fprintf(stderr, "[mm] index: Sketch::index + frequency filter + flat index on the device done at %.2f s (%zu keys, %zu points)\n", since(), c->idx.nKeys, c->idx.nPoints);
   return frc;
 }

@@ -388,9 +388,12 @@ int mm_flatten_device_index(mm_ctx* c, const mm_minmer* dRec, size_t n, size_t n
 
 // Sketch::index + the frequency filter on the device, from minmerIndex BEFORE the drop (host array, reference layout), then the flat
 // device index.  Leaves nothing on the host but the frequent-seed list (small) and, with MM_OPT_KEEP_FULL_INDEX, the caller's records.
-int mm_finalize_index_device(mm_ctx* c, const mm_minmer* hAll, size_t nAll, float kmerPctThreshold, const int32_t* contigLen, const int32_t* refGroup, size_t nContigs) {
+int mm_finalize_index_device(mm_ctx* c, const std::vector<std::pair<const mm_minmer*, size_t>>& parts, float kmerPctThreshold, const int32_t* contigLen,
+                             const int32_t* refGroup, size_t nContigs) {
   DeviceIndex& I = c->idx;
   I.ready = false;
+  size_t nAll = 0;
+  for (const auto& p : parts) nAll += p.second;
   if (nAll >= (1ull << 31)) { c->err = "mm_index_build: more than 2^31 minmer records"; return MM_ERR_CAPACITY; }
   Tmp T;
   DevBuf& scratch = *T.make();
@@ -399,7 +402,13 @@ int mm_finalize_index_device(mm_ctx* c, const mm_minmer* hAll, size_t nAll, floa
   unsigned long long* diag = c->dCounters.as<unsigned long long>() + 16;       // [16] sort check, [17] nFreq, [18] list cursor, [19] threshold
   MM_HIP(c, hipMemsetAsync(diag, 0, 32, c->stream));
   MM_HIP(c, dAll.ensure(nAll * sizeof(mm_minmer) + 64));
-  if (nAll) MM_HIP(c, hipMemcpyAsync(dAll.p, hAll, nAll * sizeof(mm_minmer), hipMemcpyHostToDevice, c->stream));
+  {
+    size_t at = 0;                                     // the contigs' records go up one after the other: no concatenated host copy
+    for (const auto& p : parts) {
+      if (p.second) MM_HIP(c, hipMemcpyAsync(dAll.as<mm_minmer>() + at, p.first, p.second * sizeof(mm_minmer), hipMemcpyHostToDevice, c->stream));
+      at += p.second;
+    }
+  }
   size_t nk = 0, nRuns = 0;
   DevBuf& sIdx = *T.make(); DevBuf& flags = *T.make(); DevBuf& pre = *T.make();
   if (nAll) {

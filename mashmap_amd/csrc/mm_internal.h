@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <utility>
 #include <vector>
 #include "../../include/mashmap_hip.h"
 
@@ -148,7 +149,8 @@ void mm_comm_release(mm_ctx* c);
 int mm_launch_l2(mm_ctx* c, unsigned long long* cnt);   // cnt: device counters [4] cursor [5] overflow [6] slot overflow
 int mm_build_device_index(mm_ctx* c, const int32_t* contigLen, const int32_t* refGroup, size_t nContigs);   // from the host mirrors
 int mm_flatten_device_index(mm_ctx* c, const mm_minmer* dRec, size_t n, size_t nk, size_t np, const int32_t* contigLen, const int32_t* refGroup, size_t nContigs);
-int mm_finalize_index_device(mm_ctx* c, const mm_minmer* hAll, size_t nAll, float kmerPctThreshold, const int32_t* contigLen, const int32_t* refGroup, size_t nContigs);
+int mm_finalize_index_device(mm_ctx* c, const std::vector<std::pair<const mm_minmer*, size_t>>& parts, float kmerPctThreshold, const int32_t* contigLen,
+                             const int32_t* refGroup, size_t nContigs);
 int mm_mirror_minmers(mm_ctx* c);
 int mm_mirror_map(mm_ctx* c);
 int mm_scan_i32_to_i64(mm_ctx* c, int64_t n, const int32_t* dIn, int64_t* dOut, int64_t* total);

@@ -1,8 +1,8 @@
-"""Multi-GPU plumbing: one process per GPU, reads sharded, index replicated, one all-gatherv of the
-32-byte L2 locus records (include/mashmap_hip.h: mm_l2_locus) at the end of a pass.
-
-torch.distributed only moves bytes here; the backend is "nccl" (= RCCL over xGMI) on GPUs and "gloo" in the CPU tests.
-Fragments never interact before the CPU filters (computeMap.hpp:679-697 work per read), so there is no other collective.
+"""Read-block arithmetic of the multi-GPU layout: one process per GPU, reads sharded in contiguous blocks, index
+replicated.  The exchange step of the product is the RCCL all-gatherv inside libmashmap_hip.so (mashmap_amd/csrc/mm_comm.hip:
+mm_allgatherv_mappings), which bench.py and skch::Map call; `allgatherv_records` below is the same collective over torch.distributed,
+kept for the CPU tests (gloo) that pin down the layout -- rank-major records, contiguous read blocks == input order -- where no GPU
+and no RCCL exist.
 """
 import numpy as np
 

@@ -30,6 +30,10 @@ c3)
   echo "== configs3 full" | tee -a $OUT/log.txt
   MM_DEBUG=1 timeout 1500 python bench.py --steps 3 --warmup 1 --workload configs3 > $OUT/bench_c3.json 2> $OUT/bench_c3.err
   grep -v "^\[mm\] sketch\|lookup+L1" $OUT/bench_c3.err | tail -12 | tee -a $OUT/log.txt; cat $OUT/bench_c3.json | tee -a $OUT/log.txt ;;
+ns)
+  echo "== north_star target: 10 kbp reads vs 3 Gbp" | tee -a $OUT/log.txt
+  MM_DEBUG=1 timeout 1500 python bench.py --steps 3 --warmup 1 --workload northstar > $OUT/bench_ns.json 2> $OUT/bench_ns.err
+  grep "index" $OUT/bench_ns.err | tail -8 | tee -a $OUT/log.txt; cat $OUT/bench_ns.json | tee -a $OUT/log.txt ;;
 c4)
   echo "== configs4 full" | tee -a $OUT/log.txt
   MM_DEBUG=1 timeout 1500 python bench.py --steps 3 --warmup 1 --workload configs4 > $OUT/bench_c4.json 2> $OUT/bench_c4.err

@@ -3,6 +3,8 @@
 import json
 import os
 
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -88,6 +90,35 @@ def test_map_vs_reference_golden(gold):
         assert g2 == e["l2"], f
         nl2 += len(g2)
     assert nl2 > 60
+    # the candidate mappings the device selects (k_l2_select) and the floats the product derives from them, against what the real
+    # reference's mapSingleQueryFrag reported: integers exactly, identities / upper bound / k-mer complexity to 1e-6
+    lib = capi.load()
+    recs = ctx.mappings()
+    by_frag, at = {}, 0
+    for m in recs:
+        while (int(frs[at]["readId"]), int(frs[at]["fragStart"])) != (int(m["querySeqId"]), int(m["fragStart"])):
+            at += 1
+        by_frag.setdefault(at, []).append(m)
+    nmap = 0
+    for f in range(nF):
+        e = gf[f]
+        got = []
+        for m in by_frag.get(f, []):
+            ql, qs, sh = int(m["fragLen"]), int(m["sketchSize"]), int(m["conservedSketches"])
+            md = lib.mm_stat_j2md(C.c_float(1.0 * sh / qs), P["k"])
+            ident = np.float32(1.0) - np.float32(md)
+            ub = np.float32(1.0) - np.float32(lib.mm_stat_md_lower_bound(C.c_float(md), qs, P["k"], C.c_float(0.95)))
+            mh01 = float(np.longdouble(int(m["maxHash"])) / np.longdouble(2 ** 64 - 1))
+            kc = float(np.float32((float(int(m["rawSketchSize"])) / mh01) / ((ql - P["k"] + 1) * 2)))
+            got.append(([ql, int(m["refStartPos"]), int(m["refStartPos"]) + ql, 0, ql, int(m["refSeqId"]), int(m["querySeqId"]), ql, qs, sh, int(m["strand"])],
+                        [float(ident), float(ub), kc]))
+        got.sort(key=lambda x: (x[0][5], x[0][1]))
+        exp = sorted(zip([x[:11] for x in e["maps_i"]], [[float(v) for v in x] for x in e["maps_f"]]), key=lambda x: (x[0][5], x[0][1]))
+        assert [g[0] for g in got] == [x[0] for x in exp], f
+        for g, x in zip(got, exp):
+            assert all(abs(a - b) <= 1e-6 for a, b in zip(g[1], x[1])), (f, g[1], x[1])
+        nmap += len(got)
+    assert nmap > 50
     ctx.close()
 
 
