@@ -109,3 +109,18 @@ def paf_cases():
         ("allvsall_Y", hap, None, ["--pi", "95", "-n", "1", "-Y", "#"]),
         ("allvsall_X_lower", hap, hap, ["--pi", "90", "-X", "--lowerTriangular", "-n", "3"]),
     ]
+
+
+def paf_list_cases():
+    """command lines whose inputs are LISTS of files (--rl / --ql, parseCmdArgs.hpp:293-313): (name, [records of reference file i], [records
+    of query file j], extra argv).  configs[4] of BASELINE.json has this form: --dense --pi 80, 20 kbp reads at 15-20 % error, ten references."""
+    cs = [U.random_dna(900 + i, n) for i, n in enumerate((90000, 70000, 110000, 60000, 80000, 100000, 65000, 75000, 95000, 85000))]
+    blk = U.mutate(cs[0][20000:50000], 91, 0.05); cs[7][10000:10000 + len(blk)] = blk[:len(cs[7]) - 10000][:len(blk)]
+    ref_files = [[("f%d_chr" % i, c)] for i, c in enumerate(cs)]
+    ref_files[3].append(("f3_extra", U.random_dna(950, 30000)))
+    reads = []
+    for j, err in enumerate((0.15, 0.18, 0.20)):
+        reads += [("n%d_%s" % (j, n), a) for n, a, _ in U.sample_reads(cs, 70 + j, 14, 20000, err)]
+    q_files = [reads[:20], reads[20:]]
+    return [("rl_dense_pi80_20kbp", ref_files, q_files, ["--dense", "--pi", "80"]),
+            ("rl_default_n3", ref_files, q_files, ["-n", "3"])]

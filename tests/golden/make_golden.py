@@ -75,6 +75,16 @@ def main():
             if qrec is not None:
                 qf = os.path.join(td, name + ".q.fa"); U.write_fasta(qf, qrec); args += ["-q", qf]
             subprocess.run(args, check=True, capture_output=True)
+    with tempfile.TemporaryDirectory() as td:
+        for name, ref_files, q_files, extra in CS.paf_list_cases():
+            rl, ql = os.path.join(td, name + ".rl"), os.path.join(td, name + ".ql")
+            with open(rl, "w") as f:
+                for i, recs in enumerate(ref_files):
+                    fn = os.path.join(td, "%s.ref%d.fa" % (name, i)); U.write_fasta(fn, recs); f.write(fn + "\n")
+            with open(ql, "w") as f:
+                for i, recs in enumerate(q_files):
+                    fn = os.path.join(td, "%s.q%d.fa" % (name, i)); U.write_fasta(fn, recs); f.write(fn + "\n")
+            subprocess.run([U.REF_BIN, "--rl", rl, "--ql", ql, "-o", os.path.join(pafdir, name + ".paf"), "-t", "2"] + extra, check=True, capture_output=True)
     with open(os.path.join(HERE, "golden.json"), "w") as f:
         json.dump(out, f, indent=0, separators=(",", ":"))
     print("golden: %d hashes, %d sketches, %d minmer cases, %d fragments" %

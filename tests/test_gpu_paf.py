@@ -58,6 +58,35 @@ def test_paf_identical_to_reference(name, tmp_path):
         assert dr == exp, _diff(dr, exp)
 
 
+@pytest.mark.parametrize("name", [c[0] for c in CS.paf_list_cases()])
+def test_paf_with_file_lists(name, tmp_path):
+    """--rl / --ql: several reference files share one seqId space (winSketch.hpp:174-214), several query files one read counter; the
+    configs[4] form (--dense --pi 80, 20 kbp reads at 15-20 % error, ten reference files)"""
+    _, ref_files, q_files, extra = {c[0]: c for c in CS.paf_list_cases()}[name]
+    td = str(tmp_path)
+    rl, ql = os.path.join(td, "refs.txt"), os.path.join(td, "queries.txt")
+    with open(rl, "w") as f:
+        for i, recs in enumerate(ref_files):
+            fn = os.path.join(td, "ref%d.fa" % i); U.write_fasta(fn, recs); f.write(fn + "\n")
+    with open(ql, "w") as f:
+        for i, recs in enumerate(q_files):
+            fn = os.path.join(td, "q%d.fa" % i); U.write_fasta(fn, recs); f.write(fn + "\n")
+    exp = open(os.path.join(PAF_DIR, name + ".paf"), "rb").read()
+    assert len(exp) > 0
+    for binary, tag in ((HIP_BIN, "hip"), (DROPIN_BIN, "dropin"), (U.REF_BIN, "ref")):
+        if tag != "hip" and not os.path.exists(binary):
+            continue
+        out = os.path.join(td, tag + ".paf")
+        p = subprocess.run([binary, "--rl", rl, "--ql", ql, "-o", out, "-t", "4"] + extra, capture_output=True, text=True)
+        assert p.returncode == 0, p.stderr[-2000:]
+        got = open(out, "rb").read()
+        assert got == exp, tag + ": " + _diff(got, exp)
+    env = dict(os.environ, MASHMAP_HIP_DEVICES="0,0")      # and sharded over two contexts
+    out = os.path.join(td, "sharded.paf")
+    p = subprocess.run([HIP_BIN, "--rl", rl, "--ql", ql, "-o", out, "-t", "4"] + extra, capture_output=True, text=True, env=env)
+    assert p.returncode == 0 and open(out, "rb").read() == exp
+
+
 def test_paf_independent_of_batching_and_threads(tmp_path):
     _, refrec, qrec, extra = CASES["default"]
     a = _run(HIP_BIN, str(tmp_path), "default", refrec, qrec, extra, "t1", threads="1")
