@@ -44,13 +44,16 @@ for it in range(n_iter):
     if qrec is not None:
         qf = os.path.join(td, "q%d.fa" % it); U.write_fasta(qf, qrec); base += ["-q", qf]
     outs = {}
+    shard = pick(19, ["", "", "0,0", "0,0,0"])              # some runs sharded over several contexts (MASHMAP_HIP_DEVICES)
     for tag, exe in (("hip", HIP), ("ref", U.REF_BIN)):
-        p = subprocess.run([exe] + base + ["-o", os.path.join(td, tag + ".paf")], capture_output=True, text=True)
+        env = dict(os.environ)
+        if tag == "hip" and shard: env["MASHMAP_HIP_DEVICES"] = shard; env["MASHMAP_HIP_BATCH_MBP"] = pick(20, ["512", "0.04", "0.2"])
+        p = subprocess.run([exe] + base + ["-o", os.path.join(td, tag + ".paf")], capture_output=True, text=True, env=env)
         outs[tag] = (p.returncode, open(os.path.join(td, tag + ".paf"), "rb").read() if p.returncode == 0 else p.stderr[-300:])
     ok = outs["hip"][0] == 0 and outs["ref"][0] == 0 and outs["hip"][1] == outs["ref"][1]
     if not ok: bad += 1
     nl = outs["ref"][1].count(b"\n") if outs["ref"][0] == 0 else -1
-    print("ok  " if ok else "FAIL", it, " ".join(args), "allvsall" if allvsall else "reads", "lines", nl, flush=True)
+    print("ok  " if ok else "FAIL", it, " ".join(args), "allvsall" if allvsall else "reads", "lines", nl, ("devices " + shard) if shard else "", flush=True)
     if not ok:
         if outs["hip"][0] != 0 or outs["ref"][0] != 0: print("   rc", outs["hip"][0], outs["ref"][0], str(outs["hip"][1])[-200:] if outs["hip"][0] else "", flush=True)
         else:

@@ -121,9 +121,9 @@ def fuzz_scenario(seed0, it):
     """a random but reproducible (k, segLength, sketchSize, pi, flags, error rate, genome shape) scenario for run_and_compare"""
     r = U.splitmix64(seed0 * 7919 + it, 16)
     pick = lambda i, xs: xs[int(r[i] % np.uint64(len(xs)))]
-    k = pick(0, [15, 16, 17, 19, 19, 19, 21, 24])
+    k = pick(0, [15, 16, 17, 19, 19, 19, 21, 24] if seed0 < 3 else [9, 12, 16, 18, 19, 19, 20, 21, 26, 28, 30, 32])
     L = pick(1, [500, 1000, 2000, 5000, 5000, 10000])
-    s = pick(2, [10, 20, 40, 64, 65, 128, 130, 130, 200, 310, 498])
+    s = pick(2, [10, 20, 40, 64, 65, 128, 130, 130, 200, 310, 498] if seed0 < 3 else [16, 64, 130, 200, 257, 310, 498, 700, 1100, 1279])
     if s > (L - k) // 4: s = max(5, (L - k) // 8)
     pi = pick(3, [0.80, 0.85, 0.85, 0.90, 0.95])
     err = pick(4, [0.0, 0.02, 0.05, 0.10, 0.15])
