@@ -274,6 +274,7 @@ def main():
     ap.add_argument("--ref-contig-len", type=int, default=0)
     ap.add_argument("--kmer", type=int, default=0, help="k-mer size (default: the reference's 19; other sizes are not the BASELINE configuration)")
     ap.add_argument("--cpu-sample", type=int, default=30000)
+    ap.add_argument("--sync-exchange", action="store_true", help="N>1: all-gatherv on the compute stream instead of overlapped with the next batch")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -367,12 +368,23 @@ def main():
         dist.broadcast_object_list(box, src=0)
         ctx.comm_init_rank(box[0], rank, world)
 
+    inflight = [False]
+
     def step():
         ctx.map()
-        if world > 1:
-            ctx.allgatherv_mappings()                   # all-gatherv of the candidate mappings over RCCL/xGMI, on the library's stream
+        if world > 1:                                   # all-gatherv of the candidate mappings over RCCL/xGMI: the exchange of batch i
+            if args.sync_exchange:                      # runs on the library's exchange stream under the kernels of batch i+1
+                ctx.allgatherv_mappings()               # (--sync-exchange: on the compute stream, the step waits for it)
+                return
+            if inflight[0]:
+                ctx.allgatherv_mappings_end()
+            ctx.allgatherv_mappings_begin()
+            inflight[0] = True
 
-    def fence():
+    def fence():                                        # the last exchange is waited for INSIDE the timed region
+        if inflight[0]:
+            ctx.allgatherv_mappings_end()
+            inflight[0] = False
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -452,7 +464,7 @@ def main():
                                       ref_mbp, len(ref_lens)),
                        "k": K, "segLength": SEG, "sketchSize": SKETCH, "sketchSize_note": W["sketch_note"],
                        "percentageIdentity": PI, "fragments_per_gpu": nF,
-                       "parallelism": "reads sharded, index replicated, RCCL all-gatherv of candidate mappings (libmashmap_hip: mm_allgatherv_mappings)"
+                       "parallelism": "reads sharded, index replicated, RCCL all-gatherv of candidate mappings (libmashmap_hip: mm_allgatherv_mappings_begin/_end, overlapped with the next batch)"
                        if world > 1 else "single GPU", "mean_interval_points_per_fragment": round(P, 1),
                        "l1_candidates_per_gpu": n1, "l2_loci_per_gpu": n2, "candidate_mappings_per_gpu": nmap,
                        "index_build_s": round(index_s, 2),

@@ -267,6 +267,12 @@ int mm_comm_init_rank(mm_ctx* ctx, const void* id, int rank, int world);
 int mm_comm_init_local(mm_ctx** ctxs, int n);
 int mm_comm_world(const mm_ctx* ctx, int* rank, int* world);
 int mm_allgatherv_mappings(mm_ctx* ctx);
+/* The same exchange overlapped with the next batch: _begin snapshots the resident candidate mappings and returns at once (the exchange
+ * runs on a stream and a host thread of its own); the caller may upload and map the next batch; _end waits for the exchange, after
+ * which mm_gathered_* serve the records of the batch _begin was called on.  One exchange in flight per context; every rank must call
+ * _begin / _end in the same order as the other ranks' (they are collectives). */
+int mm_allgatherv_mappings_begin(mm_ctx* ctx);
+int mm_allgatherv_mappings_end(mm_ctx* ctx);
 int mm_allgatherv_mappings_local(mm_ctx** ctxs, int n);
 int mm_gathered_counts(const mm_ctx* ctx, size_t* perRank, size_t* total);
 int mm_gathered_download(mm_ctx* ctx, mm_mapping* out, size_t cap);

@@ -112,6 +112,8 @@ def load():
         "mm_comm_world": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
         "mm_allgatherv_mappings": (C.c_int, [vp]),
         "mm_allgatherv_mappings_local": (C.c_int, [C.POINTER(vp), C.c_int]),
+        "mm_allgatherv_mappings_begin": (C.c_int, [vp]),
+        "mm_allgatherv_mappings_end": (C.c_int, [vp]),
         "mm_gathered_counts": (C.c_int, [vp, vp, C.POINTER(sz)]),
         "mm_gathered_download": (C.c_int, [vp, vp, sz]),
         "mm_gathered_device": (C.c_int, [vp, C.POINTER(vp), C.POINTER(sz)]),
@@ -137,6 +139,7 @@ EXPORTS = ["mm_abi_version", "mm_create", "mm_destroy", "mm_last_error", "mm_ind
            "mm_kernel_name", "mm_synchronize", "mm_stream", "mm_bench_hash_only",
            "mm_set_replay_tables", "mm_mappings_count", "mm_mappings_download", "mm_mappings_device", "mm_comm_unique_id",
            "mm_comm_init_rank", "mm_comm_init_local", "mm_comm_world", "mm_allgatherv_mappings", "mm_allgatherv_mappings_local",
+           "mm_allgatherv_mappings_begin", "mm_allgatherv_mappings_end",
            "mm_gathered_counts", "mm_gathered_download", "mm_gathered_device", "mm_index_replicate", "mm_stat_replay_tables", "mm_host_alloc", "mm_host_free"]
 
 
@@ -348,6 +351,13 @@ class Context:
 
     def allgatherv_mappings(self):
         self._ck(self.lib.mm_allgatherv_mappings(self.h), "mm_allgatherv_mappings")
+
+    def allgatherv_mappings_begin(self):
+        """start the exchange of the resident candidate mappings; the next batch may be mapped before allgatherv_mappings_end()"""
+        self._ck(self.lib.mm_allgatherv_mappings_begin(self.h), "mm_allgatherv_mappings_begin")
+
+    def allgatherv_mappings_end(self):
+        self._ck(self.lib.mm_allgatherv_mappings_end(self.h), "mm_allgatherv_mappings_end")
 
     def gathered(self, world):
         counts = np.zeros(world, dtype=np.uint64); tot = C.c_size_t()

@@ -62,7 +62,9 @@ void mm_destroy(mm_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
+  if (c->gatherThread.joinable()) c->gatherThread.join();
   mm_comm_release(c);
+  if (c->commStream) (void)hipStreamDestroy(c->commStream);
   for (DevBuf* b : c->allBufs()) b->release();
   if (c->evA) (void)hipEventDestroy(c->evA);
   if (c->evB) (void)hipEventDestroy(c->evB);

@@ -76,15 +76,41 @@ void place(mm_ctx* c) {
   c->nGathered = c->gatherDisp.back();
 }
 
-// the `world` broadcasts of one rank (to be called between GroupStart / GroupEnd)
-int issue_broadcasts(mm_ctx* c, Rccl* R) {
+// the `world` broadcasts of one rank (to be called between GroupStart / GroupEnd); `mine` = this rank's records
+struct ErrSink { std::string err; };   // error text of the exchange thread (c->err belongs to the caller's thread)
+
+template <class E>
+int issue_broadcasts(mm_ctx* c, E* e, Rccl* R, const void* mine, hipStream_t stream) {
   const int world = c->commWorld;
   for (int r = 0; r < world; r++) {
     const size_t bytes = c->gatherCounts[r] * sizeof(mm_mapping);
     if (!bytes) continue;
     char* slot = (char*)c->dGathered.p + c->gatherDisp[r] * sizeof(mm_mapping);
-    MM_NCCL(c, R, R->Broadcast(r == c->commRank ? c->dMappings.p : (const void*)slot, slot, bytes, ncclChar, r, (ncclComm_t)c->comm, c->stream));
+    MM_NCCL(e, R, R->Broadcast(r == c->commRank ? mine : (const void*)slot, slot, bytes, ncclChar, r, (ncclComm_t)c->comm, stream));
   }
+  return MM_OK;
+}
+
+// the exchange of one rank: counts (all-gather), slots, `world` grouped broadcasts; returns with `stream` drained
+template <class E>
+int exchange(mm_ctx* c, E* e, Rccl* R, const void* mine, size_t nMine, hipStream_t stream) {
+  MM_HIP(e, hipSetDevice(c->device));
+  const int world = c->commWorld;
+  unsigned long long cnt = nMine;
+  unsigned long long* dC = c->dCommCounts.as<unsigned long long>();
+  MM_HIP(e, hipMemcpyAsync(dC + world, &cnt, 8, hipMemcpyHostToDevice, stream));
+  MM_NCCL(e, R, R->AllGather(dC + world, dC, 1, ncclUint64, (ncclComm_t)c->comm, stream));
+  std::vector<unsigned long long> h(world);
+  MM_HIP(e, hipMemcpyAsync(h.data(), dC, (size_t)world * 8, hipMemcpyDeviceToHost, stream));
+  MM_HIP(e, hipStreamSynchronize(stream));
+  c->gatherCounts.assign(h.begin(), h.end());
+  place(c);
+  MM_HIP(e, c->dGathered.ensure(c->nGathered * sizeof(mm_mapping) + 64));
+  MM_NCCL(e, R, R->GroupStart());
+  const int rc = issue_broadcasts(c, e, R, mine, stream);
+  MM_NCCL(e, R, R->GroupEnd());
+  if (rc != MM_OK) return rc;
+  MM_HIP(e, hipStreamSynchronize(stream));
   return MM_OK;
 }
 
@@ -148,25 +174,43 @@ int mm_comm_world(const mm_ctx* c, int* rank, int* world) {
 int mm_allgatherv_mappings(mm_ctx* c) {
   if (!c->comm || c->commCopy) { c->err = "mm_allgatherv_mappings: mm_comm_init_rank first"; return MM_ERR_STATE; }
   if (!c->mapped || !c->haveReplayTables) { c->err = "mm_allgatherv_mappings: no candidate mappings resident"; return MM_ERR_STATE; }
+  if (c->gatherThread.joinable()) { c->err = "mm_allgatherv_mappings: an overlapped exchange is in flight (mm_allgatherv_mappings_end first)"; return MM_ERR_STATE; }
+  Rccl* R = rccl_open(c->err);
+  if (!R) return MM_ERR_DEVICE;
+  c->gathered = false;
+  const int rc = exchange(c, c, R, c->dMappings.p, c->nMappings, c->stream);
+  if (rc != MM_OK) return rc;
+  c->gathered = true;
+  return MM_OK;
+}
+
+int mm_allgatherv_mappings_begin(mm_ctx* c) {
+  if (!c->comm || c->commCopy) { c->err = "mm_allgatherv_mappings_begin: mm_comm_init_rank first"; return MM_ERR_STATE; }
+  if (!c->mapped || !c->haveReplayTables) { c->err = "mm_allgatherv_mappings_begin: no candidate mappings resident"; return MM_ERR_STATE; }
+  if (c->gatherThread.joinable()) { c->err = "mm_allgatherv_mappings_begin: the previous exchange has not been ended"; return MM_ERR_STATE; }
   Rccl* R = rccl_open(c->err);
   if (!R) return MM_ERR_DEVICE;
   MM_HIP(c, hipSetDevice(c->device));
-  const int world = c->commWorld;
-  unsigned long long mine = c->nMappings;
-  unsigned long long* dC = c->dCommCounts.as<unsigned long long>();
-  MM_HIP(c, hipMemcpyAsync(dC + world, &mine, 8, hipMemcpyHostToDevice, c->stream));
-  MM_NCCL(c, R, R->AllGather(dC + world, dC, 1, ncclUint64, (ncclComm_t)c->comm, c->stream));
-  std::vector<unsigned long long> h(world);
-  MM_HIP(c, hipMemcpyAsync(h.data(), dC, (size_t)world * 8, hipMemcpyDeviceToHost, c->stream));
+  if (!c->commStream) MM_HIP(c, hipStreamCreateWithFlags(&c->commStream, hipStreamNonBlocking));
+  // snapshot: the next mm_map_fragments overwrites dMappings while the exchange is in flight
+  const size_t n = c->nMappings;
+  MM_HIP(c, c->dGatherSrc.ensure(n * sizeof(mm_mapping) + 64));
+  if (n) MM_HIP(c, hipMemcpyAsync(c->dGatherSrc.p, c->dMappings.p, n * sizeof(mm_mapping), hipMemcpyDeviceToDevice, c->stream));
   MM_HIP(c, hipStreamSynchronize(c->stream));
-  c->gatherCounts.assign(h.begin(), h.end());
-  place(c);
-  MM_HIP(c, c->dGathered.ensure(c->nGathered * sizeof(mm_mapping) + 64));
-  MM_NCCL(c, R, R->GroupStart());
-  const int rc = issue_broadcasts(c, R);
-  MM_NCCL(c, R, R->GroupEnd());
-  if (rc != MM_OK) return rc;
-  MM_HIP(c, hipStreamSynchronize(c->stream));
+  c->gathered = false;
+  c->gatherRc = MM_OK;
+  c->gatherThread = std::thread([c, R, n]() {
+    ErrSink e;
+    c->gatherRc = exchange(c, &e, R, c->dGatherSrc.p, n, c->commStream);
+    c->gatherErr = e.err;
+  });
+  return MM_OK;
+}
+
+int mm_allgatherv_mappings_end(mm_ctx* c) {
+  if (!c->gatherThread.joinable()) { c->err = "mm_allgatherv_mappings_end: no exchange in flight"; return MM_ERR_STATE; }
+  c->gatherThread.join();
+  if (c->gatherRc != MM_OK) { c->err = c->gatherErr; return c->gatherRc; }
   c->gathered = true;
   return MM_OK;
 }
@@ -192,7 +236,7 @@ int mm_allgatherv_mappings_local(mm_ctx** ctxs, int n) {
     if (!R) return MM_ERR_DEVICE;
     MM_NCCL(c0, R, R->GroupStart());
     int rc = MM_OK;
-    for (int i = 0; i < n && rc == MM_OK; i++) { (void)hipSetDevice(ctxs[i]->device); rc = issue_broadcasts(ctxs[i], R); if (rc != MM_OK) c0->err = ctxs[i]->err; }
+    for (int i = 0; i < n && rc == MM_OK; i++) { (void)hipSetDevice(ctxs[i]->device); rc = issue_broadcasts(ctxs[i], ctxs[i], R, ctxs[i]->dMappings.p, ctxs[i]->stream); if (rc != MM_OK) c0->err = ctxs[i]->err; }
     MM_NCCL(c0, R, R->GroupEnd());
     if (rc != MM_OK) return rc;
   } else {

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 #include "../../include/mashmap_hip.h"
@@ -104,6 +105,9 @@ struct mm_ctx {
   // multi-GPU exchange (mm_comm.hip)
   void* comm = nullptr; int commRank = 0, commWorld = 0; bool commCopy = false;   // commCopy: local group whose contexts share a device
   DevBuf dCommCounts, dGathered; std::vector<size_t> gatherCounts, gatherDisp; size_t nGathered = 0; bool gathered = false;
+  // overlapped exchange (mm_allgatherv_mappings_begin / _end): a snapshot of the records, a stream of its own, the host thread that
+  // runs the exchange while the caller maps the next batch
+  DevBuf dGatherSrc; hipStream_t commStream = nullptr; std::thread gatherThread; int gatherRc = 0; std::string gatherErr;
   std::vector<DevBuf*> allBufs();
   DevBuf dL2Info, dL2Cnt, dL2Off, dL2Ops, dScanTmp, dL2Tmp, dL2Wide, dL2Exact, dL2Cells, dListB, dListC, dBigList;     // L2 staging: per-candidate stream extents, op counts/offsets, located ops
   bool sketched = false, mapped = false;

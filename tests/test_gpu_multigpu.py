@@ -89,6 +89,36 @@ def test_rccl_communicator_world_of_one():
     ctx.close()
 
 
+def test_overlapped_exchange_world_of_one():
+    """mm_allgatherv_mappings_begin / _end: the exchange of batch A runs while batch B is uploaded and mapped; afterwards the gathered
+    records are A's and the resident ones are B's"""
+    from mashmap_amd import capi
+    contigs = [("c0", U.random_dna(21, 400000))]
+    A = [a for _, a, _ in U.sample_reads([c for _, c in contigs], 22, 40, 10000, 0.08)]
+    B = [a for _, a, _ in U.sample_reads([c for _, c in contigs], 23, 25, 7000, 0.05)]
+    (ctx,) = _setup([0], contigs)
+    ctx.comm_init_rank(capi.comm_unique_id(), 0, 1)
+    with pytest.raises(capi.MashmapError):
+        ctx.allgatherv_mappings_end()                                 # nothing in flight
+    for rnd in range(3):
+        ctx.reads_upload(A); ctx.map()
+        mineA = ctx.mappings()
+        ctx.allgatherv_mappings_begin()
+        with pytest.raises(capi.MashmapError):
+            ctx.allgatherv_mappings_begin()                           # one exchange in flight per context
+        with pytest.raises(capi.MashmapError):
+            ctx.allgatherv_mappings()
+        ctx.reads_upload(B); ctx.map()
+        mineB = ctx.mappings()
+        ctx.allgatherv_mappings_end()
+        got, counts = ctx.gathered(1)
+        assert len(mineA) >= 40 and len(mineB) >= 25 and mineA.tobytes() != mineB.tobytes()
+        assert list(counts) == [len(mineA)] and got.tobytes() == mineA.tobytes()
+        assert ctx.mappings().tobytes() == mineB.tobytes()
+    ctx.allgatherv_mappings_begin()                                   # a context destroyed with an exchange in flight joins it
+    ctx.close()
+
+
 def _run(td, name, refrec, qrec, extra, tag, devices, threads="4", env_extra=None):
     rf = os.path.join(td, name + ".ref.fa")
     if not os.path.exists(rf):
