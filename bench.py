@@ -413,7 +413,7 @@ def main():
         bases_step = nreads * READ_LEN * world
         value = bases_step * args.steps / dt / 1e9
         step_ms = dt / args.steps * 1e3
-        # roofline of the dominant kernel (k_sketch_fragments): algorithmic bytes per fragment = L/4 packed bases in
+        # roofline of the dominant kernel (k_sketch_fast): algorithmic bytes per fragment = L/4 packed bases in
         # + 24 B per sketch entry out, divided by its average HIP-event duration in the timed region
         sk_ms, sk_n = prof["sketch"]
         sk_avg = sk_ms / max(1, sk_n)

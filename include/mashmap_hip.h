@@ -177,7 +177,8 @@ int mm_reads_upload(mm_ctx* ctx, const char* bases, const int64_t* readOffsets, 
  * (pageable memory is staged through a bounce buffer at a fraction of it).  Optional: any host pointer works. */
 void* mm_host_alloc(size_t bytes);
 void  mm_host_free(void* p);
-/* same, from already device-resident ASCII (hipMalloc'ed by the caller, e.g. a torch tensor) */
+/* same, from already device-resident ASCII (hipMalloc'ed by the caller, e.g. a torch tensor).  The bytes are read on the context's own
+ * stream (mm_stream): work of the caller's stream that produces them must have completed before the call. */
 int mm_reads_upload_device(mm_ctx* ctx, const void* dBases, size_t nBases, const int64_t* readOffsets, size_t nReads,
                            const int32_t* readRefGroup, const int32_t* readSelfSeqId, int32_t seqCounterBase);
 size_t mm_num_fragments(const mm_ctx* ctx);

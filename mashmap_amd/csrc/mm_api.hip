@@ -8,7 +8,7 @@
 static thread_local std::string g_createErr;
 
 static const char* kKernelNames[MM_K_COUNT] = {
-  "k_pack2bit", "k_sketch_fragments", "k_sketch_fragments(hard)", "k_seed_lookup", "k_sort_points",
+  "k_pack2bit", "k_sketch_fast", "k_sketch_hard", "k_seed_lookup", "k_sort_points",
   "k_l1_sweep", "k_l2_sweep", "k_ref_hash", "k_l2_locate", "k_winnow_tiles", "k_l2_select"};
 
 std::vector<DevBuf*> mm_ctx::allBufs() {

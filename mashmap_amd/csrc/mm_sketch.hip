@@ -1,7 +1,7 @@
 // mashmap_amd/csrc/mm_sketch.hip -- a1 (pack) and a4 (query-fragment sketch) kernels.
 //
 //   k_pack2bit          makeUpperCaseAndValidDNA            src/map/include/commonFunc.hpp:97
-//   k_sketch_fragments  CommonFunc::sketchSequence          src/map/include/commonFunc.hpp:183-288
+//   k_sketch_fast / k_sketch_hard  CommonFunc::sketchSequence          src/map/include/commonFunc.hpp:183-288
 //
 // One workgroup per query fragment.  Integer-ALU bound (2 x MurmurHash3_x64_128 per base); the
 // packed input is only 0.25 B/bp (+0.125 B/bp N mask).  See DESIGN.md for the roofline terms.
@@ -58,10 +58,9 @@ __global__ void k_pack2bit(const uint8_t* __restrict__ ascii, const int64_t* __r
 #define MM_SK_PADH 256             // hard kernel
 #define MM_SK_DUPCAP 256          // repeat occurrences a fast-kernel fragment may defer (more: the hard kernel takes the fragment)
 #define MM_SK_GUARD 4             // always-empty slots on either side of the table: the ranking reads windows of that many neighbours
-struct SkTable {
+struct SkTable {                  // the hard kernel's table: every occurrence is folded in with atomics as it is hashed
   uint64_t* key; int32_t* first; int32_t* last; int32_t* sum;
-  uint32_t* counters;            // [0] distinct keys (hard kernel)  [1] overflow (table, spill, queue, duplicate list)  [2] occupied slots  [3] duplicates
-  uint32_t* dup;                 // fast kernel: deferred repeat occurrences, slot | (pos << 1 | strand bit) << 13
+  uint32_t* counters;            // [0] distinct keys  [1] overflow (load limit passed, spill area full)  [2] occupied slots
   uint64_t* occW; uint32_t* occP; // occupancy bit words and their exclusive prefix counts
   uint32_t nSlots, maxLoad, M; int sh;
 
@@ -74,44 +73,16 @@ struct SkTable {
   }
   __device__ __forceinline__ uint32_t home(uint64_t h) const { return __umulhi((uint32_t)((h << sh) >> 32), M); }
 
-  // Fast kernel.  A survivor that claims an empty slot owns it: first / last / strand sum are written with plain stores (an unclaimed
-  // slot is never read, so those arrays are not even initialised).  A repeat occurrence of a resident hash -- rare outside repeats --
-  // is put on a short list and folded in with atomics after the workgroup barrier, when every owner's stores are visible.  One
-  // returning LDS atomic per survivor instead of five: the LDS atomic pipeline, not the VALU, paced this phase at large sketches.
-  __device__ __forceinline__ void insert_fast(uint64_t h, uint32_t meta) {
-    uint32_t slot = home(h);
-    for (;;) {
-      const unsigned long long prev = atomicCAS((unsigned long long*)&key[slot], (unsigned long long)MM_HASH_MAX, (unsigned long long)h);
-      if (prev == MM_HASH_MAX) { const int pos = (int)(meta >> 1); first[slot] = pos; last[slot] = pos; sum[slot] = (meta & 1u) ? 1 : -1; return; }
-      if (prev == h) {
-        const uint32_t at = atomicAdd(&counters[3], 1u);
-        if (at < MM_SK_DUPCAP) dup[at] = slot | (meta << 13); else atomicOr(&counters[1], 1u);
-        return;
-      }
-      if (++slot >= nSlots) { atomicOr(&counters[1], 1u); return; }
-    }
-  }
-  __device__ __forceinline__ void fold_duplicates(int tid, int nthr) {
-    const uint32_t n = counters[3] < MM_SK_DUPCAP ? counters[3] : MM_SK_DUPCAP;
-    for (uint32_t i = (uint32_t)tid; i < n; i += (uint32_t)nthr) {
-      const uint32_t d = dup[i], slot = d & 0x1FFFu, meta = d >> 13;
-      const int pos = (int)(meta >> 1);
-      atomicMin(&first[slot], pos); atomicMax(&last[slot], pos); atomicAdd(&sum[slot], (meta & 1u) ? 1 : -1);
-    }
-  }
-  // COUNT: keep the number of distinct keys in counters[0] and flag the load limit as it is passed (the hard kernel, which inserts
-  // straight from the hash loop and must notice a flooded table early); the fast kernel counts occupied slots afterwards instead --
-  // one returning LDS atomic less on the dependency chain of every new key
-  template <bool COUNT>
+  // the number of distinct keys is kept in counters[0] and the load limit flagged as it is passed: the kernel inserts straight from
+  // the hash loop and must notice a flooded table early
   __device__ __forceinline__ void insert(uint64_t h, int pos, int st) {
     uint32_t slot = home(h);
     for (uint32_t probes = 1;; probes++) {
-      // a flooded table (hard kernel, cut still too high) is abandoned early; looked at every 16th probe only, the
-      // volatile generic load is slow
+      // a flooded table (cut still too high) is abandoned early; looked at every 16th probe only, the volatile generic load is slow
       if ((probes & 15u) == 0 && ((volatile uint32_t*)counters)[1]) return;
       const unsigned long long prev = atomicCAS((unsigned long long*)&key[slot], (unsigned long long)MM_HASH_MAX,
                                                 (unsigned long long)h);
-      if (COUNT && prev == MM_HASH_MAX) {
+      if (prev == MM_HASH_MAX) {
         if (atomicAdd(&counters[0], 1u) >= maxLoad) atomicOr(&counters[1], 1u);
       }
       if (prev == MM_HASH_MAX || prev == h) {
@@ -137,42 +108,30 @@ __device__ __forceinline__ uint64_t mm_window_or(uint64_t x) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_sketch_fragments<K, HARD>
-//   FAST (HARD=false): hash every k-mer on both strands, keep canonical hashes below a threshold
-//     T ~ 1.75 * s / (2n) * 2^64 in per-wave LDS queues (ballot compaction, the queue head lives in an
-//     SGPR: no atomic, no LDS round trip inside the hash loop), de-duplicate them in the ordered LDS
-//     table above (first / last position, strand sum), rank the distinct ones, emit the s smallest.
-//     If a queue or the table overflows, or fewer than s distinct survive while T < max, the fragment
-//     is appended to the hard list instead.
-//   HARD: exact for any input (tandem repeats, low complexity, N-rich): survivors go straight into
-//     a larger table (duplicates collapse) and T is bisected until s <= distinct <= load limit.
+// k_sketch_hard<K>: the fragments k_sketch_fast gave up on -- tandem repeats, low complexity, N-rich -- exact for any input.
+//   Survivors go straight from the hash loop into a larger table (duplicates collapse there, however many), and the cut T is
+//   moved until s <= distinct <= load limit: first in proportion to the distinct count the previous cut produced (the fast
+//   kernel leaves its own count in skCount[f] as the first hint), then by bisection once a cut has flooded the table.
 // ---------------------------------------------------------------------------------------------
-template <int K, bool HARD>
+#define MM_SK_HINT_OVERFLOW 0xFFFFFFFFu   // skCount[f] of a listed fragment: a queue / table / duplicate list of the fast kernel overflowed
+template <int K>
 __device__ __forceinline__ void
-mm_sketch_fragment(unsigned char* smem, const int f, const uint4* __restrict__ gTabs, const uint32_t* __restrict__ bases2, const uint32_t* __restrict__ nmask,
-                   const DFrag* __restrict__ frags, const uint32_t* __restrict__ readHasN, int s, int wantFast, int HT, int PAD,
-                   uint64_t* __restrict__ skHash, int2* __restrict__ skPos, int8_t* __restrict__ skStrand,
-                   uint32_t* __restrict__ skCount, int32_t* __restrict__ hardList, uint32_t* __restrict__ hardCount,
-                   unsigned long long* __restrict__ phaseStats = nullptr) {
-  // MM_SKETCH_STATS: shader-clock cycles thread 0 spends up to each phase boundary, summed over workgroups (diagnostics only)
-  unsigned long long tPrev = phaseStats ? __builtin_amdgcn_s_memtime() : 0ull;
-  auto mark = [&](int ph) {
-    if (phaseStats && threadIdx.x == 0) { const unsigned long long t = __builtin_amdgcn_s_memtime(); atomicAdd(&phaseStats[ph], t - tPrev); tPrev = t; }
-  };
+mm_sketch_hard(unsigned char* smem, const int f, const uint4* __restrict__ gTabs, const uint32_t* __restrict__ bases2, const uint32_t* __restrict__ nmask,
+               const DFrag* __restrict__ frags, const uint32_t* __restrict__ readHasN, int s, int wantFast, int HT, int PAD,
+               uint64_t* __restrict__ skHash, int2* __restrict__ skPos, int8_t* __restrict__ skStrand, uint32_t* __restrict__ skCount) {
   const DFrag fr = frags[f];
   const int len = fr.len;
   const int n = len - K + 1;                        // k-mer positions
   const int tid = threadIdx.x, nthr = blockDim.x;
   if (n <= 0) { if (tid == 0) skCount[f] = 0; return; }
   const bool hasN = readHasN[fr.readId] != 0;
+  const uint32_t hint = skCount[f];                 // distinct survivors under the fast kernel's cut, or MM_SK_HINT_OVERFLOW
 
   // ---- LDS carve (every offset a multiple of 16) ----
   const int nW = (len + 15) / 16 + 3;               // code words incl. 2 words of run-off for the last strip
   const int nM = (len + 31) / 32 + 2;
   const int NS = HT + PAD;                          // table slots (multiple of 64)
   const int nOcc = NS >> 6;
-  const int nWaves = nthr >> 6;
-  const uint32_t QC = HARD ? 0u : (uint32_t)HT / (uint32_t)nWaves;     // queue slots per wave
   size_t off = 0;
   using Tabs = typename MMTabsFor<K>::type;
   Tabs* tabs = (Tabs*)(smem + off); off += sizeof(Tabs);
@@ -180,12 +139,8 @@ mm_sketch_fragment(unsigned char* smem, const int f, const uint4* __restrict__ g
   for (int i = tid; i < (int)(sizeof(Tabs) / 16); i += nthr) ((uint4*)tabs)[i] = gTabs[i];   // visible after the first __syncthreads() below
   uint32_t* sW = (uint32_t*)(smem + off); off += (((size_t)nW * 4 + 15) / 16) * 16;
   uint32_t* sM = (uint32_t*)(smem + off); off += (((size_t)nM * 4 + 15) / 16) * 16;
-  uint64_t* qH = (uint64_t*)(smem + off); off += HARD ? 0 : (size_t)HT * 8;     // per-wave queues: hashes
-  uint32_t* qM = (uint32_t*)(smem + off); off += HARD ? 0 : (size_t)HT * 4;     //                  pos<<1 | (strand > 0)
   SkTable tab;
   tab.key = (uint64_t*)(smem + off) + MM_SK_GUARD; off += (size_t)(NS + 2 * MM_SK_GUARD) * 8;   // MM_SK_GUARD always-empty slots on either side: the ranking reads windows
-  uint32_t* qCnt = (uint32_t*)(smem + off); off += 64;
-  tab.dup = (uint32_t*)(smem + off); off += HARD ? 0 : (size_t)MM_SK_DUPCAP * 4;                                           // survivors queued by every wave
   tab.occW = (uint64_t*)(smem + off); off += (size_t)nOcc * 8;
   tab.first = (int32_t*)(smem + off); off += (size_t)NS * 4;
   tab.last = (int32_t*)(smem + off); off += (size_t)NS * 4;
@@ -210,30 +165,29 @@ mm_sketch_fragment(unsigned char* smem, const int f, const uint4* __restrict__ g
     }
   }
 
-  // threshold: the canonical hash is the smaller of two uniform 64-bit values, so P[h < T] ~ 2T / 2^64; the cut is placed
-  // where `want` (> s) survivors are expected.  Any T gives the exact sketch as long as >= s distinct hashes survive
-  // (checked below), so a float estimate is enough.
-  uint64_t T;
-  {
-    const uint32_t want = HARD ? (uint32_t)s * 2u : (uint32_t)wantFast;
-    T = (want >= (uint32_t)n) ? MM_HASH_MAX : (uint64_t)((float)want / (float)(2 * n) * 18446744073709551616.0f);
-  }
-  uint64_t lo = 0, hi = MM_HASH_MAX; bool hiInf = true;   // HARD bisection state (uniform across the block)
+  // Any cut gives the exact sketch as long as >= s distinct hashes survive it (checked below), so float estimates are enough.
+  // `scaled(T, D)`: the cut under which 1.6 s distinct hashes are expected when T produced D (distinct counts grow with the cut
+  // in proportion for all but pathological inputs; the loop below corrects those), at least twice T.
+  auto scaled = [&](uint64_t T, uint32_t D) -> uint64_t {
+    float r = 1.6f * (float)s / (float)(D ? D : 1u);
+    if (r < 2.0f) r = 2.0f;
+    const float t = (float)T * r;
+    return t >= 1.8e19f ? MM_HASH_MAX : (uint64_t)t;
+  };
+  uint64_t T = ((uint32_t)wantFast >= (uint32_t)n) ? MM_HASH_MAX : (uint64_t)((float)wantFast / (float)(2 * n) * 18446744073709551616.0f);   // the fast kernel's cut
+  if (hint != MM_SK_HINT_OVERFLOW && T != MM_HASH_MAX) T = scaled(T, hint);
+  uint64_t lo = 0, hi = MM_HASH_MAX; bool hiInf = true;   // bisection state (uniform across the block)
   const int nStrips = (n + 15) >> 4;
   uint32_t D = 0;
 
   for (int attempt = 0;; attempt++) {
     tab.set_cut(T, (uint32_t)HT);
-    if (HARD) for (int i = tid; i < NS; i += nthr) { tab.key[i] = MM_HASH_MAX; tab.first[i] = 0x7fffffff; tab.last[i] = -1; tab.sum[i] = 0; }
-    else for (int i = tid; i < NS; i += nthr) tab.key[i] = MM_HASH_MAX;
+    for (int i = tid; i < NS; i += nthr) { tab.key[i] = MM_HASH_MAX; tab.first[i] = 0x7fffffff; tab.last[i] = -1; tab.sum[i] = 0; }
     if (tid < MM_SK_GUARD) { tab.key[-1 - tid] = MM_HASH_MAX; tab.key[NS + tid] = MM_HASH_MAX; }
     if (tid < 4) tab.counters[tid] = 0;
     __syncthreads();
-    mark(0);                                          // staging + table init
 
-    // ---- phase 1: hash both strands of every k-mer ----
-    const uint32_t qBase = (uint32_t)(tid >> 6) * QC, qEnd = qBase + QC;
-    uint32_t qHead = qBase;                         // wave-uniform (only ballots feed it)
+    // ---- hash both strands of every k-mer ----
     const bool allPass = (T == MM_HASH_MAX);
     for (int strip = tid; strip < nStrips; strip += nthr) {
       // bit j: position strip*16+j exists and its k-mer holds no N
@@ -248,43 +202,10 @@ mm_sketch_fragment(unsigned char* smem, const int f, const uint4* __restrict__ g
         const uint64_t h = hf < hr ? hf : hr;
         bool pass = false;                          // nested ifs: the compiler keeps the three tests as exec masks
         if ((ok & (1u << j)) != 0) { if (hf != hr) { if (allPass || h < T) pass = true; } }
-        if (HARD) {
-          if (pass) tab.template insert<true>(h, pos, hf < hr ? 1 : -1);
-        } else {
-          const uint64_t m = __builtin_amdgcn_ballot_w64(pass);
-          const uint32_t idx = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, qHead));
-          if (pass && idx < qEnd) { qH[idx] = h; qM[idx] = ((uint32_t)pos << 1) | (hf < hr ? 1u : 0u); }
-          qHead += (uint32_t)__popcll(m);
-        }
+        if (pass) tab.insert(h, pos, hf < hr ? 1 : -1);
       });
     }
-    uint32_t qCount = qHead - qBase;
-    mark(1);                                          // hash loop of wave 0 (its two passes when the last wave was folded in)
-    if (!HARD) {
-      // lanes that left the strip loop early (or never entered it) hold a stale count; lane 0 owns the smallest strip
-      qCount = (uint32_t)__builtin_amdgcn_readfirstlane((int)qCount);
-      if (mm_lane() == 0) { qCnt[tid >> 6] = qCount; if (qCount > QC) atomicOr(&tab.counters[1], 1u); }
-    }
     __syncthreads();
-    if (!HARD && tab.counters[1] == 0) {
-      // all threads drain all queues: entry g of the concatenated queues goes to thread g mod nthr, so every round of inserts is full
-      // (the queues themselves are uneven: wave 0 may have hashed twice as many strips)
-      uint32_t pre[17]; pre[0] = 0;
-#pragma unroll
-      for (int w = 0; w < 16; w++) pre[w + 1] = pre[w] + (w < nWaves ? qCnt[w] : 0u);
-      const uint32_t total = pre[16];
-      for (uint32_t g = (uint32_t)tid; g < total; g += (uint32_t)nthr) {
-        uint32_t w = 0, start = 0;                  // the queue entry g falls into, and where that queue starts in the concatenation
-#pragma unroll
-        for (int x = 1; x < 16; x++) if (g >= pre[x]) { w = (uint32_t)x; start = pre[x]; }
-        const uint32_t at = w * QC + (g - start);
-        tab.insert_fast(qH[at], qM[at]);
-      }
-    }
-    mark(2);                                          // thread 0's share of the drain
-    __syncthreads();
-    mark(3);                                          // waiting for the other waves
-    if (!HARD) tab.fold_duplicates(tid, nthr);        // owners' stores are visible now
 
     // ---- occupancy words, their prefix counts (wave 0: one DPP scan per 64 words), number of distinct keys ----
     for (int base = 0; base < NS; base += nthr) {
@@ -304,45 +225,22 @@ mm_sketch_fragment(unsigned char* smem, const int f, const uint4* __restrict__ g
         if (w < nOcc) tab.occP[w] = (uint32_t)(carry + ex);
         carry += mm_wave_sum(v);
       }
-      if (tid == 0) { tab.counters[2] = (uint32_t)carry; if (!HARD && (uint32_t)carry > tab.maxLoad) tab.counters[1] = 1u; }
+      if (tid == 0) tab.counters[2] = (uint32_t)carry;
     }
     __syncthreads();
-    mark(4);                                          // occupancy words + prefix counts
 
     D = tab.counters[2];
     const bool overflow = tab.counters[1] != 0;
-    if (!HARD) {
-      if (overflow || (D < (uint32_t)s && T != MM_HASH_MAX)) {
-        if (tid == 0) { const uint32_t at = atomicAdd(hardCount, 1u); hardList[at] = f; skCount[f] = 0; }
-        return;
-      }
-      break;
-    } else {
-      if (overflow) { hi = T; hiInf = false; }
-      else if (D < (uint32_t)s && T != MM_HASH_MAX) { lo = T; }
-      else break;
-      if (hiInf) T = (T > MM_HASH_MAX / 4) ? MM_HASH_MAX : T * 4;
-      else T = lo + (hi - lo) / 2;
-      __syncthreads();
-      if (attempt > 200) break;                     // cannot happen (bisection on 64 bits); keeps the loop bounded
-    }
+    if (overflow) { hi = T; hiInf = false; }
+    else if (D < (uint32_t)s && T != MM_HASH_MAX) { lo = T; }
+    else break;
+    T = hiInf ? scaled(T, D) : lo + (hi - lo) / 2;
+    __syncthreads();
+    if (attempt > 200) break;                       // cannot happen (bisection on 64 bits); keeps the loop bounded
   }
 
   // ---- rank every key inside its cluster; emit the s smallest, ascending (commonFunc.hpp:278-286) ----
-  // Fast kernel: the occupied slots are first listed in slot order (the queue memory is free again), so that every thread ranks
-  // D / nthr keys instead of visiting NS / nthr slots of which two thirds are empty; a key's position in that list is the number of
-  // occupied slots before it.  Hard kernel: straight over the slots.
-  uint32_t* occList = qM;
-  if (!HARD) {
-    for (int slot = tid; slot < NS; slot += nthr) {
-      const uint64_t m = tab.occW[slot >> 6];
-      if ((m >> (slot & 63)) & 1ull) occList[tab.occP[slot >> 6] + (uint32_t)__popcll(m & ((1ull << (slot & 63)) - 1ull))] = (uint32_t)slot;
-    }
-    __syncthreads();
-  }
-  const int nIter = HARD ? NS : (int)D;
-  for (int it = tid; it < nIter; it += nthr) {
-    const int slot = HARD ? it : (int)occList[it];
+  for (int slot = tid; slot < NS; slot += nthr) {
     const uint64_t k = tab.key[slot];
     if (k == MM_HASH_MAX) continue;
     // the cluster around the slot: MM_SK_GUARD neighbours on either side are fetched at once (independent LDS reads, one latency);
@@ -362,11 +260,8 @@ mm_sketch_fragment(unsigned char* smem, const int f, const uint4* __restrict__ g
     }
     if (openL) { while (q > 0) { const uint64_t o = tab.key[q - 1]; if (o == MM_HASH_MAX) break; smaller += o < k ? 1u : 0u; q--; } }
     if (openR) { for (int r = slot + 1 + MM_SK_GUARD; r < NS; r++) { const uint64_t o = tab.key[r]; if (o == MM_HASH_MAX) break; smaller += o < k ? 1u : 0u; } }
-    uint32_t rank;
-    if (HARD) {
-      const uint64_t below = tab.occW[q >> 6] & ((1ull << (q & 63)) - 1ull);
-      rank = tab.occP[q >> 6] + (uint32_t)__popcll(below) + smaller;
-    } else rank = (uint32_t)(it - (slot - q)) + smaller;      // every slot of [q, slot) is occupied
+    const uint64_t below = tab.occW[q >> 6] & ((1ull << (q & 63)) - 1ull);
+    const uint32_t rank = tab.occP[q >> 6] + (uint32_t)__popcll(below) + smaller;
     if (rank < (uint32_t)s) {
       const size_t o = (size_t)f * s + rank;
       skHash[o] = k;
@@ -377,29 +272,22 @@ mm_sketch_fragment(unsigned char* smem, const int f, const uint4* __restrict__ g
     }
   }
   if (tid == 0) skCount[f] = D < (uint32_t)s ? D : (uint32_t)s;
-  mark(5);                                            // ranking + output (thread 0's share)
 }
 
-template <int K, bool HARD>
+template <int K>
 __global__ void __launch_bounds__(1024)
-k_sketch_fragments(const uint4* __restrict__ gTabs, const uint32_t* __restrict__ bases2, const uint32_t* __restrict__ nmask,
-                   const DFrag* __restrict__ frags, const uint32_t* __restrict__ readHasN,
-                   const int32_t* __restrict__ fragList, const uint32_t* __restrict__ fragListCount, int s, int wantFast, int HT, int PAD,
-                   uint64_t* __restrict__ skHash, int2* __restrict__ skPos, int8_t* __restrict__ skStrand,
-                   uint32_t* __restrict__ skCount, int32_t* __restrict__ hardList, uint32_t* __restrict__ hardCount,
-                   unsigned long long* __restrict__ phaseStats) {
+k_sketch_hard(const uint4* __restrict__ gTabs, const uint32_t* __restrict__ bases2, const uint32_t* __restrict__ nmask,
+              const DFrag* __restrict__ frags, const uint32_t* __restrict__ readHasN,
+              const int32_t* __restrict__ fragList, const uint32_t* __restrict__ fragListCount, int s, int wantFast, int HT, int PAD,
+              uint64_t* __restrict__ skHash, int2* __restrict__ skPos, int8_t* __restrict__ skStrand, uint32_t* __restrict__ skCount) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  static_assert(HARD, "the fast path is k_sketch_fast");
-  {
-    // the hard list's length stays on the device (no host round trip between the two kernels): a fixed grid walks it
-    const uint32_t nList = *fragListCount;
-    for (uint32_t i = blockIdx.x; i < nList; i += gridDim.x) {
-      mm_sketch_fragment<K, true>(smem, fragList[i], gTabs, bases2, nmask, frags, readHasN, s, wantFast, HT, PAD, skHash, skPos, skStrand, skCount, hardList, hardCount);
-      __syncthreads();                              // the next fragment reuses the LDS
-    }
+  // the hard list's length stays on the device (no host round trip between the two kernels): a fixed grid walks it
+  const uint32_t nList = *fragListCount;
+  for (uint32_t i = blockIdx.x; i < nList; i += gridDim.x) {
+    mm_sketch_hard<K>(smem, fragList[i], gTabs, bases2, nmask, frags, readHasN, s, wantFast, HT, PAD, skHash, skPos, skStrand, skCount);
+    __syncthreads();                                // the next fragment reuses the LDS
   }
 }
-
 
 // ---------------------------------------------------------------------------------------------
 // Fast sketch kernel, per fragment (one workgroup).  What paces it besides the hash loop is how many workgroups share a CU -- the
@@ -593,7 +481,8 @@ mm_sketch_fast(unsigned char* smem, const int f, const uint4* __restrict__ gTabs
   __syncthreads();
   const uint32_t D = tab.counters[2];
   if (tab.counters[1] != 0 || (D < (uint32_t)s && T != MM_HASH_MAX)) {
-    if (tid == 0) { const uint32_t at = atomicAdd(hardCount, 1u); hardList[at] = f; skCount[f] = 0; }
+    // skCount[f] carries the first hint for the hard kernel's cut: the distinct count under this one, unless something overflowed
+    if (tid == 0) { const uint32_t at = atomicAdd(hardCount, 1u); hardList[at] = f; skCount[f] = tab.counters[1] != 0 ? MM_SK_HINT_OVERFLOW : D; }
     return;
   }
   // the occupied slots in slot order (the queue memory is free again): every thread then ranks D / nthr keys instead of visiting
@@ -703,11 +592,11 @@ template <int K>
 __global__ void k_sketch_tables(typename MMTabsFor<K>::type* out) { mm_tables_init<K>(*out, (int)threadIdx.x, (int)blockDim.x); }
 
 // ---------------------------------------------------------------------------------------------
-static size_t sketch_lds_bytes(size_t tabBytes, int maxLen, int HT, int PAD, bool hard) {
+static size_t sketch_hard_lds(size_t tabBytes, int maxLen, int HT, int PAD) {      // the carve of mm_sketch_hard
   const size_t nW = (size_t)(maxLen + 15) / 16 + 3, nM = (size_t)(maxLen + 31) / 32 + 2;
   const size_t NS = (size_t)HT + PAD, nOcc = NS / 64;
-  return tabBytes + ((nW * 4 + 15) / 16) * 16 + ((nM * 4 + 15) / 16) * 16 + (hard ? 0 : (size_t)HT * 12) +
-         NS * (8 + 4 + 4 + 4) + 2 * MM_SK_GUARD * 8 + 64 + (hard ? 0 : (size_t)MM_SK_DUPCAP * 4) + nOcc * 8 + ((nOcc * 4 + 15) / 16) * 16 + 16;
+  return tabBytes + ((nW * 4 + 15) / 16) * 16 + ((nM * 4 + 15) / 16) * 16 + NS * (8 + 4 + 4 + 4) + 2 * MM_SK_GUARD * 8 + nOcc * 8 +
+         ((nOcc * 4 + 15) / 16) * 16 + 16;
 }
 static int next_pow2(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 
@@ -749,14 +638,16 @@ static FastGeom sketch_fast_geom(int K, int s, int maxLen, size_t tabBytes, bool
   g.lds = sketch_fast_lds(tabBytes, maxLen, g.HT, MM_SK_PAD, g.QC, nWaves);
   return g;
 }
-static int sketch_ht_hard(int s) { return next_pow2(s * 3 < 4096 ? 4096 : s * 3); }   // load limit 5/8 of it stays >= 2 s
+// hard kernel's table: the load limit, 5/8 of it, stays >= 2 s (the window [s, limit] the cut must hit is an octave wide); no larger
+// than that needs, because its LDS sets how many listed fragments a CU works on at once (s = 130: 4 workgroups)
+static int sketch_ht_hard(int s) { const int w = (s * 16 + 4) / 5; return next_pow2(w < 1024 ? 1024 : w); }
 
 // Parameter combinations the LDS-resident kernels cannot hold are refused when the context is created (not after the reference
 // index has been built): the sketch tables + a staged fragment of segLength bases, and the 16-bit L2 state cells of k_l2_sweep.
 int mm_check_params(const mm_params* p, std::string& err) {
   const int s = p->sketchSize, L = p->segLength;
   const size_t tabBytes = p->kmerSize >= 16 ? sizeof(MMProdTables) : sizeof(MMTables);
-  const size_t ldsFast = sketch_fast_geom(p->kmerSize, s, L, tabBytes, false).lds, ldsHard = sketch_lds_bytes(tabBytes, L, sketch_ht_hard(s), MM_SK_PADH, true);
+  const size_t ldsFast = sketch_fast_geom(p->kmerSize, s, L, tabBytes, false).lds, ldsHard = sketch_hard_lds(tabBytes, L, sketch_ht_hard(s), MM_SK_PADH);
   const size_t ldsL2 = (size_t)(s + 1) * 64 * 2;
   const size_t lim = 160 * 1024;
   if (ldsFast > lim || ldsHard > lim || ldsL2 > lim) {
@@ -779,7 +670,7 @@ static int launch_sketch_k(mm_ctx* c) {
   const FastGeom g = sketch_fast_geom(K, s, maxLen, sizeof(Tabs), MMHasSL20<K>::value);
   const int HTH = sketch_ht_hard(s);
   const int PAD = MM_SK_PAD, PADH = MM_SK_PADH;     // spill slots behind the ordered tables (no wrap-around)
-  const size_t ldsFast = g.lds, ldsHard = sketch_lds_bytes(sizeof(Tabs), maxLen, HTH, PADH, true);
+  const size_t ldsFast = g.lds, ldsHard = sketch_hard_lds(sizeof(Tabs), maxLen, HTH, PADH);
   if (ldsHard > 160 * 1024 || ldsFast > 160 * 1024) { c->err = "fragment too long / sketch too large for the LDS-resident sketch kernel"; return MM_ERR_ARG; }
   int nStrips = (maxLen - K + 1 + 15) / 16; if (nStrips < 1) nStrips = 1;
   int threadsHard = ((nStrips + 63) / 64) * 64; if (threadsHard > 1024) threadsHard = 1024;
@@ -792,7 +683,7 @@ static int launch_sketch_k(mm_ctx* c) {
   MM_HIP(c, hipMemsetAsync(c->dCounters.p, 0, 64, c->stream));
   unsigned long long* phaseStats = nullptr;
   if (getenv("MM_SKETCH_STATS")) { phaseStats = c->dCounters.as<unsigned long long>() + 24; MM_HIP(c, hipMemsetAsync(phaseStats, 0, 64, c->stream)); }
-  MM_HIP(c, hipFuncSetAttribute((const void*)k_sketch_fragments<K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsHard));
+  MM_HIP(c, hipFuncSetAttribute((const void*)k_sketch_hard<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsHard));
   {
     KernelTimer t(c, MM_K_SKETCH);
     auto launch = [&](auto kern) {
@@ -823,10 +714,10 @@ static int launch_sketch_k(mm_ctx* c) {
     // fixed grid over the device-resident hard list (its workgroups leave at once when the list is empty or short)
     KernelTimer t(c, MM_K_SKETCH_HARD);
     const int grid = nF < 1024 ? nF : 1024;
-    hipLaunchKernelGGL((k_sketch_fragments<K, true>), dim3(grid), dim3(threadsHard), ldsHard, c->stream,
+    hipLaunchKernelGGL((k_sketch_hard<K>), dim3(grid), dim3(threadsHard), ldsHard, c->stream,
                        c->dSketchTabs.as<uint4>(), c->dBases2.as<uint32_t>(), c->dNmask.as<uint32_t>(), c->dFrags.as<DFrag>(), c->dReadHasN.as<uint32_t>(),
                        c->dHardList.as<int32_t>(), c->dCounters.as<uint32_t>(), s, g.wantFast, HTH, PADH, c->dSkHash.as<uint64_t>(), c->dSkPos.as<int2>(), c->dSkStrand.as<int8_t>(),
-                       c->dSkCount.as<uint32_t>(), c->dHardList.as<int32_t>(), c->dCounters.as<uint32_t>() + 1, (unsigned long long*)nullptr);
+                       c->dSkCount.as<uint32_t>());
     MM_HIP(c, hipGetLastError());
   }
   return MM_OK;

@@ -16,7 +16,7 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_BUSY_CYCLES"):
         continue
     for row in csv.DictReader(open(fn)):
         name = row["kernel"].replace("void ", "").split("<")[0]
-        if "; true>" in row["kernel"]:                      # k_sketch_fragments<K; true> is the hard-list re-run, k_l2_sweep<true> the wide pass
+        if "; true>" in row["kernel"]:                      # k_l2_sweep<true> is the wide pass
             name += "_hard"
         if row["kernel"].endswith("<true>"):
             name += "_wide"

@@ -83,3 +83,40 @@ def test_sketch_parameter_grid(oracle, k, s, L):
     reads.append(U.with_n_runs(U.random_dna(9, L), 3, 4, 33))
     reads.append(U.tandem_repeat(8, L, 101))
     _check(oracle, reads, k, s, L)
+
+
+def test_sketch_many_hard_fragments(oracle):
+    """a batch in which a large share of the fragments leaves the fast kernel (satellites: 171 distinct k-mers; N runs; tandem repeats):
+    the device-resident hard list holds tens of thousands of fragments, every one of them must still come out exact"""
+    from mashmap_amd import capi
+    rng = np.random.default_rng(77)
+    nR, L, k, s = 60000, 5000, 19, 130
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    reads = lut[rng.integers(0, 4, size=(nR, L))]
+    kind = rng.integers(0, 4, size=nR)                                       # 0: random, 1: satellite, 2: N run, 3: tandem 2 kbp
+    for r in np.nonzero(kind == 1)[0]:
+        unit = lut[rng.integers(0, 4, size=171)]
+        reads[r] = np.tile(unit, L // 171 + 1)[:L]
+    reads[kind == 2, 500:2800] = ord("N")
+    for r in np.nonzero(kind == 3)[0][:4000]:
+        unit = lut[rng.integers(0, 4, size=50)]
+        reads[r, 1000:3000] = np.tile(unit, 40)
+    ctx = capi.Context(k=k, segLength=L, sketchSize=s)
+    flat = np.ascontiguousarray(reads.reshape(-1))
+    nF = ctx.reads_upload([flat[i * L:(i + 1) * L] for i in range(nR)])
+    assert nF == nR
+    got, cnt = ctx.sketch()
+    ctx.close()
+    sat = np.nonzero(kind == 1)[0]
+    assert len(sat) > 10000 and (cnt[sat] == s).all()                        # 171 distinct canonical hashes >= s
+    pick = np.concatenate([rng.choice(np.nonzero(kind == x)[0], 150, replace=False) for x in range(4)])
+    bad = 0
+    for f in pick:
+        e = oracle.sketch_sequence(reads[f], k, s, int(f))
+        g = [(int(x["hash"]), int(x["wpos"]), int(x["wpos_end"]), int(x["seqId"]), int(x["strand"])) for x in got[f, :cnt[f]]]
+        bad += g != e
+    assert bad == 0
+    # hashes ascending and distinct in every fragment, hard or not
+    h = got["hash"].astype(np.uint64)
+    inc = (h[:, 1:] > h[:, :-1]) | (np.arange(1, s)[None, :] >= cnt[:, None])
+    assert inc.all()
