@@ -610,10 +610,10 @@ static size_t sketch_fast_lds(size_t tabBytes, int maxLen, int HT, int PAD, int 
 }
 static FastGeom sketch_fast_geom(int K, int s, int maxLen, size_t tabBytes, bool sl20Built) {
   FastGeom g;
-  // survivors the fast kernel aims for: s + max(s/2, 4 sqrt(s)) (their count is ~Poisson, so s stays >= 4 sigma away);
-  // fewer = less queue/table work, more fragments redone by the hard kernel (1 in 2 M at s = 130).  MM_SKETCH_CUT = factor on s.
-  double margin = s * 0.5; if (margin < 4.0 * sqrt((double)s)) margin = 4.0 * sqrt((double)s);
-  g.wantFast = (int)(s + margin + 0.999);
+  // survivors the fast kernel aims for: s + 4.2 sqrt(s) (their count is ~Poisson, so s stays about 4 sigma away): fewer = less queue /
+  // table work and less LDS, more fragments redone by k_sketch_hard (measured, profiles/r02v_sketch_geometry.txt: 0.007 % of random
+  // fragments at s = 130, 0.008 % at 310, 0.02 % at 498, at 44 ns each).  MM_SKETCH_CUT = wanted survivors / s.
+  g.wantFast = (int)(s + 4.2 * sqrt((double)s) + 0.999);
   if (const char* e = getenv("MM_SKETCH_CUT")) { double cut = atof(e); if (cut < 1.05) cut = 1.05; if (cut > 2.5) cut = 2.5; g.wantFast = (int)(s * cut + 0.999); }
   int n = maxLen - K + 1; if (n < 1) n = 1;
   // positions per thread: 16, or 20 where that fills whole waves better (the workgroup's critical path is ceil(waves / 4 SIMDs) strips)
@@ -628,14 +628,33 @@ static FastGeom sketch_fast_geom(int K, int s, int maxLen, size_t tabBytes, bool
   g.threads = wavesFor(g.SL) * 64;
   if (const char* e = getenv("MM_SKETCH_THREADS")) { const int t = atoi(e); if (t >= 64 && t <= 1024 && t % 64 == 0) g.threads = t; }
   const int nWaves = g.threads / 64;
-  int HT = (int)(2.4 * g.wantFast + 63) / 64 * 64; if (HT < 256) HT = 256;
-  g.HT = HT;
-  // a wave queues the survivors of its 64 threads' strips: their expectation + 6 standard deviations
+  // a wave queues the survivors of its 64 threads' strips: their expectation + qsig standard deviations; the table has htf slots per
+  // wanted survivor (load limit = 5/8 of them).  The kernel's table phases wait on LDS latency and are hidden by the other workgroups
+  // of the CU, whose number the LDS footprint decides (allocated in 1280-byte units out of 160 KB): the roomy geometry is kept unless a
+  // tighter one lets one more workgroup in (s = 130: 7 instead of 6, s = 310: 5 instead of 4, s = 498: 4 instead of 3 -- 49 -> 42 ms per
+  // 1.6 M fragments there).  MM_SKETCH_HTF / MM_SKETCH_QSIG pin the two numbers.
   int nStrips = (n + g.SL - 1) / g.SL; if (nStrips < 1) nStrips = 1;
   const int passes = (nStrips + g.threads - 1) / g.threads;
   double ex = 64.0 * passes * g.SL * (double)g.wantFast / (double)n; if (ex > g.wantFast) ex = g.wantFast;
-  g.QC = ((int)(ex + 6.0 * sqrt(ex) + 8.0) + 3) & ~3;
-  g.lds = sketch_fast_lds(tabBytes, maxLen, g.HT, MM_SK_PAD, g.QC, nWaves);
+  auto shape = [&](double htf, double qsig) {
+    int HT = (int)(htf * g.wantFast + 63) / 64 * 64; if (HT < 256) HT = 256;
+    g.HT = HT;
+    g.QC = ((int)(ex + qsig * sqrt(ex) + 8.0) + 3) & ~3;
+    g.lds = sketch_fast_lds(tabBytes, maxLen, g.HT, MM_SK_PAD, g.QC, nWaves);
+    const size_t unit = 1280, alloc = (g.lds + unit - 1) / unit * unit;
+    return (int)((size_t)160 * 1024 / alloc);      // workgroups a CU holds
+  };
+  const char* eh = getenv("MM_SKETCH_HTF"); const char* eq = getenv("MM_SKETCH_QSIG");
+  if (eh || eq) {
+    double htf = eh ? atof(eh) : 2.4, qsig = eq ? atof(eq) : 6.0;
+    if (htf < 1.8) htf = 1.8; if (htf > 4.0) htf = 4.0; if (qsig < 3.0) qsig = 3.0; if (qsig > 8.0) qsig = 8.0;
+    (void)shape(htf, qsig);
+  } else {
+    const double cand[3][2] = {{2.4, 6.0}, {2.2, 6.0}, {2.2, 5.0}};
+    int best = 0, bestWg = shape(cand[0][0], cand[0][1]);
+    for (int i = 1; i < 3; i++) { const int wg = shape(cand[i][0], cand[i][1]); if (wg > bestWg) { bestWg = wg; best = i; } }
+    (void)shape(cand[best][0], cand[best][1]);
+  }
   return g;
 }
 // hard kernel's table: the load limit, 5/8 of it, stays >= 2 s (the window [s, limit] the cut must hit is an octave wide); no larger
