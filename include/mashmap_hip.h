@@ -173,6 +173,12 @@ int     mm_stat_replay_tables(int sketchSize, int k, float percentageIdentity, f
  */
 int mm_reads_upload(mm_ctx* ctx, const char* bases, const int64_t* readOffsets, size_t nReads,
                     const int32_t* readRefGroup, const int32_t* readSelfSeqId, int32_t seqCounterBase);
+/* Optional: start the host-to-device copy of the ASCII bytes the NEXT mm_reads_upload will name -- [bases, bases + nBytes) must be exactly
+ * the range that call reads, i.e. its `bases + readOffsets[0]` and `readOffsets[nReads] - readOffsets[0]` -- on a stream of the context's
+ * own, so that it runs under the kernels of the batch being mapped (call it between mm_reads_upload and mm_map_fragments of the current
+ * batch).  mm_reads_upload recognises the range and skips its own copy; any other upload simply discards the prefetch.  The bytes must
+ * stay unchanged until that upload returns, and should be page-locked (mm_host_alloc): a copy from pageable memory does not overlap. */
+int mm_reads_prefetch(mm_ctx* ctx, const char* bases, size_t nBytes);
 /* page-locked host memory for the `bases` of mm_reads_upload / mm_index_build: the copy to the GPU is then a single DMA at PCIe rate
  * (pageable memory is staged through a bounce buffer at a fraction of it).  Optional: any host pointer works. */
 void* mm_host_alloc(size_t bytes);

@@ -118,6 +118,7 @@ def load():
         "mm_gathered_download": (C.c_int, [vp, vp, sz]),
         "mm_gathered_device": (C.c_int, [vp, C.POINTER(vp), C.POINTER(sz)]),
         "mm_index_replicate": (C.c_int, [vp, vp]),
+        "mm_reads_prefetch": (C.c_int, [vp, vp, sz]),
         "mm_synchronize": (C.c_int, [vp]),
         "mm_stream": (vp, [vp]),
     }
@@ -140,7 +141,7 @@ EXPORTS = ["mm_abi_version", "mm_create", "mm_destroy", "mm_last_error", "mm_ind
            "mm_set_replay_tables", "mm_mappings_count", "mm_mappings_download", "mm_mappings_device", "mm_comm_unique_id",
            "mm_comm_init_rank", "mm_comm_init_local", "mm_comm_world", "mm_allgatherv_mappings", "mm_allgatherv_mappings_local",
            "mm_allgatherv_mappings_begin", "mm_allgatherv_mappings_end",
-           "mm_gathered_counts", "mm_gathered_download", "mm_gathered_device", "mm_index_replicate", "mm_stat_replay_tables", "mm_host_alloc", "mm_host_free"]
+           "mm_gathered_counts", "mm_gathered_download", "mm_gathered_device", "mm_index_replicate", "mm_stat_replay_tables", "mm_host_alloc", "mm_host_free", "mm_reads_prefetch"]
 
 
 def stat_sketch_cutoffs(sketchSize, k, hg=True):
@@ -261,6 +262,12 @@ class Context:
         ss = np.ascontiguousarray(selfSeqId, dtype=np.int32) if selfSeqId is not None else None
         self._ck(self.lib.mm_reads_upload(self.h, _ptr(buf), _ptr(offs), n, _ptr(rg), _ptr(ss), seqCounterBase), "mm_reads_upload")
         return self.num_fragments()
+
+    def reads_prefetch(self, buf):
+        """start the H2D copy of the concatenated uint8 array the next reads_upload((buf, offs)) will pass (the array must stay alive
+        and unchanged until then)"""
+        assert buf.dtype == np.uint8 and buf.flags["C_CONTIGUOUS"]
+        self._ck(self.lib.mm_reads_prefetch(self.h, _ptr(buf), buf.size), "mm_reads_prefetch")
 
     def reads_upload_device(self, dptr, nbytes, offs, refGroup=None, selfSeqId=None, seqCounterBase=0):
         offs = np.ascontiguousarray(offs, dtype=np.int64)

@@ -14,7 +14,7 @@ static const char* kKernelNames[MM_K_COUNT] = {
 std::vector<DevBuf*> mm_ctx::allBufs() {
   DeviceIndex& I = idx;
   return {&I.evKey, &I.evAux, &I.evHash, &I.contigOff, &I.opKey, &I.opAux, &I.opHash, &I.blockOff, &I.evBlock, &I.contigBlock, &I.contigLen, &I.refGroup,
-          &I.htSlots, &I.filter, &I.ptKeys, &I.keys, &I.keyOff, &I.keyFreq, &dMinHits, &dCutoffs, &dAscii, &dReadSrcOff, &dReadPackOff, &dReadLen, &dReadGroup, &dReadSelf, &dReadHasN,
+          &I.htSlots, &I.filter, &I.ptKeys, &I.keys, &I.keyOff, &I.keyFreq, &dMinHits, &dCutoffs, &dAscii, &dAsciiNext, &dReadSrcOff, &dReadPackOff, &dReadLen, &dReadGroup, &dReadSelf, &dReadHasN,
           &dBases2, &dNmask, &dFrags, &dSkHash, &dSkPos, &dSkStrand, &dSkCount, &dHardList, &dCounters, &dSketchTabs, &dQHash, &dQStrand, &dSeedVal,
           &dStats, &dPtOff, &dPts, &dL1, &dL1b, &dL1Cursors, &dL1Off, &dL2, &dL2Info, &dL2Cnt, &dL2Off, &dL2Ops, &dScanTmp, &dL2Tmp, &dL2Wide, &dL2Exact, &dL2Cells,
           &dListB, &dListC, &dBigList, &dL2First, &dL2Num, &dAccept, &dMinIsz, &dSelCnt, &dSelOff, &dSelHeap, &dFragTab, &dMappings, &dCommCounts, &dGathered};
@@ -65,6 +65,8 @@ void mm_destroy(mm_ctx* c) {
   if (c->gatherThread.joinable()) c->gatherThread.join();
   mm_comm_release(c);
   if (c->commStream) (void)hipStreamDestroy(c->commStream);
+  if (c->copyStream) { (void)hipStreamSynchronize(c->copyStream); (void)hipStreamDestroy(c->copyStream); }
+  if (c->copyDone) (void)hipEventDestroy(c->copyDone);
   for (DevBuf* b : c->allBufs()) b->release();
   if (c->evA) (void)hipEventDestroy(c->evA);
   if (c->evB) (void)hipEventDestroy(c->evB);
@@ -206,13 +208,17 @@ static int upload_reads_common(mm_ctx* c, const void* src, bool srcOnDevice, siz
   const size_t srcBase = (size_t)readOffsets[0];
   const size_t nSrc = (size_t)(readOffsets[nReads] - readOffsets[0]);
   for (size_t r = 0; r <= nReads; r++) srcOff[r] -= (int64_t)srcBase;
-  MM_HIP(c, c->dAscii.ensure(nSrc + 64));
+  // bytes mm_reads_prefetch has already sent (same host range): take that buffer and wait for its copy on the device
+  const bool prefetched = !srcOnDevice && c->prefetchValid && nSrc && c->prefetchPtr == (const void*)((const char*)src + srcBase) && c->prefetchBytes == nSrc;
+  c->prefetchValid = false;
+  if (prefetched) { std::swap(c->dAscii, c->dAsciiNext); MM_HIP(c, hipStreamWaitEvent(c->stream, c->copyDone, 0)); }
+  else MM_HIP(c, c->dAscii.ensure(nSrc + 64));
   MM_HIP(c, c->dReadSrcOff.ensure((nReads + 1) * 8)); MM_HIP(c, c->dReadPackOff.ensure((nReads + 1) * 8));
   MM_HIP(c, c->dReadLen.ensure(nReads * 4 + 4)); MM_HIP(c, c->dReadGroup.ensure(nReads * 4 + 4)); MM_HIP(c, c->dReadSelf.ensure(nReads * 4 + 4));
   MM_HIP(c, c->dReadHasN.ensure(nReads * 4 + 4));
   MM_HIP(c, c->dBases2.ensure((size_t)pk / 4 + 64)); MM_HIP(c, c->dNmask.ensure((size_t)pk / 8 + 64));
   MM_HIP(c, c->dFrags.ensure(dfr.size() * sizeof(DFrag) + 16));
-  if (nSrc) MM_HIP(c, hipMemcpyAsync(c->dAscii.p, (const char*)src + srcBase, nSrc, srcOnDevice ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+  if (nSrc && !prefetched) MM_HIP(c, hipMemcpyAsync(c->dAscii.p, (const char*)src + srcBase, nSrc, srcOnDevice ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
   MM_HIP(c, hipMemcpyAsync(c->dReadSrcOff.p, srcOff.data(), (nReads + 1) * 8, hipMemcpyHostToDevice, c->stream));
   MM_HIP(c, hipMemcpyAsync(c->dReadPackOff.p, packOff.data(), (nReads + 1) * 8, hipMemcpyHostToDevice, c->stream));
   if (nReads) MM_HIP(c, hipMemcpyAsync(c->dReadLen.p, rlen.data(), nReads * 4, hipMemcpyHostToDevice, c->stream));
@@ -239,6 +245,19 @@ int mm_reads_upload(mm_ctx* c, const char* bases, const int64_t* readOffsets, si
 int mm_reads_upload_device(mm_ctx* c, const void* dBases, size_t nBases, const int64_t* readOffsets, size_t nReads, const int32_t* g,
                            const int32_t* s, int32_t base) {
   return upload_reads_common(c, dBases, true, nBases, readOffsets, nReads, g, s, base);
+}
+
+int mm_reads_prefetch(mm_ctx* c, const char* bases, size_t nBytes) {
+  c->prefetchValid = false;
+  if (!bases || !nBytes) return MM_OK;
+  MM_HIP(c, hipSetDevice(c->device));
+  if (!c->copyStream) MM_HIP(c, hipStreamCreateWithFlags(&c->copyStream, hipStreamNonBlocking));
+  if (!c->copyDone) MM_HIP(c, hipEventCreateWithFlags(&c->copyDone, hipEventDisableTiming));
+  MM_HIP(c, c->dAsciiNext.ensure(nBytes + 64));
+  MM_HIP(c, hipMemcpyAsync(c->dAsciiNext.p, bases, nBytes, hipMemcpyHostToDevice, c->copyStream));
+  MM_HIP(c, hipEventRecord(c->copyDone, c->copyStream));
+  c->prefetchPtr = bases; c->prefetchBytes = nBytes; c->prefetchValid = true;
+  return MM_OK;
 }
 
 void* mm_host_alloc(size_t bytes) {

@@ -85,6 +85,9 @@ struct mm_ctx {
   size_t nReads = 0, nFrags = 0, nPackedBases = 0;
   int32_t seqCounterBase = 0, maxFragLen = 0;
   DevBuf dAscii, dReadSrcOff, dReadPackOff, dReadLen, dReadGroup, dReadSelf, dReadHasN;
+  // mm_reads_prefetch: the next batch's ASCII bytes, copied on a stream of their own while the current batch is mapped
+  DevBuf dAsciiNext; hipStream_t copyStream = nullptr; hipEvent_t copyDone = nullptr;
+  const void* prefetchPtr = nullptr; size_t prefetchBytes = 0; bool prefetchValid = false;
   DevBuf dBases2, dNmask, dFrags;
   std::vector<mm_fragment> hFrags;
 

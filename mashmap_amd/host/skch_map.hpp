@@ -91,6 +91,8 @@ class Map {
       return true;
     }
     void close() { { std::lock_guard<std::mutex> lk(mu); done = true; } cvEmpty.notify_all(); }
+    // the batch the next get() will return, if it is already there (only the consumer removes elements, so it stays put)
+    const Batch* peekFront() { std::lock_guard<std::mutex> lk(mu); return q.empty() ? nullptr : &q.front(); }
   };
 
  public:
@@ -181,7 +183,7 @@ class Map {
     });
     {
       Batch cur;
-      while (parsed.get(cur)) { deviceStage(cur); mapped.put(std::move(cur)); cur = Batch(); }
+      while (parsed.get(cur)) { deviceStage(cur, parsed); mapped.put(std::move(cur)); cur = Batch(); }
       mapped.close();
     }
     reader.join();
@@ -218,7 +220,22 @@ class Map {
 
   // ------------------------------------------------------------------------------------------------------------------
   // device stage: the batch's reads -> candidate mappings (batch.recs), on one GPU or sharded over all contexts
-  void deviceStage(Batch& batch) {
+  // contiguous blocks of about equal bases, one per context (a block may be empty)
+  std::vector<size_t> blocksOf(const Batch& batch) const {
+    const size_t nReads = batch.size(), nCtx = ctxs.size();
+    std::vector<size_t> cutAt(nCtx + 1, nReads);
+    cutAt[0] = 0;
+    const int64_t total = batch.in.offs[nReads];
+    size_t r = 0;
+    for (size_t i = 1; i < nCtx; i++) {
+      const int64_t want = total * (int64_t)i / (int64_t)nCtx;
+      while (r < nReads && batch.in.offs[r] < want) r++;
+      cutAt[i] = r;
+    }
+    return cutAt;
+  }
+
+  void deviceStage(Batch& batch, Channel& parsed) {
     const size_t nReads = batch.size();
     const size_t nCtx = ctxs.size();
     const bool timing = getenv("MASHMAP_HIP_TIMING") != nullptr;
@@ -229,23 +246,20 @@ class Map {
       readSelf.resize(nReads);
       for (size_t r = 0; r < nReads; r++) { auto it = refNameToId.find(batch.in.names[r]); readSelf[r] = it == refNameToId.end() ? -1 : it->second; }
     }
-    // contiguous blocks of about equal bases, one per context (a block may be empty)
-    std::vector<size_t> cutAt(nCtx + 1, nReads);
-    cutAt[0] = 0;
-    {
-      const int64_t total = batch.in.offs[nReads];
-      size_t r = 0;
-      for (size_t i = 1; i < nCtx; i++) {
-        const int64_t want = total * (int64_t)i / (int64_t)nCtx;
-        while (r < nReads && batch.in.offs[r] < want) r++;
-        cutAt[i] = r;
-      }
-    }
+    const std::vector<size_t> cutAt = blocksOf(batch);
+    // the batch the reader has already parsed behind this one: its bases travel to the GPU while this one is mapped
+    const Batch* next = parsed.peekFront();
+    std::vector<size_t> nextCut;
+    if (next && next->size()) nextCut = blocksOf(*next);
     auto runBlock = [&](size_t i) {
       mm_ctx* c = ctxs[i];
       const size_t b = cutAt[i], e = cutAt[i + 1];
       if (mm_reads_upload(c, batch.in.bases, batch.in.offs.data() + b, e - b, param.skip_prefix ? readGroup.data() + b : nullptr,
                           param.skip_self ? readSelf.data() + b : nullptr, batch.firstSeqCounter + (seqno_t)b) != MM_OK) die("mm_reads_upload", c);
+      if (!nextCut.empty()) {
+        const int64_t o0 = next->in.offs[nextCut[i]], o1 = next->in.offs[nextCut[i + 1]];
+        if (mm_reads_prefetch(c, next->in.bases + o0, (size_t)(o1 - o0)) != MM_OK) die("mm_reads_prefetch", c);
+      }
       if (mm_map_fragments(c) != MM_OK) die("mm_map_fragments", c);
     };
     if (nCtx == 1) runBlock(0);

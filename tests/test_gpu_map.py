@@ -251,3 +251,38 @@ def test_map_overlapping_windows_of_one_hash(oracle):
     ctx.map()
     assert ctx.profile_read()["l2"][1] >= 2, "no candidate reached the exact sweep"
     ctx.close(); oracle.free(h)
+
+
+def test_reads_prefetch_is_invisible(oracle):
+    """mm_reads_prefetch: the next batch's bytes copied under the current batch's kernels; the upload that names the same range uses them,
+    any other upload ignores them -- results identical either way"""
+    from mashmap_amd import capi
+    g = U.random_dna(301, 500000)
+    contigs = [("c0", g)]
+    A = [a for _, a, _ in U.sample_reads([g], 302, 60, 10000, 0.08)]
+    B = [a for _, a, _ in U.sample_reads([g], 303, 45, 7777, 0.05)]
+    def cat(reads):
+        offs = np.zeros(len(reads) + 1, dtype=np.int64); offs[1:] = np.cumsum([len(r) for r in reads])
+        return np.ascontiguousarray(np.concatenate(reads)), offs
+    bufA, offA = cat(A); bufB, offB = cat(B)
+    ctx = capi.Context(k=19, segLength=5000, sketchSize=130, flags=capi.MM_FLAG_HG_FILTER)
+    ctx.index_build([g], kmerPct=0.001); ctx.set_tables_default(0.85)
+    ctx.reads_upload((bufB, offB)); ctx.map(); wantB = ctx.mappings().tobytes(); wantB2 = ctx.results()[2].tobytes()
+    ctx.reads_upload((bufA, offA)); ctx.map(); wantA = ctx.mappings().tobytes()
+    for rnd in range(3):
+        ctx.reads_upload((bufA, offA))
+        ctx.reads_prefetch(bufB)                                            # travels while A is mapped
+        ctx.map()
+        assert ctx.mappings().tobytes() == wantA
+        ctx.reads_upload((bufB, offB)); ctx.map()                           # uses the prefetched bytes
+        assert ctx.mappings().tobytes() == wantB and ctx.results()[2].tobytes() == wantB2
+    ctx.reads_upload((bufA, offA)); ctx.reads_prefetch(bufB); ctx.map()
+    ctx.reads_upload((bufA, offA)); ctx.map()                               # a different range: the prefetch is dropped
+    assert ctx.mappings().tobytes() == wantA
+    half = bufB[:int(offB[20])]                                          # a view: same address, fewer bytes
+    ctx.reads_prefetch(bufB)
+    ctx.reads_upload((half, offB[:21].copy())); ctx.map()                   # same start, different length: dropped as well
+    ctx.reads_upload((bufB, offB)); ctx.map()
+    assert ctx.mappings().tobytes() == wantB
+    ctx.close()
+    assert len(wantA) > 48 * 100 and len(wantB) > 48 * 40
