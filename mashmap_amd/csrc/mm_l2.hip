@@ -145,11 +145,16 @@ k_scan_add(int64_t n, int64_t* __restrict__ out, const int64_t* __restrict__ til
 
 // ---------------------------------------------------------------------------------------------
 // k_l2_locate: one wave per candidate (4 per workgroup, no workgroup barrier).  LDS per wave: the fragment's query sketch
-// (hash + strand) and a 256-bucket table over [0, qmax] that turns the lower_bound of a hash into one table read plus a scan of
-// ~0.5 entries (the hashes of a sketch are uniform, so equal-width buckets are balanced).
+// (hash + strand) and a table of NB >= s equal-width buckets over [0, qmax] that turns the lower_bound of a hash into one table read
+// plus a walk of ~1 entry (the hashes of a sketch are uniform, so equal-width buckets are balanced).
+// LDS of one wave of k_l2_locate: sketch + sentinel (8 B each), their high words (4 B), NB + 1 bucket starts (2 B), strands (1 B)
+__host__ __device__ static inline size_t mm_locate_lds_per_wave(int s, int NB) {
+  const size_t b = (size_t)(s + 1) * 8 + (size_t)(s + 2) / 2 * 8 + (size_t)(NB + 4) * 2 + (((size_t)s + 15) & ~(size_t)15);
+  return (b + 15) & ~(size_t)15;
+}
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-k_l2_locate(int nCand, int s, const mm_l1_candidate* __restrict__ l1, const mm_frag_stats* __restrict__ stats,
+k_l2_locate(int nCand, int s, int NB, const mm_l1_candidate* __restrict__ l1, const mm_frag_stats* __restrict__ stats,
             const uint64_t* __restrict__ qHash, const int8_t* __restrict__ qStrand,
             const uint64_t* __restrict__ skHash, const int8_t* __restrict__ skStrand,
             const uint32_t* __restrict__ evKey, const uint32_t* __restrict__ evAux, const uint64_t* __restrict__ evHash,
@@ -158,11 +163,11 @@ k_l2_locate(int nCand, int s, const mm_l1_candidate* __restrict__ l1, const mm_f
             const int32_t* __restrict__ opCnt, uint32_t* __restrict__ ops, unsigned long long* __restrict__ counters /* [6] |= 4: gap too wide */) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const size_t perWave = (size_t)s * 8 + 260 * 2 + (((size_t)s + 15) & ~(size_t)15);
-  unsigned char* base = smem + (size_t)wave * ((perWave + 15) & ~(size_t)15);
-  uint64_t* q = (uint64_t*)base;
-  uint16_t* bkt = (uint16_t*)(base + (size_t)s * 8);               // bkt[b] = #query hashes whose bucket is < b, b = 0..256
-  int8_t* qs = (int8_t*)(base + (size_t)s * 8 + 260 * 2);
+  unsigned char* base = smem + (size_t)wave * mm_locate_lds_per_wave(s, NB);
+  uint64_t* q = (uint64_t*)base;                                   // the query sketch + one sentinel
+  uint32_t* qhi = (uint32_t*)(base + (size_t)(s + 1) * 8);         // its high words (the bucket walk compares these)
+  uint16_t* bkt = (uint16_t*)(base + (size_t)(s + 1) * 8 + (size_t)(s + 2) / 2 * 8);   // bkt[b] = #query hashes whose bucket is < b, b = 0..NB
+  int8_t* qs = (int8_t*)(base + (size_t)(s + 1) * 8 + (size_t)(s + 2) / 2 * 8 + (size_t)(NB + 4) * 2);
   for (int c = blockIdx.x * 4 + wave; c < nCand; c += gridDim.x * 4) {
     const mm_l1_candidate cand = l1[c];
     const int f = cand.frag;
@@ -175,21 +180,22 @@ k_l2_locate(int nCand, int s, const mm_l1_candidate* __restrict__ l1, const mm_f
     const bool raw = in.sketch < 0;
     const uint64_t* srcH = (raw ? skHash : qHash) + (size_t)f * s;
     const int8_t* srcS = (raw ? skStrand : qStrand) + (size_t)f * s;
-    for (int p = lane; p < S; p += 64) { q[p] = srcH[p]; qs[p] = srcS[p]; }
+    for (int p = lane; p < S; p += 64) { const uint64_t h = srcH[p]; q[p] = h; qhi[p] = (uint32_t)(h >> 32); qs[p] = srcS[p]; }
+    if (lane == 0) { q[S] = ~0ull; qhi[S] = ~0u; }                 // sentinel: a walk for h <= qmax needs no end test
     __threadfence_block();
     const uint64_t qmax = q[S - 1];
-    // bucket(h): monotone map of [0, qmax] onto 0..255: the top 24 significant bits times M >> 32, M <= 2^32 * 256 / (top24(qmax) + 1)
-    // (any smaller M stays monotone and below 256; the float estimate is shaded down)
+    // bucket(h): monotone map of [0, qmax] onto 0..NB-1: the top 24 significant bits times M >> 32, M <= 2^32 * NB / (top24(qmax) + 1)
+    // (any smaller M stays monotone and below NB; the float estimate is shaded down)
     const int sh = qmax ? (int)__builtin_clzll(qmax) : 63;
-    const uint32_t bM = (uint32_t)(256.0f * 4294967296.0f / ((float)(uint32_t)((qmax << sh) >> 40) + 1.0f) * 0.99999f);
+    const uint32_t bM = (uint32_t)((float)NB * 4294967296.0f / ((float)(uint32_t)((qmax << sh) >> 40) + 1.0f) * 0.99999f);
     auto bucket = [&](uint64_t h) -> int { return (int)__umulhi((uint32_t)((h << sh) >> 40), bM); };
     // bkt[b] = #{p : bucket(q[p]) < b}.  q is sorted, so entry p owns the buckets (bucket(q[p-1]), bucket(q[p])] and the
-    // sentinel p = S owns the rest up to 256: a scatter of ~2 stores per lane instead of 257 binary searches
+    // sentinel p = S owns the rest up to NB: a scatter of ~NB/S stores per lane instead of NB + 1 binary searches
     for (int p0 = 0; p0 <= S; p0 += 64) {
       const int p = p0 + lane;
       if (p <= S) {
         const int from = p == 0 ? 0 : bucket(q[p - 1]) + 1;
-        const int to = p == S ? 256 : bucket(q[p]);
+        const int to = p == S ? NB : bucket(q[p]);
         for (int b = from; b <= to; b++) bkt[b] = (uint16_t)p;
       }
     }
@@ -197,9 +203,12 @@ k_l2_locate(int nCand, int s, const mm_l1_candidate* __restrict__ l1, const mm_f
     auto locate = [&](uint64_t h) -> uint32_t {
       if (h > qmax) return 0u;
       const int b = bucket(h);
-      int lo = bkt[b]; const int hi = bkt[b + 1];
-      while (lo < hi && q[lo] < h) lo++;
-      // lo == lower_bound(q, h): everything in earlier buckets is smaller, everything in later ones larger
+      // lower_bound(q, h): everything in earlier buckets is smaller and h <= qmax < sentinel, so the walk from the bucket's first entry
+      // ends by itself; it runs on the 32-bit high words (32-bit LDS reads and compares) and only a tie there looks at all 64 bits
+      int lo = bkt[b];
+      const uint32_t hh = (uint32_t)(h >> 32);
+      while (qhi[lo] < hh) lo++;
+      if (qhi[lo] == hh) { while (q[lo] < h) lo++; }
       return (uint32_t)(lo + 1) | (q[lo] == h ? 0x800u : 0u) | ((uint32_t)((int)qs[lo] + 1) << 12);   // bits 12..13: query strand + 1
     };
     // the slide ends with the last insert at or before rangeEnd (evictions behind it are never reached, :1340)
@@ -625,11 +634,14 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt) {
     int rc = mm_scan_i32_to_i64(c, nC, c->dL2Cnt.as<int32_t>(), c->dL2Off.as<int64_t>(), &totalOps);
     if (rc != MM_OK) return rc;
     MM_HIP(c, c->dL2Ops.ensure((size_t)totalOps * 4 + 256));
-    const size_t perWave = (((size_t)s * 8 + 260 * 2 + (((size_t)s + 15) & ~(size_t)15)) + 15) & ~(size_t)15;
-    const size_t ldsLoc = perWave * 4;
+    // buckets of the query-sketch search: at least one per sketch entry (more buckets cost more to fill per candidate than the shorter
+    // walks save: profiles/r02z_locate_buckets.txt)
+    int NB = 256; while (NB < s) NB <<= 1;
+    if (const char* e = getenv("MM_L2_BUCKETS")) { const int v = atoi(e); if (v >= 64 && v <= 16384 && (v & (v - 1)) == 0) NB = v; }
+    const size_t ldsLoc = mm_locate_lds_per_wave(s, NB) * 4;
     MM_HIP(c, hipFuncSetAttribute((const void*)k_l2_locate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsLoc));
     int blocks = (nC + 3) / 4; if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL(k_l2_locate, dim3(blocks), dim3(256), ldsLoc, c->stream, nC, s, c->dL1.as<mm_l1_candidate>(),
+    hipLaunchKernelGGL(k_l2_locate, dim3(blocks), dim3(256), ldsLoc, c->stream, nC, s, NB, c->dL1.as<mm_l1_candidate>(),
                        c->dStats.as<mm_frag_stats>(), c->dQHash.as<uint64_t>(), c->dQStrand.as<int8_t>(), c->dSkHash.as<uint64_t>(), c->dSkStrand.as<int8_t>(),
                        I.evKey.as<uint32_t>(),
                        I.evAux.as<uint32_t>(), I.evHash.as<uint64_t>(), I.opKey.as<uint32_t>(), I.opAux.as<uint32_t>(), I.opHash.as<uint64_t>(),
