@@ -22,12 +22,15 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <iostream>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <unordered_set>
@@ -46,12 +49,69 @@ struct ParsedBatch {
 
 namespace detail {
 
-inline void run_parallel(unsigned threads, const std::function<void(unsigned)>& fn) {
+}  // namespace detail
+
+// Persistent workers for the host stages (a batch is parsed / post-processed in a handful of short parallel sections; starting
+// a hundred std::threads for each of them costs milliseconds per batch).  run(n, fn) calls fn(0) .. fn(n - 1), each exactly once, on the
+// workers and the calling thread, and returns when all have finished.  One run at a time per pool.
+class WorkerPool {
+ public:
+  explicit WorkerPool(unsigned threads) { for (unsigned i = 1; i < threads; i++) th_.emplace_back([this] { loop(); }); }
+  ~WorkerPool() {
+    { std::lock_guard<std::mutex> lk(mu_); stop_ = true; gen_++; }
+    cv_.notify_all();
+    for (auto& t : th_) t.join();
+  }
+  WorkerPool(const WorkerPool&) = delete;
+  WorkerPool& operator=(const WorkerPool&) = delete;
+  unsigned size() const { return (unsigned)th_.size() + 1; }
+  void run(unsigned n, const std::function<void(unsigned)>& fn) {
+    if (n == 0) return;
+    if (n == 1 || th_.empty()) { for (unsigned t = 0; t < n; t++) fn(t); return; }
+    auto job = std::make_shared<Job>();
+    job->fn = &fn; job->n = n; job->left.store(n);
+    { std::lock_guard<std::mutex> lk(mu_); cur_ = job; gen_++; }
+    cv_.notify_all();
+    help(*job);
+    std::unique_lock<std::mutex> lk(mu_);
+    done_.wait(lk, [&] { return job->left.load() == 0; });
+  }
+
+ private:
+  // every run has its own task counter: a worker that wakes up late holds the finished job and finds nothing left in it
+  struct Job { const std::function<void(unsigned)>* fn = nullptr; unsigned n = 0; std::atomic<unsigned> next{0}, left{0}; };
+  std::vector<std::thread> th_;
+  std::mutex mu_; std::condition_variable cv_, done_;
+  std::shared_ptr<Job> cur_; uint64_t gen_ = 0; bool stop_ = false;
+  void help(Job& j) {
+    for (;;) {
+      const unsigned t = j.next.fetch_add(1);
+      if (t >= j.n) return;
+      (*j.fn)(t);
+      if (j.left.fetch_sub(1) == 1) { std::lock_guard<std::mutex> lk(mu_); done_.notify_all(); }
+    }
+  }
+  void loop() {
+    uint64_t seen = 0;
+    for (;;) {
+      std::shared_ptr<Job> j;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return gen_ != seen; });
+        seen = gen_;
+        if (stop_) return;
+        j = cur_;
+      }
+      if (j) help(*j);
+    }
+  }
+};
+
+namespace detail {
+
+inline void run_parallel(WorkerPool& pool, unsigned threads, const std::function<void(unsigned)>& fn) {
   if (threads <= 1) { fn(0); return; }
-  std::vector<std::thread> th;
-  for (unsigned t = 1; t < threads; t++) th.emplace_back(fn, t);
-  fn(0);
-  for (auto& x : th) x.join();
+  pool.run(threads, fn);
 }
 
 // start of the next line at or after p (one past the next '\n'), or e
@@ -111,7 +171,7 @@ class MmapSource : public RawSource {
 
 // gzip / BGZF: inflated into an internal buffer; the tail behind the last record boundary is carried into the next window
 class GzSource : public RawSource {
-  std::string path_; size_t window_; unsigned threads_;
+  std::string path_; size_t window_; unsigned threads_; WorkerPool* pool_;
   FILE* raw_ = nullptr; bool bgzf_ = false; gzFile gz_ = nullptr;
   std::vector<char> buf_; size_t carry_ = 0; bool eof_ = false;
   std::vector<unsigned char> comp_;
@@ -145,7 +205,7 @@ class GzSource : public RawSource {
       }
       const size_t base = buf_.size(); buf_.resize(base + uTot);
       std::atomic<size_t> nextB(0); std::atomic<int> bad(0);
-      run_parallel(std::max(1u, std::min<unsigned>(threads_, (unsigned)blks.size())), [&](unsigned) {
+      run_parallel(*pool_, std::max(1u, std::min<unsigned>(threads_, (unsigned)blks.size())), [&](unsigned) {
         z_stream zs;
         for (size_t i = nextB.fetch_add(1); i < blks.size(); i = nextB.fetch_add(1)) {
           if (!blks[i].uLen) continue;
@@ -164,7 +224,7 @@ class GzSource : public RawSource {
   }
 
  public:
-  GzSource(const std::string& path, size_t window, unsigned threads) : path_(path), window_(window), threads_(threads) {
+  GzSource(const std::string& path, size_t window, unsigned threads, WorkerPool* pool) : path_(path), window_(window), threads_(threads), pool_(pool) {
     raw_ = fopen(path.c_str(), "rb");
     if (!raw_) return;
     unsigned char h[18] = {0};
@@ -209,7 +269,7 @@ class BatchReader {
   BatchReader(std::vector<std::string> files, size_t windowBytes, unsigned threads, std::unordered_set<std::string> keepSeq = {},
               std::string keepPrefix = "", Alloc a = nullptr, Free f = nullptr)
       : files_(std::move(files)), window_(std::max<size_t>(windowBytes, 1u << 16)), threads_(std::max(1u, threads)), keepSeq_(std::move(keepSeq)),
-        keepPrefix_(std::move(keepPrefix)), alloc_(a ? a : [](size_t n) { return (char*)malloc(n); }), free_(f ? f : [](char* p) { free(p); }) {}
+        keepPrefix_(std::move(keepPrefix)), pool_(std::max(1u, threads)), alloc_(a ? a : [](size_t n) { return (char*)malloc(n); }), free_(f ? f : [](char* p) { free(p); }) {}
   ~BatchReader() { delete src_; }
 
   // index of the file the batch returned last came from, and whether it was that file's last batch
@@ -237,6 +297,7 @@ class BatchReader {
  private:
   std::vector<std::string> files_; size_t window_; unsigned threads_;
   std::unordered_set<std::string> keepSeq_; std::string keepPrefix_;
+  WorkerPool pool_;
   Alloc alloc_; Free free_;
   detail::RawSource* src_ = nullptr; size_t nextFile_ = 0, curFile_ = 0; bool fasta_ = true, firstWindow_ = true, fileDone_ = false;
 
@@ -244,7 +305,7 @@ class BatchReader {
     bool gz = false;
     { FILE* f = fopen(path.c_str(), "rb"); if (f) { unsigned char m[2] = {0, 0}; if (fread(m, 1, 2, f) == 2) gz = m[0] == 31 && m[1] == 139; fclose(f); } }
     bool ok = false;
-    if (gz) { auto* s = new detail::GzSource(path, window_, threads_); ok = s->ok(); src_ = s; }
+    if (gz) { auto* s = new detail::GzSource(path, window_, threads_, &pool_); ok = s->ok(); src_ = s; }
     else { auto* s = new detail::MmapSource(path, window_); ok = s->ok(); src_ = s; }
     const char c = ok ? src_->first_byte() : 0;
     if (!ok || (c != '>' && c != '@')) {
@@ -262,10 +323,10 @@ class BatchReader {
     std::vector<const char*> cut(T + 1, e);
     cut[0] = b;
     const bool fasta = fasta_;
-    detail::run_parallel(T, [&](unsigned t) { if (t) cut[t] = detail::next_record(b, b + n / T * t, e, fasta); });   // may scan a long record: in parallel
+    detail::run_parallel(pool_, T, [&](unsigned t) { if (t) cut[t] = detail::next_record(b, b + n / T * t, e, fasta); });   // may scan a long record: in parallel
     for (unsigned t = 1; t <= T; t++) if (cut[t] < cut[t - 1]) cut[t] = cut[t - 1];
     std::vector<std::vector<Rec>> recs(T);
-    detail::run_parallel(T, [&](unsigned t) {
+    detail::run_parallel(pool_, T, [&](unsigned t) {
       const char* q = cut[t]; const char* pe = cut[t + 1];
       auto& R = recs[t];
       while (q < pe) {
@@ -298,7 +359,7 @@ class BatchReader {
     const size_t base = out.names.size();
     out.names.resize(base + nRec); out.offs.resize(base + nRec + 1);
     // names + filters (per thread), then lengths -> offsets
-    detail::run_parallel(T, [&](unsigned t) {
+    detail::run_parallel(pool_, T, [&](unsigned t) {
       for (size_t i = 0; i < recs[t].size(); i++) {
         Rec& r = recs[t][i];
         const char* hb = r.hdr + 1; const char* he = r.body > r.hdr && r.body[-1] == '\n' ? r.body - 1 : r.body;   // header line without its '\n'
@@ -321,7 +382,7 @@ class BatchReader {
     }
     // sequence bytes, line breaks dropped
     char* dst0 = out.bases;
-    detail::run_parallel(T, [&](unsigned t) {
+    detail::run_parallel(pool_, T, [&](unsigned t) {
       for (size_t i = 0; i < recs[t].size(); i++) {
         const Rec& r = recs[t][i];
         if (!r.keep || !r.seqLen) continue;

@@ -31,6 +31,7 @@
 #include <fstream>
 #include <functional>
 #include <iostream>
+#include <memory>
 #include <mutex>
 #include <numeric>
 #include <set>
@@ -66,6 +67,7 @@ class Map {
   std::vector<mm_ctx*> ctxs;                     // one per GPU (Sketch::contexts)
   mm_ctx* ctx;                                   // ctxs[0]
   MapPost post;                                  // everything downstream of the device integers (skch_map_post.hpp)
+  std::unique_ptr<mmhost::WorkerPool> postPool;  // the post stage's threads
   struct Batch {
     mmhost::ParsedBatch in;                      // names, offsets, bases (page-locked buffer, recycled through bufferPool)
     seqno_t firstSeqCounter = 0;
@@ -314,10 +316,8 @@ class Map {
           if (reportNow && !perRead[r].empty()) { os.str(std::string()); post.reportReadMappings(perRead[r], batch.in.names[r], os); text[r] = os.str(); }
         }
     };
-    std::vector<std::thread> pool;
-    for (unsigned t = 1; t < nThreads; t++) pool.emplace_back(work);
-    work();
-    for (auto& th : pool) th.join();
+    if (!postPool || postPool->size() != nThreads) postPool.reset(new mmhost::WorkerPool(nThreads));   // persistent: a batch is milliseconds of work
+    postPool->run(nThreads, [&](unsigned) { work(); });
     const auto t1 = skch::Time::now();
     for (size_t r = 0; r < nReads; r++) {                  // mapModuleHandleOutput (:724-752), input order
       if (!perRead[r].empty()) totalReadsMapped++;
