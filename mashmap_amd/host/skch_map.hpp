@@ -21,6 +21,8 @@
 // all-gatherv (mm_allgatherv_mappings_local) -- rank-major == input order -- before the CPU filters, the one-to-one filter
 // (:358-405) included, see them.
 #pragma once
+#include <malloc.h>
+
 #include <algorithm>
 #include <atomic>
 #include <cmath>
@@ -142,14 +144,26 @@ class Map {
     const char* be = getenv("MASHMAP_HIP_BATCH_MBP");
     const size_t batchBases = (size_t)((be ? atof(be) : 512.0) * 1e6);
     Channel parsed(2), mapped(2);
+    if (!getenv("MASHMAP_HIP_NO_MALLOPT")) {
+      // every batch allocates and frees a few megabyte-sized vectors (records, per-read results, PAF text) from three stages at once:
+      // keep them on the heap instead of mmap/munmap per batch (each unmap interrupts every thread of the process), and keep the heap
+      mallopt(M_MMAP_THRESHOLD, 32 << 20); mallopt(M_TRIM_THRESHOLD, 1 << 30); mallopt(M_TOP_PAD, 256 << 20);
+    }
     std::thread reader([&]() {
-      // multi-threaded ingest (seq_parse.hpp): a window of the file per batch, parsed by param.threads workers straight into a
-      // page-locked buffer
-      // (memchr + memcpy saturate the memory system with a few dozen threads; more only adds thread start-up per window)
+      // multi-threaded ingest (seq_parse.hpp): a window of the file per batch, parsed straight into a page-locked buffer.  8 workers:
+      // memchr + memcpy at that width keep up with the device stage, and more of them page-faulting through the same file mapping next
+      // to the post stage's threads stall each other for tens of milliseconds at a time (profiles/r03d_e2e_thread_sweep.txt: 32 reader
+      // threads 18 Gbp/s end to end, 8 threads 24-26)
       const char* rte = getenv("MASHMAP_HIP_READER_THREADS");
-      const unsigned readerThreads = rte ? (unsigned)std::max(1, atoi(rte)) : (unsigned)std::min(32, std::max(1, param.threads));
+      const unsigned readerThreads = rte ? (unsigned)std::max(1, atoi(rte)) : (unsigned)std::min(8, std::max(1, param.threads));
       mmhost::BatchReader rd(param.querySequences, batchBases, readerThreads, {}, "",
-                             [](size_t n) { return (char*)mm_host_alloc(n); }, [](char* p) { mm_host_free(p); });
+                             [](size_t n) {                       // only when the pool (skch_sketch.hpp) has run dry
+                               const auto t0 = skch::Time::now();
+                               char* p = (char*)mm_host_alloc(n);
+                               if (getenv("MASHMAP_HIP_TIMING")) std::cerr << "[mashmap_hip::timing] reader: page-locked " << n << " bytes itself in "
+                                                                           << std::chrono::duration<double>(skch::Time::now() - t0).count() << " s" << std::endl;
+                               return p;
+                             }, [](char* p) { mm_host_free(p); });
       while (true) {
         Batch batch;
         { auto b = HostBufferPool::instance().take(0); batch.in.bases = b.first; batch.in.cap = b.second; }

@@ -84,7 +84,7 @@ class Sketch {
       // page-locked buffers for the query batches skch::Map will read: locked in the background while the index is built
       const char* be = getenv("MASHMAP_HIP_BATCH_MBP");
       const size_t batchBytes = (size_t)((be ? atof(be) : 512.0) * 1e6);
-      HostBufferPool::instance().prefetch(6, batchBytes + batchBytes / 8 + (1u << 20));
+      HostBufferPool::instance().prefetch(8, batchBytes + batchBytes / 8 + (1u << 20));   // reader 1 + two queues of 2 + device 1 + post 1, one spare
     }
     if (!p.saveIndexFilename.empty()) mm_set_option(ctx_, MM_OPT_KEEP_FULL_INDEX, 1);
     this->build();
@@ -248,7 +248,7 @@ class Sketch {
     std::vector<mmhost::ParsedBatch> parts;
     const bool needBases = param.loadIndexFilename.empty();
     for (const auto& fileName : param.refSequences) {
-      mmhost::BatchReader rd({fileName}, (size_t)-1 >> 1, (unsigned)std::max(1, param.threads), allowed, param.target_prefix,
+      mmhost::BatchReader rd({fileName}, (size_t)-1 >> 1, (unsigned)std::min(16, std::max(1, param.threads)), allowed, param.target_prefix,   // see skch_map.hpp: more workers than this get in each other's way
                              [](size_t n) { return (char*)mm_host_alloc(n); }, [](char* p) { mm_host_free(p); });
       mmhost::ParsedBatch b;
       while (rd.next(b)) {
