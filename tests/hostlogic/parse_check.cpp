@@ -4,7 +4,27 @@
 #include <cstdlib>
 #include "../../mashmap_amd/host/seq_parse.hpp"
 
+// "pool": mmhost::WorkerPool under stress -- thousands of short runs of varying width, every index of every run exactly once, runs
+// never leaking into each other; prints "pool ok <runs> <tasks>" or the first violation
+static int pool_check(unsigned threads, int runs) {
+  mmhost::WorkerPool pool(threads);
+  std::vector<std::atomic<int>> hits(4096);
+  unsigned long long total = 0;
+  for (int r = 0; r < runs; r++) {
+    const unsigned n = (unsigned)(1 + (r * 2654435761u >> 7) % (r % 5 == 0 ? 4096 : 3 * threads));
+    for (unsigned i = 0; i < n; i++) hits[i].store(0);
+    std::atomic<unsigned long long> sum(0);
+    pool.run(n, [&](unsigned t) { hits[t].fetch_add(1); sum.fetch_add((unsigned long long)t + 1); if ((t & 63) == 0) std::this_thread::yield(); });
+    for (unsigned i = 0; i < n; i++) if (hits[i].load() != 1) { printf("pool FAIL run %d index %u executed %d times\n", r, i, hits[i].load()); return 1; }
+    if (sum.load() != (unsigned long long)n * (n + 1) / 2) { printf("pool FAIL run %d sum\n", r); return 1; }
+    total += n;
+  }
+  printf("pool ok %d %llu\n", runs, total);
+  return 0;
+}
+
 int main(int argc, char** argv) {
+  if (argc == 4 && std::string(argv[1]) == "pool") return pool_check((unsigned)atoi(argv[2]), atoi(argv[3]));
   if (argc < 4) return 2;
   const size_t window = (size_t)atol(argv[1]); const unsigned threads = (unsigned)atoi(argv[2]);
   std::string prefix; int a = 3;

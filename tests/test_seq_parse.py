@@ -109,3 +109,10 @@ def test_parallel_reader_matches_the_serial_semantics(exe, tmp_path, kind):
         open(path + ".nonl", "wb").write(raw.rstrip(b"\n"))
         p = subprocess.run([exe, "90000", "3", path + ".nonl", path], capture_output=True, text=True)
         assert p.stdout.splitlines() == want + want
+
+
+@pytest.mark.parametrize("threads", [1, 2, 7, 32])
+def test_worker_pool_runs_every_task_exactly_once(exe, threads):
+    """mmhost::WorkerPool (the persistent workers of the reader and the post stage): 4000 back-to-back runs of 1 .. 4096 tasks"""
+    out = subprocess.run([exe, "pool", str(threads), "4000"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.startswith("pool ok 4000"), out.stdout + out.stderr
