@@ -154,7 +154,7 @@ __host__ __device__ static inline size_t mm_locate_lds_per_wave(int s, int NB) {
 }
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-k_l2_locate(int nCand, int s, int NB, const mm_l1_candidate* __restrict__ l1, const mm_frag_stats* __restrict__ stats,
+k_l2_locate(int cBase, int nCand, int64_t opsBase, int s, int NB, const mm_l1_candidate* __restrict__ l1, const mm_frag_stats* __restrict__ stats,
             const uint64_t* __restrict__ qHash, const int8_t* __restrict__ qStrand,
             const uint64_t* __restrict__ skHash, const int8_t* __restrict__ skStrand,
             const uint32_t* __restrict__ evKey, const uint32_t* __restrict__ evAux, const uint64_t* __restrict__ evHash,
@@ -168,12 +168,13 @@ k_l2_locate(int nCand, int s, int NB, const mm_l1_candidate* __restrict__ l1, co
   uint32_t* qhi = (uint32_t*)(base + (size_t)(s + 1) * 8);         // its high words (the bucket walk compares these)
   uint16_t* bkt = (uint16_t*)(base + (size_t)(s + 1) * 8 + (size_t)(s + 2) / 2 * 8);   // bkt[b] = #query hashes whose bucket is < b, b = 0..NB
   int8_t* qs = (int8_t*)(base + (size_t)(s + 1) * 8 + (size_t)(s + 2) / 2 * 8 + (size_t)(NB + 4) * 2);
-  for (int c = blockIdx.x * 4 + wave; c < nCand; c += gridDim.x * 4) {
+  for (int ci = blockIdx.x * 4 + wave; ci < nCand; ci += gridDim.x * 4) {
+    const int c = cBase + ci;                                      // this launch covers the candidates [cBase, cBase + nCand): their streams start at ops[opOff - opsBase]
     const mm_l1_candidate cand = l1[c];
     const int f = cand.frag;
     const L2Info in = info[c];
     const int S = in.sketch & 0x7fffffff;
-    uint32_t* out = ops + opOff[c];
+    uint32_t* out = ops + (opOff[c] - opsBase);
     const int cap = opCnt[c];
     __threadfence_block();                                         // previous candidate's LDS reads are done
     // a fragment that lost no frequent seed has no copy in qHash/qStrand: its sketch is the raw one (k_lookup_l1)
@@ -314,7 +315,7 @@ template <int B> __device__ __forceinline__ int mm_bit_mask(uint32_t x) { int m;
 // ---------------------------------------------------------------------------------------------
 template <bool WIDE>
 __global__ void __launch_bounds__(64)
-k_l2_sweep(int nCand, const int32_t* __restrict__ candList, int segLength, const mm_l1_candidate* __restrict__ l1, const mm_frag_stats* __restrict__ stats,
+k_l2_sweep(int cBase, int nCand, int64_t opsBase, const int32_t* __restrict__ candList, int segLength, const mm_l1_candidate* __restrict__ l1, const mm_frag_stats* __restrict__ stats,
            const int64_t* __restrict__ opOff, const int32_t* __restrict__ opCnt, const uint32_t* __restrict__ ops,
            const int64_t* __restrict__ l1Off, L2Tmp* __restrict__ tmp, int locap, mm_l2_locus* __restrict__ l2, unsigned long long l2Cap,
            int32_t* __restrict__ wideList, int32_t* __restrict__ exactList, int64_t* __restrict__ l2First, int32_t* __restrict__ l2Num,
@@ -330,11 +331,11 @@ k_l2_sweep(int nCand, const int32_t* __restrict__ candList, int segLength, const
   const int lane = threadIdx.x;
   const int li = blockIdx.x * 64 + lane;
   if (li >= nCand) return;
-  const int cIdx = candList ? candList[li] : li;
+  const int cIdx = candList ? candList[li] : cBase + li;   // candidates [cBase, cBase + nCand), or the listed ones (absolute indices); ops holds the streams from opsBase on
   const mm_l1_candidate cand = l1[cIdx];
   const int f = cand.frag;
   const int S = stats[f].sketchSize;
-  const uint4* src = (const uint4*)(ops + opOff[cIdx]);
+  const uint4* src = (const uint4*)(ops + (opOff[cIdx] - opsBase));
   const int nSteps = opCnt[cIdx] / E_STEP;             // 16 entries = 4 x 16 bytes per step
   int posAcc = cand.rangeStartPos;                     // running position of the delta code
   const int lbase = WIDE ? (lane & 31) * 2 + (lane >> 5) : lane * 4;
@@ -504,7 +505,7 @@ k_l2_sweep(int nCand, const int32_t* __restrict__ candList, int segLength, const
 // ---------------------------------------------------------------------------------------------
 struct ExactCell { int32_t cnt; int16_t vote; int16_t active; };
 __global__ void __launch_bounds__(64)
-k_l2_sweep_exact(int nList, const int32_t* __restrict__ list, int segLength, const mm_l1_candidate* __restrict__ l1, const mm_frag_stats* __restrict__ stats,
+k_l2_sweep_exact(int nList, int64_t opsBase, const int32_t* __restrict__ list, int segLength, const mm_l1_candidate* __restrict__ l1, const mm_frag_stats* __restrict__ stats,
                  const int64_t* __restrict__ opOff, const int32_t* __restrict__ opCnt, const uint32_t* __restrict__ ops,
                  const int64_t* __restrict__ l1Off, ExactCell* __restrict__ cells, int cellStride, L2Tmp* __restrict__ tmp, int locap,
                  mm_l2_locus* __restrict__ l2, unsigned long long l2Cap, int64_t* __restrict__ l2First, int32_t* __restrict__ l2Num,
@@ -519,7 +520,7 @@ k_l2_sweep_exact(int nList, const int32_t* __restrict__ list, int segLength, con
   cell[0] = ExactCell{0, 0, 0};
   for (int p = 1; p <= S; p++) cell[p] = ExactCell{1, 0, 0};                   // SlideMapper::init (:103-121)
   int pivot = S, pivRank = S, shared = 0, votes = 0;
-  const uint32_t* src = ops + opOff[cIdx];
+  const uint32_t* src = ops + (opOff[cIdx] - opsBase);
   const int nEnt = opCnt[cIdx];
   int posAcc = cand.rangeStartPos;
   int bestShared = 1; bool inRun = false;
@@ -633,22 +634,62 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt) {
     MM_HIP(c, hipGetLastError());
     int rc = mm_scan_i32_to_i64(c, nC, c->dL2Cnt.as<int32_t>(), c->dL2Off.as<int64_t>(), &totalOps);
     if (rc != MM_OK) return rc;
-    MM_HIP(c, c->dL2Ops.ensure((size_t)totalOps * 4 + 256));
-    // buckets of the query-sketch search: at least one per sketch entry (more buckets cost more to fill per candidate than the shorter
-    // walks save: profiles/r02z_locate_buckets.txt)
-    int NB = 256; while (NB < s) NB <<= 1;
-    if (const char* e = getenv("MM_L2_BUCKETS")) { const int v = atoi(e); if (v >= 64 && v <= 16384 && (v & (v - 1)) == 0) NB = v; }
-    const size_t ldsLoc = mm_locate_lds_per_wave(s, NB) * 4;
-    MM_HIP(c, hipFuncSetAttribute((const void*)k_l2_locate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsLoc));
-    int blocks = (nC + 3) / 4; if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL(k_l2_locate, dim3(blocks), dim3(256), ldsLoc, c->stream, nC, s, NB, c->dL1.as<mm_l1_candidate>(),
+  }
+  // The located streams (4 bytes per event a candidate touches: ~5 KB per candidate at s = 130) live in HBM only between the locate and
+  // the sweep kernels.  A batch with very many candidates -- reads out of repeat families -- is taken through the two in chunks of
+  // consecutive candidates whose streams fit MM_L2_STREAM_MIB (default 24 GiB), so the buffer does not grow with the repeat content.
+  struct Chunk { int c0, n; int64_t base; };
+  std::vector<Chunk> chunks;
+  int64_t maxChunkOps = totalOps;
+  {
+    int64_t budget = (int64_t)24 << 28;                                    // in 4-byte entries
+    if (const char* e = getenv("MM_L2_STREAM_MIB")) { const double v = atof(e); if (v > 0) budget = (int64_t)(v * 262144.0); }
+    if (totalOps <= budget || nC <= 1) chunks.push_back(Chunk{0, nC, 0});
+    else {
+      const int64_t* dOff = c->dL2Off.as<int64_t>();
+      auto offAt = [&](int i, int64_t& v) -> int {                          // opOff[i], opOff[nC] = totalOps
+        if (i >= nC) { v = totalOps; return MM_OK; }
+        MM_HIP(c, hipMemcpy(&v, dOff + i, 8, hipMemcpyDeviceToHost));
+        return MM_OK;
+      };
+      maxChunkOps = 0;
+      int c0 = 0; int64_t base = 0;
+      while (c0 < nC) {
+        int lo = c0 + 1, hi = nC;                                          // largest c1 with opOff[c1] - base <= budget, at least one candidate
+        while (lo < hi) {
+          const int mid = lo + (hi - lo + 1) / 2;
+          int64_t v; const int rc = offAt(mid, v); if (rc != MM_OK) return rc;
+          if (v - base <= budget) lo = mid; else hi = mid - 1;
+        }
+        int64_t end; { const int rc = offAt(lo, end); if (rc != MM_OK) return rc; }
+        chunks.push_back(Chunk{c0, lo - c0, base});
+        if (end - base > maxChunkOps) maxChunkOps = end - base;
+        c0 = lo; base = end;
+      }
+      if (getenv("MM_DEBUG")) fprintf(stderr, "[mm] L2: %lld stream entries of %d candidates in %zu chunks of at most %lld\n", (long long)totalOps, nC, chunks.size(), (long long)maxChunkOps);
+    }
+  }
+  MM_HIP(c, c->dL2Ops.ensure((size_t)maxChunkOps * 4 + 256));
+  // buckets of the query-sketch search: at least one per sketch entry (more buckets cost more to fill per candidate than the shorter
+  // walks save: profiles/r02z_locate_buckets.txt)
+  int NB = 256; while (NB < s) NB <<= 1;
+  if (const char* e = getenv("MM_L2_BUCKETS")) { const int v = atoi(e); if (v >= 64 && v <= 16384 && (v & (v - 1)) == 0) NB = v; }
+  const size_t ldsLoc = mm_locate_lds_per_wave(s, NB) * 4;
+  MM_HIP(c, hipFuncSetAttribute((const void*)k_l2_locate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsLoc));
+  auto locate = [&](const Chunk& ch) -> int {
+    KernelTimer t(c, MM_K_L2_LOCATE);
+    int blocks = (ch.n + 3) / 4; if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(k_l2_locate, dim3(blocks), dim3(256), ldsLoc, c->stream, ch.c0, ch.n, ch.base, s, NB, c->dL1.as<mm_l1_candidate>(),
                        c->dStats.as<mm_frag_stats>(), c->dQHash.as<uint64_t>(), c->dQStrand.as<int8_t>(), c->dSkHash.as<uint64_t>(), c->dSkStrand.as<int8_t>(),
                        I.evKey.as<uint32_t>(),
                        I.evAux.as<uint32_t>(), I.evHash.as<uint64_t>(), I.opKey.as<uint32_t>(), I.opAux.as<uint32_t>(), I.opHash.as<uint64_t>(),
                        I.contigOff.as<int64_t>(),
                        c->dL2Info.as<L2Info>(), c->dL2Off.as<int64_t>(), c->dL2Cnt.as<int32_t>(), c->dL2Ops.as<uint32_t>(), cnt);
     MM_HIP(c, hipGetLastError());
-  }
+    return MM_OK;
+  };
+  const bool oneChunk = chunks.size() == 1;
+  if (oneChunk) { const int rc = locate(chunks[0]); if (rc != MM_OK) return rc; }      // its streams stay put over the retries below
   const size_t ldsWide = (size_t)(s + 1) * 64 * 2;                         // cells 0..S, 16 bit
   const size_t ldsNarrow = (size_t)((s + 1 + 3) / 4) * 256;                 // 8 bit
   if (ldsWide > 160 * 1024) { c->err = "sketchSize too large for the LDS-resident L2 state"; return MM_ERR_ARG; }
@@ -663,42 +704,47 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt) {
     MM_HIP(c, c->dL2.ensure(c->l2Cap * sizeof(mm_l2_locus) + 64));
     MM_HIP(c, c->dL2Tmp.ensure((size_t)nC * locap * sizeof(L2Tmp) + 64));
     MM_HIP(c, hipMemsetAsync(cnt + 4, 0, 16, c->stream));                  // [4] cursor [5] overflow; [6] keeps the locate kernel's flag
-    MM_HIP(c, hipMemsetAsync(cnt + 7, 0, 8, c->stream));                   // [7] candidates queued for the wide pass
-    MM_HIP(c, hipMemsetAsync(cnt, 0, 8, c->stream));                       // [0] candidates queued for the exact pass (the lookup stage is done with it)
-    {
-      KernelTimer t(c, MM_K_L2);
-      hipLaunchKernelGGL((k_l2_sweep<false>), dim3((unsigned)((nC + 63) / 64)), dim3(64), ldsNarrow, c->stream, nC, (const int32_t*)nullptr, c->P.segLength,
-                         c->dL1.as<mm_l1_candidate>(), c->dStats.as<mm_frag_stats>(), c->dL2Off.as<int64_t>(), c->dL2Cnt.as<int32_t>(), c->dL2Ops.as<uint32_t>(),
-                         c->dL1Off.as<int64_t>(), c->dL2Tmp.as<L2Tmp>(), locap, c->dL2.as<mm_l2_locus>(), (unsigned long long)c->l2Cap,
-                         c->dL2Wide.as<int32_t>(), c->dL2Exact.as<int32_t>(), c->dL2First.as<int64_t>(), c->dL2Num.as<int32_t>(), cnt);
-      MM_HIP(c, hipGetLastError());
-    }
-    MM_HIP(c, hipMemcpyAsync(hc, cnt, 64, hipMemcpyDeviceToHost, c->stream));
-    MM_HIP(c, hipStreamSynchronize(c->stream));
-    if (hc[7] && !(hc[6] & 1ull) && !hc[5]) {                              // the few candidates whose 5-bit counters overflowed
-      const int nWide = (int)hc[7];
-      if (getenv("MM_DEBUG")) fprintf(stderr, "[mm] L2 sweep: %d of %d candidates redone with 16-bit cells\n", nWide, nC);
-      KernelTimer t(c, MM_K_L2);
-      hipLaunchKernelGGL((k_l2_sweep<true>), dim3((unsigned)((nWide + 63) / 64)), dim3(64), ldsWide, c->stream, nWide, c->dL2Wide.as<int32_t>(), c->P.segLength,
-                         c->dL1.as<mm_l1_candidate>(), c->dStats.as<mm_frag_stats>(), c->dL2Off.as<int64_t>(), c->dL2Cnt.as<int32_t>(), c->dL2Ops.as<uint32_t>(),
-                         c->dL1Off.as<int64_t>(), c->dL2Tmp.as<L2Tmp>(), locap, c->dL2.as<mm_l2_locus>(), (unsigned long long)c->l2Cap,
-                         (int32_t*)nullptr, c->dL2Exact.as<int32_t>(), c->dL2First.as<int64_t>(), c->dL2Num.as<int32_t>(), cnt);
-      MM_HIP(c, hipGetLastError());
+    for (const Chunk& ch : chunks) {
+      if (!oneChunk) { const int rc = locate(ch); if (rc != MM_OK) return rc; }
+      MM_HIP(c, hipMemsetAsync(cnt + 7, 0, 8, c->stream));                 // [7] candidates queued for the wide pass
+      MM_HIP(c, hipMemsetAsync(cnt, 0, 8, c->stream));                     // [0] candidates queued for the exact pass (the lookup stage is done with it)
+      {
+        KernelTimer t(c, MM_K_L2);
+        hipLaunchKernelGGL((k_l2_sweep<false>), dim3((unsigned)((ch.n + 63) / 64)), dim3(64), ldsNarrow, c->stream, ch.c0, ch.n, ch.base, (const int32_t*)nullptr, c->P.segLength,
+                           c->dL1.as<mm_l1_candidate>(), c->dStats.as<mm_frag_stats>(), c->dL2Off.as<int64_t>(), c->dL2Cnt.as<int32_t>(), c->dL2Ops.as<uint32_t>(),
+                           c->dL1Off.as<int64_t>(), c->dL2Tmp.as<L2Tmp>(), locap, c->dL2.as<mm_l2_locus>(), (unsigned long long)c->l2Cap,
+                           c->dL2Wide.as<int32_t>(), c->dL2Exact.as<int32_t>(), c->dL2First.as<int64_t>(), c->dL2Num.as<int32_t>(), cnt);
+        MM_HIP(c, hipGetLastError());
+      }
       MM_HIP(c, hipMemcpyAsync(hc, cnt, 64, hipMemcpyDeviceToHost, c->stream));
       MM_HIP(c, hipStreamSynchronize(c->stream));
-    }
-    if (hc[0] && !(hc[6] & 1ull) && !hc[5]) {                              // candidates with a doubly open query hash: the literal sweep
-      const int nExact = (int)hc[0];
-      if (getenv("MM_DEBUG")) fprintf(stderr, "[mm] L2 sweep: %d of %d candidates redone by the exact kernel (overlapping windows of one hash)\n", nExact, nC);
-      MM_HIP(c, c->dL2Cells.ensure((size_t)nExact * (size_t)(s + 1) * sizeof(ExactCell) + 64));
-      KernelTimer t(c, MM_K_L2);
-      hipLaunchKernelGGL(k_l2_sweep_exact, dim3((unsigned)((nExact + 63) / 64)), dim3(64), 0, c->stream, nExact, c->dL2Exact.as<int32_t>(), c->P.segLength,
-                         c->dL1.as<mm_l1_candidate>(), c->dStats.as<mm_frag_stats>(), c->dL2Off.as<int64_t>(), c->dL2Cnt.as<int32_t>(), c->dL2Ops.as<uint32_t>(),
-                         c->dL1Off.as<int64_t>(), c->dL2Cells.as<ExactCell>(), s + 1, c->dL2Tmp.as<L2Tmp>(), locap, c->dL2.as<mm_l2_locus>(),
-                         (unsigned long long)c->l2Cap, c->dL2First.as<int64_t>(), c->dL2Num.as<int32_t>(), cnt);
-      MM_HIP(c, hipGetLastError());
-      MM_HIP(c, hipMemcpyAsync(hc, cnt, 64, hipMemcpyDeviceToHost, c->stream));
-      MM_HIP(c, hipStreamSynchronize(c->stream));
+      if (hc[7] && !(hc[6] & 1ull) && !hc[5]) {                            // the few candidates whose 5-bit counters overflowed
+        const int nWide = (int)hc[7];
+        if (getenv("MM_DEBUG")) fprintf(stderr, "[mm] L2 sweep: %d of %d candidates redone with 16-bit cells\n", nWide, ch.n);
+        KernelTimer t(c, MM_K_L2);
+        hipLaunchKernelGGL((k_l2_sweep<true>), dim3((unsigned)((nWide + 63) / 64)), dim3(64), ldsWide, c->stream, 0, nWide, ch.base, c->dL2Wide.as<int32_t>(), c->P.segLength,
+                           c->dL1.as<mm_l1_candidate>(), c->dStats.as<mm_frag_stats>(), c->dL2Off.as<int64_t>(), c->dL2Cnt.as<int32_t>(), c->dL2Ops.as<uint32_t>(),
+                           c->dL1Off.as<int64_t>(), c->dL2Tmp.as<L2Tmp>(), locap, c->dL2.as<mm_l2_locus>(), (unsigned long long)c->l2Cap,
+                           (int32_t*)nullptr, c->dL2Exact.as<int32_t>(), c->dL2First.as<int64_t>(), c->dL2Num.as<int32_t>(), cnt);
+        MM_HIP(c, hipGetLastError());
+        MM_HIP(c, hipMemcpyAsync(hc, cnt, 64, hipMemcpyDeviceToHost, c->stream));
+        MM_HIP(c, hipStreamSynchronize(c->stream));
+      }
+      if (hc[0] && !(hc[6] & 1ull) && !hc[5]) {                            // candidates with a doubly open query hash: the literal sweep
+        const int nExact = (int)hc[0];
+        if (getenv("MM_DEBUG")) fprintf(stderr, "[mm] L2 sweep: %d of %d candidates redone by the exact kernel (overlapping windows of one hash)\n", nExact, ch.n);
+        MM_HIP(c, c->dL2Cells.ensure((size_t)nExact * (size_t)(s + 1) * sizeof(ExactCell) + 64));
+        KernelTimer t(c, MM_K_L2);
+        hipLaunchKernelGGL(k_l2_sweep_exact, dim3((unsigned)((nExact + 63) / 64)), dim3(64), 0, c->stream, nExact, ch.base, c->dL2Exact.as<int32_t>(), c->P.segLength,
+                           c->dL1.as<mm_l1_candidate>(), c->dStats.as<mm_frag_stats>(), c->dL2Off.as<int64_t>(), c->dL2Cnt.as<int32_t>(), c->dL2Ops.as<uint32_t>(),
+                           c->dL1Off.as<int64_t>(), c->dL2Cells.as<ExactCell>(), s + 1, c->dL2Tmp.as<L2Tmp>(), locap, c->dL2.as<mm_l2_locus>(),
+                           (unsigned long long)c->l2Cap, c->dL2First.as<int64_t>(), c->dL2Num.as<int32_t>(), cnt);
+        MM_HIP(c, hipGetLastError());
+        MM_HIP(c, hipMemcpyAsync(hc, cnt, 64, hipMemcpyDeviceToHost, c->stream));
+        MM_HIP(c, hipStreamSynchronize(c->stream));
+      }
+      if (hc[6] & 1ull) break;                                             // slots ran out: everything is redone below with more of them (a full locus
+                                                                           // buffer lets the other chunks run on, so that the cursor ends at the total demand)
     }
     if (hc[6] & 1ull) {                                                    // a candidate with more tied loci than slots (tandem repeats): more slots, again
       if ((size_t)nC * (size_t)locap * 2 * sizeof(L2Tmp) > ((size_t)64 << 30)) break;

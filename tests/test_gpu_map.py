@@ -286,3 +286,31 @@ def test_reads_prefetch_is_invisible(oracle):
     assert ctx.mappings().tobytes() == wantB
     ctx.close()
     assert len(wantA) > 48 * 100 and len(wantB) > 48 * 40
+
+
+def test_l2_in_chunks_of_candidates(oracle, monkeypatch):
+    """a batch whose located streams exceed MM_L2_STREAM_MIB goes through locate + sweep in chunks of consecutive candidates (repeat-rich
+    batches would otherwise size the stream buffer); loci, candidate mappings and their order do not change -- wide and exact re-runs
+    included (tandem repeats: tied loci and counter overflows)"""
+    from mashmap_amd import capi
+    g = U.random_dna(401, 300000)
+    rep = U.random_dna(402, 3000)
+    for at in (20000, 90000, 150000, 220000):                                 # a dispersed repeat: several candidates per fragment
+        m = U.mutate(rep, at, 0.01); n = min(len(m), len(rep)); g[at:at + n] = m[:n]
+    g[260000:268000] = U.tandem_repeat(403, 8000, 37)
+    reads = [a for _, a, _ in U.sample_reads([g], 404, 80, 6000, 0.05)]
+    reads += [g[19000:25000].copy(), g[259000:266000].copy(), U.revcomp(g[89000:95500])]
+    def run(budget):
+        if budget is None: monkeypatch.delenv("MM_L2_STREAM_MIB", raising=False)
+        else: monkeypatch.setenv("MM_L2_STREAM_MIB", budget)
+        ctx = capi.Context(k=16, segLength=2000, sketchSize=64, flags=capi.MM_FLAG_HG_FILTER)
+        ctx.index_build([g], kmerPct=0.0); ctx.set_tables_default(0.85)
+        ctx.reads_upload(reads); ctx.map()
+        st, l1, l2 = ctx.results()
+        out = (st.tobytes(), l1.tobytes(), l2.tobytes(), ctx.mappings().tobytes(), len(l1), len(l2))
+        ctx.close()
+        return out
+    whole = run(None)
+    assert whole[4] > 300 and whole[5] > 250
+    for budget in ("0.02", "0.2", "1.5"):
+        assert run(budget)[:4] == whole[:4], budget
