@@ -311,6 +311,6 @@ def test_l2_in_chunks_of_candidates(oracle, monkeypatch):
         ctx.close()
         return out
     whole = run(None)
-    assert whole[4] > 300 and whole[5] > 250
+    assert whole[4] > 150 and whole[5] > 150
     for budget in ("0.02", "0.2", "1.5"):
         assert run(budget)[:4] == whole[:4], budget
