@@ -663,13 +663,155 @@ __device__ void l1_sweep_fragment(const uint64_t* __restrict__ p, int nPts, int 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_l1_stream: the L1 stage of a queued fragment by one WAVE, streaming its sorted points from HBM 64 at a time (coalesced) -- any
+// number of points.  Same formulation as mm_l1_fused: the overlap count after a position group is the running sum of +1 (OPEN) / -1
+// (CLOSE) up to its last point; pass 1 finds the best count (computeMap.hpp:948-999), pass 2 folds the groups whose count reaches
+// minimumHits -- the last group never does, :1024-1098 -- into runs per contig and joins runs closer than segLength (:1102-1115).  The
+// fold over the groups is sequential, as in the reference, but wave-uniform and only over the groups that matter (flagged ones and the
+// one that ends a run).  A position group that spans two contigs or minimumHits <= 0 leaves the fragment to the literal k_l1_sweep
+// (list `lit`).  Fragments with many points are the rule in repeat families (segmental duplications: every locus x copies), where the
+// one-thread-per-fragment kernel costs 50-170 ns per fragment (profiles/r03j_repeat_probe.txt).
+// ---------------------------------------------------------------------------------------------
+#define MM_STREAM_BUF 64            // candidates kept in LDS by the counting pass (more: the writing pass runs again)
+struct L1RunS { int32_t seq, start, end, isize; };
+__global__ void __launch_bounds__(256)
+k_l1_stream(int nList, const int32_t* __restrict__ list, const int64_t* __restrict__ ptOff, const uint64_t* __restrict__ pts,
+            mm_frag_stats* __restrict__ stats, const int32_t* __restrict__ minHitsTab, const int32_t* __restrict__ cutoffs, int nCutoffs,
+            int sParam, int segLength, int hg, mm_l1_candidate* __restrict__ l1, unsigned long long l1Cap, int64_t* __restrict__ l1Off,
+            int32_t* __restrict__ lit, unsigned int* __restrict__ litCount, unsigned long long* __restrict__ counters /* [2] l1 cursor, [3] overflow */) {
+  __shared__ L1RunS bufAll[4][MM_STREAM_BUF];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  L1RunS* buf = bufAll[wave];
+  const int li = blockIdx.x * 4 + wave;
+  if (li >= nList) return;
+  const int f = list[li];
+  const int nPts = stats[f].nPoints, S = stats[f].sketchSize;
+  if (nPts <= 0 || S <= 0) { if (lane == 0) { stats[f].nL1 = 0; l1Off[f] = 0; } return; }
+  const uint64_t* p = pts + ptOff[2 * f];
+  int minHits = minHitsTab[S];
+
+  // one chunk of 64 points: key, overlap count after the point, whether it ends a position group
+  auto chunk = [&](int i0, int carry, uint64_t& k, int& run, bool& gLast, bool& mixed, int& sum) {
+    const int idx = i0 + lane;
+    const bool valid = idx < nPts;
+    k = valid ? p[idx] : MM_EMPTY;
+    const uint64_t prv = (valid && idx > 0) ? p[idx - 1] : MM_EMPTY;
+    const uint64_t nxt = (idx + 1 < nPts) ? p[idx + 1] : MM_EMPTY;
+    mixed = valid && prv != MM_EMPTY && (uint32_t)(prv >> 1) == (uint32_t)(k >> 1) && (prv >> 33) != (k >> 33);
+    const int delta = valid ? ((k & 1ull) ? 1 : -1) : 0;
+    run = carry + mm_wave_excl_scan(delta) + delta;
+    gLast = valid && (nxt == MM_EMPTY || (uint32_t)(nxt >> 1) != (uint32_t)(k >> 1));
+    sum = mm_wave_sum(delta);
+  };
+
+  // ---- pass 1: best overlap count, number of groups, the mixed-group test ----
+  int best = 0, G = 0; bool anyMixed = false;
+  {
+    int carry = 0;
+    for (int i0 = 0; i0 < nPts; i0 += 64) {
+      uint64_t k; int run, sum; bool gLast, mixed;
+      chunk(i0, carry, k, run, gLast, mixed, sum);
+      if (gLast && run > best) best = run;
+      G += (int)__popcll(__ballot(gLast));
+      anyMixed = anyMixed || __ballot(mixed) != 0;
+      carry += sum;
+    }
+    best = mm_wave_max(best);
+  }
+  bool go = G > 0;
+  if (go && hg) {                                                 // computeMap.hpp:984-998
+    if (best < minHits) go = false;
+    else {
+      const double div = (double)sParam / 1000.0 > 1.0 ? (double)sParam / 1000.0 : 1.0;
+      int ci = (int)((double)(best < S ? best : S) / div);
+      if (ci >= nCutoffs) ci = nCutoffs - 1;
+      const int cut = cutoffs[ci];
+      minHits = cut > minHits ? cut : minHits;
+    }
+  }
+  if (anyMixed || minHits <= 0) {                                 // the literal kernel's business
+    if (lane == 0) lit[atomicAdd(litCount, 1u)] = f;
+    return;
+  }
+
+  // ---- pass 2: runs of flagged groups -> joined candidates; counted (the first MM_STREAM_BUF kept in LDS), then written ----
+  int total = 0; long long base = 0;
+  for (int pass = 0; pass < 2; pass++) {
+    const bool write = pass == 1;
+    int count = 0;
+    bool have = false; L1RunS pend{0, 0, 0, 0};
+    auto flush = [&]() {
+      if (have) {
+        if (lane == 0) {
+          if (write) { mm_l1_candidate o; o.frag = f; o.seqId = pend.seq; o.rangeStartPos = pend.start; o.rangeEndPos = pend.end; o.intersectionSize = pend.isize; l1[base + count] = o; }
+          else if (count < MM_STREAM_BUF) buf[count] = pend;
+        }
+        count++; have = false;
+      }
+    };
+    auto emit = [&](int seq, int start, int end, int isize) {      // L1Emit::run for a single reference group
+      if (have && seq == pend.seq && !(start > pend.end + segLength)) { pend.end = end; pend.isize = isize > pend.isize ? isize : pend.isize; }
+      else { flush(); pend.seq = seq; pend.start = start; pend.end = end; pend.isize = isize; have = true; }
+    };
+    if (go) {
+      bool inRun = false; int rSeq = 0, rStart = 0, rEnd = 0, rSize = 0;
+      int carry = 0, gBase = 0;
+      for (int i0 = 0; i0 < nPts; i0 += 64) {
+        uint64_t k; int run, sum; bool gLast, mixed;
+        chunk(i0, carry, k, run, gLast, mixed, sum);
+        carry += sum;
+        const uint64_t GM = __ballot(gLast);
+        const int gidx = gBase + (int)mm_popc_below(GM);
+        gBase += (int)__popcll(GM);
+        const uint64_t FM = __ballot(gLast && gidx < G - 1 && run >= minHits);
+        if (!FM && !inRun) continue;                              // nothing here can start, extend or end a run
+        const int gseq = (int)(k >> 33), gpos = (int)(uint32_t)(k >> 1);
+        uint64_t rest = GM;
+        for (;;) {
+          const uint64_t cand = inRun ? rest : (rest & FM);       // outside a run only a flagged group matters
+          if (!cand) break;
+          const int b = (int)__builtin_ctzll(cand);
+          rest &= ~((2ull << b) - 1ull);
+          const int seq = __builtin_amdgcn_readlane(gseq, b), pos = __builtin_amdgcn_readlane(gpos, b), ov = __builtin_amdgcn_readlane(run, b);
+          if ((FM >> b) & 1ull) {
+            if (inRun && rSeq != seq) { emit(rSeq, rStart, rEnd, rSize); inRun = false; }
+            if (!inRun) { rSeq = seq; rStart = pos; rEnd = pos; rSize = ov; inRun = true; }
+            else { rEnd = pos; rSize = ov > rSize ? ov : rSize; }
+          } else { emit(rSeq, rStart, rEnd, rSize); inRun = false; }
+        }
+      }
+      if (inRun) emit(rSeq, rStart, rEnd, rSize);
+      flush();
+    }
+    if (!write) {
+      total = count;
+      if (total > 0) {
+        long long b0 = 0;
+        if (lane == 0) b0 = (long long)atomicAdd(&counters[2], (unsigned long long)total);
+        base = ((long long)__builtin_amdgcn_readfirstlane((int)(b0 >> 32)) << 32) | (unsigned int)__builtin_amdgcn_readfirstlane((int)b0);
+        if ((unsigned long long)base + (unsigned long long)total > l1Cap) { if (lane == 0) atomicOr(&counters[3], 1ull); total = 0; }
+      }
+      if (total > 0 && total <= MM_STREAM_BUF) {                   // the counting pass kept them all
+        __threadfence_block();
+        if (lane < total) { const L1RunS r = buf[lane]; mm_l1_candidate o; o.frag = f; o.seqId = r.seq; o.rangeStartPos = r.start; o.rangeEndPos = r.end; o.intersectionSize = r.isize; l1[base + lane] = o; }
+        break;
+      }
+      if (total == 0) break;
+    }
+  }
+  if (lane == 0) { stats[f].nL1 = total; l1Off[f] = total > 0 ? base : 0; }
+}
+
 __global__ void __launch_bounds__(256)
 k_l1_sweep(int nList, const int32_t* __restrict__ list, const int64_t* __restrict__ ptOff, const uint64_t* __restrict__ pts,
            mm_frag_stats* __restrict__ stats,
            const int32_t* __restrict__ minHitsTab, const int32_t* __restrict__ cutoffs, int nCutoffs, int sParam, int segLength,
            MapFlags fl, const int32_t* __restrict__ refGroup, mm_l1_candidate* __restrict__ l1, unsigned long long l1Cap,
-           int64_t* __restrict__ l1Off, unsigned long long* __restrict__ counters /* [2] l1 cursor, [3] overflow */) {
+           int64_t* __restrict__ l1Off, unsigned long long* __restrict__ counters /* [2] l1 cursor, [3] overflow */,
+           const unsigned int* __restrict__ nListDev /* non-null: the list's length lives on the device (what k_l1_stream left over) */) {
   const int li = blockIdx.x * blockDim.x + threadIdx.x;
+  if (nListDev) nList = (int)*nListDev;
   if (li >= nList) return;
   const int f = list[li];
   const int nPts = stats[f].nPoints, S = stats[f].sketchSize;
@@ -798,10 +940,23 @@ int mm_launch_map(mm_ctx* c) {
       MM_HIP(c, hipMemsetAsync(cnt + 3, 0, 8, c->stream));
       {
         KernelTimer t(c, MM_K_L1);
-        hipLaunchKernelGGL(k_l1_sweep, dim3((nBig + 255) / 256), dim3(256), 0, c->stream, nBig, c->dBigList.as<int32_t>(), c->dPtOff.as<int64_t>(),
+        // a wave per fragment streams the sorted points; what it cannot take (a position group across two contigs, minimumHits 0) and
+        // every fragment under -Y reference groups goes to the literal one-thread-per-fragment kernel
+        const bool stream = !fl.skipPrefix && !getenv("MM_L1_LITERAL");
+        const int32_t* sweepList = c->dBigList.as<int32_t>(); const unsigned int* sweepCount = nullptr;
+        if (stream) {
+          MM_HIP(c, hipMemsetAsync(cls, 0, 8, c->stream));
+          hipLaunchKernelGGL(k_l1_stream, dim3((nBig + 3) / 4), dim3(256), 0, c->stream, nBig, c->dBigList.as<int32_t>(), c->dPtOff.as<int64_t>(),
+                             c->dPts.as<uint64_t>(), c->dStats.as<mm_frag_stats>(), c->dMinHits.as<int32_t>(), c->dCutoffs.as<int32_t>(),
+                             (int)c->nCutoffs, s, c->P.segLength, fl.hg, c->dL1.as<mm_l1_candidate>(), (unsigned long long)denseCap,
+                             c->dL1Off.as<int64_t>(), listB.as<int32_t>(), cls, cnt);
+          MM_HIP(c, hipGetLastError());
+          sweepList = listB.as<int32_t>(); sweepCount = cls;
+        }
+        hipLaunchKernelGGL(k_l1_sweep, dim3((nBig + 255) / 256), dim3(256), 0, c->stream, nBig, sweepList, c->dPtOff.as<int64_t>(),
                            c->dPts.as<uint64_t>(), c->dStats.as<mm_frag_stats>(), c->dMinHits.as<int32_t>(), c->dCutoffs.as<int32_t>(),
                            (int)c->nCutoffs, s, c->P.segLength, fl, I.refGroup.as<int32_t>(), c->dL1.as<mm_l1_candidate>(),
-                           (unsigned long long)denseCap, c->dL1Off.as<int64_t>(), cnt);
+                           (unsigned long long)denseCap, c->dL1Off.as<int64_t>(), cnt, sweepCount);
         MM_HIP(c, hipGetLastError());
       }
       unsigned long long h2[2];
