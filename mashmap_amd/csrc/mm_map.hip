@@ -668,8 +668,8 @@ __device__ void l1_sweep_fragment(const uint64_t* __restrict__ p, int nPts, int 
 // number of points.  Same formulation as mm_l1_fused: the overlap count after a position group is the running sum of +1 (OPEN) / -1
 // (CLOSE) up to its last point; pass 1 finds the best count (computeMap.hpp:948-999), pass 2 folds the groups whose count reaches
 // minimumHits -- the last group never does, :1024-1098 -- into runs per contig and joins runs closer than segLength (:1102-1115).  The
-// fold over the groups is sequential, as in the reference, but wave-uniform and only over the groups that matter (flagged ones and the
-// one that ends a run).  A position group that spans two contigs or minimumHits <= 0 leaves the fragment to the literal k_l1_sweep
+// fold is sequential, as in the reference, but wave-uniform and only over the groups that start a run or end one (everything between
+// two of those extends the run: a masked wave maximum).  A position group that spans two contigs or minimumHits <= 0 leaves the fragment to the literal k_l1_sweep
 // (list `lit`).  Fragments with many points are the rule in repeat families (segmental duplications: every locus x copies), where the
 // one-thread-per-fragment kernel costs 50-170 ns per fragment (profiles/r03j_repeat_probe.txt).
 // ---------------------------------------------------------------------------------------------
@@ -757,29 +757,57 @@ k_l1_stream(int nList, const int32_t* __restrict__ list, const int64_t* __restri
     if (go) {
       bool inRun = false; int rSeq = 0, rStart = 0, rEnd = 0, rSize = 0;
       int carry = 0, gBase = 0;
+      bool prevFlagC = false; int prevSeqC = 0;                   // the last group of the chunks so far: flagged?, its contig
       for (int i0 = 0; i0 < nPts; i0 += 64) {
         uint64_t k; int run, sum; bool gLast, mixed;
         chunk(i0, carry, k, run, gLast, mixed, sum);
         carry += sum;
         const uint64_t GM = __ballot(gLast);
+        if (!GM) continue;
         const int gidx = gBase + (int)mm_popc_below(GM);
         gBase += (int)__popcll(GM);
-        const uint64_t FM = __ballot(gLast && gidx < G - 1 && run >= minHits);
-        if (!FM && !inRun) continue;                              // nothing here can start, extend or end a run
+        const bool flag = gLast && gidx < G - 1 && run >= minHits;
+        const uint64_t FM = __ballot(flag);
         const int gseq = (int)(k >> 33), gpos = (int)(uint32_t)(k >> 1);
-        uint64_t rest = GM;
-        for (;;) {
-          const uint64_t cand = inRun ? rest : (rest & FM);       // outside a run only a flagged group matters
-          if (!cand) break;
-          const int b = (int)__builtin_ctzll(cand);
-          rest &= ~((2ull << b) - 1ull);
-          const int seq = __builtin_amdgcn_readlane(gseq, b), pos = __builtin_amdgcn_readlane(gpos, b), ov = __builtin_amdgcn_readlane(run, b);
-          if ((FM >> b) & 1ull) {
-            if (inRun && rSeq != seq) { emit(rSeq, rStart, rEnd, rSize); inRun = false; }
-            if (!inRun) { rSeq = seq; rStart = pos; rEnd = pos; rSize = ov; inRun = true; }
-            else { rEnd = pos; rSize = ov > rSize ? ov : rSize; }
-          } else { emit(rSeq, rStart, rEnd, rSize); inRun = false; }
+        const int lastG = 63 - (int)__builtin_clzll(GM);
+        const bool lastFlag = (FM >> lastG) & 1ull; const int lastSeq = __builtin_amdgcn_readlane(gseq, lastG);
+        if (FM || prevFlagC) {
+          // the group before this lane's: in the chunk, or the carried one
+          const uint64_t below = GM & ((1ull << lane) - 1ull);
+          const int pl = below ? 63 - (int)__builtin_clzll(below) : lane;
+          const int sseq = __shfl(gseq, pl);
+          const bool pf = below ? (((FM >> pl) & 1ull) != 0) : prevFlagC;
+          const int ps = below ? sseq : prevSeqC;
+          // a flagged group continues the run of a flagged predecessor on the same contig; the groups that matter are the others:
+          // flagged ones that start a run, and unflagged ones right behind a flagged one, which end it.  Between two of those every
+          // flagged group just extends the run: its end is the last one's position, its size the largest count.
+          const uint64_t startM = __ballot(flag && !(pf && ps == gseq));
+          const uint64_t breakM = __ballot(gLast && !flag && pf);
+          auto extend = [&](int lo, int hi) {                       // flagged groups of the lanes [lo, hi) join the open run
+            if (lo >= 64) return;
+            const uint64_t m = FM & ~((1ull << lo) - 1ull) & (hi >= 64 ? ~0ull : ((1ull << hi) - 1ull));
+            if (!m) return;
+            rEnd = __builtin_amdgcn_readlane(gpos, 63 - (int)__builtin_clzll(m));
+            const int mx = mm_wave_max((flag && lane >= lo && lane < hi) ? run : 0);
+            rSize = mx > rSize ? mx : rSize;
+          };
+          uint64_t ev = startM | breakM;
+          int segLo = 0;
+          while (ev) {
+            const int bpos = (int)__builtin_ctzll(ev);
+            ev &= ev - 1ull;
+            if (inRun) extend(segLo, bpos);
+            if ((breakM >> bpos) & 1ull) { if (inRun) emit(rSeq, rStart, rEnd, rSize); inRun = false; }
+            else {
+              if (inRun) emit(rSeq, rStart, rEnd, rSize);
+              rSeq = __builtin_amdgcn_readlane(gseq, bpos); rStart = __builtin_amdgcn_readlane(gpos, bpos); rEnd = rStart;
+              rSize = __builtin_amdgcn_readlane(run, bpos); inRun = true;
+            }
+            segLo = bpos + 1;
+          }
+          if (inRun) extend(segLo, 64);
         }
+        prevFlagC = lastFlag; prevSeqC = lastSeq;
       }
       if (inRun) emit(rSeq, rStart, rEnd, rSize);
       flush();
@@ -969,6 +997,7 @@ int mm_launch_map(mm_ctx* c) {
         if (fusedL1) MM_HIP(c, hipMemcpyAsync(nb.p, c->dL1.p, (size_t)fusedL1 * sizeof(mm_l1_candidate), hipMemcpyDeviceToDevice, c->stream));
         MM_HIP(c, hipStreamSynchronize(c->stream));
         c->dL1.release(); c->dL1 = nb; denseCap = newCap;
+        if (c->l1Cap < newCap) c->l1Cap = newCap;                  // the next pass sizes both candidate buffers for it: no retry, no reallocation
         hc[3] = 1; continue;
       }
       hc[2] = h2[0]; hc[3] = 0;
