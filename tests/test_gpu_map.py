@@ -314,3 +314,31 @@ def test_l2_in_chunks_of_candidates(oracle, monkeypatch):
     assert whole[4] > 150 and whole[5] > 150
     for budget in ("0.02", "0.2", "1.5"):
         assert run(budget)[:4] == whole[:4], budget
+
+
+def test_map_many_candidates_per_fragment(oracle, monkeypatch):
+    """a 1.5 kbp unit strewn 90 times over a contig, every copy further than segLength from the next: a read of the unit has ~90 L1
+    candidates -- more than k_l1_stream keeps in LDS while counting (its second, writing pass), and the same bytes as the literal kernel"""
+    from mashmap_amd import capi
+    rng = np.random.default_rng(9)
+    unit = U.random_dna(501, 1500)
+    g = U.random_dna(502, 90 * 6000 + 4000)
+    for i in range(90):
+        at = 2000 + i * 6000 + int(rng.integers(0, 800))
+        m = U.mutate(unit, 600 + i, 0.004); n = min(len(m), 1500); g[at:at + n] = m[:n]
+    contigs = [("rep", g), ("other", U.random_dna(503, 50000))]
+    reads = [("u%d" % i, U.mutate(unit, 700 + i, 0.01)[:1400].copy()) for i in range(6)] + [("urc", U.revcomp(unit)), ("bg", g[100:1600].copy())]
+    nF, nl = run_and_compare(oracle, contigs, reads, k=16, L=1000, s=80, pi=0.85, kmerPct=0.0)
+    assert nF == 2 * len(reads) and nl > 100                                  # 1000 + an overlapping tail fragment per read
+    def once(literal):
+        if literal: monkeypatch.setenv("MM_L1_LITERAL", "1")
+        else: monkeypatch.delenv("MM_L1_LITERAL", raising=False)
+        ctx = capi.Context(k=16, segLength=1000, sketchSize=80, flags=capi.MM_FLAG_HG_FILTER)
+        ctx.index_build([a for _, a in contigs], kmerPct=0.0); ctx.set_tables_default(0.85)
+        ctx.reads_upload([a for _, a in reads]); ctx.map()
+        st, l1, l2 = ctx.results()
+        ctx.close()
+        return st, l1, l2
+    a, b = once(False), once(True)
+    assert a[0]["nL1"].max() > 64
+    assert a[0].tobytes() == b[0].tobytes() and a[1].tobytes() == b[1].tobytes() and a[2].tobytes() == b[2].tobytes()
