@@ -181,13 +181,20 @@ class GzSource : public RawSource {
       const size_t at = buf_.size(); buf_.resize(at + (8u << 20));
       const int got = gzread(gz_, buf_.data() + at, 8u << 20);
       buf_.resize(at + (got > 0 ? (size_t)got : 0));
-      if (got <= 0) eof_ = true;
+      if (got <= 0) {
+        // gzread() <= 0 is the end of the data only if zlib says so: a truncated or corrupt stream must not pass for a short file
+        int zerr = Z_OK; const char* msg = gzerror(gz_, &zerr);
+        if (got < 0 || (zerr != Z_OK && zerr != Z_STREAM_END)) {
+          std::cerr << "[mashmap_hip] error while inflating " << path_ << ": " << (msg && *msg ? msg : "gzread failed") << std::endl; exit(1);
+        }
+        eof_ = true;
+      }
     }
     return !buf_.empty();
   }
   // BGZF (SAM spec 4.1): gzip member with extra subfield 'B','C' holding BSIZE = block size - 1; payload = raw deflate; trailer CRC32 + ISIZE
   bool fill_bgzf(size_t want) {
-    struct Blk { size_t cOff, cLen, uOff, uLen; };
+    struct Blk { size_t cOff, cLen, uOff, uLen; uint32_t crc; };
     while (buf_.size() < want && !eof_) {
       std::vector<Blk> blks; comp_.clear();
       size_t uTot = 0;
@@ -200,7 +207,8 @@ class GzSource : public RawSource {
         if (fread(comp_.data() + at, 1, bsize - 18, raw_) != bsize - 18) { std::cerr << "[mashmap_hip] truncated BGZF file " << path_ << std::endl; exit(1); }
         const unsigned char* t = comp_.data() + at + bsize - 18 - 4;
         const size_t isize = (size_t)t[0] | ((size_t)t[1] << 8) | ((size_t)t[2] << 16) | ((size_t)t[3] << 24);
-        blks.push_back(Blk{at, bsize - 18 - 8, uTot, isize});
+        const uint32_t crc = (uint32_t)t[-4] | ((uint32_t)t[-3] << 8) | ((uint32_t)t[-2] << 16) | ((uint32_t)t[-1] << 24);
+        blks.push_back(Blk{at, bsize - 18 - 8, uTot, isize, crc});
         uTot += isize;
       }
       const size_t base = buf_.size(); buf_.resize(base + uTot);
@@ -215,7 +223,8 @@ class GzSource : public RawSource {
           zs.next_out = (Bytef*)(buf_.data() + base + blks[i].uOff); zs.avail_out = (uInt)blks[i].uLen;
           const int rc = inflate(&zs, Z_FINISH);
           inflateEnd(&zs);
-          if (rc != Z_STREAM_END) bad = 1;
+          if (rc != Z_STREAM_END || zs.total_out != blks[i].uLen) bad = 1;
+          else if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), (const Bytef*)(buf_.data() + base + blks[i].uOff), (uInt)blks[i].uLen) != blks[i].crc) bad = 1;   // trailer: CRC32 of the payload
         }
       });
       if (bad) { std::cerr << "[mashmap_hip] corrupt BGZF block in " << path_ << std::endl; exit(1); }
@@ -224,7 +233,11 @@ class GzSource : public RawSource {
   }
 
  public:
-  GzSource(const std::string& path, size_t window, unsigned threads, WorkerPool* pool) : path_(path), window_(window), threads_(threads), pool_(pool) {
+  // streamOnly: the path is not a regular file (FIFO, /dev/stdin, process substitution): it can be opened and read exactly once, so
+  // there is no sniffing with a handle of its own -- gzopen reads plain data transparently and gzip (BGZF included: concatenated
+  // members) by inflating it, which is what the reference's igzstream does with such inputs (src/common/gzstream.h:50)
+  GzSource(const std::string& path, size_t window, unsigned threads, WorkerPool* pool, bool streamOnly = false) : path_(path), window_(window), threads_(threads), pool_(pool) {
+    if (streamOnly) { gz_ = gzopen(path.c_str(), "rb"); if (gz_) gzbuffer(gz_, 1u << 20); return; }
     raw_ = fopen(path.c_str(), "rb");
     if (!raw_) return;
     unsigned char h[18] = {0};
@@ -302,10 +315,14 @@ class BatchReader {
   detail::RawSource* src_ = nullptr; size_t nextFile_ = 0, curFile_ = 0; bool fasta_ = true, firstWindow_ = true, fileDone_ = false;
 
   void openFile(const std::string& path) {
+    // mmap and the two-byte gzip sniff need a regular file; anything else (a FIFO, /dev/stdin, `-q <(zcat x.gz)`) is read once, as a stream
+    struct stat st;
+    const bool regular = stat(path.c_str(), &st) == 0 && S_ISREG(st.st_mode);
     bool gz = false;
-    { FILE* f = fopen(path.c_str(), "rb"); if (f) { unsigned char m[2] = {0, 0}; if (fread(m, 1, 2, f) == 2) gz = m[0] == 31 && m[1] == 139; fclose(f); } }
+    if (regular) { FILE* f = fopen(path.c_str(), "rb"); if (f) { unsigned char m[2] = {0, 0}; if (fread(m, 1, 2, f) == 2) gz = m[0] == 31 && m[1] == 139; fclose(f); } }
     bool ok = false;
-    if (gz) { auto* s = new detail::GzSource(path, window_, threads_, &pool_); ok = s->ok(); src_ = s; }
+    if (!regular) { auto* s = new detail::GzSource(path, window_, threads_, &pool_, true); ok = s->ok(); src_ = s; }
+    else if (gz) { auto* s = new detail::GzSource(path, window_, threads_, &pool_); ok = s->ok(); src_ = s; }
     else { auto* s = new detail::MmapSource(path, window_); ok = s->ok(); src_ = s; }
     const char c = ok ? src_->first_byte() : 0;
     if (!ok || (c != '>' && c != '@')) {

@@ -116,3 +116,40 @@ def test_worker_pool_runs_every_task_exactly_once(exe, threads):
     """mmhost::WorkerPool (the persistent workers of the reader and the post stage): 4000 back-to-back runs of 1 .. 4096 tasks"""
     out = subprocess.run([exe, "pool", str(threads), "4000"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.startswith("pool ok 4000"), out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("kind", ["fasta60", "fastq", "fasta60.gz", "fasta60.bgzf"])
+def test_non_regular_inputs_are_read_as_streams(exe, tmp_path, kind):
+    """-q <(cat x.fa) / <(gzip -c x.fa) / a FIFO: the reference's igzstream reads them; no mmap, no sniffing handle that eats bytes"""
+    rs = records()[:120]
+    raw = fastq_bytes(rs) if kind.startswith("fastq") else fasta_bytes(rs, 60)
+    data = gzip.compress(raw) if kind.endswith(".gz") else bgzf_bytes(raw) if kind.endswith(".bgzf") else raw
+    path = str(tmp_path / "plain.in")
+    open(path, "wb").write(data)
+    want = expect(rs)
+    for window, threads in ((70000, 3), (1 << 40, 1)):
+        p = subprocess.run(["bash", "-c", '"%s" %d %d <(cat "%s")' % (exe, window, threads, path)], capture_output=True, text=True)
+        assert p.returncode == 0, p.stderr
+        assert p.stdout.splitlines() == want
+    fifo = str(tmp_path / "fifo")
+    os.mkfifo(fifo)
+    feeder = subprocess.Popen(["bash", "-c", 'cat "%s" > "%s"' % (path, fifo)])
+    p = subprocess.run([exe, "65536", "4", fifo], capture_output=True, text=True, timeout=120)
+    feeder.wait()
+    assert p.returncode == 0 and p.stdout.splitlines() == want, p.stderr
+
+
+def test_truncated_or_corrupt_gzip_is_an_error(exe, tmp_path):
+    rs = records()[:200]
+    raw = fasta_bytes(rs, 60)
+    gz = gzip.compress(raw)
+    cut = str(tmp_path / "cut.fa.gz")
+    open(cut, "wb").write(gz[:len(gz) * 2 // 3])
+    p = subprocess.run([exe, "70000", "3", cut], capture_output=True, text=True)
+    assert p.returncode != 0 and "inflating" in p.stderr, (p.returncode, p.stderr[-200:])
+    bg = bytearray(bgzf_bytes(raw))
+    bg[len(bg) // 2] ^= 0x55                                   # a flipped payload byte: inflate error or CRC mismatch
+    bad = str(tmp_path / "bad.fa.bgzf")
+    open(bad, "wb").write(bytes(bg))
+    p = subprocess.run([exe, "70000", "3", bad], capture_output=True, text=True)
+    assert p.returncode != 0 and "BGZF" in p.stderr, (p.returncode, p.stderr[-200:])
