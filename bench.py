@@ -19,6 +19,11 @@ Workloads (BASELINE.json `configs`; the default is configs[1], the configuration
   configs4  per-GPU share of configs[4]: 625 k x 20 kbp reads at 15-20 % error vs 10 x 300 Mbp (the --rl list shares one seqId
             space, winSketch.hpp:174-214), --dense --pi 80 => sketchSize 498
 --reads / --ref-contigs / --ref-contig-len scale a workload down; the JSON line names what actually ran.
+
+The default run (configs1, nothing scaled, one GPU) also measures the north_star target sentence itself -- 1 M x 10 kbp reads at pi 85
+against the human-scale (3 Gbp) index -- after the headline measurement and attaches it as the extra key `north_star_target`
+(stock segLength 5000, and a segLength 10000 variant: the sentence says "10 kbp segments"); `value` / `config` / `roofline` stay the
+configs[1] figures.  --no-north-star skips it.
 """
 import argparse
 import json
@@ -238,6 +243,132 @@ def host_path(ctx, W, nreads, ref_lens, steps_ms):
             "note": "skch::Map overlaps the host stage of batch i with the device stage of batch i+1 (pipelined); serial = no overlap"}
 
 
+def pmc_entry(workload_key, kernel="k_sketch_fast"):
+    """counters of one kernel from the committed PMC passes of this workload (profiles/pmc_traffic.json: per workload, per kernel,
+    per launch), and where they came from -- they are NOT measured in the bench run itself"""
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        wl = json.load(open(pmc)).get(workload_key)
+        if not wl or kernel not in wl:
+            return None, None
+        return wl[kernel], "profiles/pmc_traffic.json [%s] (rocprofv3 --pmc passes %s of this workload; not measured in this run)" % (workload_key, wl.get("_source", "?"))
+    except Exception:
+        return None, None
+
+
+def roofline_block(ctx, capi, W, workload_key, nF, prof, step_ms, pmc_ok):
+    """roofline of the dominant kernel (k_sketch_fast): algorithmic bytes per fragment = L/4 packed bases in + 24 B per sketch entry out
+    (SURVEY section 8d), divided by its average HIP-event duration in the timed region; the integer yardstick; VALU issue peaks"""
+    SEG, SKETCH = W["seg"], W["sketch"]
+    sk_ms, sk_n = prof["sketch"]
+    sk_avg = sk_ms / max(1, sk_n)
+    frag_bytes = SEG / 4.0 + 24.0 * SKETCH
+    ach = frag_bytes * nF / (sk_avg / 1e3) / 1e9 if sk_ms > 0 else 0.0
+    # integer roofline (SURVEY section 8d(ii)): the same fragments through a kernel that only hashes (2 x MurmurHash3_x64_128 per base)
+    integer = None
+    try:
+        hms = ctx.bench_hash_only(3)
+        integer = {"hash_only_ms": round(hms, 3), "hash_only_gbps": round(nF * SEG / hms / 1e6, 2),
+                   "sketch_kernel_frac": round(hms / sk_avg, 4) if sk_avg > 0 else None, "step_frac": round(hms / step_ms, 4),
+                   "note": "k_hash_only: the sketch kernel's own geometry (positions per thread, threads per workgroup, LDS claim), staging and tables, "
+                           "nothing but the two hashes per position; frac = its time / the kernel's (step's) time = share of the integer floor reached"}
+    except capi.MashmapError as e:
+        log("[bench] hash-only microbenchmark unavailable:", e)
+    # HBM bytes / VALU instructions per launch of that kernel from the committed PMC passes of the same workload
+    traffic = valu = source = None
+    if pmc_ok:
+        ent, source = pmc_entry(workload_key)
+        if ent:
+            traffic = ent.get("hbm_bytes_per_launch")
+            ninst = ent.get("SQ_INSTS_VALU")
+            if ninst and sk_avg > 0:
+                per_s = ninst / (sk_avg * 1e-3)
+                mix = 3.35                          # cycles per wave-instruction of this kernel's VOP3/VOP2 mix (profiles/r02_valu_rate.txt, r02_sketch_instruction_mix.txt)
+                valu = {"wave_instructions_per_launch": ninst,
+                        "util_vs_2_cycles_per_instr": round(per_s / (SIMDS * CLOCK_HZ / 2.0), 3),
+                        "util_vs_measured_mix": round(per_s / (SIMDS * CLOCK_HZ / mix), 3),
+                        "util_vs_4_cycles_per_instr": round(per_s / (SIMDS * CLOCK_HZ / 4.0), 3),
+                        "model": "1024 SIMDs x 2.4 GHz; three issue peaks: 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md nominal, SIMD-32), "
+                                 "%.2f cycles (this kernel's mix of VOP3 integer ops at ~4.2 and VOP2 ops at ~2.3 cycles measured by "
+                                 "scripts/probes/valu_rate.hip, output in profiles/), 4 cycles (every instruction at the VOP3 rate)" % mix}
+    return {"bound": "hbm", "kernel": "k_sketch_fast", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": source,
+            "algorithmic_bytes_per_fragment": frag_bytes, "avg_launch_ms": round(sk_avg, 3),
+            "algorithmic_bytes_per_launch": frag_bytes * nF,
+            "note": "integer-issue bound kernel (2 x MurmurHash3_x64_128 per base); the HBM fraction is small by construction -- "
+                    "`int` (hash-only yardstick) and `valu` (issue peaks) are the rooflines that bind, DESIGN.md section 3",
+            "int": integer, "valu": valu}
+
+
+def timed_passes(ctx, warmup, steps):
+    """W untimed passes, then K timed ones bracketed by a stream synchronisation; returns (seconds, per-kernel HIP-event times)"""
+    for _ in range(warmup):
+        ctx.map()
+    ctx.profile(True); ctx.profile_read(reset=True)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ctx.map()
+    ctx.synchronize()
+    dt = time.perf_counter() - t0
+    prof = ctx.profile_read(reset=True)
+    ctx.profile(False)
+    return dt, prof
+
+
+def north_star_target(torch, dev, capi, local, warmup, steps):
+    """BASELINE.json's north_star target sentence on one GPU: 1 M x 10 kbp ONT-like reads, pi 85, against a human-scale index (3 Gbp,
+    24 x 125 Mbp), device-resident packed bases in -> candidate mappings out.  Two variants on the same data: the stock command line
+    (segLength 5000, the metric's "s=5000": two fragments per read) and segLength 10000 ("10 kbp segments": one fragment per read);
+    sketchSize 310 = what the stock binary derives for a 3 GB reference file at either segment length."""
+    base = dict(WORKLOADS["northstar"])
+    t0 = time.time()
+    contigs = make_reference(torch, dev, base["ref_contigs"], base["ref_contig_len"])
+    ref_np = [c.cpu().numpy() for c in contigs]
+    reads_t = make_reads(torch, dev, contigs, base["reads"], base["read_len"], base["err"], seed=1000)
+    torch.cuda.synchronize()
+    del contigs
+    torch.cuda.empty_cache()
+    gen_s = time.time() - t0
+    nreads, READ_LEN = base["reads"], base["read_len"]
+    offs = np.arange(nreads + 1, dtype=np.int64) * READ_LEN
+    res = {}
+    for key, seg in (("segLength5000", 5000), ("segLength10000", 10000)):
+        W = dict(base, seg=seg)
+        ctx = capi.Context(k=W["k"], segLength=seg, sketchSize=W["sketch"], flags=capi.MM_FLAG_HG_FILTER, device=local)
+        t0 = time.time()
+        ctx.index_build(ref_np, kmerPct=0.001)
+        index_s = time.time() - t0
+        ctx.set_tables_default(W["pi"])
+        nF = ctx.reads_upload_device(reads_t.data_ptr(), reads_t.numel(), offs, seqCounterBase=0)
+        dt, prof = timed_passes(ctx, warmup, steps)
+        step_ms = dt / steps * 1e3
+        n1, n2 = ctx.result_counts()
+        stats, _, _ = ctx.results()
+        nmap = len(ctx.mappings())
+        wl_key = "northstar" if seg == 5000 else "northstar_seg10000"
+        res[key] = {
+            "value": round(nreads * READ_LEN * steps / dt / 1e9, 4), "unit": "Gbp/s", "ms_per_step": round(step_ms, 3), "steps": steps, "warmup": warmup,
+            "kernels": {k: {"ms_per_step": v[0] / steps, "launches_per_step": v[1] / steps} for k, v in prof.items() if v[1]},
+            "roofline": roofline_block(ctx, capi, W, wl_key, nF, prof, step_ms, True),
+            "index_build_s": round(index_s, 2),
+            "workload": "%d x %d bp reads (10%% ONT-like error) vs %.0f Mbp synthetic reference (%d contigs), k %d, segLength %d, sketchSize %d, pi %.2f: "
+                        "%d fragments, %.1f interval points per fragment, %d L1 candidates, %d L2 loci, %d candidate mappings"
+                        % (nreads, READ_LEN, sum(len(a) for a in ref_np) / 1e6, len(ref_np), W["k"], seg, W["sketch"], W["pi"], nF,
+                           float(stats["nPoints"].mean()), n1, n2, nmap)}
+        log("[north_star] %s: %.1f Gbp/s, %.1f ms per pass, index %.1f s" % (key, res[key]["value"], step_ms, index_s))
+        ctx.close()
+        del ctx
+    out = dict(res["segLength5000"])
+    out["what"] = ("BASELINE.json north_star target (>= 50 query Gbp/s sketch+map on 1 x MI355X, 10 kbp reads at pi 85 against a human-scale index), measured in "
+                   "this run behind the headline configuration; inputs resident in HBM, same timed region as `value`")
+    out["target_gbps"] = 50.0
+    out["sketchSize_note"] = base["sketch_note"]
+    out["synthetic_data_s"] = round(gen_s, 2)
+    out["segLength_10000"] = res["segLength10000"]
+    return out
+
+
 class StubContext:
     """CPU stand-in used ONLY by tests/test_bench_spawn.py (--stub): lets the launcher / rank plumbing of this script run where there
     is no GPU.  It maps nothing; a line produced with it says "data": "stub"."""
@@ -270,13 +401,23 @@ def main():
     ap.add_argument("--reads", type=int, default=int(os.environ.get("MM_BENCH_READS", 0)), help="reads per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true")
+    ap.add_argument("--no-north-star", action="store_true", help="default run only: skip the north_star target measurement (3 Gbp index) behind the headline one")
+    ap.add_argument("--north-star-steps", type=int, default=5, help="timed passes of each north_star variant (at most --steps)")
     ap.add_argument("--ref-contigs", type=int, default=0, help="contigs of the synthetic reference (default: the workload's)")
     ap.add_argument("--ref-contig-len", type=int, default=0)
     ap.add_argument("--kmer", type=int, default=0, help="k-mer size (default: the reference's 19; other sizes are not the BASELINE configuration)")
     ap.add_argument("--cpu-sample", type=int, default=30000)
     ap.add_argument("--sync-exchange", action="store_true", help="N>1: all-gatherv on the compute stream instead of overlapped with the next batch")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--north-star-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if args.north_star_child:                           # the default run's second measurement (see north_star_target), one GPU
+        import torch
+        from mashmap_amd import capi
+        torch.cuda.set_device(0)
+        print(json.dumps(north_star_target(torch, torch.device("cuda", 0), capi, 0, args.warmup, args.steps)), flush=True)
+        return
 
     # ---- N ranks: start them ourselves unless a launcher already did
     if args.gpus < 1:
@@ -413,44 +554,7 @@ def main():
         bases_step = nreads * READ_LEN * world
         value = bases_step * args.steps / dt / 1e9
         step_ms = dt / args.steps * 1e3
-        # roofline of the dominant kernel (k_sketch_fast): algorithmic bytes per fragment = L/4 packed bases in
-        # + 24 B per sketch entry out, divided by its average HIP-event duration in the timed region
-        sk_ms, sk_n = prof["sketch"]
-        sk_avg = sk_ms / max(1, sk_n)
-        frag_bytes = SEG / 4.0 + 24.0 * SKETCH
-        ach = frag_bytes * nF / (sk_avg / 1e3) / 1e9 if sk_ms > 0 else 0.0
-        # integer roofline: the same fragments through a kernel that only hashes (2 x MurmurHash3_x64_128 per base)
-        integer = None
-        try:
-            hms = ctx.bench_hash_only(3)
-            integer = {"hash_only_ms": round(hms, 3), "hash_only_gbps": round(nF * SEG / hms / 1e6, 2),
-                       "sketch_kernel_frac": round(hms / sk_avg, 4) if sk_avg > 0 else None, "step_frac": round(hms / step_ms, 4),
-                       "note": "k_hash_only: same decomposition, staging and tables as k_sketch_fast, nothing but the two hashes per position; "
-                               "frac = its time / the kernel's (step's) time = share of the integer floor reached"}
-        except capi.MashmapError as e:
-            log("[bench] hash-only microbenchmark unavailable:", e)
-        # HBM bytes / VALU instructions per launch of that kernel from the committed PMC passes; only meaningful for the workload
-        # the passes were taken on (profiles/pmc_traffic.json names it)
-        traffic = None
-        valu = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc) and is_default:
-            try:
-                ent = json.load(open(pmc)).get("k_sketch_fast", {})
-                traffic = ent.get("hbm_bytes_per_launch")
-                ninst = ent.get("SQ_INSTS_VALU")
-                if ninst and sk_avg > 0:
-                    per_s = ninst / (sk_avg * 1e-3)
-                    mix = 3.35                          # cycles per wave-instruction of this kernel's VOP3/VOP2 mix (profiles/r02_valu_rate.txt, r02_sketch_instruction_mix.txt)
-                    valu = {"wave_instructions_per_launch": ninst,
-                            "util_vs_2_cycles_per_instr": round(per_s / (SIMDS * CLOCK_HZ / 2.0), 3),
-                            "util_vs_measured_mix": round(per_s / (SIMDS * CLOCK_HZ / mix), 3),
-                            "util_vs_4_cycles_per_instr": round(per_s / (SIMDS * CLOCK_HZ / 4.0), 3),
-                            "model": "1024 SIMDs x 2.4 GHz; three issue peaks: 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md nominal, SIMD-32), "
-                                     "%.2f cycles (this kernel's mix of VOP3 integer ops at ~4.2 and VOP2 ops at ~2.3 cycles measured by "
-                                     "scripts/probes/valu_rate.hip, output in profiles/), 4 cycles (every instruction at the VOP3 rate)" % mix}
-            except Exception:
-                traffic = None
+        roofline = roofline_block(ctx, capi, W, args.workload, nF, prof, step_ms, not scaled)
         kernels = {k: {"ms_per_step": v[0] / args.steps, "launches_per_step": v[1] / args.steps} for k, v in prof.items() if v[1]}
         P = float(stats["nPoints"].mean())
         ref_mbp = sum(ref_lens) / 1e6
@@ -470,21 +574,30 @@ def main():
                        "index_build_s": round(index_s, 2),
                        "identity_tables": "minimumHits / sketchCutoffs / acceptance from mm_stats.hpp's re-derivation of GSL's binomial and hypergeometric "
                                           "CDFs (GSL is not in the image; SURVEY section 8c: the one unpinned boundary)"},
-            "roofline": {"bound": "hbm", "kernel": "k_sketch_fast", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "algorithmic_bytes_per_fragment": frag_bytes, "avg_launch_ms": round(sk_avg, 3),
-                         "algorithmic_bytes_per_launch": frag_bytes * nF,
-                         "note": "integer-issue bound kernel (2 x MurmurHash3_x64_128 per base); the HBM fraction is small by construction -- "
-                                 "`int` (hash-only yardstick) and `valu` (issue peaks) are the rooflines that bind, DESIGN.md section 3",
-                         "int": integer, "valu": valu},
+            "roofline": roofline,
             "kernels": kernels,
         }
         if world == 1 and not args.no_host_path:
             out["host_path"] = host_path(ctx, W, nreads, ref_lens, step_ms)
         if want_cpu:
             out["cpu_baseline"] = cpu_baseline(W, ref_np, reads_np, min(args.cpu_sample, nreads))
+        if is_default and world == 1 and not args.no_north_star:
+            # in a process of its own, after this one has let go of its index and reads: whatever happens there, the headline line is printed
+            ctx.close(); ctx = None
+            del reads_np, ref_np
+            torch.cuda.empty_cache()
+            cmd = [sys.executable, os.path.abspath(__file__), "--north-star-child", "--steps", str(max(1, min(args.steps, args.north_star_steps))),
+                   "--warmup", str(min(args.warmup, 2))]
+            try:
+                p = subprocess.run(cmd, stdout=subprocess.PIPE, timeout=600, env=dict(os.environ, HIP_VISIBLE_DEVICES=os.environ.get("HIP_VISIBLE_DEVICES", str(local))))
+                line = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+                out["north_star_target"] = json.loads(line[-1]) if p.returncode == 0 and line else {"error": "child exited with %d" % p.returncode}
+            except Exception as e:
+                log("[bench] north_star target measurement failed:", repr(e))
+                out["north_star_target"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
-    ctx.close()
+    if ctx is not None:
+        ctx.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -198,9 +198,10 @@ int mm_sketch_download(mm_ctx* ctx, mm_minmer* out, uint32_t* counts);
 /*
  * The whole hot path for every resident fragment: sketch (a4) -> getSeedHits (a8) ->
  * getSeedIntervalPoints (a9) -> computeL1CandidateRegions (a10) -> computeL2MappedRegions for
- * every L1 candidate (a13).  Equivalent of the integer part of Map::mapSingleQueryFrag
- * (computeMap.hpp:756); identities and the best-first / early-exit replay of doL2Mapping
- * (:1182-1267) are host work on these integers.  Results stay on the device until downloaded.
+ * every L1 candidate (a13) -> doL2Mapping's best-first walk with its early exit and acceptance test
+ * (a12, :1182-1267; k_l2_select on the integer tables of mm_set_replay_tables) -> candidate mappings (mm_mapping).
+ * Equivalent of the integer part of Map::mapSingleQueryFrag (computeMap.hpp:756); only the floats of MappingResult
+ * (identity, upper bound, complexity) are host work on these integers.  Results stay on the device until downloaded.
  */
 int mm_map_fragments(mm_ctx* ctx);
 int mm_result_counts(const mm_ctx* ctx, size_t* nL1, size_t* nL2);

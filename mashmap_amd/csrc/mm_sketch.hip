@@ -554,12 +554,13 @@ k_sketch_fast(const uint4* __restrict__ gTabs, const uint32_t* __restrict__ base
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_hash_only<K>: the integer roofline's yardstick.  Same decomposition and staging as the fast sketch
-// kernel -- workgroup per fragment, thread per 16-position strip, packed words and hasher tables in LDS -- but nothing besides
-// the 2 x MurmurHash3_x64_128 per position: no N mask, no cut, no queues, no table.  The canonical hashes are folded into one
-// value per thread that is stored only if it equals an impossible constant, so the hashes stay live and nothing is written.
+// k_hash_only<K, SL>: the integer roofline's yardstick, at the fast sketch kernel's OWN geometry: workgroup per
+// fragment, the same thread count, the same SL positions per thread (window cut out of four LDS words), the same LDS claim (so the same
+// number of workgroups share a CU), packed words and hasher tables in LDS -- but nothing besides the 2 x MurmurHash3_x64_128 per
+// position: no N mask, no cut, no queues, no table.  The canonical hashes are folded into one value per thread that is stored only if
+// it equals an impossible constant, so the hashes stay live and nothing is written.
 // ---------------------------------------------------------------------------------------------
-template <int K>
+template <int K, int SL>
 __global__ void __launch_bounds__(1024)
 k_hash_only(const uint4* __restrict__ gTabs, const uint32_t* __restrict__ bases2, const DFrag* __restrict__ frags, uint64_t* __restrict__ sink) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -571,7 +572,7 @@ k_hash_only(const uint4* __restrict__ gTabs, const uint32_t* __restrict__ bases2
   Tabs* tabs = (Tabs*)smem;
   for (int i = tid; i < (int)(sizeof(Tabs) / 16); i += nthr) ((uint4*)tabs)[i] = gTabs[i];
   uint32_t* sW = (uint32_t*)(smem + sizeof(Tabs));
-  const int nW = (len + 15) / 16 + 3;
+  const int nW = (len + 15) / 16 + 4;
   {
     const int64_t w0 = fr.base >> 4; const int sh = (int)(fr.base & 15) * 2;
     for (int j = tid; j < nW; j += nthr) {
@@ -580,10 +581,18 @@ k_hash_only(const uint4* __restrict__ gTabs, const uint32_t* __restrict__ bases2
     }
   }
   __syncthreads();
-  const int nStrips = (n + 15) >> 4;
+  const int nStrips = (n + SL - 1) / SL;
   uint64_t acc = 0;
-  for (int strip = tid; strip < nStrips; strip += nthr)
-    mm_strip_hashes<K>(sW[strip], sW[strip + 1], sW[strip + 2], *tabs, [&](int j, uint64_t hf, uint64_t hr) { acc += hf < hr ? hf : hr; });
+  for (int strip = tid; strip < nStrips; strip += nthr) {
+    const int b0 = strip * SL;
+    const int wi = b0 >> 4, bsh = (b0 & 15) * 2;
+    uint32_t w0 = sW[wi], w1 = sW[wi + 1], w2 = sW[wi + 2];
+    if (SL % 16 != 0) {
+      const uint32_t w3 = sW[wi + 3];
+      if (bsh) { w0 = __builtin_amdgcn_alignbit(w1, w0, bsh); w1 = __builtin_amdgcn_alignbit(w2, w1, bsh); w2 = __builtin_amdgcn_alignbit(w3, w2, bsh); }
+    }
+    mm_strip_hashes<K, SL>(w0, w1, w2, *tabs, [&](int j, uint64_t hf, uint64_t hr) { acc += hf < hr ? hf : hr; });
+  }
   if (acc == 0x9E3779B97F4A7C15ull) sink[0] = acc;
 }
 
@@ -747,12 +756,13 @@ static int launch_hash_only_k(mm_ctx* c, int reps, double* msAvg) {
   using Tabs = typename MMTabsFor<K>::type;
   const int nF = (int)c->nFrags;
   const int maxLen = c->maxFragLen;
-  int nStrips = (maxLen - K + 1 + 15) / 16; if (nStrips < 1) nStrips = 1;
-  int threads = ((nStrips + 63) / 64) * 64; if (threads > 1024) threads = 1024;
-  size_t lds = sizeof(Tabs) + (((size_t)(maxLen + 15) / 16 + 3) * 4 + 15) / 16 * 16;
-  // MM_HASH_ONLY_LDS=bytes: claim that much LDS per workgroup (occupancy experiment: how the hash loop fares at the resident-wave
-  // count the sketch kernel's tables leave it)
-  if (const char* e = getenv("MM_HASH_ONLY_LDS")) { const size_t want = (size_t)atol(e); if (want > lds && want <= 160 * 1024) lds = want; }
+  // the sketch kernel's geometry for these fragments: positions per thread, threads per workgroup, LDS per workgroup
+  const FastGeom g = sketch_fast_geom(K, c->P.sketchSize, maxLen, sizeof(Tabs), MMHasSL20<K>::value);
+  const size_t need = sizeof(Tabs) + (((size_t)(maxLen + 15) / 16 + 4) * 4 + 15) / 16 * 16;
+  size_t lds = g.lds > need ? g.lds : need;
+  // MM_HASH_ONLY_LDS=bytes: claim that much LDS per workgroup instead (occupancy experiment); MM_HASH_ONLY_BARE=1: only what the kernel needs
+  if (getenv("MM_HASH_ONLY_BARE")) lds = need;
+  if (const char* e = getenv("MM_HASH_ONLY_LDS")) { const size_t want = (size_t)atol(e); if (want > need && want <= 160 * 1024) lds = want; }
   if (c->sketchTabsK != K) {
     MM_HIP(c, c->dSketchTabs.ensure(sizeof(Tabs)));
     hipLaunchKernelGGL((k_sketch_tables<K>), dim3(1), dim3(256), 0, c->stream, c->dSketchTabs.as<Tabs>());
@@ -760,12 +770,16 @@ static int launch_hash_only_k(mm_ctx* c, int reps, double* msAvg) {
     c->sketchTabsK = K;
   }
   MM_HIP(c, c->dCounters.ensure(256));
-  MM_HIP(c, hipFuncSetAttribute((const void*)k_hash_only<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   float total = 0;
   for (int r = 0; r <= reps; r++) {                 // launch 0 is a warm-up
     MM_HIP(c, hipEventRecord(c->evA, c->stream));
-    hipLaunchKernelGGL((k_hash_only<K>), dim3(nF), dim3(threads), lds, c->stream, c->dSketchTabs.as<uint4>(), c->dBases2.as<uint32_t>(), c->dFrags.as<DFrag>(),
-                       c->dCounters.as<uint64_t>() + 24);
+    auto launch = [&](auto kern) {
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(kern, dim3(nF), dim3(g.threads), lds, c->stream, c->dSketchTabs.as<uint4>(), c->dBases2.as<uint32_t>(), c->dFrags.as<DFrag>(),
+                         c->dCounters.as<uint64_t>() + 24);
+    };
+    if constexpr (MMHasSL20<K>::value) { if (g.SL == 20) launch(k_hash_only<K, 20>); else launch(k_hash_only<K, 16>); }
+    else launch(k_hash_only<K, 16>);
     MM_HIP(c, hipGetLastError());
     MM_HIP(c, hipEventRecord(c->evB, c->stream));
     MM_HIP(c, hipEventSynchronize(c->evB));

@@ -5,9 +5,10 @@
 // (:100-101, called once per reported MappingResult, :1802), same PAF text (:1758-1806).
 //
 // What moved: sketchSequence, getSeedHits, getSeedIntervalPoints, computeL1CandidateRegions and
-// computeL2MappedRegions (:818-1451) run on the GPU for a whole batch of reads at once (mm_map_fragments).  What stays
-// here, on host threads, is everything that touches floating point or std:: algorithm order:
-//   * the best-first / early-exit replay of doL2Mapping (:1182-1267) over the device's integer L2 loci,
+// computeL2MappedRegions (:818-1451) and the best-first / early-exit walk of doL2Mapping (:1182-1267, k_l2_select on integer tables
+// of its two float decisions) run on the GPU for a whole batch of reads at once (mm_map_fragments).  What stays here, on host
+// threads, is everything that touches floating point or std:: algorithm order:
+//   * the floats of MappingResult (nucIdentity, its upper bound, kmerComplexity) from the candidate mappings' integers,
 //   * chaining (mergeMappingsInRange :1580-1702), filterWeakMappings :423, the plane-sweep filters
 //     (filter.hpp:103-160 query axis, :334-396 reference axis), filterFalseHighIdentity :441,
 //     mappingBoundarySanityCheck :1714, sparsifyMappings :481 and the PAF writer.
