@@ -380,11 +380,10 @@ class StubContext:
         time.sleep(0.002)
 
     def allgatherv(self, dist):
-        import torch
-        from mashmap_amd import shard
-        mine = torch.full((3 + self.rank, shard.L2_WORDS), self.rank, dtype=torch.int32)
-        got, counts = shard.allgatherv_records(mine, dist)
-        assert got.shape[0] == sum(counts)
+        from mashmap_amd import capi, shard
+        mine = np.zeros(3 + self.rank, dtype=capi.MAPPING_DT); mine["querySeqId"] = self.rank
+        got, counts = shard.allgatherv_mappings(mine, dist)
+        assert len(got) == sum(counts) and (got["querySeqId"] == np.repeat(np.arange(len(counts)), counts)).all()
 
 
 def free_port():

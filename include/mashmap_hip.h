@@ -284,6 +284,9 @@ int mm_allgatherv_mappings_end(mm_ctx* ctx);
 int mm_allgatherv_mappings_local(mm_ctx** ctxs, int n);
 int mm_gathered_counts(const mm_ctx* ctx, size_t* perRank, size_t* total);
 int mm_gathered_download(mm_ctx* ctx, mm_mapping* out, size_t cap);
+/* device address of the gathered records.  Lifetime: valid until the next exchange of this context STARTS (mm_allgatherv_mappings,
+ * mm_allgatherv_mappings_local or mm_allgatherv_mappings_begin): the exchange may reallocate the buffer and rewrites the counts, from
+ * its own thread in the overlapped form -- consume (or copy) the records of batch i before calling _begin for batch i+1. */
 int mm_gathered_device(const mm_ctx* ctx, const mm_mapping** dMappings, size_t* total);
 int mm_index_replicate(mm_ctx* dst, mm_ctx* src);
 

@@ -15,9 +15,12 @@
 // RCCL is opened with dlopen on first use: single-GPU users of libmashmap_hip.so never load it.  Contexts of a local group that
 // share a device (two contexts on one GPU) cannot form an RCCL communicator; they exchange by device-to-device copies instead.
 #include "mm_internal.h"
+#include "mm_exchange_plan.h"
 #include <rccl/rccl.h>
 #include <dlfcn.h>
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -29,6 +32,7 @@ struct Rccl {
   decltype(&ncclCommInitRank) CommInitRank = nullptr;
   decltype(&ncclCommInitAll) CommInitAll = nullptr;
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclCommAbort) CommAbort = nullptr;        // optional
   decltype(&ncclAllGather) AllGather = nullptr;
   decltype(&ncclBroadcast) Broadcast = nullptr;
   decltype(&ncclGroupStart) GroupStart = nullptr;
@@ -43,16 +47,25 @@ Rccl* rccl_open(std::string& err) {
   std::lock_guard<std::mutex> lk(g_rcclMu);
   if (g_rccl.h) return &g_rccl;
   if (!g_rccl.err.empty()) { err = g_rccl.err; return nullptr; }
-  const char* names[] = {getenv("MASHMAP_HIP_RCCL"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-  void* h = nullptr;
-  for (const char* n : names) { if (n && *n && (h = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break; }
+  // A process that already has an RCCL mapped (torch ships its own librccl.so: bench.py's ranks run dist.init_process_group("nccl") beside
+  // this library's communicator) must not get a second copy of the library with its own global state: take the mapped one first
+  // (RTLD_NOLOAD), load one only if there is none.  MASHMAP_HIP_RCCL=path pins a file; MM_DEBUG / MASHMAP_HIP_TIMING log what was bound.
+  const char* names[] = {getenv("MASHMAP_HIP_RCCL"), "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+  void* h = nullptr; const char* how = "already mapped";
+  for (const char* n : names) { if (n && *n && (h = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD))) break; }
+  if (!h) { how = "loaded"; for (const char* n : names) { if (n && *n && (h = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break; } }
   if (!h) { g_rccl.err = std::string("cannot load RCCL (librccl.so.1): ") + (dlerror() ? dlerror() : "not found"); err = g_rccl.err; return nullptr; }
+  if (getenv("MM_DEBUG") || getenv("MASHMAP_HIP_TIMING")) {
+    Dl_info di; void* f = dlsym(h, "ncclGetUniqueId");
+    fprintf(stderr, "[mm] RCCL bound to %s (%s)\n", (f && dladdr(f, &di) && di.dli_fname) ? di.dli_fname : "?", how);
+  }
   bool ok = true;
   auto sym = [&](const char* n) { void* p = dlsym(h, n); if (!p) ok = false; return p; };
   g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))sym("ncclGetUniqueId");
   g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))sym("ncclCommInitRank");
   g_rccl.CommInitAll = (decltype(g_rccl.CommInitAll))sym("ncclCommInitAll");
   g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))sym("ncclCommDestroy");
+  g_rccl.CommAbort = (decltype(g_rccl.CommAbort))dlsym(h, "ncclCommAbort");
   g_rccl.AllGather = (decltype(g_rccl.AllGather))sym("ncclAllGather");
   g_rccl.Broadcast = (decltype(g_rccl.Broadcast))sym("ncclBroadcast");
   g_rccl.GroupStart = (decltype(g_rccl.GroupStart))sym("ncclGroupStart");
@@ -71,9 +84,10 @@ Rccl* rccl_open(std::string& err) {
 
 // slots of the gathered buffer from the per-rank counts
 void place(mm_ctx* c) {
-  c->gatherDisp.assign(c->gatherCounts.size() + 1, 0);
-  for (size_t r = 0; r < c->gatherCounts.size(); r++) c->gatherDisp[r + 1] = c->gatherDisp[r] + c->gatherCounts[r];
-  c->nGathered = c->gatherDisp.back();
+  const int world = (int)c->gatherCounts.size();
+  std::vector<uint64_t> cnt(c->gatherCounts.begin(), c->gatherCounts.end()), disp((size_t)world + 1, 0);
+  c->nGathered = (size_t)mm_exchange_place(cnt.data(), world, disp.data());
+  c->gatherDisp.assign(disp.begin(), disp.end());
 }
 
 // the `world` broadcasts of one rank (to be called between GroupStart / GroupEnd); `mine` = this rank's records
@@ -155,12 +169,20 @@ int mm_comm_init_local(mm_ctx** ctxs, int n) {
   bool distinct = true;
   for (int i = 0; i < n; i++) { devs[i] = ctxs[i]->device; for (int j = 0; j < i; j++) if (devs[j] == devs[i]) distinct = false; }
   for (int i = 0; i < n; i++) { mm_comm_release(ctxs[i]); ctxs[i]->commRank = i; ctxs[i]->commWorld = n; ctxs[i]->commCopy = true; }
-  if (distinct && n > 1) {
-    Rccl* R = rccl_open(c0->err);
-    if (!R) return MM_ERR_DEVICE;
+  // every context starts on the copy path (device / peer copies: always available inside one process); distinct GPUs move to RCCL
+  // broadcasts when a communicator can be had.  No RCCL, or a failing ncclCommInitAll, is not an error here -- the group stays on
+  // peer copies, with a warning -- unless MASHMAP_HIP_REQUIRE_RCCL is set.
+  if (distinct && n > 1 && !getenv("MASHMAP_HIP_NO_RCCL")) {
+    std::string why;
+    Rccl* R = rccl_open(why);
     std::vector<ncclComm_t> comms(n, nullptr);
-    MM_NCCL(c0, R, R->CommInitAll(comms.data(), n, devs.data()));
-    for (int i = 0; i < n; i++) { ctxs[i]->comm = comms[i]; ctxs[i]->commCopy = false; }
+    bool ok = R != nullptr;
+    if (ok) { const ncclResult_t r = R->CommInitAll(comms.data(), n, devs.data()); if (r != ncclSuccess) { ok = false; why = std::string("ncclCommInitAll: ") + R->GetErrorString(r); } }
+    if (ok) for (int i = 0; i < n; i++) { ctxs[i]->comm = comms[i]; ctxs[i]->commCopy = false; }
+    else {
+      if (getenv("MASHMAP_HIP_REQUIRE_RCCL")) { c0->err = why; return MM_ERR_DEVICE; }
+      fprintf(stderr, "[mm] warning: no RCCL communicator for the local group (%s); candidate mappings are exchanged by peer copies\n", why.c_str());
+    }
   }
   return MM_OK;
 }
@@ -237,8 +259,17 @@ int mm_allgatherv_mappings_local(mm_ctx** ctxs, int n) {
     MM_NCCL(c0, R, R->GroupStart());
     int rc = MM_OK;
     for (int i = 0; i < n && rc == MM_OK; i++) { (void)hipSetDevice(ctxs[i]->device); rc = issue_broadcasts(ctxs[i], ctxs[i], R, ctxs[i]->dMappings.p, ctxs[i]->stream); if (rc != MM_OK) c0->err = ctxs[i]->err; }
+    if (rc != MM_OK) {
+      // some ranks of the group have issued their broadcasts and others have not: completing the group could wait forever.  The
+      // communicators are abandoned (the group with them) and the contexts fall back to peer copies for whatever comes next.
+      std::string keep = c0->err;
+      if (R->CommAbort) for (int i = 0; i < n; i++) if (ctxs[i]->comm) { (void)R->CommAbort((ncclComm_t)ctxs[i]->comm); ctxs[i]->comm = nullptr; }
+      (void)R->GroupEnd();
+      for (int i = 0; i < n; i++) { ctxs[i]->comm = nullptr; ctxs[i]->commCopy = true; }
+      c0->err = keep;
+      return rc;
+    }
     MM_NCCL(c0, R, R->GroupEnd());
-    if (rc != MM_OK) return rc;
   } else {
     // contexts sharing a device: slot r of every context is a device copy of context r's records (mm_map_fragments has synchronised
     // every source stream)

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "skch_map_post.hpp"
+#include "../csrc/mm_exchange_plan.h"
 
 extern "C" {
 
@@ -59,5 +60,8 @@ int64_t mmh_post_batch(int k, int segLength, int sketchSize, float pi, int filte
   if (seconds) *seconds = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
   return n;
 }
+
+// slots of the all-gatherv of candidate mappings (mm_exchange_plan.h, what mm_comm.hip places its RCCL broadcasts by): disp[world + 1]
+uint64_t mmh_exchange_plan(const uint64_t* counts, int world, uint64_t* disp) { return mm_exchange_place(counts, world, disp); }
 
 }  // extern "C"

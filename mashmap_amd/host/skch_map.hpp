@@ -17,10 +17,10 @@
 // chains / filters / prints batch i on param.threads std::threads.  Output order == input order (ThreadPool.hpp:187-211).
 //
 // Device stage.  The kernels report, per fragment, the candidate mappings doL2Mapping would have pushed (mm_mapping, k_l2_select);
-// with several contexts (MASHMAP_HIP_DEVICES, one per GPU, index replicated by Sketch) a batch's reads are cut into contiguous
-// blocks of about equal bases, every context maps its block, and the blocks' candidate mappings are exchanged with one RCCL
-// all-gatherv (mm_allgatherv_mappings_local) -- rank-major == input order -- before the CPU filters, the one-to-one filter
-// (:358-405) included, see them.
+// with several contexts (MASHMAP_HIP_DEVICES, one per GPU, index replicated by Sketch) a batch -- 512 Mbp PER CONTEXT -- is cut into
+// contiguous blocks of about equal bases, every context maps its block and hands its records to the host (each GPU over its own
+// link; rank-major == input order) before the CPU filters, the one-to-one filter (:358-405) included, see them.
+// MASHMAP_HIP_EXCHANGE=allgather puts the device-side all-gatherv (mm_allgatherv_mappings_local, RCCL over xGMI) in front instead.
 #pragma once
 #include <malloc.h>
 
@@ -31,6 +31,7 @@
 #include <cstdint>
 #include <deque>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <functional>
 #include <iostream>
@@ -142,10 +143,12 @@ class Map {
     uint64_t totalBp = 0;
     std::ofstream outstrm(param.outFileName);
     MappingResultsVector_t allReadMappings;
-    const char* be = getenv("MASHMAP_HIP_BATCH_MBP");
-    const size_t batchBases = (size_t)((be ? atof(be) : 512.0) * 1e6);
+    // a batch = MASHMAP_HIP_BATCH_MBP (default 512 Mbp) PER CONTEXT: every GPU of a sharded run gets a block as large as the batch of a
+    // single-GPU run (tens of milliseconds of kernels), instead of an n-th of it
+    const QueryBatchPlan plan = queryBatchPlan(param.querySequences, ctxs.size());
+    const size_t batchBases = plan.batchBases;
     Channel parsed(2), mapped(2);
-    if (!getenv("MASHMAP_HIP_NO_MALLOPT")) {
+    if (!getenv("MASHMAP_HIP_NO_MALLOPT") && (!plan.inputKnown || plan.inputBytes > (256u << 20))) {
       // every batch allocates and frees a few megabyte-sized vectors (records, per-read results, PAF text) from three stages at once:
       // keep them on the heap instead of mmap/munmap per batch (each unmap interrupts every thread of the process), and keep the heap
       mallopt(M_MMAP_THRESHOLD, 32 << 20); mallopt(M_TRIM_THRESHOLD, 1 << 30); mallopt(M_TOP_PAD, 256 << 20);
@@ -205,6 +208,7 @@ class Map {
     }
     reader.join();
     poster.join();
+    HostBufferPool::instance().stop();                      // nobody asks for page-locked buffers any more
 
     if (param.filterMode == filter::ONETOONE) {            // :358-406
       const int n_mappings = (int)param.numMappingsForSegment - 1;
@@ -268,6 +272,15 @@ class Map {
     const Batch* next = parsed.peekFront();
     std::vector<size_t> nextCut;
     if (next && next->size()) nextCut = blocksOf(*next);
+    // How the blocks' candidate mappings reach the host stage.  One process drives all contexts here, so the records are wanted in
+    // host memory, once: by default every context downloads its own block (n copies in parallel, one per GPU's own link; rank-major
+    // concatenation == input order), which serves every filter mode -- the one-to-one filter (:358-405) runs on the host over all
+    // records either way.  MASHMAP_HIP_EXCHANGE=allgather keeps the device-side all-gatherv (mm_allgatherv_mappings_local: RCCL over
+    // xGMI between distinct GPUs) in front of a single download from context 0 -- the layout one-process-per-GPU runs need
+    // (bench.py --gpus N, mm_allgatherv_mappings_begin/_end).
+    const char* xe = getenv("MASHMAP_HIP_EXCHANGE");
+    const bool gatherOnDevice = nCtx > 1 && xe && std::string(xe) == "allgather";
+    std::vector<std::vector<mm_mapping>> blockRecs(gatherOnDevice || nCtx == 1 ? 0 : nCtx);
     auto runBlock = [&](size_t i) {
       mm_ctx* c = ctxs[i];
       const size_t b = cutAt[i], e = cutAt[i + 1];
@@ -278,6 +291,12 @@ class Map {
         if (mm_reads_prefetch(c, next->in.bases + o0, (size_t)(o1 - o0)) != MM_OK) die("mm_reads_prefetch", c);
       }
       if (mm_map_fragments(c) != MM_OK) die("mm_map_fragments", c);
+      if (!blockRecs.empty()) {
+        size_t nb = 0;
+        if (mm_mappings_count(c, &nb) != MM_OK) die("mm_mappings_count", c);
+        blockRecs[i].resize(nb);
+        if (nb && mm_mappings_download(c, blockRecs[i].data(), nb, &nb) != MM_OK) die("mm_mappings_download", c);
+      }
     };
     if (nCtx == 1) runBlock(0);
     else {
@@ -291,13 +310,18 @@ class Map {
       if (mm_mappings_count(ctx, &n) != MM_OK) die("mm_mappings_count");
       batch.recs.resize(n);
       if (mm_mappings_download(ctx, batch.recs.data(), n, &n) != MM_OK) die("mm_mappings_download");
-    } else {
+    } else if (gatherOnDevice) {
       if (mm_allgatherv_mappings_local(ctxs.data(), (int)nCtx) != MM_OK) die("mm_allgatherv_mappings_local");
       if (mm_gathered_counts(ctx, nullptr, &n) != MM_OK) die("mm_gathered_counts");
       batch.recs.resize(n);
       if (mm_gathered_download(ctx, batch.recs.data(), n) != MM_OK) die("mm_gathered_download");
+    } else {
+      for (const auto& v : blockRecs) n += v.size();
+      batch.recs.resize(n);
+      size_t at = 0;
+      for (const auto& v : blockRecs) { if (!v.empty()) std::memcpy(batch.recs.data() + at, v.data(), v.size() * sizeof(mm_mapping)); at += v.size(); }
     }
-    if (timing) std::cerr << "[mashmap_hip::timing] device stage (upload + pack + kernels" << (nCtx > 1 ? " + all-gatherv" : "") << " + download of " << n
+    if (timing) std::cerr << "[mashmap_hip::timing] device stage (upload + pack + kernels" << (gatherOnDevice ? " + all-gatherv" : "") << " + download of " << n
                           << " candidate mappings): " << std::chrono::duration<double>(skch::Time::now() - t0).count() << " s" << std::endl;
   }
 

@@ -81,10 +81,10 @@ class Sketch {
     }
     ctx_ = ctxs_[0];
     {
-      // page-locked buffers for the query batches skch::Map will read: locked in the background while the index is built
-      const char* be = getenv("MASHMAP_HIP_BATCH_MBP");
-      const size_t batchBytes = (size_t)((be ? atof(be) : 512.0) * 1e6);
-      HostBufferPool::instance().prefetch(8, batchBytes + batchBytes / 8 + (1u << 20));   // reader 1 + two queues of 2 + device 1 + post 1, one spare
+      // page-locked buffers for the query batches skch::Map will read: locked in the background while the index is built; sized and
+      // counted by what the query files hold (skch_types.hpp: queryBatchPlan)
+      const QueryBatchPlan plan = queryBatchPlan(p.querySequences, ctxs_.size());
+      HostBufferPool::instance().prefetch(plan.buffers, plan.bufferBytes);
     }
     if (!p.saveIndexFilename.empty()) mm_set_option(ctx_, MM_OPT_KEEP_FULL_INDEX, 1);
     this->build();

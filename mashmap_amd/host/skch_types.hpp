@@ -131,23 +131,37 @@ static const std::string VERSION = "3.1.3";
 #endif
 
 // Page-locked batch buffers for the query reader (skch::Map).  Locking pages costs about a second per few GB, so the buffers are
-// allocated by a background thread while skch::Sketch builds the reference index, and recycled between batches afterwards.
+// allocated by a background thread while skch::Sketch builds the reference index, and recycled between batches afterwards.  Their
+// size and number follow the query files (queryBatchPlan): a small job locks one small buffer, not gigabytes; the background thread
+// stops as soon as nobody will ask any more (stop(): skch::Map when mapping has finished, and the destructor).
+#include <sys/stat.h>
+#include <algorithm>
+#include <atomic>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <condition_variable>
 #include <mutex>
+#include <string>
 #include <thread>
 #include <utility>
+#include <vector>
 extern "C" { void* mm_host_alloc(size_t bytes); void mm_host_free(void* p); }
 namespace skch {
 class HostBufferPool {
-  std::mutex mu_; std::condition_variable cv_; std::vector<std::pair<char*, size_t>> free_; std::thread bg_; size_t pending_ = 0;
+  std::mutex mu_; std::condition_variable cv_; std::vector<std::pair<char*, size_t>> free_; std::thread bg_; size_t pending_ = 0; std::atomic<bool> stop_{false};
  public:
   static HostBufferPool& instance() { static HostBufferPool p; return p; }
-  ~HostBufferPool() { if (bg_.joinable()) bg_.join(); for (auto& b : free_) mm_host_free(b.first); }
+  ~HostBufferPool() { stop(); for (auto& b : free_) mm_host_free(b.first); }
+  // no further buffers will be asked for: the background thread ends after the allocation it is in
+  void stop() { stop_ = true; if (bg_.joinable()) bg_.join(); std::lock_guard<std::mutex> lk(mu_); pending_ = 0; cv_.notify_all(); }
   void prefetch(size_t n, size_t bytes) {
     if (bg_.joinable()) bg_.join();
+    stop_ = false;
     { std::lock_guard<std::mutex> lk(mu_); pending_ = n; }
     bg_ = std::thread([this, n, bytes]() {
       for (size_t i = 0; i < n; i++) {
+        if (stop_) { std::lock_guard<std::mutex> lk(mu_); pending_ = 0; cv_.notify_all(); return; }
         char* p = (char*)mm_host_alloc(bytes);
         std::lock_guard<std::mutex> lk(mu_);
         if (p) free_.emplace_back(p, bytes);
@@ -166,5 +180,29 @@ class HostBufferPool {
   }
   void give(char* p, size_t bytes) { if (!p) return; std::lock_guard<std::mutex> lk(mu_); free_.emplace_back(p, bytes); cv_.notify_all(); }
 };
-}  // namespace skch
 
+// How skch::Map takes the query files through the GPUs: bases per batch (MASHMAP_HIP_BATCH_MBP, default 512 Mbp, PER GPU CONTEXT -- a
+// batch is cut into one block per context, and a block is what keeps a GPU busy for tens of milliseconds), and the page-locked buffers
+// that go with it: as many as batches can be in flight at once (reader 1 + two queues of 2 + device 1 + post 1 + one spare), but no more
+// than the input needs, each no larger than the input.
+struct QueryBatchPlan { size_t batchBases; size_t bufferBytes; size_t buffers; uint64_t inputBytes; bool inputKnown; };
+inline QueryBatchPlan queryBatchPlan(const std::vector<std::string>& queryFiles, size_t nContexts) {
+  const char* be = getenv("MASHMAP_HIP_BATCH_MBP");
+  QueryBatchPlan q;
+  q.batchBases = (size_t)((be ? atof(be) : 512.0) * 1e6) * (nContexts ? nContexts : 1);
+  q.inputBytes = 0; q.inputKnown = !queryFiles.empty();
+  for (const auto& f : queryFiles) {
+    struct stat st;
+    if (stat(f.c_str(), &st) != 0 || !S_ISREG(st.st_mode)) { q.inputKnown = false; continue; }     // a pipe: size unknown
+    bool gz = false;
+    if (FILE* fp = fopen(f.c_str(), "rb")) { unsigned char m[2] = {0, 0}; gz = fread(m, 1, 2, fp) == 2 && m[0] == 31 && m[1] == 139; fclose(fp); }
+    q.inputBytes += (uint64_t)st.st_size * (gz ? 5u : 1u);           // DNA text deflates to between a fifth and a third
+  }
+  const size_t full = q.batchBases + q.batchBases / 8 + (1u << 20);
+  if (!q.inputKnown) { q.bufferBytes = full; q.buffers = 8; return q; }
+  const uint64_t batches = q.inputBytes / q.batchBases + 1;
+  q.bufferBytes = (size_t)std::min<uint64_t>(full, q.inputBytes + q.inputBytes / 8 + (1u << 20));
+  q.buffers = (size_t)std::min<uint64_t>(8, batches + 1);
+  return q;
+}
+}  // namespace skch

@@ -1,12 +1,44 @@
-"""Read-block arithmetic of the multi-GPU layout: one process per GPU, reads sharded in contiguous blocks, index
-replicated.  The exchange step of the product is the RCCL all-gatherv inside libmashmap_hip.so (mashmap_amd/csrc/mm_comm.hip:
-mm_allgatherv_mappings), which bench.py and skch::Map call; `allgatherv_records` below is the same collective over torch.distributed,
-kept for the CPU tests (gloo) that pin down the layout -- rank-major records, contiguous read blocks == input order -- where no GPU
-and no RCCL exist.
-"""
+"""Host-side plumbing of the multi-GPU layout: one process per GPU, reads sharded in contiguous blocks, index
+replicated, ONE exchange step -- the all-gatherv of the candidate mappings (mm_mapping, 48 bytes) before the CPU filters.
+
+In the product that exchange is RCCL inside libmashmap_hip.so (mashmap_amd/csrc/mm_comm.hip: a count all-gather, then `world`
+broadcasts, root r into slot r of the gathered buffer).  `allgatherv_mappings` below runs the SAME protocol over a torch.distributed
+group -- slots placed by the product's own mm_exchange_plan.h (through libmashmap_host.so: mmh_exchange_plan) -- so that the layout
+contract (rank-major records == input order, no padding, empty slots skipped alike by every rank) is exercised by world-size-2 gloo
+processes where no GPU and no RCCL exist (tests/test_shard_gloo.py, bench.py --stub)."""
+import ctypes as C
+import os
+
 import numpy as np
 
-L2_WORDS = 8          # int32 words per mm_l2_locus: frag, cand, seqId, meanOptimalPos, optimalStart, optimalEnd, sharedSketchSize, strand
+HERE = os.path.dirname(os.path.abspath(__file__))
+HOST_LIB = os.path.join(HERE, "lib", "libmashmap_host.so")
+_host = None
+
+
+def host_lib():
+    """libmashmap_host.so: the CPU half of the product (exchange plan, MapPost = chaining + filters); no GPU needed"""
+    global _host
+    if _host is None:
+        if not os.path.exists(HOST_LIB):
+            raise RuntimeError("%s not built (make -C mashmap_amd/host)" % HOST_LIB)
+        lib = C.CDLL(HOST_LIB)
+        lib.mmh_exchange_plan.restype = C.c_uint64
+        lib.mmh_exchange_plan.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        lib.mmh_post_batch.restype = C.c_int64
+        lib.mmh_post_batch.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t,
+                                       C.c_void_p, C.c_size_t, C.c_int32, C.c_int, C.POINTER(C.c_double), C.c_void_p, C.c_size_t]
+        _host = lib
+    return _host
+
+
+def exchange_plan(counts):
+    """slot displacements (records) of the gathered buffer from the per-rank record counts: disp[r] .. disp[r+1] is rank r's slot"""
+    cnt = np.ascontiguousarray(counts, dtype=np.uint64)
+    disp = np.zeros(len(cnt) + 1, dtype=np.uint64)
+    total = host_lib().mmh_exchange_plan(cnt.ctypes.data, len(cnt), disp.ctypes.data)
+    assert int(disp[-1]) == int(total)
+    return disp
 
 
 def read_block(n_reads, rank, world):
@@ -19,7 +51,7 @@ def read_block(n_reads, rank, world):
 
 def read_block_by_bases(read_lengths, rank, world):
     """same, balancing bases instead of read counts (reads of very different lengths): cut points at equal shares of the
-    cumulative length; deterministic and identical on every rank"""
+    cumulative length; deterministic and identical on every rank (skch::Map::blocksOf cuts a batch the same way)"""
     lens = np.asarray(read_lengths, dtype=np.int64)
     cum = np.concatenate([[0], np.cumsum(lens)])
     total = int(cum[-1])
@@ -30,41 +62,25 @@ def read_block_by_bases(read_lengths, rank, world):
     return cuts[rank], cuts[rank + 1]
 
 
-def allgatherv_records(local, dist, device=None, words=L2_WORDS):
-    """all-gatherv of an (n_local, words) int32 tensor; returns (gathered (N, words) tensor, counts list).
-    Counts first (one all_gather of a scalar per rank), then one padded all_gather; rank r's records land at
-    sum(counts[:r]) in the result."""
+def allgatherv_mappings(local, dist, device=None):
+    """the exchange step over a torch.distributed group.  local: this rank's candidate mappings, a numpy structured array of 48-byte
+    records (capi.MAPPING_DT).  Returns (all ranks' records, rank-major; counts).  Protocol of mm_comm.hip::exchange: counts first
+    (one all_gather of a scalar), slots from mm_exchange_plan.h, then one broadcast per non-empty slot, root r -> slot r."""
     import torch
-    world = dist.get_world_size()
-    device = device if device is not None else local.device
-    n = torch.tensor([local.shape[0]], dtype=torch.int64, device=device)
+    world, rank = dist.get_world_size(), dist.get_rank()
+    rec = local.dtype.itemsize
+    n = torch.tensor([len(local)], dtype=torch.int64, device=device)
     counts_t = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
     dist.all_gather(counts_t, n)
     counts = [int(c.item()) for c in counts_t]
-    mx = max(counts) if counts else 0
-    if mx == 0:
-        return torch.zeros((0, words), dtype=torch.int32, device=device), counts
-    mine = torch.zeros((mx, words), dtype=torch.int32, device=device)
-    mine[:local.shape[0]] = local
-    if dist.get_backend() == "nccl":
-        buf = torch.empty((world * mx, words), dtype=torch.int32, device=device)
-        dist.all_gather_into_tensor(buf, mine)
-        parts = [buf[r * mx:r * mx + counts[r]] for r in range(world)]
-    else:
-        bufs = [torch.empty((mx, words), dtype=torch.int32, device=device) for _ in range(world)]
-        dist.all_gather(bufs, mine)
-        parts = [bufs[r][:counts[r]] for r in range(world)]
-    return torch.cat(parts, dim=0), counts
-
-
-def globalise_fragments(gathered, counts, frags_per_rank):
-    """rewrite the rank-local fragment ids (column 0) of gathered records into global fragment ids: rank r's fragments
-    follow those of ranks < r (reads are sharded in contiguous blocks, so this is the single-GPU numbering)"""
-    import torch
-    out = gathered.clone()
-    off, base = 0, 0
-    for r, c in enumerate(counts):
-        out[off:off + c, 0] += base
-        off += c
-        base += int(frags_per_rank[r])
-    return out
+    disp = exchange_plan(counts)
+    buf = torch.zeros(int(disp[-1]) * rec, dtype=torch.uint8, device=device)
+    mine = torch.from_numpy(np.frombuffer(local.tobytes(), dtype=np.uint8).copy()).to(buf.device)
+    for r in range(world):
+        if counts[r] == 0:
+            continue
+        slot = buf[int(disp[r]) * rec:int(disp[r + 1]) * rec]
+        if r == rank:
+            slot.copy_(mine)
+        dist.broadcast(slot, src=r)
+    return np.frombuffer(buf.cpu().numpy().tobytes(), dtype=local.dtype), counts

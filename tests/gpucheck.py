@@ -17,8 +17,10 @@ def prefix_groups(names, delim):
 
 
 def run_and_compare(oracle, contigs, reads, k=19, L=5000, s=130, pi=0.85, flags=U.FLAG_HG, delim="\0", kmerPct=0.001,
-                    seqCounterBase=0, check_points=True, verbose=True, mutate_index=None):
-    """contigs: [(name, uint8 array)], reads: [(name, uint8 array)].  Returns (nFragments, nMappedLoci)."""
+                    seqCounterBase=0, check_points=True, verbose=True, mutate_index=None, device_index=False):
+    """contigs: [(name, uint8 array)], reads: [(name, uint8 array)].  Returns (nFragments, nMappedLoci).
+    device_index: the context builds its own index from the contigs' bases (mm_index_build: a5-a7 on the device) instead of taking the
+    oracle's -- every stage downstream is then checked against the oracle on top of the DEVICE-built index."""
     from mashmap_amd import capi
     h = oracle.session(contigs, k, L, s, pi, U.FILTER_MAP, flags, delim.encode() if delim != "\0" else b"\0", kmerPct, mutate_index=mutate_index)
     ix = oracle.export_index(h)
@@ -37,7 +39,11 @@ def run_and_compare(oracle, contigs, reads, k=19, L=5000, s=130, pi=0.85, flags=
             p = n[:n.rfind(delim)] if delim in n else n
             readGroup.append(refGroup[pre.index(p)] if p in pre else -1)
     selfId = [cnames.index(n) if n in cnames else -1 for n, _ in reads]
-    ctx.index_upload(ix["minmers"], ix["keys"], ix["offsets"], ix["points"], ix["freq"], ix["contigLen"], refGroup)
+    if device_index:
+        assert mutate_index is None
+        ctx.index_build([a for _, a in contigs], refGroup, kmerPct)
+    else:
+        ctx.index_upload(ix["minmers"], ix["keys"], ix["offsets"], ix["points"], ix["freq"], ix["contigLen"], refGroup)
     ctx.set_tables(oracle.min_hits_table(s, k, pi), oracle.cutoffs(h))
     ctx.set_replay_tables(*capi.stat_replay_tables(s, k, pi, 0.0, not (flags & U.FLAG_DROP_LOW_ID)))
     nF = ctx.reads_upload([a for _, a in reads], readGroup, selfId, seqCounterBase)

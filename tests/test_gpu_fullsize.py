@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 K, SEG, SKETCH, PI = 19, 5000, 130, 0.85
-N_READS, READ_LEN, N_SAMPLE = 1_000_000, 10_000, 1000
+N_READS, READ_LEN, N_SAMPLE = 1_000_000, 10_000, 10_000      # 1 % of the reads go through the oracle, integer for integer
 
 
 def _rows_by_fragment(l1, l2, reads=None, per=2):

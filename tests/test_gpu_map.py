@@ -34,6 +34,19 @@ def test_map_default_config(oracle):
     assert nF > 300 and nl > 250
 
 
+@pytest.mark.parametrize("flags,delim,kmerPct", [(U.FLAG_HG, "\0", 0.001), (U.FLAG_HG, "\0", 0.5), (U.FLAG_HG | U.FLAG_SKIP_PREFIX, "#", 0.001)])
+def test_map_against_the_device_built_index(oracle, flags, delim, kmerPct):
+    """index -> map stage by stage at small size: mm_index_build (a5-a7 on the device) feeds the map kernels, and every integer of every
+    stage must still equal the oracle's -- the other tests upload the ORACLE's index; the full-size test samples"""
+    names = ["hapA#1#chr1", "hapA#1#chr2", "hapB#1#chr1"] if delim == "#" else None
+    contigs = genome(111, [400000, 300000, 200000], names=names)
+    reads = reads_for(contigs, 15, 100, 10000, 0.10) + reads_for(contigs, 16, 20, 7777, 0.04)
+    if delim == "#":
+        reads = [("hapA#1#r%d" % i if i % 2 else "hapC#9#r%d" % i, a) for i, (_, a) in enumerate(reads)]
+    nF, nl = run_and_compare(oracle, contigs, reads, flags=flags, delim=delim, kmerPct=kmerPct, device_index=True)
+    assert nF > 200 and nl > 100
+
+
 def test_map_frequent_seeds(oracle):
     contigs = genome(21, [300000, 250000, 200000])
     reads = reads_for(contigs, 7, 80, 10000, 0.08)

@@ -148,6 +148,10 @@ def test_paf_of_a_sharded_run_is_the_single_gpu_paf(name, tmp_path):
     for devs in lists:
         got = _run(str(tmp_path), name, refrec, qrec, extra, "d" + devs.replace(",", ""), devs)
         assert got == exp, "MASHMAP_HIP_DEVICES=%s differs from the golden PAF" % devs
-    # small batches: several exchanges per run, some blocks empty
-    got = _run(str(tmp_path), name, refrec, qrec, extra, "small", "0,0,0", env_extra={"MASHMAP_HIP_BATCH_MBP": "0.03"})
+    # small batches: several exchanges per run, some blocks empty (the batch size is per context: 3 x 0.01 Mbp)
+    got = _run(str(tmp_path), name, refrec, qrec, extra, "small", "0,0,0", env_extra={"MASHMAP_HIP_BATCH_MBP": "0.01"})
     assert got == exp
+    # the device-side all-gatherv in front of a single download (the default hands every context's block to the host directly)
+    for devs, mbp in (("0,0", "512"), ("0,0,0", "0.01")):
+        got = _run(str(tmp_path), name, refrec, qrec, extra, "gather" + devs.replace(",", ""), devs, env_extra={"MASHMAP_HIP_EXCHANGE": "allgather", "MASHMAP_HIP_BATCH_MBP": mbp})
+        assert got == exp, "MASHMAP_HIP_EXCHANGE=allgather with MASHMAP_HIP_DEVICES=%s differs from the golden PAF" % devs
