@@ -187,6 +187,26 @@ void  mm_host_free(void* p);
  * stream (mm_stream): work of the caller's stream that produces them must have completed before the call. */
 int mm_reads_upload_device(mm_ctx* ctx, const void* dBases, size_t nBases, const int64_t* readOffsets, size_t nReads,
                            const int32_t* readRefGroup, const int32_t* readSelfSeqId, int32_t seqCounterBase);
+/*
+ * The same batch for a caller that has normalised and packed the reads itself (the layout k_pack2bit produces on the device, DESIGN.md
+ * section 2): PCIe then carries 0.375 bytes per base instead of 1.  Read r has readLengths[r] bases and starts at packed base
+ * P(r) = sum over earlier reads of ceil(len / 32) * 32:
+ *   bases2  2 bit/base, A0 C1 G2 T3 (the code of an N is 0), sixteen bases per uint32, first base in the low bits; read r owns the words
+ *           [P(r) / 16, P(r+1) / 16), bases behind its end are 0
+ *   nmask   1 bit/base, set where makeUpperCaseAndValidDNA (commonFunc.hpp:97) leaves an 'N' (anything but A C G T a c g t); read r owns
+ *           the words [P(r) / 32, P(r+1) / 32)
+ *   readHasN[r] != 0 iff any mask bit of read r is set; NULL: derived from nmask here
+ * mm_pack_read produces the words of one read on the host (AVX2 + BMI2 when the CPU has them; mm_pack_read_portable is the plain loop,
+ * same result): 2 * ceil(len / 32) code words and ceil(len / 32) mask words; returns the number of N bases.
+ * mm_reads_prefetch_packed is mm_reads_prefetch for the next mm_reads_upload_packed (same two pointers, nPackedBases = P(nReads)).
+ * mm_reads_packed_download returns the resident packed batch of any upload (parity tests); any pointer may be NULL.
+ */
+int mm_reads_upload_packed(mm_ctx* ctx, const uint32_t* bases2, const uint32_t* nmask, const uint8_t* readHasN, const int32_t* readLengths,
+                           size_t nReads, const int32_t* readRefGroup, const int32_t* readSelfSeqId, int32_t seqCounterBase);
+int mm_reads_prefetch_packed(mm_ctx* ctx, const uint32_t* bases2, const uint32_t* nmask, size_t nPackedBases);
+size_t mm_pack_read(const char* ascii, size_t len, uint32_t* bases2, uint32_t* nmask);
+size_t mm_pack_read_portable(const char* ascii, size_t len, uint32_t* bases2, uint32_t* nmask);
+int mm_reads_packed_download(mm_ctx* ctx, uint32_t* bases2, uint32_t* nmask, uint32_t* readHasN, size_t* nPackedBases);
 size_t mm_num_fragments(const mm_ctx* ctx);
 int mm_fragments_download(mm_ctx* ctx, mm_fragment* out);
 

@@ -119,6 +119,11 @@ def load():
         "mm_gathered_device": (C.c_int, [vp, C.POINTER(vp), C.POINTER(sz)]),
         "mm_index_replicate": (C.c_int, [vp, vp]),
         "mm_reads_prefetch": (C.c_int, [vp, vp, sz]),
+        "mm_reads_upload_packed": (C.c_int, [vp, vp, vp, vp, vp, sz, vp, vp, i32]),
+        "mm_reads_prefetch_packed": (C.c_int, [vp, vp, vp, sz]),
+        "mm_pack_read": (sz, [vp, sz, vp, vp]),
+        "mm_pack_read_portable": (sz, [vp, sz, vp, vp]),
+        "mm_reads_packed_download": (C.c_int, [vp, vp, vp, vp, C.POINTER(sz)]),
         "mm_synchronize": (C.c_int, [vp]),
         "mm_stream": (vp, [vp]),
     }
@@ -141,7 +146,8 @@ EXPORTS = ["mm_abi_version", "mm_create", "mm_destroy", "mm_last_error", "mm_ind
            "mm_set_replay_tables", "mm_mappings_count", "mm_mappings_download", "mm_mappings_device", "mm_comm_unique_id",
            "mm_comm_init_rank", "mm_comm_init_local", "mm_comm_world", "mm_allgatherv_mappings", "mm_allgatherv_mappings_local",
            "mm_allgatherv_mappings_begin", "mm_allgatherv_mappings_end",
-           "mm_gathered_counts", "mm_gathered_download", "mm_gathered_device", "mm_index_replicate", "mm_stat_replay_tables", "mm_host_alloc", "mm_host_free", "mm_reads_prefetch"]
+           "mm_gathered_counts", "mm_gathered_download", "mm_gathered_device", "mm_index_replicate", "mm_stat_replay_tables", "mm_host_alloc", "mm_host_free", "mm_reads_prefetch",
+           "mm_reads_upload_packed", "mm_reads_prefetch_packed", "mm_pack_read", "mm_pack_read_portable", "mm_reads_packed_download"]
 
 
 def stat_sketch_cutoffs(sketchSize, k, hg=True):
@@ -177,6 +183,23 @@ def stat_replay_tables(sketchSize, k, pi, aniDiff=0.0, keepLow=True):
     if load().mm_stat_replay_tables(sketchSize, k, pi, aniDiff, 1 if keepLow else 0, _ptr(acc), _ptr(mi)) != 0:
         raise MashmapError("mm_stat_replay_tables failed")
     return acc, mi
+
+
+def pack_reads(reads, portable=False):
+    """host-side makeUpperCaseAndValidDNA + 2-bit packing of a list of uint8 arrays (mm_pack_read; no GPU needed): the arrays
+    mm_reads_upload_packed takes -- (bases2 uint32, nmask uint32, hasN uint8, lengths int32)"""
+    lib = load()
+    fn = lib.mm_pack_read_portable if portable else lib.mm_pack_read
+    lens = np.array([len(r) for r in reads], dtype=np.int32)
+    groups = (lens.astype(np.int64) + 31) // 32
+    start = np.concatenate([[0], np.cumsum(groups)])
+    b2 = np.zeros(max(1, int(start[-1]) * 2), dtype=np.uint32); nm = np.zeros(max(1, int(start[-1])), dtype=np.uint32)
+    hasn = np.zeros(max(1, len(reads)), dtype=np.uint8)
+    for i, r in enumerate(reads):
+        a = np.ascontiguousarray(r, dtype=np.uint8)
+        nN = fn(_ptr(a), len(a), C.c_void_p(b2.ctypes.data + 8 * int(start[i])), C.c_void_p(nm.ctypes.data + 4 * int(start[i])))
+        hasn[i] = 1 if nN else 0
+    return b2[:int(start[-1]) * 2] if start[-1] else b2[:0], nm[:int(start[-1])] if start[-1] else nm[:0], hasn[:len(reads)], lens
 
 
 class Context:
@@ -261,7 +284,29 @@ class Context:
         rg = np.ascontiguousarray(refGroup, dtype=np.int32) if refGroup is not None else None
         ss = np.ascontiguousarray(selfSeqId, dtype=np.int32) if selfSeqId is not None else None
         self._ck(self.lib.mm_reads_upload(self.h, _ptr(buf), _ptr(offs), n, _ptr(rg), _ptr(ss), seqCounterBase), "mm_reads_upload")
+        self._nreads = n
         return self.num_fragments()
+
+    def reads_upload_packed(self, packed, refGroup=None, selfSeqId=None, seqCounterBase=0, prefetch=False):
+        """packed: what pack_reads() returns (bases2, nmask, hasN, lengths); prefetch=True sends the words ahead with mm_reads_prefetch_packed"""
+        b2, nm, hasn, lens = packed
+        rg = np.ascontiguousarray(refGroup, dtype=np.int32) if refGroup is not None else None
+        ss = np.ascontiguousarray(selfSeqId, dtype=np.int32) if selfSeqId is not None else None
+        if prefetch:
+            self._ck(self.lib.mm_reads_prefetch_packed(self.h, _ptr(b2), _ptr(nm), nm.size * 32), "mm_reads_prefetch_packed")
+        self._ck(self.lib.mm_reads_upload_packed(self.h, _ptr(b2), _ptr(nm), _ptr(hasn), _ptr(lens), len(lens), _ptr(rg), _ptr(ss), seqCounterBase),
+                 "mm_reads_upload_packed")
+        self._nreads = len(lens)
+        return self.num_fragments()
+
+    def reads_packed_download(self):
+        n = C.c_size_t()
+        self._ck(self.lib.mm_reads_packed_download(self.h, None, None, None, C.byref(n)), "mm_reads_packed_download")
+        b2 = np.zeros(n.value // 16, dtype=np.uint32); nm = np.zeros(n.value // 32, dtype=np.uint32)
+        nreads = C.c_size_t()
+        hasn = np.zeros(max(1, self._nreads), dtype=np.uint32)
+        self._ck(self.lib.mm_reads_packed_download(self.h, _ptr(b2), _ptr(nm), _ptr(hasn), C.byref(n)), "mm_reads_packed_download")
+        return b2, nm, hasn[:self._nreads]
 
     def reads_prefetch(self, buf):
         """start the H2D copy of the concatenated uint8 array the next reads_upload((buf, offs)) will pass (the array must stay alive
@@ -275,6 +320,7 @@ class Context:
         ss = np.ascontiguousarray(selfSeqId, dtype=np.int32) if selfSeqId is not None else None
         self._ck(self.lib.mm_reads_upload_device(self.h, C.c_void_p(dptr), nbytes, _ptr(offs), len(offs) - 1, _ptr(rg), _ptr(ss),
                                                  seqCounterBase), "mm_reads_upload_device")
+        self._nreads = len(offs) - 1
         return self.num_fragments()
 
     def num_fragments(self):

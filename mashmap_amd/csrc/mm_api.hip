@@ -4,6 +4,7 @@
 #include <cstring>
 #include <thread>
 #include "../host/mm_stats.hpp"
+#include "../host/pack2bit.hpp"
 
 static thread_local std::string g_createErr;
 
@@ -164,9 +165,17 @@ int mm_stat_sketch_cutoffs(int sketchSize, int k, int hgFilter, int32_t* out, si
 // ---------------------------------------------------------------------------------------------
 // reads
 // ---------------------------------------------------------------------------------------------
-static int upload_reads_common(mm_ctx* c, const void* src, bool srcOnDevice, size_t nBasesTotal, const int64_t* readOffsets,
-                               size_t nReads, const int32_t* readRefGroup, const int32_t* readSelfSeqId, int32_t seqCounterBase) {
-  if (!readOffsets || (nBasesTotal && !src)) { c->err = "mm_reads_upload: null argument"; return MM_ERR_ARG; }
+// where the bases of an upload come from: ASCII in host memory, ASCII in device memory, or already packed in host memory
+struct ReadSource {
+  const void* ascii = nullptr; bool onDevice = false;
+  const uint32_t* b2 = nullptr; const uint32_t* nm = nullptr; const uint8_t* hasN = nullptr; const int32_t* lengths = nullptr;   // packed form
+  bool packed() const { return b2 != nullptr || lengths != nullptr; }
+};
+
+static int upload_reads_common(mm_ctx* c, const ReadSource& S, const int64_t* readOffsets, size_t nReads, const int32_t* readRefGroup,
+                               const int32_t* readSelfSeqId, int32_t seqCounterBase) {
+  const bool packed = S.packed();
+  if (packed ? (nReads && !S.lengths) : !readOffsets) { c->err = "mm_reads_upload: null argument"; return MM_ERR_ARG; }
   MM_HIP(c, hipSetDevice(c->device));
   const int k = c->P.kmerSize, L = c->P.segLength;
   const bool split = !(c->P.flags & MM_FLAG_NO_SPLIT);
@@ -176,10 +185,10 @@ static int upload_reads_common(mm_ctx* c, const void* src, bool srcOnDevice, siz
   std::vector<DFrag> dfr;
   int64_t pk = 0; int32_t maxLen = 0;
   for (size_t r = 0; r < nReads; r++) {
-    const int64_t len64 = readOffsets[r + 1] - readOffsets[r];
+    const int64_t len64 = packed ? (int64_t)S.lengths[r] : readOffsets[r + 1] - readOffsets[r];
     if (len64 < 0 || len64 > 0x7fffffff) { c->err = "mm_reads_upload: read length out of range (offset_t is int32, base_types.hpp:21)"; return MM_ERR_ARG; }
     const int32_t len = (int32_t)len64;
-    srcOff[r] = readOffsets[r]; packOff[r] = pk; rlen[r] = len;
+    srcOff[r] = packed ? 0 : readOffsets[r]; packOff[r] = pk; rlen[r] = len;
     if (len >= k) {                                   // computeMap.hpp:325 (shorter reads are skipped)
       if (!split || len <= L) {                       // :587
         if (len > L) { c->err = "mm_reads_upload: a read longer than segLength with split off (windowLen != 0) is not supported on the device path"; return MM_ERR_ARG; }
@@ -201,24 +210,48 @@ static int upload_reads_common(mm_ctx* c, const void* src, bool srcOnDevice, siz
     }
     pk += ((int64_t)len + 31) / 32 * 32;
   }
-  srcOff[nReads] = readOffsets[nReads]; packOff[nReads] = pk;
+  if (packed && pk && (!S.b2 || !S.nm)) { c->err = "mm_reads_upload_packed: null argument"; return MM_ERR_ARG; }
+  srcOff[nReads] = packed ? 0 : readOffsets[nReads]; packOff[nReads] = pk;
   c->nReads = nReads; c->nFrags = dfr.size(); c->nPackedBases = (size_t)pk; c->seqCounterBase = seqCounterBase; c->maxFragLen = maxLen;
   c->sketched = false; c->mapped = false; c->fragTabStale = true; c->gathered = false;
 
-  const size_t srcBase = (size_t)readOffsets[0];
-  const size_t nSrc = (size_t)(readOffsets[nReads] - readOffsets[0]);
+  const size_t srcBase = packed ? 0 : (size_t)readOffsets[0];
+  const size_t nSrc = packed ? 0 : (size_t)(readOffsets[nReads] - readOffsets[0]);
+  if (!packed && nSrc && !S.ascii) { c->err = "mm_reads_upload: null argument"; return MM_ERR_ARG; }
   for (size_t r = 0; r <= nReads; r++) srcOff[r] -= (int64_t)srcBase;
-  // bytes mm_reads_prefetch has already sent (same host range): take that buffer and wait for its copy on the device
-  const bool prefetched = !srcOnDevice && c->prefetchValid && nSrc && c->prefetchPtr == (const void*)((const char*)src + srcBase) && c->prefetchBytes == nSrc;
+  // bytes mm_reads_prefetch[_packed] has already sent (same host range): take that buffer and wait for its copy on the device
+  bool prefetched = false;
+  if (c->prefetchValid) {
+    if (!packed && !c->prefetchPacked && !S.onDevice && nSrc && c->prefetchPtr == (const void*)((const char*)S.ascii + srcBase) && c->prefetchBytes == nSrc) prefetched = true;
+    if (packed && c->prefetchPacked && pk && c->prefetchPtr == (const void*)S.b2 && c->prefetchPtr2 == (const void*)S.nm && c->prefetchBytes == (size_t)pk) prefetched = true;
+  }
   c->prefetchValid = false;
-  if (prefetched) { std::swap(c->dAscii, c->dAsciiNext); MM_HIP(c, hipStreamWaitEvent(c->stream, c->copyDone, 0)); }
-  else MM_HIP(c, c->dAscii.ensure(nSrc + 64));
+  if (prefetched) { if (!packed) std::swap(c->dAscii, c->dAsciiNext); MM_HIP(c, hipStreamWaitEvent(c->stream, c->copyDone, 0)); }
+  else if (!packed) MM_HIP(c, c->dAscii.ensure(nSrc + 64));
   MM_HIP(c, c->dReadSrcOff.ensure((nReads + 1) * 8)); MM_HIP(c, c->dReadPackOff.ensure((nReads + 1) * 8));
   MM_HIP(c, c->dReadLen.ensure(nReads * 4 + 4)); MM_HIP(c, c->dReadGroup.ensure(nReads * 4 + 4)); MM_HIP(c, c->dReadSelf.ensure(nReads * 4 + 4));
   MM_HIP(c, c->dReadHasN.ensure(nReads * 4 + 4));
   MM_HIP(c, c->dBases2.ensure((size_t)pk / 4 + 64)); MM_HIP(c, c->dNmask.ensure((size_t)pk / 8 + 64));
   MM_HIP(c, c->dFrags.ensure(dfr.size() * sizeof(DFrag) + 16));
-  if (nSrc && !prefetched) MM_HIP(c, hipMemcpyAsync(c->dAscii.p, (const char*)src + srcBase, nSrc, srcOnDevice ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+  std::vector<uint32_t> hasN32;
+  if (packed) {
+    // the words are the device layout already: straight into dBases2 / dNmask (from the prefetch staging buffer if they travelled ahead)
+    if (pk) {
+      if (prefetched) {
+        MM_HIP(c, hipMemcpyAsync(c->dBases2.p, c->dAsciiNext.p, (size_t)pk / 4, hipMemcpyDeviceToDevice, c->stream));
+        MM_HIP(c, hipMemcpyAsync(c->dNmask.p, (const char*)c->dAsciiNext.p + (size_t)pk / 4, (size_t)pk / 8, hipMemcpyDeviceToDevice, c->stream));
+      } else {
+        MM_HIP(c, hipMemcpyAsync(c->dBases2.p, S.b2, (size_t)pk / 4, hipMemcpyHostToDevice, c->stream));
+        MM_HIP(c, hipMemcpyAsync(c->dNmask.p, S.nm, (size_t)pk / 8, hipMemcpyHostToDevice, c->stream));
+      }
+    }
+    hasN32.assign(nReads + 1, 0u);
+    for (size_t r = 0; r < nReads; r++) {
+      if (S.hasN) hasN32[r] = S.hasN[r] ? 1u : 0u;
+      else { const uint32_t* w = S.nm + packOff[r] / 32; const size_t nw = (size_t)((packOff[r + 1] - packOff[r]) / 32); uint32_t any = 0; for (size_t i = 0; i < nw; i++) any |= w[i]; hasN32[r] = any ? 1u : 0u; }
+    }
+    MM_HIP(c, hipMemcpyAsync(c->dReadHasN.p, hasN32.data(), nReads * 4 + 4, hipMemcpyHostToDevice, c->stream));
+  } else if (nSrc && !prefetched) MM_HIP(c, hipMemcpyAsync(c->dAscii.p, (const char*)S.ascii + srcBase, nSrc, S.onDevice ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
   MM_HIP(c, hipMemcpyAsync(c->dReadSrcOff.p, srcOff.data(), (nReads + 1) * 8, hipMemcpyHostToDevice, c->stream));
   MM_HIP(c, hipMemcpyAsync(c->dReadPackOff.p, packOff.data(), (nReads + 1) * 8, hipMemcpyHostToDevice, c->stream));
   if (nReads) MM_HIP(c, hipMemcpyAsync(c->dReadLen.p, rlen.data(), nReads * 4, hipMemcpyHostToDevice, c->stream));
@@ -229,34 +262,71 @@ static int upload_reads_common(mm_ctx* c, const void* src, bool srcOnDevice, siz
     MM_HIP(c, hipMemcpyAsync(c->dReadGroup.p, grp.data(), nReads * 4, hipMemcpyHostToDevice, c->stream));
     MM_HIP(c, hipMemcpyAsync(c->dReadSelf.p, self.data(), nReads * 4, hipMemcpyHostToDevice, c->stream));
   }
-  MM_HIP(c, hipMemsetAsync(c->dReadHasN.p, 0, nReads * 4 + 4, c->stream));
+  if (!packed) MM_HIP(c, hipMemsetAsync(c->dReadHasN.p, 0, nReads * 4 + 4, c->stream));
   MM_HIP(c, hipMemsetAsync((char*)c->dBases2.p + pk / 4, 0, 64, c->stream));   // run-off words read by the last fragment
   MM_HIP(c, hipMemsetAsync((char*)c->dNmask.p + pk / 8, 0, 64, c->stream));
   if (!dfr.empty()) MM_HIP(c, hipMemcpyAsync(c->dFrags.p, dfr.data(), dfr.size() * sizeof(DFrag), hipMemcpyHostToDevice, c->stream));
-  int rc = mm_launch_pack(c);
-  if (rc != MM_OK) return rc;
+  if (!packed) { const int rc = mm_launch_pack(c); if (rc != MM_OK) return rc; }
   MM_HIP(c, hipStreamSynchronize(c->stream));         // host staging vectors go out of scope
   return MM_OK;
 }
 
 int mm_reads_upload(mm_ctx* c, const char* bases, const int64_t* readOffsets, size_t nReads, const int32_t* g, const int32_t* s, int32_t base) {
-  return upload_reads_common(c, bases, false, 0 + (size_t)(readOffsets ? readOffsets[nReads] : 0), readOffsets, nReads, g, s, base);
+  ReadSource S; S.ascii = bases;
+  return upload_reads_common(c, S, readOffsets, nReads, g, s, base);
 }
 int mm_reads_upload_device(mm_ctx* c, const void* dBases, size_t nBases, const int64_t* readOffsets, size_t nReads, const int32_t* g,
                            const int32_t* s, int32_t base) {
-  return upload_reads_common(c, dBases, true, nBases, readOffsets, nReads, g, s, base);
+  (void)nBases;
+  ReadSource S; S.ascii = dBases; S.onDevice = true;
+  return upload_reads_common(c, S, readOffsets, nReads, g, s, base);
+}
+int mm_reads_upload_packed(mm_ctx* c, const uint32_t* bases2, const uint32_t* nmask, const uint8_t* readHasN, const int32_t* readLengths, size_t nReads,
+                           const int32_t* g, const int32_t* s, int32_t base) {
+  static const int32_t none = 0;
+  ReadSource S; S.b2 = bases2; S.nm = nmask; S.hasN = readHasN; S.lengths = readLengths ? readLengths : &none;
+  return upload_reads_common(c, S, nullptr, nReads, g, s, base);
+}
+size_t mm_pack_read(const char* ascii, size_t len, uint32_t* bases2, uint32_t* nmask) { return mmhost::pack2bit(ascii, len, bases2, nmask); }
+size_t mm_pack_read_portable(const char* ascii, size_t len, uint32_t* bases2, uint32_t* nmask) { return mmhost::pack2bit_scalar(ascii, len, bases2, nmask); }
+
+int mm_reads_packed_download(mm_ctx* c, uint32_t* bases2, uint32_t* nmask, uint32_t* readHasN, size_t* nPackedBases) {
+  if (nPackedBases) *nPackedBases = c->nPackedBases;
+  MM_HIP(c, hipSetDevice(c->device));
+  if (bases2 && c->nPackedBases) MM_HIP(c, hipMemcpyAsync(bases2, c->dBases2.p, c->nPackedBases / 4, hipMemcpyDeviceToHost, c->stream));
+  if (nmask && c->nPackedBases) MM_HIP(c, hipMemcpyAsync(nmask, c->dNmask.p, c->nPackedBases / 8, hipMemcpyDeviceToHost, c->stream));
+  if (readHasN && c->nReads) MM_HIP(c, hipMemcpyAsync(readHasN, c->dReadHasN.p, c->nReads * 4, hipMemcpyDeviceToHost, c->stream));
+  MM_HIP(c, hipStreamSynchronize(c->stream));
+  return MM_OK;
+}
+
+static int prefetch_common(mm_ctx* c, const void* p0, size_t n0, const void* p1, size_t n1) {
+  MM_HIP(c, hipSetDevice(c->device));
+  if (!c->copyStream) MM_HIP(c, hipStreamCreateWithFlags(&c->copyStream, hipStreamNonBlocking));
+  if (!c->copyDone) MM_HIP(c, hipEventCreateWithFlags(&c->copyDone, hipEventDisableTiming));
+  MM_HIP(c, c->dAsciiNext.ensure(n0 + n1 + 64));
+  MM_HIP(c, hipMemcpyAsync(c->dAsciiNext.p, p0, n0, hipMemcpyHostToDevice, c->copyStream));
+  if (n1) MM_HIP(c, hipMemcpyAsync((char*)c->dAsciiNext.p + n0, p1, n1, hipMemcpyHostToDevice, c->copyStream));
+  MM_HIP(c, hipEventRecord(c->copyDone, c->copyStream));
+  return MM_OK;
 }
 
 int mm_reads_prefetch(mm_ctx* c, const char* bases, size_t nBytes) {
   c->prefetchValid = false;
   if (!bases || !nBytes) return MM_OK;
-  MM_HIP(c, hipSetDevice(c->device));
-  if (!c->copyStream) MM_HIP(c, hipStreamCreateWithFlags(&c->copyStream, hipStreamNonBlocking));
-  if (!c->copyDone) MM_HIP(c, hipEventCreateWithFlags(&c->copyDone, hipEventDisableTiming));
-  MM_HIP(c, c->dAsciiNext.ensure(nBytes + 64));
-  MM_HIP(c, hipMemcpyAsync(c->dAsciiNext.p, bases, nBytes, hipMemcpyHostToDevice, c->copyStream));
-  MM_HIP(c, hipEventRecord(c->copyDone, c->copyStream));
-  c->prefetchPtr = bases; c->prefetchBytes = nBytes; c->prefetchValid = true;
+  const int rc = prefetch_common(c, bases, nBytes, nullptr, 0);
+  if (rc != MM_OK) return rc;
+  c->prefetchPtr = bases; c->prefetchPtr2 = nullptr; c->prefetchBytes = nBytes; c->prefetchPacked = false; c->prefetchValid = true;
+  return MM_OK;
+}
+
+int mm_reads_prefetch_packed(mm_ctx* c, const uint32_t* bases2, const uint32_t* nmask, size_t nPackedBases) {
+  c->prefetchValid = false;
+  if (!bases2 || !nmask || !nPackedBases) return MM_OK;
+  if (nPackedBases % 32) { c->err = "mm_reads_prefetch_packed: the packed length of a batch is a multiple of 32 bases"; return MM_ERR_ARG; }
+  const int rc = prefetch_common(c, bases2, nPackedBases / 4, nmask, nPackedBases / 8);
+  if (rc != MM_OK) return rc;
+  c->prefetchPtr = bases2; c->prefetchPtr2 = nmask; c->prefetchBytes = nPackedBases; c->prefetchPacked = true; c->prefetchValid = true;
   return MM_OK;
 }
 

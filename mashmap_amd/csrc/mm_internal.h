@@ -87,7 +87,7 @@ struct mm_ctx {
   DevBuf dAscii, dReadSrcOff, dReadPackOff, dReadLen, dReadGroup, dReadSelf, dReadHasN;
   // mm_reads_prefetch: the next batch's ASCII bytes, copied on a stream of their own while the current batch is mapped
   DevBuf dAsciiNext; hipStream_t copyStream = nullptr; hipEvent_t copyDone = nullptr;
-  const void* prefetchPtr = nullptr; size_t prefetchBytes = 0; bool prefetchValid = false;
+  const void* prefetchPtr = nullptr; const void* prefetchPtr2 = nullptr; size_t prefetchBytes = 0; bool prefetchValid = false, prefetchPacked = false;
   DevBuf dBases2, dNmask, dFrags;
   std::vector<mm_fragment> hFrags;
 

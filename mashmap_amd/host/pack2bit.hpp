@@ -1,0 +1,110 @@
+// mashmap_amd/host/pack2bit.hpp -- makeUpperCaseAndValidDNA (src/map/include/commonFunc.hpp:97-107) + 2-bit packing on the HOST.
+//
+// The device layout of a batch of reads (`dBases2`, `dNmask`) is 2 bit/base (A0 C1 G2 T3, sixteen bases per
+// uint32, first base in the low bits) + 1 bit/base that is set where the normalised base is 'N' (lower case folded to upper case,
+// everything but A C G T -> N; the code of an N is 0), every read starting on a 32-base boundary.  k_pack2bit (mm_sketch.hip) produces
+// it from ASCII on the GPU; this header produces the same words on the CPU, so that a caller whose bytes are in host memory anyway --
+// the FASTA parser touches every base once while it drops the line breaks -- can ship 0.375 bytes per base over PCIe instead of 1
+// (mm_reads_upload_packed).  Bit-identical to k_pack2bit for every byte value 0..255 (tests/test_pack2bit.py, tests/test_gpu_sketch.py).
+//
+// AVX2 + BMI2 where the CPU has them (32 bases per step: compare against the four letters, two movemasks, two pdeps), a plain loop
+// otherwise; chosen at run time.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+#include <string.h>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
+
+namespace mmhost {
+
+// one group of up to 32 bases -> (code word pair as one uint64, N mask); bases beyond n are absent (code 0, mask 0)
+static inline void pack32_scalar(const unsigned char* s, size_t n, uint64_t& codes, uint32_t& nm) {
+  uint64_t c = 0; uint32_t m = 0;
+  for (size_t i = 0; i < n; i++) {
+    const uint32_t ch = s[i] & 0xDFu;                                  // a-z -> A-Z (only letters can land on A/C/G/T)
+    const bool ok = (ch == 'A') | (ch == 'C') | (ch == 'G') | (ch == 'T');
+    c |= (uint64_t)(ok ? (((ch >> 1) ^ (ch >> 2)) & 3u) : 0u) << (2 * i);   // A0 C1 G2 T3
+    m |= (ok ? 0u : 1u) << i;
+  }
+  codes = c; nm = m;
+}
+
+// n bases (any n) -> ceil(n/32) mask words and 2*ceil(n/32) code words; returns the number of N bases
+static inline size_t pack2bit_scalar(const char* ascii, size_t n, uint32_t* bases2, uint32_t* nmask) {
+  const unsigned char* s = (const unsigned char*)ascii;
+  size_t nN = 0;
+  for (size_t g = 0; g * 32 < n; g++) {
+    uint64_t c; uint32_t m;
+    pack32_scalar(s + g * 32, n - g * 32 < 32 ? n - g * 32 : 32, c, m);
+    bases2[2 * g] = (uint32_t)c; bases2[2 * g + 1] = (uint32_t)(c >> 32); nmask[g] = m;
+    nN += (size_t)__builtin_popcount(m);
+  }
+  return nN;
+}
+
+#if defined(__x86_64__)
+__attribute__((target("avx2,bmi2")))
+static inline size_t pack2bit_avx2(const char* ascii, size_t n, uint32_t* bases2, uint32_t* nmask) {
+  const unsigned char* s = (const unsigned char*)ascii;
+  const __m256i up = _mm256_set1_epi8((char)0xDF), cA = _mm256_set1_epi8('A'), cC = _mm256_set1_epi8('C'), cG = _mm256_set1_epi8('G'), cT = _mm256_set1_epi8('T');
+  size_t nN = 0;
+  const size_t full = n / 32;
+  for (size_t g = 0; g < full; g++) {
+    const __m256i b = _mm256_and_si256(_mm256_loadu_si256((const __m256i*)(s + g * 32)), up);
+    const __m256i isC = _mm256_cmpeq_epi8(b, cC), isG = _mm256_cmpeq_epi8(b, cG), isT = _mm256_cmpeq_epi8(b, cT);
+    const __m256i ok = _mm256_or_si256(_mm256_or_si256(_mm256_cmpeq_epi8(b, cA), isC), _mm256_or_si256(isG, isT));
+    // code bit 0 is set for C and T, bit 1 for G and T
+    const uint32_t b0 = (uint32_t)_mm256_movemask_epi8(_mm256_or_si256(isC, isT));
+    const uint32_t b1 = (uint32_t)_mm256_movemask_epi8(_mm256_or_si256(isG, isT));
+    const uint32_t m = ~(uint32_t)_mm256_movemask_epi8(ok);
+    const uint64_t c = _pdep_u64(b0, 0x5555555555555555ull) | _pdep_u64(b1, 0xAAAAAAAAAAAAAAAAull);
+    bases2[2 * g] = (uint32_t)c; bases2[2 * g + 1] = (uint32_t)(c >> 32); nmask[g] = m;
+    nN += (size_t)__builtin_popcount(m);
+  }
+  if (n % 32) {
+    uint64_t c; uint32_t m;
+    pack32_scalar(s + full * 32, n % 32, c, m);
+    bases2[2 * full] = (uint32_t)c; bases2[2 * full + 1] = (uint32_t)(c >> 32); nmask[full] = m;
+    nN += (size_t)__builtin_popcount(m);
+  }
+  return nN;
+}
+static inline bool pack2bit_have_avx2() {
+  static const bool have = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2");
+  return have;
+}
+#endif
+
+static inline size_t pack2bit(const char* ascii, size_t n, uint32_t* bases2, uint32_t* nmask) {
+#if defined(__x86_64__)
+  if (pack2bit_have_avx2()) return pack2bit_avx2(ascii, n, bases2, nmask);
+#endif
+  return pack2bit_scalar(ascii, n, bases2, nmask);
+}
+
+// Streaming form for input that arrives in pieces (FASTA lines): feed() any number of byte ranges, finish() once.  Groups of 32 bases
+// are packed as soon as they are complete; at most 31 bases wait in `carry`.
+struct Pack2bitStream {
+  uint32_t* b2; uint32_t* nm; size_t groups = 0, nN = 0; unsigned char carry[32]; size_t nCarry = 0;
+  Pack2bitStream(uint32_t* bases2, uint32_t* nmask) : b2(bases2), nm(nmask) {}
+  void feed(const char* p, size_t n) {
+    if (nCarry) {
+      const size_t take = 32 - nCarry < n ? 32 - nCarry : n;
+      memcpy(carry + nCarry, p, take); nCarry += take; p += take; n -= take;
+      if (nCarry < 32) return;
+      nN += pack2bit((const char*)carry, 32, b2 + 2 * groups, nm + groups); groups++; nCarry = 0;
+    }
+    const size_t full = n / 32;
+    if (full) { nN += pack2bit(p, full * 32, b2 + 2 * groups, nm + groups); groups += full; }
+    nCarry = n - full * 32;
+    if (nCarry) memcpy(carry, p + full * 32, nCarry);
+  }
+  size_t finish() {                                                    // returns the number of N bases of the whole read
+    if (nCarry) { nN += pack2bit((const char*)carry, nCarry, b2 + 2 * groups, nm + groups); groups++; nCarry = 0; }
+    return nN;
+  }
+};
+
+}  // namespace mmhost

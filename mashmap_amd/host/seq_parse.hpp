@@ -36,6 +36,8 @@
 #include <unordered_set>
 #include <vector>
 
+#include "pack2bit.hpp"
+
 namespace mmhost {
 
 struct ParsedBatch {
@@ -45,6 +47,15 @@ struct ParsedBatch {
   size_t cap = 0;
   size_t size() const { return names.size(); }
   int64_t totalBases() const { return offs.back(); }
+  // packed form (BatchReader with packOutput): the buffer holds the device layout of the batch instead of ASCII -- 2-bit codes, then
+  // the N mask (pack2bit.hpp; every record starts on a 32-base boundary: record r at packed base packOffs[r]) -- 0.375 bytes per base
+  bool packed = false;
+  int64_t packedBases = 0;           // packOffs.back()
+  std::vector<int64_t> packOffs;     // size() + 1 entries
+  std::vector<int32_t> lens;         // bases of every record (offs differences)
+  std::vector<uint8_t> hasN;         // record holds a base that is not A C G T a c g t
+  uint32_t* bases2() const { return (uint32_t*)bases; }
+  uint32_t* nmask() const { return (uint32_t*)(bases + packedBases / 4); }
 };
 
 namespace detail {
@@ -280,9 +291,10 @@ class BatchReader {
   typedef std::function<void(char*)> Free;
 
   BatchReader(std::vector<std::string> files, size_t windowBytes, unsigned threads, std::unordered_set<std::string> keepSeq = {},
-              std::string keepPrefix = "", Alloc a = nullptr, Free f = nullptr)
+              std::string keepPrefix = "", Alloc a = nullptr, Free f = nullptr, bool packOutput = false)
       : files_(std::move(files)), window_(std::max<size_t>(windowBytes, 1u << 16)), threads_(std::max(1u, threads)), keepSeq_(std::move(keepSeq)),
-        keepPrefix_(std::move(keepPrefix)), pool_(std::max(1u, threads)), alloc_(a ? a : [](size_t n) { return (char*)malloc(n); }), free_(f ? f : [](char* p) { free(p); }) {}
+        keepPrefix_(std::move(keepPrefix)), pool_(std::max(1u, threads)), alloc_(a ? a : [](size_t n) { return (char*)malloc(n); }), free_(f ? f : [](char* p) { free(p); }),
+        packOutput_(packOutput) {}
   ~BatchReader() { delete src_; }
 
   // index of the file the batch returned last came from, and whether it was that file's last batch
@@ -312,6 +324,7 @@ class BatchReader {
   std::unordered_set<std::string> keepSeq_; std::string keepPrefix_;
   WorkerPool pool_;
   Alloc alloc_; Free free_;
+  bool packOutput_ = false;          // batches carry 2-bit codes + N mask (what mm_reads_upload_packed takes) instead of ASCII
   detail::RawSource* src_ = nullptr; size_t nextFile_ = 0, curFile_ = 0; bool fasta_ = true, firstWindow_ = true, fileDone_ = false;
 
   void openFile(const std::string& path) {
@@ -330,6 +343,41 @@ class BatchReader {
       exit(1);
     }
     fasta_ = c == '>';
+  }
+
+  // the sequence bytes of the window's records as 2-bit codes + N mask: the workers normalise and pack while they drop the line breaks
+  // (the bytes are touched once either way; the packed batch is 3/8 the size of the ASCII one on its way to the GPU)
+  void packWindow(const std::vector<std::vector<detail::Rec>>& recs, const std::vector<size_t>& first, unsigned T, bool fasta, size_t nRec, ParsedBatch& out) {
+    out.packOffs.assign(nRec + 1, 0); out.lens.assign(nRec, 0); out.hasN.assign(nRec, 0);
+    int64_t pk = 0;
+    for (size_t r = 0; r < nRec; r++) { const int64_t len = out.offs[r + 1] - out.offs[r]; out.lens[r] = (int32_t)len; out.packOffs[r] = pk; pk += (len + 31) / 32 * 32; }
+    out.packOffs[nRec] = pk; out.packedBases = pk;
+    const size_t need = (size_t)pk / 4 + (size_t)pk / 8 + 64;
+    if (need > out.cap) {
+      if (out.bases) free_(out.bases);
+      out.bases = alloc_(need + (need >> 4) + 4096);
+      if (!out.bases) { std::cerr << "[mashmap_hip] out of host memory for a batch of " << pk << " packed bases" << std::endl; exit(1); }
+      out.cap = need + (need >> 4) + 4096;
+    }
+    uint32_t* b2 = out.bases2(); uint32_t* nm = out.nmask();
+    detail::run_parallel(pool_, T, [&](unsigned t) {
+      for (size_t i = 0; i < recs[t].size(); i++) {
+        const detail::Rec& r = recs[t][i];
+        const size_t ri = first[t] + i;
+        if (!r.keep || !r.seqLen) continue;
+        Pack2bitStream st(b2 + out.packOffs[ri] / 16, nm + out.packOffs[ri] / 32);
+        if (fasta) {
+          const char* l = r.body;
+          while (l < r.end) {
+            const char* nl = (const char*)memchr(l, '\n', (size_t)(r.end - l));
+            const char* le = nl ? nl : r.end;
+            st.feed(l, (size_t)(le - l));
+            l = nl ? nl + 1 : r.end;
+          }
+        } else st.feed(r.body, (size_t)r.seqLen);
+        out.hasN[ri] = st.finish() ? 1 : 0;
+      }
+    });
   }
 
   void parseWindow(const char* p, size_t n, ParsedBatch& out) {
@@ -391,6 +439,8 @@ class BatchReader {
     int64_t at = out.offs[base];
     for (unsigned t = 0; t < T; t++) for (size_t i = 0; i < recs[t].size(); i++) { out.offs[base + first[t] + i] = at; at += recs[t][i].seqLen; }
     out.offs[base + nRec] = at;
+    out.packed = packOutput_;
+    if (packOutput_) { packWindow(recs, first, T, fasta, nRec, out); return; }
     if ((size_t)at + 64 > out.cap) {
       char* nb = alloc_((size_t)at + ((size_t)at >> 4) + 4096);
       if (!nb) { std::cerr << "[mashmap_hip] out of host memory for a batch of " << at << " bases" << std::endl; exit(1); }

@@ -72,6 +72,7 @@ class Map {
   mm_ctx* ctx;                                   // ctxs[0]
   MapPost post;                                  // everything downstream of the device integers (skch_map_post.hpp)
   std::unique_ptr<mmhost::WorkerPool> postPool;  // the post stage's threads
+  bool packedUpload = true;                      // batches travel as 2-bit codes + N mask (set in mapQuery)
   struct Batch {
     mmhost::ParsedBatch in;                      // names, offsets, bases (page-locked buffer, recycled through bufferPool)
     seqno_t firstSeqCounter = 0;
@@ -153,6 +154,9 @@ class Map {
       // keep them on the heap instead of mmap/munmap per batch (each unmap interrupts every thread of the process), and keep the heap
       mallopt(M_MMAP_THRESHOLD, 32 << 20); mallopt(M_TRIM_THRESHOLD, 1 << 30); mallopt(M_TOP_PAD, 256 << 20);
     }
+    // the reader's workers normalise and pack the bases (2 bit + N mask, pack2bit.hpp) while they drop the line breaks, so that PCIe
+    // carries 0.375 bytes per base instead of 1 (mm_reads_upload_packed); MASHMAP_HIP_ASCII_UPLOAD=1 ships ASCII to k_pack2bit instead
+    packedUpload = getenv("MASHMAP_HIP_ASCII_UPLOAD") == nullptr;
     std::thread reader([&]() {
       // multi-threaded ingest (seq_parse.hpp): a window of the file per batch, parsed straight into a page-locked buffer.  8 workers:
       // memchr + memcpy at that width keep up with the device stage, and more of them page-faulting through the same file mapping next
@@ -167,7 +171,7 @@ class Map {
                                if (getenv("MASHMAP_HIP_TIMING")) std::cerr << "[mashmap_hip::timing] reader: page-locked " << n << " bytes itself in "
                                                                            << std::chrono::duration<double>(skch::Time::now() - t0).count() << " s" << std::endl;
                                return p;
-                             }, [](char* p) { mm_host_free(p); });
+                             }, [](char* p) { mm_host_free(p); }, packedUpload);
       while (true) {
         Batch batch;
         { auto b = HostBufferPool::instance().take(0); batch.in.bases = b.first; batch.in.cap = b.second; }
@@ -284,11 +288,22 @@ class Map {
     auto runBlock = [&](size_t i) {
       mm_ctx* c = ctxs[i];
       const size_t b = cutAt[i], e = cutAt[i + 1];
-      if (mm_reads_upload(c, batch.in.bases, batch.in.offs.data() + b, e - b, param.skip_prefix ? readGroup.data() + b : nullptr,
-                          param.skip_self ? readSelf.data() + b : nullptr, batch.firstSeqCounter + (seqno_t)b) != MM_OK) die("mm_reads_upload", c);
-      if (!nextCut.empty()) {
-        const int64_t o0 = next->in.offs[nextCut[i]], o1 = next->in.offs[nextCut[i + 1]];
-        if (mm_reads_prefetch(c, next->in.bases + o0, (size_t)(o1 - o0)) != MM_OK) die("mm_reads_prefetch", c);
+      if (batch.in.packed) {
+        const int64_t p0 = batch.in.packOffs[b];
+        if (mm_reads_upload_packed(c, batch.in.bases2() + p0 / 16, batch.in.nmask() + p0 / 32, batch.in.hasN.data() + b, batch.in.lens.data() + b, e - b,
+                                   param.skip_prefix ? readGroup.data() + b : nullptr, param.skip_self ? readSelf.data() + b : nullptr,
+                                   batch.firstSeqCounter + (seqno_t)b) != MM_OK) die("mm_reads_upload_packed", c);
+        if (!nextCut.empty() && next->in.packed) {
+          const int64_t o0 = next->in.packOffs[nextCut[i]], o1 = next->in.packOffs[nextCut[i + 1]];
+          if (mm_reads_prefetch_packed(c, next->in.bases2() + o0 / 16, next->in.nmask() + o0 / 32, (size_t)(o1 - o0)) != MM_OK) die("mm_reads_prefetch_packed", c);
+        }
+      } else {
+        if (mm_reads_upload(c, batch.in.bases, batch.in.offs.data() + b, e - b, param.skip_prefix ? readGroup.data() + b : nullptr,
+                            param.skip_self ? readSelf.data() + b : nullptr, batch.firstSeqCounter + (seqno_t)b) != MM_OK) die("mm_reads_upload", c);
+        if (!nextCut.empty()) {
+          const int64_t o0 = next->in.offs[nextCut[i]], o1 = next->in.offs[nextCut[i + 1]];
+          if (mm_reads_prefetch(c, next->in.bases + o0, (size_t)(o1 - o0)) != MM_OK) die("mm_reads_prefetch", c);
+        }
       }
       if (mm_map_fragments(c) != MM_OK) die("mm_map_fragments", c);
       if (!blockRecs.empty()) {

@@ -27,18 +27,33 @@ int main(int argc, char** argv) {
   if (argc == 4 && std::string(argv[1]) == "pool") return pool_check((unsigned)atoi(argv[2]), atoi(argv[3]));
   if (argc < 4) return 2;
   const size_t window = (size_t)atol(argv[1]); const unsigned threads = (unsigned)atoi(argv[2]);
-  std::string prefix; int a = 3;
-  if (std::string(argv[3]) == "--prefix") { prefix = argv[4]; a = 5; }
+  std::string prefix; int a = 3; bool packed = false;
+  if (std::string(argv[a]) == "--packed") { packed = true; a++; }      // the reader packs (2-bit codes + N mask); the hash is of the normalised sequence they encode
+  if (std::string(argv[a]) == "--prefix") { prefix = argv[a + 1]; a += 2; }
   std::vector<std::string> files;
   for (int i = a; i < argc; i++) files.push_back(argv[i]);
-  mmhost::BatchReader rd(files, window, threads, {}, prefix);
+  mmhost::BatchReader rd(files, window, threads, {}, prefix, nullptr, nullptr, packed);
   mmhost::ParsedBatch b;
   size_t batches = 0;
   while (rd.next(b)) {
     batches++;
     for (size_t r = 0; r < b.size(); r++) {
       unsigned long long h = 1469598103934665603ull;
-      for (int64_t i = b.offs[r]; i < b.offs[r + 1]; i++) { h ^= (unsigned char)b.bases[i]; h *= 1099511628211ull; }
+      if (!packed) for (int64_t i = b.offs[r]; i < b.offs[r + 1]; i++) { h ^= (unsigned char)b.bases[i]; h *= 1099511628211ull; }
+      else {
+        const int64_t len = b.offs[r + 1] - b.offs[r], p0 = b.packOffs[r];
+        if (b.lens[r] != len || p0 % 32 || b.packOffs[r + 1] - p0 != (len + 31) / 32 * 32) { printf("bad packed layout at record %zu\n", r); return 1; }
+        bool anyN = false;
+        for (int64_t i = 0; i < b.packOffs[r + 1] - p0; i++) {
+          const int64_t g = p0 + i;
+          const unsigned code = (b.bases2()[g >> 4] >> (2 * (g & 15))) & 3u, isN = (b.nmask()[g >> 5] >> (g & 31)) & 1u;
+          if (i >= len) { if (code || isN) { printf("padding not zero at record %zu\n", r); return 1; } continue; }
+          if (isN && code) { printf("N with a code at record %zu\n", r); return 1; }
+          anyN |= isN != 0;
+          h ^= (unsigned char)(isN ? 'N' : "ACGT"[code]); h *= 1099511628211ull;
+        }
+        if ((b.hasN[r] != 0) != anyN) { printf("hasN wrong at record %zu\n", r); return 1; }
+      }
       printf("%s\t%lld\t%llu\n", b.names[r].c_str(), (long long)(b.offs[r + 1] - b.offs[r]), h);
     }
   }

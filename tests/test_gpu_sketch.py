@@ -120,3 +120,46 @@ def test_sketch_many_hard_fragments(oracle):
     h = got["hash"].astype(np.uint64)
     inc = (h[:, 1:] > h[:, :-1]) | (np.arange(1, s)[None, :] >= cnt[:, None])
     assert inc.all()
+
+
+def test_packed_upload_equals_ascii_upload(oracle):
+    """mm_reads_upload_packed (host-side normalise + 2-bit pack, pack2bit.hpp) leaves the SAME words in HBM as mm_reads_upload +
+    k_pack2bit -- lower case, IUPAC letters, bytes >= 127, N runs, every tail length -- and the sketches that follow are identical"""
+    from mashmap_amd import capi
+    rng = np.random.default_rng(7)
+    reads = [U.random_dna(200 + i, n) for i, n in enumerate((10000, 5000, 5001, 4999, 12345, 31, 32, 33, 19, 18, 1))]
+    reads.append(U.lowercase_some(U.random_dna(300, 9000), 3))
+    reads.append(U.with_n_runs(U.random_dna(301, 11000), 5, 5, 333))
+    reads.append(rng.choice(np.frombuffer(b"ACGTNnacgtRYKMSWBDHV*-.", dtype=np.uint8), 7000))
+    weird = U.random_dna(302, 6000); weird[::97] = rng.integers(127, 256, len(weird[::97])).astype(np.uint8); weird[5::211] = 0
+    reads.append(weird)
+    reads.append(np.zeros(0, dtype=np.uint8))
+    ctx = capi.Context(k=19, segLength=5000, sketchSize=130)
+    nF = ctx.reads_upload(reads, seqCounterBase=40)
+    a2, am, ah = ctx.reads_packed_download()
+    sk_a, cnt_a = ctx.sketch()
+    for portable in (False, True):
+        packed = capi.pack_reads(reads, portable)
+        assert a2.tobytes() == packed[0].tobytes() and am.tobytes() == packed[1].tobytes(), "host packing differs from k_pack2bit"
+        assert (ah != 0).tolist() == (packed[2] != 0).tolist()
+    for prefetch in (False, True):
+        assert ctx.reads_upload_packed(packed, seqCounterBase=40, prefetch=prefetch) == nF
+        p2, pm, ph = ctx.reads_packed_download()
+        assert p2.tobytes() == a2.tobytes() and pm.tobytes() == am.tobytes() and ph.tobytes() == ah.tobytes()
+        sk_p, cnt_p = ctx.sketch()
+        assert cnt_p.tobytes() == cnt_a.tobytes() and sk_p.tobytes() == sk_a.tobytes()
+    # a sub-block of the batch (what a context of a sharded run gets): words and mask from the block's first read on
+    lens = packed[3]
+    g0 = int(((lens[:3].astype(np.int64) + 31) // 32).sum())
+    sub = (packed[0][2 * g0:], packed[1][g0:], packed[2][3:], lens[3:])
+    ctx.reads_upload_packed(sub, seqCounterBase=43)
+    sk_s, cnt_s = ctx.sketch()
+    f0 = sum(1 for fr in ctx.fragments())
+    skip = nF - f0
+    assert cnt_s.tobytes() == cnt_a[skip:].tobytes() and sk_s.tobytes() == sk_a[skip:].tobytes()
+    ctx.close()
+    exp = _expect(oracle, reads, 19, 130, 5000)
+    assert nF == len(exp)
+    for f in (0, 1, nF - 1):
+        g = [(int(x["hash"]), int(x["wpos"]), int(x["wpos_end"]), int(x["seqId"]) - 40, int(x["strand"])) for x in sk_a[f, :cnt_a[f]]]
+        assert g == exp[f]

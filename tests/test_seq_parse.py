@@ -153,3 +153,32 @@ def test_truncated_or_corrupt_gzip_is_an_error(exe, tmp_path):
     open(bad, "wb").write(bytes(bg))
     p = subprocess.run([exe, "70000", "3", bad], capture_output=True, text=True)
     assert p.returncode != 0 and "BGZF" in p.stderr, (p.returncode, p.stderr[-200:])
+
+
+def _normalise(seq):
+    t = bytearray(b"N" * 256)
+    for c in b"ACGT":
+        t[c] = c; t[c + 32] = c
+    return bytes(seq).translate(bytes(t))
+
+
+@pytest.mark.parametrize("kind", ["fasta60", "fastq", "fasta60.gz"])
+def test_packing_reader_encodes_the_normalised_sequences(exe, tmp_path, kind):
+    """BatchReader with packOutput (what skch::Map feeds mm_reads_upload_packed): the 2-bit codes + N mask of every record decode to
+    makeUpperCaseAndValidDNA of its sequence (commonFunc.hpp:97), records start on 32-base boundaries, padding is zero"""
+    rs = records()
+    rng = np.random.default_rng(9)
+    rs = [(h, (bytes(rng.choice(np.frombuffer(b"ACGTNnacgtRYKM*-", dtype=np.uint8), len(s))) if i % 9 == 4 else s)) for i, (h, s) in enumerate(rs)]
+    raw = fastq_bytes(rs) if kind.startswith("fastq") else fasta_bytes(rs, 60)
+    path = str(tmp_path / ("in." + kind))
+    if kind.endswith(".gz"):
+        with gzip.open(path, "wb") as f:
+            f.write(raw)
+    else:
+        open(path, "wb").write(raw)
+    want = ["%s\t%d\t%d" % (h.split(" ")[0], len(s), fnv(_normalise(s))) for h, s in rs]
+    for window, threads in ((1 << 40, 1), (70000, 3), (300000, 8)):
+        p = subprocess.run([exe, str(window), str(threads), "--packed", path], capture_output=True, text=True)
+        assert p.returncode == 0, p.stdout[-300:] + p.stderr
+        got = p.stdout.splitlines()
+        assert got == want, (kind, window, threads, [x for x in zip(got, want) if x[0] != x[1]][:3])
