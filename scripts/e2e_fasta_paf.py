@@ -23,25 +23,27 @@ def main():
     ap.add_argument("--threads", type=int, default=min(128, os.cpu_count() or 1))
     ap.add_argument("--dir", default="/tmp/mm_e2e")
     ap.add_argument("--batch-mbp", type=float, default=512.0)
+    ap.add_argument("--reuse", action="store_true", help="the FASTA files of an earlier call are still in --dir")
     args = ap.parse_args()
-    import torch
     os.makedirs(args.dir, exist_ok=True)
     W = B.WORKLOADS["configs1"]
-    dev = torch.device("cuda", 0)
-    contigs = B.make_reference(torch, dev, W["ref_contigs"], W["ref_contig_len"])
     rp, qp, op = os.path.join(args.dir, "ref.fa"), os.path.join(args.dir, "reads.fa"), os.path.join(args.dir, "out.paf")
-    B.write_fasta(rp, ["chr%d" % i for i in range(len(contigs))], [c.cpu().numpy() for c in contigs])
-    t0 = time.time()
     L = W["read_len"]
-    with open(qp, "wb") as f:
+    t0 = time.time()
+    if not (args.reuse and os.path.exists(rp) and os.path.exists(qp)):
+      import torch
+      dev = torch.device("cuda", 0)
+      contigs = B.make_reference(torch, dev, W["ref_contigs"], W["ref_contig_len"])
+      B.write_fasta(rp, ["chr%d" % i for i in range(len(contigs))], [c.cpu().numpy() for c in contigs])
+      with open(qp, "wb") as f:
         chunk = 100_000
         for r0 in range(0, args.reads, chunk):
             n = min(chunk, args.reads - r0)
             rd = B.make_reads(torch, dev, contigs, n, L, W["err"], seed=1000 + r0).cpu().numpy().reshape(n, L)
             hdr = np.frombuffer(b"".join(b">read%07d\n" % (r0 + i) for i in range(n)), dtype=np.uint8).reshape(n, 13)      # fixed-width names
             f.write(np.concatenate([hdr, rd, np.full((n, 1), 10, dtype=np.uint8)], axis=1).tobytes())
-    del contigs
-    torch.cuda.empty_cache()
+      del contigs
+      torch.cuda.empty_cache()
     log = "[e2e] wrote %.2f GB of FASTA in %.1f s" % (os.path.getsize(qp) / 1e9, time.time() - t0)
     print(log, file=sys.stderr)
     env = dict(os.environ, MASHMAP_HIP_TIMING="1", MASHMAP_HIP_BATCH_MBP=str(args.batch_mbp))
@@ -67,7 +69,9 @@ def main():
     nlines = sum(1 for _ in open(op, "rb"))
     bases = args.reads * L
     out = {"what": "mashmap_hip -r ref.fa -q reads.fa (FASTA -> PAF), BASELINE configs[1]: %d x %d bp reads vs 100 Mbp, -t %d; 'time spent mapping the query' "
-                   "(parse + upload + kernels + chain/filter + PAF text), stages overlap (reader | device | post)" % (args.reads, L, args.threads),
+                   "(parse + upload + kernels + chain/filter + PAF text), stages overlap (reader | device | post); upload %s, reader threads %s"
+                   % (args.reads, L, args.threads, "ASCII (1 B/bp)" if os.environ.get("MASHMAP_HIP_ASCII_UPLOAD") else "packed by the parser (0.375 B/bp)",
+                      os.environ.get("MASHMAP_HIP_READER_THREADS", "default")),
            "gbps_fasta_to_paf": round(bases / best["map_s"] / 1e9, 3), "paf_lines": nlines, "fasta_bytes": os.path.getsize(qp), **{k: round(v, 3) for k, v in best.items()}}
     print(json.dumps(out))
 
