@@ -326,8 +326,8 @@ int mm_index_replicate(mm_ctx* dst, mm_ctx* src) {
   MM_HIP(dst, hipSetDevice(dst->device));
   DeviceIndex& D = dst->idx; DeviceIndex& S = src->idx;
   D.ready = false;
-  DevBuf* d[] = {&D.evKey, &D.evAux, &D.evHash, &D.contigOff, &D.opKey, &D.opAux, &D.opHash, &D.blockOff, &D.evBlock, &D.contigBlock, &D.contigLen, &D.refGroup, &D.htSlots, &D.filter, &D.ptKeys};
-  DevBuf* s[] = {&S.evKey, &S.evAux, &S.evHash, &S.contigOff, &S.opKey, &S.opAux, &S.opHash, &S.blockOff, &S.evBlock, &S.contigBlock, &S.contigLen, &S.refGroup, &S.htSlots, &S.filter, &S.ptKeys};
+  DevBuf* d[] = {&D.evKey, &D.evAux, &D.evHash, &D.contigOff, &D.opKey, &D.opAux, &D.opHash, &D.blockOff, &D.evBlock, &D.contigBlock, &D.contigLen, &D.refGroup, &D.htSlots, &D.htTags, &D.filter, &D.ptKeys};
+  DevBuf* s[] = {&S.evKey, &S.evAux, &S.evHash, &S.contigOff, &S.opKey, &S.opAux, &S.opHash, &S.blockOff, &S.evBlock, &S.contigBlock, &S.contigLen, &S.refGroup, &S.htSlots, &S.htTags, &S.filter, &S.ptKeys};
   for (size_t i = 0; i < sizeof d / sizeof d[0]; i++) {
     if (!s[i]->bytes) continue;
     MM_HIP(dst, d[i]->ensure(s[i]->bytes));
@@ -335,7 +335,7 @@ int mm_index_replicate(mm_ctx* dst, mm_ctx* src) {
     else MM_HIP(dst, hipMemcpyPeerAsync(d[i]->p, dst->device, s[i]->p, src->device, s[i]->bytes, dst->stream));
   }
   MM_HIP(dst, hipStreamSynchronize(dst->stream));
-  D.nRec = S.nRec; D.nKeys = S.nKeys; D.nPoints = S.nPoints; D.nContigs = S.nContigs; D.htCap = S.htCap; D.filterMask = S.filterMask;
+  D.nRec = S.nRec; D.nKeys = S.nKeys; D.nPoints = S.nPoints; D.nContigs = S.nContigs; D.htCap = S.htCap; D.filterMask = S.filterMask; D.tagged = S.tagged;
   D.ready = true;
   dst->freqThreshold = src->freqThreshold;
   dst->mapped = false;

@@ -133,6 +133,12 @@ __host__ __device__ __forceinline__ uint64_t mm_filter_bits(uint64_t h) {
 }
 __host__ __device__ __forceinline__ uint64_t mm_filter_word(uint64_t h, uint64_t wordMask) { return (h >> 32) & wordMask; }
 
+// Tag layer of the seed table (large indexes): buckets of 16 slots, one tag byte per slot, 0 = empty slot.  The bucket comes from the low
+// bits of the hash (as the slot of the untagged table does), the tag from bits 29..36 (the minmer hashes of an index are the small ones
+// of their windows: the top bits are zero).
+#define MM_TAG_BUCKET 16
+__host__ __device__ __forceinline__ uint32_t mm_seed_tag(uint64_t h) { const uint32_t t = (uint32_t)(h >> 29) & 0xFFu; return t ? t : 0xA7u; }
+
 // ---------------------------------------------------------------------------------------------
 // Strip hasher.  For K = 17..19 (one 16-byte block + a tail of K-16 <= 3 bytes; K = 19 is MashMap's default) the tail has
 // at most 64 values, so its complete mix (k1*C1, rotl 31, *C2) comes from a 64-entry LDS table indexed by the 2-bit codes:

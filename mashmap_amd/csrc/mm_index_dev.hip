@@ -237,7 +237,8 @@ k_ht_clear(size_t cap, HtSlot* __restrict__ ht) {
 }
 __global__ void __launch_bounds__(256)
 k_ht_insert(size_t nk, const uint64_t* __restrict__ keys, const uint64_t* __restrict__ keyOff, const uint8_t* __restrict__ freq, HtSlot* __restrict__ ht,
-            uint64_t mask, unsigned long long* __restrict__ filter, uint64_t filterMask, unsigned long long* __restrict__ diag /* [3] |= 1 value overflow, |= 2 duplicate key */) {
+            uint64_t mask, unsigned long long* __restrict__ filter, uint64_t filterMask, uint8_t* __restrict__ tags /* non-null: bucketised placement + tag bytes */,
+            unsigned long long* __restrict__ diag /* [3] |= 1 value overflow, |= 2 duplicate key */) {
   const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (k >= nk) return;
   const uint64_t key = keys[k];
@@ -248,6 +249,21 @@ k_ht_insert(size_t nk, const uint64_t* __restrict__ keys, const uint64_t* __rest
   if (f) { off = 0; cnt = 0; }
   if (cnt >= (1ull << 23) || off >= (1ull << 40)) { atomicOr(&diag[3], 1ull); return; }
   const uint64_t val = (off << 24) | (cnt << 1) | (f ? 1ull : 0ull);
+  if (tags) {
+    // tagged table: the key goes into the first bucket, from its home bucket on, that still has a free slot (no deletions: the
+    // buckets before it stay full, which is what ends an unsuccessful look-up at the first bucket with an empty tag)
+    uint64_t b = (key & mask) & ~(uint64_t)(MM_TAG_BUCKET - 1);
+    const uint32_t start = (uint32_t)(key >> 40);                      // spread the first attempts of a bucket's keys over its slots
+    while (true) {
+      for (uint32_t i = 0; i < MM_TAG_BUCKET; i++) {
+        const uint64_t slot = b + ((start + i) & (MM_TAG_BUCKET - 1));
+        const unsigned long long prev = atomicCAS((unsigned long long*)&ht[slot].key, (unsigned long long)MM_EMPTY, (unsigned long long)key);
+        if (prev == MM_EMPTY) { ht[slot].val = val; tags[slot] = (uint8_t)mm_seed_tag(key); return; }
+        if (prev == key) { atomicOr(&diag[3], 2ull); return; }
+      }
+      b = (b + MM_TAG_BUCKET) & mask;
+    }
+  }
   uint64_t slot = key & mask;
   while (true) {
     const unsigned long long prev = atomicCAS((unsigned long long*)&ht[slot].key, (unsigned long long)MM_EMPTY, (unsigned long long)key);
@@ -261,6 +277,15 @@ k_ht_insert(size_t nk, const uint64_t* __restrict__ keys, const uint64_t* __rest
 // ---------------------------------------------------------------------------------------------
 // host orchestration
 // ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_order_keys(int c0, int n, const int32_t* __restrict__ key, int shift, uint32_t maxKey, uint32_t* __restrict__ kOut, int32_t* __restrict__ vOut) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint32_t k = (uint32_t)key[c0 + i] >> shift; if (k > maxKey) k = maxKey;
+  kOut[i] = maxKey - k;                                              // ascending sort of the complement = descending order
+  vOut[i] = c0 + i;
+}
+
 namespace {
 
 struct Tmp {                        // scratch device buffers of one build, released at the end
@@ -366,11 +391,22 @@ int mm_flatten_device_index(mm_ctx* c, const mm_minmer* dRec, size_t n, size_t n
   uint64_t maxMiB = 64;
   if (const char* e = getenv("MM_FILTER_MAX_MIB")) maxMiB = strtoull(e, nullptr, 10);
   if (fbits / 8 > (maxMiB << 20)) fbits = 0;
+  // Tag layer instead of the filter for tables beyond MM_SEED_TAGS_MIN_MIB (default 1024 MiB of slots: indexes of more than ~30 M keys,
+  // where neither the table nor a filter of any useful size stays cached): one tag byte per slot, buckets of 16 slots.  MM_SEED_TAGS=1 / 0
+  // forces it on / off (tests run the small parity cases both ways).
+  bool tagged = cap * 16 > ((size_t)1024 << 20);
+  if (const char* e = getenv("MM_SEED_TAGS_MIN_MIB")) tagged = cap * 16 > ((size_t)strtoull(e, nullptr, 10) << 20);
+  if (const char* e = getenv("MM_SEED_TAGS")) tagged = atoi(e) != 0;
+  if (cap < 4 * MM_TAG_BUCKET) tagged = false;
+  if (tagged) fbits = 0;
   MM_HIP(c, I.htSlots.ensure(cap * 16)); MM_HIP(c, I.filter.ensure((fbits ? fbits / 8 : 4) + 64));
+  MM_HIP(c, I.htTags.ensure(tagged ? cap + 64 : 64));
   K_LAUNCH(k_ht_clear, cap, cap, I.htSlots.as<HtSlot>());
   MM_HIP(c, hipMemsetAsync(I.filter.p, 0, (fbits ? fbits / 8 : 4), c->stream));
+  if (tagged) MM_HIP(c, hipMemsetAsync(I.htTags.p, 0, cap + 64, c->stream));
   if (nk) K_LAUNCH(k_ht_insert, nk, nk, I.keys.as<uint64_t>(), I.keyOff.as<uint64_t>(), I.keyFreq.as<uint8_t>(), I.htSlots.as<HtSlot>(), (uint64_t)(cap - 1),
-                   I.filter.as<unsigned long long>(), fbits ? fbits / 64 - 1 : 0ull, diag);
+                   I.filter.as<unsigned long long>(), fbits ? fbits / 64 - 1 : 0ull, tagged ? I.htTags.as<uint8_t>() : (uint8_t*)nullptr, diag);
+  I.tagged = tagged;
   MM_HIP(c, hipGetLastError());
   std::vector<int32_t> grp(nContigs, 0);
   if (refGroup) grp.assign(refGroup, refGroup + nContigs);
@@ -570,4 +606,16 @@ int mm_mirror_map(mm_ctx* c) {
   }
   c->mirrorMap = true;
   return MM_OK;
+}
+
+// The indices c0 .. c0+n-1 ordered by descending key[i] >> shift (ties keep their order): the L2 sweep runs one candidate per lane, so
+// a wave takes as long as its longest stream -- with the candidates taken in order of stream length the 64 of a wave are alike.
+int mm_order_desc(mm_ctx* c, const int32_t* dKey, int c0, int n, int shift, int32_t* dOrder) {
+  if (n <= 0) return MM_OK;
+  const uint32_t maxKey = 0xFFFu;                                   // 12 bits of key: two radix passes
+  DevBuf& k0 = c->dL2Sort[0]; DevBuf& k1 = c->dL2Sort[1]; DevBuf& v0 = c->dL2Sort[2]; DevBuf& tmp = c->dL2Sort[3];
+  MM_HIP(c, k0.ensure((size_t)n * 4 + 64)); MM_HIP(c, k1.ensure((size_t)n * 4 + 64)); MM_HIP(c, v0.ensure((size_t)n * 4 + 64));
+  hipLaunchKernelGGL(k_order_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c0, n, dKey, shift, maxKey, k0.as<uint32_t>(), v0.as<int32_t>());
+  MM_HIP(c, hipGetLastError());
+  return sort_pairs(c, tmp, k0.as<uint32_t>(), k1.as<uint32_t>(), v0.as<int32_t>(), dOrder, (size_t)n, 0u, 12u);
 }

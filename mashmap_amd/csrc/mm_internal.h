@@ -58,6 +58,10 @@ struct DeviceIndex {
   DevBuf refGroup;             // int32[nContigs] (all 0 when unused)
   DevBuf htSlots;              // {uint64 key, uint64 val}[htCap]; val = offset<<24 | count<<1 | freq (one 16-byte slot per probe)
   DevBuf filter; uint64_t filterMask = 0;   // presence filter in front of htSlots: uint64 words, mm_filter_word / mm_filter_bits (mm_device.h); word mask, 0 = disabled
+  // large tables (human-scale index): htSlots is placed in buckets of MM_TAG_BUCKET slots and fronted by one TAG BYTE per slot (0 = empty):
+  // a probe reads the 16 tags of the seed's home bucket -- one 16-byte load out of an array 1/16 the size of the table -- and touches
+  // the 16-byte slot only where a tag matches (~86 % of query seeds are absent from the index: sequencing errors)
+  DevBuf htTags; bool tagged = false;
   DevBuf ptKeys;               // uint64[nPoints]: seqId<<33 | pos<<1 | (side==OPEN)
   DevBuf keys, keyOff, keyFreq; // the lookup map's key table in the order of ptKeys: uint64 key, uint64 first point (nKeys + 1), uint8 isFrequent
   bool ready = false;
@@ -113,6 +117,7 @@ struct mm_ctx {
   DevBuf dGatherSrc; hipStream_t commStream = nullptr; std::thread gatherThread; int gatherRc = 0; std::string gatherErr;
   std::vector<DevBuf*> allBufs();
   DevBuf dL2Info, dL2Cnt, dL2Off, dL2Ops, dScanTmp, dL2Tmp, dL2Wide, dL2Exact, dL2Cells, dListB, dListC, dBigList;     // L2 staging: per-candidate stream extents, op counts/offsets, located ops
+  DevBuf dL2Sort[4], dL2Order;                          // candidates of a chunk in order of descending stream length (mm_order_desc)
   bool sketched = false, mapped = false;
   bool keepPoints = false;                              // mm_set_option(MM_OPT_KEEP_POINTS): route every fragment through the HBM point list
 
@@ -161,3 +166,4 @@ int mm_finalize_index_device(mm_ctx* c, const std::vector<std::pair<const mm_min
 int mm_mirror_minmers(mm_ctx* c);
 int mm_mirror_map(mm_ctx* c);
 int mm_scan_i32_to_i64(mm_ctx* c, int64_t n, const int32_t* dIn, int64_t* dOut, int64_t* total);
+int mm_order_desc(mm_ctx* c, const int32_t* dKey, int c0, int n, int shift, int32_t* dOrder);   // mm_index_dev.hip (rocPRIM radix sort)

@@ -289,14 +289,31 @@ __device__ __forceinline__ int mm_l1_fused(uint64_t (&k)[R], FuseScratch& sc, in
 //   * otherwise (many points, -Y groups, a position group spanning contigs, or keepPoints for the parity API): reserves
 //     slots in the global point buffer, gathers there and queues the fragment for k_sort_points_* + k_l1_sweep.
 // ---------------------------------------------------------------------------------------------
+// tag bytes of one bucket of the tagged seed table (mm_internal.h: htTags) against the tag of a query seed: cand16 = slots whose tag
+// equals it (a set bit above a matching or empty byte of the same 4-byte word may be spurious -- candidates are verified against the
+// slot's key anyway), hasEmpty = the bucket still has a free slot, i.e. no key of this bucket lives further on
+__device__ __forceinline__ void mm_tag_scan(uint4 t, uint32_t tag, uint32_t& cand16, bool& hasEmpty) {
+  const uint32_t rep = tag * 0x01010101u;
+  const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+  uint32_t c = 0, e = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const uint32_t x = w[i] ^ rep;
+    const uint32_t zc = (x - 0x01010101u) & ~x & 0x80808080u;          // zero bytes of x: bit 7 of the byte
+    c |= ((((zc >> 7) * 0x00204081u) >> 21) & 0xFu) << (4 * i);          // the four flags side by side
+    e |= (w[i] - 0x01010101u) & ~w[i] & 0x80808080u;
+  }
+  cand16 = c; hasEmpty = e != 0;
+}
+
 #define MM_LOOKUP_WPB 4             // waves (= fragments) per workgroup
 #define MM_L1_REGIONS 64            // L1 output cursors: a same-address atomic costs ~10 ns, so fragments spread over 64 of them
 #define MM_L1_CURSOR_STRIDE 32      // u64 words between cursors (256 bytes)
-template <int MAXPTS>
+template <int MAXPTS, bool TAGS>
 __global__ void __launch_bounds__(MM_LOOKUP_WPB * 64, MAXPTS <= 128 ? 8 : MAXPTS <= 256 ? 6 : 5)
 k_lookup_l1(int nFrags, int s, const DFrag* __restrict__ frags,
             const uint64_t* __restrict__ skHash, const int8_t* __restrict__ skStrand, const uint32_t* __restrict__ skCount,
-            const HtSlot* __restrict__ ht, uint64_t htMask, const uint64_t* __restrict__ filter, uint64_t filterMask,
+            const HtSlot* __restrict__ ht, uint64_t htMask, const uint64_t* __restrict__ filter, uint64_t filterMask, const uint8_t* __restrict__ tags,
             const uint64_t* __restrict__ ptKeys, const int32_t* __restrict__ refGroup,
             const int32_t* __restrict__ readGroup, const int32_t* __restrict__ readSelf, int seqCounterBase, MapFlags fl, int keepPoints,
             uint64_t* __restrict__ qHash, int8_t* __restrict__ qStrand, uint64_t* __restrict__ seedVal,
@@ -341,6 +358,7 @@ k_lookup_l1(int nFrags, int s, const DFrag* __restrict__ frags,
     uint64_t h[4], val[4]; bool act[4], found[4], open[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) { const int r = base + u * 64 + lane; act[u] = r < cnt; h[u] = act[u] ? skHash[fo + r] : 0ull; }
+    if constexpr (!TAGS) {
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       open[u] = act[u];
@@ -359,6 +377,40 @@ k_lookup_l1(int nFrags, int s, const DFrag* __restrict__ frags,
         slot = (slot + 1) & htMask;
         sl[u] = ht[slot];
       }
+    }
+    } else {
+    // Tagged table (human-scale index).  One 16-byte load per seed fetches the tag bytes of its home bucket, out of an array 1/16 the
+    // size of the table; the four sub-rounds' loads are in flight together.  A slot is fetched only where a tag matches (a present
+    // seed, or one absent seed in ~40 by chance); an absent seed ends at the first bucket with a free slot: its own, but for ~0.03 %.
+    uint4 tg[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { open[u] = act[u]; tg[u] = make_uint4(0u, 0u, 0u, 0u); if (act[u]) tg[u] = *(const uint4*)(tags + ((h[u] & htMask) & ~(uint64_t)(MM_TAG_BUCKET - 1))); }
+    uint32_t cand[4]; bool emp[4]; HtSlot sl[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      mm_tag_scan(tg[u], mm_seed_tag(h[u]), cand[u], emp[u]);
+      if (!act[u]) { cand[u] = 0; emp[u] = true; }
+      sl[u].key = MM_EMPTY; sl[u].val = 0;
+      if (cand[u]) sl[u] = ht[((h[u] & htMask) & ~(uint64_t)(MM_TAG_BUCKET - 1)) + (uint32_t)__builtin_ctz(cand[u])];   // the first candidates of all four sub-rounds travel together
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      found[u] = false; val[u] = 0;
+      uint64_t b = (h[u] & htMask) & ~(uint64_t)(MM_TAG_BUCKET - 1);
+      uint32_t cd = cand[u]; bool em = emp[u]; bool have = cd != 0;  // `have`: sl[u] holds the slot of cd's lowest bit
+      while (cd || !em) {
+        while (cd) {
+          const uint32_t i = (uint32_t)__builtin_ctz(cd); cd &= cd - 1u;
+          const HtSlot x = have ? sl[u] : ht[b + i];
+          have = false;
+          if (x.key == h[u]) { found[u] = true; val[u] = x.val; cd = 0; em = true; }
+        }
+        if (!em) {                                                   // a full bucket without the key: on to the next one
+          b = (b + MM_TAG_BUCKET) & htMask;
+          mm_tag_scan(*(const uint4*)(tags + b), mm_seed_tag(h[u]), cd, em);
+        }
+      }
+    }
     }
     // The sketch after frequent-seed removal goes to qHash/qStrand only if a seed was removed (or the sketch spans several
     // batches): otherwise it equals the raw sketch, and readers (k_l2_locate, mm_query_sketch_download) take that instead
@@ -905,10 +957,11 @@ int mm_launch_map(mm_ctx* c) {
       // larger ones (points come in proportion to the sketch: s = 310 averages ~176 per fragment with a long tail)
       int fuse = s > 256 ? 512 : s > 160 ? 256 : 128;
       if (const char* e = getenv("MM_FUSE_MAXPTS")) { const int v = atoi(e); fuse = v >= 512 ? 512 : v >= 256 ? 256 : 128; }
-      auto kern = fuse == 512 ? k_lookup_l1<512> : fuse == 256 ? k_lookup_l1<256> : k_lookup_l1<128>;
+      auto kern = I.tagged ? (fuse == 512 ? k_lookup_l1<512, true> : fuse == 256 ? k_lookup_l1<256, true> : k_lookup_l1<128, true>)
+                           : (fuse == 512 ? k_lookup_l1<512, false> : fuse == 256 ? k_lookup_l1<256, false> : k_lookup_l1<128, false>);
       hipLaunchKernelGGL(kern, dim3((nF + MM_LOOKUP_WPB - 1) / MM_LOOKUP_WPB), dim3(MM_LOOKUP_WPB * 64), 0, c->stream, nF, s, c->dFrags.as<DFrag>(),
                          c->dSkHash.as<uint64_t>(), c->dSkStrand.as<int8_t>(), c->dSkCount.as<uint32_t>(),
-                         I.htSlots.as<HtSlot>(), (uint64_t)(I.htCap - 1), I.filter.as<uint64_t>(), (uint64_t)I.filterMask, I.ptKeys.as<uint64_t>(),
+                         I.htSlots.as<HtSlot>(), (uint64_t)(I.htCap - 1), I.filter.as<uint64_t>(), (uint64_t)I.filterMask, I.htTags.as<uint8_t>(), I.ptKeys.as<uint64_t>(),
                          I.refGroup.as<int32_t>(), c->dReadGroup.as<int32_t>(), c->dReadSelf.as<int32_t>(), c->seqCounterBase, fl,
                          c->keepPoints ? 1 : 0,
                          c->dQHash.as<uint64_t>(), c->dQStrand.as<int8_t>(), c->dSeedVal.as<uint64_t>(), c->dStats.as<mm_frag_stats>(),

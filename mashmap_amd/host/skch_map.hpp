@@ -30,6 +30,7 @@
 #include <condition_variable>
 #include <cstdint>
 #include <deque>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
@@ -73,6 +74,8 @@ class Map {
   MapPost post;                                  // everything downstream of the device integers (skch_map_post.hpp)
   std::unique_ptr<mmhost::WorkerPool> postPool;  // the post stage's threads
   bool packedUpload = true;                      // batches travel as 2-bit codes + N mask (set in mapQuery)
+  skch::Time::time_point tStart = skch::Time::now();   // MASHMAP_HIP_TIMING lines carry the time since the Map was constructed
+  std::string at() const { char b[48]; snprintf(b, sizeof b, " [t=%.4f]", std::chrono::duration<double>(skch::Time::now() - tStart).count()); return b; }
   struct Batch {
     mmhost::ParsedBatch in;                      // names, offsets, bases (page-locked buffer, recycled through bufferPool)
     seqno_t firstSeqCounter = 0;
@@ -123,7 +126,9 @@ class Map {
       if (mm_set_tables(c, minHits.data(), minHits.size(), cut32.data(), cut32.size()) != MM_OK) die("mm_set_tables", c);
       if (mm_set_replay_tables(c, accept.data(), minIsz.data(), (size_t)p.sketchSize + 1) != MM_OK) die("mm_set_replay_tables", c);
     }
+    if (getenv("MASHMAP_HIP_TIMING")) std::cerr << "[mashmap_hip::timing] integer tables ready" << at() << std::endl;
     this->mapQuery();
+    if (getenv("MASHMAP_HIP_TIMING")) std::cerr << "[mashmap_hip::timing] mapQuery done" << at() << std::endl;
   }
 
   static void insertL2ResultsToVec(MappingResultsVector_t& v, const MappingResult& reportedL2Result) { v.push_back(reportedL2Result); }
@@ -178,7 +183,7 @@ class Map {
         const auto tr0 = skch::Time::now();
         const bool more = rd.next(batch.in);
         if (more && getenv("MASHMAP_HIP_TIMING")) std::cerr << "[mashmap_hip::timing] reader: parsed " << batch.size() << " records, " << batch.in.totalBases() << " bases in "
-                                                            << std::chrono::duration<double>(skch::Time::now() - tr0).count() << " s" << std::endl;
+                                                            << std::chrono::duration<double>(skch::Time::now() - tr0).count() << " s" << at() << std::endl;
         if (!more) { HostBufferPool::instance().give(batch.in.bases, batch.in.cap); break; }
         batch.firstSeqCounter = seqCounter;
         for (size_t r = 0; r < batch.size(); r++) {
@@ -285,9 +290,11 @@ class Map {
     const char* xe = getenv("MASHMAP_HIP_EXCHANGE");
     const bool gatherOnDevice = nCtx > 1 && xe && std::string(xe) == "allgather";
     std::vector<std::vector<mm_mapping>> blockRecs(gatherOnDevice || nCtx == 1 ? 0 : nCtx);
+    double phase[3] = {0, 0, 0};                           // context 0: upload, kernels, download (seconds)
     auto runBlock = [&](size_t i) {
       mm_ctx* c = ctxs[i];
       const size_t b = cutAt[i], e = cutAt[i + 1];
+      const auto p0 = skch::Time::now();
       if (batch.in.packed) {
         const int64_t p0 = batch.in.packOffs[b];
         if (mm_reads_upload_packed(c, batch.in.bases2() + p0 / 16, batch.in.nmask() + p0 / 32, batch.in.hasN.data() + b, batch.in.lens.data() + b, e - b,
@@ -305,7 +312,9 @@ class Map {
           if (mm_reads_prefetch(c, next->in.bases + o0, (size_t)(o1 - o0)) != MM_OK) die("mm_reads_prefetch", c);
         }
       }
+      const auto p1 = skch::Time::now();
       if (mm_map_fragments(c) != MM_OK) die("mm_map_fragments", c);
+      if (i == 0) { phase[0] = std::chrono::duration<double>(p1 - p0).count(); phase[1] = std::chrono::duration<double>(skch::Time::now() - p1).count(); }
       if (!blockRecs.empty()) {
         size_t nb = 0;
         if (mm_mappings_count(c, &nb) != MM_OK) die("mm_mappings_count", c);
@@ -321,6 +330,7 @@ class Map {
       for (auto& t : th) t.join();
     }
     size_t n = 0;
+    const auto p2 = skch::Time::now();
     if (nCtx == 1) {
       if (mm_mappings_count(ctx, &n) != MM_OK) die("mm_mappings_count");
       batch.recs.resize(n);
@@ -337,7 +347,8 @@ class Map {
       for (const auto& v : blockRecs) { if (!v.empty()) std::memcpy(batch.recs.data() + at, v.data(), v.size() * sizeof(mm_mapping)); at += v.size(); }
     }
     if (timing) std::cerr << "[mashmap_hip::timing] device stage (upload + pack + kernels" << (gatherOnDevice ? " + all-gatherv" : "") << " + download of " << n
-                          << " candidate mappings): " << std::chrono::duration<double>(skch::Time::now() - t0).count() << " s" << std::endl;
+                          << " candidate mappings): " << std::chrono::duration<double>(skch::Time::now() - t0).count() << " s (upload " << phase[0] << ", kernels " << phase[1]
+                          << ", download " << std::chrono::duration<double>(skch::Time::now() - p2).count() << ")" << at() << std::endl;
   }
 
   // post stage: per read, chaining + filters + PAF text on param.threads threads; then output in input order
@@ -382,7 +393,7 @@ class Map {
       }
     }
     if (timing) std::cerr << "[mashmap_hip::timing] post stage: chain + filter + format " << std::chrono::duration<double>(t1 - t0).count()
-                          << " s, output " << std::chrono::duration<double>(skch::Time::now() - t1).count() << " s" << std::endl;
+                          << " s, output " << std::chrono::duration<double>(skch::Time::now() - t1).count() << " s" << at() << std::endl;
   }
 
 };

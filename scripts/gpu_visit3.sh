@@ -49,10 +49,10 @@ prof:*)
   done ;;
 fuzz)
   echo "== fuzz parity" | tee -a $OUT/log.txt
-  timeout 900 python scripts/fuzz_parity.py ${FUZZ_SEED:-5} ${FUZZ_N:-20} 2>&1 | tail -25 | tee -a $OUT/log.txt ;;
+  timeout 900 python scripts/fuzz_parity.py ${FUZZ_N:-20} ${FUZZ_SEED:-5} 2>&1 | tail -25 | tee -a $OUT/log.txt ;;
 fuzzpaf)
   echo "== fuzz PAF" | tee -a $OUT/log.txt
-  timeout 900 python scripts/fuzz_paf.py ${FUZZ_SEED:-5} ${FUZZ_N:-15} 2>&1 | tail -20 | tee -a $OUT/log.txt ;;
+  timeout 900 python scripts/fuzz_paf.py ${FUZZ_N:-15} ${FUZZ_SEED:-5} 2>&1 | tail -20 | tee -a $OUT/log.txt ;;
 esac
 done
 echo "== done" | tee -a $OUT/log.txt

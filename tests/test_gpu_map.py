@@ -47,6 +47,26 @@ def test_map_against_the_device_built_index(oracle, flags, delim, kmerPct):
     assert nF > 200 and nl > 100
 
 
+@pytest.mark.parametrize("case", ["default", "device_index_freq", "sketch310", "skip_self"])
+def test_map_with_the_tagged_seed_table(oracle, monkeypatch, case):
+    """the seed table of a human-scale index (buckets of 16 slots behind one tag byte per slot, k_lookup_l1<.., true>) forced onto small
+    indexes: same integers as the oracle at every stage; ~0.4 % of the buckets overflow into the next one at this load"""
+    monkeypatch.setenv("MM_SEED_TAGS", "1")
+    contigs = genome(211, [400000, 300000, 200000])
+    reads = reads_for(contigs, 25, 100, 10000, 0.10) + [("unrelated", U.random_dna(12, 15000)), ("short", U.random_dna(9, 700))]
+    if case == "default":
+        nF, nl = run_and_compare(oracle, contigs, reads)
+        assert nF > 200 and nl > 150
+    elif case == "device_index_freq":
+        run_and_compare(oracle, contigs, reads, kmerPct=0.5, device_index=True)
+    elif case == "sketch310":
+        run_and_compare(oracle, contigs, reads_for(contigs, 26, 40, 15000, 0.10), s=310)
+    else:
+        names = [c[0] for c in contigs]
+        rs = [(names[i % 3] if i % 4 == 0 else n, a) for i, (n, a) in enumerate(reads)]
+        run_and_compare(oracle, contigs, rs, flags=U.FLAG_HG | U.FLAG_SKIP_SELF)
+
+
 def test_map_frequent_seeds(oracle):
     contigs = genome(21, [300000, 250000, 200000])
     reads = reads_for(contigs, 7, 80, 10000, 0.08)
