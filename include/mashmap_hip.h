@@ -45,7 +45,8 @@ enum {
 typedef struct {
   int32_t kmerSize;       /* Parameters::kmerSize   (1..32) */
   int32_t segLength;      /* Parameters::segLength  */
-  int32_t sketchSize;     /* Parameters::sketchSize (1..1279: the L2 state of 64 candidates must fit one CU's LDS; mm_create checks) */
+  int32_t sketchSize;     /* Parameters::sketchSize (1 .. ~5000 at segLength <= 50 kbp: the exact sketch kernel's key table and the L2 kernels'
+                             per-wave state must fit one CU's 160 KB of LDS; mm_create checks and says what does not fit) */
   int32_t flags;          /* MM_FLAG_* */
 } mm_params;
 

@@ -16,7 +16,7 @@ std::vector<DevBuf*> mm_ctx::allBufs() {
   DeviceIndex& I = idx;
   return {&I.evKey, &I.evAux, &I.evHash, &I.contigOff, &I.opKey, &I.opAux, &I.opHash, &I.blockOff, &I.evBlock, &I.contigBlock, &I.contigLen, &I.refGroup,
           &I.htSlots, &I.htTags, &I.filter, &I.ptKeys, &I.keys, &I.keyOff, &I.keyFreq, &dMinHits, &dCutoffs, &dAscii, &dAsciiNext, &dReadSrcOff, &dReadPackOff, &dReadLen, &dReadGroup, &dReadSelf, &dReadHasN,
-          &dBases2, &dNmask, &dFrags, &dSkHash, &dSkPos, &dSkStrand, &dSkCount, &dHardList, &dCounters, &dSketchTabs, &dQHash, &dQStrand, &dSeedVal,
+          &dBases2, &dNmask, &dFrags, &dSkHash, &dSkPos, &dSkStrand, &dSkCount, &dHardList, &dCounters, &dSketchSpill, &dSketchTabs, &dQHash, &dQStrand, &dSeedVal,
           &dStats, &dPtOff, &dPts, &dL1, &dL1b, &dL1Cursors, &dL1Off, &dL2, &dL2Info, &dL2Cnt, &dL2Off, &dL2Ops, &dScanTmp, &dL2Tmp, &dL2Wide, &dL2Exact, &dL2Cells,
           &dListB, &dListC, &dBigList, &dL2Sort[0], &dL2Sort[1], &dL2Sort[2], &dL2Sort[3], &dL2Order, &dL2First, &dL2Num, &dAccept, &dMinIsz, &dSelCnt, &dSelOff, &dSelHeap, &dFragTab, &dMappings, &dCommCounts, &dGathered};
 }
@@ -130,8 +130,7 @@ int mm_set_tables(mm_ctx* c, const int32_t* minHits, size_t nMinHits, const int3
 
 int mm_set_tables_default(mm_ctx* c, float pi) {
   const int s = c->P.sketchSize, k = c->P.kmerSize;
-  std::vector<int32_t> mh((size_t)s + 1, 0);
-  for (int q = 1; q <= s; q++) mh[q] = mmhost::Stat::estimateMinimumHitsRelaxed(q, k, pi, mmhost::fixed::confidence_interval);
+  std::vector<int32_t> mh = mmhost::minHitsTable(s, k, pi);
   std::vector<int> cut = mmhost::sketchCutoffs(s, k, mmhost::fixed::ANIDiff, mmhost::fixed::ANIDiffConf, (c->P.flags & MM_FLAG_HG_FILTER) != 0);
   std::vector<int32_t> cut32(cut.begin(), cut.end());
   int rc = mm_set_tables(c, mh.data(), mh.size(), cut32.data(), cut32.size());
@@ -183,6 +182,7 @@ static int upload_reads_common(mm_ctx* c, const ReadSource& S, const int64_t* re
   std::vector<int32_t> rlen(nReads);
   c->hFrags.clear();
   std::vector<DFrag> dfr;
+  dfr.reserve(c->hFrags.capacity() ? c->hFrags.capacity() : nReads * 2 + 16);
   int64_t pk = 0; int32_t maxLen = 0;
   for (size_t r = 0; r < nReads; r++) {
     const int64_t len64 = packed ? (int64_t)S.lengths[r] : readOffsets[r + 1] - readOffsets[r];

@@ -97,7 +97,7 @@ struct mm_ctx {
 
   // sketches: raw (a4) and after frequent-seed removal (a8)
   DevBuf dSkHash, dSkPos, dSkStrand, dSkCount;          // [nFrags*s] u64, int2, i8 ; [nFrags] u32
-  DevBuf dHardList, dCounters;
+  DevBuf dHardList, dCounters, dSketchSpill;            // dSketchSpill: first / last / strand-sum arrays of k_sketch_hard<K, true> (large sketches)
   DevBuf dSketchTabs; int sketchTabsK = 0;        // strip-hasher tables for kmerSize sketchTabsK (built once, copied into LDS by every workgroup)
   DevBuf dQHash, dQStrand, dSeedVal;                    // post-removal sketch + per-seed lookup value
   DevBuf dStats;                                        // mm_frag_stats[nFrags]

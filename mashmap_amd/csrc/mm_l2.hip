@@ -36,27 +36,31 @@ struct L2Info { int64_t e0; int32_t nPre; int32_t nAll;         // slice [e0, e0
                 int32_t target; int32_t pad; };                 // pre-load takes records with wpos >= target = rangeStart - segLength - 1 (:1290)
 struct L2Tmp { int32_t start, end, shared, strand; };
 
-// stream entry (uint32):
-//   bits 0..10  1-based position j of the hash in the query sketch (0: beyond the sketch -> no effect on the state)
-//   bit  11     hash equals q[j]
-//   bits 12..13 strand vote of a matching insert + 1 (query strand x reference strand)
-//   bits 14..26 insert / end: wpos minus the running position (previous insert's wpos, rangeStart at first)
-//   bits 27..31 kind, one bit each (the sweep turns a bit into a lane mask with one v_bfe_i32):
-//               insert + evaluate, eviction, pre-load insert (computeMap.hpp:1323-1338), end of stream, skip
-//   skip: adds its low 27 bits to the running position (a gap that does not fit 13 bits)
+// stream entry (uint32), JB = width of the sketch-position field (11 for sketches of up to 2046 entries, 13 beyond):
+//   bits 0..JB-1        1-based position j of the hash in the query sketch (0: beyond the sketch -> no effect on the state)
+//   bit  JB             hash equals q[j]
+//   bits JB+1..JB+2     strand vote of a matching insert + 1 (query strand x reference strand)
+//   bits JB+3..26       insert / end: wpos minus the running position (previous insert's wpos, rangeStart at first)
+//   bits 27..31         kind, one bit each (the sweep turns a bit into a lane mask with one v_bfe_i32):
+//                       insert + evaluate, eviction, pre-load insert (computeMap.hpp:1323-1338), end of stream, skip
+//   skip: adds its low 27 bits to the running position (a gap that does not fit the delta field)
 #define E_INS_BIT 27
 #define E_DEL_BIT 28
 #define E_PRE_BIT 29
 #define E_END_BIT 30
 #define E_SKIP_BIT 31
-#define E_MAXDELTA 0x1FFFu
-#define E_DELTA_SHIFT 14
 #define E_SKIP_MAX ((1u << 27) - 1u)
 #define E_STEP 16           // entries per 64-byte sweep step
+template <int JB> struct EF {
+  static constexpr uint32_t JMASK = (1u << JB) - 1u;
+  static constexpr int MATCH_BIT = JB, VOTE_SHIFT = JB + 1, DELTA_SHIFT = JB + 3, DELTA_BITS = 27 - (JB + 3);
+  static constexpr uint32_t MAXDELTA = (1u << DELTA_BITS) - 1u;
+};
+static inline int mm_l2_jb(int s) { return s > 2046 ? 13 : 11; }
 
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-k_l2_extents(int nCand, int segLength, const mm_l1_candidate* __restrict__ l1, const mm_frag_stats* __restrict__ stats, const uint32_t* __restrict__ evKey,
+k_l2_extents(int nCand, int segLength, int deltaBits, const mm_l1_candidate* __restrict__ l1, const mm_frag_stats* __restrict__ stats, const uint32_t* __restrict__ evKey,
              const int64_t* __restrict__ contigBlock, const int64_t* __restrict__ blockOff,
              const int64_t* __restrict__ evBlock, L2Info* __restrict__ info, int32_t* __restrict__ cnt) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -82,9 +86,9 @@ k_l2_extents(int nCand, int segLength, const mm_l1_candidate* __restrict__ l1, c
   o.open0 = ob; o.nOpen = (int32_t)(oe - ob); o.target = target;
   o.sketch = fst.sketchSize | (fst.rawSketchSize == fst.sketchSize ? (int32_t)0x80000000 : 0); o.pad = 0;
   info[c] = o;
-  // upper bound of the stream: every event, the end marker, one skip per 8 K of range, slack for the end marker's own skips
+  // upper bound of the stream: every event, the end marker, one skip per 2^deltaBits of range, slack for the end marker's own skips
   // (the record behind the last insert may be anywhere in the contig: up to 2^31 / 2^27 of them)
-  const int n = o.nAll + o.nOpen + 1 + ((cand.rangeEndPos - cand.rangeStartPos) >> 13) + 20;
+  const int n = o.nAll + o.nOpen + 1 + ((cand.rangeEndPos - cand.rangeStartPos) >> deltaBits) + 20;
   cnt[c] = (n + E_STEP - 1) & ~(E_STEP - 1);
 }
 
@@ -153,6 +157,7 @@ __host__ __device__ static inline size_t mm_locate_lds_per_wave(int s, int NB) {
   return (b + 15) & ~(size_t)15;
 }
 // ---------------------------------------------------------------------------------------------
+template <int JB>
 __global__ void __launch_bounds__(256)
 k_l2_locate(int cBase, int nCand, int64_t opsBase, int s, int NB, const mm_l1_candidate* __restrict__ l1, const mm_frag_stats* __restrict__ stats,
             const uint64_t* __restrict__ qHash, const int8_t* __restrict__ qStrand,
@@ -168,7 +173,8 @@ k_l2_locate(int cBase, int nCand, int64_t opsBase, int s, int NB, const mm_l1_ca
   uint32_t* qhi = (uint32_t*)(base + (size_t)(s + 1) * 8);         // its high words (the bucket walk compares these)
   uint16_t* bkt = (uint16_t*)(base + (size_t)(s + 1) * 8 + (size_t)(s + 2) / 2 * 8);   // bkt[b] = #query hashes whose bucket is < b, b = 0..NB
   int8_t* qs = (int8_t*)(base + (size_t)(s + 1) * 8 + (size_t)(s + 2) / 2 * 8 + (size_t)(NB + 4) * 2);
-  for (int ci = blockIdx.x * 4 + wave; ci < nCand; ci += gridDim.x * 4) {
+  const int wpb = (int)(blockDim.x >> 6);                          // waves per workgroup: 4, fewer when a sketch's LDS share is large
+  for (int ci = blockIdx.x * wpb + wave; ci < nCand; ci += gridDim.x * wpb) {
     const int c = cBase + ci;                                      // this launch covers the candidates [cBase, cBase + nCand): their streams start at ops[opOff - opsBase]
     const mm_l1_candidate cand = l1[c];
     const int f = cand.frag;
@@ -210,7 +216,7 @@ k_l2_locate(int cBase, int nCand, int64_t opsBase, int s, int NB, const mm_l1_ca
       const uint32_t hh = (uint32_t)(h >> 32);
       while (qhi[lo] < hh) lo++;
       if (qhi[lo] == hh) { while (q[lo] < h) lo++; }
-      return (uint32_t)(lo + 1) | (q[lo] == h ? 0x800u : 0u) | ((uint32_t)((int)qs[lo] + 1) << 12);   // bits 12..13: query strand + 1
+      return (uint32_t)(lo + 1) | (q[lo] == h ? (1u << EF<JB>::MATCH_BIT) : 0u) | ((uint32_t)((int)qs[lo] + 1) << EF<JB>::VOTE_SHIFT);   // query strand + 1
     };
     // the slide ends with the last insert at or before rangeEnd (evictions behind it are never reached, :1340)
     int lastRel = -1;                                              // index of that insert relative to e0
@@ -256,7 +262,7 @@ k_l2_locate(int cBase, int nCand, int64_t opsBase, int s, int NB, const mm_l1_ca
         if (keep) {
           op = locate(h);
           // vote of a matching insert = query strand x reference strand: a REV record (aux bit 31) mirrors the field around 1
-          if (isIns && (aux >> 31)) op = (op & ~0x3000u) | ((2u - ((op >> 12) & 3u)) << 12);
+          if (isIns && (aux >> 31)) op = (op & ~(3u << EF<JB>::VOTE_SHIFT)) | ((2u - ((op >> EF<JB>::VOTE_SHIFT) & 3u)) << EF<JB>::VOTE_SHIFT);
           op |= 1u << (inPre ? E_PRE_BIT : (isIns ? E_INS_BIT : E_DEL_BIT));
           evalIns = !inPre && isIns;
         }
@@ -271,17 +277,17 @@ k_l2_locate(int cBase, int nCand, int64_t opsBase, int s, int NB, const mm_l1_ca
         if (below) prevPos = p2;
       }
       const int delta = evalIns ? pos - prevPos : 0;
-      const bool needSkip = evalIns && delta > (int)E_MAXDELTA;
-      if (needSkip && (uint32_t)(delta - (int)E_MAXDELTA) > E_SKIP_MAX) tooWide = true;
+      const bool needSkip = evalIns && delta > (int)EF<JB>::MAXDELTA;
+      if (needSkip && (uint32_t)(delta - (int)EF<JB>::MAXDELTA) > E_SKIP_MAX) tooWide = true;
       const int mine = keep ? (needSkip ? 2 : 1) : 0;
       const uint64_t mKeep = __ballot(keep), mSkip = __ballot(needSkip);          // slots before this lane: one per kept event, one more per skip
       const int at = outN + (int)mm_popc_below(mKeep) + (int)mm_popc_below(mSkip);
       if (keep && at + mine <= cap) {
         if (needSkip) {
-          const uint32_t extra = (uint32_t)(delta - (int)E_MAXDELTA);
+          const uint32_t extra = (uint32_t)(delta - (int)EF<JB>::MAXDELTA);
           out[at] = (1u << E_SKIP_BIT) | (extra & E_SKIP_MAX);
-          out[at + 1] = op | (E_MAXDELTA << E_DELTA_SHIFT);
-        } else out[at] = op | ((uint32_t)delta << E_DELTA_SHIFT);
+          out[at + 1] = op | (EF<JB>::MAXDELTA << EF<JB>::DELTA_SHIFT);
+        } else out[at] = op | ((uint32_t)delta << EF<JB>::DELTA_SHIFT);
       }
       outN += __popcll(mKeep) + __popcll(mSkip);
       if (mIns) posAcc = __shfl(pos, 63 - (int)__builtin_clzll(mIns));
@@ -289,12 +295,12 @@ k_l2_locate(int cBase, int nCand, int64_t opsBase, int s, int NB, const mm_l1_ca
     if (lane == 0) {                                               // end marker: carries the wpos behind the last insert
       int at = outN;
       uint32_t delta = lastRel >= 0 ? (uint32_t)(nextW - posAcc) : 0u;
-      while (delta > E_MAXDELTA) {                                 // that record may be far away: as many skips as it takes
-        const uint32_t extra = delta - E_MAXDELTA > E_SKIP_MAX ? E_SKIP_MAX : delta - E_MAXDELTA;
+      while (delta > EF<JB>::MAXDELTA) {                           // that record may be far away: as many skips as it takes
+        const uint32_t extra = delta - EF<JB>::MAXDELTA > E_SKIP_MAX ? E_SKIP_MAX : delta - EF<JB>::MAXDELTA;
         if (at < cap) out[at] = (1u << E_SKIP_BIT) | extra;
         at++; delta -= extra;
       }
-      if (at < cap) out[at] = (1u << E_END_BIT) | (delta << E_DELTA_SHIFT);
+      if (at < cap) out[at] = (1u << E_END_BIT) | (delta << EF<JB>::DELTA_SHIFT);
       else tooWide = true;                                         // cannot happen: the reservation covers every event + skips
     }
     if (__ballot(tooWide) && lane == 0) atomicOr(&counters[6], 4ull);
@@ -313,7 +319,9 @@ template <int B> __device__ __forceinline__ int mm_bit_mask(uint32_t x) { int m;
 // Every lane owns an LDS bank: 8-bit cell p of lane l is byte p & 3 of dword (p >> 2) * 64 + l; 16-bit cell p of lane l is
 // half l >> 5 of dword p * 32 + (l & 31).  Both 32-lane halves of a DS instruction then see 32 distinct banks.
 // ---------------------------------------------------------------------------------------------
-template <bool WIDE>
+// LPW lanes of a wave carry a candidate (64; fewer for sketches whose 64 states would not fit a CU's LDS: 32, 16 or 8 -- the other
+// lanes leave at once); JB: width of the stream entries' sketch-position field.
+template <bool WIDE, int JB, int LPW>
 __global__ void __launch_bounds__(64)
 k_l2_sweep(int cBase, int nCand, int64_t opsBase, const int32_t* __restrict__ candList, int segLength, const mm_l1_candidate* __restrict__ l1, const mm_frag_stats* __restrict__ stats,
            const int64_t* __restrict__ opOff, const int32_t* __restrict__ opCnt, const uint32_t* __restrict__ ops,
@@ -329,8 +337,8 @@ k_l2_sweep(int cBase, int nCand, int64_t opsBase, const int32_t* __restrict__ ca
   extern __shared__ __attribute__((aligned(16))) unsigned char cellRaw[];
   CellT* cell = (CellT*)cellRaw;
   const int lane = threadIdx.x;
-  const int li = blockIdx.x * 64 + lane;
-  if (li >= nCand) return;
+  const int li = blockIdx.x * LPW + lane;
+  if (lane >= LPW || li >= nCand) return;
   const int cIdx = candList ? candList[li] : cBase + li;   // candidates [cBase, cBase + nCand), or the listed ones (absolute indices); ops holds the streams from opsBase on
   const mm_l1_candidate cand = l1[cIdx];
   const int f = cand.frag;
@@ -338,8 +346,8 @@ k_l2_sweep(int cBase, int nCand, int64_t opsBase, const int32_t* __restrict__ ca
   const uint4* src = (const uint4*)(ops + (opOff[cIdx] - opsBase));
   const int nSteps = opCnt[cIdx] / E_STEP;             // 16 entries = 4 x 16 bytes per step
   int posAcc = cand.rangeStartPos;                     // running position of the delta code
-  const int lbase = WIDE ? (lane & 31) * 2 + (lane >> 5) : lane * 4;
-#define CELL(p) cell[WIDE ? (p) * 64 + lbase : ((p) >> 2) * 256 + lbase + ((p) & 3)]
+  const int lbase = WIDE ? (LPW == 64 ? (lane & 31) * 2 + (lane >> 5) : lane) : lane * 4;
+#define CELL(p) cell[WIDE ? (p) * LPW + lbase : ((p) >> 2) * (LPW * 4) + lbase + ((p) & 3)]
   CELL(0) = 0;
   for (int p = 1; p <= S; p++) CELL(p) = (CellT)(1u | (1u << (CB + 1)));       // num_before_inc = 1, inactive, vote 0
   int pivot = S, pivRank = S, shared = 0, votes = 0;
@@ -359,15 +367,15 @@ k_l2_sweep(int cBase, int nCand, int64_t opsBase, const int32_t* __restrict__ ca
   // front, independent of the case.  insM: the entry inserts (insert or pre-load), delM: it evicts.
   int doubleOpen = 0, cntOverflow = 0;
   auto apply = [&](uint32_t e, int insM, int delM) {
-    const int j = (int)(e & 0x7FFu) & (insM | delM);   // 0: no hash / hash beyond the query sketch -> no effect (cell 0 is a dummy)
+    const int j = (int)(e & EF<JB>::JMASK) & (insM | delM);   // 0: no hash / hash beyond the query sketch -> no effect (cell 0 is a dummy)
     const int valid = neg(-j) & ~cntOverflow;          // after a counter overflow the lane only idles to the end
-    const int mt = BITM(e, 11);
+    const int mt = BITM(e, EF<JB>::MATCH_BIT);
     const int ltS = neg(pivot - S);                    // pivot + 1 <= S
     const int pn = pivot - ltS;                        // min(pivot + 1, S)
     const uint32_t cw = CELL(j), pw = CELL(pivot), nw = CELL(pn);
     const int vi = valid & insM, vd = valid & delM;
     const int IM = vi & mt, IN = vi & ~mt, DM = vd & mt, DN = vd & ~mt;
-    const int vf = (int)((e >> 12) & 3u);              // vote + 1; a query hash normally has one open reference window at a time (windowLen == 0):
+    const int vf = (int)((e >> EF<JB>::VOTE_SHIFT) & 3u);   // vote + 1; a query hash normally has one open reference window at a time (windowLen == 0):
     doubleOpen |= IM & BITM(cw, CB);                   // the 2-bit vote relies on it; a candidate that violates it is handed to k_l2_sweep_exact
     cntOverflow |= IN & neg((int)(CMASK - 1u) - (int)(cw & CMASK));   // the counter of this cell is full: redo the candidate with wide cells
     const int repl = (int)(cw & CMASK) | sel(IM, (int)((1u << CB) | ((uint32_t)vf << (CB + 1))), (int)(1u << (CB + 1)));
@@ -441,7 +449,7 @@ k_l2_sweep(int cBase, int nCand, int64_t opsBase, const int32_t* __restrict__ ca
       const int mIns = BITM(e, 27) & act, mDel = BITM(e, 28) & act, mPre = BITM(e, 29) & act, mEnd = BITM(e, 30) & act;
       const int mSkip = neg((int)e) & act;
       const int ie = mIns | mEnd;
-      posAcc += ((int)((e >> E_DELTA_SHIFT) & E_MAXDELTA) & ie) | ((int)(e & E_SKIP_MAX) & mSkip);
+      posAcc += ((int)((e >> EF<JB>::DELTA_SHIFT) & EF<JB>::MAXDELTA) & ie) | ((int)(e & E_SKIP_MAX) & mSkip);
       const int wpos = posAcc;
       evaluate(ie & evalPending, wpos);
       evalPending = (evalPending & ~ie) | mIns;
@@ -462,7 +470,7 @@ k_l2_sweep(int cBase, int nCand, int64_t opsBase, const int32_t* __restrict__ ca
   int total = nFlushed + (havePend ? 1 : 0);
   if (cntOverflow) {
     total = 0;
-    if (WIDE) atomicOr(&counters[6], 8ull);            // cannot happen: 12 bits hold every open record of a sketch <= 1024
+    if (WIDE) exactList[atomicAdd(&counters[0], 1ull)] = cIdx;   // > 4094 open reference-only hashes between two query hashes: the literal kernel counts in 32 bits
     else wideList[atomicAdd(&counters[7], 1ull)] = cIdx;
   }
   if (doubleOpen && !cntOverflow) {                    // a query hash with two reference windows open at once: the 2-bit vote cell cannot hold it;
@@ -505,7 +513,7 @@ k_l2_sweep(int cBase, int nCand, int64_t opsBase, const int32_t* __restrict__ ca
 // ---------------------------------------------------------------------------------------------
 struct ExactCell { int32_t cnt; int16_t vote; int16_t active; };
 __global__ void __launch_bounds__(64)
-k_l2_sweep_exact(int nList, int64_t opsBase, const int32_t* __restrict__ list, int segLength, const mm_l1_candidate* __restrict__ l1, const mm_frag_stats* __restrict__ stats,
+k_l2_sweep_exact(int jb, int nList, int64_t opsBase, const int32_t* __restrict__ list, int segLength, const mm_l1_candidate* __restrict__ l1, const mm_frag_stats* __restrict__ stats,
                  const int64_t* __restrict__ opOff, const int32_t* __restrict__ opCnt, const uint32_t* __restrict__ ops,
                  const int64_t* __restrict__ l1Off, ExactCell* __restrict__ cells, int cellStride, L2Tmp* __restrict__ tmp, int locap,
                  mm_l2_locus* __restrict__ l2, unsigned long long l2Cap, int64_t* __restrict__ l2First, int32_t* __restrict__ l2Num,
@@ -516,6 +524,7 @@ k_l2_sweep_exact(int nList, int64_t opsBase, const int32_t* __restrict__ list, i
   const mm_l1_candidate cand = l1[cIdx];
   const int f = cand.frag;
   const int S = stats[f].sketchSize;
+  const uint32_t jmask = (1u << jb) - 1u; const int deltaShift = jb + 3; const uint32_t maxDelta = (1u << (27 - deltaShift)) - 1u;
   ExactCell* cell = cells + (size_t)li * cellStride;
   cell[0] = ExactCell{0, 0, 0};
   for (int p = 1; p <= S; p++) cell[p] = ExactCell{1, 0, 0};                   // SlideMapper::init (:103-121)
@@ -539,7 +548,7 @@ k_l2_sweep_exact(int nList, int64_t opsBase, const int32_t* __restrict__ list, i
     const uint32_t e = src[i];
     const bool isIns = (e >> E_INS_BIT) & 1u, isDel = (e >> E_DEL_BIT) & 1u, isPre = (e >> E_PRE_BIT) & 1u, isEnd = (e >> E_END_BIT) & 1u, isSkip = (e >> E_SKIP_BIT) & 1u;
     if (isSkip) { posAcc += (int)(e & E_SKIP_MAX); continue; }
-    if (isIns || isEnd) posAcc += (int)((e >> E_DELTA_SHIFT) & E_MAXDELTA);
+    if (isIns || isEnd) posAcc += (int)((e >> deltaShift) & maxDelta);
     const int wpos = posAcc;
     if ((isIns || isEnd) && evalPending) {                                       // the evaluation behind the previous insert (:1376-1430): it needed this wpos
       if (evShared > bestShared) {
@@ -556,13 +565,13 @@ k_l2_sweep_exact(int nList, int64_t opsBase, const int32_t* __restrict__ list, i
     }
     if (isEnd) break;
     if (isIns) { evalPending = true; evPrevVotes = lastVotes; }
-    const int j = (int)(e & 0x7FFu);
+    const int j = (int)(e & jmask);
     if (j > 0 && (isIns || isPre || isDel)) {
-      const bool match = (e >> 11) & 1u;
+      const bool match = (e >> jb) & 1u;
       ExactCell c = cell[j];
       if (isIns || isPre) {                                                      // insert_minmer (:125-165)
         if (match) {
-          c.active = 1; c.vote = (int16_t)(c.vote + ((int)((e >> 12) & 3u) - 1));
+          c.active = 1; c.vote = (int16_t)(c.vote + ((int)((e >> (jb + 1)) & 3u) - 1));
           if (j <= pivot) { shared++; votes += c.vote; }
           cell[j] = c;
         } else {
@@ -621,6 +630,7 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt) {
   const DeviceIndex& I = c->idx;
   const int s = c->P.sketchSize;
   const int nC = (int)c->nL1;
+  const int JB = mm_l2_jb(s);                                              // width of the stream entries' sketch-position field
   MM_HIP(c, c->dL2Info.ensure((size_t)nC * sizeof(L2Info) + 64));
   MM_HIP(c, c->dL2Cnt.ensure((size_t)nC * 4 + 64));
   MM_HIP(c, c->dL2Off.ensure((size_t)nC * 8 + 64));
@@ -628,7 +638,7 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt) {
   int64_t totalOps = 0;
   {
     KernelTimer t(c, MM_K_L2_LOCATE);
-    hipLaunchKernelGGL(k_l2_extents, dim3((nC + 255) / 256), dim3(256), 0, c->stream, nC, c->P.segLength, c->dL1.as<mm_l1_candidate>(), c->dStats.as<mm_frag_stats>(),
+    hipLaunchKernelGGL(k_l2_extents, dim3((nC + 255) / 256), dim3(256), 0, c->stream, nC, c->P.segLength, JB == 13 ? EF<13>::DELTA_BITS : EF<11>::DELTA_BITS, c->dL1.as<mm_l1_candidate>(), c->dStats.as<mm_frag_stats>(),
                        I.evKey.as<uint32_t>(), I.contigBlock.as<int64_t>(), I.blockOff.as<int64_t>(), I.evBlock.as<int64_t>(),
                        c->dL2Info.as<L2Info>(), c->dL2Cnt.as<int32_t>());
     MM_HIP(c, hipGetLastError());
@@ -674,27 +684,53 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt) {
   // walks save: profiles/r02z_locate_buckets.txt)
   int NB = 256; while (NB < s) NB <<= 1;
   if (const char* e = getenv("MM_L2_BUCKETS")) { const int v = atoi(e); if (v >= 64 && v <= 16384 && (v & (v - 1)) == 0) NB = v; }
-  const size_t ldsLoc = mm_locate_lds_per_wave(s, NB) * 4;
-  MM_HIP(c, hipFuncSetAttribute((const void*)k_l2_locate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsLoc));
+  // waves per workgroup: 4, fewer when four sketches + bucket tables would not fit a CU's LDS
+  int wpb = 4; while (wpb > 1 && mm_locate_lds_per_wave(s, NB) * wpb > 160 * 1024) wpb >>= 1;
+  const size_t ldsLoc = mm_locate_lds_per_wave(s, NB) * wpb;
+  if (ldsLoc > 160 * 1024) { c->err = "sketchSize too large for the LDS-resident query sketch of k_l2_locate"; return MM_ERR_ARG; }
   auto locate = [&](const Chunk& ch) -> int {
     KernelTimer t(c, MM_K_L2_LOCATE);
-    int blocks = (ch.n + 3) / 4; if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL(k_l2_locate, dim3(blocks), dim3(256), ldsLoc, c->stream, ch.c0, ch.n, ch.base, s, NB, c->dL1.as<mm_l1_candidate>(),
-                       c->dStats.as<mm_frag_stats>(), c->dQHash.as<uint64_t>(), c->dQStrand.as<int8_t>(), c->dSkHash.as<uint64_t>(), c->dSkStrand.as<int8_t>(),
-                       I.evKey.as<uint32_t>(),
-                       I.evAux.as<uint32_t>(), I.evHash.as<uint64_t>(), I.opKey.as<uint32_t>(), I.opAux.as<uint32_t>(), I.opHash.as<uint64_t>(),
-                       I.contigOff.as<int64_t>(),
-                       c->dL2Info.as<L2Info>(), c->dL2Off.as<int64_t>(), c->dL2Cnt.as<int32_t>(), c->dL2Ops.as<uint32_t>(), cnt);
+    int blocks = (ch.n + wpb - 1) / wpb; if (blocks > 256 * 32) blocks = 256 * 32;
+    auto go = [&](auto kern) {
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsLoc);
+      hipLaunchKernelGGL(kern, dim3(blocks), dim3(wpb * 64), ldsLoc, c->stream, ch.c0, ch.n, ch.base, s, NB, c->dL1.as<mm_l1_candidate>(),
+                         c->dStats.as<mm_frag_stats>(), c->dQHash.as<uint64_t>(), c->dQStrand.as<int8_t>(), c->dSkHash.as<uint64_t>(), c->dSkStrand.as<int8_t>(),
+                         I.evKey.as<uint32_t>(),
+                         I.evAux.as<uint32_t>(), I.evHash.as<uint64_t>(), I.opKey.as<uint32_t>(), I.opAux.as<uint32_t>(), I.opHash.as<uint64_t>(),
+                         I.contigOff.as<int64_t>(),
+                         c->dL2Info.as<L2Info>(), c->dL2Off.as<int64_t>(), c->dL2Cnt.as<int32_t>(), c->dL2Ops.as<uint32_t>(), cnt);
+    };
+    if (JB == 13) go(k_l2_locate<13>); else go(k_l2_locate<11>);
     MM_HIP(c, hipGetLastError());
     return MM_OK;
   };
   const bool oneChunk = chunks.size() == 1;
   if (oneChunk) { const int rc = locate(chunks[0]); if (rc != MM_OK) return rc; }      // its streams stay put over the retries below
-  const size_t ldsWide = (size_t)(s + 1) * 64 * 2;                         // cells 0..S, 16 bit
-  const size_t ldsNarrow = (size_t)((s + 1 + 3) / 4) * 256;                 // 8 bit
-  if (ldsWide > 160 * 1024) { c->err = "sketchSize too large for the LDS-resident L2 state"; return MM_ERR_ARG; }
-  MM_HIP(c, hipFuncSetAttribute((const void*)k_l2_sweep<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsWide));
-  MM_HIP(c, hipFuncSetAttribute((const void*)k_l2_sweep<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsNarrow));
+  // candidates per wave of the sweeps (LPW): 64, fewer when the LDS state of 64 does not fit a CU -- 8-bit cells first, 16-bit cells
+  // for the rare candidate whose 5-bit counters overflow
+  const int lpwN = JB == 11 ? 64 : ((size_t)((s + 4) / 4) * 128 <= 160 * 1024 ? 32 : 16);
+  const int lpwW = JB == 11 ? ((size_t)(s + 1) * 128 <= 160 * 1024 ? 64 : 32) : ((size_t)(s + 1) * 32 <= 160 * 1024 ? 16 : 8);
+  const size_t ldsWide = (size_t)(s + 1) * lpwW * 2;                       // cells 0..S, 16 bit
+  const size_t ldsNarrow = (size_t)((s + 1 + 3) / 4) * lpwN * 4;           // 8 bit
+  if (ldsWide > 160 * 1024 || ldsNarrow > 160 * 1024) { c->err = "sketchSize too large for the LDS-resident L2 state"; return MM_ERR_ARG; }
+  // one launch of a sweep kernel: n candidates starting at c0, or the n listed ones
+  auto sweep = [&](bool wide, int c0, int n, int64_t opsBase, const int32_t* list, int locap_) {
+    auto go = [&](auto kern, int lpw, size_t lds) {
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(kern, dim3((unsigned)((n + lpw - 1) / lpw)), dim3(64), lds, c->stream, c0, n, opsBase, list, c->P.segLength,
+                         c->dL1.as<mm_l1_candidate>(), c->dStats.as<mm_frag_stats>(), c->dL2Off.as<int64_t>(), c->dL2Cnt.as<int32_t>(), c->dL2Ops.as<uint32_t>(),
+                         c->dL1Off.as<int64_t>(), c->dL2Tmp.as<L2Tmp>(), locap_, c->dL2.as<mm_l2_locus>(), (unsigned long long)c->l2Cap,
+                         c->dL2Wide.as<int32_t>(), c->dL2Exact.as<int32_t>(), c->dL2First.as<int64_t>(), c->dL2Num.as<int32_t>(), cnt);
+    };
+    if (!wide) {
+      if (JB == 11) go(k_l2_sweep<false, 11, 64>, 64, ldsNarrow);
+      else if (lpwN == 32) go(k_l2_sweep<false, 13, 32>, 32, ldsNarrow);
+      else go(k_l2_sweep<false, 13, 16>, 16, ldsNarrow);
+    } else {
+      if (JB == 11) { if (lpwW == 64) go(k_l2_sweep<true, 11, 64>, 64, ldsWide); else go(k_l2_sweep<true, 11, 32>, 32, ldsWide); }
+      else { if (lpwW == 16) go(k_l2_sweep<true, 13, 16>, 16, ldsWide); else go(k_l2_sweep<true, 13, 8>, 8, ldsWide); }
+    }
+  };
   MM_HIP(c, c->dL2Wide.ensure((size_t)nC * 4 + 64)); MM_HIP(c, c->dL2Exact.ensure((size_t)nC * 4 + 64));
   MM_HIP(c, c->dL2First.ensure((size_t)nC * 8 + 64)); MM_HIP(c, c->dL2Num.ensure((size_t)nC * 4 + 64));
   if (c->l2Cap < c->nL1 * 2 + 1024) c->l2Cap = c->nL1 * 2 + 1024;
@@ -720,10 +756,7 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt) {
           if (rc != MM_OK) return rc;
           order = c->dL2Order.as<int32_t>();
         }
-        hipLaunchKernelGGL((k_l2_sweep<false>), dim3((unsigned)((ch.n + 63) / 64)), dim3(64), ldsNarrow, c->stream, ch.c0, ch.n, ch.base, order, c->P.segLength,
-                           c->dL1.as<mm_l1_candidate>(), c->dStats.as<mm_frag_stats>(), c->dL2Off.as<int64_t>(), c->dL2Cnt.as<int32_t>(), c->dL2Ops.as<uint32_t>(),
-                           c->dL1Off.as<int64_t>(), c->dL2Tmp.as<L2Tmp>(), locap, c->dL2.as<mm_l2_locus>(), (unsigned long long)c->l2Cap,
-                           c->dL2Wide.as<int32_t>(), c->dL2Exact.as<int32_t>(), c->dL2First.as<int64_t>(), c->dL2Num.as<int32_t>(), cnt);
+        sweep(false, ch.c0, ch.n, ch.base, order, locap);
         MM_HIP(c, hipGetLastError());
       }
       MM_HIP(c, hipMemcpyAsync(hc, cnt, 64, hipMemcpyDeviceToHost, c->stream));
@@ -732,10 +765,7 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt) {
         const int nWide = (int)hc[7];
         if (getenv("MM_DEBUG")) fprintf(stderr, "[mm] L2 sweep: %d of %d candidates redone with 16-bit cells\n", nWide, ch.n);
         KernelTimer t(c, MM_K_L2);
-        hipLaunchKernelGGL((k_l2_sweep<true>), dim3((unsigned)((nWide + 63) / 64)), dim3(64), ldsWide, c->stream, 0, nWide, ch.base, c->dL2Wide.as<int32_t>(), c->P.segLength,
-                           c->dL1.as<mm_l1_candidate>(), c->dStats.as<mm_frag_stats>(), c->dL2Off.as<int64_t>(), c->dL2Cnt.as<int32_t>(), c->dL2Ops.as<uint32_t>(),
-                           c->dL1Off.as<int64_t>(), c->dL2Tmp.as<L2Tmp>(), locap, c->dL2.as<mm_l2_locus>(), (unsigned long long)c->l2Cap,
-                           (int32_t*)nullptr, c->dL2Exact.as<int32_t>(), c->dL2First.as<int64_t>(), c->dL2Num.as<int32_t>(), cnt);
+        sweep(true, 0, nWide, ch.base, c->dL2Wide.as<int32_t>(), locap);
         MM_HIP(c, hipGetLastError());
         MM_HIP(c, hipMemcpyAsync(hc, cnt, 64, hipMemcpyDeviceToHost, c->stream));
         MM_HIP(c, hipStreamSynchronize(c->stream));
@@ -745,7 +775,7 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt) {
         if (getenv("MM_DEBUG")) fprintf(stderr, "[mm] L2 sweep: %d of %d candidates redone by the exact kernel (overlapping windows of one hash)\n", nExact, ch.n);
         MM_HIP(c, c->dL2Cells.ensure((size_t)nExact * (size_t)(s + 1) * sizeof(ExactCell) + 64));
         KernelTimer t(c, MM_K_L2);
-        hipLaunchKernelGGL(k_l2_sweep_exact, dim3((unsigned)((nExact + 63) / 64)), dim3(64), 0, c->stream, nExact, ch.base, c->dL2Exact.as<int32_t>(), c->P.segLength,
+        hipLaunchKernelGGL(k_l2_sweep_exact, dim3((unsigned)((nExact + 63) / 64)), dim3(64), 0, c->stream, JB, nExact, ch.base, c->dL2Exact.as<int32_t>(), c->P.segLength,
                            c->dL1.as<mm_l1_candidate>(), c->dStats.as<mm_frag_stats>(), c->dL2Off.as<int64_t>(), c->dL2Cnt.as<int32_t>(), c->dL2Ops.as<uint32_t>(),
                            c->dL1Off.as<int64_t>(), c->dL2Cells.as<ExactCell>(), s + 1, c->dL2Tmp.as<L2Tmp>(), locap, c->dL2.as<mm_l2_locus>(),
                            (unsigned long long)c->l2Cap, c->dL2First.as<int64_t>(), c->dL2Num.as<int32_t>(), cnt);
@@ -767,7 +797,6 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt) {
     break;
   }
   if (hc[6] & 4ull) { c->err = "a gap of more than 2^27 bases between consecutive reference minmers inside an L1 candidate is not representable in the L2 stream"; return MM_ERR_ARG; }
-  if (hc[6] & 8ull) { c->err = "L2 state counter overflow with 16-bit cells"; return MM_ERR_STATE; }
   if (hc[6] & 1ull) { c->err = "an L1 candidate with more tied L2 loci than 64 GiB of staging can hold"; return MM_ERR_CAPACITY; }
   if (hc[5]) { c->err = "L2 locus buffer overflow"; return MM_ERR_CAPACITY; }
   c->nL2 = (size_t)hc[4];

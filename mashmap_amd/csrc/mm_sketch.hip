@@ -114,10 +114,13 @@ __device__ __forceinline__ uint64_t mm_window_or(uint64_t x) {
 //   kernel leaves its own count in skCount[f] as the first hint), then by bisection once a cut has flooded the table.
 // ---------------------------------------------------------------------------------------------
 #define MM_SK_HINT_OVERFLOW 0xFFFFFFFFu   // skCount[f] of a listed fragment: a queue / table / duplicate list of the fast kernel overflowed
-template <int K>
+// SPILL: the first / last / strand-sum arrays of the table live in HBM scratch (`spill`: 3 x NS int32 per workgroup) instead of LDS --
+// sketches beyond ~1500 entries, whose key table alone fills most of a CU's 160 KB (the reference's --dense derives sketchSize =
+// 0.02 (1 + (1 - pi) / 0.05) (segLength - k): 1998 for --pi 80 -s 20000, parseCmdArgs.hpp:626-630).  Same atomics, slower memory; exact all the same.
+template <int K, bool SPILL>
 __device__ __forceinline__ void
 mm_sketch_hard(unsigned char* smem, const int f, const uint4* __restrict__ gTabs, const uint32_t* __restrict__ bases2, const uint32_t* __restrict__ nmask,
-               const DFrag* __restrict__ frags, const uint32_t* __restrict__ readHasN, int s, int wantFast, int HT, int PAD,
+               const DFrag* __restrict__ frags, const uint32_t* __restrict__ readHasN, int s, int wantFast, int HT, int PAD, int32_t* __restrict__ spill,
                uint64_t* __restrict__ skHash, int2* __restrict__ skPos, int8_t* __restrict__ skStrand, uint32_t* __restrict__ skCount) {
   const DFrag fr = frags[f];
   const int len = fr.len;
@@ -142,9 +145,14 @@ mm_sketch_hard(unsigned char* smem, const int f, const uint4* __restrict__ gTabs
   SkTable tab;
   tab.key = (uint64_t*)(smem + off) + MM_SK_GUARD; off += (size_t)(NS + 2 * MM_SK_GUARD) * 8;   // MM_SK_GUARD always-empty slots on either side: the ranking reads windows
   tab.occW = (uint64_t*)(smem + off); off += (size_t)nOcc * 8;
-  tab.first = (int32_t*)(smem + off); off += (size_t)NS * 4;
-  tab.last = (int32_t*)(smem + off); off += (size_t)NS * 4;
-  tab.sum = (int32_t*)(smem + off); off += (size_t)NS * 4;
+  if constexpr (SPILL) {
+    int32_t* g = spill + (size_t)blockIdx.x * 3 * (size_t)NS;
+    tab.first = g; tab.last = g + NS; tab.sum = g + 2 * (size_t)NS;
+  } else {
+    tab.first = (int32_t*)(smem + off); off += (size_t)NS * 4;
+    tab.last = (int32_t*)(smem + off); off += (size_t)NS * 4;
+    tab.sum = (int32_t*)(smem + off); off += (size_t)NS * 4;
+  }
   tab.occP = (uint32_t*)(smem + off); off += (((size_t)nOcc * 4 + 15) / 16) * 16;
   tab.counters = (uint32_t*)(smem + off); off += 16;
   tab.nSlots = (uint32_t)NS; tab.maxLoad = (uint32_t)HT * 5u / 8u;
@@ -185,6 +193,7 @@ mm_sketch_hard(unsigned char* smem, const int f, const uint4* __restrict__ gTabs
     for (int i = tid; i < NS; i += nthr) { tab.key[i] = MM_HASH_MAX; tab.first[i] = 0x7fffffff; tab.last[i] = -1; tab.sum[i] = 0; }
     if (tid < MM_SK_GUARD) { tab.key[-1 - tid] = MM_HASH_MAX; tab.key[NS + tid] = MM_HASH_MAX; }
     if (tid < 4) tab.counters[tid] = 0;
+    if constexpr (SPILL) __threadfence();                 // the spilled arrays' initial values, before other threads' atomics reach them
     __syncthreads();
 
     // ---- hash both strands of every k-mer ----
@@ -205,6 +214,7 @@ mm_sketch_hard(unsigned char* smem, const int f, const uint4* __restrict__ gTabs
         if (pass) tab.insert(h, pos, hf < hr ? 1 : -1);
       });
     }
+    if constexpr (SPILL) __threadfence();                 // the atomics on the spilled arrays, before the ranking threads read them
     __syncthreads();
 
     // ---- occupancy words, their prefix counts (wave 0: one DPP scan per 64 words), number of distinct keys ----
@@ -265,28 +275,42 @@ mm_sketch_hard(unsigned char* smem, const int f, const uint4* __restrict__ gTabs
     if (rank < (uint32_t)s) {
       const size_t o = (size_t)f * s + rank;
       skHash[o] = k;
-      skPos[o] = make_int2(tab.first[slot], tab.last[slot]);
+      int vf, vl, vs;
+      if constexpr (SPILL) {                          // written by device-scope atomics: read at the same scope, past the CU's L1
+        vf = __hip_atomic_load(&tab.first[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        vl = __hip_atomic_load(&tab.last[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        vs = __hip_atomic_load(&tab.sum[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else { vf = tab.first[slot]; vl = tab.last[slot]; vs = tab.sum[slot]; }
+      skPos[o] = make_int2(vf, vl);
       // the reference accumulates the strand in an int16 (base_types.hpp:24, commonFunc.hpp:268)
-      const int16_t acc = (int16_t)tab.sum[slot];
+      const int16_t acc = (int16_t)vs;
       skStrand[o] = acc > 0 ? 1 : (acc == 0 ? 0 : -1);
     }
   }
   if (tid == 0) skCount[f] = D < (uint32_t)s ? D : (uint32_t)s;
 }
 
-template <int K>
+template <int K, bool SPILL>
 __global__ void __launch_bounds__(1024)
 k_sketch_hard(const uint4* __restrict__ gTabs, const uint32_t* __restrict__ bases2, const uint32_t* __restrict__ nmask,
               const DFrag* __restrict__ frags, const uint32_t* __restrict__ readHasN,
-              const int32_t* __restrict__ fragList, const uint32_t* __restrict__ fragListCount, int s, int wantFast, int HT, int PAD,
+              const int32_t* __restrict__ fragList, const uint32_t* __restrict__ fragListCount, int s, int wantFast, int HT, int PAD, int32_t* __restrict__ spill,
               uint64_t* __restrict__ skHash, int2* __restrict__ skPos, int8_t* __restrict__ skStrand, uint32_t* __restrict__ skCount) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // the hard list's length stays on the device (no host round trip between the two kernels): a fixed grid walks it
   const uint32_t nList = *fragListCount;
   for (uint32_t i = blockIdx.x; i < nList; i += gridDim.x) {
-    mm_sketch_hard<K>(smem, fragList[i], gTabs, bases2, nmask, frags, readHasN, s, wantFast, HT, PAD, skHash, skPos, skStrand, skCount);
+    mm_sketch_hard<K, SPILL>(smem, fragList[i], gTabs, bases2, nmask, frags, readHasN, s, wantFast, HT, PAD, spill, skHash, skPos, skStrand, skCount);
     __syncthreads();                                // the next fragment reuses the LDS
   }
+}
+
+// every fragment on the hard list (sketches the fast kernel's LDS geometry cannot hold): no hint for the first cut
+__global__ void __launch_bounds__(256)
+k_sketch_all_hard(int nF, int32_t* __restrict__ hardList, uint32_t* __restrict__ hardCount, uint32_t* __restrict__ skCount) {
+  const int f = blockIdx.x * 256 + threadIdx.x;
+  if (f < nF) { hardList[f] = f; skCount[f] = MM_SK_HINT_OVERFLOW; }
+  if (f == 0) *hardCount = (uint32_t)nF;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -670,18 +694,54 @@ static FastGeom sketch_fast_geom(int K, int s, int maxLen, size_t tabBytes, bool
 // than that needs, because its LDS sets how many listed fragments a CU works on at once (s = 130: 4 workgroups)
 static int sketch_ht_hard(int s) { const int w = (s * 16 + 4) / 5; return next_pow2(w < 1024 ? 1024 : w); }
 
+// How the two sketch kernels are run for (k, s, fragment length): the fast kernel when its geometry fits (LDS, and table slots that fit
+// the 13-bit field of its duplicate list), otherwise every fragment goes down the hard list; the hard kernel with its whole table in
+// LDS when that fits, otherwise with the first / last / strand-sum arrays spilled to HBM scratch and, if the power-of-two table still
+// does not fit, the smallest table that keeps its load limit (5/8) at 2 s.  ok == false: not even that fits (the message says why).
+struct SketchPlan { bool ok, useFast, spill; FastGeom g; int HTH; size_t ldsFast, ldsHard; };
+static size_t sketch_hard_lds_spill(size_t tabBytes, int maxLen, int HT, int PAD) {
+  const size_t nW = (size_t)(maxLen + 15) / 16 + 3, nM = (size_t)(maxLen + 31) / 32 + 2;
+  const size_t NS = (size_t)HT + PAD, nOcc = NS / 64;
+  return tabBytes + ((nW * 4 + 15) / 16) * 16 + ((nM * 4 + 15) / 16) * 16 + NS * 8 + 2 * MM_SK_GUARD * 8 + nOcc * 8 + ((nOcc * 4 + 15) / 16) * 16 + 16;
+}
+static SketchPlan sketch_plan(int K, int s, int maxLen, size_t tabBytes, bool sl20Built) {
+  const size_t lim = 160 * 1024;
+  SketchPlan P;
+  P.g = sketch_fast_geom(K, s, maxLen, tabBytes, sl20Built);
+  P.ldsFast = P.g.lds;
+  P.useFast = P.ldsFast <= lim && P.g.HT + MM_SK_PAD <= 8192 && maxLen < (1 << 18) && !getenv("MM_SKETCH_ALL_HARD");
+  P.HTH = sketch_ht_hard(s);
+  P.spill = getenv("MM_SKETCH_SPILL") != nullptr;
+  P.ldsHard = sketch_hard_lds(tabBytes, maxLen, P.HTH, MM_SK_PADH);
+  if (P.ldsHard > lim || P.spill) {
+    P.spill = true;
+    P.ldsHard = sketch_hard_lds_spill(tabBytes, maxLen, P.HTH, MM_SK_PADH);
+    if (P.ldsHard > lim) {                          // not a power of two then: load limit 5/8 HT >= 2 s
+      P.HTH = (((s * 16 + 4) / 5) + 63) / 64 * 64;
+      P.ldsHard = sketch_hard_lds_spill(tabBytes, maxLen, P.HTH, MM_SK_PADH);
+    }
+  }
+  P.ok = P.ldsHard <= lim;
+  return P;
+}
+
 // Parameter combinations the LDS-resident kernels cannot hold are refused when the context is created (not after the reference
 // index has been built): the sketch tables + a staged fragment of segLength bases, and the 16-bit L2 state cells of k_l2_sweep.
 int mm_check_params(const mm_params* p, std::string& err) {
   const int s = p->sketchSize, L = p->segLength;
   const size_t tabBytes = p->kmerSize >= 16 ? sizeof(MMProdTables) : sizeof(MMTables);
-  const size_t ldsFast = sketch_fast_geom(p->kmerSize, s, L, tabBytes, false).lds, ldsHard = sketch_hard_lds(tabBytes, L, sketch_ht_hard(s), MM_SK_PADH);
-  const size_t ldsL2 = (size_t)(s + 1) * 64 * 2;
+  const SketchPlan P = sketch_plan(p->kmerSize, s, L, tabBytes, false);
   const size_t lim = 160 * 1024;
-  if (ldsFast > lim || ldsHard > lim || ldsL2 > lim) {
-    char b[320];
-    snprintf(b, sizeof b, "mm_create: segLength %d with sketchSize %d needs %zu / %zu bytes of LDS in the sketch kernels and %zu in the L2 sweep; a CU has %zu "
-             "(sketchSize <= 1279; segLength up to ~150 kbp at sketchSize 1024)", L, s, ldsFast, ldsHard, ldsL2, lim);
+  // L2: the 16-bit state cells of as few as 8 candidates per wave, the query sketch + bucket table of one wave of k_l2_locate, and the
+  // 13-bit sketch-position field of the located stream (mm_l2.hip)
+  const size_t ldsL2 = (size_t)(s + 1) * 8 * 2;
+  int NB = 256; while (NB < s) NB <<= 1;
+  const size_t ldsLoc = (size_t)(s + 1) * 8 + (size_t)(s + 2) / 2 * 8 + (size_t)(NB + 4) * 2 + (size_t)s + 32;
+  if (!P.ok || ldsL2 > lim || ldsLoc > lim || s > 8190) {
+    char b[400];
+    snprintf(b, sizeof b, "mm_create: segLength %d with sketchSize %d needs %zu bytes of LDS in the sketch kernel (table of the exact path, spilled form), %zu in the L2 "
+             "sweep and %zu in the L2 locate kernel; a CU has %zu (sketchSize up to ~5000 at segLength <= 50 kbp; segLength up to ~150 kbp at sketchSize 1024)",
+             L, s, P.ldsHard, ldsL2, ldsLoc, lim);
     err = b; return MM_ERR_ARG;
   }
   return MM_OK;
@@ -695,11 +755,12 @@ static int launch_sketch_k(mm_ctx* c) {
   const int nF = (int)c->nFrags;
   using Tabs = typename MMTabsFor<K>::type;
   const int maxLen = c->maxFragLen;
-  const FastGeom g = sketch_fast_geom(K, s, maxLen, sizeof(Tabs), MMHasSL20<K>::value);
-  const int HTH = sketch_ht_hard(s);
+  const SketchPlan plan = sketch_plan(K, s, maxLen, sizeof(Tabs), MMHasSL20<K>::value);
+  const FastGeom g = plan.g;
+  const int HTH = plan.HTH;
   const int PAD = MM_SK_PAD, PADH = MM_SK_PADH;     // spill slots behind the ordered tables (no wrap-around)
-  const size_t ldsFast = g.lds, ldsHard = sketch_hard_lds(sizeof(Tabs), maxLen, HTH, PADH);
-  if (ldsHard > 160 * 1024 || ldsFast > 160 * 1024) { c->err = "fragment too long / sketch too large for the LDS-resident sketch kernel"; return MM_ERR_ARG; }
+  const size_t ldsFast = plan.ldsFast, ldsHard = plan.ldsHard;
+  if (!plan.ok) { c->err = "fragment too long / sketch too large for the LDS-resident sketch kernel"; return MM_ERR_ARG; }
   int nStrips = (maxLen - K + 1 + 15) / 16; if (nStrips < 1) nStrips = 1;
   int threadsHard = ((nStrips + 63) / 64) * 64; if (threadsHard > 1024) threadsHard = 1024;
   if (c->sketchTabsK != K) {
@@ -711,8 +772,7 @@ static int launch_sketch_k(mm_ctx* c) {
   MM_HIP(c, hipMemsetAsync(c->dCounters.p, 0, 64, c->stream));
   unsigned long long* phaseStats = nullptr;
   if (getenv("MM_SKETCH_STATS")) { phaseStats = c->dCounters.as<unsigned long long>() + 24; MM_HIP(c, hipMemsetAsync(phaseStats, 0, 64, c->stream)); }
-  MM_HIP(c, hipFuncSetAttribute((const void*)k_sketch_hard<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsHard));
-  {
+  if (plan.useFast) {
     KernelTimer t(c, MM_K_SKETCH);
     auto launch = [&](auto kern) {
       (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsFast);
@@ -724,8 +784,13 @@ static int launch_sketch_k(mm_ctx* c) {
     if constexpr (MMHasSL20<K>::value) { if (g.SL == 20) launch(k_sketch_fast<K, 20>); else launch(k_sketch_fast<K, 16>); }
     else launch(k_sketch_fast<K, 16>);
     MM_HIP(c, hipGetLastError());
+  } else {
+    // the fast kernel's LDS geometry cannot hold this sketch: every fragment takes the exact path
+    KernelTimer t(c, MM_K_SKETCH);
+    hipLaunchKernelGGL(k_sketch_all_hard, dim3((nF + 255) / 256), dim3(256), 0, c->stream, nF, c->dHardList.as<int32_t>(), c->dCounters.as<uint32_t>(), c->dSkCount.as<uint32_t>());
+    MM_HIP(c, hipGetLastError());
   }
-  if (phaseStats) {
+  if (phaseStats && plan.useFast) {
     unsigned long long h[8];
     MM_HIP(c, hipMemcpyAsync(h, phaseStats, 64, hipMemcpyDeviceToHost, c->stream));
     MM_HIP(c, hipStreamSynchronize(c->stream));
@@ -736,16 +801,24 @@ static int launch_sketch_k(mm_ctx* c) {
     uint32_t nHard = 0;
     MM_HIP(c, hipMemcpyAsync(&nHard, c->dCounters.p, 4, hipMemcpyDeviceToHost, c->stream));
     MM_HIP(c, hipStreamSynchronize(c->stream));
-    fprintf(stderr, "[mm] sketch: %d fragments, %u to the hard path, threads %d x %d positions, HT %d, lds %zu/%zu\n", nF, nHard, g.threads, g.SL, g.HT, ldsFast, ldsHard);
+    fprintf(stderr, "[mm] sketch: %d fragments, %u to the hard path%s, threads %d x %d positions, HT %d, lds %zu/%zu%s\n", nF, nHard, plan.useFast ? "" : " (fast kernel not usable at this size)",
+            g.threads, g.SL, g.HT, ldsFast, ldsHard, plan.spill ? " (hard table: position / strand arrays in HBM)" : "");
   }
   {
     // fixed grid over the device-resident hard list (its workgroups leave at once when the list is empty or short)
     KernelTimer t(c, MM_K_SKETCH_HARD);
     const int grid = nF < 1024 ? nF : 1024;
-    hipLaunchKernelGGL((k_sketch_hard<K>), dim3(grid), dim3(threadsHard), ldsHard, c->stream,
-                       c->dSketchTabs.as<uint4>(), c->dBases2.as<uint32_t>(), c->dNmask.as<uint32_t>(), c->dFrags.as<DFrag>(), c->dReadHasN.as<uint32_t>(),
-                       c->dHardList.as<int32_t>(), c->dCounters.as<uint32_t>(), s, g.wantFast, HTH, PADH, c->dSkHash.as<uint64_t>(), c->dSkPos.as<int2>(), c->dSkStrand.as<int8_t>(),
-                       c->dSkCount.as<uint32_t>());
+    auto launchHard = [&](auto kern, int32_t* spill) {
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsHard);
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(threadsHard), ldsHard, c->stream,
+                         c->dSketchTabs.as<uint4>(), c->dBases2.as<uint32_t>(), c->dNmask.as<uint32_t>(), c->dFrags.as<DFrag>(), c->dReadHasN.as<uint32_t>(),
+                         c->dHardList.as<int32_t>(), c->dCounters.as<uint32_t>(), s, g.wantFast, HTH, PADH, spill, c->dSkHash.as<uint64_t>(), c->dSkPos.as<int2>(), c->dSkStrand.as<int8_t>(),
+                         c->dSkCount.as<uint32_t>());
+    };
+    if (plan.spill) {
+      MM_HIP(c, c->dSketchSpill.ensure((size_t)grid * 3 * (size_t)(HTH + PADH) * 4 + 64));
+      launchHard(k_sketch_hard<K, true>, c->dSketchSpill.as<int32_t>());
+    } else launchHard(k_sketch_hard<K, false>, (int32_t*)nullptr);
     MM_HIP(c, hipGetLastError());
   }
   return MM_OK;
@@ -759,7 +832,7 @@ static int launch_hash_only_k(mm_ctx* c, int reps, double* msAvg) {
   // the sketch kernel's geometry for these fragments: positions per thread, threads per workgroup, LDS per workgroup
   const FastGeom g = sketch_fast_geom(K, c->P.sketchSize, maxLen, sizeof(Tabs), MMHasSL20<K>::value);
   const size_t need = sizeof(Tabs) + (((size_t)(maxLen + 15) / 16 + 4) * 4 + 15) / 16 * 16;
-  size_t lds = g.lds > need ? g.lds : need;
+  size_t lds = (g.lds > need && g.lds <= 160 * 1024) ? g.lds : need;
   // MM_HASH_ONLY_LDS=bytes: claim that much LDS per workgroup instead (occupancy experiment); MM_HASH_ONLY_BARE=1: only what the kernel needs
   if (getenv("MM_HASH_ONLY_BARE")) lds = need;
   if (const char* e = getenv("MM_HASH_ONLY_LDS")) { const size_t want = (size_t)atol(e); if (want > need && want <= 160 * 1024) lds = want; }

@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdint>
 #include <atomic>
+#include <functional>
 #include <numeric>
 #include <thread>
 #include <vector>
@@ -19,7 +20,14 @@
 namespace mmhost {
 namespace Stat {
 
-inline double lnChoose(unsigned n, unsigned m) { return std::lgamma(n + 1.0) - std::lgamma(m + 1.0) - std::lgamma((double)n - m + 1.0); }
+// lgamma(x + 1.0) for integer x: the tail sums below evaluate it millions of times at large sketch sizes (sketchSize^3 terms behind the
+// minimum-hits table), always at small integers -- a table of the very same std::lgamma values, so every sum keeps its bits
+inline double lgammaInt(unsigned x) {
+  constexpr unsigned N = 1u << 15;
+  static const std::vector<double> tab = [] { std::vector<double> t(N); for (unsigned i = 0; i < N; i++) t[i] = std::lgamma(i + 1.0); return t; }();
+  return x < N ? tab[x] : std::lgamma(x + 1.0);
+}
+inline double lnChoose(unsigned n, unsigned m) { return lgammaInt(n) - lgammaInt(m) - lgammaInt(n - m); }
 
 // P[X > k], X ~ Binomial(n, p)  (== gsl_cdf_binomial_Q(k, p, n))
 inline double binomialUpperTail(unsigned k, double p, unsigned n) {
@@ -121,36 +129,71 @@ constexpr float ANIDiff = 0.0f;
 constexpr float ANIDiffConf = 0.999f;
 }
 
-// Map::sketchCutoffs as filled by Map::setProbs (computeMap.hpp:128,178-258)
-inline std::vector<int> sketchCutoffs(int sketchSize, int kmerSize, float ANIDiff, float ANIDiffConf, bool stage1_topANI_filter) {
+// Map::sketchCutoffs as filled by Map::setProbs (computeMap.hpp:128,178-258).  The reference evaluates gsl_cdf_hypergeometric_P afresh at
+// every step of every binary search (minutes at sketchSize >= 1000); here the running sums of each (ss, ss - ci, ci) distribution are
+// kept per ci -- the same additions in the same order, so the same doubles -- and the cmax rows are independent (host threads).
+inline std::vector<int> sketchCutoffs(int sketchSize, int kmerSize, float ANIDiff, float ANIDiffConf, bool stage1_topANI_filter, unsigned threads = 0) {
   std::vector<int> cut((size_t)(std::min<double>(sketchSize, fixed::ss_table_max) + 1), 1);
   if (!stage1_topANI_filter) return cut;
   const float deltaANI = ANIDiff;
   const float min_p = 1 - ANIDiffConf;
   const int ss = (int)std::min<double>(sketchSize, fixed::ss_table_max);
-  std::vector<std::vector<double>> probs(ss + 1, std::vector<double>(ss + 1));
-  for (int ci = 0; ci <= ss; ci++)
-    for (int y = 0; y <= ci; y++) probs[ci][y] = Stat::hypergeometricPdf(y, ss, ss - ci, ci);
+  if (threads == 0) threads = std::max(1u, std::thread::hardware_concurrency());
+  // probs[ci][y] = pdf(y; ss, ss - ci, ci); cum[ci][y] = probs[ci][0] + ... + probs[ci][y] (summed upwards, as hypergeometricCdf does)
+  std::vector<std::vector<double>> probs(ss + 1, std::vector<double>(ss + 1)), cum(ss + 1);
+  auto parallel = [&](int n, const std::function<void(int)>& fn) {
+    std::atomic<int> next(0);
+    auto work = [&]() { for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i); };
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < threads && (int)t < n; t++) pool.emplace_back(work);
+    work();
+    for (auto& th : pool) th.join();
+  };
+  parallel(ss + 1, [&](int ci) {
+    cum[ci].resize(ci + 1);
+    double acc = 0.0;
+    for (int y = 0; y <= ci; y++) { probs[ci][y] = Stat::hypergeometricPdf(y, ss, ss - ci, ci); acc += probs[ci][y]; cum[ci][y] = acc; }
+  });
+  // == Stat::hypergeometricCdf(k, ss, ss - ci, ci)
+  auto cdf = [&](unsigned k, int ci) -> double {
+    if (k >= (unsigned)ss || k >= (unsigned)ci) return 1.0;
+    const double acc = cum[ci][k];
+    return acc > 1.0 ? 1.0 : acc;
+  };
   auto distDiff = [&](int cmax, int ci) {
     double prAbove = 0;
     for (int ymax = 0; ymax <= cmax; ymax++) {
       const double pymax = probs[cmax][ymax];
       const double yi_cutoff = deltaANI == 0 ? (double)ymax
           : std::floor(Stat::md2j(Stat::j2md((float)((double)ymax / ss), kmerSize) + deltaANI, kmerSize) * ss);
-      double pi_acc = (yi_cutoff - 1) >= 0 ? Stat::hypergeometricCdf((unsigned)(yi_cutoff - 1), ss, ss - ci, ci) : 0;
+      double pi_acc = (yi_cutoff - 1) >= 0 ? cdf((unsigned)(yi_cutoff - 1), ci) : 0;
       pi_acc = 1 - pi_acc;
       prAbove += pymax * pi_acc;
       if (prAbove > min_p) return true;
     }
     return prAbove > min_p;
   };
-  for (int cmax = 1; cmax <= ss; cmax++) {
+  parallel(ss, [&](int i) {
+    const int cmax = i + 1;
     // lowest ci in [0, ss) for which distDiff holds (the reference binary-searches a monotone predicate with std::upper_bound)
     int lo = 0, hi = ss;
     while (lo < hi) { const int mid = lo + (hi - lo) / 2; if (distDiff(cmax, mid)) hi = mid; else lo = mid + 1; }
     cut[cmax] = lo == 0 ? 1 : lo;
-  }
+  });
   return cut;
+}
+
+// estimateMinimumHitsRelaxed for every Q.sketchSize 0..sketchSize (computeMap.hpp:1144), on host threads (each entry is an O(q^2) search)
+inline std::vector<int32_t> minHitsTable(int sketchSize, int kmerSize, float percentageIdentity, unsigned threads = 0) {
+  std::vector<int32_t> mh((size_t)sketchSize + 1, 0);
+  if (threads == 0) threads = std::max(1u, std::thread::hardware_concurrency());
+  std::atomic<int> next(sketchSize);                       // largest first: they take longest
+  auto work = [&]() { for (int q = next.fetch_sub(1); q >= 1; q = next.fetch_sub(1)) mh[q] = Stat::estimateMinimumHitsRelaxed(q, kmerSize, percentageIdentity, fixed::confidence_interval); };
+  std::vector<std::thread> pool;
+  for (unsigned t = 1; t < threads && (int)t < sketchSize; t++) pool.emplace_back(work);
+  work();
+  for (auto& th : pool) th.join();
+  return mh;
 }
 
 // Integer tables that let doL2Mapping's best-first walk (computeMap.hpp:1182-1267) run without floating point:

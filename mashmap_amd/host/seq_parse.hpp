@@ -145,7 +145,8 @@ inline const char* next_record(const char* base, const char* p, const char* e, b
   return q;
 }
 
-struct Rec { const char* hdr; const char* body; const char* end; int64_t seqLen; bool keep; };
+struct Rec { const char* hdr; const char* body; const char* end; int64_t seqLen; bool keep; size_t seg0, seg1; };   // seg0..seg1: its sequence lines (Seg list of its thread)
+struct Seg { const char* p; size_t n; };   // one line of sequence bytes (without the line break)
 
 // source of raw (decompressed) bytes, window by window; every window ends on a record boundary
 class RawSource {
@@ -153,6 +154,7 @@ class RawSource {
   virtual ~RawSource() {}
   virtual bool next(const char*& p, size_t& n, bool fasta, bool first) = 0;   // false: exhausted
   virtual char first_byte() = 0;
+  virtual bool fileMapped() const { return false; }                           // windows point into a file mapping (pages may not be mapped yet)
 };
 
 class MmapSource : public RawSource {
@@ -167,6 +169,7 @@ class MmapSource : public RawSource {
   }
   ~MmapSource() override { if (data_) munmap((void*)data_, size_); if (fd_ >= 0) close(fd_); }
   bool ok() const { return fd_ >= 0; }
+  bool fileMapped() const override { return true; }
   char first_byte() override { return size_ ? data_[0] : 0; }
   bool next(const char*& p, size_t& n, bool fasta, bool) override {
     if (pos_ >= size_) return false;
@@ -347,7 +350,8 @@ class BatchReader {
 
   // the sequence bytes of the window's records as 2-bit codes + N mask: the workers normalise and pack while they drop the line breaks
   // (the bytes are touched once either way; the packed batch is 3/8 the size of the ASCII one on its way to the GPU)
-  void packWindow(const std::vector<std::vector<detail::Rec>>& recs, const std::vector<size_t>& first, unsigned T, bool fasta, size_t nRec, ParsedBatch& out) {
+  void packWindow(const std::vector<std::vector<detail::Rec>>& recs, const std::vector<std::vector<detail::Seg>>& segs, const std::vector<size_t>& first, unsigned T,
+                  size_t nRec, ParsedBatch& out) {
     out.packOffs.assign(nRec + 1, 0); out.lens.assign(nRec, 0); out.hasN.assign(nRec, 0);
     int64_t pk = 0;
     for (size_t r = 0; r < nRec; r++) { const int64_t len = out.offs[r + 1] - out.offs[r]; out.lens[r] = (int32_t)len; out.packOffs[r] = pk; pk += (len + 31) / 32 * 32; }
@@ -366,15 +370,7 @@ class BatchReader {
         const size_t ri = first[t] + i;
         if (!r.keep || !r.seqLen) continue;
         Pack2bitStream st(b2 + out.packOffs[ri] / 16, nm + out.packOffs[ri] / 32);
-        if (fasta) {
-          const char* l = r.body;
-          while (l < r.end) {
-            const char* nl = (const char*)memchr(l, '\n', (size_t)(r.end - l));
-            const char* le = nl ? nl : r.end;
-            st.feed(l, (size_t)(le - l));
-            l = nl ? nl + 1 : r.end;
-          }
-        } else st.feed(r.body, (size_t)r.seqLen);
+        for (size_t g = r.seg0; g < r.seg1; g++) st.feed(segs[t][g].p, segs[t][g].n);
         out.hasN[ri] = st.finish() ? 1 : 0;
       }
     });
@@ -391,11 +387,19 @@ class BatchReader {
     detail::run_parallel(pool_, T, [&](unsigned t) { if (t) cut[t] = detail::next_record(b, b + n / T * t, e, fasta); });   // may scan a long record: in parallel
     for (unsigned t = 1; t <= T; t++) if (cut[t] < cut[t - 1]) cut[t] = cut[t - 1];
     std::vector<std::vector<Rec>> recs(T);
+    std::vector<std::vector<detail::Seg>> segs(T);        // the sequence lines found by the scan below: the copy / pack pass does not search again
+    const bool mapped = src_ && src_->fileMapped();
     detail::run_parallel(pool_, T, [&](unsigned t) {
       const char* q = cut[t]; const char* pe = cut[t + 1];
-      auto& R = recs[t];
+      if (mapped && pe > q) {
+        // page-cache pages of the file are mapped one fault (16 pages) at a time otherwise: one call maps this thread's whole piece
+        // (MADV_POPULATE_READ, Linux >= 5.14; an older kernel refuses it and the faults happen as before)
+        const uintptr_t a = (uintptr_t)q & ~(uintptr_t)4095, z = ((uintptr_t)pe + 4095) & ~(uintptr_t)4095;
+        (void)madvise((void*)a, (size_t)(z - a), 22 /* MADV_POPULATE_READ */);
+      }
+      auto& R = recs[t]; auto& S = segs[t];
       while (q < pe) {
-        Rec r; r.hdr = q; r.keep = true;
+        Rec r; r.hdr = q; r.keep = true; r.seg0 = S.size();
         const char* body = detail::next_line(q, e);
         r.body = body;
         if (fasta) {
@@ -403,6 +407,7 @@ class BatchReader {
           while (l < e && *l != '>') {
             const char* nl = (const char*)memchr(l, '\n', (size_t)(e - l));
             const char* le = nl ? nl : e;
+            if (le > l) S.push_back(detail::Seg{l, (size_t)(le - l)});
             len += le - l;
             l = nl ? nl + 1 : e;
           }
@@ -411,8 +416,10 @@ class BatchReader {
           const char* nl = (const char*)memchr(body, '\n', (size_t)(e - body));
           const char* le = nl ? nl : e;
           r.seqLen = body < e ? le - body : 0;
+          if (r.seqLen) S.push_back(detail::Seg{body, (size_t)r.seqLen});
           r.end = detail::next_line(detail::next_line(nl ? nl + 1 : e, e), e);   // '+' line and quality line skipped
         }
+        r.seg1 = S.size();
         R.push_back(r);
         q = r.end;
       }
@@ -440,7 +447,7 @@ class BatchReader {
     for (unsigned t = 0; t < T; t++) for (size_t i = 0; i < recs[t].size(); i++) { out.offs[base + first[t] + i] = at; at += recs[t][i].seqLen; }
     out.offs[base + nRec] = at;
     out.packed = packOutput_;
-    if (packOutput_) { packWindow(recs, first, T, fasta, nRec, out); return; }
+    if (packOutput_) { packWindow(recs, segs, first, T, nRec, out); return; }
     if ((size_t)at + 64 > out.cap) {
       char* nb = alloc_((size_t)at + ((size_t)at >> 4) + 4096);
       if (!nb) { std::cerr << "[mashmap_hip] out of host memory for a batch of " << at << " bases" << std::endl; exit(1); }
@@ -454,15 +461,7 @@ class BatchReader {
         const Rec& r = recs[t][i];
         if (!r.keep || !r.seqLen) continue;
         char* d = dst0 + out.offs[base + first[t] + i];
-        if (fasta) {
-          const char* l = r.body;
-          while (l < r.end) {
-            const char* nl = (const char*)memchr(l, '\n', (size_t)(r.end - l));
-            const char* le = nl ? nl : r.end;
-            std::memcpy(d, l, (size_t)(le - l)); d += le - l;
-            l = nl ? nl + 1 : r.end;
-          }
-        } else std::memcpy(d, r.body, (size_t)r.seqLen);
+        for (size_t g = r.seg0; g < r.seg1; g++) { std::memcpy(d, segs[t][g].p, segs[t][g].n); d += segs[t][g].n; }
       }
     });
   }

@@ -114,9 +114,7 @@ class Map {
     for (size_t i = 0; i < refsketch.metadata.size(); i++) refNameToId.emplace(refsketch.metadata[i].name, (int)i);
     // integer tables the kernels consume: estimateMinimumHitsRelaxed per Q.sketchSize (:1144), sketchCutoffs (:178-258), and the two
     // tables of doL2Mapping's walk (acceptance :1221, ANI cut-off :1192-1202)
-    std::vector<int32_t> minHits((size_t)p.sketchSize + 1, 0);
-    for (int q = 1; q <= p.sketchSize; q++)
-      minHits[q] = mmhost::Stat::estimateMinimumHitsRelaxed(q, p.kmerSize, p.percentageIdentity, skch::fixed::confidence_interval);
+    std::vector<int32_t> minHits = mmhost::minHitsTable(p.sketchSize, p.kmerSize, p.percentageIdentity);
     std::vector<int> cut = mmhost::sketchCutoffs(p.sketchSize, p.kmerSize, p.ANIDiff, p.ANIDiffConf, p.stage1_topANI_filter);
     std::vector<int32_t> cut32(cut.begin(), cut.end());
     std::vector<uint8_t> accept; std::vector<int16_t> minIsz;
@@ -384,14 +382,19 @@ class Map {
     if (!postPool || postPool->size() != nThreads) postPool.reset(new mmhost::WorkerPool(nThreads));   // persistent: a batch is milliseconds of work
     postPool->run(nThreads, [&](unsigned) { work(); });
     const auto t1 = skch::Time::now();
+    size_t textBytes = 0;
+    if (reportNow) for (size_t r = 0; r < nReads; r++) textBytes += text[r].size();
+    std::string all;                                       // the batch's PAF text, input order, written with one call
+    all.reserve(textBytes);
     for (size_t r = 0; r < nReads; r++) {                  // mapModuleHandleOutput (:724-752), input order
       if (!perRead[r].empty()) totalReadsMapped++;
       if (!reportNow) allReadMappings.insert(allReadMappings.end(), perRead[r].begin(), perRead[r].end());
       else {
-        outstrm << text[r];
+        all += text[r];
         if (processMappingResults) for (const auto& e : perRead[r]) processMappingResults(e);
       }
     }
+    if (!all.empty()) outstrm.write(all.data(), (std::streamsize)all.size());
     if (timing) std::cerr << "[mashmap_hip::timing] post stage: chain + filter + format " << std::chrono::duration<double>(t1 - t0).count()
                           << " s, output " << std::chrono::duration<double>(skch::Time::now() - t1).count() << " s" << at() << std::endl;
   }

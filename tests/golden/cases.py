@@ -96,6 +96,9 @@ def paf_cases():
         for c in range(3):
             a = base[c] if h == 0 else U.mutate(base[c], 700 + 10 * h + c, 0.015 * h)
             hap.append(("S%d#1#chr%d" % (h, c), a))
+    # long noisy reads for the large-sketch command line (--dense at -s 20000: sketchSize 1998, parseCmdArgs.hpp:626-630)
+    long_reads = [(n + "_L", a) for n, a, _ in U.sample_reads(cs[:3], 18, 10, 45000, 0.12)] + [(n + "_M", a) for n, a, _ in U.sample_reads(cs[:3], 19, 6, 20000, 0.15)]
+    long_reads += [("unrelated_L", U.random_dna(606, 41000)), ("short19k", cs[0][200000:219000].copy())]
     asm = [("q_chr1", U.mutate(cs[0], 90, 0.01)), ("q_chr2", U.revcomp(U.mutate(cs[1], 91, 0.01))), ("q_chr3", U.mutate(cs[2], 92, 0.02))]
     return [
         ("default", ref, reads, []),
@@ -108,6 +111,7 @@ def paf_cases():
         ("asm_one2one", ref, asm, ["--pi", "95", "-s", "10000", "-f", "one-to-one", "-J", "40"]),
         ("allvsall_Y", hap, None, ["--pi", "95", "-n", "1", "-Y", "#"]),
         ("allvsall_X_lower", hap, hap, ["--pi", "90", "-X", "--lowerTriangular", "-n", "3"]),
+        ("dense_pi80_s20000", ref, long_reads, ["--dense", "--pi", "80", "-s", "20000"]),
     ]
 
 

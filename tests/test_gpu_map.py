@@ -218,6 +218,16 @@ def test_map_sketch_beyond_1024(oracle):
     run_and_compare(oracle, contigs, reads, L=10000, s=1100, pi=0.80)
 
 
+@pytest.mark.parametrize("L,s,pi,err", [(20000, 1998, 0.80, 0.15), (40000, 4000, 0.80, 0.12)])
+def test_map_sketch_beyond_1279(oracle, L, s, pi, err):
+    """sketch sizes the reference's --dense derives for long segments (0.02 (1 + (1 - pi) / 0.05) (segLength - k), parseCmdArgs.hpp:626-630):
+    1998 for --pi 80 -s 20000, 4000 for -s 40000.  Hard sketch table spilled to HBM (beyond ~3400 every fragment takes that path),
+    13-bit sketch positions in the L2 stream (s > 2046), 32 / 16 candidates per wave in the sweeps."""
+    contigs = genome(551, [500000, 400000], repeats=False)
+    reads = reads_for(contigs, 53, 10, 2 * L + 777, err) + reads_for(contigs, 54, 4, L, err / 2)
+    run_and_compare(oracle, contigs, reads, L=L, s=s, pi=pi, check_points=False)
+
+
 def test_index_with_a_hyper_frequent_seed():
     """a frequent seed's point list is never read on the device (getSeedHits drops the seed first): a list of 2^23 points and more
     (a satellite array in a real genome) must not be refused.  Synthetic index: the resident one plus one such key."""

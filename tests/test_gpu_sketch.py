@@ -76,7 +76,9 @@ def test_sketch_adversarial(oracle):
                                    (26, 90, 3000), (28, 120, 4000), (30, 77, 2000),                    # even sizes above 25
                                    (10, 20, 400), (9, 16, 300), (8, 12, 300), (7, 10, 200), (6, 8, 200), (5, 6, 150), (4, 5, 100), (3, 4, 100),
                                    (2, 3, 64), (1, 2, 64),                                             # the reference takes any -k (parseCmdArgs.hpp:435)
-                                   (19, 1100, 10000), (19, 1279, 12000)])                              # sketches beyond 1024 entries
+                                   (19, 1100, 10000), (19, 1279, 12000),                               # sketches beyond 1024 entries
+                                   (19, 1998, 20000),                                                  # --dense --pi 80 -s 20000 (parseCmdArgs.hpp:626-630): hard table spilled to HBM
+                                   (19, 4000, 40000), (16, 2500, 15000)])                              # beyond the fast kernel's geometry: every fragment on the exact path
 def test_sketch_parameter_grid(oracle, k, s, L):
     g = U.random_dna(11, 200000)
     reads = [a for _, a, _ in U.sample_reads([g], 5 + k, 12, 2 * L + 123, 0.08)]
