@@ -28,7 +28,7 @@ bench:*)
   grep -v "^\[mm\] sketch\|lookup+L1" $OUT/bench_$WL.err | tail -8 | tee -a $OUT/log.txt; cat $OUT/bench_$WL.json | tee -a $OUT/log.txt ;;
 e2e)
   echo "== FASTA -> PAF end to end" | tee -a $OUT/log.txt
-  for RT in 8 16; do
+  for RT in ${E2E_THREADS:-8 12 16}; do
     MASHMAP_HIP_READER_THREADS=$RT timeout 900 python scripts/e2e_fasta_paf.py ${E2E_ARGS} > $OUT/e2e_rt$RT.json 2> $OUT/e2e_rt$RT.err
     tail -1 $OUT/e2e_rt$RT.json | tee -a $OUT/log.txt
     E2E_ARGS="--reuse"
