@@ -33,6 +33,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <unordered_set>
 #include <vector>
 
@@ -157,19 +158,77 @@ class RawSource {
   virtual bool fileMapped() const { return false; }                           // windows point into a file mapping (pages may not be mapped yet)
 };
 
+}  // namespace detail
+
+// Mappings of plain (uncompressed, regular) input files made AHEAD of their use: skch::Sketch starts prefault() on the query files while
+// the reference index is being built, so that when skch::Map's reader reaches a file its pages are already in the page tables -- the
+// parser's workers then run at memory speed instead of taking a page fault per 64 KB (a third of their time on a 10 GB FASTA).  A file
+// the cache does not hold is mapped by the reader itself, as before.
+class MappedFileCache {
+ public:
+  struct Entry { int fd = -1; const char* data = nullptr; size_t size = 0; };
+  static MappedFileCache& instance() { static MappedFileCache c; return c; }
+  ~MappedFileCache() { wait(); for (auto& kv : map_) { if (kv.second.data) munmap((void*)kv.second.data, kv.second.size); if (kv.second.fd >= 0) close(kv.second.fd); } }
+  // maps the files and starts `threads` background threads that populate the mappings front to back
+  void prefault(const std::vector<std::string>& paths, unsigned threads) {
+    std::lock_guard<std::mutex> lk(mu_);
+    for (const auto& path : paths) {
+      if (map_.count(path)) continue;
+      struct stat st;
+      if (stat(path.c_str(), &st) != 0 || !S_ISREG(st.st_mode) || st.st_size == 0) continue;
+      Entry e; e.fd = open(path.c_str(), O_RDONLY);
+      if (e.fd < 0) continue;
+      unsigned char m[2] = {0, 0};
+      if (pread(e.fd, m, 2, 0) == 2 && m[0] == 31 && m[1] == 139) { close(e.fd); continue; }      // gzip: read through zlib, not mapped
+      e.size = (size_t)st.st_size;
+      void* p = mmap(nullptr, e.size, PROT_READ, MAP_PRIVATE, e.fd, 0);
+      if (p == MAP_FAILED) { close(e.fd); continue; }
+      e.data = (const char*)p;
+      map_[path] = e;
+      const size_t piece = (size_t)64 << 20;
+      for (size_t off = 0; off < e.size; off += piece) jobs_.push_back(Job{e.data + off, std::min(piece, e.size - off)});
+    }
+    if (workers_.empty() && !jobs_.empty())
+      for (unsigned t = 0; t < std::max(1u, threads); t++) workers_.emplace_back([this] { run(); });
+  }
+  bool lookup(const std::string& path, Entry& out) { std::lock_guard<std::mutex> lk(mu_); auto it = map_.find(path); if (it == map_.end()) return false; out = it->second; return true; }
+  void wait() { std::vector<std::thread> w; { std::lock_guard<std::mutex> lk(mu_); w.swap(workers_); } for (auto& t : w) t.join(); }
+
+ private:
+  struct Job { const char* p; size_t n; };
+  std::mutex mu_; std::unordered_map<std::string, Entry> map_; std::vector<Job> jobs_; size_t next_ = 0; std::vector<std::thread> workers_;
+  void run() {
+    for (;;) {
+      Job j;
+      { std::lock_guard<std::mutex> lk(mu_); if (next_ >= jobs_.size()) return; j = jobs_[next_++]; }
+      const uintptr_t a = (uintptr_t)j.p & ~(uintptr_t)4095, z = ((uintptr_t)j.p + j.n + 4095) & ~(uintptr_t)4095;
+      if (madvise((void*)a, (size_t)(z - a), 22 /* MADV_POPULATE_READ, Linux >= 5.14 */) != 0) {
+        volatile char sink = 0;                                      // older kernel: touch every page
+        for (size_t o = 0; o < j.n; o += 4096) sink = (char)(sink + j.p[o]);
+        (void)sink;
+      }
+    }
+  }
+};
+
+namespace detail {
+
 class MmapSource : public RawSource {
-  int fd_ = -1; const char* data_ = nullptr; size_t size_ = 0, pos_ = 0, window_;
+  int fd_ = -1; const char* data_ = nullptr; size_t size_ = 0, pos_ = 0, window_; bool owned_ = true;
  public:
   MmapSource(const std::string& path, size_t window) : window_(window) {
+    MappedFileCache::Entry ce;
+    if (MappedFileCache::instance().lookup(path, ce)) { fd_ = ce.fd; data_ = ce.data; size_ = ce.size; owned_ = false; return; }   // mapped (and being populated) ahead
     fd_ = open(path.c_str(), O_RDONLY);
     if (fd_ < 0) return;
     struct stat st; if (fstat(fd_, &st) != 0) return;
     size_ = (size_t)st.st_size;
     if (size_) { void* m = mmap(nullptr, size_, PROT_READ, MAP_PRIVATE, fd_, 0); if (m == MAP_FAILED) { size_ = 0; return; } data_ = (const char*)m; madvise((void*)data_, size_, MADV_SEQUENTIAL); }
   }
-  ~MmapSource() override { if (data_) munmap((void*)data_, size_); if (fd_ >= 0) close(fd_); }
+  ~MmapSource() override { if (!owned_) return; if (data_) munmap((void*)data_, size_); if (fd_ >= 0) close(fd_); }
+  bool prefaulted() const { return !owned_; }
   bool ok() const { return fd_ >= 0; }
-  bool fileMapped() const override { return true; }
+  bool fileMapped() const override { return owned_; }               // a mapping from the cache is populated by its own threads
   char first_byte() override { return size_ ? data_[0] : 0; }
   bool next(const char*& p, size_t& n, bool fasta, bool) override {
     if (pos_ >= size_) return false;

@@ -166,7 +166,7 @@ class Map {
       // to the post stage's threads stall each other for tens of milliseconds at a time (profiles/r03d_e2e_thread_sweep.txt: 32 reader
       // threads 18 Gbp/s end to end, 8 threads 24-26)
       const char* rte = getenv("MASHMAP_HIP_READER_THREADS");
-      const unsigned readerThreads = rte ? (unsigned)std::max(1, atoi(rte)) : (unsigned)std::min(8, std::max(1, param.threads));
+      const unsigned readerThreads = rte ? (unsigned)std::max(1, atoi(rte)) : (unsigned)std::min(12, std::max(1, param.threads));
       mmhost::BatchReader rd(param.querySequences, batchBases, readerThreads, {}, "",
                              [](size_t n) {                       // only when the pool (skch_sketch.hpp) has run dry
                                const auto t0 = skch::Time::now();
