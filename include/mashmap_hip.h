@@ -38,8 +38,10 @@ enum {
   MM_FLAG_SKIP_SELF = 2,        /* skip_self              (parseCmdArgs.hpp:341) */
   MM_FLAG_SKIP_PREFIX = 4,      /* skip_prefix            (parseCmdArgs.hpp:349) */
   MM_FLAG_LOWER_TRIANGULAR = 8, /* lower_triangular       (parseCmdArgs.hpp:334) */
-  MM_FLAG_NO_SPLIT = 16         /* !split                 (parseCmdArgs.hpp:427); reads longer than segLength are then refused by
-                                   mm_reads_upload (windowLen != 0, computeMap.hpp:933, is not built) */
+  MM_FLAG_NO_SPLIT = 16         /* !split                 (parseCmdArgs.hpp:427): a read longer than segLength is then ONE fragment with
+                                   windowLen = len - segLength != 0 (computeMap.hpp:933, :1309); a batch that holds such a read goes through
+                                   the literal kernels (k_l1_window, k_l2_window: exact, not fast).  The read must fit the sketch kernels'
+                                   LDS staging (~150 kbp at sketchSize <= 1024; mm_map_fragments says so otherwise). */
 };
 
 typedef struct {

@@ -17,7 +17,7 @@ std::vector<DevBuf*> mm_ctx::allBufs() {
   return {&I.evKey, &I.evAux, &I.evHash, &I.contigOff, &I.opKey, &I.opAux, &I.opHash, &I.blockOff, &I.evBlock, &I.contigBlock, &I.contigLen, &I.refGroup,
           &I.htSlots, &I.htTags, &I.filter, &I.ptKeys, &I.keys, &I.keyOff, &I.keyFreq, &dMinHits, &dCutoffs, &dAscii, &dAsciiNext, &dReadSrcOff, &dReadPackOff, &dReadLen, &dReadGroup, &dReadSelf, &dReadHasN,
           &dBases2, &dNmask, &dFrags, &dSkHash, &dSkPos, &dSkStrand, &dSkCount, &dHardList, &dCounters, &dSketchSpill, &dSketchTabs, &dQHash, &dQStrand, &dSeedVal,
-          &dStats, &dPtOff, &dPts, &dL1, &dL1b, &dL1Cursors, &dL1Off, &dL2, &dL2Info, &dL2Cnt, &dL2Off, &dL2Ops, &dScanTmp, &dL2Tmp, &dL2Wide, &dL2Exact, &dL2Cells,
+          &dStats, &dPtOff, &dPts, &dPtIds, &dWinFreq, &dWinExt, &dWinHeap, &dWinKeys, &dWinVals, &dWinOffH, &dWinOffT, &dWinCntH, &dWinCntT, &dL1, &dL1b, &dL1Cursors, &dL1Off, &dL2, &dL2Info, &dL2Cnt, &dL2Off, &dL2Ops, &dScanTmp, &dL2Tmp, &dL2Wide, &dL2Exact, &dL2Cells,
           &dListB, &dListC, &dBigList, &dL2Sort[0], &dL2Sort[1], &dL2Sort[2], &dL2Sort[3], &dL2Order, &dL2First, &dL2Num, &dAccept, &dMinIsz, &dSelCnt, &dSelOff, &dSelHeap, &dFragTab, &dMappings, &dCommCounts, &dGathered};
 }
 
@@ -183,15 +183,15 @@ static int upload_reads_common(mm_ctx* c, const ReadSource& S, const int64_t* re
   c->hFrags.clear();
   std::vector<DFrag> dfr;
   dfr.reserve(c->hFrags.capacity() ? c->hFrags.capacity() : nReads * 2 + 16);
-  int64_t pk = 0; int32_t maxLen = 0;
+  int64_t pk = 0; int32_t maxLen = 0; bool anyLong = false;
   for (size_t r = 0; r < nReads; r++) {
     const int64_t len64 = packed ? (int64_t)S.lengths[r] : readOffsets[r + 1] - readOffsets[r];
     if (len64 < 0 || len64 > 0x7fffffff) { c->err = "mm_reads_upload: read length out of range (offset_t is int32, base_types.hpp:21)"; return MM_ERR_ARG; }
     const int32_t len = (int32_t)len64;
     srcOff[r] = packed ? 0 : readOffsets[r]; packOff[r] = pk; rlen[r] = len;
     if (len >= k) {                                   // computeMap.hpp:325 (shorter reads are skipped)
-      if (!split || len <= L) {                       // :587
-        if (len > L) { c->err = "mm_reads_upload: a read longer than segLength with split off (windowLen != 0) is not supported on the device path"; return MM_ERR_ARG; }
+      if (!split || len <= L) {                       // :587 -- with split off a read longer than segLength is ONE fragment (windowLen = len - segLength, :933)
+        if (len > L) anyLong = true;
         c->hFrags.push_back(mm_fragment{(int32_t)r, 0, len, 0});
         dfr.push_back(DFrag{pk, len, (int32_t)r});
         maxLen = std::max(maxLen, len);
@@ -214,6 +214,7 @@ static int upload_reads_common(mm_ctx* c, const ReadSource& S, const int64_t* re
   srcOff[nReads] = packed ? 0 : readOffsets[nReads]; packOff[nReads] = pk;
   c->nReads = nReads; c->nFrags = dfr.size(); c->nPackedBases = (size_t)pk; c->seqCounterBase = seqCounterBase; c->maxFragLen = maxLen;
   c->sketched = false; c->mapped = false; c->fragTabStale = true; c->gathered = false;
+  c->windowed = anyLong;
 
   const size_t srcBase = packed ? 0 : (size_t)readOffsets[0];
   const size_t nSrc = packed ? 0 : (size_t)(readOffsets[nReads] - readOffsets[0]);

@@ -102,6 +102,9 @@ struct mm_ctx {
   DevBuf dQHash, dQStrand, dSeedVal;                    // post-removal sketch + per-seed lookup value
   DevBuf dStats;                                        // mm_frag_stats[nFrags]
   DevBuf dPtOff, dPts; size_t ptsCap = 0;               // per-fragment offset (int64) + sorted keys
+  // --noSplit with reads longer than segLength (windowLen != 0, computeMap.hpp:933): the literal kernels' state
+  bool windowed = false;                                // some resident fragment is longer than segLength
+  DevBuf dPtIds, dWinFreq, dWinExt, dWinHeap, dWinKeys, dWinVals, dWinOffH, dWinOffT, dWinCntH, dWinCntT;
   DevBuf dL1, dL1b, dL1Cursors; size_t l1Cap = 0, nL1 = 0;   // dL1b: the region-filled buffer k_l1_compact reads from
   DevBuf dL1Off;                                        // int64[nFrags] first candidate of a fragment
   DevBuf dL2; size_t l2Cap = 0, nL2 = 0;

@@ -24,6 +24,7 @@
 // streaming pre-pass followed by a sweep whose only memory traffic is one sequential stream per lane.
 #include "mm_internal.h"
 #include "mm_device.h"
+#include "mm_heap.h"
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
@@ -612,6 +613,236 @@ k_l2_sweep_exact(int jb, int nList, int64_t opsBase, const int32_t* __restrict__
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// windowLen != 0 (--noSplit with a read longer than segLength; computeMap.hpp:1276-1451 with Q.len > segLength): the L2 stage literally, one
+// thread per candidate.  minmerIndex is walked as the insert events of the contig's stream (they are its records, in index order); the
+// open records sit in a heap ordered by wpos_end with libstdc++'s element movements (std::push_heap / std::pop_heap, mm_heap.h); a
+// count of open windows per hash (hash_to_freq, :1310) decides, as in the reference, whether a record enters the SlideMapper and whether
+// the position is evaluated at all -- including the reference's way of retiring a record whose hash was counted more than once
+// (:1344-1357: the front is decremented until its count reaches zero, then popped).  State per candidate in HBM scratch: SlideMapper
+// cells, the heap, an open-addressing table for the counts.  A slow path by design: correctness for the one mode the fast kernels
+// cannot express; split mode never comes here.
+// ---------------------------------------------------------------------------------------------
+struct WinExt { int64_t e0, e1; };                               // events [e0, e1) of the contig: from lower_bound(rangeStart - segLength - 1) to the last wpos <= rangeEnd + windowLen
+__global__ void __launch_bounds__(256)
+k_l2_window_extents(int nCand, int segLength, const mm_l1_candidate* __restrict__ l1, const DFrag* __restrict__ frags, const uint32_t* __restrict__ evKey,
+                    const int64_t* __restrict__ contigOff, WinExt* __restrict__ ext, int32_t* __restrict__ cntH, int32_t* __restrict__ cntT) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nCand) return;
+  const mm_l1_candidate cand = l1[c];
+  int W = frags[cand.frag].len - segLength; if (W < 0) W = 0;
+  const int64_t cb = contigOff[cand.seqId], ce = contigOff[cand.seqId + 1];
+  auto lowerIn = [&](int64_t lo, int64_t hi, uint64_t key) { while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if ((uint64_t)evKey[mid] < key) lo = mid + 1; else hi = mid; } return lo; };
+  const long long target = (long long)cand.rangeStartPos - segLength - 1;
+  const int64_t e0 = target <= 0 ? cb : lowerIn(cb, ce, (uint64_t)target * 2ull);
+  const long long last = (long long)cand.rangeEndPos + W;
+  const int64_t e1 = last < 0 ? e0 : lowerIn(e0, ce, (uint64_t)last * 2ull + 2ull);
+  ext[c] = WinExt{e0, e1 < e0 ? e0 : e1};
+  const int64_t n = (e1 < e0 ? 0 : e1 - e0) + 2;
+  int64_t t = 16; while (t < 2 * n) t <<= 1;
+  cntH[c] = (int32_t)n; cntT[c] = (int32_t)t;
+}
+
+__global__ void __launch_bounds__(64)
+k_l2_window(int nCand, int s, int segLength, const mm_l1_candidate* __restrict__ l1, const mm_frag_stats* __restrict__ stats, const DFrag* __restrict__ frags,
+            const uint64_t* __restrict__ qHash, const int8_t* __restrict__ qStrand, const uint64_t* __restrict__ skHash, const int8_t* __restrict__ skStrand,
+            const uint32_t* __restrict__ evKey, const uint32_t* __restrict__ evAux, const uint64_t* __restrict__ evHash, const int64_t* __restrict__ contigOff,
+            const WinExt* __restrict__ ext, const int64_t* __restrict__ offH, const int64_t* __restrict__ offT, const int32_t* __restrict__ cntT,
+            int32_t* __restrict__ heapAll, uint64_t* __restrict__ tabKeys, int32_t* __restrict__ tabVals, ExactCell* __restrict__ cells,
+            const int64_t* __restrict__ l1Off, L2Tmp* __restrict__ tmp, int locap, mm_l2_locus* __restrict__ l2, unsigned long long l2Cap,
+            int64_t* __restrict__ l2First, int32_t* __restrict__ l2Num, unsigned long long* __restrict__ counters) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nCand) return;
+  const mm_l1_candidate cand = l1[c];
+  const int f = cand.frag;
+  const mm_frag_stats fst = stats[f];
+  const int S = fst.sketchSize;
+  int W = frags[f].len - segLength; if (W < 0) W = 0;
+  const bool raw = fst.rawSketchSize == fst.sketchSize;                         // no seed was removed: the sketch is the raw one (k_lookup_l1)
+  const uint64_t* q = (raw ? skHash : qHash) + (size_t)f * s;                  // Q.minmerTableQuery, ascending
+  const int8_t* qs = (raw ? skStrand : qStrand) + (size_t)f * s;
+  ExactCell* cell = cells + (size_t)c * (s + 1);
+  cell[0] = ExactCell{0, 0, 0};
+  for (int p = 1; p <= S; p++) cell[p] = ExactCell{1, 0, 0};                   // SlideMapper::init (slidingMap.hpp:103-121)
+  int pivot = S, pivRank = S, shared = 0, votes = 0;
+  int32_t* heap = heapAll + offH[c]; int nHeap = 0;                             // event indices relative to e0
+  uint64_t* tk = tabKeys + offT[c]; int32_t* tv = tabVals + offT[c];
+  const uint32_t tmask = (uint32_t)cntT[c] - 1u;
+  for (uint32_t i = 0; i <= tmask; i++) { tk[i] = ~0ull; tv[i] = 0; }
+  const WinExt X = ext[c];
+  const int64_t ce = contigOff[cand.seqId + 1];
+  auto wposOf = [&](int64_t e) { return (int)(evKey[e] >> 1); };
+  auto wendOf = [&](int64_t e) { return (int)(evAux[e] & 0x7fffffffu); };
+  auto freqOf = [&](uint64_t h) -> int32_t* {                                    // hash_to_freq[h] (created at 0 on first access, like operator[])
+    uint32_t i = (uint32_t)(h * 0x9E3779B97F4A7C15ull >> 40) & tmask;
+    while (tk[i] != h) { if (tk[i] == ~0ull) { tk[i] = h; break; } i = (i + 1) & tmask; }
+    return &tv[i];
+  };
+  auto locate = [&](uint64_t h, bool& match) -> int {                            // 1-based lower_bound in the sketch; 0: beyond its last hash
+    int lo = 0, hi = S;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (q[mid] < h) lo = mid + 1; else hi = mid; }
+    if (lo >= S) { match = false; return 0; }
+    match = q[lo] == h; return lo + 1;
+  };
+  auto insertMinmer = [&](int64_t e) {                                           // slidingMap.hpp:125-165
+    bool match; const int j = locate(evHash[e], match);
+    if (j == 0) return;
+    ExactCell x = cell[j];
+    if (match) {
+      x.active = 1; x.vote = (int16_t)(x.vote + (int)qs[j - 1] * ((evAux[e] >> 31) ? -1 : 1));
+      cell[j] = x;
+      if (j <= pivot) { shared++; votes += x.vote; }
+    } else {
+      x.cnt++; cell[j] = x;
+      if (j <= pivot) pivRank++;
+      if (pivRank > S) { const ExactCell pc = cell[pivot]; shared -= pc.active; votes -= pc.vote; pivRank -= pc.cnt; pivot--; }
+    }
+  };
+  auto deleteMinmer = [&](int64_t e) {                                           // slidingMap.hpp:171-211
+    bool match; const int j = locate(evHash[e], match);
+    if (j == 0) return;
+    ExactCell x = cell[j];
+    if (match) {
+      if (j <= pivot) { shared--; votes -= x.vote; }
+      x.active = 0; x.vote = 0; cell[j] = x;
+    } else {
+      x.cnt--; cell[j] = x;
+      if (j <= pivot) pivRank--;
+      if (pivot + 1 <= S && pivRank + cell[pivot + 1].cnt <= S) { pivot++; const ExactCell pc = cell[pivot]; shared += pc.active; votes += pc.vote; pivRank += pc.cnt; }
+    }
+  };
+  auto later = [&](int32_t a, int32_t b) { return wendOf(X.e0 + a) > wendOf(X.e0 + b); };   // heap_cmp (:1299): min-heap on wpos_end
+  auto nextIns = [&](int64_t e) { while (e < ce && !(evKey[e] & 1u)) e++; return e; };       // minmerIndex records = insert events
+  // wpos of the record behind `e` in the same contig, else its own (:1387-1390)
+  auto nextWpos = [&](int64_t e) { const int64_t n = nextIns(e + 1); return n < ce ? wposOf(n) : wposOf(e); };
+
+  int bestShared = 1; bool inRun = false;
+  int curStart = 0, curEnd = 0, curShared = 0;
+  int nFlushed = 0; bool havePend = false; L2Tmp pend{0, 0, 0, 0};
+  L2Tmp* mySlots = tmp + (size_t)c * locap;
+  bool slotOverflow = false;
+  auto close_run = [&](int strand) {                                             // :1417-1426 / :1440-1449
+    if (!havePend || pend.end + segLength < curStart) {
+      if (havePend) { if (nFlushed < locap) mySlots[nFlushed] = pend; else slotOverflow = true; nFlushed++; }
+      pend.start = curStart; pend.end = curEnd; pend.shared = curShared; pend.strand = strand; havePend = true;
+    } else pend.end = curEnd;
+  };
+
+  int64_t it = nextIns(X.e0);
+  while (it < ce && wposOf(it) < cand.rangeStartPos) {                           // set up the window (:1323-1338)
+    if (wendOf(it) > cand.rangeStartPos) {
+      int32_t* fq = freqOf(evHash[it]);
+      if (W > 0) (*fq)++;
+      if (W == 0 || *fq == 1) {
+        heap[nHeap] = (int32_t)(it - X.e0); nHeap++;
+        mm_heap_push(heap, nHeap - 1, 0, heap[nHeap - 1], later);
+        insertMinmer(it);
+      }
+    }
+    it = nextIns(it + 1);
+  }
+  while (it < ce && (long long)wposOf(it) <= (long long)cand.rangeEndPos + W) {  // the slide (:1340-1434)
+    const int prevVotes = votes;
+    while (nHeap > 0 && wendOf(X.e0 + heap[0]) <= wposOf(it) - W) {
+      const int64_t fr = X.e0 + heap[0];
+      int32_t* fq = freqOf(evHash[fr]);
+      if (W > 0) (*fq)--;
+      if (W == 0 || *fq == 0) {
+        deleteMinmer(fr);
+        mm_pop_heap(heap, nHeap, later); nHeap--;
+      }
+    }
+    int32_t* fq = freqOf(evHash[it]);
+    if (W > 0) (*fq)++;
+    if (W == 0 || *fq == 1) {
+      insertMinmer(it);
+      heap[nHeap] = (int32_t)(it - X.e0); nHeap++;
+      mm_heap_push(heap, nHeap - 1, 0, heap[nHeap - 1], later);
+    } else { it = nextIns(it + 1); continue; }
+    if (shared > bestShared) {
+      nFlushed = 0; havePend = false;
+      inRun = true; bestShared = shared; curShared = shared;
+      curStart = wposOf(it);                                                     // (no "- windowLen" here in the reference, :1384)
+      curEnd = nextWpos(it) - W;
+    } else if (shared == bestShared) {
+      if (!inRun) { curShared = shared; curStart = wposOf(it) - W; }
+      inRun = true;
+      curEnd = nextWpos(it) - W;
+    } else {
+      if (inRun) { curEnd = nextWpos(it) - W; close_run(prevVotes >= 0 ? 1 : -1); curStart = curEnd = curShared = 0; }
+      inRun = false;
+    }
+    it = nextIns(it + 1);
+  }
+  if (inRun) close_run(votes >= 0 ? 1 : -1);
+  int total = nFlushed + (havePend ? 1 : 0);
+  if (slotOverflow) { atomicOr(&counters[6], 1ull); total = 0; }
+  unsigned long long base = 0;
+  if (total > 0) {
+    base = atomicAdd(&counters[4], (unsigned long long)total);
+    if (base + (unsigned long long)total > l2Cap) { atomicOr(&counters[5], 1ull); return; }
+  }
+  l2First[c] = (int64_t)base; l2Num[c] = total;
+  const int candLocal = (int)(c - l1Off[f]);
+  for (int k = 0; k < total; k++) {
+    const L2Tmp t = (k < nFlushed) ? mySlots[k] : pend;
+    mm_l2_locus o;
+    o.frag = f; o.cand = candLocal; o.seqId = cand.seqId; o.optimalStart = t.start; o.optimalEnd = t.end;
+    o.meanOptimalPos = (t.start + t.end) / 2; o.sharedSketchSize = t.shared; o.strand = t.strand;
+    l2[base + k] = o;
+  }
+}
+
+static int mm_launch_l2_window(mm_ctx* c, unsigned long long* cnt) {
+  const DeviceIndex& I = c->idx;
+  const int s = c->P.sketchSize;
+  const int nC = (int)c->nL1;
+  MM_HIP(c, c->dWinExt.ensure((size_t)nC * sizeof(WinExt) + 64));
+  MM_HIP(c, c->dWinCntH.ensure((size_t)nC * 4 + 64)); MM_HIP(c, c->dWinCntT.ensure((size_t)nC * 4 + 64));
+  MM_HIP(c, c->dWinOffH.ensure((size_t)nC * 8 + 64)); MM_HIP(c, c->dWinOffT.ensure((size_t)nC * 8 + 64));
+  MM_HIP(c, c->dL2First.ensure((size_t)nC * 8 + 64)); MM_HIP(c, c->dL2Num.ensure((size_t)nC * 4 + 64));
+  int64_t totH = 0, totT = 0;
+  {
+    KernelTimer t(c, MM_K_L2_LOCATE);
+    hipLaunchKernelGGL(k_l2_window_extents, dim3((nC + 255) / 256), dim3(256), 0, c->stream, nC, c->P.segLength, c->dL1.as<mm_l1_candidate>(), c->dFrags.as<DFrag>(),
+                       I.evKey.as<uint32_t>(), I.contigOff.as<int64_t>(), c->dWinExt.as<WinExt>(), c->dWinCntH.as<int32_t>(), c->dWinCntT.as<int32_t>());
+    MM_HIP(c, hipGetLastError());
+    int rc = mm_scan_i32_to_i64(c, nC, c->dWinCntH.as<int32_t>(), c->dWinOffH.as<int64_t>(), &totH); if (rc != MM_OK) return rc;
+    rc = mm_scan_i32_to_i64(c, nC, c->dWinCntT.as<int32_t>(), c->dWinOffT.as<int64_t>(), &totT); if (rc != MM_OK) return rc;
+  }
+  if ((size_t)totT * 12 + (size_t)totH * 4 > ((size_t)96 << 30)) { c->err = "windowLen != 0: the candidates of this batch need more than 96 GiB of scratch; use smaller batches (MASHMAP_HIP_BATCH_MBP)"; return MM_ERR_CAPACITY; }
+  MM_HIP(c, c->dWinHeap.ensure((size_t)totH * 4 + 64)); MM_HIP(c, c->dWinKeys.ensure((size_t)totT * 8 + 64)); MM_HIP(c, c->dWinVals.ensure((size_t)totT * 4 + 64));
+  MM_HIP(c, c->dL2Cells.ensure((size_t)nC * (size_t)(s + 1) * sizeof(ExactCell) + 64));
+  if (c->l2Cap < c->nL1 * 2 + 1024) c->l2Cap = c->nL1 * 2 + 1024;
+  unsigned long long hc[8];
+  int locap = MM_LOCAP0;
+  for (int attempt = 0; attempt < 24; attempt++) {
+    MM_HIP(c, c->dL2.ensure(c->l2Cap * sizeof(mm_l2_locus) + 64));
+    MM_HIP(c, c->dL2Tmp.ensure((size_t)nC * locap * sizeof(L2Tmp) + 64));
+    MM_HIP(c, hipMemsetAsync(cnt + 4, 0, 24, c->stream));
+    {
+      KernelTimer t(c, MM_K_L2);
+      hipLaunchKernelGGL(k_l2_window, dim3((nC + 63) / 64), dim3(64), 0, c->stream, nC, s, c->P.segLength, c->dL1.as<mm_l1_candidate>(), c->dStats.as<mm_frag_stats>(),
+                         c->dFrags.as<DFrag>(), c->dQHash.as<uint64_t>(), c->dQStrand.as<int8_t>(), c->dSkHash.as<uint64_t>(), c->dSkStrand.as<int8_t>(),
+                         I.evKey.as<uint32_t>(), I.evAux.as<uint32_t>(), I.evHash.as<uint64_t>(), I.contigOff.as<int64_t>(), c->dWinExt.as<WinExt>(),
+                         c->dWinOffH.as<int64_t>(), c->dWinOffT.as<int64_t>(), c->dWinCntT.as<int32_t>(), c->dWinHeap.as<int32_t>(), c->dWinKeys.as<uint64_t>(),
+                         c->dWinVals.as<int32_t>(), c->dL2Cells.as<ExactCell>(), c->dL1Off.as<int64_t>(), c->dL2Tmp.as<L2Tmp>(), locap, c->dL2.as<mm_l2_locus>(),
+                         (unsigned long long)c->l2Cap, c->dL2First.as<int64_t>(), c->dL2Num.as<int32_t>(), cnt);
+      MM_HIP(c, hipGetLastError());
+    }
+    MM_HIP(c, hipMemcpyAsync(hc, cnt, 64, hipMemcpyDeviceToHost, c->stream));
+    MM_HIP(c, hipStreamSynchronize(c->stream));
+    if (hc[6] & 1ull) { if ((size_t)nC * (size_t)locap * 2 * sizeof(L2Tmp) > ((size_t)64 << 30)) break; locap *= 2; continue; }
+    if (hc[5]) { c->l2Cap = (size_t)hc[4] + (size_t)hc[4] / 8 + 1024; continue; }
+    break;
+  }
+  if (hc[6] & 1ull) { c->err = "an L1 candidate with more tied L2 loci than 64 GiB of staging can hold"; return MM_ERR_CAPACITY; }
+  if (hc[5]) { c->err = "L2 locus buffer overflow"; return MM_ERR_CAPACITY; }
+  c->nL2 = (size_t)hc[4];
+  return MM_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 int mm_scan_i32_to_i64(mm_ctx* c, int64_t n, const int32_t* dIn, int64_t* dOut, int64_t* total) {
   const int64_t nTiles = (n + SCAN_TILE - 1) / SCAN_TILE;
@@ -627,6 +858,7 @@ int mm_scan_i32_to_i64(mm_ctx* c, int64_t n, const int32_t* dIn, int64_t* dOut, 
 }
 
 int mm_launch_l2(mm_ctx* c, unsigned long long* cnt) {
+  if (c->windowed) return mm_launch_l2_window(c, cnt);               // fragments longer than segLength (--noSplit): the literal kernel
   const DeviceIndex& I = c->idx;
   const int s = c->P.sketchSize;
   const int nC = (int)c->nL1;

@@ -143,10 +143,12 @@ struct FuseScratchT {
 
 // Interval points of the fragment's surviving seeds -> dst[0..P) (skip_self / skip_prefix / lower_triangular applied,
 // computeMap.hpp:891-896; dropped points become MM_EMPTY and sort to the end).  Returns the wave-wide count of kept points.
+// ids (may be null): the seed every point came from, as a small number unique inside the fragment (round * 64 + lane) -- what the
+// windowLen != 0 sweep counts open windows per hash by (computeMap.hpp:950: hash_to_freq)
 template <class Dst, class ValAt>
 __device__ __forceinline__ int mm_gather_points(Dst dst, int nRounds, ValAt&& valAt,
                                                 const uint64_t* __restrict__ ptKeys, const int32_t* __restrict__ refGroup,
-                                                int rg, int self, int seqCounter, MapFlags fl, int lane) {
+                                                int rg, int self, int seqCounter, MapFlags fl, int lane, uint16_t* __restrict__ ids = nullptr) {
   int nValid = 0, done = 0;
   for (int rd = 0; rd < nRounds; rd++) {
     const uint64_t val = valAt(rd);                // table value of this lane's seed in round rd (0: none)
@@ -162,6 +164,7 @@ __device__ __forceinline__ int mm_gather_points(Dst dst, int nRounds, ValAt&& va
       if (fl.lowerTri && !(seqCounter > seqId)) drop = true;
       if (drop) key = MM_EMPTY; else nValid++;
       dst[my + j] = key;
+      if (ids) ids[my + j] = (uint16_t)(rd * 64 + lane);
     }
     done += mm_wave_sum(c);
   }
@@ -317,7 +320,7 @@ k_lookup_l1(int nFrags, int s, const DFrag* __restrict__ frags,
             const uint64_t* __restrict__ ptKeys, const int32_t* __restrict__ refGroup,
             const int32_t* __restrict__ readGroup, const int32_t* __restrict__ readSelf, int seqCounterBase, MapFlags fl, int keepPoints,
             uint64_t* __restrict__ qHash, int8_t* __restrict__ qStrand, uint64_t* __restrict__ seedVal,
-            mm_frag_stats* __restrict__ stats, int64_t* __restrict__ ptOff, uint64_t* __restrict__ pts, unsigned long long ptsCap,
+            mm_frag_stats* __restrict__ stats, int64_t* __restrict__ ptOff, uint64_t* __restrict__ pts, uint16_t* __restrict__ ptIds /* keepPoints == 2 */, unsigned long long ptsCap,
             const int32_t* __restrict__ minHitsTab, const int32_t* __restrict__ cutoffs, int nCutoffs, int segLength,
             mm_l1_candidate* __restrict__ l1, unsigned long long regionCap, unsigned long long* __restrict__ l1Cursors,
             int64_t* __restrict__ l1Off, int32_t* __restrict__ bigList,
@@ -495,6 +498,7 @@ k_lookup_l1(int nFrags, int s, const DFrag* __restrict__ frags,
     // slow path: points go to HBM, sorted and swept by the follow-up kernels (slots: a power of two above 64 for the sorters)
     int slots = P;
     if (P > 64) { slots = 128; while (slots < P) slots <<= 1; }
+    else if (keepPoints == 2 && P > 0) { slots = 2; while (slots < P) slots <<= 1; }      // windowed mode: every list goes through the LDS / HBM sorters
     unsigned long long off = 0;
     if (lane == 0 && slots > 0) off = atomicAdd(&counters[0], (unsigned long long)slots);
     off = ((unsigned long long)(uint32_t)__shfl((int)(off >> 32), 0) << 32) | (uint32_t)__shfl((int)(uint32_t)off, 0);
@@ -503,10 +507,11 @@ k_lookup_l1(int nFrags, int s, const DFrag* __restrict__ frags,
     nValid = 0;
     if (ok && slots > 0) {
       // the table values are still in the probing lanes' registers (the order of the points is irrelevant: they are sorted next)
+      uint16_t* idDst = keepPoints == 2 ? ptIds + off : nullptr;
       if (oneBatch) nValid = mm_gather_points(pts + off, 4, [&](int rd) { return rd == 0 ? pv[0] : rd == 1 ? pv[1] : rd == 2 ? pv[2] : pv[3]; },
-                                              ptKeys, refGroup, rg, self, seqCounter, fl, lane);
+                                              ptKeys, refGroup, rg, self, seqCounter, fl, lane, idDst);
       else nValid = mm_gather_points(pts + off, (outIdx + 63) >> 6, [&](int rd) { const int i = rd * 64 + lane; return i < outIdx ? seedVal[fo + i] : 0ull; },
-                                     ptKeys, refGroup, rg, self, seqCounter, fl, lane);
+                                     ptKeys, refGroup, rg, self, seqCounter, fl, lane, idDst);
       for (int j = P + lane; j < slots; j += 64) pts[off + j] = MM_EMPTY;
     }
     if (lane == 0) {
@@ -576,35 +581,41 @@ k_sort_points_wave(int nList, const int32_t* __restrict__ list, const int64_t* _
 
 // 65..LDSCAP points (power of two): one 256-thread workgroup per fragment, bitonic sort staged in LDS
 #define MM_SORT_LDSCAP 4096
+// ids (may be null): a 16-bit payload that travels with its key (windowed mode: the seed of every point)
 __global__ void __launch_bounds__(256)
-k_sort_points_block(const int64_t* __restrict__ ptOff, uint64_t* __restrict__ pts, const int32_t* __restrict__ list) {
+k_sort_points_block(const int64_t* __restrict__ ptOff, uint64_t* __restrict__ pts, const int32_t* __restrict__ list, uint16_t* __restrict__ ids) {
   __shared__ uint64_t sk[MM_SORT_LDSCAP];
+  __shared__ uint16_t si[MM_SORT_LDSCAP];
   const int f = list[blockIdx.x];
   const int64_t off = ptOff[2 * f]; const int n = (int)ptOff[2 * f + 1];
-  for (int i = threadIdx.x; i < n; i += 256) sk[i] = pts[off + i];
+  for (int i = threadIdx.x; i < n; i += 256) { sk[i] = pts[off + i]; if (ids) si[i] = ids[off + i]; }
   __syncthreads();
   for (int k = 2; k <= n; k <<= 1)
     for (int j = k >> 1; j > 0; j >>= 1) {
       for (int i = threadIdx.x; i < n; i += 256) {
         const int p = i ^ j;
-        if (p > i) { const uint64_t a = sk[i], b = sk[p]; if ((a > b) == ((i & k) == 0)) { sk[i] = b; sk[p] = a; } }
+        if (p > i) {
+          const uint64_t a = sk[i], b = sk[p];
+          if ((a > b) == ((i & k) == 0)) { sk[i] = b; sk[p] = a; if (ids) { const uint16_t t = si[i]; si[i] = si[p]; si[p] = t; } }
+        }
       }
       __syncthreads();
     }
-  for (int i = threadIdx.x; i < n; i += 256) pts[off + i] = sk[i];
+  for (int i = threadIdx.x; i < n; i += 256) { pts[off + i] = sk[i]; if (ids) ids[off + i] = si[i]; }
 }
 
 // > LDSCAP points: one 1024-thread workgroup per fragment, bitonic sort in global memory (rare: very repetitive seeds)
 __global__ void __launch_bounds__(1024)
-k_sort_points_global(const int64_t* __restrict__ ptOff, uint64_t* __restrict__ pts, const int32_t* __restrict__ list) {
+k_sort_points_global(const int64_t* __restrict__ ptOff, uint64_t* __restrict__ pts, const int32_t* __restrict__ list, uint16_t* __restrict__ ids) {
   const int f = list[blockIdx.x];
   const int64_t off = ptOff[2 * f]; const int64_t n = ptOff[2 * f + 1];
   uint64_t* a = pts + off;
+  uint16_t* d = ids ? ids + off : nullptr;
   for (int64_t k = 2; k <= n; k <<= 1)
     for (int64_t j = k >> 1; j > 0; j >>= 1) {
       for (int64_t i = threadIdx.x; i < n; i += 1024) {
         const int64_t p = i ^ j;
-        if (p > i) { const uint64_t x = a[i], y = a[p]; if ((x > y) == ((i & k) == 0)) { a[i] = y; a[p] = x; } }
+        if (p > i) { const uint64_t x = a[i], y = a[p]; if ((x > y) == ((i & k) == 0)) { a[i] = y; a[p] = x; if (d) { const uint16_t t = d[i]; d[i] = d[p]; d[p] = t; } } }
       }
       __threadfence_block();
       __syncthreads();
@@ -613,11 +624,11 @@ k_sort_points_global(const int64_t* __restrict__ ptOff, uint64_t* __restrict__ p
 
 // splits the queued fragments into the block / global sorter lists (wave-aggregated cursors)
 __global__ void k_classify_sort(int nList, const int32_t* __restrict__ list, const int64_t* __restrict__ ptOff,
-                                int32_t* __restrict__ listB, int32_t* __restrict__ listC, unsigned int* __restrict__ cnt /* [0] B, [1] C */) {
+                                int32_t* __restrict__ listB, int32_t* __restrict__ listC, unsigned int* __restrict__ cnt /* [0] B, [1] C */, int minB /* lists longer than this go to the LDS sorter */) {
   const int li = blockIdx.x * blockDim.x + threadIdx.x;
   int f = -1; int64_t n = 0;
   if (li < nList) { f = list[li]; n = ptOff[2 * f + 1]; }
-  const bool isC = n > MM_SORT_LDSCAP, isB = !isC && n > 64;
+  const bool isC = n > MM_SORT_LDSCAP, isB = !isC && n > minB;
   const uint64_t mB = __ballot(isB), mC = __ballot(isC);
   unsigned int bB = 0, bC = 0;
   if (mB && mm_lane() == (uint32_t)__builtin_ctzll(mB)) bB = atomicAdd(&cnt[0], (unsigned int)__popcll(mB));
@@ -916,6 +927,110 @@ k_l1_sweep(int nList, const int32_t* __restrict__ list, const int64_t* __restric
   l1Off[f] = base;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// k_l1_window: computeL1CandidateRegions for fragments LONGER than segLength (--noSplit: Q.len > segLength, windowLen =
+// Q.len - segLength != 0, computeMap.hpp:933), literally: one thread per fragment over its sorted points, the trailing pointer windowLen
+// behind the leading one, and a count of open windows per seed (hash_to_freq, :948) -- a seed adds to the overlap only while its count
+// goes 0 -> 1 and leaves it only when it returns to 0.  `ids` numbers the seeds of a fragment (mm_gather_points); `freq` is this
+// thread's slice of a zero-initialised scratch array.  Handles windowLen == 0 as well (a batch may mix short and long reads).
+// ---------------------------------------------------------------------------------------------
+__device__ void l1_window_fragment(const uint64_t* __restrict__ p, const uint16_t* __restrict__ ids, int nPts, int W, int32_t* __restrict__ freq, int nFreq,
+                                   int sketchSizeQ, int minHits0, const int32_t* __restrict__ cutoffs, int nCutoffs, int sParam, int segLength, MapFlags fl,
+                                   const int32_t* __restrict__ refGroup, L1Emit& em) {
+  auto seqOf = [&](int i) { return (int)(p[i] >> 33); };
+  auto posOf = [&](int i) { return (int)(uint32_t)(p[i] >> 1); };
+  auto behind = [&](int t, int l) { const int st = seqOf(t), sl = seqOf(l); return (st == sl && posOf(t) <= posOf(l) - W) || st < sl; };   // :952-954
+  auto closeAt = [&](int t, int& overlap) { if (!(p[t] & 1ull)) { const int id = ids[t]; if (W != 0) freq[id]--; if (W == 0 || freq[id] == 0) overlap--; } };
+  auto openAt = [&](int l, int& overlap) { if (p[l] & 1ull) { const int id = ids[l]; if (W == 0 || freq[id] == 0) overlap++; if (W != 0) freq[id]++; } };
+  int b = 0;
+  while (b < nPts) {
+    int e = nPts;
+    if (fl.skipPrefix) {
+      const int g = refGroup[seqOf(b)];
+      e = b; while (e < nPts && refGroup[seqOf(e)] == g) e++;
+    }
+    int minHits = minHits0;
+    bool go = true;
+    if (fl.hg) {                                                 // pass 1: best overlap (:948-999)
+      for (int i = 0; i < nFreq; i++) freq[i] = 0;
+      int overlap = 0, best = 0, trail = b, lead = b;
+      while (lead < e) {
+        while (trail < e && behind(trail, lead)) { closeAt(trail, overlap); trail++; }
+        const int cur = posOf(lead);
+        while (lead < e && posOf(lead) == cur) { openAt(lead, overlap); lead++; }
+        best = overlap > best ? overlap : best;
+      }
+      if (best < minHits) go = false;
+      else {
+        const double div = (double)sParam / 1000.0 > 1.0 ? (double)sParam / 1000.0 : 1.0;
+        int ci = (int)((double)(best < sketchSizeQ ? best : sketchSizeQ) / div);
+        if (ci >= nCutoffs) ci = nCutoffs - 1;
+        const int cut = cutoffs[ci];
+        minHits = cut > minHits ? cut : minHits;
+      }
+    }
+    if (go) {                                                    // pass 2 (:1001-1098); hash_to_freq.clear() first (:1001-1003)
+      for (int i = 0; i < nFreq; i++) freq[i] = 0;
+      bool firstOfGroup = true, inRun = false;
+      int rSeq = 0, rStart = 0, rEnd = 0, rSize = 0;
+      int overlap = 0, trail = b, lead = b;
+      int prevSeq = 0, prevPos = 0;
+      int curSeq = seqOf(b), curPos = posOf(b);
+      while (lead < e) {
+        const int prevOverlap = overlap;
+        while (trail < e && behind(trail, lead)) { closeAt(trail, overlap); trail++; }
+        if (posOf(lead) != curPos) { prevSeq = curSeq; prevPos = curPos; curSeq = seqOf(lead); curPos = posOf(lead); }
+        while (lead < e && posOf(lead) == curPos) { openAt(lead, overlap); lead++; }
+        if (prevOverlap >= minHits) {
+          if (inRun && rSeq != prevSeq) { em.run(rSeq, rStart, rEnd, rSize, segLength, firstOfGroup); inRun = false; }
+          if (!inRun) { rStart = prevPos - W; rEnd = prevPos - W; rSeq = prevSeq; rSize = prevOverlap; inRun = true; }
+          else { rSize = prevOverlap > rSize ? prevOverlap : rSize; rEnd = prevPos - W; }
+        } else {
+          if (inRun) em.run(rSeq, rStart, rEnd, rSize, segLength, firstOfGroup);
+          inRun = false;
+        }
+      }
+      if (inRun) em.run(rSeq, rStart, rEnd, rSize, segLength, firstOfGroup);
+    }
+    em.flush();
+    b = e;
+  }
+}
+
+__global__ void __launch_bounds__(64)
+k_l1_window(int nList, const int32_t* __restrict__ list, const DFrag* __restrict__ frags, const int64_t* __restrict__ ptOff, const uint64_t* __restrict__ pts,
+            const uint16_t* __restrict__ ptIds, mm_frag_stats* __restrict__ stats, const int32_t* __restrict__ minHitsTab, const int32_t* __restrict__ cutoffs,
+            int nCutoffs, int sParam, int segLength, MapFlags fl, const int32_t* __restrict__ refGroup, int32_t* __restrict__ freqAll, int nFreq,
+            mm_l1_candidate* __restrict__ l1, unsigned long long l1Cap, int64_t* __restrict__ l1Off, unsigned long long* __restrict__ counters /* [2] l1 cursor, [3] overflow */) {
+  const int li = blockIdx.x * blockDim.x + threadIdx.x;
+  if (li >= nList) return;
+  const int f = list[li];
+  const int nPts = stats[f].nPoints, S = stats[f].sketchSize;
+  int nOut = 0; long long base = 0;
+  if (nPts > 0 && S > 0) {
+    const uint64_t* p = pts + ptOff[2 * f];
+    const uint16_t* ids = ptIds + ptOff[2 * f];
+    int W = frags[f].len - segLength; if (W < 0) W = 0;
+    int32_t* freq = freqAll + (size_t)li * nFreq;
+    const int minHits0 = minHitsTab[S];
+    L1Emit em; em.out = nullptr; em.frag = f; em.count = 0; em.write = false; em.have = false;
+    l1_window_fragment(p, ids, nPts, W, freq, nFreq, S, minHits0, cutoffs, nCutoffs, sParam, segLength, fl, refGroup, em);
+    nOut = em.count;
+    if (nOut > 0) {
+      base = (long long)atomicAdd(&counters[2], (unsigned long long)nOut);
+      if ((unsigned long long)base + nOut > l1Cap) { atomicOr(&counters[3], 1ull); nOut = 0; }
+      else if (nOut <= 2) { l1[base] = em.b0; if (nOut == 2) l1[base + 1] = em.b1; }
+      else {
+        L1Emit ew; ew.out = l1 + base; ew.frag = f; ew.count = 0; ew.write = true; ew.have = false;
+        l1_window_fragment(p, ids, nPts, W, freq, nFreq, S, minHits0, cutoffs, nCutoffs, sParam, segLength, fl, refGroup, ew);
+      }
+    }
+  }
+  stats[f].nL1 = nOut;
+  l1Off[f] = base;
+}
+
 // ---------------------------------------------------------------------------------------------
 // launcher
 // ---------------------------------------------------------------------------------------------
@@ -931,7 +1046,10 @@ int mm_launch_map(mm_ctx* c) {
   if (nF == 0) return MM_OK;
   MapFlags fl{(c->P.flags & MM_FLAG_HG_FILTER) ? 1 : 0, (c->P.flags & MM_FLAG_SKIP_SELF) ? 1 : 0,
               (c->P.flags & MM_FLAG_SKIP_PREFIX) ? 1 : 0, (c->P.flags & MM_FLAG_LOWER_TRIANGULAR) ? 1 : 0};
-  const bool allSlow = c->keepPoints || fl.skipPrefix;
+  // fragments longer than segLength (--noSplit): windowLen != 0 -- every fragment takes the literal path with its points (and their
+  // seeds' numbers) in HBM: k_l1_window here, k_l2_window in mm_l2.hip
+  const bool windowed = c->windowed;
+  const bool allSlow = c->keepPoints || fl.skipPrefix || windowed;
   if (c->ptsCap == 0) c->ptsCap = allSlow ? (size_t)nF * 128 + 4096 : (size_t)nF * 8 + 65536;
   if (c->l1Cap == 0) c->l1Cap = (size_t)nF * 2 + 1024;
   DevBuf& listB = c->dListB; DevBuf& listC = c->dListC;
@@ -946,6 +1064,7 @@ int mm_launch_map(mm_ctx* c) {
   for (int attempt = 0; attempt < 10; attempt++) {          // grow-and-retry on capacity overflow (points or L1 candidates)
     regionCap = (c->l1Cap + MM_L1_REGIONS - 1) / MM_L1_REGIONS + 64;
     MM_HIP(c, c->dPts.ensure(c->ptsCap * 8 + 64));
+    MM_HIP(c, c->dPtIds.ensure(windowed ? c->ptsCap * 2 + 64 : 64));
     MM_HIP(c, c->dL1.ensure(regionCap * MM_L1_REGIONS * sizeof(mm_l1_candidate) + 64));
     MM_HIP(c, c->dL1b.ensure(regionCap * MM_L1_REGIONS * sizeof(mm_l1_candidate) + 64));
     MM_HIP(c, c->dL1Cursors.ensure(sizeof hcur));
@@ -963,9 +1082,9 @@ int mm_launch_map(mm_ctx* c) {
                          c->dSkHash.as<uint64_t>(), c->dSkStrand.as<int8_t>(), c->dSkCount.as<uint32_t>(),
                          I.htSlots.as<HtSlot>(), (uint64_t)(I.htCap - 1), I.filter.as<uint64_t>(), (uint64_t)I.filterMask, I.htTags.as<uint8_t>(), I.ptKeys.as<uint64_t>(),
                          I.refGroup.as<int32_t>(), c->dReadGroup.as<int32_t>(), c->dReadSelf.as<int32_t>(), c->seqCounterBase, fl,
-                         c->keepPoints ? 1 : 0,
+                         windowed ? 2 : (c->keepPoints ? 1 : 0),
                          c->dQHash.as<uint64_t>(), c->dQStrand.as<int8_t>(), c->dSeedVal.as<uint64_t>(), c->dStats.as<mm_frag_stats>(),
-                         c->dPtOff.as<int64_t>(), c->dPts.as<uint64_t>(), (unsigned long long)c->ptsCap,
+                         c->dPtOff.as<int64_t>(), c->dPts.as<uint64_t>(), c->dPtIds.as<uint16_t>(), (unsigned long long)c->ptsCap,
                          c->dMinHits.as<int32_t>(), c->dCutoffs.as<int32_t>(), (int)c->nCutoffs, c->P.segLength,
                          c->dL1.as<mm_l1_candidate>(), regionCap, c->dL1Cursors.as<unsigned long long>(), c->dL1Off.as<int64_t>(),
                          c->dBigList.as<int32_t>(), cnt);
@@ -1003,15 +1122,16 @@ int mm_launch_map(mm_ctx* c) {
     unsigned int* cls = (unsigned int*)(c->dCounters.as<unsigned long long>() + 16);   // [16] two 32-bit class counters
     {
       KernelTimer t(c, MM_K_SORT);
-      hipLaunchKernelGGL(k_sort_points_wave, dim3((nBig + 3) / 4), dim3(256), 0, c->stream, nBig, c->dBigList.as<int32_t>(), c->dPtOff.as<int64_t>(), c->dPts.as<uint64_t>());
+      uint16_t* sortIds = windowed ? c->dPtIds.as<uint16_t>() : (uint16_t*)nullptr;
+      if (!windowed) hipLaunchKernelGGL(k_sort_points_wave, dim3((nBig + 3) / 4), dim3(256), 0, c->stream, nBig, c->dBigList.as<int32_t>(), c->dPtOff.as<int64_t>(), c->dPts.as<uint64_t>());
       hipLaunchKernelGGL(k_classify_sort, dim3((nBig + 255) / 256), dim3(256), 0, c->stream, nBig, c->dBigList.as<int32_t>(), c->dPtOff.as<int64_t>(),
-                         listB.as<int32_t>(), listC.as<int32_t>(), cls);
+                         listB.as<int32_t>(), listC.as<int32_t>(), cls, windowed ? 1 : 64);
       MM_HIP(c, hipGetLastError());
       unsigned int hcls[2];
       MM_HIP(c, hipMemcpyAsync(hcls, cls, 8, hipMemcpyDeviceToHost, c->stream));
       MM_HIP(c, hipStreamSynchronize(c->stream));
-      if (hcls[0]) hipLaunchKernelGGL(k_sort_points_block, dim3(hcls[0]), dim3(256), 0, c->stream, c->dPtOff.as<int64_t>(), c->dPts.as<uint64_t>(), listB.as<int32_t>());
-      if (hcls[1]) hipLaunchKernelGGL(k_sort_points_global, dim3(hcls[1]), dim3(1024), 0, c->stream, c->dPtOff.as<int64_t>(), c->dPts.as<uint64_t>(), listC.as<int32_t>());
+      if (hcls[0]) hipLaunchKernelGGL(k_sort_points_block, dim3(hcls[0]), dim3(256), 0, c->stream, c->dPtOff.as<int64_t>(), c->dPts.as<uint64_t>(), listB.as<int32_t>(), sortIds);
+      if (hcls[1]) hipLaunchKernelGGL(k_sort_points_global, dim3(hcls[1]), dim3(1024), 0, c->stream, c->dPtOff.as<int64_t>(), c->dPts.as<uint64_t>(), listC.as<int32_t>(), sortIds);
       MM_HIP(c, hipGetLastError());
     }
     for (int attempt = 0; attempt < 8; attempt++) {
@@ -1023,8 +1143,17 @@ int mm_launch_map(mm_ctx* c) {
         KernelTimer t(c, MM_K_L1);
         // a wave per fragment streams the sorted points; what it cannot take (a position group across two contigs, minimumHits 0) and
         // every fragment under -Y reference groups goes to the literal one-thread-per-fragment kernel
-        const bool stream = !fl.skipPrefix && !getenv("MM_L1_LITERAL");
+        const bool stream = !fl.skipPrefix && !getenv("MM_L1_LITERAL") && !windowed;
         const int32_t* sweepList = c->dBigList.as<int32_t>(); const unsigned int* sweepCount = nullptr;
+        if (windowed) {
+          const int nFreq = s > 256 ? s : 256;                                     // seeds are numbered round * 64 + lane
+          MM_HIP(c, c->dWinFreq.ensure((size_t)nBig * nFreq * 4 + 64));
+          hipLaunchKernelGGL(k_l1_window, dim3((nBig + 63) / 64), dim3(64), 0, c->stream, nBig, c->dBigList.as<int32_t>(), c->dFrags.as<DFrag>(), c->dPtOff.as<int64_t>(),
+                             c->dPts.as<uint64_t>(), c->dPtIds.as<uint16_t>(), c->dStats.as<mm_frag_stats>(), c->dMinHits.as<int32_t>(), c->dCutoffs.as<int32_t>(),
+                             (int)c->nCutoffs, s, c->P.segLength, fl, I.refGroup.as<int32_t>(), c->dWinFreq.as<int32_t>(), nFreq, c->dL1.as<mm_l1_candidate>(),
+                             (unsigned long long)denseCap, c->dL1Off.as<int64_t>(), cnt);
+          MM_HIP(c, hipGetLastError());
+        } else {
         if (stream) {
           MM_HIP(c, hipMemsetAsync(cls, 0, 8, c->stream));
           hipLaunchKernelGGL(k_l1_stream, dim3((nBig + 3) / 4), dim3(256), 0, c->stream, nBig, c->dBigList.as<int32_t>(), c->dPtOff.as<int64_t>(),
@@ -1039,6 +1168,7 @@ int mm_launch_map(mm_ctx* c) {
                            (int)c->nCutoffs, s, c->P.segLength, fl, I.refGroup.as<int32_t>(), c->dL1.as<mm_l1_candidate>(),
                            (unsigned long long)denseCap, c->dL1Off.as<int64_t>(), cnt, sweepCount);
         MM_HIP(c, hipGetLastError());
+        }
       }
       unsigned long long h2[2];
       MM_HIP(c, hipMemcpyAsync(h2, cnt + 2, 16, hipMemcpyDeviceToHost, c->stream));

@@ -112,6 +112,8 @@ def paf_cases():
         ("allvsall_Y", hap, None, ["--pi", "95", "-n", "1", "-Y", "#"]),
         ("allvsall_X_lower", hap, hap, ["--pi", "90", "-X", "--lowerTriangular", "-n", "3"]),
         ("dense_pi80_s20000", ref, long_reads, ["--dense", "--pi", "80", "-s", "20000"]),
+        ("nosplit", ref, reads, ["--noSplit"]),                      # reads of 6.2, 10, 12 and 31 kbp at segLength 5000: windowLen != 0
+        ("nosplit_pi90_n3", ref, reads + long_reads[:6], ["--noSplit", "--pi", "90", "-n", "3", "-s", "3000"]),
     ]
 
 

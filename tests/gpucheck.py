@@ -29,6 +29,7 @@ def run_and_compare(oracle, contigs, reads, k=19, L=5000, s=130, pi=0.85, flags=
     if flags & U.FLAG_SKIP_SELF: cflags |= capi.MM_FLAG_SKIP_SELF
     if flags & U.FLAG_SKIP_PREFIX: cflags |= capi.MM_FLAG_SKIP_PREFIX
     if flags & U.FLAG_LOWER_TRI: cflags |= capi.MM_FLAG_LOWER_TRIANGULAR
+    if flags & U.FLAG_NOSPLIT: cflags |= capi.MM_FLAG_NO_SPLIT        # a read longer than segLength is one fragment (windowLen != 0)
     ctx = capi.Context(k=k, segLength=L, sketchSize=s, flags=cflags)
     cnames = [n for n, _ in contigs]
     refGroup = readGroup = None

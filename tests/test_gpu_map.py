@@ -228,6 +228,33 @@ def test_map_sketch_beyond_1279(oracle, L, s, pi, err):
     run_and_compare(oracle, contigs, reads, L=L, s=s, pi=pi, check_points=False)
 
 
+@pytest.mark.parametrize("mode", ["default", "dup_nohg", "prefix"])
+def test_map_no_split_reads_longer_than_the_segment(oracle, mode):
+    """--noSplit (MM_FLAG_NO_SPLIT): a read longer than segLength is one fragment, windowLen = Q.len - segLength != 0 (computeMap.hpp:933,
+    :1309) -- the literal kernels k_l1_window / k_l2_window (hash_to_freq counts, heap of open records in libstdc++ order, shifted
+    coordinates) against the oracle, whose windowLen path is pinned to the real reference (test_oracle_vs_ref.py).  Mixed with reads
+    shorter than a segment (windowLen == 0 through the same kernels)."""
+    cs = [U.random_dna(700 + i, n) for i, n in enumerate((300000, 200000, 150000))]
+    flags, delim, names = U.FLAG_HG | U.FLAG_NOSPLIT, "\0", ["chr0", "chr1", "chr2"]
+    if mode == "dup_nohg":
+        unit = cs[0][40000:52000].copy()
+        for j in range(3):
+            m = U.mutate(unit, 90 + j, 0.002 * j)[:12000]
+            cs[0][100000 + j * 20000:100000 + j * 20000 + len(m)] = m
+        cs[1][50000:62000] = unit
+        flags = U.FLAG_NOSPLIT
+    if mode == "prefix":
+        flags |= U.FLAG_SKIP_PREFIX; delim = "#"; names = ["A#1#x", "A#1#y", "B#1#x"]
+    contigs = list(zip(names, cs))
+    reads = [(nm, a) for nm, a, _ in U.sample_reads(cs, 13, 16, 12345, 0.08)] + [(nm, a) for nm, a, _ in U.sample_reads(cs, 14, 8, 31000, 0.05)]
+    reads += [("exact", cs[0][38000:61000].copy()), ("short", cs[1][1000:4000].copy()), ("just_over", cs[1][70000:75001].copy()), ("tiny", cs[2][5:17].copy()),
+              ("long80k", U.mutate(cs[2][20000:100000], 5, 0.03))]
+    if mode == "prefix":
+        reads = [("B#1#r%d" % i if i % 2 else "C#1#r%d" % i, a) for i, (_, a) in enumerate(reads)]
+    nF, nl = run_and_compare(oracle, contigs, reads, flags=flags, delim=delim)
+    assert nF == len([1 for _, a in reads if len(a) >= 19]) and nl >= 20
+
+
 def test_index_with_a_hyper_frequent_seed():
     """a frequent seed's point list is never read on the device (getSeedHits drops the seed first): a list of 2^23 points and more
     (a satellite array in a real genome) must not be refused.  Synthetic index: the resident one plus one such key."""

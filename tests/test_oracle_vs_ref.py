@@ -88,3 +88,36 @@ def test_session_and_fragments(oracle, ref, mode):
                 nl2 += len(er["l2"])
         assert nl2 > 20
         ref.free(hr); oracle.free(ho)
+
+
+@pytest.mark.parametrize("mode", ["default", "dup"])
+def test_fragments_longer_than_the_segment_window_len(oracle, ref, mode):
+    """--noSplit: a read longer than segLength is ONE fragment with windowLen = Q.len - segLength != 0 (computeMap.hpp:933, :1309): the
+    hash_to_freq branches of computeL1CandidateRegions and computeL2MappedRegions, the heap of open records, the shifted coordinates.
+    `dup`: a reference with exact repeats, so that hashes are open more than once inside the window (the counts matter)."""
+    k, L, s, pi = 19, 5000, 130, 0.85
+    cs = [U.random_dna(700 + i, n) for i, n in enumerate((300000, 200000))]
+    if mode == "dup":
+        unit = cs[0][40000:52000].copy()
+        for j in range(3):
+            m = U.mutate(unit, 90 + j, 0.002 * j)[:12000]
+            cs[0][100000 + j * 20000:100000 + j * 20000 + len(m)] = m
+        cs[1][50000:62000] = unit
+    contigs = list(zip(["chr0", "chr1"], cs))
+    reads = [(nm, a) for nm, a, _ in U.sample_reads(cs, 13, 10, 12345, 0.08)] + [(nm, a) for nm, a, _ in U.sample_reads(cs, 14, 6, 31000, 0.05)]
+    reads += [("exact", cs[0][38000:61000].copy()), ("short", cs[1][1000:4000].copy()), ("just_over", cs[1][70000:75001].copy())]
+    with tempfile.TemporaryDirectory() as td:
+        fa = os.path.join(td, "r.fa")
+        U.write_fasta(fa, contigs)
+        fl = U.FLAG_HG | U.FLAG_NOSPLIT
+        hr = ref.session([fa], k, L, s, pi, U.FILTER_MAP, fl, b"\0", 0.001)
+        ho = oracle.session(contigs, k, L, s, pi, U.FILTER_MAP, fl, b"\0", 0.001)
+        nl2 = 0
+        for ri, (nm, a) in enumerate(reads):
+            eo = oracle.map_fragment(ho, a, ri, nm.encode(), len(a), s)
+            er = ref.map_fragment(hr, a, ri, nm.encode(), len(a), s)
+            for key in ("sketch", "l1", "l2", "maps_i", "minimumHits", "sketchSize", "rawSketchSize"):
+                assert eo[key] == er[key], (mode, ri, nm, key, eo[key][:3] if isinstance(eo[key], list) else eo[key], er[key][:3] if isinstance(er[key], list) else er[key])
+            nl2 += len(er["l2"])
+        assert nl2 >= 10
+        ref.free(hr); oracle.free(ho)
