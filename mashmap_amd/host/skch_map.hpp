@@ -74,12 +74,17 @@ class Map {
   MapPost post;                                  // everything downstream of the device integers (skch_map_post.hpp)
   std::unique_ptr<mmhost::WorkerPool> postPool;  // the post stage's threads
   bool packedUpload = true;                      // batches travel as 2-bit codes + N mask (set in mapQuery)
+  // Host-to-device copies run ahead of the kernels: every context has ONE staging slot (mm_reads_prefetch[_packed]).  Whoever finds it
+  // free starts the copy of the next batch's block -- the device stage right after it has taken over the previous copy, or the reader
+  // the moment it has parsed a batch while the slot is idle -- so the copy of batch i+1 always runs under the kernels of batch i.
+  std::mutex pfMu; std::vector<char> slotFree; bool earlyPrefetch = true;
   skch::Time::time_point tStart = skch::Time::now();   // MASHMAP_HIP_TIMING lines carry the time since the Map was constructed
   std::string at() const { char b[48]; snprintf(b, sizeof b, " [t=%.4f]", std::chrono::duration<double>(skch::Time::now() - tStart).count()); return b; }
   struct Batch {
     mmhost::ParsedBatch in;                      // names, offsets, bases (page-locked buffer, recycled through bufferPool)
     seqno_t firstSeqCounter = 0;
     std::vector<mm_mapping> recs;                // candidate mappings of the batch, read-major (filled by the device stage)
+    mutable std::vector<char> prefetched;        // per context: the batch's block is already on its way to that GPU (guarded by pfMu)
     size_t size() const { return in.names.size(); }
   };
   // page-locked batch buffers come from skch::HostBufferPool (allocated while the index was being built) and are recycled
@@ -160,6 +165,8 @@ class Map {
     // the reader's workers normalise and pack the bases (2 bit + N mask, pack2bit.hpp) while they drop the line breaks, so that PCIe
     // carries 0.375 bytes per base instead of 1 (mm_reads_upload_packed); MASHMAP_HIP_ASCII_UPLOAD=1 ships ASCII to k_pack2bit instead
     packedUpload = getenv("MASHMAP_HIP_ASCII_UPLOAD") == nullptr;
+    earlyPrefetch = getenv("MASHMAP_HIP_NO_EARLY_PREFETCH") == nullptr;
+    slotFree.assign(ctxs.size(), earlyPrefetch ? 1 : 0);
     std::thread reader([&]() {
       // multi-threaded ingest (seq_parse.hpp): a window of the file per batch, parsed straight into a page-locked buffer.  8 workers:
       // memchr + memcpy at that width keep up with the device stage, and more of them page-faulting through the same file mapping next
@@ -197,7 +204,14 @@ class Map {
           // short reads travel too (they yield no fragment) so that seqCounter == firstSeqCounter + index inside the batch
           seqCounter++;
         }
-        if (batch.size()) parsed.put(std::move(batch));
+        if (batch.size()) {
+          {                                               // idle staging slots: this batch's blocks start travelling now
+            std::lock_guard<std::mutex> lk(pfMu);
+            std::vector<size_t> cut;
+            for (size_t i = 0; i < ctxs.size(); i++) if (slotFree[i]) { if (cut.empty()) cut = blocksOf(batch); issuePrefetch(batch, i, cut); }
+          }
+          parsed.put(std::move(batch));
+        }
       }
       parsed.close();
     });
@@ -246,6 +260,20 @@ class Map {
               << ", total input bp = " << totalBp << std::endl;
   }
 
+  // starts the copy of context i's block of `b` into that context's staging slot (pfMu held)
+  void issuePrefetch(const Batch& b, size_t i, const std::vector<size_t>& cut) {
+    mm_ctx* c = ctxs[i];
+    if (b.in.packed) {
+      const int64_t o0 = b.in.packOffs[cut[i]], o1 = b.in.packOffs[cut[i + 1]];
+      if (mm_reads_prefetch_packed(c, b.in.bases2() + o0 / 16, b.in.nmask() + o0 / 32, (size_t)(o1 - o0)) != MM_OK) die("mm_reads_prefetch_packed", c);
+    } else {
+      const int64_t o0 = b.in.offs[cut[i]], o1 = b.in.offs[cut[i + 1]];
+      if (mm_reads_prefetch(c, b.in.bases + o0, (size_t)(o1 - o0)) != MM_OK) die("mm_reads_prefetch", c);
+    }
+    if (b.prefetched.size() != ctxs.size()) b.prefetched.assign(ctxs.size(), 0);
+    b.prefetched[i] = 1; slotFree[i] = 0;
+  }
+
   // ------------------------------------------------------------------------------------------------------------------
   // device stage: the batch's reads -> candidate mappings (batch.recs), on one GPU or sharded over all contexts
   // contiguous blocks of about equal bases, one per context (a block may be empty)
@@ -275,10 +303,6 @@ class Map {
       for (size_t r = 0; r < nReads; r++) { auto it = refNameToId.find(batch.in.names[r]); readSelf[r] = it == refNameToId.end() ? -1 : it->second; }
     }
     const std::vector<size_t> cutAt = blocksOf(batch);
-    // the batch the reader has already parsed behind this one: its bases travel to the GPU while this one is mapped
-    const Batch* next = parsed.peekFront();
-    std::vector<size_t> nextCut;
-    if (next && next->size()) nextCut = blocksOf(*next);
     // How the blocks' candidate mappings reach the host stage.  One process drives all contexts here, so the records are wanted in
     // host memory, once: by default every context downloads its own block (n copies in parallel, one per GPU's own link; rank-major
     // concatenation == input order), which serves every filter mode -- the one-to-one filter (:358-405) runs on the host over all
@@ -298,17 +322,17 @@ class Map {
         if (mm_reads_upload_packed(c, batch.in.bases2() + p0 / 16, batch.in.nmask() + p0 / 32, batch.in.hasN.data() + b, batch.in.lens.data() + b, e - b,
                                    param.skip_prefix ? readGroup.data() + b : nullptr, param.skip_self ? readSelf.data() + b : nullptr,
                                    batch.firstSeqCounter + (seqno_t)b) != MM_OK) die("mm_reads_upload_packed", c);
-        if (!nextCut.empty() && next->in.packed) {
-          const int64_t o0 = next->in.packOffs[nextCut[i]], o1 = next->in.packOffs[nextCut[i + 1]];
-          if (mm_reads_prefetch_packed(c, next->in.bases2() + o0 / 16, next->in.nmask() + o0 / 32, (size_t)(o1 - o0)) != MM_OK) die("mm_reads_prefetch_packed", c);
-        }
       } else {
         if (mm_reads_upload(c, batch.in.bases, batch.in.offs.data() + b, e - b, param.skip_prefix ? readGroup.data() + b : nullptr,
                             param.skip_self ? readSelf.data() + b : nullptr, batch.firstSeqCounter + (seqno_t)b) != MM_OK) die("mm_reads_upload", c);
-        if (!nextCut.empty()) {
-          const int64_t o0 = next->in.offs[nextCut[i]], o1 = next->in.offs[nextCut[i + 1]];
-          if (mm_reads_prefetch(c, next->in.bases + o0, (size_t)(o1 - o0)) != MM_OK) die("mm_reads_prefetch", c);
-        }
+      }
+      {
+        // the staging slot of this context is free again: the batch the reader has already parsed behind this one starts travelling
+        // while this one is mapped; if there is none yet, the reader starts the copy itself as soon as it has one
+        std::lock_guard<std::mutex> lk(pfMu);
+        const Batch* next = parsed.peekFront();
+        if (next && next->size() && !(next->prefetched.size() == ctxs.size() && next->prefetched[i])) issuePrefetch(*next, i, blocksOf(*next));
+        else if (!next && earlyPrefetch) slotFree[i] = 1;
       }
       const auto p1 = skch::Time::now();
       if (mm_map_fragments(c) != MM_OK) die("mm_map_fragments", c);
