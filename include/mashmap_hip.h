@@ -193,7 +193,10 @@ int mm_reads_upload_device(mm_ctx* ctx, const void* dBases, size_t nBases, const
 /*
  * The same batch for a caller that has normalised and packed the reads itself (the layout k_pack2bit produces on the device, DESIGN.md
  * section 2): PCIe then carries 0.375 bytes per base instead of 1.  Read r has readLengths[r] bases and starts at packed base
- * P(r) = sum over earlier reads of ceil(len / 32) * 32:
+ * P(r) = sum over earlier reads of ceil(len / 32) * 32 -- or, with readStarts != NULL, at P(r) = readStarts[r] - readStarts[0]: ascending
+ * multiples of 32 with P(r+1) >= P(r) + ceil(len / 32) * 32, i.e. gaps between reads are allowed (a parser whose threads pack their
+ * pieces of a file independently leaves one between pieces; the words of a gap travel with the rest and are never read as bases).
+ * P(nReads) is the end of the last read:
  *   bases2  2 bit/base, A0 C1 G2 T3 (the code of an N is 0), sixteen bases per uint32, first base in the low bits; read r owns the words
  *           [P(r) / 16, P(r+1) / 16), bases behind its end are 0
  *   nmask   1 bit/base, set where makeUpperCaseAndValidDNA (commonFunc.hpp:97) leaves an 'N' (anything but A C G T a c g t); read r owns
@@ -205,7 +208,7 @@ int mm_reads_upload_device(mm_ctx* ctx, const void* dBases, size_t nBases, const
  * mm_reads_packed_download returns the resident packed batch of any upload (parity tests); any pointer may be NULL.
  */
 int mm_reads_upload_packed(mm_ctx* ctx, const uint32_t* bases2, const uint32_t* nmask, const uint8_t* readHasN, const int32_t* readLengths,
-                           size_t nReads, const int32_t* readRefGroup, const int32_t* readSelfSeqId, int32_t seqCounterBase);
+                           const int64_t* readStarts, size_t nReads, const int32_t* readRefGroup, const int32_t* readSelfSeqId, int32_t seqCounterBase);
 int mm_reads_prefetch_packed(mm_ctx* ctx, const uint32_t* bases2, const uint32_t* nmask, size_t nPackedBases);
 size_t mm_pack_read(const char* ascii, size_t len, uint32_t* bases2, uint32_t* nmask);
 size_t mm_pack_read_portable(const char* ascii, size_t len, uint32_t* bases2, uint32_t* nmask);

@@ -119,7 +119,7 @@ def load():
         "mm_gathered_device": (C.c_int, [vp, C.POINTER(vp), C.POINTER(sz)]),
         "mm_index_replicate": (C.c_int, [vp, vp]),
         "mm_reads_prefetch": (C.c_int, [vp, vp, sz]),
-        "mm_reads_upload_packed": (C.c_int, [vp, vp, vp, vp, vp, sz, vp, vp, i32]),
+        "mm_reads_upload_packed": (C.c_int, [vp, vp, vp, vp, vp, vp, sz, vp, vp, i32]),
         "mm_reads_prefetch_packed": (C.c_int, [vp, vp, vp, sz]),
         "mm_pack_read": (sz, [vp, sz, vp, vp]),
         "mm_pack_read_portable": (sz, [vp, sz, vp, vp]),
@@ -287,14 +287,16 @@ class Context:
         self._nreads = n
         return self.num_fragments()
 
-    def reads_upload_packed(self, packed, refGroup=None, selfSeqId=None, seqCounterBase=0, prefetch=False):
-        """packed: what pack_reads() returns (bases2, nmask, hasN, lengths); prefetch=True sends the words ahead with mm_reads_prefetch_packed"""
+    def reads_upload_packed(self, packed, refGroup=None, selfSeqId=None, seqCounterBase=0, prefetch=False, starts=None):
+        """packed: what pack_reads() returns (bases2, nmask, hasN, lengths); prefetch=True sends the words ahead with mm_reads_prefetch_packed;
+        starts: packed base of every read's first base (gapped layout), None = the reads follow each other"""
         b2, nm, hasn, lens = packed
+        st = np.ascontiguousarray(starts, dtype=np.int64) if starts is not None else None
         rg = np.ascontiguousarray(refGroup, dtype=np.int32) if refGroup is not None else None
         ss = np.ascontiguousarray(selfSeqId, dtype=np.int32) if selfSeqId is not None else None
         if prefetch:
             self._ck(self.lib.mm_reads_prefetch_packed(self.h, _ptr(b2), _ptr(nm), nm.size * 32), "mm_reads_prefetch_packed")
-        self._ck(self.lib.mm_reads_upload_packed(self.h, _ptr(b2), _ptr(nm), _ptr(hasn), _ptr(lens), len(lens), _ptr(rg), _ptr(ss), seqCounterBase),
+        self._ck(self.lib.mm_reads_upload_packed(self.h, _ptr(b2), _ptr(nm), _ptr(hasn), _ptr(lens), _ptr(st), len(lens), _ptr(rg), _ptr(ss), seqCounterBase),
                  "mm_reads_upload_packed")
         self._nreads = len(lens)
         return self.num_fragments()

@@ -168,6 +168,7 @@ int mm_stat_sketch_cutoffs(int sketchSize, int k, int hgFilter, int32_t* out, si
 struct ReadSource {
   const void* ascii = nullptr; bool onDevice = false;
   const uint32_t* b2 = nullptr; const uint32_t* nm = nullptr; const uint8_t* hasN = nullptr; const int32_t* lengths = nullptr;   // packed form
+  const int64_t* starts = nullptr;                     // packed form with gaps: packed base at which every read starts (multiples of 32, ascending)
   bool packed() const { return b2 != nullptr || lengths != nullptr; }
 };
 
@@ -188,6 +189,11 @@ static int upload_reads_common(mm_ctx* c, const ReadSource& S, const int64_t* re
     const int64_t len64 = packed ? (int64_t)S.lengths[r] : readOffsets[r + 1] - readOffsets[r];
     if (len64 < 0 || len64 > 0x7fffffff) { c->err = "mm_reads_upload: read length out of range (offset_t is int32, base_types.hpp:21)"; return MM_ERR_ARG; }
     const int32_t len = (int32_t)len64;
+    if (packed && S.starts) {                         // reads placed by the caller: gaps between them are allowed (and never read as bases)
+      const int64_t at = S.starts[r] - S.starts[0];
+      if (at < pk || (at & 31)) { c->err = "mm_reads_upload_packed: readStarts must be ascending multiples of 32 that leave room for every read"; return MM_ERR_ARG; }
+      pk = at;
+    }
     srcOff[r] = packed ? 0 : readOffsets[r]; packOff[r] = pk; rlen[r] = len;
     if (len >= k) {                                   // computeMap.hpp:325 (shorter reads are skipped)
       if (!split || len <= L) {                       // :587 -- with split off a read longer than segLength is ONE fragment (windowLen = len - segLength, :933)
@@ -282,10 +288,10 @@ int mm_reads_upload_device(mm_ctx* c, const void* dBases, size_t nBases, const i
   ReadSource S; S.ascii = dBases; S.onDevice = true;
   return upload_reads_common(c, S, readOffsets, nReads, g, s, base);
 }
-int mm_reads_upload_packed(mm_ctx* c, const uint32_t* bases2, const uint32_t* nmask, const uint8_t* readHasN, const int32_t* readLengths, size_t nReads,
-                           const int32_t* g, const int32_t* s, int32_t base) {
+int mm_reads_upload_packed(mm_ctx* c, const uint32_t* bases2, const uint32_t* nmask, const uint8_t* readHasN, const int32_t* readLengths, const int64_t* readStarts,
+                           size_t nReads, const int32_t* g, const int32_t* s, int32_t base) {
   static const int32_t none = 0;
-  ReadSource S; S.b2 = bases2; S.nm = nmask; S.hasN = readHasN; S.lengths = readLengths ? readLengths : &none;
+  ReadSource S; S.b2 = bases2; S.nm = nmask; S.hasN = readHasN; S.lengths = readLengths ? readLengths : &none; S.starts = nReads ? readStarts : nullptr;
   return upload_reads_common(c, S, nullptr, nReads, g, s, base);
 }
 size_t mm_pack_read(const char* ascii, size_t len, uint32_t* bases2, uint32_t* nmask) { return mmhost::pack2bit(ascii, len, bases2, nmask); }

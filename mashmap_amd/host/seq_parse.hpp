@@ -55,8 +55,11 @@ struct ParsedBatch {
   std::vector<int64_t> packOffs;     // size() + 1 entries
   std::vector<int32_t> lens;         // bases of every record (offs differences)
   std::vector<uint8_t> hasN;         // record holds a base that is not A C G T a c g t
+  int64_t maskBase = 0;              // the N mask words start behind maskBase / 4 bytes of code words (>= packedBases: the single-pass packer sizes the code area before it knows the records)
+  // packed base behind the last base (rounded up to 32) of record r1 - 1: where a block of records [r0, r1) ends (the next record may start later: gaps)
+  int64_t packEnd(size_t r0, size_t r1) const { return r1 > r0 ? packOffs[r1 - 1] + ((int64_t)lens[r1 - 1] + 31) / 32 * 32 : packOffs[r0]; }
   uint32_t* bases2() const { return (uint32_t*)bases; }
-  uint32_t* nmask() const { return (uint32_t*)(bases + packedBases / 4); }
+  uint32_t* nmask() const { return (uint32_t*)(bases + maskBase / 4); }
 };
 
 namespace detail {
@@ -414,7 +417,7 @@ class BatchReader {
     out.packOffs.assign(nRec + 1, 0); out.lens.assign(nRec, 0); out.hasN.assign(nRec, 0);
     int64_t pk = 0;
     for (size_t r = 0; r < nRec; r++) { const int64_t len = out.offs[r + 1] - out.offs[r]; out.lens[r] = (int32_t)len; out.packOffs[r] = pk; pk += (len + 31) / 32 * 32; }
-    out.packOffs[nRec] = pk; out.packedBases = pk;
+    out.packOffs[nRec] = pk; out.packedBases = pk; out.maskBase = pk;
     const size_t need = (size_t)pk / 4 + (size_t)pk / 8 + 64;
     if (need > out.cap) {
       if (out.bases) free_(out.bases);
@@ -435,8 +438,106 @@ class BatchReader {
     });
   }
 
+  // Packed batches in ONE pass over the window (the parser is bound by memory traffic: the two-pass form reads every byte twice).  Every
+  // thread takes its piece of the window and, record by record, finds the lines and packs them straight into the batch buffer, into a
+  // region of its own that starts where the piece's first byte would land plus some slack per thread -- a record's packed length is at
+  // most 28 bases more than its bytes in the file, so a region overflows only on pathological input (thousands of near-empty records),
+  // and then the window is redone by the two-pass path.  The regions leave gaps between them: mm_reads_upload_packed takes the
+  // reads' start positions (packOffs) as they are.
+  bool parseWindowPackedOnePass(const char* p, size_t n, ParsedBatch& out) {
+    const char* b = p; const char* e = p + n;
+    const unsigned T = (unsigned)std::min<size_t>(threads_, std::max<size_t>(1, n >> 16));
+    std::vector<const char*> cut(T + 1, e);
+    cut[0] = b;
+    const bool fasta = fasta_;
+    detail::run_parallel(pool_, T, [&](unsigned t) { if (t) cut[t] = detail::next_record(b, b + n / T * t, e, fasta); });
+    for (unsigned t = 1; t <= T; t++) if (cut[t] < cut[t - 1]) cut[t] = cut[t - 1];
+    const int64_t slack = 1 << 16;
+    std::vector<int64_t> G(T + 1);
+    for (unsigned t = 0; t <= T; t++) G[t] = (((int64_t)(cut[t] - b) + (int64_t)t * slack) + 31) / 32 * 32;
+    const size_t need = (size_t)G[T] / 4 + (size_t)G[T] / 8 + 64;
+    if (need > out.cap) {
+      if (out.bases) free_(out.bases);
+      out.bases = alloc_(need + (need >> 4) + 4096);
+      if (!out.bases) { std::cerr << "[mashmap_hip] out of host memory for a batch of " << G[T] << " packed bases" << std::endl; exit(1); }
+      out.cap = need + (need >> 4) + 4096;
+    }
+    out.maskBase = G[T];
+    uint32_t* b2 = out.bases2(); uint32_t* nm = out.nmask();
+    struct Lite { std::string name; int32_t len; uint8_t hasN; int64_t start; };
+    std::vector<std::vector<Lite>> recs(T);
+    std::atomic<int> overflow(0);
+    const bool mapped = src_ && src_->fileMapped();
+    detail::run_parallel(pool_, T, [&](unsigned t) {
+      const char* q = cut[t]; const char* pe = cut[t + 1];
+      if (mapped && pe > q) {
+        const uintptr_t a = (uintptr_t)q & ~(uintptr_t)4095, z = ((uintptr_t)pe + 4095) & ~(uintptr_t)4095;
+        (void)madvise((void*)a, (size_t)(z - a), 22 /* MADV_POPULATE_READ */);
+      }
+      auto& R = recs[t];
+      R.reserve((size_t)(pe - q) / 4096 + 16);
+      int64_t cur = G[t];
+      while (q < pe) {
+        const char* body = detail::next_line(q, e);
+        const char* hb = q + 1; const char* he = body > q && body[-1] == '\n' ? body - 1 : body;   // header line without its '\n'
+        if (he < hb) he = hb;
+        const char* sp = (const char*)memchr(hb, ' ', (size_t)(he - hb));
+        Lite r; r.name.assign(hb, sp ? sp : he); r.start = cur; r.len = 0; r.hasN = 0;
+        const bool keep = (keepPrefix_.empty() || r.name.compare(0, keepPrefix_.size(), keepPrefix_) == 0) && (keepSeq_.empty() || keepSeq_.count(r.name));
+        const char* end;
+        // room for the longest record this piece could still hold is not known in advance: stop at the region's end, line by line
+        Pack2bitStream st(b2 + cur / 16, nm + cur / 32);
+        int64_t len = 0; bool fits = true;
+        auto feed = [&](const char* l, size_t m) {
+          if (!keep || !m || !fits) return;
+          if (cur + (len + (int64_t)m + 31) / 32 * 32 > G[t + 1]) { fits = false; return; }
+          st.feed(l, m); len += (int64_t)m;
+        };
+        if (fasta) {
+          const char* l = body;
+          while (l < e && *l != '>') {
+            const char* nl = (const char*)memchr(l, '\n', (size_t)(e - l));
+            const char* le = nl ? nl : e;
+            feed(l, (size_t)(le - l));
+            l = nl ? nl + 1 : e;
+          }
+          end = l;
+        } else {
+          const char* nl = (const char*)memchr(body, '\n', (size_t)(e - body));
+          const char* le = nl ? nl : e;
+          if (body < e) feed(body, (size_t)(le - body));
+          end = detail::next_line(detail::next_line(nl ? nl + 1 : e, e), e);                       // '+' line and quality line skipped
+        }
+        if (!fits || len > 0x7fffffff) { overflow = 1; return; }
+        r.hasN = st.finish() ? 1 : 0; r.len = (int32_t)len;
+        cur += (len + 31) / 32 * 32;
+        R.push_back(std::move(r));
+        q = end;
+      }
+    });
+    if (overflow) return false;
+    size_t nRec = 0;
+    std::vector<size_t> first(T + 1, 0);
+    for (unsigned t = 0; t < T; t++) { first[t] = nRec; nRec += recs[t].size(); }
+    out.names.resize(nRec); out.offs.assign(nRec + 1, 0); out.packOffs.assign(nRec + 1, 0); out.lens.assign(nRec, 0); out.hasN.assign(nRec, 0);
+    detail::run_parallel(pool_, T, [&](unsigned t) {
+      for (size_t i = 0; i < recs[t].size(); i++) {
+        auto& r = recs[t][i]; const size_t ri = first[t] + i;
+        out.names[ri].swap(r.name); out.lens[ri] = r.len; out.hasN[ri] = r.hasN; out.packOffs[ri] = r.start;
+      }
+    });
+    int64_t at = 0;
+    for (size_t r = 0; r < nRec; r++) { out.offs[r] = at; at += out.lens[r]; }
+    out.offs[nRec] = at;
+    const int64_t endAt = nRec ? out.packOffs[nRec - 1] + ((int64_t)out.lens[nRec - 1] + 31) / 32 * 32 : 0;
+    out.packOffs[nRec] = endAt; out.packedBases = endAt;
+    out.packed = true;
+    return true;
+  }
+
   void parseWindow(const char* p, size_t n, ParsedBatch& out) {
     using detail::Rec;
+    if (packOutput_ && out.names.empty() && !getenv("MASHMAP_HIP_TWO_PASS_PACK") && parseWindowPackedOnePass(p, n, out)) return;
     const char* b = p; const char* e = p + n;
     const unsigned T = (unsigned)std::min<size_t>(threads_, std::max<size_t>(1, n >> 16));
     // piece t = records that start in [cut[t], cut[t+1])

@@ -264,7 +264,7 @@ class Map {
   void issuePrefetch(const Batch& b, size_t i, const std::vector<size_t>& cut) {
     mm_ctx* c = ctxs[i];
     if (b.in.packed) {
-      const int64_t o0 = b.in.packOffs[cut[i]], o1 = b.in.packOffs[cut[i + 1]];
+      const int64_t o0 = b.in.packOffs[cut[i]], o1 = b.in.packEnd(cut[i], cut[i + 1]);
       if (mm_reads_prefetch_packed(c, b.in.bases2() + o0 / 16, b.in.nmask() + o0 / 32, (size_t)(o1 - o0)) != MM_OK) die("mm_reads_prefetch_packed", c);
     } else {
       const int64_t o0 = b.in.offs[cut[i]], o1 = b.in.offs[cut[i + 1]];
@@ -319,7 +319,8 @@ class Map {
       const auto p0 = skch::Time::now();
       if (batch.in.packed) {
         const int64_t p0 = batch.in.packOffs[b];
-        if (mm_reads_upload_packed(c, batch.in.bases2() + p0 / 16, batch.in.nmask() + p0 / 32, batch.in.hasN.data() + b, batch.in.lens.data() + b, e - b,
+        if (mm_reads_upload_packed(c, batch.in.bases2() + p0 / 16, batch.in.nmask() + p0 / 32, batch.in.hasN.data() + b, batch.in.lens.data() + b,
+                                   batch.in.packOffs.data() + b, e - b,
                                    param.skip_prefix ? readGroup.data() + b : nullptr, param.skip_self ? readSelf.data() + b : nullptr,
                                    batch.firstSeqCounter + (seqno_t)b) != MM_OK) die("mm_reads_upload_packed", c);
       } else {

@@ -42,9 +42,10 @@ int main(int argc, char** argv) {
       if (!packed) for (int64_t i = b.offs[r]; i < b.offs[r + 1]; i++) { h ^= (unsigned char)b.bases[i]; h *= 1099511628211ull; }
       else {
         const int64_t len = b.offs[r + 1] - b.offs[r], p0 = b.packOffs[r];
-        if (b.lens[r] != len || p0 % 32 || b.packOffs[r + 1] - p0 != (len + 31) / 32 * 32) { printf("bad packed layout at record %zu\n", r); return 1; }
+        const int64_t span = (len + 31) / 32 * 32;                      // a record's own words; the next record may start later (gaps between the threads' pieces)
+        if (b.lens[r] != len || p0 % 32 || b.packOffs[r + 1] - p0 < span || b.packEnd(r, r + 1) != p0 + span) { printf("bad packed layout at record %zu\n", r); return 1; }
         bool anyN = false;
-        for (int64_t i = 0; i < b.packOffs[r + 1] - p0; i++) {
+        for (int64_t i = 0; i < span; i++) {
           const int64_t g = p0 + i;
           const unsigned code = (b.bases2()[g >> 4] >> (2 * (g & 15))) & 3u, isN = (b.nmask()[g >> 5] >> (g & 31)) & 1u;
           if (i >= len) { if (code || isN) { printf("padding not zero at record %zu\n", r); return 1; } continue; }

@@ -182,3 +182,16 @@ def test_packing_reader_encodes_the_normalised_sequences(exe, tmp_path, kind):
         assert p.returncode == 0, p.stdout[-300:] + p.stderr
         got = p.stdout.splitlines()
         assert got == want, (kind, window, threads, [x for x in zip(got, want) if x[0] != x[1]][:3])
+
+
+def test_packing_reader_falls_back_on_near_empty_records(exe, tmp_path):
+    """thousands of one-base records: their packed form (32 bases each) is larger than their bytes in the file, the single-pass packer's
+    regions overflow and the window is redone by the two-pass path -- same records either way"""
+    rs = [("t%d" % i, bytes([b"ACGTN"[i % 5]]) * (1 + i % 3)) for i in range(60000)] + [("big", U.random_dna(5, 200000).tobytes())]
+    path = str(tmp_path / "tiny.fa")
+    open(path, "wb").write(fasta_bytes(rs, 0))
+    want = ["%s\t%d\t%d" % (h, len(s), fnv(_normalise(s))) for h, s in rs]
+    for window, threads in ((1 << 40, 4), (200000, 8)):
+        p = subprocess.run([exe, str(window), str(threads), "--packed", path], capture_output=True, text=True)
+        assert p.returncode == 0, p.stdout[-300:] + p.stderr
+        assert p.stdout.splitlines() == want
