@@ -388,35 +388,49 @@ class Map {
         recBegin[r] = i;
       }
     }
-    std::vector<MappingResultsVector_t> perRead(nReads);
-    std::vector<std::string> text(nReads);
+    // per CHUNK of 64 consecutive reads, not per read: one text buffer, one result vector, one counter (a hundred thousand small
+    // allocations and frees per batch on this thread cost as much as the stage's work)
     const bool reportNow = param.filterMode != filter::ONETOONE;
+    const bool keepMaps = !reportNow || (bool)processMappingResults;
+    const size_t chunk = 64, nChunks = (nReads + chunk - 1) / chunk;
+    std::vector<std::string> chunkText(reportNow ? nChunks : 0);
+    std::vector<MappingResultsVector_t> chunkMaps(keepMaps ? nChunks : 0);
+    std::vector<int32_t> chunkMapped(nChunks, 0);
     const unsigned nThreads = (unsigned)std::max(1, param.threads);
     std::atomic<size_t> next(0);
     auto work = [&]() {
       std::ostringstream os;
-      const size_t chunk = 64;
-      for (size_t r0 = next.fetch_add(chunk); r0 < nReads; r0 = next.fetch_add(chunk))
-        for (size_t r = r0; r < std::min(nReads, r0 + chunk); r++) {
+      MappingResultsVector_t one;
+      for (size_t ci = next.fetch_add(1); ci < nChunks; ci = next.fetch_add(1)) {
+        os.str(std::string());
+        int mappedHere = 0;
+        for (size_t r = ci * chunk; r < std::min(nReads, (ci + 1) * chunk); r++) {
           const offset_t len = (offset_t)(batch.in.offs[r + 1] - batch.in.offs[r]);
           if (len < param.kmerSize || recBegin[r] == recBegin[r + 1]) continue;
-          post.mapModuleFromRecords(batch.recs.data() + recBegin[r], batch.recs.data() + recBegin[r + 1], len, perRead[r]);
-          if (reportNow && !perRead[r].empty()) { os.str(std::string()); post.reportReadMappings(perRead[r], batch.in.names[r], os); text[r] = os.str(); }
+          one.clear();
+          post.mapModuleFromRecords(batch.recs.data() + recBegin[r], batch.recs.data() + recBegin[r + 1], len, one);
+          if (one.empty()) continue;
+          mappedHere++;
+          if (reportNow) post.reportReadMappings(one, batch.in.names[r], os);
+          if (keepMaps) chunkMaps[ci].insert(chunkMaps[ci].end(), one.begin(), one.end());
         }
+        chunkMapped[ci] = mappedHere;
+        if (reportNow) chunkText[ci] = os.str();
+      }
     };
     if (!postPool || postPool->size() != nThreads) postPool.reset(new mmhost::WorkerPool(nThreads));   // persistent: a batch is milliseconds of work
     postPool->run(nThreads, [&](unsigned) { work(); });
     const auto t1 = skch::Time::now();
     size_t textBytes = 0;
-    if (reportNow) for (size_t r = 0; r < nReads; r++) textBytes += text[r].size();
+    for (const auto& t : chunkText) textBytes += t.size();
     std::string all;                                       // the batch's PAF text, input order, written with one call
     all.reserve(textBytes);
-    for (size_t r = 0; r < nReads; r++) {                  // mapModuleHandleOutput (:724-752), input order
-      if (!perRead[r].empty()) totalReadsMapped++;
-      if (!reportNow) allReadMappings.insert(allReadMappings.end(), perRead[r].begin(), perRead[r].end());
+    for (size_t ci = 0; ci < nChunks; ci++) {              // mapModuleHandleOutput (:724-752), input order
+      totalReadsMapped += chunkMapped[ci];
+      if (!reportNow) allReadMappings.insert(allReadMappings.end(), chunkMaps[ci].begin(), chunkMaps[ci].end());
       else {
-        all += text[r];
-        if (processMappingResults) for (const auto& e : perRead[r]) processMappingResults(e);
+        all += chunkText[ci];
+        if (processMappingResults) for (const auto& e : chunkMaps[ci]) processMappingResults(e);
       }
     }
     if (!all.empty()) outstrm.write(all.data(), (std::streamsize)all.size());

@@ -150,6 +150,19 @@ def test_packed_upload_equals_ascii_upload(oracle):
         assert p2.tobytes() == a2.tobytes() and pm.tobytes() == am.tobytes() and ph.tobytes() == ah.tobytes()
         sk_p, cnt_p = ctx.sketch()
         assert cnt_p.tobytes() == cnt_a.tobytes() and sk_p.tobytes() == sk_a.tobytes()
+    # gapped layout (the single-pass parser's threads leave gaps between their pieces): 96 garbage bases behind every read
+    groups = (lens.astype(np.int64) + 31) // 32 if False else (packed[3].astype(np.int64) + 31) // 32
+    cstart = np.concatenate([[0], np.cumsum(groups)])[:-1] * 32
+    gstart = cstart + np.arange(len(groups)) * 96
+    total = int(gstart[-1] + groups[-1] * 32 + 96)
+    g2 = np.full(total // 16, 0xFFFFFFFF, dtype=np.uint32); gm = np.full(total // 32, 0xFFFFFFFF, dtype=np.uint32)
+    for r in range(len(groups)):
+        n = int(groups[r])
+        g2[gstart[r] // 16:gstart[r] // 16 + 2 * n] = packed[0][cstart[r] // 16:cstart[r] // 16 + 2 * n]
+        gm[gstart[r] // 32:gstart[r] // 32 + n] = packed[1][cstart[r] // 32:cstart[r] // 32 + n]
+    assert ctx.reads_upload_packed((g2, gm, packed[2], packed[3]), seqCounterBase=40, starts=gstart + 640) == nF
+    sk_g, cnt_g = ctx.sketch()
+    assert cnt_g.tobytes() == cnt_a.tobytes() and sk_g.tobytes() == sk_a.tobytes(), "gapped packed layout"
     # a sub-block of the batch (what a context of a sharded run gets): words and mask from the block's first read on
     lens = packed[3]
     g0 = int(((lens[:3].astype(np.int64) + 31) // 32).sum())
