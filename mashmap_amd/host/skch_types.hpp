@@ -187,6 +187,7 @@ class HostBufferPool {
 // than the input needs, each no larger than the input.
 struct QueryBatchPlan { size_t batchBases; size_t bufferBytes; size_t buffers; uint64_t inputBytes; bool inputKnown; };
 inline QueryBatchPlan queryBatchPlan(const std::vector<std::string>& queryFiles, size_t nContexts) {
+  const bool packed = getenv("MASHMAP_HIP_ASCII_UPLOAD") == nullptr;   // the reader packs: a batch buffer holds 3/8 byte per base, not 1
   const char* be = getenv("MASHMAP_HIP_BATCH_MBP");
   QueryBatchPlan q;
   q.batchBases = (size_t)((be ? atof(be) : 512.0) * 1e6) * (nContexts ? nContexts : 1);
@@ -198,10 +199,12 @@ inline QueryBatchPlan queryBatchPlan(const std::vector<std::string>& queryFiles,
     if (FILE* fp = fopen(f.c_str(), "rb")) { unsigned char m[2] = {0, 0}; gz = fread(m, 1, 2, fp) == 2 && m[0] == 31 && m[1] == 139; fclose(fp); }
     q.inputBytes += (uint64_t)st.st_size * (gz ? 5u : 1u);           // DNA text deflates to between a fifth and a third
   }
-  const size_t full = q.batchBases + q.batchBases / 8 + (1u << 20);
+  const size_t ascii = q.batchBases + q.batchBases / 8 + (1u << 20);
+  const size_t full = packed ? (ascii + (2u << 20)) / 8 * 3 + (1u << 20) : ascii;      // locking pages costs ~0.2 s per GB: no more than needed
   if (!q.inputKnown) { q.bufferBytes = full; q.buffers = 8; return q; }
   const uint64_t batches = q.inputBytes / q.batchBases + 1;
-  q.bufferBytes = (size_t)std::min<uint64_t>(full, q.inputBytes + q.inputBytes / 8 + (1u << 20));
+  const uint64_t whole = q.inputBytes + q.inputBytes / 8 + (1u << 20);
+  q.bufferBytes = (size_t)std::min<uint64_t>(full, packed ? whole / 8 * 3 + (2u << 20) : whole);
   q.buffers = (size_t)std::min<uint64_t>(8, batches + 1);
   return q;
 }
