@@ -231,7 +231,7 @@ class MmapSource : public RawSource {
   ~MmapSource() override { if (!owned_) return; if (data_) munmap((void*)data_, size_); if (fd_ >= 0) close(fd_); }
   bool prefaulted() const { return !owned_; }
   bool ok() const { return fd_ >= 0; }
-  bool fileMapped() const override { return owned_; }               // a mapping from the cache is populated by its own threads
+  bool fileMapped() const override { return true; }                 // also for a mapping from the cache: its own threads may not have reached this window yet (populating populated pages is cheap)
   char first_byte() override { return size_ ? data_[0] : 0; }
   bool next(const char*& p, size_t& n, bool fasta, bool) override {
     if (pos_ >= size_) return false;

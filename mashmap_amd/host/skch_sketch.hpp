@@ -86,7 +86,7 @@ class Sketch {
       const QueryBatchPlan plan = queryBatchPlan(p.querySequences, ctxs_.size());
       HostBufferPool::instance().prefetch(plan.buffers, plan.bufferBytes);
       // ... and the query files' pages are mapped into this process meanwhile (seq_parse.hpp: MappedFileCache)
-      if (!getenv("MASHMAP_HIP_NO_PREFAULT")) mmhost::MappedFileCache::instance().prefault(p.querySequences, 4);
+      if (!getenv("MASHMAP_HIP_NO_PREFAULT")) mmhost::MappedFileCache::instance().prefault(p.querySequences, 8);
     }
     if (!p.saveIndexFilename.empty()) mm_set_option(ctx_, MM_OPT_KEEP_FULL_INDEX, 1);
     this->build();
