@@ -138,7 +138,7 @@ inline std::vector<int> sketchCutoffs(int sketchSize, int kmerSize, float ANIDif
   const float deltaANI = ANIDiff;
   const float min_p = 1 - ANIDiffConf;
   const int ss = (int)std::min<double>(sketchSize, fixed::ss_table_max);
-  if (threads == 0) threads = std::max(1u, std::thread::hardware_concurrency());
+  if (threads == 0) threads = std::max(1u, std::min(std::thread::hardware_concurrency(), (unsigned)ss / 16u + 1u));   // starting a thread costs more than a row of a small table
   // probs[ci][y] = pdf(y; ss, ss - ci, ci); cum[ci][y] = probs[ci][0] + ... + probs[ci][y] (summed upwards, as hypergeometricCdf does)
   std::vector<std::vector<double>> probs(ss + 1, std::vector<double>(ss + 1)), cum(ss + 1);
   auto parallel = [&](int n, const std::function<void(int)>& fn) {
@@ -186,7 +186,7 @@ inline std::vector<int> sketchCutoffs(int sketchSize, int kmerSize, float ANIDif
 // estimateMinimumHitsRelaxed for every Q.sketchSize 0..sketchSize (computeMap.hpp:1144), on host threads (each entry is an O(q^2) search)
 inline std::vector<int32_t> minHitsTable(int sketchSize, int kmerSize, float percentageIdentity, unsigned threads = 0) {
   std::vector<int32_t> mh((size_t)sketchSize + 1, 0);
-  if (threads == 0) threads = std::max(1u, std::thread::hardware_concurrency());
+  if (threads == 0) threads = std::max(1u, std::min(std::thread::hardware_concurrency(), (unsigned)sketchSize / 16u + 1u));
   std::atomic<int> next(sketchSize);                       // largest first: they take longest
   auto work = [&]() { for (int q = next.fetch_sub(1); q >= 1; q = next.fetch_sub(1)) mh[q] = Stat::estimateMinimumHitsRelaxed(q, kmerSize, percentageIdentity, fixed::confidence_interval); };
   std::vector<std::thread> pool;
@@ -207,6 +207,7 @@ inline void replayTables(int sketchSize, int k, float percentageIdentity, float 
   const size_t stride = (size_t)sketchSize + 1;
   accept.assign(stride * stride, 0); minIsz.assign(stride * stride, 0);
   if (threads < 1) threads = 1;
+  threads = std::min(threads, (unsigned)sketchSize / 16u + 1u);
   std::atomic<int> next(1);
   auto work = [&]() {
     for (int Qs = next.fetch_add(1); Qs <= sketchSize; Qs = next.fetch_add(1)) {

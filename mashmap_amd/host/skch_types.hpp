@@ -200,7 +200,7 @@ inline QueryBatchPlan queryBatchPlan(const std::vector<std::string>& queryFiles,
     q.inputBytes += (uint64_t)st.st_size * (gz ? 5u : 1u);           // DNA text deflates to between a fifth and a third
   }
   const size_t ascii = q.batchBases + q.batchBases / 8 + (1u << 20);
-  const size_t full = packed ? (ascii + (2u << 20)) / 8 * 3 + (1u << 20) : ascii;      // locking pages costs ~0.2 s per GB: no more than needed
+  const size_t full = (packed && !getenv("MASHMAP_HIP_BIG_BUFFERS")) ? (ascii + (2u << 20)) / 8 * 3 + (1u << 20) : ascii;      // locking pages costs ~0.2 s per GB: no more than needed
   if (!q.inputKnown) { q.bufferBytes = full; q.buffers = 8; return q; }
   const uint64_t batches = q.inputBytes / q.batchBases + 1;
   const uint64_t whole = q.inputBytes + q.inputBytes / 8 + (1u << 20);
