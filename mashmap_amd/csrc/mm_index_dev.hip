@@ -168,14 +168,13 @@ k_event_keys(size_t n, const mm_minmer* __restrict__ rec, uint64_t* __restrict__
 }
 __global__ void __launch_bounds__(256)
 k_event_fill(size_t nEv, const mm_minmer* __restrict__ rec, const uint64_t* __restrict__ key, const uint32_t* __restrict__ val, uint32_t* __restrict__ evKey,
-             uint32_t* __restrict__ evAux, uint64_t* __restrict__ evHash, uint32_t* __restrict__ evHi) {
+             uint32_t* __restrict__ evAux, uint64_t* __restrict__ evHash) {
   const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= nEv) return;
   const mm_minmer m = rec[val[e] >> 1];
   evKey[e] = (uint32_t)key[e];
   evAux[e] = (val[e] & 1u) ? 0u : ((uint32_t)m.wpos_end | (m.strand < 0 ? 0x80000000u : 0u));
   evHash[e] = m.hash;
-  evHi[e] = (uint32_t)(m.hash >> 32);
 }
 __global__ void k_contig_event_off(size_t nEv, const uint64_t* __restrict__ key, int nContigs, int64_t* __restrict__ off) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -338,7 +337,7 @@ int mm_flatten_device_index(mm_ctx* c, const mm_minmer* dRec, size_t n, size_t n
   const int maxLen = (int)hd[2];
   // ---- event stream
   const size_t nEv = 2 * n;
-  MM_HIP(c, I.evKey.ensure(nEv * 4 + 256)); MM_HIP(c, I.evAux.ensure(nEv * 4 + 256)); MM_HIP(c, I.evHash.ensure(nEv * 8 + 512)); MM_HIP(c, I.evHi.ensure(nEv * 4 + 256));
+  MM_HIP(c, I.evKey.ensure(nEv * 4 + 256)); MM_HIP(c, I.evAux.ensure(nEv * 4 + 256)); MM_HIP(c, I.evHash.ensure(nEv * 8 + 512));
   MM_HIP(c, I.contigOff.ensure((nContigs + 1) * 8));
   if (n) {
     DevBuf& k0 = *T.make(); DevBuf& k1 = *T.make(); DevBuf& v0 = *T.make(); DevBuf& v1 = *T.make();
@@ -347,7 +346,7 @@ int mm_flatten_device_index(mm_ctx* c, const mm_minmer* dRec, size_t n, size_t n
     // stable: equal keys keep minmerIndex order -- inserts at one position in index order, evictions in the order a stable sort by wpos_end gives
     int rc = sort_pairs(c, scratch, k0.as<uint64_t>(), k1.as<uint64_t>(), v0.as<uint32_t>(), v1.as<uint32_t>(), nEv, 0u, 32u + bits_for(nContigs));
     if (rc != MM_OK) return rc;
-    K_LAUNCH(k_event_fill, nEv, nEv, dRec, k1.as<uint64_t>(), v1.as<uint32_t>(), I.evKey.as<uint32_t>(), I.evAux.as<uint32_t>(), I.evHash.as<uint64_t>(), I.evHi.as<uint32_t>());
+    K_LAUNCH(k_event_fill, nEv, nEv, dRec, k1.as<uint64_t>(), v1.as<uint32_t>(), I.evKey.as<uint32_t>(), I.evAux.as<uint32_t>(), I.evHash.as<uint64_t>());
     hipLaunchKernelGGL(k_contig_event_off, dim3((unsigned)((nContigs + 1 + 255) / 256)), dim3(256), 0, c->stream, nEv, k1.as<uint64_t>(), nC, I.contigOff.as<int64_t>());
     MM_HIP(c, hipGetLastError());
     MM_HIP(c, hipStreamSynchronize(c->stream));

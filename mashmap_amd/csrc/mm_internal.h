@@ -47,7 +47,6 @@ struct DeviceIndex {
   DevBuf evKey;                // uint32 pos*2 + isInsert
   DevBuf evAux;                // uint32 insert: wpos_end | REV<<31 ; eviction: 0
   DevBuf evHash;               // uint64 hash of the record
-  DevBuf evHi;                 // uint32 its high word: what k_l2_locate streams (the full hash is fetched only on a tie with a query hash's high word)
   DevBuf contigOff;            // int64[nContigs+1] event offsets
   // records still open at every MM_OPEN_BLOCK-th position (wpos < B < wpos_end, index order), as insert events: the L2 pre-load of a
   // candidate starts from the list of its block instead of streaming a whole segLength of events (computeMap.hpp:1323-1338)

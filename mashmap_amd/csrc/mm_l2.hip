@@ -163,7 +163,7 @@ __global__ void __launch_bounds__(256)
 k_l2_locate(int cBase, int nCand, int64_t opsBase, int s, int NB, const mm_l1_candidate* __restrict__ l1, const mm_frag_stats* __restrict__ stats,
             const uint64_t* __restrict__ qHash, const int8_t* __restrict__ qStrand,
             const uint64_t* __restrict__ skHash, const int8_t* __restrict__ skStrand,
-            const uint32_t* __restrict__ evKey, const uint32_t* __restrict__ evAux, const uint64_t* __restrict__ evHash, const uint32_t* __restrict__ evHi,
+            const uint32_t* __restrict__ evKey, const uint32_t* __restrict__ evAux, const uint64_t* __restrict__ evHash,
             const uint32_t* __restrict__ opKey, const uint32_t* __restrict__ opAux, const uint64_t* __restrict__ opHash,
             const int64_t* __restrict__ contigOff, const L2Info* __restrict__ info, const int64_t* __restrict__ opOff,
             const int32_t* __restrict__ opCnt, uint32_t* __restrict__ ops, unsigned long long* __restrict__ counters /* [6] |= 4: gap too wide */) {
@@ -191,42 +191,33 @@ k_l2_locate(int cBase, int nCand, int64_t opsBase, int s, int NB, const mm_l1_ca
     for (int p = lane; p < S; p += 64) { const uint64_t h = srcH[p]; q[p] = h; qhi[p] = (uint32_t)(h >> 32); qs[p] = srcS[p]; }
     if (lane == 0) { q[S] = ~0ull; qhi[S] = ~0u; }                 // sentinel: a walk for h <= qmax needs no end test
     __threadfence_block();
-    // Everything below works on the HIGH WORDS of the hashes: an event of the slide costs 8 bytes of index (position + high word); the
-    // full 64-bit hash (and the record's end / strand word) are fetched only by the lanes that need them -- a high word that ties with
-    // a query hash's (every true match does, ~5 % of the events; chance ties ~1e-6), a pre-load record, a matching insert.
-    const uint32_t qmaxHi = qhi[S - 1];
-    // bucket(hh): monotone map of [0, qmaxHi] onto 0..NB-1: the top 24 significant bits times M >> 32, M <= 2^32 * NB / (top24(qmaxHi) + 1)
+    const uint64_t qmax = q[S - 1];
+    // bucket(h): monotone map of [0, qmax] onto 0..NB-1: the top 24 significant bits times M >> 32, M <= 2^32 * NB / (top24(qmax) + 1)
     // (any smaller M stays monotone and below NB; the float estimate is shaded down)
-    const int sh = qmaxHi ? (int)__builtin_clz(qmaxHi) : 31;
-    const uint32_t bM = (uint32_t)((float)NB * 4294967296.0f / ((float)((qmaxHi << sh) >> 8) + 1.0f) * 0.99999f);
-    auto bucket = [&](uint32_t hh) -> int { return (int)__umulhi((hh << sh) >> 8, bM); };
-    // bkt[b] = #{p : bucket(qhi[p]) < b}.  q is sorted, so entry p owns the buckets (bucket(q[p-1]), bucket(q[p])] and the
+    const int sh = qmax ? (int)__builtin_clzll(qmax) : 63;
+    const uint32_t bM = (uint32_t)((float)NB * 4294967296.0f / ((float)(uint32_t)((qmax << sh) >> 40) + 1.0f) * 0.99999f);
+    auto bucket = [&](uint64_t h) -> int { return (int)__umulhi((uint32_t)((h << sh) >> 40), bM); };
+    // bkt[b] = #{p : bucket(q[p]) < b}.  q is sorted, so entry p owns the buckets (bucket(q[p-1]), bucket(q[p])] and the
     // sentinel p = S owns the rest up to NB: a scatter of ~NB/S stores per lane instead of NB + 1 binary searches
     for (int p0 = 0; p0 <= S; p0 += 64) {
       const int p = p0 + lane;
       if (p <= S) {
-        const int from = p == 0 ? 0 : bucket(qhi[p - 1]) + 1;
-        const int to = p == S ? NB : bucket(qhi[p]);
+        const int from = p == 0 ? 0 : bucket(q[p - 1]) + 1;
+        const int to = p == S ? NB : bucket(q[p]);
         for (int b = from; b <= to; b++) bkt[b] = (uint16_t)p;
       }
     }
     __threadfence_block();
-    // 1-based lower_bound of the hash with high word hh in the sketch (+ match bit + query strand), 0 if it lies beyond the last query
-    // hash; `full()` loads the 64-bit hash, called only on a tie of the high words
-    auto locate = [&](uint32_t hh, auto&& full) -> uint32_t {
-      if (hh > qmaxHi) return 0u;
-      // everything in earlier buckets is smaller and hh <= qmaxHi < sentinel, so the walk from the bucket's first entry ends by itself:
-      // four entries per step, counted while they stay below hh (the entries behind the sentinel are never counted)
-      int lo = bkt[bucket(hh)];
-      for (;;) {
-        const bool c0 = qhi[lo] < hh, c1 = c0 && qhi[lo + 1] < hh, c2 = c1 && qhi[lo + 2] < hh, c3 = c2 && qhi[lo + 3] < hh;
-        lo += (int)c0 + (int)c1 + (int)c2 + (int)c3;
-        if (!c3) break;
-      }
-      bool match = false;
-      if (qhi[lo] == hh) { const uint64_t h = full(); while (q[lo] < h) lo++; match = q[lo] == h; }
-      if (lo >= S) return 0u;                                      // a tie with the last query hash's high word, but larger than it
-      return (uint32_t)(lo + 1) | (match ? (1u << EF<JB>::MATCH_BIT) : 0u) | ((uint32_t)((int)qs[lo] + 1) << EF<JB>::VOTE_SHIFT);   // query strand + 1
+    auto locate = [&](uint64_t h) -> uint32_t {
+      if (h > qmax) return 0u;
+      const int b = bucket(h);
+      // lower_bound(q, h): everything in earlier buckets is smaller and h <= qmax < sentinel, so the walk from the bucket's first entry
+      // ends by itself; it runs on the 32-bit high words (32-bit LDS reads and compares) and only a tie there looks at all 64 bits
+      int lo = bkt[b];
+      const uint32_t hh = (uint32_t)(h >> 32);
+      while (qhi[lo] < hh) lo++;
+      if (qhi[lo] == hh) { while (q[lo] < h) lo++; }
+      return (uint32_t)(lo + 1) | (q[lo] == h ? (1u << EF<JB>::MATCH_BIT) : 0u) | ((uint32_t)((int)qs[lo] + 1) << EF<JB>::VOTE_SHIFT);   // query strand + 1
     };
     // the slide ends with the last insert at or before rangeEnd (evictions behind it are never reached, :1340)
     int lastRel = -1;                                              // index of that insert relative to e0
@@ -258,28 +249,21 @@ k_l2_locate(int cBase, int nCand, int64_t opsBase, int s, int NB, const mm_l1_ca
       const int i = iAll - nOpen;
       const bool inPre = inOpen || i < in.nPre;
       const bool live = inPre ? true : i < nEv;
-      uint32_t key = 0, aux = 0, hh = 0;
+      uint32_t key = 0, aux = 0; uint64_t h = 0;
       if (live) {
-        if (inOpen) { key = opKey[in.open0 + iAll]; aux = opAux[in.open0 + iAll]; hh = (uint32_t)(opHash[in.open0 + iAll] >> 32); }
-        else { key = evKey[in.e0 + i]; hh = evHi[in.e0 + i]; if (inPre) aux = evAux[in.e0 + i]; }
+        if (inOpen) { key = opKey[in.open0 + iAll]; aux = opAux[in.open0 + iAll]; h = opHash[in.open0 + iAll]; }
+        else { key = evKey[in.e0 + i]; aux = evAux[in.e0 + i]; h = evHash[in.e0 + i]; }
       }
       const bool isIns = (key & 1u) != 0;
       const int pos = (int)(key >> 1);
       uint32_t op = 0; bool keep = false, evalIns = false;
       if (live) {
-        auto full = [&]() -> uint64_t { return inOpen ? opHash[in.open0 + iAll] : evHash[in.e0 + i]; };
         if (inPre) keep = isIns && (int)(aux & 0x7fffffffu) > cand.rangeStartPos && pos >= in.target;   // still open at rangeStart (:1323-1338)
-        else keep = isIns || hh <= qmaxHi;                                              // an eviction outside the sketch's range changes nothing
+        else keep = isIns || h <= qmax;                                                 // an eviction outside the sketch's range changes nothing
         if (keep) {
-          op = locate(hh, full);
-          if (!isIns && op == 0u) keep = false;                                         // (an eviction whose high word ties with the last query hash's, but beyond it)
-        }
-        if (keep) {
+          op = locate(h);
           // vote of a matching insert = query strand x reference strand: a REV record (aux bit 31) mirrors the field around 1
-          if (isIns && (op >> EF<JB>::MATCH_BIT & 1u)) {
-            if (!inPre) aux = evAux[in.e0 + i];
-            if (aux >> 31) op = (op & ~(3u << EF<JB>::VOTE_SHIFT)) | ((2u - ((op >> EF<JB>::VOTE_SHIFT) & 3u)) << EF<JB>::VOTE_SHIFT);
-          }
+          if (isIns && (aux >> 31)) op = (op & ~(3u << EF<JB>::VOTE_SHIFT)) | ((2u - ((op >> EF<JB>::VOTE_SHIFT) & 3u)) << EF<JB>::VOTE_SHIFT);
           op |= 1u << (inPre ? E_PRE_BIT : (isIns ? E_INS_BIT : E_DEL_BIT));
           evalIns = !inPre && isIns;
         }
@@ -944,7 +928,7 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt) {
       hipLaunchKernelGGL(kern, dim3(blocks), dim3(wpb * 64), ldsLoc, c->stream, ch.c0, ch.n, ch.base, s, NB, c->dL1.as<mm_l1_candidate>(),
                          c->dStats.as<mm_frag_stats>(), c->dQHash.as<uint64_t>(), c->dQStrand.as<int8_t>(), c->dSkHash.as<uint64_t>(), c->dSkStrand.as<int8_t>(),
                          I.evKey.as<uint32_t>(),
-                         I.evAux.as<uint32_t>(), I.evHash.as<uint64_t>(), I.evHi.as<uint32_t>(), I.opKey.as<uint32_t>(), I.opAux.as<uint32_t>(), I.opHash.as<uint64_t>(),
+                         I.evAux.as<uint32_t>(), I.evHash.as<uint64_t>(), I.opKey.as<uint32_t>(), I.opAux.as<uint32_t>(), I.opHash.as<uint64_t>(),
                          I.contigOff.as<int64_t>(),
                          c->dL2Info.as<L2Info>(), c->dL2Off.as<int64_t>(), c->dL2Cnt.as<int32_t>(), c->dL2Ops.as<uint32_t>(), cnt);
     };
