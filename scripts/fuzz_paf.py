@@ -12,7 +12,7 @@ seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 bad = 0
 td = tempfile.mkdtemp()
 for it in range(n_iter):
-    r = U.splitmix64(seed0 * 104729 + it, 24)
+    r = U.splitmix64(seed0 * 104729 + it, 28)
     pick = lambda i, xs: xs[int(r[i] % np.uint64(len(xs)))]
     L = pick(0, [1000, 2000, 5000, 5000, 10000])
     nct = pick(1, [1, 2, 4])
@@ -39,6 +39,8 @@ for it in range(n_iter):
     args += pick(16, [[], [], ["-M"], ["-K"], ["--noHgFilter"], ["--legacy"], ["--reportPercentage"], ["--filterLengthMismatches"]])
     args += pick(17, [[], [], ["-l", str(2 * L)], ["-c", str(3 * L)], ["--kmerThreshold", "0.5"], ["-k", "16"], ["--hgFilterAniDiff", "1"]])
     if allvsall: args += pick(18, [["-Y", "#"], ["-X"], ["-X", "--lowerTriangular"], []])
+    args += pick(21, [[], [], [], ["--noSplit"]])           # reads longer than a segment as one fragment (windowLen != 0)
+    if pick(22, [0, 0, 0, 0, 1]): args += ["--dense", "--pi", "80"] if "--dense" not in args and "-J" not in args else []
     rf = os.path.join(td, "r%d.fa" % it); U.write_fasta(rf, list(zip(names, cs)))
     base = ["-r", rf, "-t", "4"] + args
     if qrec is not None:
@@ -48,6 +50,8 @@ for it in range(n_iter):
     for tag, exe in (("hip", HIP), ("ref", U.REF_BIN)):
         env = dict(os.environ)
         if tag == "hip" and shard: env["MASHMAP_HIP_DEVICES"] = shard; env["MASHMAP_HIP_BATCH_MBP"] = pick(20, ["512", "0.04", "0.2"])
+        if tag == "hip" and pick(23, [0, 0, 1]): env["MM_SEED_TAGS"] = "1"                       # the human-scale seed table layout forced onto the small index
+        if tag == "hip" and pick(23, [0, 1, 0]): env["MASHMAP_HIP_ASCII_UPLOAD"] = "1"           # the ASCII upload path instead of the packing parser
         p = subprocess.run([exe] + base + ["-o", os.path.join(td, tag + ".paf")], capture_output=True, text=True, env=env)
         outs[tag] = (p.returncode, open(os.path.join(td, tag + ".paf"), "rb").read() if p.returncode == 0 else p.stderr[-300:])
     ok = outs["hip"][0] == 0 and outs["ref"][0] == 0 and outs["hip"][1] == outs["ref"][1]
