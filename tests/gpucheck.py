@@ -134,7 +134,8 @@ def fuzz_scenario(seed0, it):
     if s > (L - k) // 4: s = max(5, (L - k) // 8)
     pi = pick(3, [0.80, 0.85, 0.85, 0.90, 0.95])
     err = pick(4, [0.0, 0.02, 0.05, 0.10, 0.15])
-    flags = pick(5, [U.FLAG_HG, U.FLAG_HG, 0, U.FLAG_HG | U.FLAG_SKIP_SELF, U.FLAG_HG | U.FLAG_LOWER_TRI])
+    flags = pick(5, [U.FLAG_HG, U.FLAG_HG, 0, U.FLAG_HG | U.FLAG_SKIP_SELF, U.FLAG_HG | U.FLAG_LOWER_TRI] +
+                 ([U.FLAG_HG | U.FLAG_NOSPLIT, U.FLAG_NOSPLIT, U.FLAG_HG | U.FLAG_NOSPLIT | U.FLAG_SKIP_SELF] if seed0 >= 20 else []))   # campaigns from seed 20 on: --noSplit (windowLen != 0)
     nct = pick(6, [1, 2, 3, 5])
     shape = pick(7, ["random", "random", "repeat", "tandem", "nruns", "dup"])
     kmerPct = pick(8, [0.001, 0.001, 0.0, 0.5])
