@@ -17,10 +17,10 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_BUSY_CYCLES"):
     if not os.path.exists(fn):
         continue
     for row in csv.DictReader(open(fn)):
-        name = row["kernel"].replace("void ", "").split("<")[0]
-        if "; true>" in row["kernel"]:                      # k_l2_sweep<true> is the wide pass
-            name += "_hard"
-        if row["kernel"].endswith("<true>"):
+        full = row["kernel"].replace("void ", "")
+        name = full.split("<")[0]
+        targs = full[len(name) + 1:].rstrip(">").replace(";", ",").split(",") if "<" in full else []
+        if name == "k_l2_sweep" and targs and targs[0].strip() == "true":      # k_l2_sweep<true, JB, LPW> is the wide-cell pass
             name += "_wide"
         d = out.setdefault(name, {})
         # several instantiations of one template (k_lookup_l1<128> / <512>): keep the one with more dispatches' worth of traffic
