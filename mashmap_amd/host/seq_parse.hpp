@@ -17,6 +17,7 @@
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <sched.h>
 #include <unistd.h>
 #include <zlib.h>
 
@@ -40,6 +41,32 @@
 #include "pack2bit.hpp"
 
 namespace mmhost {
+
+// CPUs this process may actually use at once: the smaller of the hardware threads, the affinity mask and the container's CPU quota
+// (cgroup v2 cpu.max, v1 cpu.cfs_quota_us / cpu.cfs_period_us).  A container that shows 256 hardware threads and is given 16 CPUs'
+// worth of time per 100 ms period *throttles* a process that runs more threads than that: every thread of it, the one that feeds the
+// GPU included, stands still until the period ends (tens of milliseconds per burst -- profiles/r05b_*).  Stage widths are capped by
+// this number.  MASHMAP_HIP_CPUS overrides.
+inline unsigned availableCpus() {
+  static const unsigned n = [] {
+    if (const char* e = getenv("MASHMAP_HIP_CPUS")) { const int v = atoi(e); if (v > 0) return (unsigned)v; }
+    unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) { const int c = CPU_COUNT(&set); if (c > 0) hw = std::min(hw, (unsigned)c); }
+    double quota = -1, period = -1;
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+      char q[64] = {0};
+      if (fscanf(f, "%63s %lf", q, &period) == 2 && strcmp(q, "max") != 0) quota = atof(q);
+      fclose(f);
+    } else {
+      if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%lf", &quota) != 1) quota = -1; fclose(g); }
+      if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%lf", &period) != 1) period = -1; fclose(g); }
+    }
+    if (quota > 0 && period > 0) hw = std::min(hw, (unsigned)std::max(1.0, quota / period + 0.5));
+    return hw;
+  }();
+  return n;
+}
 
 struct ParsedBatch {
   std::vector<std::string> names;

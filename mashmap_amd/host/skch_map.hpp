@@ -23,6 +23,7 @@
 // MASHMAP_HIP_EXCHANGE=allgather puts the device-side all-gatherv (mm_allgatherv_mappings_local, RCCL over xGMI) in front instead.
 #pragma once
 #include <malloc.h>
+#include <sys/mman.h>
 
 #include <algorithm>
 #include <atomic>
@@ -124,7 +125,7 @@ class Map {
     std::vector<int32_t> cut32(cut.begin(), cut.end());
     std::vector<uint8_t> accept; std::vector<int16_t> minIsz;
     mmhost::replayTables(p.sketchSize, p.kmerSize, p.percentageIdentity, p.ANIDiff, p.keep_low_pct_id,
-                         std::max(1u, std::max((unsigned)std::max(1, p.threads), std::thread::hardware_concurrency())), accept, minIsz);
+                         mmhost::availableCpus(), accept, minIsz);
     for (mm_ctx* c : ctxs) {
       if (mm_set_tables(c, minHits.data(), minHits.size(), cut32.data(), cut32.size()) != MM_OK) die("mm_set_tables", c);
       if (mm_set_replay_tables(c, accept.data(), minIsz.data(), (size_t)p.sketchSize + 1) != MM_OK) die("mm_set_replay_tables", c);
@@ -167,13 +168,34 @@ class Map {
     packedUpload = getenv("MASHMAP_HIP_ASCII_UPLOAD") == nullptr;
     earlyPrefetch = getenv("MASHMAP_HIP_NO_EARLY_PREFETCH") == nullptr;
     slotFree.assign(ctxs.size(), earlyPrefetch ? 1 : 0);
+    // diagnostic (MASHMAP_HIP_STALL_TRACE=1): a thread that sleeps 0.5 ms at a time and reports when the sleep, a one-page mmap/munmap
+    // (address-space lock) or a first touch of a fresh page took more than 3 ms -- tells a process-wide stall (scheduler, CPU quota)
+    // from a lock inside the process when the stage timings show all three stages pausing at once
+    std::atomic<bool> stallStop{false};
+    std::thread stallTrace;
+    if (getenv("MASHMAP_HIP_STALL_TRACE")) stallTrace = std::thread([&]() {
+      while (!stallStop) {
+        const auto a = skch::Time::now();
+        std::this_thread::sleep_for(std::chrono::microseconds(500));
+        const auto b = skch::Time::now();
+        void* q = mmap(nullptr, 4096, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        const auto c = skch::Time::now();
+        if (q != MAP_FAILED) { *(volatile char*)q = 1; }
+        const auto d = skch::Time::now();
+        if (q != MAP_FAILED) munmap(q, 4096);
+        const auto e = skch::Time::now();
+        auto sec = [](skch::Time::time_point x, skch::Time::time_point y) { return std::chrono::duration<double>(y - x).count(); };
+        if (sec(a, e) > 0.0035)
+          std::cerr << "[mashmap_hip::stall] sleep " << sec(a, b) << " mmap " << sec(b, c) << " touch " << sec(c, d) << " munmap " << sec(d, e) << at() << std::endl;
+      }
+    });
     std::thread reader([&]() {
       // multi-threaded ingest (seq_parse.hpp): a window of the file per batch, parsed straight into a page-locked buffer.  8 workers:
       // memchr + memcpy at that width keep up with the device stage, and more of them page-faulting through the same file mapping next
       // to the post stage's threads stall each other for tens of milliseconds at a time (profiles/r03d_e2e_thread_sweep.txt: 32 reader
       // threads 18 Gbp/s end to end, 8 threads 24-26)
       const char* rte = getenv("MASHMAP_HIP_READER_THREADS");
-      const unsigned readerThreads = rte ? (unsigned)std::max(1, atoi(rte)) : (unsigned)std::min(12, std::max(1, param.threads));
+      const unsigned readerThreads = rte ? (unsigned)std::max(1, atoi(rte)) : std::min((unsigned)std::min(12, std::max(1, param.threads)), std::max(1u, mmhost::availableCpus() * 3 / 4));
       mmhost::BatchReader rd(param.querySequences, batchBases, readerThreads, {}, "",
                              [](size_t n) {                       // only when the pool (skch_sketch.hpp) has run dry
                                const auto t0 = skch::Time::now();
@@ -229,6 +251,7 @@ class Map {
     }
     reader.join();
     poster.join();
+    stallStop = true; if (stallTrace.joinable()) stallTrace.join();
     HostBufferPool::instance().stop();                      // nobody asks for page-locked buffers any more
 
     if (param.filterMode == filter::ONETOONE) {            // :358-406
@@ -396,7 +419,10 @@ class Map {
     std::vector<std::string> chunkText(reportNow ? nChunks : 0);
     std::vector<MappingResultsVector_t> chunkMaps(keepMaps ? nChunks : 0);
     std::vector<int32_t> chunkMapped(nChunks, 0);
-    const unsigned nThreads = (unsigned)std::max(1, param.threads);
+    // no wider than the CPUs the process may use (a container's quota: seq_parse.hpp availableCpus) -- more threads than that do not
+    // finish the batch sooner, they get the whole process throttled
+    const char* pte = getenv("MASHMAP_HIP_POST_THREADS");
+    const unsigned nThreads = pte ? (unsigned)std::max(1, atoi(pte)) : std::min((unsigned)std::max(1, param.threads), mmhost::availableCpus());
     std::atomic<size_t> next(0);
     auto work = [&]() {
       std::ostringstream os;

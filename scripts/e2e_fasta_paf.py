@@ -63,7 +63,7 @@ def main():
         out_s = sum(float(x) for x in re.findall(r", output ([0-9.eE+-]+) s", p.stderr))
         read_s = sum(float(x) for x in re.findall(r"reader: parsed .*? in ([0-9.eE+-]+) s", p.stderr))
         cur = dict(map_s=tmap, index_s=tidx, wall_s=wall, device_stage_s=dev_s, post_stage_s=post_s, output_s=out_s, reader_s=read_s)
-        print("\n".join(l for l in p.stderr.splitlines() if "timing" in l or "time spent" in l), file=sys.stderr)
+        print("\n".join(l for l in p.stderr.splitlines() if "timing" in l or "time spent" in l or "stall" in l), file=sys.stderr)
         if best is None or tmap < best["map_s"]:
             best = cur
     nlines = sum(1 for _ in open(op, "rb"))
