@@ -92,6 +92,20 @@ struct MMStrip {
 };
 
 __device__ __forceinline__ uint32_t mm_lane() { return threadIdx.x & 63u; }
+// Lane masks straight from the compare (llvm.amdgcn.icmp: one v_cmp_*_e64 into an SGPR pair; inactive lanes read 0) and a 64-bit select on
+// such a mask as two VOP3 v_cndmask.  cmp + two selects issue in 12.3 cycles this way against 16.3 in the vcc / VOP2 form the compiler picks
+// for `a < b ? a : b` (profiles/r02_valu_rate.txt), and a test that is only ever used as a mask never becomes a 0/1 register first.
+#define MM_ICMP_NE 33
+#define MM_ICMP_ULT 36
+__device__ __forceinline__ uint64_t mm_mask_lt64(uint64_t a, uint64_t b) { return __builtin_amdgcn_uicmpl(a, b, MM_ICMP_ULT); }
+__device__ __forceinline__ uint64_t mm_mask_ne64(uint64_t a, uint64_t b) { return __builtin_amdgcn_uicmpl(a, b, MM_ICMP_NE); }
+__device__ __forceinline__ uint64_t mm_mask_nz32(uint32_t a) { return __builtin_amdgcn_uicmp(a, 0u, MM_ICMP_NE); }
+__device__ __forceinline__ uint64_t mm_mask_select64(uint64_t mask, uint64_t a, uint64_t b) {    // this lane's bit of mask ? a : b
+  uint32_t lo, hi;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(lo) : "v"((uint32_t)b), "v"((uint32_t)a), "s"(mask));
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(hi) : "v"((uint32_t)(b >> 32)), "v"((uint32_t)(a >> 32)), "s"(mask));
+  return ((uint64_t)hi << 32) | lo;
+}
 __device__ __forceinline__ uint32_t mm_popc_below(uint64_t mask) {    // set bits of mask strictly below this lane
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }

@@ -424,7 +424,7 @@ mm_sketch_fast(unsigned char* smem, const int f, const uint4* __restrict__ gTabs
   // ---- phase 1: hash both strands of every k-mer ----
   const uint32_t qBase = (uint32_t)(tid >> 6) * (uint32_t)QC, qEnd = qBase + (uint32_t)QC;
   uint32_t qHead = qBase;                           // wave-uniform (only ballots feed it)
-  const bool allPass = (T == MM_HASH_MAX);
+  const uint64_t allPassM = (T == MM_HASH_MAX) ? ~0ull : 0ull;     // wave-uniform
   for (int strip = tid; strip < nStrips; strip += nthr) {
     const int b0 = strip * SL;                      // first base of the strip: the 48-base window is cut out of four LDS words
     const int wi = b0 >> 4, bsh = (b0 & 15) * 2;
@@ -444,12 +444,12 @@ mm_sketch_fast(unsigned char* smem, const int f, const uint4* __restrict__ gTabs
     }
     mm_strip_hashes<K, SL>(w0, w1, w2, *tabs, [&](int j, uint64_t hf, uint64_t hr) {
       const int pos = b0 + j;
-      const uint64_t h = hf < hr ? hf : hr;
-      bool pass = false;                            // nested ifs: the compiler keeps the three tests as exec masks
-      if ((ok & (1u << j)) != 0) { if (hf != hr) { if (allPass || h < T) pass = true; } }
-      const uint64_t m = __builtin_amdgcn_ballot_w64(pass);
+      // the tests as lane masks in scalar registers (mm_device.h): nothing but the two selects of the minimum touches a vector register
+      const uint64_t mLt = mm_mask_lt64(hf, hr);
+      const uint64_t h = mm_mask_select64(mLt, hf, hr);
+      const uint64_t m = mm_mask_nz32(ok & (1u << j)) & mm_mask_ne64(hf, hr) & (mm_mask_lt64(h, T) | allPassM);
       const uint32_t idx = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, qHead));
-      if (pass && idx < qEnd) { qH[idx] = h; qM[idx] = ((uint32_t)pos << 1) | (hf < hr ? 1u : 0u); }
+      if (__builtin_amdgcn_inverse_ballot_w64(m) && idx < qEnd) { qH[idx] = h; qM[idx] = ((uint32_t)pos << 1) | (__builtin_amdgcn_inverse_ballot_w64(mLt) ? 1u : 0u); }
       qHead += (uint32_t)__popcll(m);
     });
   }
@@ -615,7 +615,7 @@ k_hash_only(const uint4* __restrict__ gTabs, const uint32_t* __restrict__ bases2
       const uint32_t w3 = sW[wi + 3];
       if (bsh) { w0 = __builtin_amdgcn_alignbit(w1, w0, bsh); w1 = __builtin_amdgcn_alignbit(w2, w1, bsh); w2 = __builtin_amdgcn_alignbit(w3, w2, bsh); }
     }
-    mm_strip_hashes<K, SL>(w0, w1, w2, *tabs, [&](int j, uint64_t hf, uint64_t hr) { acc += hf < hr ? hf : hr; });
+    mm_strip_hashes<K, SL>(w0, w1, w2, *tabs, [&](int j, uint64_t hf, uint64_t hr) { acc += mm_mask_select64(mm_mask_lt64(hf, hr), hf, hr); });
   }
   if (acc == 0x9E3779B97F4A7C15ull) sink[0] = acc;
 }
