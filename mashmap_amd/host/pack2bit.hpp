@@ -7,11 +7,12 @@
 // the FASTA parser touches every base once while it drops the line breaks -- can ship 0.375 bytes per base over PCIe instead of 1
 // (mm_reads_upload_packed).  Bit-identical to k_pack2bit for every byte value 0..255 (tests/test_pack2bit.py, tests/test_gpu_sketch.py).
 //
-// AVX2 + BMI2 where the CPU has them (32 bases per step: compare against the four letters, two movemasks, two pdeps), a plain loop
-// otherwise; chosen at run time.
+// AVX-512BW + BMI2 (64 bases per step) or AVX2 + BMI2 (32 bases per step: compare against the four letters, movemasks, pdeps) where the
+// CPU has them, a plain loop otherwise; chosen at run time.
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #if defined(__x86_64__)
 #include <immintrin.h>
@@ -71,15 +72,46 @@ static inline size_t pack2bit_avx2(const char* ascii, size_t n, uint32_t* bases2
   }
   return nN;
 }
-static inline bool pack2bit_have_avx2() {
-  static const bool have = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2");
-  return have;
+// AVX-512BW: the four compares of 64 bases come back as 64-bit masks (no movemask), four pdeps spread them into the code words
+__attribute__((target("avx512f,avx512bw,bmi2")))
+static inline size_t pack2bit_avx512(const char* ascii, size_t n, uint32_t* bases2, uint32_t* nmask) {
+  const unsigned char* s = (const unsigned char*)ascii;
+  const __m512i up = _mm512_set1_epi8((char)0xDF), cA = _mm512_set1_epi8('A'), cC = _mm512_set1_epi8('C'), cG = _mm512_set1_epi8('G'), cT = _mm512_set1_epi8('T');
+  size_t nN = 0;
+  const size_t full = n / 64;
+  for (size_t g = 0; g < full; g++) {
+    const __m512i b = _mm512_and_si512(_mm512_loadu_si512((const void*)(s + g * 64)), up);
+    const uint64_t isA = _mm512_cmpeq_epi8_mask(b, cA), isC = _mm512_cmpeq_epi8_mask(b, cC), isG = _mm512_cmpeq_epi8_mask(b, cG), isT = _mm512_cmpeq_epi8_mask(b, cT);
+    const uint64_t b0 = isC | isT, b1 = isG | isT, m = ~(isA | b0 | isG);
+    const uint64_t c0 = _pdep_u64(b0 & 0xFFFFFFFFull, 0x5555555555555555ull) | _pdep_u64(b1 & 0xFFFFFFFFull, 0xAAAAAAAAAAAAAAAAull);
+    const uint64_t c1 = _pdep_u64(b0 >> 32, 0x5555555555555555ull) | _pdep_u64(b1 >> 32, 0xAAAAAAAAAAAAAAAAull);
+    memcpy(bases2 + 4 * g, &c0, 8); memcpy(bases2 + 4 * g + 2, &c1, 8); memcpy(nmask + 2 * g, &m, 8);
+    nN += (size_t)__builtin_popcountll(m);
+  }
+  if (n % 64) nN += pack2bit_avx2(ascii + full * 64, n % 64, bases2 + 4 * full, nmask + 2 * full);
+  return nN;
+}
+// 0 portable loop, 1 AVX2 + BMI2, 2 AVX-512BW + BMI2: the widest the CPU has; MASHMAP_HIP_PACK_ISA=scalar|avx2|avx512 narrows it (tests)
+static inline int pack2bit_isa() {
+  static const int isa = [] {
+    int best = 0;
+    if (__builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2")) best = 1;
+    if (best == 1 && __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw")) best = 2;
+    if (const char* e = getenv("MASHMAP_HIP_PACK_ISA")) {
+      const int want = !strcmp(e, "scalar") ? 0 : !strcmp(e, "avx2") ? 1 : !strcmp(e, "avx512") ? 2 : best;
+      if (want < best) best = want;
+    }
+    return best;
+  }();
+  return isa;
 }
 #endif
 
 static inline size_t pack2bit(const char* ascii, size_t n, uint32_t* bases2, uint32_t* nmask) {
 #if defined(__x86_64__)
-  if (pack2bit_have_avx2()) return pack2bit_avx2(ascii, n, bases2, nmask);
+  const int isa = pack2bit_isa();
+  if (isa == 2) return pack2bit_avx512(ascii, n, bases2, nmask);
+  if (isa == 1) return pack2bit_avx2(ascii, n, bases2, nmask);
 #endif
   return pack2bit_scalar(ascii, n, bases2, nmask);
 }

@@ -84,7 +84,7 @@ class Map {
   struct Batch {
     mmhost::ParsedBatch in;                      // names, offsets, bases (page-locked buffer, recycled through bufferPool)
     seqno_t firstSeqCounter = 0;
-    std::vector<mm_mapping> recs;                // candidate mappings of the batch, read-major (filled by the device stage)
+    PinnedRecs<mm_mapping> recs;                 // candidate mappings of the batch, read-major (filled by the device stage; page-locked, skch_types.hpp)
     mutable std::vector<char> prefetched;        // per context: the batch's block is already on its way to that GPU (guarded by pfMu)
     size_t size() const { return in.names.size(); }
   };
@@ -334,7 +334,7 @@ class Map {
     // (bench.py --gpus N, mm_allgatherv_mappings_begin/_end).
     const char* xe = getenv("MASHMAP_HIP_EXCHANGE");
     const bool gatherOnDevice = nCtx > 1 && xe && std::string(xe) == "allgather";
-    std::vector<std::vector<mm_mapping>> blockRecs(gatherOnDevice || nCtx == 1 ? 0 : nCtx);
+    std::vector<PinnedRecs<mm_mapping>> blockRecs(gatherOnDevice || nCtx == 1 ? 0 : nCtx);
     double phase[3] = {0, 0, 0};                           // context 0: upload, kernels, download (seconds)
     auto runBlock = [&](size_t i) {
       mm_ctx* c = ctxs[i];

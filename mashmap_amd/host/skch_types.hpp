@@ -181,6 +181,50 @@ class HostBufferPool {
   void give(char* p, size_t bytes) { if (!p) return; std::lock_guard<std::mutex> lk(mu_); free_.emplace_back(p, bytes); cv_.notify_all(); }
 };
 
+// Page-locked, uninitialised storage for the records a batch brings back from the GPU (48-byte candidate mappings).  A std::vector
+// would zero megabytes per batch before the copy overwrites them, and a copy into pageable memory is staged by the runtime at a fifth
+// of the link's rate; the buffers are recycled through a free list, a batch that outgrows every free one page-locks a larger one, and
+// plain malloc stands in when page-locking fails.
+template <class T>
+class PinnedRecs {
+  struct Pool { std::mutex mu; std::vector<std::pair<void*, size_t>> free_;
+                ~Pool() { for (auto& b : free_) mm_host_free(b.first); } };
+  static Pool& pool() { static Pool p; return p; }
+  T* p_ = nullptr; size_t n_ = 0, cap_ = 0; bool pinned_ = false;
+  void release() {
+    if (!p_) return;
+    if (pinned_) { std::lock_guard<std::mutex> lk(pool().mu); pool().free_.emplace_back((void*)p_, cap_ * sizeof(T)); }
+    else free(p_);
+    p_ = nullptr; n_ = cap_ = 0; pinned_ = false;
+  }
+ public:
+  PinnedRecs() = default;
+  PinnedRecs(const PinnedRecs&) = delete; PinnedRecs& operator=(const PinnedRecs&) = delete;
+  PinnedRecs(PinnedRecs&& o) noexcept : p_(o.p_), n_(o.n_), cap_(o.cap_), pinned_(o.pinned_) { o.p_ = nullptr; o.n_ = o.cap_ = 0; }
+  PinnedRecs& operator=(PinnedRecs&& o) noexcept { if (this != &o) { release(); p_ = o.p_; n_ = o.n_; cap_ = o.cap_; pinned_ = o.pinned_; o.p_ = nullptr; o.n_ = o.cap_ = 0; } return *this; }
+  ~PinnedRecs() { release(); }
+  T* data() { return p_; } const T* data() const { return p_; }
+  size_t size() const { return n_; } bool empty() const { return n_ == 0; }
+  T& operator[](size_t i) { return p_[i]; } const T& operator[](size_t i) const { return p_[i]; }
+  // contents are NOT kept and NOT initialised
+  void resize(size_t n) {
+    if (n <= cap_) { n_ = n; return; }
+    release();
+    const size_t want = n * sizeof(T);
+    {
+      std::lock_guard<std::mutex> lk(pool().mu);
+      auto& f = pool().free_;
+      for (size_t i = 0; i < f.size(); i++) if (f[i].second >= want) { p_ = (T*)f[i].first; cap_ = f[i].second / sizeof(T); pinned_ = true; f.erase(f.begin() + (std::ptrdiff_t)i); break; }
+    }
+    if (!p_) {
+      const size_t bytes = std::max<size_t>(want + want / 4, (size_t)1 << 20);
+      if (void* q = mm_host_alloc(bytes)) { p_ = (T*)q; cap_ = bytes / sizeof(T); pinned_ = true; }
+      else { p_ = (T*)malloc(want); cap_ = n; pinned_ = false; if (!p_) { std::fprintf(stderr, "[mashmap_hip] out of memory\n"); exit(1); } }
+    }
+    n_ = n;
+  }
+};
+
 // How skch::Map takes the query files through the GPUs: bases per batch (MASHMAP_HIP_BATCH_MBP, default 512 Mbp, PER GPU CONTEXT -- a
 // batch is cut into one block per context, and a block is what keeps a GPU busy for tens of milliseconds), and the page-locked buffers
 // that go with it: as many as batches can be in flight at once (reader 1 + two queues of 2 + device 1 + post 1 + one spare), but no more

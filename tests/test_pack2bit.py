@@ -1,6 +1,12 @@
 """mm_pack_read (mashmap_amd/host/pack2bit.hpp: makeUpperCaseAndValidDNA, commonFunc.hpp:97, + 2-bit packing on the host) against a
-plain restatement of k_pack2bit's per-base rule: every byte value, every tail length, AVX2 and portable paths.  CPU only."""
+plain restatement of k_pack2bit's per-base rule: every byte value, every tail length, the AVX-512 / AVX2 / portable paths (the widest
+one the CPU has by default; MASHMAP_HIP_PACK_ISA narrows it, one subprocess per setting).  CPU only."""
+import os
+import subprocess
+import sys
+
 import numpy as np
+import pytest
 
 from mashmap_amd import capi
 
@@ -18,7 +24,7 @@ def ref_pack(a):
     return b2, nm
 
 
-def test_pack_read_every_byte_value_and_tail():
+def check_every_byte_value_and_tail():
     rng = np.random.default_rng(1)
     reads = [np.arange(256, dtype=np.uint8), rng.integers(0, 256, 1000).astype(np.uint8), np.frombuffer(b"ACGTacgtNnRYKM-*xX", dtype=np.uint8)]
     reads += [rng.choice(np.frombuffer(b"ACGTacgtN", dtype=np.uint8), n) for n in (0, 1, 15, 16, 17, 31, 32, 33, 63, 64, 65, 97, 5000)]
@@ -31,3 +37,17 @@ def test_pack_read_every_byte_value_and_tail():
             assert hasn[i] == (1 if en.any() else 0) and lens[i] == len(r)
             at += g
         assert at == len(nm)
+
+
+def test_pack_read_every_byte_value_and_tail():
+    check_every_byte_value_and_tail()
+
+
+@pytest.mark.parametrize("isa", ["scalar", "avx2", "avx512"])
+def test_pack_read_with_the_instruction_set_narrowed(isa):
+    """the dispatcher reads MASHMAP_HIP_PACK_ISA once per process: a fresh interpreter per setting (a CPU without the set falls back)"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASHMAP_HIP_PACK_ISA=isa, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    p = subprocess.run([sys.executable, "-c", "import tests.test_pack2bit as t; t.check_every_byte_value_and_tail(); print('ok')"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and p.stdout.strip().endswith("ok"), p.stderr[-2000:]
