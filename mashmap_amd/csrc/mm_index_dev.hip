@@ -610,6 +610,13 @@ int mm_mirror_map(mm_ctx* c) {
 
 // The indices c0 .. c0+n-1 ordered by descending key[i] >> shift (ties keep their order): the L2 sweep runs one candidate per lane, so
 // a wave takes as long as its longest stream -- with the candidates taken in order of stream length the 64 of a wave are alike.
+// ascending order of the n (key, value) pairs the caller has written to dL2Sort[0] (uint32 keys of `bits` bits) and dL2Sort[2] (int32 values)
+int mm_order_pairs(mm_ctx* c, int n, unsigned bits, int32_t* dOrder) {
+  if (n <= 0) return MM_OK;
+  DevBuf& k0 = c->dL2Sort[0]; DevBuf& k1 = c->dL2Sort[1]; DevBuf& v0 = c->dL2Sort[2]; DevBuf& tmp = c->dL2Sort[3];
+  MM_HIP(c, k1.ensure((size_t)n * 4 + 64));
+  return sort_pairs(c, tmp, k0.as<uint32_t>(), k1.as<uint32_t>(), v0.as<int32_t>(), dOrder, (size_t)n, 0u, bits);
+}
 int mm_order_desc(mm_ctx* c, const int32_t* dKey, int c0, int n, int shift, int32_t* dOrder) {
   if (n <= 0) return MM_OK;
   const uint32_t maxKey = 0xFFFu;                                   // 12 bits of key: two radix passes

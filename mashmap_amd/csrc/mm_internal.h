@@ -120,7 +120,7 @@ struct mm_ctx {
   DevBuf dGatherSrc; hipStream_t commStream = nullptr; std::thread gatherThread; int gatherRc = 0; std::string gatherErr;
   std::vector<DevBuf*> allBufs();
   DevBuf dL2Info, dL2Cnt, dL2Off, dL2Ops, dScanTmp, dL2Tmp, dL2Wide, dL2Exact, dL2Cells, dListB, dListC, dBigList;     // L2 staging: per-candidate stream extents, op counts/offsets, located ops
-  DevBuf dL2Sort[4], dL2Order;                          // candidates of a chunk in order of descending stream length (mm_order_desc)
+  DevBuf dL2Sort[4], dL2Order, dL2OrderPos;                          // candidates of a chunk in order of descending stream length (mm_order_desc)
   bool sketched = false, mapped = false;
   bool keepPoints = false;                              // mm_set_option(MM_OPT_KEEP_POINTS): route every fragment through the HBM point list
 
@@ -170,3 +170,4 @@ int mm_mirror_minmers(mm_ctx* c);
 int mm_mirror_map(mm_ctx* c);
 int mm_scan_i32_to_i64(mm_ctx* c, int64_t n, const int32_t* dIn, int64_t* dOut, int64_t* total);
 int mm_order_desc(mm_ctx* c, const int32_t* dKey, int c0, int n, int shift, int32_t* dOrder);   // mm_index_dev.hip (rocPRIM radix sort)
+int mm_order_pairs(mm_ctx* c, int n, unsigned bits, int32_t* dOrder);                          // same file: pairs already in dL2Sort[0] / dL2Sort[2]

@@ -149,6 +149,19 @@ k_scan_add(int64_t n, int64_t* __restrict__ out, const int64_t* __restrict__ til
 }
 
 // ---------------------------------------------------------------------------------------------
+// Sort keys that put the candidates of a chunk in REFERENCE order (the event index where a candidate's slice starts, coarsened).
+// k_l2_locate streams ~3 segment lengths of the index per candidate and the reads cover the reference several times over, in random
+// order: taken as they come, every slice is fetched from HBM (16 B per event: the kernel sits on the HBM roofline against a human-scale
+// index); taken in reference order, the waves in flight at any moment read one neighbourhood of the index, which the Infinity Cache holds.
+__global__ void __launch_bounds__(256)
+k_l2_pos_keys(int c0, int n, int shift, const L2Info* __restrict__ info, uint32_t* __restrict__ kOut, int32_t* __restrict__ vOut) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  kOut[i] = (uint32_t)(info[c0 + i].e0 >> shift);
+  vOut[i] = c0 + i;
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_l2_locate: one wave per candidate (4 per workgroup, no workgroup barrier).  LDS per wave: the fragment's query sketch
 // (hash + strand) and a table of NB >= s equal-width buckets over [0, qmax] that turns the lower_bound of a hash into one table read
 // plus a walk of ~1 entry (the hashes of a sketch are uniform, so equal-width buckets are balanced).
@@ -166,7 +179,8 @@ k_l2_locate(int cBase, int nCand, int64_t opsBase, int s, int NB, const mm_l1_ca
             const uint32_t* __restrict__ evKey, const uint32_t* __restrict__ evAux, const uint64_t* __restrict__ evHash,
             const uint32_t* __restrict__ opKey, const uint32_t* __restrict__ opAux, const uint64_t* __restrict__ opHash,
             const int64_t* __restrict__ contigOff, const L2Info* __restrict__ info, const int64_t* __restrict__ opOff,
-            const int32_t* __restrict__ opCnt, uint32_t* __restrict__ ops, unsigned long long* __restrict__ counters /* [6] |= 4: gap too wide */) {
+            const int32_t* __restrict__ opCnt, uint32_t* __restrict__ ops, const int32_t* __restrict__ order /* candidates in reference order, or null */,
+            unsigned long long* __restrict__ counters /* [6] |= 4: gap too wide */) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   unsigned char* base = smem + (size_t)wave * mm_locate_lds_per_wave(s, NB);
@@ -176,7 +190,7 @@ k_l2_locate(int cBase, int nCand, int64_t opsBase, int s, int NB, const mm_l1_ca
   int8_t* qs = (int8_t*)(base + (size_t)(s + 1) * 8 + (size_t)(s + 2) / 2 * 8 + (size_t)(NB + 4) * 2);
   const int wpb = (int)(blockDim.x >> 6);                          // waves per workgroup: 4, fewer when a sketch's LDS share is large
   for (int ci = blockIdx.x * wpb + wave; ci < nCand; ci += gridDim.x * wpb) {
-    const int c = cBase + ci;                                      // this launch covers the candidates [cBase, cBase + nCand): their streams start at ops[opOff - opsBase]
+    const int c = order ? order[ci] : cBase + ci;                  // this launch covers the candidates [cBase, cBase + nCand): their streams start at ops[opOff - opsBase]
     const mm_l1_candidate cand = l1[c];
     const int f = cand.frag;
     const L2Info in = info[c];
@@ -920,8 +934,22 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt) {
   int wpb = 4; while (wpb > 1 && mm_locate_lds_per_wave(s, NB) * wpb > 160 * 1024) wpb >>= 1;
   const size_t ldsLoc = mm_locate_lds_per_wave(s, NB) * wpb;
   if (ldsLoc > 160 * 1024) { c->err = "sketchSize too large for the LDS-resident query sketch of k_l2_locate"; return MM_ERR_ARG; }
+  // total events of the index -> a shift that leaves 16 bits of key (two radix passes)
+  int posShift = 0; { const int64_t nEv = (int64_t)(I.evKey.bytes / 4); while ((nEv >> posShift) > 0xFFFF) posShift++; }
+  static const bool sortLocate = getenv("MM_L2_LOCATE_NO_SORT") == nullptr;
   auto locate = [&](const Chunk& ch) -> int {
     KernelTimer t(c, MM_K_L2_LOCATE);
+    const int32_t* order = nullptr;
+    if (sortLocate && ch.n > 4096) {
+      MM_HIP(c, c->dL2OrderPos.ensure((size_t)ch.n * 4 + 64));
+      MM_HIP(c, c->dL2Sort[0].ensure((size_t)ch.n * 4 + 64)); MM_HIP(c, c->dL2Sort[2].ensure((size_t)ch.n * 4 + 64));
+      hipLaunchKernelGGL(k_l2_pos_keys, dim3((unsigned)((ch.n + 255) / 256)), dim3(256), 0, c->stream, ch.c0, ch.n, posShift, c->dL2Info.as<L2Info>(),
+                         c->dL2Sort[0].as<uint32_t>(), c->dL2Sort[2].as<int32_t>());
+      MM_HIP(c, hipGetLastError());
+      const int rc = mm_order_pairs(c, ch.n, 16u, c->dL2OrderPos.as<int32_t>());
+      if (rc != MM_OK) return rc;
+      order = c->dL2OrderPos.as<int32_t>();
+    }
     int blocks = (ch.n + wpb - 1) / wpb; if (blocks > 256 * 32) blocks = 256 * 32;
     auto go = [&](auto kern) {
       (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsLoc);
@@ -930,7 +958,7 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt) {
                          I.evKey.as<uint32_t>(),
                          I.evAux.as<uint32_t>(), I.evHash.as<uint64_t>(), I.opKey.as<uint32_t>(), I.opAux.as<uint32_t>(), I.opHash.as<uint64_t>(),
                          I.contigOff.as<int64_t>(),
-                         c->dL2Info.as<L2Info>(), c->dL2Off.as<int64_t>(), c->dL2Cnt.as<int32_t>(), c->dL2Ops.as<uint32_t>(), cnt);
+                         c->dL2Info.as<L2Info>(), c->dL2Off.as<int64_t>(), c->dL2Cnt.as<int32_t>(), c->dL2Ops.as<uint32_t>(), order, cnt);
     };
     if (JB == 13) go(k_l2_locate<13>); else go(k_l2_locate<11>);
     MM_HIP(c, hipGetLastError());
