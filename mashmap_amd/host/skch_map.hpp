@@ -80,6 +80,12 @@ class Map {
   // the moment it has parsed a batch while the slot is idle -- so the copy of batch i+1 always runs under the kernels of batch i.
   std::mutex pfMu; std::vector<char> slotFree; bool earlyPrefetch = true;
   skch::Time::time_point tStart = skch::Time::now();   // MASHMAP_HIP_TIMING lines carry the time since the Map was constructed
+  // one write per diagnostic line: three stages log at once, and `std::cerr << a << b` from two threads interleaves inside a line
+  struct LogLine {
+    std::ostringstream os;
+    template <class T> LogLine& operator<<(const T& v) { os << v; return *this; }
+    ~LogLine() { os << '\n'; const std::string t = os.str(); std::fwrite(t.data(), 1, t.size(), stderr); }
+  };
   std::string at() const { char b[48]; snprintf(b, sizeof b, " [t=%.4f]", std::chrono::duration<double>(skch::Time::now() - tStart).count()); return b; }
   struct Batch {
     mmhost::ParsedBatch in;                      // names, offsets, bases (page-locked buffer, recycled through bufferPool)
@@ -130,9 +136,9 @@ class Map {
       if (mm_set_tables(c, minHits.data(), minHits.size(), cut32.data(), cut32.size()) != MM_OK) die("mm_set_tables", c);
       if (mm_set_replay_tables(c, accept.data(), minIsz.data(), (size_t)p.sketchSize + 1) != MM_OK) die("mm_set_replay_tables", c);
     }
-    if (getenv("MASHMAP_HIP_TIMING")) std::cerr << "[mashmap_hip::timing] integer tables ready" << at() << std::endl;
+    if (getenv("MASHMAP_HIP_TIMING")) LogLine() << "[mashmap_hip::timing] integer tables ready" << at();
     this->mapQuery();
-    if (getenv("MASHMAP_HIP_TIMING")) std::cerr << "[mashmap_hip::timing] mapQuery done" << at() << std::endl;
+    if (getenv("MASHMAP_HIP_TIMING")) LogLine() << "[mashmap_hip::timing] mapQuery done" << at();
   }
 
   static void insertL2ResultsToVec(MappingResultsVector_t& v, const MappingResult& reportedL2Result) { v.push_back(reportedL2Result); }
@@ -186,7 +192,7 @@ class Map {
         const auto e = skch::Time::now();
         auto sec = [](skch::Time::time_point x, skch::Time::time_point y) { return std::chrono::duration<double>(y - x).count(); };
         if (sec(a, e) > 0.0035)
-          std::cerr << "[mashmap_hip::stall] sleep " << sec(a, b) << " mmap " << sec(b, c) << " touch " << sec(c, d) << " munmap " << sec(d, e) << at() << std::endl;
+          LogLine() << "[mashmap_hip::stall] sleep " << sec(a, b) << " mmap " << sec(b, c) << " touch " << sec(c, d) << " munmap " << sec(d, e) << at();
       }
     });
     std::thread reader([&]() {
@@ -200,8 +206,8 @@ class Map {
                              [](size_t n) {                       // only when the pool (skch_sketch.hpp) has run dry
                                const auto t0 = skch::Time::now();
                                char* p = (char*)mm_host_alloc(n);
-                               if (getenv("MASHMAP_HIP_TIMING")) std::cerr << "[mashmap_hip::timing] reader: page-locked " << n << " bytes itself in "
-                                                                           << std::chrono::duration<double>(skch::Time::now() - t0).count() << " s" << std::endl;
+                               if (getenv("MASHMAP_HIP_TIMING")) LogLine() << "[mashmap_hip::timing] reader: page-locked " << n << " bytes itself in "
+                                                                           << std::chrono::duration<double>(skch::Time::now() - t0).count() << " s";
                                return p;
                              }, [](char* p) { mm_host_free(p); }, packedUpload);
       while (true) {
@@ -209,8 +215,8 @@ class Map {
         { auto b = HostBufferPool::instance().take(0); batch.in.bases = b.first; batch.in.cap = b.second; }
         const auto tr0 = skch::Time::now();
         const bool more = rd.next(batch.in);
-        if (more && getenv("MASHMAP_HIP_TIMING")) std::cerr << "[mashmap_hip::timing] reader: parsed " << batch.size() << " records, " << batch.in.totalBases() << " bases in "
-                                                            << std::chrono::duration<double>(skch::Time::now() - tr0).count() << " s" << at() << std::endl;
+        if (more && getenv("MASHMAP_HIP_TIMING")) LogLine() << "[mashmap_hip::timing] reader: parsed " << batch.size() << " records, " << batch.in.totalBases() << " bases in "
+                                                            << std::chrono::duration<double>(skch::Time::now() - tr0).count() << " s" << at();
         if (!more) { HostBufferPool::instance().give(batch.in.bases, batch.in.cap); break; }
         batch.firstSeqCounter = seqCounter;
         for (size_t r = 0; r < batch.size(); r++) {
@@ -392,9 +398,9 @@ class Map {
       size_t at = 0;
       for (const auto& v : blockRecs) { if (!v.empty()) std::memcpy(batch.recs.data() + at, v.data(), v.size() * sizeof(mm_mapping)); at += v.size(); }
     }
-    if (timing) std::cerr << "[mashmap_hip::timing] device stage (upload + pack + kernels" << (gatherOnDevice ? " + all-gatherv" : "") << " + download of " << n
+    if (timing) LogLine() << "[mashmap_hip::timing] device stage (upload + pack + kernels" << (gatherOnDevice ? " + all-gatherv" : "") << " + download of " << n
                           << " candidate mappings): " << std::chrono::duration<double>(skch::Time::now() - t0).count() << " s (upload " << phase[0] << ", kernels " << phase[1]
-                          << ", download " << std::chrono::duration<double>(skch::Time::now() - p2).count() << ")" << at() << std::endl;
+                          << ", download " << std::chrono::duration<double>(skch::Time::now() - p2).count() << ")" << at();
   }
 
   // post stage: per read, chaining + filters + PAF text on param.threads threads; then output in input order
@@ -460,8 +466,8 @@ class Map {
       }
     }
     if (!all.empty()) outstrm.write(all.data(), (std::streamsize)all.size());
-    if (timing) std::cerr << "[mashmap_hip::timing] post stage: chain + filter + format " << std::chrono::duration<double>(t1 - t0).count()
-                          << " s, output " << std::chrono::duration<double>(skch::Time::now() - t1).count() << " s" << at() << std::endl;
+    if (timing) LogLine() << "[mashmap_hip::timing] post stage: chain + filter + format " << std::chrono::duration<double>(t1 - t0).count()
+                          << " s, output " << std::chrono::duration<double>(skch::Time::now() - t1).count() << " s" << at();
   }
 
 };

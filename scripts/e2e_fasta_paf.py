@@ -58,10 +58,13 @@ def main():
             print(p.stderr[-2000:], file=sys.stderr); raise SystemExit(1)
         tmap = float(re.search(r"time spent mapping the query: ([0-9.eE+-]+)", p.stderr).group(1))
         tidx = float(re.search(r"time spent computing the reference index: ([0-9.eE+-]+)", p.stderr).group(1))
-        dev_s = sum(float(x) for x in re.findall(r"device stage.*?: ([0-9.eE+-]+) s", p.stderr))
-        post_s = sum(float(x) for x in re.findall(r"post stage: chain \+ filter \+ format ([0-9.eE+-]+) s", p.stderr))
-        out_s = sum(float(x) for x in re.findall(r", output ([0-9.eE+-]+) s", p.stderr))
-        read_s = sum(float(x) for x in re.findall(r"reader: parsed .*? in ([0-9.eE+-]+) s", p.stderr))
+        def fl(x):
+            try: return float(x)
+            except ValueError: return 0.0
+        dev_s = sum(fl(x) for x in re.findall(r"device stage.*?: ([0-9.eE+-]+) s", p.stderr))
+        post_s = sum(fl(x) for x in re.findall(r"post stage: chain \+ filter \+ format ([0-9.eE+-]+) s", p.stderr))
+        out_s = sum(fl(x) for x in re.findall(r", output ([0-9.eE+-]+) s", p.stderr))
+        read_s = sum(fl(x) for x in re.findall(r"reader: parsed .*? in ([0-9.eE+-]+) s", p.stderr))
         cur = dict(map_s=tmap, index_s=tidx, wall_s=wall, device_stage_s=dev_s, post_stage_s=post_s, output_s=out_s, reader_s=read_s)
         print("\n".join(l for l in p.stderr.splitlines() if "timing" in l or "time spent" in l or "stall" in l), file=sys.stderr)
         if best is None or tmap < best["map_s"]:
