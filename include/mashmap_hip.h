@@ -40,8 +40,8 @@ enum {
   MM_FLAG_LOWER_TRIANGULAR = 8, /* lower_triangular       (parseCmdArgs.hpp:334) */
   MM_FLAG_NO_SPLIT = 16         /* !split                 (parseCmdArgs.hpp:427): a read longer than segLength is then ONE fragment with
                                    windowLen = len - segLength != 0 (computeMap.hpp:933, :1309); a batch that holds such a read goes through
-                                   the literal kernels (k_l1_window, k_l2_window: exact, not fast).  The read must fit the sketch kernels'
-                                   LDS staging (~150 kbp at sketchSize <= 1024; mm_map_fragments says so otherwise). */
+                                   the literal kernels (k_l1_window, k_l2_window: exact, not fast).  A read of any length: one that does not
+                                   fit a CU's LDS (a whole contig as a read) is sketched by the exact kernel from global memory. */
 };
 
 typedef struct {

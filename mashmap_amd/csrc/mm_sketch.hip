@@ -121,6 +121,7 @@ template <int K, bool SPILL>
 __device__ __forceinline__ void
 mm_sketch_hard(unsigned char* smem, const int f, const uint4* __restrict__ gTabs, const uint32_t* __restrict__ bases2, const uint32_t* __restrict__ nmask,
                const DFrag* __restrict__ frags, const uint32_t* __restrict__ readHasN, int s, int wantFast, int HT, int PAD, int32_t* __restrict__ spill,
+               const bool stream /* the fragment does not fit the LDS: its words are read from global memory as they are needed */,
                uint64_t* __restrict__ skHash, int2* __restrict__ skPos, int8_t* __restrict__ skStrand, uint32_t* __restrict__ skCount) {
   const DFrag fr = frags[f];
   const int len = fr.len;
@@ -131,8 +132,8 @@ mm_sketch_hard(unsigned char* smem, const int f, const uint4* __restrict__ gTabs
   const uint32_t hint = skCount[f];                 // distinct survivors under the fast kernel's cut, or MM_SK_HINT_OVERFLOW
 
   // ---- LDS carve (every offset a multiple of 16) ----
-  const int nW = (len + 15) / 16 + 3;               // code words incl. 2 words of run-off for the last strip
-  const int nM = (len + 31) / 32 + 2;
+  const int nW = stream ? 0 : (len + 15) / 16 + 3;  // code words incl. 2 words of run-off for the last strip
+  const int nM = stream ? 0 : (len + 31) / 32 + 2;
   const int NS = HT + PAD;                          // table slots (multiple of 64)
   const int nOcc = NS >> 6;
   size_t off = 0;
@@ -158,20 +159,32 @@ mm_sketch_hard(unsigned char* smem, const int f, const uint4* __restrict__ gTabs
   tab.nSlots = (uint32_t)NS; tab.maxLoad = (uint32_t)HT * 5u / 8u;
 
   // ---- stage the fragment, re-aligned so that LDS word j holds bases 16j..16j+15 ----
+  const int64_t gw0 = fr.base >> 4; const int gsh = (int)(fr.base & 15) * 2;
+  const int64_t gm0 = fr.base >> 5; const int gmsh = (int)(fr.base & 31);
   {
-    const int64_t w0 = fr.base >> 4; const int sh = (int)(fr.base & 15) * 2;
     for (int j = tid; j < nW; j += nthr) {
-      const uint32_t a = bases2[w0 + j], b = bases2[w0 + j + 1];
-      sW[j] = sh ? __builtin_amdgcn_alignbit(b, a, sh) : a;
+      const uint32_t a = bases2[gw0 + j], b = bases2[gw0 + j + 1];
+      sW[j] = gsh ? __builtin_amdgcn_alignbit(b, a, gsh) : a;
     }
     if (hasN) {
-      const int64_t m0 = fr.base >> 5; const int msh = (int)(fr.base & 31);
       for (int j = tid; j < nM; j += nthr) {
-        const uint32_t a = nmask[m0 + j], b = nmask[m0 + j + 1];
-        sM[j] = msh ? __builtin_amdgcn_alignbit(b, a, msh) : a;
+        const uint32_t a = nmask[gm0 + j], b = nmask[gm0 + j + 1];
+        sM[j] = gmsh ? __builtin_amdgcn_alignbit(b, a, gmsh) : a;
       }
     }
   }
+  // word j of the re-aligned fragment / of its N mask: from the LDS copy, or -- a fragment longer than the LDS (a whole contig under
+  // --noSplit) -- straight from the packed batch, realigned on the fly (neighbouring strips share their words in the caches)
+  auto wordAt = [&](int j) -> uint32_t {
+    if (!stream) return sW[j];
+    const uint32_t a = bases2[gw0 + j], b = bases2[gw0 + j + 1];
+    return gsh ? __builtin_amdgcn_alignbit(b, a, gsh) : a;
+  };
+  auto maskAt = [&](int j) -> uint32_t {
+    if (!stream) return sM[j];
+    const uint32_t a = nmask[gm0 + j], b = nmask[gm0 + j + 1];
+    return gmsh ? __builtin_amdgcn_alignbit(b, a, gmsh) : a;
+  };
 
   // Any cut gives the exact sketch as long as >= s distinct hashes survive it (checked below), so float estimates are enough.
   // `scaled(T, D)`: the cut under which 1.6 s distinct hashes are expected when T produced D (distinct counts grow with the cut
@@ -203,10 +216,10 @@ mm_sketch_hard(unsigned char* smem, const int f, const uint4* __restrict__ gTabs
       const int rem = n - strip * 16;
       uint32_t ok = rem >= 16 ? 0xFFFFu : ((1u << rem) - 1u);
       if (hasN) {
-        const uint64_t m64 = (uint64_t)sM[strip >> 1] | ((uint64_t)sM[(strip >> 1) + 1] << 32);
+        const uint64_t m64 = (uint64_t)maskAt(strip >> 1) | ((uint64_t)maskAt((strip >> 1) + 1) << 32);
         ok &= ~(uint32_t)mm_window_or<K>(m64 >> ((strip & 1) * 16));
       }
-      mm_strip_hashes<K>(sW[strip], sW[strip + 1], sW[strip + 2], *tabs, [&](int j, uint64_t hf, uint64_t hr) {
+      mm_strip_hashes<K>(wordAt(strip), wordAt(strip + 1), wordAt(strip + 2), *tabs, [&](int j, uint64_t hf, uint64_t hr) {
         const int pos = strip * 16 + j;
         const uint64_t h = hf < hr ? hf : hr;
         bool pass = false;                          // nested ifs: the compiler keeps the three tests as exec masks
@@ -294,13 +307,13 @@ template <int K, bool SPILL>
 __global__ void __launch_bounds__(1024)
 k_sketch_hard(const uint4* __restrict__ gTabs, const uint32_t* __restrict__ bases2, const uint32_t* __restrict__ nmask,
               const DFrag* __restrict__ frags, const uint32_t* __restrict__ readHasN,
-              const int32_t* __restrict__ fragList, const uint32_t* __restrict__ fragListCount, int s, int wantFast, int HT, int PAD, int32_t* __restrict__ spill,
+              const int32_t* __restrict__ fragList, const uint32_t* __restrict__ fragListCount, int s, int wantFast, int HT, int PAD, int32_t* __restrict__ spill, int stream,
               uint64_t* __restrict__ skHash, int2* __restrict__ skPos, int8_t* __restrict__ skStrand, uint32_t* __restrict__ skCount) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // the hard list's length stays on the device (no host round trip between the two kernels): a fixed grid walks it
   const uint32_t nList = *fragListCount;
   for (uint32_t i = blockIdx.x; i < nList; i += gridDim.x) {
-    mm_sketch_hard<K, SPILL>(smem, fragList[i], gTabs, bases2, nmask, frags, readHasN, s, wantFast, HT, PAD, spill, skHash, skPos, skStrand, skCount);
+    mm_sketch_hard<K, SPILL>(smem, fragList[i], gTabs, bases2, nmask, frags, readHasN, s, wantFast, HT, PAD, spill, stream != 0, skHash, skPos, skStrand, skCount);
     __syncthreads();                                // the next fragment reuses the LDS
   }
 }
@@ -699,7 +712,7 @@ static int sketch_ht_hard(int s) { const int w = (s * 16 + 4) / 5; return next_p
 // the 13-bit field of its duplicate list), otherwise every fragment goes down the hard list; the hard kernel with its whole table in
 // LDS when that fits, otherwise with the first / last / strand-sum arrays spilled to HBM scratch and, if the power-of-two table still
 // does not fit, the smallest table that keeps its load limit (5/8) at 2 s.  ok == false: not even that fits (the message says why).
-struct SketchPlan { bool ok, useFast, spill; FastGeom g; int HTH; size_t ldsFast, ldsHard; };
+struct SketchPlan { bool ok, useFast, spill, stream = false; FastGeom g; int HTH; size_t ldsFast, ldsHard; };
 static size_t sketch_hard_lds_spill(size_t tabBytes, int maxLen, int HT, int PAD) {
   const size_t nW = (size_t)(maxLen + 15) / 16 + 3, nM = (size_t)(maxLen + 31) / 32 + 2;
   const size_t NS = (size_t)HT + PAD, nOcc = NS / 64;
@@ -722,6 +735,12 @@ static SketchPlan sketch_plan(int K, int s, int maxLen, size_t tabBytes, bool sl
       P.ldsHard = sketch_hard_lds_spill(tabBytes, maxLen, P.HTH, MM_SK_PADH);
     }
   }
+  if (P.ldsHard > lim) {                            // the staged fragment is what does not fit (a whole contig as one fragment under --noSplit):
+    P.stream = true;                                // the exact kernel reads its words from global memory instead
+    P.HTH = sketch_ht_hard(s);
+    P.ldsHard = sketch_hard_lds_spill(tabBytes, 0, P.HTH, MM_SK_PADH);
+    if (P.ldsHard > lim) { P.HTH = (((s * 16 + 4) / 5) + 63) / 64 * 64; P.ldsHard = sketch_hard_lds_spill(tabBytes, 0, P.HTH, MM_SK_PADH); }
+  }
   P.ok = P.ldsHard <= lim;
   return P;
 }
@@ -741,7 +760,7 @@ int mm_check_params(const mm_params* p, std::string& err) {
   if (!P.ok || ldsL2 > lim || ldsLoc > lim || s > 8190) {
     char b[400];
     snprintf(b, sizeof b, "mm_create: segLength %d with sketchSize %d needs %zu bytes of LDS in the sketch kernel (table of the exact path, spilled form), %zu in the L2 "
-             "sweep and %zu in the L2 locate kernel; a CU has %zu (sketchSize up to ~5000 at segLength <= 50 kbp; segLength up to ~150 kbp at sketchSize 1024)",
+             "sweep and %zu in the L2 locate kernel; a CU has %zu (sketchSize up to ~5000)",
              L, s, P.ldsHard, ldsL2, ldsLoc, lim);
     err = b; return MM_ERR_ARG;
   }
@@ -803,7 +822,7 @@ static int launch_sketch_k(mm_ctx* c) {
     MM_HIP(c, hipMemcpyAsync(&nHard, c->dCounters.p, 4, hipMemcpyDeviceToHost, c->stream));
     MM_HIP(c, hipStreamSynchronize(c->stream));
     fprintf(stderr, "[mm] sketch: %d fragments, %u to the hard path%s, threads %d x %d positions, HT %d, lds %zu/%zu%s\n", nF, nHard, plan.useFast ? "" : " (fast kernel not usable at this size)",
-            g.threads, g.SL, g.HT, ldsFast, ldsHard, plan.spill ? " (hard table: position / strand arrays in HBM)" : "");
+            g.threads, g.SL, g.HT, ldsFast, ldsHard, plan.stream ? " (hard table: position / strand arrays in HBM; fragments read from global memory)" : plan.spill ? " (hard table: position / strand arrays in HBM)" : "");
   }
   {
     // fixed grid over the device-resident hard list (its workgroups leave at once when the list is empty or short)
@@ -813,7 +832,7 @@ static int launch_sketch_k(mm_ctx* c) {
       (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsHard);
       hipLaunchKernelGGL(kern, dim3(grid), dim3(threadsHard), ldsHard, c->stream,
                          c->dSketchTabs.as<uint4>(), c->dBases2.as<uint32_t>(), c->dNmask.as<uint32_t>(), c->dFrags.as<DFrag>(), c->dReadHasN.as<uint32_t>(),
-                         c->dHardList.as<int32_t>(), c->dCounters.as<uint32_t>(), s, g.wantFast, HTH, PADH, spill, c->dSkHash.as<uint64_t>(), c->dSkPos.as<int2>(), c->dSkStrand.as<int8_t>(),
+                         c->dHardList.as<int32_t>(), c->dCounters.as<uint32_t>(), s, g.wantFast, HTH, PADH, spill, plan.stream ? 1 : 0, c->dSkHash.as<uint64_t>(), c->dSkPos.as<int2>(), c->dSkStrand.as<int8_t>(),
                          c->dSkCount.as<uint32_t>());
     };
     if (plan.spill) {

@@ -255,6 +255,17 @@ def test_map_no_split_reads_longer_than_the_segment(oracle, mode):
     assert nF == len([1 for _, a in reads if len(a) >= 19]) and nl >= 20
 
 
+def test_map_no_split_read_longer_than_the_lds(oracle):
+    """--noSplit with a read that is a whole contig (all-vs-all of assemblies): 450 kbp as ONE fragment does not fit a CU's LDS -- the
+    exact sketch kernel then reads the fragment's words from global memory (mm_sketch.hip: stream) -- and windowLen = 445 kbp through
+    k_l1_window / k_l2_window.  Every integer against the oracle."""
+    g0, g1 = U.random_dna(801, 600000), U.random_dna(802, 300000)
+    long_read = U.mutate(g0[100000:550000], 81, 0.03)
+    reads = [("contig_as_a_read", long_read), ("r1", U.mutate(g1[20000:31000], 82, 0.05)), ("r2", U.revcomp(U.mutate(g0[5000:9000], 83, 0.02)))]
+    nF, nl = run_and_compare(oracle, [("chr0", g0), ("chr1", g1)], reads, flags=U.FLAG_HG | U.FLAG_NOSPLIT, check_points=False)
+    assert nF == 3 and nl >= 3
+
+
 def test_index_with_a_hyper_frequent_seed():
     """a frequent seed's point list is never read on the device (getSeedHits drops the seed first): a list of 2^23 points and more
     (a satellite array in a real genome) must not be refused.  Synthetic index: the resident one plus one such key."""
