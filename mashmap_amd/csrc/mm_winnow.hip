@@ -18,6 +18,7 @@
 // sequence) is re-run in DENSE mode, where every valid k-mer position is a candidate.
 #include "mm_internal.h"
 #include "mm_device.h"
+#include <type_traits>
 #include "mm_winnow.h"
 #include <algorithm>
 
@@ -66,18 +67,25 @@ k_cand_write(const uint64_t* __restrict__ H, const int8_t* __restrict__ ST, int6
 // ---------------------------------------------------------------------------------------------
 // wave helpers
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int wn_sum(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
+// reductions over the 64 lanes on the DPP lanes (mm_device.h): the kernel below is one wave per workgroup with wave-uniform control flow,
+// so all lanes are active wherever these are called.  (ds_bpermute shuffles -- an LDS round trip per step, twelve per 64-bit minimum --
+// were a fifth of a refill step.)
+__device__ __forceinline__ int wn_sum(int v) { return mm_wave_sum(v); }
 __device__ __forceinline__ uint64_t wn_min64(uint64_t v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const uint64_t y = ((uint64_t)(uint32_t)__shfl_xor((int)(v >> 32), o) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)v, o);
+  auto step = [&](auto ctrl) {
+    constexpr int C = decltype(ctrl)::value;
+    const uint64_t y = ((uint64_t)(uint32_t)mm_dpp0<C>((int)(v >> 32)) << 32) | (uint32_t)mm_dpp0<C>((int)(uint32_t)v);   // these controls give every lane a source: no fill
     v = y < v ? y : v;
+  };
+  step(std::integral_constant<int, MM_DPP_QUAD_1032>()); step(std::integral_constant<int, MM_DPP_QUAD_2301>());
+  step(std::integral_constant<int, MM_DPP_ROW_HALF_MIRROR>()); step(std::integral_constant<int, MM_DPP_ROW_MIRROR>());
+  uint64_t r = ~0ull;
+#pragma unroll
+  for (int row = 0; row < 4; row++) {
+    const uint64_t x = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(v >> 32), row * 16) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, row * 16);
+    r = x < r ? x : r;
   }
-  return v;
+  return r;
 }
 
 // the sketch of the current window: n entries ascending by hash, in this wave's LDS
@@ -199,12 +207,21 @@ k_winnow_tiles(const int32_t* __restrict__ tileList,
     for (int64_t base = a; base < b; base += 64) {
       const int64_t i = base + lane;
       uint64_t hv = (i < b && validAt(i)) ? hashAt(i) : WN_NONE;
-      if (hv != WN_NONE && sk.n > 0 && hv <= mx && sk.contains_lane(hv)) hv = WN_NONE;
+      // The sketch holds the min(s, distinct) smallest hashes of the window -- except for a newcomer that has just arrived below the
+      // maximum, and refill() puts that one in before it asks for a minimum -- so a window hash at or below the sketch's maximum IS a
+      // member: no search.  MM_WINNOW_CHECK builds verify it with the binary search this line used to be.
+#ifdef MM_WINNOW_CHECK
+      if (hv != WN_NONE && sk.n > 0 && hv <= mx && !sk.contains_lane(hv)) __builtin_trap();
+#endif
+      if (hv != WN_NONE && sk.n > 0 && hv <= mx) hv = WN_NONE;
       best = hv < best ? hv : best;
     }
     return wn_min64(best);
   };
-  auto refill = [&](int startVal, int64_t a, int64_t b) {                 // :487-505
+  auto refill = [&](int startVal, int64_t a, int64_t b, bool haveNew, uint64_t hNew) {   // :487-505
+    // a newcomer below the sketch's maximum is the smallest hash outside the sketch (everything else outside is above the maximum,
+    // the evicted one included): it goes in first, which restores the invariant pendMin relies on
+    if (haveNew && sk.n > 0 && sk.n < s && hNew <= sk.maxHash()) { int cnt, sm; occ(hNew, a, b, cnt, sm); sk.insert(hNew, startVal, sm, lane); }
     while (sk.n < s) {
       const uint64_t pm = pendMin(a, b);
       if (pm == WN_NONE) break;
@@ -223,7 +240,7 @@ k_winnow_tiles(const int32_t* __restrict__ tileList,
     b = lo;
   }
   // cold start: the sketch of window W0; runs that were already open get their start from the previous tile later
-  refill(W0 == 0 ? 0 : WN_CARRY, a, b);
+  refill(W0 == 0 ? 0 : WN_CARRY, a, b, false, 0ull);
   if (!DENSE && sk.n < s) fail = true;
 
   int W = W0;
@@ -284,7 +301,7 @@ k_winnow_tiles(const int32_t* __restrict__ tileList,
       sk.n--; removed = true;
     }
     if (sk.n < s && (removed || newPending)) {
-      refill(W, a, b);
+      refill(W, a, b, newPending, hArr);
       if (!DENSE && sk.n < s) fail = true;                                  // the cut may be hiding k-mers that belong in the sketch
     }
   }
