@@ -10,7 +10,20 @@ struct WinnowBuffers {       // grow-only device scratch shared by the contigs o
   DevBuf blockCnt, blockOff, cPos, cHash, cSt;
   DevBuf out, outCount, outOff, open, openCount, status, dense;
   DevBuf redoList, out2, outCount2, open2, openCount2, status2;
+  // page-locked landing area for a contig's records and open lists (hundreds of megabytes per contig at human scale): the copy down
+  // runs at the link's rate instead of through the runtime's pageable staging, and the host vectors are filled from it in one pass
+  // (a vector sized first is zero-filled first)
+  void* hStage = nullptr; size_t hStageBytes = 0;
+  void* host(size_t bytes) {                     // nullptr when page-locking fails: the caller copies into pageable memory as before
+    if (bytes <= hStageBytes) return hStage;
+    if (hStage) { (void)hipHostFree(hStage); hStage = nullptr; hStageBytes = 0; }
+    const size_t cap = bytes + bytes / 8 + 4096;
+    if (hipHostMalloc(&hStage, cap, hipHostMallocDefault) != hipSuccess) { hStage = nullptr; (void)hipGetLastError(); return nullptr; }
+    hStageBytes = cap;
+    return hStage;
+  }
   void release() {
+    if (hStage) { (void)hipHostFree(hStage); hStage = nullptr; hStageBytes = 0; }
     DevBuf* all[] = {&blockCnt, &blockOff, &cPos, &cHash, &cSt, &out, &outCount, &outOff, &open, &openCount, &status, &dense,
                      &redoList, &out2, &outCount2, &open2, &openCount2, &status2};
     for (DevBuf* b : all) b->release();

@@ -394,13 +394,26 @@ int mm_winnow_contig_device(mm_ctx* c, WinnowBuffers& B, const uint64_t* dH, con
   hipLaunchKernelGGL(k_winnow_compact, dim3(nTiles), dim3(256), 0, c->stream, B.out.as<mm_minmer>(), outCap, B.outCount.as<int32_t>(),
                      B.outOff.as<int64_t>(), B.dense.as<mm_minmer>());
   MM_HIP(c, hipGetLastError());
-  std::vector<mm_minmer> first((size_t)total);
-  tileCount.assign((size_t)nTiles, 0); openCount.assign((size_t)nTiles, 0); openRuns.assign((size_t)nTiles * s, WnOpenRun{0, 0, 0});
-  if (total) MM_HIP(c, hipMemcpyAsync(first.data(), B.dense.p, (size_t)total * sizeof(mm_minmer), hipMemcpyDeviceToHost, c->stream));
+  std::vector<mm_minmer> first;
+  tileCount.assign((size_t)nTiles, 0); openCount.assign((size_t)nTiles, 0);
+  const size_t recBytes = (size_t)total * sizeof(mm_minmer), runBytes = (size_t)nTiles * s * sizeof(WnOpenRun), recPad = (recBytes + 255) & ~(size_t)255;
+  unsigned char* hs = (unsigned char*)B.host(recPad + runBytes + 64);
+  if (hs) {
+    if (total) MM_HIP(c, hipMemcpyAsync(hs, B.dense.p, recBytes, hipMemcpyDeviceToHost, c->stream));
+    MM_HIP(c, hipMemcpyAsync(hs + recPad, B.open.p, runBytes, hipMemcpyDeviceToHost, c->stream));
+  } else {
+    first.resize((size_t)total); openRuns.assign((size_t)nTiles * s, WnOpenRun{0, 0, 0});
+    if (total) MM_HIP(c, hipMemcpyAsync(first.data(), B.dense.p, recBytes, hipMemcpyDeviceToHost, c->stream));
+    MM_HIP(c, hipMemcpyAsync(openRuns.data(), B.open.p, runBytes, hipMemcpyDeviceToHost, c->stream));
+  }
   MM_HIP(c, hipMemcpyAsync(tileCount.data(), B.outCount.p, (size_t)nTiles * 4, hipMemcpyDeviceToHost, c->stream));
   MM_HIP(c, hipMemcpyAsync(openCount.data(), B.openCount.p, (size_t)nTiles * 4, hipMemcpyDeviceToHost, c->stream));
-  MM_HIP(c, hipMemcpyAsync(openRuns.data(), B.open.p, (size_t)nTiles * s * sizeof(WnOpenRun), hipMemcpyDeviceToHost, c->stream));
   MM_HIP(c, hipStreamSynchronize(c->stream));
+  if (hs) {
+    const mm_minmer* r0 = (const mm_minmer*)hs; const WnOpenRun* o0 = (const WnOpenRun*)(hs + recPad);
+    first.assign(r0, r0 + (size_t)total);
+    openRuns.assign(o0, o0 + (size_t)nTiles * s);
+  }
   if (redo.empty()) { records.swap(first); return MM_OK; }
 
   // ---- failed tiles again, every valid k-mer a candidate, room for the worst case (3 records per window step + flush)
