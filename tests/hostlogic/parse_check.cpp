@@ -25,6 +25,7 @@ static int pool_check(unsigned threads, int runs) {
 
 int main(int argc, char** argv) {
   if (argc == 4 && std::string(argv[1]) == "pool") return pool_check((unsigned)atoi(argv[2]), atoi(argv[3]));
+  if (argc == 2 && std::string(argv[1]) == "cpus") { printf("%u\n", mmhost::availableCpus()); return 0; }   // what the stage widths are capped by
   if (argc < 4) return 2;
   const size_t window = (size_t)atol(argv[1]); const unsigned threads = (unsigned)atoi(argv[2]);
   std::string prefix; int a = 3; bool packed = false;

@@ -195,3 +195,24 @@ def test_packing_reader_falls_back_on_near_empty_records(exe, tmp_path):
         p = subprocess.run([exe, str(window), str(threads), "--packed", path], capture_output=True, text=True)
         assert p.returncode == 0, p.stdout[-300:] + p.stderr
         assert p.stdout.splitlines() == want
+
+
+def test_available_cpus_follows_override_affinity_and_quota(exe):
+    """the number the reader / post stage widths are capped by (seq_parse.hpp availableCpus): MASHMAP_HIP_CPUS wins; otherwise no more
+    than the hardware threads, the affinity mask, or a cgroup CPU quota if this container has one"""
+    env = dict(os.environ); env.pop("MASHMAP_HIP_CPUS", None)
+    n = int(subprocess.check_output([exe, "cpus"], env=env).split()[0])
+    assert 1 <= n <= (os.cpu_count() or 1)
+    if hasattr(os, "sched_getaffinity"):
+        assert n <= len(os.sched_getaffinity(0))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            assert n <= max(1, int(float(q) / float(per) + 0.5))
+    except (OSError, ValueError):
+        pass
+    assert int(subprocess.check_output([exe, "cpus"], env=dict(env, MASHMAP_HIP_CPUS="3")).split()[0]) == 3
+    if hasattr(os, "sched_setaffinity") and len(os.sched_getaffinity(0)) > 1:
+        one = sorted(os.sched_getaffinity(0))[:1]
+        out = subprocess.check_output(["python3", "-c", "import os,subprocess,sys; os.sched_setaffinity(0, {%d}); sys.stdout.write(subprocess.check_output([%r, 'cpus']).decode())" % (one[0], exe)], env=env)
+        assert int(out.split()[0]) == 1
