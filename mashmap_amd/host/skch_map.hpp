@@ -279,9 +279,9 @@ class Map {
       std::sort(allReadMappings.begin(), allReadMappings.end(), [](const MappingResult& a, const MappingResult& b2) {
         return std::tie(a.querySeqId, a.queryStartPos, a.refSeqId, a.refStartPos) < std::tie(b2.querySeqId, b2.queryStartPos, b2.refSeqId, b2.refStartPos);
       });
-      std::ostringstream os;
-      post.reportReadMappings(allReadMappings, "", os);
-      outstrm << os.str();
+      std::string text;
+      post.appendReadMappings(allReadMappings, "", text);
+      outstrm.write(text.data(), (std::streamsize)text.size());
       if (processMappingResults) for (const auto& e : allReadMappings) processMappingResults(e);
     }
     std::cerr << "[mashmap::skch::Map::mapQuery] count of mapped reads = " << totalReadsMapped
@@ -431,10 +431,10 @@ class Map {
     const unsigned nThreads = pte ? (unsigned)std::max(1, atoi(pte)) : std::min((unsigned)std::max(1, param.threads), mmhost::availableCpus());
     std::atomic<size_t> next(0);
     auto work = [&]() {
-      std::ostringstream os;
+      std::string text;                                    // the chunk's PAF lines (MapPost::appendReadMappings: std::to_chars, no stream)
       MappingResultsVector_t one;
       for (size_t ci = next.fetch_add(1); ci < nChunks; ci = next.fetch_add(1)) {
-        os.str(std::string());
+        text.clear();
         int mappedHere = 0;
         for (size_t r = ci * chunk; r < std::min(nReads, (ci + 1) * chunk); r++) {
           const offset_t len = (offset_t)(batch.in.offs[r + 1] - batch.in.offs[r]);
@@ -443,11 +443,11 @@ class Map {
           post.mapModuleFromRecords(batch.recs.data() + recBegin[r], batch.recs.data() + recBegin[r + 1], len, one);
           if (one.empty()) continue;
           mappedHere++;
-          if (reportNow) post.reportReadMappings(one, batch.in.names[r], os);
+          if (reportNow) post.appendReadMappings(one, batch.in.names[r], text);
           if (keepMaps) chunkMaps[ci].insert(chunkMaps[ci].end(), one.begin(), one.end());
         }
         chunkMapped[ci] = mappedHere;
-        if (reportNow) chunkText[ci] = os.str();
+        if (reportNow) chunkText[ci] = text;
       }
     };
     if (!postPool || postPool->size() != nThreads) postPool.reset(new mmhost::WorkerPool(nThreads));   // persistent: a batch is milliseconds of work

@@ -12,6 +12,7 @@
 #pragma once
 #include <algorithm>
 #include <atomic>
+#include <charconv>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -431,7 +432,9 @@ class MapPost {
   }
 
   // PAF text (:1758-1806); the caller invokes processMappingResults afterwards, in output order
-  void reportReadMappings(MappingResultsVector_t& readMappings, const std::string& queryName, std::ostream& outstrm) const {
+  // computeMap.hpp:1758-1806, literally: one insertion after the other into a stream.  This form is the CHECKER of appendReadMappings
+  // below (tests/test_host_logic.py runs both on the same mappings in every output mode); the pipeline uses the other one.
+  void reportReadMappingsStream(const MappingResultsVector_t& readMappings, const std::string& queryName, std::ostream& outstrm) const {
     for (auto& e : readMappings) {
       const float fakeMapQ = e.nucIdentity == 1 ? 255 : std::round(-10.0 * std::log10(1 - (e.nucIdentity)));
       const std::string sep = param.legacy_output ? " " : "\t";
@@ -450,6 +453,41 @@ class MapPost {
       }
       outstrm << "\n";
     }
+  }
+
+  // The same text appended to a string, field by field with std::to_chars: a stream insertion of a float goes through the locale
+  // machinery (~0.3 us each, three per line), and a million reads a second is what the post stage has to keep up with.  An unformatted
+  // operator<< of a float / double / long double is printf's %g with precision 6, which is chars_format::general with precision 6.
+  void appendReadMappings(const MappingResultsVector_t& readMappings, const std::string& queryName, std::string& out) const {
+    char b[64];
+    auto num = [&](long long v) { const auto r = std::to_chars(b, b + sizeof b, v); out.append(b, r.ptr); };
+    auto flt = [&](auto v) { const auto r = std::to_chars(b, b + sizeof b, v, std::chars_format::general, 6); out.append(b, r.ptr); };
+    const char sep = param.legacy_output ? ' ' : '\t';
+    const int back = param.legacy_output ? 1 : 0;
+    for (const auto& e : readMappings) {
+      const float fakeMapQ = e.nucIdentity == 1 ? 255 : std::round(-10.0 * std::log10(1 - (e.nucIdentity)));
+      out += param.filterMode == filter::ONETOONE ? (*qmetadata)[e.querySeqId].name : queryName;
+      out += sep; num(e.queryLen); out += sep; num(e.queryStartPos); out += sep; num(e.queryEndPos - back);
+      out += sep; out += e.strand == strnd::FWD ? '+' : '-';
+      out += sep; out += metadata[e.refSeqId].name; out += sep; num(metadata[e.refSeqId].len);
+      out += sep; num(e.refStartPos); out += sep; num(e.refEndPos - back);
+      if (!param.legacy_output) {
+        out += sep; num(e.conservedSketches); out += sep; num(e.blockLength); out += sep; flt(fakeMapQ);
+        out += sep; out += "id:f:"; flt((param.report_ANI_percentage ? 100.0 : 1.0) * e.nucIdentity);
+        out += sep; out += "kc:f:"; flt(e.kmerComplexity);
+        if (!param.mergeMappings) { out += sep; out += "jc:f:"; flt(float(e.conservedSketches) / e.sketchSize); }
+      } else {
+        out += sep; flt(e.nucIdentity * 100.0);
+      }
+      out += '\n';
+    }
+  }
+
+  // the reference's name and signature (Map::reportReadMappings): the text goes to a stream
+  void reportReadMappings(MappingResultsVector_t& readMappings, const std::string& queryName, std::ostream& outstrm) const {
+    std::string t;
+    appendReadMappings(readMappings, queryName, t);
+    outstrm.write(t.data(), (std::streamsize)t.size());
   }
 };
 

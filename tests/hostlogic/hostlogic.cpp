@@ -95,4 +95,37 @@ int hl_map_read(int k, int segLength, int sketchSize, float pi, int filterMode, 
   return (int)res.size();
 }
 
+// PAF / legacy text: MapPost::appendReadMappings (std::to_chars, what the pipeline uses) against the literal stream form
+// (reportReadMappingsStream = computeMap.hpp:1758-1806) on n random mappings in every output mode.  Returns the number of modes x
+// batches whose bytes differ.
+int hl_paf_formatters_agree(int n, unsigned long long seed) {
+  auto rnd = [&]() { seed += 0x9E3779B97F4A7C15ull; unsigned long long z = seed; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); };
+  std::vector<skch::ContigInfo> meta{{"chr1", 248956422}, {"contig_with_a_long_name|x", 57}, {"c", 2147483647}};
+  std::vector<skch::ContigInfo> qmeta{{"readA", 10000}, {"read/B 2", 123456}};
+  int bad = 0;
+  for (int mode = 0; mode < 16; mode++) {
+    skch::Parameters p;
+    p.legacy_output = (mode & 1) != 0; p.report_ANI_percentage = (mode & 2) != 0; p.mergeMappings = (mode & 4) == 0;
+    p.filterMode = (mode & 8) ? skch::filter::ONETOONE : skch::filter::MAP;
+    skch::MapPost post(p, meta, std::vector<int>());
+    post.qmetadata = &qmeta;
+    skch::MappingResultsVector_t v((size_t)n);
+    for (auto& e : v) {
+      e.queryLen = (skch::offset_t)(rnd() % 3000000); e.queryStartPos = (skch::offset_t)(rnd() % 100000); e.queryEndPos = e.queryStartPos + (skch::offset_t)(rnd() % 100000);
+      e.refStartPos = (skch::offset_t)(rnd() % 2000000000); e.refEndPos = e.refStartPos + (skch::offset_t)(rnd() % 100000);
+      e.refSeqId = (skch::seqno_t)(rnd() % 3); e.querySeqId = (skch::seqno_t)(rnd() % 2);
+      e.strand = (rnd() & 1) ? skch::strnd::FWD : skch::strnd::REV;
+      e.sketchSize = 1 + (int)(rnd() % 5000); e.conservedSketches = (int)(rnd() % (unsigned)(e.sketchSize + 1)); e.blockLength = (int)(rnd() % 1000000);
+      const unsigned kind = (unsigned)(rnd() % 8);
+      e.nucIdentity = kind == 0 ? 1.0f : kind == 1 ? 0.0f : kind == 2 ? (float)((rnd() % 1000) / 1000.0) : (float)((rnd() % 100000000) / 100000000.0);
+      e.kmerComplexity = kind == 3 ? 1.0L : (long double)(rnd() % 100000) / (long double)(1 + rnd() % 100000);
+    }
+    std::ostringstream os; post.reportReadMappingsStream(v, "the/query name", os);
+    std::string t; post.appendReadMappings(v, "the/query name", t);
+    std::ostringstream os2; post.reportReadMappings(v, "the/query name", os2);
+    if (os.str() != t || os2.str() != t) bad++;
+  }
+  return bad;
+}
+
 }  // extern "C"

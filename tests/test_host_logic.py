@@ -140,3 +140,13 @@ def test_host_logic_paf_text_vs_golden(hl):
         assert len(lines) == len(gi) and all(l.split("\t")[0] == nm and len(l.split("\t")) >= 12 for l in lines)
         total += len(gi)
     assert total >= 30
+
+
+def test_paf_text_by_to_chars_equals_the_stream_form(hl):
+    """MapPost::appendReadMappings (field by field with std::to_chars: what the post stage runs) against reportReadMappingsStream (the
+    reference's insertions into a stream, computeMap.hpp:1758-1806) on random mappings -- identity 0, 1, three-digit and eight-digit
+    values, long double complexities -- in all 16 combinations of legacy / percentage / no-merge / one-to-one output"""
+    hl.hl_paf_formatters_agree.restype = C.c_int
+    hl.hl_paf_formatters_agree.argtypes = [C.c_int, C.c_ulonglong]
+    for seed in (1, 2, 3):
+        assert hl.hl_paf_formatters_agree(20000, seed) == 0
