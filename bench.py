@@ -127,6 +127,27 @@ def write_fasta(path, names, arrays, width=100):
                 f.write(a[full:].tobytes() + b"\n")
 
 
+def usable_cpus():
+    """CPUs this process may use at once: hardware threads, affinity mask, and the container's CPU quota (cgroup v2 cpu.max / v1
+    cfs_quota) -- the GPU boxes show 256 hardware threads and grant 16 CPUs' worth of time; more threads than that get the whole
+    process throttled."""
+    n = os.cpu_count() or 1
+    if hasattr(os, "sched_getaffinity"):
+        n = min(n, len(os.sched_getaffinity(0)) or n)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and per > 0:
+                n = min(n, max(1, int(q / per + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(W, ref_np, reads_np, n_sample):
     """the reference's own CPU path (oracle/_ref/mashmap_ref, built from /root/reference with the GSL stand-in) or, if that binary
     did not travel, our CPU port (oracle/liboracle.so); timed on this box's host cores on a bounded sample of the same workload."""
@@ -183,12 +204,13 @@ def cpu_baseline(W, ref_np, reads_np, n_sample):
                     compute = {"what": "-DENABLE_TIME_PROFILE_L1_L2 build of the reference: per-fragment sketch+L1+L2 seconds, no reader, no pool overhead "
                                        "(SURVEY section 8d(b)); per core, and x host cores as the ideally fed pool", "fragments_parsed": nfr, "sum_fragment_seconds": round(tot, 3),
                                "gbps_per_core": round(n_sample * read_len / tot / 1e9, 5),
-                               "gbps_all_cores_ideal": round(n_sample * read_len / tot / 1e9 * ncores, 3)}
+                               "gbps_all_cores_ideal": round(n_sample * read_len / tot / 1e9 * ncores, 3),
+                               "gbps_usable_cpus_ideal": round(n_sample * read_len / tot / 1e9 * usable_cpus(), 3)}
             if best:
                 tmap, nt = best
                 return {"value": n_sample * read_len / tmap / 1e9, "unit": "Gbp/s", "cores": nt, "kind": "reference",
                         "sample": desc + "; mashmap_ref (built from the reference sources) best of -t 8/32/64 = -t %d of %d host cores, "
-                                         "'time spent mapping the query' (includes its single-threaded FASTA reader)" % (nt, ncores),
+                                         "'time spent mapping the query' (includes its single-threaded FASTA reader); this process may use %d CPUs at once (affinity / container quota)" % (nt, ncores, usable_cpus()),
                         "fragment_compute": compute}
             log("[cpu_baseline] reference binary failed, falling back to the port:", p.stderr[-300:])
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -225,7 +247,7 @@ def host_path(ctx, W, nreads, ref_lens, steps_ms):
     rl = np.full(nreads, W["read_len"], dtype=np.int32)
     threads = os.cpu_count() or 1
     best = None
-    for nt in sorted({min(threads, 32), min(threads, 64), min(threads, 128), threads}):
+    for nt in sorted({min(threads, usable_cpus()), min(threads, 32), min(threads, 64), min(threads, 128), threads}):   # the quota-sized pool first: wider ones are throttled on a capped box
         sec = C.c_double()
         rows = lib.mmh_post_batch(W["k"], W["seg"], W["sketch"], W["pi"], 1, 1, 1, len(clens), clens.ctypes.data, recs.ctypes.data, len(recs),
                                   rl.ctypes.data, nreads, 0, nt, C.byref(sec), None, 0)
@@ -237,7 +259,7 @@ def host_path(ctx, W, nreads, ref_lens, steps_ms):
     return {"what": "packed bases -> reported MappingResult rows on one GPU + host: device pass, D2H of the candidate mappings (48 B each), "
                     "then per read mergeMappingsInRange + filterByGroup + sanity checks (MapPost, the code skch::Map runs) on host threads",
             "candidate_mappings": int(len(recs)), "rows": rows, "device_ms": round(dev_s * 1e3, 3), "download_ms": round(t_dl * 1e3, 3),
-            "host_ms": round(post_s * 1e3, 3), "host_threads": nt, "host_cores": threads,
+            "host_ms": round(post_s * 1e3, 3), "host_threads": nt, "host_cores": threads, "usable_cpus": usable_cpus(),
             "gbps_serial": round(bases / (dev_s + t_dl + post_s) / 1e9, 3),
             "gbps_pipelined": round(bases / max(dev_s, t_dl + post_s) / 1e9, 3),
             "note": "skch::Map overlaps the host stage of batch i with the device stage of batch i+1 (pipelined); serial = no overlap"}
