@@ -598,10 +598,17 @@ def main():
             "roofline": roofline,
             "kernels": kernels,
         }
+        # the two side measurements never take the headline with them
         if world == 1 and not args.no_host_path:
-            out["host_path"] = host_path(ctx, W, nreads, ref_lens, step_ms)
+            try:
+                out["host_path"] = host_path(ctx, W, nreads, ref_lens, step_ms)
+            except Exception as e:
+                log("[bench] host_path failed:", repr(e)); out["host_path"] = {"error": repr(e)}
         if want_cpu:
-            out["cpu_baseline"] = cpu_baseline(W, ref_np, reads_np, min(args.cpu_sample, nreads))
+            try:
+                out["cpu_baseline"] = cpu_baseline(W, ref_np, reads_np, min(args.cpu_sample, nreads))
+            except Exception as e:
+                log("[bench] cpu_baseline failed:", repr(e)); out["cpu_baseline"] = {"error": repr(e)}
         if is_default and world == 1 and not args.no_north_star:
             # in a process of its own, after this one has let go of its index and reads: whatever happens there, the headline line is printed
             ctx.close(); ctx = None
