@@ -271,6 +271,19 @@ int mm_index_build(mm_ctx* ctx, const char* bases, const int64_t* contigOffsets,
 int mm_index_sizes(const mm_ctx* ctx, size_t* nMinmers, size_t* nKeys, size_t* nPoints, size_t* nFreq, int32_t* freqThreshold);
 int mm_index_download(mm_ctx* ctx, mm_minmer* minmers, uint64_t* keys, uint64_t* offsets, mm_interval_point* points,
                       uint64_t* freqSeeds);
+/* how the resident index lies in HBM: what stands in for minmerPosLookupIndex (winSketch.hpp:101) -- the
+ * open-addressing seed table, whether it is the tagged layout the library picks for tables above 1 GiB (one tag byte per slot, keys
+ * placed bucket-wise), the presence filter in front of it -- and for minmerIndex (:102): the merged insert / eviction event stream and
+ * the per-block lists of open records.  Lets a caller (and the human-scale parity tests) see which lookup kernel variant a map call
+ * will run. */
+typedef struct {
+  uint64_t seedTableSlots, seedTableBytes;   /* slots of 16 bytes */
+  uint64_t tagBytes;                         /* 0 unless tagged */
+  uint64_t filterBytes;                      /* 0: no presence filter */
+  uint64_t events, openRecords;              /* entries of the event stream / of the open-record lists */
+  int32_t  tagged, pad_;
+} mm_index_layout;
+int mm_index_layout_get(const mm_ctx* ctx, mm_index_layout* out);
 
 /*
  * Index persistence (winSketch.hpp:284-374).  mm_index_download_full: the pre-drop minmerIndex (PREFIX.index); the lookup map of

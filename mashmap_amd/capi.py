@@ -124,6 +124,7 @@ def load():
         "mm_pack_read": (sz, [vp, sz, vp, vp]),
         "mm_pack_read_portable": (sz, [vp, sz, vp, vp]),
         "mm_reads_packed_download": (C.c_int, [vp, vp, vp, vp, C.POINTER(sz)]),
+        "mm_index_layout_get": (C.c_int, [vp, vp]),
         "mm_synchronize": (C.c_int, [vp]),
         "mm_stream": (vp, [vp]),
     }
@@ -147,7 +148,8 @@ EXPORTS = ["mm_abi_version", "mm_create", "mm_destroy", "mm_last_error", "mm_ind
            "mm_comm_init_rank", "mm_comm_init_local", "mm_comm_world", "mm_allgatherv_mappings", "mm_allgatherv_mappings_local",
            "mm_allgatherv_mappings_begin", "mm_allgatherv_mappings_end",
            "mm_gathered_counts", "mm_gathered_download", "mm_gathered_device", "mm_index_replicate", "mm_stat_replay_tables", "mm_host_alloc", "mm_host_free", "mm_reads_prefetch",
-           "mm_reads_upload_packed", "mm_reads_prefetch_packed", "mm_pack_read", "mm_pack_read_portable", "mm_reads_packed_download"]
+           "mm_reads_upload_packed", "mm_reads_prefetch_packed", "mm_pack_read", "mm_pack_read_portable", "mm_reads_packed_download",
+           "mm_index_layout_get"]
 
 
 def stat_sketch_cutoffs(sketchSize, k, hg=True):
@@ -248,6 +250,14 @@ class Context:
         buf = np.concatenate(contigs) if len(contigs) else np.zeros(0, dtype=np.uint8)
         rg = np.ascontiguousarray(refGroup, dtype=np.int32) if refGroup is not None else None
         self._ck(self.lib.mm_index_build(self.h, _ptr(buf), _ptr(offs), len(contigs), _ptr(rg), kmerPct), "mm_index_build")
+
+    def index_layout(self):
+        """mm_index_layout_get as a dict (seedTableSlots, seedTableBytes, tagBytes, filterBytes, events, openRecords, tagged)"""
+        a = np.zeros(7, dtype=np.uint64)
+        self._ck(self.lib.mm_index_layout_get(self.h, _ptr(a)), "mm_index_layout_get")
+        d = dict(zip(("seedTableSlots", "seedTableBytes", "tagBytes", "filterBytes", "events", "openRecords"), (int(x) for x in a[:6])))
+        d["tagged"] = int(a[6] & 0xFFFFFFFF)
+        return d
 
     def index_download(self):
         n = [C.c_size_t() for _ in range(4)]; ft = C.c_int32()

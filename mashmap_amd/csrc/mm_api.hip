@@ -435,6 +435,17 @@ int mm_index_sizes(const mm_ctx* c, size_t* nMinmers, size_t* nKeys, size_t* nPo
   return MM_OK;
 }
 
+int mm_index_layout_get(const mm_ctx* c, mm_index_layout* o) {
+  if (!c->idx.ready || !o) return MM_ERR_STATE;
+  const DeviceIndex& I = c->idx;
+  o->seedTableSlots = I.htCap; o->seedTableBytes = (uint64_t)I.htCap * 16;
+  o->tagged = I.tagged ? 1 : 0; o->pad_ = 0;
+  o->tagBytes = I.tagged ? (uint64_t)I.htCap : 0;
+  o->filterBytes = I.filterMask ? (I.filterMask + 1) * 8 : 0;
+  o->events = 2 * (uint64_t)I.nRec; o->openRecords = I.nOpen;
+  return MM_OK;
+}
+
 int mm_index_download(mm_ctx* c, mm_minmer* minmers, uint64_t* keys, uint64_t* offsets, mm_interval_point* points, uint64_t* freqSeeds) {
   if (!c->idx.ready) { c->err = "mm_index_download: no index resident"; return MM_ERR_STATE; }
   if (c->idx.keys.bytes == 0 && c->idx.nKeys) { c->err = "mm_index_download: this context holds a replica (mm_index_replicate); ask the context the index was built on"; return MM_ERR_STATE; }

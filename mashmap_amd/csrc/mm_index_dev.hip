@@ -418,7 +418,7 @@ int mm_flatten_device_index(mm_ctx* c, const mm_minmer* dRec, size_t n, size_t n
   if (hd[3] & 1ull) { c->err = "mm_index_upload: a non-frequent seed with 2^23 or more interval points (or 2^40 points in total) does not fit the packed table value"; return MM_ERR_ARG; }
   if (hd[3] & 2ull) { c->err = "mm_index_upload: duplicate key"; return MM_ERR_ARG; }
   I.filterMask = fbits ? fbits / 64 - 1 : 0;                                   // word mask
-  I.nRec = n; I.nKeys = nk; I.nPoints = np; I.nContigs = nContigs; I.htCap = cap; I.ready = true;
+  I.nRec = n; I.nKeys = nk; I.nPoints = np; I.nContigs = nContigs; I.htCap = cap; I.nOpen = (size_t)nOpen; I.ready = true;
   return MM_OK;
 }
 

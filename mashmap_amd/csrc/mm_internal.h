@@ -41,7 +41,7 @@ struct DFrag {
 #define MM_OPEN_BLOCK_SHIFT 10
 
 struct DeviceIndex {
-  size_t nRec = 0, nKeys = 0, nPoints = 0, nContigs = 0, htCap = 0;
+  size_t nRec = 0, nKeys = 0, nPoints = 0, nContigs = 0, htCap = 0, nOpen = 0;
   // minmerIndex as the L2 event stream (see mm_build_device_index): per contig, one insert event per record at wpos and one
   // eviction event at wpos_end, merged by position
   DevBuf evKey;                // uint32 pos*2 + isInsert

@@ -32,6 +32,7 @@ class Sketch {
   const skch::Parameters& param;
   int freqThreshold = std::numeric_limits<int>::max();
   std::vector<hash_t> frequentSeeds;               // ascending
+  size_t nMinmers_ = 0;                            // |minmerIndex| on the device (after the frequent-seed drop)
   mm_ctx* ctx_ = nullptr;                          // the context the index is built on (first device of the list)
   std::vector<mm_ctx*> ctxs_;                      // one per entry of MASHMAP_HIP_DEVICES; ctxs_[0] == ctx_
   Sketch();
@@ -120,11 +121,19 @@ class Sketch {
 
   int getFreqThreshold() const { return freqThreshold; }
   bool isFreqSeed(hash_t h) const { return std::binary_search(frequentSeeds.begin(), frequentSeeds.end(), h); }
+  // minmerIndex (winSketch.hpp:102) lives on the device; the host copy in reference layout is made on first use
+  void materializeMinmerIndex() {
+    if (minmerIndex.size() == nMinmers_) return;
+    minmerIndex.resize(nMinmers_);
+    if (nMinmers_ && mm_index_download(ctx_, reinterpret_cast<mm_minmer*>(minmerIndex.data()), nullptr, nullptr, nullptr, nullptr) != MM_OK) die("mm_index_download");
+  }
+  size_t minmerIndexSize() const { return nMinmers_; }
   MIIter_t searchIndex(seqno_t seqId, offset_t winpos) const {
+    const_cast<Sketch*>(this)->materializeMinmerIndex();
     return std::lower_bound(minmerIndex.begin(), minmerIndex.end(), MinmerInfo{0, winpos, 0, seqId, 0});
   }
   bool isMinmerIndexEnd(const MIIter_t& it) const { return it == minmerIndex.end(); }
-  MIIter_t getMinmerIndexEnd() const { return minmerIndex.end(); }
+  MIIter_t getMinmerIndexEnd() const { const_cast<Sketch*>(this)->materializeMinmerIndex(); return minmerIndex.end(); }
 
   // the hash -> interval points map of winSketch.hpp:100-101 on the host (only callers outside the device path need it)
   void materializeLookupIndex() {
@@ -290,12 +299,20 @@ class Sketch {
     releaseParts();
     size_t nM, nK, nP, nF; int32_t ft;
     if (mm_index_sizes(ctx_, &nM, &nK, &nP, &nF, &ft) != MM_OK) die("mm_index_sizes");
-    minmerIndex.resize(nM);
     frequentSeeds.resize(nF);
-    if (mm_index_download(ctx_, reinterpret_cast<mm_minmer*>(minmerIndex.data()), nullptr, nullptr, nullptr, frequentSeeds.data()) != MM_OK)
-      die("mm_index_download");
+    if (mm_index_download(ctx_, nullptr, nullptr, nullptr, nullptr, frequentSeeds.data()) != MM_OK) die("mm_index_download");
     std::sort(frequentSeeds.begin(), frequentSeeds.end());
     freqThreshold = ft;
+    nMinmers_ = nM;
+    // minmerIndex in reference layout is 24 bytes per record (8.7 GB for a 3 Gbp reference) that nothing on the device path reads: it is
+    // brought back from the device when somebody asks (materializeMinmerIndex / searchIndex), or right away with MASHMAP_HIP_EAGER_INDEX=1
+    if (getenv("MASHMAP_HIP_EAGER_INDEX")) materializeMinmerIndex();
+    if (getenv("MASHMAP_HIP_TIMING")) {
+      mm_index_layout lay;
+      if (mm_index_layout_get(ctx_, &lay) == MM_OK)
+        std::cerr << "[mashmap_hip::timing] index layout: seed table " << lay.seedTableSlots << " slots (" << (lay.seedTableBytes >> 20) << " MiB), tagged=" << lay.tagged
+                  << ", tag bytes " << lay.tagBytes << ", filter bytes " << lay.filterBytes << ", events " << lay.events << ", open records " << lay.openRecords << std::endl;
+    }
     std::cerr << "[mashmap::skch::Sketch::build] minmer windows picked from reference (after frequent-seed removal) = " << nM << std::endl;
     std::cerr << "[mashmap::skch::Sketch::index] unique minmers = " << nK << std::endl;
     if (nF == 0) std::cerr << "[mashmap::skch::Sketch::computeFreqHist] With threshold " << param.kmer_pct_threshold

@@ -18,7 +18,7 @@ def pytest_collection_finish(session):
     in the same process as the ones that only need the library, in any order the caller picks: bring torch's device up first."""
     if not any(item.get_closest_marker("gpu") for item in session.items):
         return
-    if not any("fullsize" in item.nodeid or "bench" in item.nodeid for item in session.items):
+    if not any("fullsize" in item.nodeid or "bench" in item.nodeid or "humanscale" in item.nodeid for item in session.items):
         return                                              # nothing selected imports torch on the GPU: spare the import
     try:
         import torch

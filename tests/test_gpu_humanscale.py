@@ -1,0 +1,157 @@
+"""Parity at human scale, where other code runs than in the small cases: a 3 Gbp reference indexed on the device (the tagged seed
+table above 1 GiB -> k_lookup_l1<.., true>, ~14 GB of open-record lists, candidates located in reference order), mapped through the
+`mashmap_hip` command line and compared BYTE FOR BYTE with the PAF of the stock binary (oracle/_ref/mashmap_ref: the reference's own
+sources, compiled by oracle/Makefile; it travels to the GPU box like the library does) on the same FASTA files:
+
+  * the north_star target workload: 10 kbp ONT-like reads, defaults (pi 85, segLength 5000), also sharded over two contexts
+    (MASHMAP_HIP_DEVICES=0,0);
+  * the BASELINE configs[2] shape: assembly contigs vs the reference, --pi 95 -s 10000 -f one-to-one (a reduced query);
+  * the BASELINE configs[4] shape: --dense --pi 80, 20 kbp reads at 15-20 % error, the reference as an --rl list of 10 files.
+
+What is matched: Map::mapQuery end to end (computeMap.hpp:263-413) with the parameters parseCmdArgs.hpp:620-641 derives.
+The reference sequence is generated once and shared by the three cases; the stock binary indexes 3 Gbp in ~1.5 minutes per case on
+the GPU box's 16 CPUs, which is what this module's run time consists of.  MASHMAP_TEST_HUMAN_GBP scales the reference (default 3),
+MASHMAP_TEST_HUMAN_READS the read sets."""
+import os
+import re
+import shutil
+import subprocess
+import sys
+import time
+
+import numpy as np
+import pytest
+
+import mmutil as U
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIP_BIN = os.path.join(ROOT, "mashmap_amd", "lib", "mashmap_hip")
+GBP = float(os.environ.get("MASHMAP_TEST_HUMAN_GBP", "3"))
+SCALE = float(os.environ.get("MASHMAP_TEST_HUMAN_READS", "1"))
+N_CONTIGS, N_FILES = 30, 10                      # 30 contigs of 100 Mbp; the --rl list holds three of them per file
+N_READS_NS, N_READS_C4, N_ASM = int(30000 * SCALE), int(6000 * SCALE), max(4, int(40 * SCALE))
+ASM_LEN = 5_000_000
+
+
+def _threads():
+    sys.path.insert(0, ROOT)
+    import bench as B
+    return str(max(4, min(32, 2 * B.usable_cpus())))
+
+
+@pytest.fixture(scope="module")
+def human(tmp_path_factory):
+    if not os.path.exists(U.REF_BIN):
+        pytest.skip("oracle/_ref/mashmap_ref (the stock binary) is not here: it is built where /root/reference exists and shipped by gpurun")
+    assert os.path.exists(HIP_BIN), "mashmap_hip not built (python -c 'import __graft_entry__ as g; g.build()')"
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench as B
+    dev = torch.device("cuda", 0)
+    td = str(tmp_path_factory.mktemp("human"))
+    t0 = time.time()
+    clen = int(GBP * 1e9) // N_CONTIGS
+    contigs = B.make_reference(torch, dev, N_CONTIGS, clen)
+    names = ["chr%d" % i for i in range(N_CONTIGS)]
+    ref_fa = os.path.join(td, "ref.fa")
+    rl = os.path.join(td, "refs.txt")
+    per = N_CONTIGS // N_FILES
+    with open(ref_fa, "wb") as whole, open(rl, "w") as lst:
+        for fi in range(N_FILES):
+            part = os.path.join(td, "ref_part%d.fa" % fi)
+            B.write_fasta(part, names[fi * per:(fi + 1) * per], [contigs[i].cpu().numpy() for i in range(fi * per, (fi + 1) * per)])
+            lst.write(part + "\n")
+            with open(part, "rb") as p:
+                shutil.copyfileobj(p, whole, 64 << 20)
+
+    def reads_fasta(path, n, length, err, seed):
+        rd = B.make_reads(torch, dev, contigs, n, length, err, seed=seed).cpu().numpy().reshape(n, length)
+        B.write_fasta(path, ["read%d" % i for i in range(n)], list(rd), width=length)
+
+    ns_fa, c4_fa, asm_fa = (os.path.join(td, x) for x in ("reads_ns.fa", "reads_c4.fa", "asm.fa"))
+    reads_fasta(ns_fa, N_READS_NS, 10000, (0.10, 0.10), 1000)
+    reads_fasta(c4_fa, N_READS_C4, 20000, (0.15, 0.20), 2000)
+    # "assembly": pieces of the reference with 1 % substitutions, every third one reverse-complemented, one with a gap of Ns
+    g = torch.Generator(device=dev); g.manual_seed(77)
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    comp = torch.zeros(256, dtype=torch.uint8, device=dev)
+    for a, b in zip(b"ACGT", b"TGCA"):
+        comp[a] = b
+    asm = []
+    for i in range(N_ASM):
+        ci = (i * 7) % N_CONTIGS
+        st = int(torch.randint(0, clen - ASM_LEN, (1,), generator=g, device=dev))
+        c = contigs[ci][st:st + ASM_LEN].clone()
+        m = torch.rand(ASM_LEN, generator=g, device=dev) < 0.01
+        c = torch.where(m, lut[torch.randint(0, 4, (ASM_LEN,), generator=g, device=dev)], c)
+        if i % 3 == 2:
+            c = comp[c.flip(0).long()]
+        if i == 1:
+            c[ASM_LEN // 2:ASM_LEN // 2 + 50000] = ord("N")
+        asm.append(c.cpu().numpy())
+    B.write_fasta(asm_fa, ["ctg%d" % i for i in range(N_ASM)], asm)
+    del contigs, asm
+    torch.cuda.empty_cache()
+    print("\n[human scale] %.2f Gbp reference in %d contigs (+ %d --rl files), %d + %d reads, %d assembly contigs written in %.0f s"
+          % (GBP, N_CONTIGS, N_FILES, N_READS_NS, N_READS_C4, N_ASM, time.time() - t0), flush=True)
+    yield dict(td=td, ref=ref_fa, rl=rl, ns=ns_fa, c4=c4_fa, asm=asm_fa, threads=_threads())
+    shutil.rmtree(td, ignore_errors=True)
+
+
+def _run(exe, args, out, env=None):
+    t0 = time.time()
+    e = dict(os.environ, MASHMAP_HIP_TIMING="1")
+    if env:
+        e.update(env)
+    p = subprocess.run([exe] + args + ["-o", out], capture_output=True, text=True, env=e)
+    assert p.returncode == 0, "%s %s\n%s" % (exe, " ".join(args), p.stderr[-3000:])
+    tm = {k.split()[0]: float(v) for k, v in re.findall(r"time spent (computing the reference index|mapping the query)\s*:\s*([0-9.eE+-]+)", p.stderr)}
+    return open(out, "rb").read(), p.stderr, time.time() - t0, tm
+
+
+def _diff(a, b):
+    la, lb = a.decode().splitlines(), b.decode().splitlines()
+    for i, (x, y) in enumerate(zip(la, lb)):
+        if x != y:
+            return "line %d:\n  got %s\n  exp %s\n(%d vs %d lines)" % (i, x, y, len(la), len(lb))
+    return "%d vs %d lines; first extra: %s" % (len(la), len(lb), (la[len(lb):] or lb[len(la):])[:1])
+
+
+def _tagged(stderr):
+    m = re.search(r"index layout: seed table (\d+) slots \((\d+) MiB\), tagged=(\d)", stderr)
+    assert m, "no index layout line in the MASHMAP_HIP_TIMING log:\n" + stderr[-1500:]
+    return int(m.group(3)) == 1, int(m.group(2))
+
+
+def _case(human, name, args, min_lines, sharded=False):
+    td = human["td"]
+    full = args + ["-t", human["threads"]]
+    got, err, wall_h, tm_h = _run(HIP_BIN, full, os.path.join(td, name + ".hip.paf"))
+    tagged, mib = _tagged(err)
+    if GBP >= 1.0:
+        assert tagged and mib > 1024, "the tagged seed table (k_lookup_l1<.., true>) is not in use at this scale: %d MiB, tagged=%s" % (mib, tagged)
+    exp, _, wall_r, tm_r = _run(U.REF_BIN, full, os.path.join(td, name + ".ref.paf"))
+    print("\n[human scale] %s: mashmap_hip %.1f s %s | stock binary %.1f s %s | %d PAF lines, seed table %d MiB tagged=%s"
+          % (name, wall_h, tm_h, wall_r, tm_r, exp.count(b"\n"), mib, tagged), flush=True)
+    assert exp.count(b"\n") >= min_lines, "the stock binary mapped only %d lines" % exp.count(b"\n")
+    assert got == exp, _diff(got, exp)
+    if sharded:
+        got2, err2, wall2, _ = _run(HIP_BIN, full, os.path.join(td, name + ".hip2.paf"), env={"MASHMAP_HIP_DEVICES": "0,0"})
+        print("[human scale] %s sharded over two contexts: %.1f s" % (name, wall2), flush=True)
+        assert got2 == exp, "MASHMAP_HIP_DEVICES=0,0: " + _diff(got2, exp)
+
+
+def test_north_star_target_defaults(human):
+    """10 kbp reads, pi 85, segLength 5000 (the stock binary derives sketchSize 310 for the 3 GB file); one context, then two"""
+    _case(human, "northstar", ["-r", human["ref"], "-q", human["ns"]], int(0.9 * N_READS_NS), sharded=True)
+
+
+def test_configs2_shape_one_to_one(human):
+    """assembly vs reference: --pi 95 -s 10000 -f one-to-one"""
+    _case(human, "configs2", ["-r", human["ref"], "-q", human["asm"], "--pi", "95", "-s", "10000", "-f", "one-to-one"], N_ASM)
+
+
+def test_configs4_shape_dense_reference_list(human):
+    """--dense --pi 80, 20 kbp reads at 15-20 % error, --rl list of 10 reference files sharing one seqId space (winSketch.hpp:174-214)"""
+    _case(human, "configs4", ["--rl", human["rl"], "-q", human["c4"], "--dense", "--pi", "80"], int(0.8 * N_READS_C4))
