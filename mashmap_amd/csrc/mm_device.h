@@ -153,6 +153,59 @@ __host__ __device__ __forceinline__ uint64_t mm_filter_word(uint64_t h, uint64_t
 #define MM_TAG_BUCKET 16
 __host__ __device__ __forceinline__ uint32_t mm_seed_tag(uint64_t h) { const uint32_t t = (uint32_t)(h >> 29) & 0xFFu; return t ? t : 0xA7u; }
 
+struct HtSlot { uint64_t key, val; };                          // one 16-byte slot: a probe costs one memory sector
+#define MM_HT_EMPTY 0xFFFFFFFFFFFFFFFFULL
+// tag bytes of one bucket of the tagged seed table (mm_internal.h: htTags) against the tag of a query seed: cand16 = slots whose tag
+// equals it (a set bit above a matching or empty byte of the same 4-byte word may be spurious -- candidates are verified against the
+// slot's key anyway), hasEmpty = the bucket still has a free slot, i.e. no key of this bucket lives further on
+__device__ __forceinline__ void mm_tag_scan(uint4 t, uint32_t tag, uint32_t& cand16, bool& hasEmpty) {
+  const uint32_t rep = tag * 0x01010101u;
+  const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+  uint32_t c = 0, e = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const uint32_t x = w[i] ^ rep;
+    const uint32_t zc = (x - 0x01010101u) & ~x & 0x80808080u;          // zero bytes of x: bit 7 of the byte
+    c |= ((((zc >> 7) * 0x00204081u) >> 21) & 0xFu) << (4 * i);          // the four flags side by side
+    e |= (w[i] - 0x01010101u) & ~w[i] & 0x80808080u;
+  }
+  cand16 = c; hasEmpty = e != 0;
+}
+
+// The seed table as a kernel argument, and the look-up of ONE hash in it: the table value (offset << 24 | count << 1 | isFrequent,
+// never 0 for a key that is present) or 0.  k_lookup_l1 (mm_map.hip) has its own form with four probes per lane in flight; this one
+// serves the sketch kernel, which probes a fragment's sketch right where it emits it (MM_SKETCH_PROBE).
+struct SeedTable { const HtSlot* ht; uint64_t mask; const uint64_t* filter; uint64_t filterMask; const uint8_t* tags; };
+__device__ __forceinline__ uint64_t mm_seed_probe(const SeedTable& T, uint64_t h) {
+  if (T.tags) {
+    uint64_t b = (h & T.mask) & ~(uint64_t)(MM_TAG_BUCKET - 1);
+    const uint32_t tag = mm_seed_tag(h);
+    for (;;) {
+      uint32_t cd; bool em;
+      mm_tag_scan(*(const uint4*)(T.tags + b), tag, cd, em);
+      while (cd) {
+        const uint32_t i = (uint32_t)__builtin_ctz(cd); cd &= cd - 1u;
+        const HtSlot x = T.ht[b + i];
+        if (x.key == h) return x.val;
+      }
+      if (em) return 0ull;
+      b = (b + MM_TAG_BUCKET) & T.mask;
+    }
+  }
+  if (T.filterMask) { const uint64_t fb = mm_filter_bits(h); if ((T.filter[mm_filter_word(h, T.filterMask)] & fb) != fb) return 0ull; }
+  uint64_t slot = h & T.mask;
+  for (;;) {
+    const HtSlot x = T.ht[slot];
+    if (x.key == h) return x.val;
+    if (x.key == MM_HT_EMPTY) return 0ull;
+    slot = (slot + 1) & T.mask;
+  }
+}
+// where the sketch kernel leaves what it found: per fragment `stride` 64-bit words in pre -- word 0: 1 = this fragment has been probed
+// (fragments of the hard list are not), words 1.. : bit r of the concatenation = sketch entry r is in the table -- and in val, at
+// f * s, the table values of the entries that are, in sketch order
+struct SeedPre { uint64_t* pre; uint64_t* val; int stride; };
+
 // ---------------------------------------------------------------------------------------------
 // Strip hasher.  For K = 17..19 (one 16-byte block + a tail of K-16 <= 3 bytes; K = 19 is MashMap's default) the tail has
 // at most 64 values, so its complete mix (k1*C1, rotl 31, *C2) comes from a 64-entry LDS table indexed by the 2-bit codes:

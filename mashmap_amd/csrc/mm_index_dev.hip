@@ -24,8 +24,7 @@
 #include <cstdlib>
 #include <cstring>
 
-#define MM_EMPTY 0xFFFFFFFFFFFFFFFFULL
-struct HtSlot { uint64_t key, val; };
+#define MM_EMPTY MM_HT_EMPTY
 
 #define K_LAUNCH(kern, n, ...) hipLaunchKernelGGL(kern, dim3((unsigned)(((n) + 255) / 256)), dim3(256), 0, c->stream, __VA_ARGS__)
 

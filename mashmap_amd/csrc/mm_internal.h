@@ -99,7 +99,9 @@ struct mm_ctx {
   DevBuf dSkHash, dSkPos, dSkStrand, dSkCount;          // [nFrags*s] u64, int2, i8 ; [nFrags] u32
   DevBuf dHardList, dCounters, dSketchSpill;            // dSketchSpill: first / last / strand-sum arrays of k_sketch_hard<K, true> (large sketches)
   DevBuf dSketchTabs; int sketchTabsK = 0;        // strip-hasher tables for kmerSize sketchTabsK (built once, copied into LDS by every workgroup)
-  DevBuf dQHash, dQStrand, dSeedVal;                    // post-removal sketch + per-seed lookup value
+  DevBuf dQHash, dQStrand;                              // post-removal sketch (written only for fragments that lose a frequent seed)
+  // MM_SKETCH_PROBE: the sketch kernel looks a fragment's sketch up in the seed table where it emits it (mm_device.h: SeedPre)
+  DevBuf dPre, dPreVal; size_t preStride = 0; bool preProbed = false;
   DevBuf dStats;                                        // mm_frag_stats[nFrags]
   DevBuf dPtOff, dPts; size_t ptsCap = 0;               // per-fragment offset (int64) + sorted keys
   // --noSplit with reads longer than segLength (windowLen != 0, computeMap.hpp:933): the literal kernels' state
@@ -157,7 +159,7 @@ int mm_check_params(const mm_params* p, std::string& err);
 int mm_launch_pack(mm_ctx* c);
 int mm_launch_pack_raw(mm_ctx* c, const uint8_t* dAscii, const int64_t* dSrcOff, const int64_t* dPackOff, const int32_t* dLen, int nReads,
                        int64_t nChunks, uint32_t* dB, uint32_t* dM, uint32_t* dHasN);
-int mm_launch_sketch(mm_ctx* c);
+int mm_launch_sketch(mm_ctx* c, bool withProbe = false);   // withProbe: look the sketches up in the resident seed table as well (MM_SKETCH_PROBE)
 int mm_launch_map(mm_ctx* c);
 int mm_launch_select(mm_ctx* c);
 void mm_comm_release(mm_ctx* c);

@@ -14,7 +14,7 @@
 #include <cstring>
 #include <numeric>
 
-#define MM_EMPTY 0xFFFFFFFFFFFFFFFFULL
+#define MM_EMPTY MM_HT_EMPTY
 
 // ---------------------------------------------------------------------------------------------
 // host: flatten the reference index
@@ -96,7 +96,6 @@ __device__ __forceinline__ uint64_t mm_shfl_down64(uint64_t v, int d) {    // d 
 }
 
 struct MapFlags { int hg, skipSelf, skipPrefix, lowerTri; };
-struct HtSlot { uint64_t key, val; };                          // one 16-byte slot: a probe costs one memory sector
 
 // ascending bitonic sort of 64*R keys held R per lane (R a power of two), element index = lane*R + r
 template <int R>
@@ -143,13 +142,14 @@ struct FuseScratchT {
 
 // Interval points of the fragment's surviving seeds -> dst[0..P) (skip_self / skip_prefix / lower_triangular applied,
 // computeMap.hpp:891-896; dropped points become MM_EMPTY and sort to the end).  Returns the wave-wide count of kept points.
-// ids (may be null): the seed every point came from, as a small number unique inside the fragment (round * 64 + lane) -- what the
+// ids (may be null): the seed every point came from, as a small number unique inside the fragment (its index in the raw sketch) -- what the
 // windowLen != 0 sweep counts open windows per hash by (computeMap.hpp:950: hash_to_freq)
+// done: points already at dst (updated); rdBase: number of the first round (a sketch probed in several batches calls this per batch)
 template <class Dst, class ValAt>
-__device__ __forceinline__ int mm_gather_points(Dst dst, int nRounds, ValAt&& valAt,
+__device__ __forceinline__ int mm_gather_points(Dst dst, int& done, int rdBase, int nRounds, ValAt&& valAt,
                                                 const uint64_t* __restrict__ ptKeys, const int32_t* __restrict__ refGroup,
                                                 int rg, int self, int seqCounter, MapFlags fl, int lane, uint16_t* __restrict__ ids = nullptr) {
-  int nValid = 0, done = 0;
+  int nValid = 0;
   for (int rd = 0; rd < nRounds; rd++) {
     const uint64_t val = valAt(rd);                // table value of this lane's seed in round rd (0: none)
     const int c = (int)((val >> 1) & 0x7fffffull);
@@ -164,7 +164,7 @@ __device__ __forceinline__ int mm_gather_points(Dst dst, int nRounds, ValAt&& va
       if (fl.lowerTri && !(seqCounter > seqId)) drop = true;
       if (drop) key = MM_EMPTY; else nValid++;
       dst[my + j] = key;
-      if (ids) ids[my + j] = (uint16_t)(rd * 64 + lane);
+      if (ids) ids[my + j] = (uint16_t)((rdBase + rd) * 64 + lane);
     }
     done += mm_wave_sum(c);
   }
@@ -292,23 +292,6 @@ __device__ __forceinline__ int mm_l1_fused(uint64_t (&k)[R], FuseScratch& sc, in
 //   * otherwise (many points, -Y groups, a position group spanning contigs, or keepPoints for the parity API): reserves
 //     slots in the global point buffer, gathers there and queues the fragment for k_sort_points_* + k_l1_sweep.
 // ---------------------------------------------------------------------------------------------
-// tag bytes of one bucket of the tagged seed table (mm_internal.h: htTags) against the tag of a query seed: cand16 = slots whose tag
-// equals it (a set bit above a matching or empty byte of the same 4-byte word may be spurious -- candidates are verified against the
-// slot's key anyway), hasEmpty = the bucket still has a free slot, i.e. no key of this bucket lives further on
-__device__ __forceinline__ void mm_tag_scan(uint4 t, uint32_t tag, uint32_t& cand16, bool& hasEmpty) {
-  const uint32_t rep = tag * 0x01010101u;
-  const uint32_t w[4] = {t.x, t.y, t.z, t.w};
-  uint32_t c = 0, e = 0;
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const uint32_t x = w[i] ^ rep;
-    const uint32_t zc = (x - 0x01010101u) & ~x & 0x80808080u;          // zero bytes of x: bit 7 of the byte
-    c |= ((((zc >> 7) * 0x00204081u) >> 21) & 0xFu) << (4 * i);          // the four flags side by side
-    e |= (w[i] - 0x01010101u) & ~w[i] & 0x80808080u;
-  }
-  cand16 = c; hasEmpty = e != 0;
-}
-
 #define MM_LOOKUP_WPB 4             // waves (= fragments) per workgroup
 #define MM_L1_REGIONS 64            // L1 output cursors: a same-address atomic costs ~10 ns, so fragments spread over 64 of them
 #define MM_L1_CURSOR_STRIDE 32      // u64 words between cursors (256 bytes)
@@ -319,7 +302,7 @@ k_lookup_l1(int nFrags, int s, const DFrag* __restrict__ frags,
             const HtSlot* __restrict__ ht, uint64_t htMask, const uint64_t* __restrict__ filter, uint64_t filterMask, const uint8_t* __restrict__ tags,
             const uint64_t* __restrict__ ptKeys, const int32_t* __restrict__ refGroup,
             const int32_t* __restrict__ readGroup, const int32_t* __restrict__ readSelf, int seqCounterBase, MapFlags fl, int keepPoints,
-            uint64_t* __restrict__ qHash, int8_t* __restrict__ qStrand, uint64_t* __restrict__ seedVal,
+            uint64_t* __restrict__ qHash, int8_t* __restrict__ qStrand, const uint64_t* __restrict__ pre, const uint64_t* __restrict__ preVal, int preStride,
             mm_frag_stats* __restrict__ stats, int64_t* __restrict__ ptOff, uint64_t* __restrict__ pts, uint16_t* __restrict__ ptIds /* keepPoints == 2 */, unsigned long long ptsCap,
             const int32_t* __restrict__ minHitsTab, const int32_t* __restrict__ cutoffs, int nCutoffs, int segLength,
             mm_l1_candidate* __restrict__ l1, unsigned long long regionCap, unsigned long long* __restrict__ l1Cursors,
@@ -357,8 +340,25 @@ k_lookup_l1(int nFrags, int s, const DFrag* __restrict__ frags,
     if (drop) key = MM_EMPTY; else nValid++;
     sc.a[at] = key;
   };
-  for (int base = 0; base < cnt; base += 256) {
-    uint64_t h[4], val[4]; bool act[4], found[4], open[4];
+  // the sketch kernel has probed this fragment already (MM_SKETCH_PROBE): found masks + the values of the found entries, in sketch order
+  const bool usePre = pre != nullptr && pre[(size_t)f * preStride] == 1ull;    // wave-uniform
+  int preRun = 0;                                                  // found entries before the batch being read (reset before every pass over the batches)
+  // the table values of the sketch entries [base, base + 256), four per lane: found[u] / val[u] for entry base + u * 64 + lane
+  auto probe = [&](int base, uint64_t (&h)[4], bool (&act)[4], bool (&found)[4], uint64_t (&val)[4]) {
+    if (usePre) {
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int r = base + u * 64 + lane;
+        act[u] = r < cnt; h[u] = 0ull;
+        const int w = (base >> 6) + u;
+        const uint64_t word = (w * 64 < cnt) ? pre[(size_t)f * preStride + 1 + w] : 0ull;
+        found[u] = act[u] && ((word >> lane) & 1ull);
+        val[u] = found[u] ? preVal[fo + preRun + (int)mm_popc_below(word)] : 0ull;
+        preRun += (int)__popcll(word);
+      }
+      return;
+    }
+    bool open[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) { const int r = base + u * 64 + lane; act[u] = r < cnt; h[u] = act[u] ? skHash[fo + r] : 0ull; }
     if constexpr (!TAGS) {
@@ -415,16 +415,24 @@ k_lookup_l1(int nFrags, int s, const DFrag* __restrict__ frags,
       }
     }
     }
-    // The sketch after frequent-seed removal goes to qHash/qStrand only if a seed was removed (or the sketch spans several
-    // batches): otherwise it equals the raw sketch, and readers (k_l2_locate, mm_query_sketch_download) take that instead
-    // (rawSketchSize == sketchSize in the fragment's stats).
-    bool writeQ = !oneBatch;
-    if (oneBatch) {
+  };
+  bool anyDrop = false;                                            // a frequent seed has been removed so far (wave-uniform)
+  for (int base = 0; base < cnt; base += 256) {
+    uint64_t h[4], val[4]; bool act[4], found[4];
+    probe(base, h, act, found, val);
+    // The sketch after frequent-seed removal goes to qHash/qStrand only if a seed was removed: otherwise it equals the raw sketch, and
+    // readers (k_l2_locate, mm_query_sketch_download) take that instead (rawSketchSize == sketchSize in the fragment's stats).  In a
+    // sketch of several batches the first removal back-fills the batches before it, which were the raw sketch unchanged.
+    {
       bool drop = false;
 #pragma unroll
       for (int u = 0; u < 4; u++) drop |= act[u] && found[u] && (val[u] & 1ull);
-      writeQ = __ballot(drop) != 0;
+      if (__ballot(drop) != 0 && !anyDrop) {
+        for (int i = lane; i < base; i += 64) { qHash[fo + i] = skHash[fo + i]; qStrand[fo + i] = skStrand[fo + i]; }
+        anyDrop = true;
+      }
     }
+    const bool writeQ = anyDrop;
     int cU[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
@@ -433,8 +441,7 @@ k_lookup_l1(int nFrags, int s, const DFrag* __restrict__ frags,
       const uint64_t m = __ballot(keep);
       if (keep && writeQ) {
         const int idx = outIdx + (int)mm_popc_below(m);
-        qHash[fo + idx] = h[u]; qStrand[fo + idx] = skStrand[fo + r];
-        if (!oneBatch) seedVal[fo + idx] = found[u] ? val[u] : 0ull;   // sketches of more than 256 entries: the slow path re-reads them
+        qHash[fo + idx] = usePre ? skHash[fo + r] : h[u]; qStrand[fo + idx] = skStrand[fo + r];
       }
       const bool kf = keep && found[u];
       pv[u] = kf ? val[u] : 0ull;
@@ -493,7 +500,6 @@ k_lookup_l1(int nFrags, int s, const DFrag* __restrict__ frags,
       }
     }
   }
-  __threadfence_block();                                           // seedVal is re-read by the slow-path gather below
   if (nOut < 0) {
     // slow path: points go to HBM, sorted and swept by the follow-up kernels (slots: a power of two above 64 for the sorters)
     int slots = P;
@@ -508,10 +514,22 @@ k_lookup_l1(int nFrags, int s, const DFrag* __restrict__ frags,
     if (ok && slots > 0) {
       // the table values are still in the probing lanes' registers (the order of the points is irrelevant: they are sorted next)
       uint16_t* idDst = keepPoints == 2 ? ptIds + off : nullptr;
-      if (oneBatch) nValid = mm_gather_points(pts + off, 4, [&](int rd) { return rd == 0 ? pv[0] : rd == 1 ? pv[1] : rd == 2 ? pv[2] : pv[3]; },
+      int at = 0;
+      if (oneBatch) nValid = mm_gather_points(pts + off, at, 0, 4, [&](int rd) { return rd == 0 ? pv[0] : rd == 1 ? pv[1] : rd == 2 ? pv[2] : pv[3]; },
                                               ptKeys, refGroup, rg, self, seqCounter, fl, lane, idDst);
-      else nValid = mm_gather_points(pts + off, (outIdx + 63) >> 6, [&](int rd) { const int i = rd * 64 + lane; return i < outIdx ? seedVal[fo + i] : 0ull; },
+      else {
+        // a sketch of several batches that leaves the fused path (rare: more points than the registers hold; every fragment under -Y
+        // groups, --noSplit and MM_OPT_KEEP_POINTS) is probed once more, batch by batch, instead of keeping 8 bytes per seed in HBM
+        preRun = 0;
+        for (int base = 0; base < cnt; base += 256) {
+          uint64_t h[4], val[4]; bool act[4], found[4];
+          probe(base, h, act, found, val);
+#pragma unroll
+          for (int u = 0; u < 4; u++) val[u] = (act[u] && found[u] && !(val[u] & 1ull)) ? val[u] : 0ull;
+          nValid += mm_gather_points(pts + off, at, base >> 6, 4, [&](int rd) { return rd == 0 ? val[0] : rd == 1 ? val[1] : rd == 2 ? val[2] : val[3]; },
                                      ptKeys, refGroup, rg, self, seqCounter, fl, lane, idDst);
+        }
+      }
       for (int j = P + lane; j < slots; j += 64) pts[off + j] = MM_EMPTY;
     }
     if (lane == 0) {
@@ -1038,8 +1056,7 @@ int mm_launch_map(mm_ctx* c) {
   const int nF = (int)c->nFrags, s = c->P.sketchSize;
   const DeviceIndex& I = c->idx;
   MM_HIP(c, c->dQHash.ensure((size_t)nF * s * 8 + 64)); MM_HIP(c, c->dQStrand.ensure((size_t)nF * s + 64));
-  // per-seed table values go through HBM only for sketches of more than 256 entries (k_lookup_l1 keeps them in registers otherwise)
-  MM_HIP(c, c->dSeedVal.ensure((s > 256 ? (size_t)nF * s * 8 : 0) + 64)); MM_HIP(c, c->dStats.ensure((size_t)nF * sizeof(mm_frag_stats) + 64));
+  MM_HIP(c, c->dStats.ensure((size_t)nF * sizeof(mm_frag_stats) + 64));
   MM_HIP(c, c->dPtOff.ensure((size_t)nF * 16 + 64)); MM_HIP(c, c->dL1Off.ensure((size_t)nF * 8 + 64));
   MM_HIP(c, c->dCounters.ensure(256));
   c->nL1 = c->nL2 = 0; c->nMappings = 0;
@@ -1083,7 +1100,8 @@ int mm_launch_map(mm_ctx* c) {
                          I.htSlots.as<HtSlot>(), (uint64_t)(I.htCap - 1), I.filter.as<uint64_t>(), (uint64_t)I.filterMask, I.htTags.as<uint8_t>(), I.ptKeys.as<uint64_t>(),
                          I.refGroup.as<int32_t>(), c->dReadGroup.as<int32_t>(), c->dReadSelf.as<int32_t>(), c->seqCounterBase, fl,
                          windowed ? 2 : (c->keepPoints ? 1 : 0),
-                         c->dQHash.as<uint64_t>(), c->dQStrand.as<int8_t>(), c->dSeedVal.as<uint64_t>(), c->dStats.as<mm_frag_stats>(),
+                         c->dQHash.as<uint64_t>(), c->dQStrand.as<int8_t>(), c->preProbed ? c->dPre.as<uint64_t>() : (const uint64_t*)nullptr, c->dPreVal.as<uint64_t>(), (int)c->preStride,
+                         c->dStats.as<mm_frag_stats>(),
                          c->dPtOff.as<int64_t>(), c->dPts.as<uint64_t>(), c->dPtIds.as<uint16_t>(), (unsigned long long)c->ptsCap,
                          c->dMinHits.as<int32_t>(), c->dCutoffs.as<int32_t>(), (int)c->nCutoffs, c->P.segLength,
                          c->dL1.as<mm_l1_candidate>(), regionCap, c->dL1Cursors.as<unsigned long long>(), c->dL1Off.as<int64_t>(),

@@ -370,7 +370,7 @@ mm_sketch_fast(unsigned char* smem, const int f, const uint4* __restrict__ gTabs
                const DFrag* __restrict__ frags, const uint32_t* __restrict__ readHasN, int s, int wantFast, int HT, int PAD, int QC,
                uint64_t* __restrict__ skHash, int2* __restrict__ skPos, int8_t* __restrict__ skStrand,
                uint32_t* __restrict__ skCount, int32_t* __restrict__ hardList, uint32_t* __restrict__ hardCount,
-               unsigned long long* __restrict__ phaseStats) {
+               unsigned long long* __restrict__ phaseStats, const SeedTable seedTab, const SeedPre seedPre) {
   // MM_SKETCH_STATS: shader-clock cycles thread 0 spends up to each phase boundary, summed over workgroups (diagnostics only)
   unsigned long long tPrev = phaseStats ? __builtin_amdgcn_s_memtime() : 0ull;
   auto mark = [&](int ph) {
@@ -573,9 +573,30 @@ mm_sketch_fast(unsigned char* smem, const int f, const uint4* __restrict__ gTabs
       // the reference accumulates the strand in an int16 (base_types.hpp:24, commonFunc.hpp:268)
       const int16_t acc = (int16_t)sum;
       skStrand[o] = acc > 0 ? 1 : (acc == 0 ? 0 : -1);
+      // MM_SKETCH_PROBE: the seed look-up of this entry, issued here -- the kernel is bound by the vector ALU and leaves HBM idle, while
+      // k_lookup_l1 against a human-scale table is bound by the lines its probes fetch.  Values meet in LDS (the queue memory is free).
+      if (seedPre.pre) qH[rank] = mm_seed_probe(seedTab, k);
     }
   }
   if (tid == 0) skCount[f] = D < (uint32_t)s ? D : (uint32_t)s;
+  if (seedPre.pre) {
+    __syncthreads();
+    if (tid < 64) {                                 // wave 0 compacts: found masks + the values of the found entries in sketch order
+      const int cntOut = (int)(D < (uint32_t)s ? D : (uint32_t)s);
+      uint64_t* pw = seedPre.pre + (size_t)f * seedPre.stride;
+      uint64_t* pv = seedPre.val + (size_t)f * s;
+      int run = 0;
+      for (int w = 0; w * 64 < cntOut; w++) {
+        const int r = w * 64 + tid;
+        const uint64_t v = r < cntOut ? qH[r] : 0ull;
+        const uint64_t m = __ballot(v != 0ull);
+        if (v != 0ull) pv[run + (int)mm_popc_below(m)] = v;
+        if (tid == 0) pw[1 + w] = m;
+        run += (int)__popcll(m);
+      }
+      if (tid == 0) pw[0] = 1ull;
+    }
+  }
   mark(5);                                          // ranking + output (thread 0's share)
 }
 
@@ -585,10 +606,10 @@ k_sketch_fast(const uint4* __restrict__ gTabs, const uint32_t* __restrict__ base
               const DFrag* __restrict__ frags, const uint32_t* __restrict__ readHasN, int s, int wantFast, int HT, int PAD, int QC,
               uint64_t* __restrict__ skHash, int2* __restrict__ skPos, int8_t* __restrict__ skStrand,
               uint32_t* __restrict__ skCount, int32_t* __restrict__ hardList, uint32_t* __restrict__ hardCount,
-              unsigned long long* __restrict__ phaseStats) {
+              unsigned long long* __restrict__ phaseStats, const SeedTable seedTab, const SeedPre seedPre) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   mm_sketch_fast<K, SL>(smem, (int)blockIdx.x, gTabs, bases2, nmask, frags, readHasN, s, wantFast, HT, PAD, QC, skHash, skPos, skStrand, skCount,
-                        hardList, hardCount, phaseStats);
+                        hardList, hardCount, phaseStats, seedTab, seedPre);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -770,7 +791,7 @@ int mm_check_params(const mm_params* p, std::string& err) {
 template <int K> struct MMHasSL20 { static constexpr bool value = (K >= 16 && K <= 21); };   // strips of 20 positions are built for these k-mer sizes
 
 template <int K>
-static int launch_sketch_k(mm_ctx* c) {
+static int launch_sketch_k(mm_ctx* c, bool withProbe) {
   const int s = c->P.sketchSize;
   const int nF = (int)c->nFrags;
   using Tabs = typename MMTabsFor<K>::type;
@@ -792,6 +813,21 @@ static int launch_sketch_k(mm_ctx* c) {
   MM_HIP(c, hipMemsetAsync(c->dCounters.p, 0, 64, c->stream));
   unsigned long long* phaseStats = nullptr;
   if (getenv("MM_SKETCH_STATS")) { phaseStats = c->dCounters.as<unsigned long long>() + 24; MM_HIP(c, hipMemsetAsync(phaseStats, 0, 64, c->stream)); }
+  // MM_SKETCH_PROBE=1: the fast kernel probes the seed table for the sketch it emits (needs the queue memory to hold s values)
+  SeedTable seedTab{nullptr, 0, nullptr, 0, nullptr}; SeedPre seedPre{nullptr, nullptr, 0};
+  c->preProbed = false;
+  {
+    static const bool probeOn = getenv("MM_SKETCH_PROBE") != nullptr && atoi(getenv("MM_SKETCH_PROBE")) != 0;
+    const DeviceIndex& I = c->idx;
+    if (probeOn && withProbe && I.ready && plan.useFast && (size_t)g.QC * (g.threads / 64) >= (size_t)s) {
+      c->preStride = (size_t)(s + 63) / 64 + 1;
+      MM_HIP(c, c->dPre.ensure((size_t)nF * c->preStride * 8 + 64)); MM_HIP(c, c->dPreVal.ensure((size_t)nF * s * 8 + 64));
+      MM_HIP(c, hipMemsetAsync(c->dPre.p, 0, (size_t)nF * c->preStride * 8, c->stream));
+      seedTab = SeedTable{I.htSlots.as<HtSlot>(), (uint64_t)(I.htCap - 1), I.filter.as<uint64_t>(), (uint64_t)I.filterMask, I.tagged ? I.htTags.as<uint8_t>() : (const uint8_t*)nullptr};
+      seedPre = SeedPre{c->dPre.as<uint64_t>(), c->dPreVal.as<uint64_t>(), (int)c->preStride};
+      c->preProbed = true;
+    }
+  }
   if (plan.useFast) {
     KernelTimer t(c, MM_K_SKETCH);
     auto launch = [&](auto kern) {
@@ -799,7 +835,7 @@ static int launch_sketch_k(mm_ctx* c) {
       hipLaunchKernelGGL(kern, dim3(nF), dim3(g.threads), ldsFast, c->stream,
                          c->dSketchTabs.as<uint4>(), c->dBases2.as<uint32_t>(), c->dNmask.as<uint32_t>(), c->dFrags.as<DFrag>(), c->dReadHasN.as<uint32_t>(),
                          s, g.wantFast, g.HT, PAD, g.QC, c->dSkHash.as<uint64_t>(), c->dSkPos.as<int2>(), c->dSkStrand.as<int8_t>(),
-                         c->dSkCount.as<uint32_t>(), c->dHardList.as<int32_t>(), c->dCounters.as<uint32_t>(), phaseStats);
+                         c->dSkCount.as<uint32_t>(), c->dHardList.as<int32_t>(), c->dCounters.as<uint32_t>(), phaseStats, seedTab, seedPre);
     };
     if constexpr (MMHasSL20<K>::value) { if (g.SL == 20) launch(k_sketch_fast<K, 20>); else launch(k_sketch_fast<K, 16>); }
     else launch(k_sketch_fast<K, 16>);
@@ -894,7 +930,7 @@ extern "C" int mm_bench_hash_only(mm_ctx* c, int reps, double* msAvg) {
   }
 }
 
-int mm_launch_sketch(mm_ctx* c) {
+int mm_launch_sketch(mm_ctx* c, bool withProbe) {
   const size_t nF = c->nFrags, s = (size_t)c->P.sketchSize;
   MM_HIP(c, c->dSkHash.ensure(nF * s * 8 + 64));
   MM_HIP(c, c->dSkPos.ensure(nF * s * 8 + 64));
@@ -904,7 +940,7 @@ int mm_launch_sketch(mm_ctx* c) {
   MM_HIP(c, c->dCounters.ensure(256));
   if (nF == 0) return MM_OK;
   switch (c->P.kmerSize) {
-#define MM_CASE(KK) case KK: return launch_sketch_k<KK>(c);
+#define MM_CASE(KK) case KK: return launch_sketch_k<KK>(c, withProbe);
     MM_CASE(1) MM_CASE(2) MM_CASE(3) MM_CASE(4) MM_CASE(5) MM_CASE(6) MM_CASE(7) MM_CASE(8) MM_CASE(9) MM_CASE(10) MM_CASE(11) MM_CASE(12) MM_CASE(13) MM_CASE(14) MM_CASE(15) MM_CASE(16) MM_CASE(17) MM_CASE(18) MM_CASE(19) MM_CASE(20) MM_CASE(21) MM_CASE(22) MM_CASE(23) MM_CASE(24) MM_CASE(25) MM_CASE(26) MM_CASE(27) MM_CASE(28) MM_CASE(29) MM_CASE(30) MM_CASE(31) MM_CASE(32)
 #undef MM_CASE
     default: c->err = "kmerSize outside 1..32"; return MM_ERR_ARG;
