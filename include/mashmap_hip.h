@@ -180,7 +180,9 @@ int mm_reads_upload(mm_ctx* ctx, const char* bases, const int64_t* readOffsets, 
  * the range that call reads, i.e. its `bases + readOffsets[0]` and `readOffsets[nReads] - readOffsets[0]` -- on a stream of the context's
  * own, so that it runs under the kernels of the batch being mapped (call it between mm_reads_upload and mm_map_fragments of the current
  * batch).  mm_reads_upload recognises the range and skips its own copy; any other upload simply discards the prefetch.  The bytes must
- * stay unchanged until that upload returns, and should be page-locked (mm_host_alloc): a copy from pageable memory does not overlap. */
+ * stay unchanged until that upload returns, and should be page-locked (mm_host_alloc): a copy from pageable memory does not overlap.
+ * The two prefetch calls are the one exception to "a ctx is thread-compatible": they may come from another thread (a reader) while the
+ * context's own thread is inside any other call; against mm_reads_upload* of the same context they are serialised inside the library. */
 int mm_reads_prefetch(mm_ctx* ctx, const char* bases, size_t nBytes);
 /* page-locked host memory for the `bases` of mm_reads_upload / mm_index_build: the copy to the GPU is then a single DMA at PCIe rate
  * (pageable memory is staged through a bounce buffer at a fraction of it).  Optional: any host pointer works. */

@@ -68,6 +68,9 @@ void mm_destroy(mm_ctx* c) {
   if (c->commStream) (void)hipStreamDestroy(c->commStream);
   if (c->copyStream) { (void)hipStreamSynchronize(c->copyStream); (void)hipStreamDestroy(c->copyStream); }
   if (c->copyDone) (void)hipEventDestroy(c->copyDone);
+  if (c->probeStream) { (void)hipStreamSynchronize(c->probeStream); (void)hipStreamDestroy(c->probeStream); }
+  for (hipEvent_t e : c->probeEv) (void)hipEventDestroy(e);
+  if (c->probeDone) (void)hipEventDestroy(c->probeDone);
   for (DevBuf* b : c->allBufs()) b->release();
   if (c->evA) (void)hipEventDestroy(c->evA);
   if (c->evB) (void)hipEventDestroy(c->evB);
@@ -176,6 +179,9 @@ static int upload_reads_common(mm_ctx* c, const ReadSource& S, const int64_t* re
                                const int32_t* readSelfSeqId, int32_t seqCounterBase) {
   const bool packed = S.packed();
   if (packed ? (nReads && !S.lengths) : !readOffsets) { c->err = "mm_reads_upload: null argument"; return MM_ERR_ARG; }
+  // the prefetch state (staging buffer, its copy event, what it holds) is matched and consumed below, and the copies out of the staging
+  // buffer have completed when this function returns: a mm_reads_prefetch* from another thread waits for that
+  std::lock_guard<std::mutex> prefetchLock(c->prefetchMu);
   MM_HIP(c, hipSetDevice(c->device));
   const int k = c->P.kmerSize, L = c->P.segLength;
   const bool split = !(c->P.flags & MM_FLAG_NO_SPLIT);
@@ -255,7 +261,11 @@ static int upload_reads_common(mm_ctx* c, const ReadSource& S, const int64_t* re
     hasN32.assign(nReads + 1, 0u);
     for (size_t r = 0; r < nReads; r++) {
       if (S.hasN) hasN32[r] = S.hasN[r] ? 1u : 0u;
-      else { const uint32_t* w = S.nm + packOff[r] / 32; const size_t nw = (size_t)((packOff[r + 1] - packOff[r]) / 32); uint32_t any = 0; for (size_t i = 0; i < nw; i++) any |= w[i]; hasN32[r] = any ? 1u : 0u; }
+      else {                                            // the read's own mask words only: the words of a gap behind it are never read (header contract)
+        const uint32_t* w = S.nm + packOff[r] / 32; const size_t nw = ((size_t)rlen[r] + 31) / 32;
+        uint32_t any = 0; for (size_t i = 0; i < nw; i++) any |= w[i];
+        hasN32[r] = any ? 1u : 0u;
+      }
     }
     MM_HIP(c, hipMemcpyAsync(c->dReadHasN.p, hasN32.data(), nReads * 4 + 4, hipMemcpyHostToDevice, c->stream));
   } else if (nSrc && !prefetched) MM_HIP(c, hipMemcpyAsync(c->dAscii.p, (const char*)S.ascii + srcBase, nSrc, S.onDevice ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
@@ -319,6 +329,7 @@ static int prefetch_common(mm_ctx* c, const void* p0, size_t n0, const void* p1,
 }
 
 int mm_reads_prefetch(mm_ctx* c, const char* bases, size_t nBytes) {
+  std::lock_guard<std::mutex> prefetchLock(c->prefetchMu);
   c->prefetchValid = false;
   if (!bases || !nBytes) return MM_OK;
   const int rc = prefetch_common(c, bases, nBytes, nullptr, 0);
@@ -328,6 +339,7 @@ int mm_reads_prefetch(mm_ctx* c, const char* bases, size_t nBytes) {
 }
 
 int mm_reads_prefetch_packed(mm_ctx* c, const uint32_t* bases2, const uint32_t* nmask, size_t nPackedBases) {
+  std::lock_guard<std::mutex> prefetchLock(c->prefetchMu);
   c->prefetchValid = false;
   if (!bases2 || !nmask || !nPackedBases) return MM_OK;
   if (nPackedBases % 32) { c->err = "mm_reads_prefetch_packed: the packed length of a batch is a multiple of 32 bases"; return MM_ERR_ARG; }

@@ -260,14 +260,18 @@ int mm_allgatherv_mappings_local(mm_ctx** ctxs, int n) {
     int rc = MM_OK;
     for (int i = 0; i < n && rc == MM_OK; i++) { (void)hipSetDevice(ctxs[i]->device); rc = issue_broadcasts(ctxs[i], ctxs[i], R, ctxs[i]->dMappings.p, ctxs[i]->stream); if (rc != MM_OK) c0->err = ctxs[i]->err; }
     if (rc != MM_OK) {
-      // some ranks of the group have issued their broadcasts and others have not: completing the group could wait forever.  The
-      // communicators are abandoned (the group with them) and the contexts fall back to peer copies for whatever comes next.
+      // Everything that can fail on our side (counts, slots, buffers) was settled before ncclGroupStart, so this is RCCL refusing to
+      // enqueue a broadcast.  The group is closed first -- aborting a communicator inside an open group is not a supported sequence --
+      // then the communicators are aborted and the contexts fall back to peer copies for whatever comes next.  Without ncclCommAbort
+      // in the bound library the communicators cannot be torn down safely: that is reported as such, not papered over.
       std::string keep = c0->err;
-      if (R->CommAbort) for (int i = 0; i < n; i++) if (ctxs[i]->comm) { (void)R->CommAbort((ncclComm_t)ctxs[i]->comm); ctxs[i]->comm = nullptr; }
       (void)R->GroupEnd();
-      for (int i = 0; i < n; i++) { ctxs[i]->comm = nullptr; ctxs[i]->commCopy = true; }
-      c0->err = keep;
-      return rc;
+      for (int i = 0; i < n; i++) {
+        if (ctxs[i]->comm && R->CommAbort) (void)R->CommAbort((ncclComm_t)ctxs[i]->comm);
+        ctxs[i]->comm = nullptr; ctxs[i]->commCopy = true;
+      }
+      c0->err = keep + (R->CommAbort ? "" : " (the bound RCCL has no ncclCommAbort: its communicators were dropped, not destroyed)");
+      return R->CommAbort ? rc : MM_ERR_DEVICE;
     }
     MM_NCCL(c0, R, R->GroupEnd());
   } else {

@@ -172,39 +172,12 @@ __device__ __forceinline__ void mm_tag_scan(uint4 t, uint32_t tag, uint32_t& can
   cand16 = c; hasEmpty = e != 0;
 }
 
-// The seed table as a kernel argument, and the look-up of ONE hash in it: the table value (offset << 24 | count << 1 | isFrequent,
-// never 0 for a key that is present) or 0.  k_lookup_l1 (mm_map.hip) has its own form with four probes per lane in flight; this one
-// serves the sketch kernel, which probes a fragment's sketch right where it emits it (MM_SKETCH_PROBE).
+// the seed table as a kernel argument (k_lookup_l1, k_gather_points, k_seed_probe: mm_map.hip)
 struct SeedTable { const HtSlot* ht; uint64_t mask; const uint64_t* filter; uint64_t filterMask; const uint8_t* tags; };
-__device__ __forceinline__ uint64_t mm_seed_probe(const SeedTable& T, uint64_t h) {
-  if (T.tags) {
-    uint64_t b = (h & T.mask) & ~(uint64_t)(MM_TAG_BUCKET - 1);
-    const uint32_t tag = mm_seed_tag(h);
-    for (;;) {
-      uint32_t cd; bool em;
-      mm_tag_scan(*(const uint4*)(T.tags + b), tag, cd, em);
-      while (cd) {
-        const uint32_t i = (uint32_t)__builtin_ctz(cd); cd &= cd - 1u;
-        const HtSlot x = T.ht[b + i];
-        if (x.key == h) return x.val;
-      }
-      if (em) return 0ull;
-      b = (b + MM_TAG_BUCKET) & T.mask;
-    }
-  }
-  if (T.filterMask) { const uint64_t fb = mm_filter_bits(h); if ((T.filter[mm_filter_word(h, T.filterMask)] & fb) != fb) return 0ull; }
-  uint64_t slot = h & T.mask;
-  for (;;) {
-    const HtSlot x = T.ht[slot];
-    if (x.key == h) return x.val;
-    if (x.key == MM_HT_EMPTY) return 0ull;
-    slot = (slot + 1) & T.mask;
-  }
-}
-// where the sketch kernel leaves what it found: per fragment `stride` 64-bit words in pre -- word 0: 1 = this fragment has been probed
-// (fragments of the hard list are not), words 1.. : bit r of the concatenation = sketch entry r is in the table -- and in val, at
+// MM_SKETCH_PROBE -- what k_seed_probe leaves for k_lookup_l1: per fragment `stride` 64-bit words in pre -- word 0: 2 = sketch emitted by
+// the fast sketch kernel, 1 = looked up; words 1.. : bit r of the concatenation = sketch entry r is in the table -- and in val, at
 // f * s, the table values of the entries that are, in sketch order
-struct SeedPre { uint64_t* pre; uint64_t* val; int stride; };
+struct SeedPre { uint64_t* pre; uint64_t* val; int stride; int mode; };
 
 // ---------------------------------------------------------------------------------------------
 // Strip hasher.  For K = 17..19 (one 16-byte block + a tail of K-16 <= 3 bytes; K = 19 is MashMap's default) the tail has

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <utility>
@@ -92,6 +93,7 @@ struct mm_ctx {
   // mm_reads_prefetch: the next batch's ASCII bytes, copied on a stream of their own while the current batch is mapped
   DevBuf dAsciiNext; hipStream_t copyStream = nullptr; hipEvent_t copyDone = nullptr;
   const void* prefetchPtr = nullptr; const void* prefetchPtr2 = nullptr; size_t prefetchBytes = 0; bool prefetchValid = false, prefetchPacked = false;
+  std::mutex prefetchMu;                                // mm_reads_prefetch* may come from another thread than the uploads (a reader thread): the staging state is shared
   DevBuf dBases2, dNmask, dFrags;
   std::vector<mm_fragment> hFrags;
 
@@ -102,6 +104,7 @@ struct mm_ctx {
   DevBuf dQHash, dQStrand;                              // post-removal sketch (written only for fragments that lose a frequent seed)
   // MM_SKETCH_PROBE: the sketch kernel looks a fragment's sketch up in the seed table where it emits it (mm_device.h: SeedPre)
   DevBuf dPre, dPreVal; size_t preStride = 0; bool preProbed = false;
+  hipStream_t probeStream = nullptr; std::vector<hipEvent_t> probeEv; hipEvent_t probeDone = nullptr;   // mode 2: k_seed_probe runs chunk by chunk beside the sketch kernel
   DevBuf dStats;                                        // mm_frag_stats[nFrags]
   DevBuf dPtOff, dPts; size_t ptsCap = 0;               // per-fragment offset (int64) + sorted keys
   // --noSplit with reads longer than segLength (windowLen != 0, computeMap.hpp:933): the literal kernels' state
@@ -161,6 +164,8 @@ int mm_launch_pack_raw(mm_ctx* c, const uint8_t* dAscii, const int64_t* dSrcOff,
                        int64_t nChunks, uint32_t* dB, uint32_t* dM, uint32_t* dHasN);
 int mm_launch_sketch(mm_ctx* c, bool withProbe = false);   // withProbe: look the sketches up in the resident seed table as well (MM_SKETCH_PROBE)
 int mm_launch_map(mm_ctx* c);
+// k_seed_probe (mm_map.hip) for the fragments [f0, f1) the sketch kernel has marked, or (list != null) for the listed ones, on `stream`
+int mm_launch_seed_probe(mm_ctx* c, hipStream_t stream, int f0, int f1, const int32_t* dList, const uint32_t* dListCount);
 int mm_launch_select(mm_ctx* c);
 void mm_comm_release(mm_ctx* c);
 int mm_launch_l2(mm_ctx* c, unsigned long long* cnt);   // cnt: device counters [4] cursor [5] overflow [6] slot overflow

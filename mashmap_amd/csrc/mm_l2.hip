@@ -293,9 +293,23 @@ k_l2_locate(int cBase, int nCand, int64_t opsBase, int s, int NB, const mm_l1_ca
       }
       const int delta = evalIns ? pos - prevPos : 0;
       const bool needSkip = evalIns && delta > (int)EF<JB>::MAXDELTA;
-      if (needSkip && (uint32_t)(delta - (int)EF<JB>::MAXDELTA) > E_SKIP_MAX) tooWide = true;
-      const int mine = keep ? (needSkip ? 2 : 1) : 0;
       const uint64_t mKeep = __ballot(keep), mSkip = __ballot(needSkip);          // slots before this lane: one per kept event, one more per skip
+      if (__ballot(needSkip && (uint32_t)(delta - (int)EF<JB>::MAXDELTA) > E_SKIP_MAX)) {
+        // a gap that one skip entry (27 bits) cannot carry -- two reference minmers of one candidate more than 2^27 bases apart: the gap
+        // is spread over as many skip entries as it takes (the reservation holds one per 2^DELTA_BITS bases of the range).  Round 3
+        // failed the batch here.
+        const uint32_t extra = needSkip ? (uint32_t)(delta - (int)EF<JB>::MAXDELTA) : 0u;
+        const int nSkip = (int)((extra + E_SKIP_MAX - 1u) / E_SKIP_MAX);
+        const int mineW = keep ? 1 + nSkip : 0;
+        int at = outN + mm_wave_excl_scan(mineW);
+        if (keep && at + mineW <= cap) {
+          uint32_t left = extra;
+          for (int i = 0; i < nSkip; i++) { const uint32_t part = left > E_SKIP_MAX ? E_SKIP_MAX : left; out[at++] = (1u << E_SKIP_BIT) | part; left -= part; }
+          out[at] = op | ((needSkip ? EF<JB>::MAXDELTA : (uint32_t)delta) << EF<JB>::DELTA_SHIFT);
+        } else if (keep) tooWide = true;                                          // cannot happen: see the reservation in k_l2_extents
+        outN += mm_wave_sum(mineW);
+      } else {
+      const int mine = keep ? (needSkip ? 2 : 1) : 0;
       const int at = outN + (int)mm_popc_below(mKeep) + (int)mm_popc_below(mSkip);
       if (keep && at + mine <= cap) {
         if (needSkip) {
@@ -305,6 +319,7 @@ k_l2_locate(int cBase, int nCand, int64_t opsBase, int s, int NB, const mm_l1_ca
         } else out[at] = op | ((uint32_t)delta << EF<JB>::DELTA_SHIFT);
       }
       outN += __popcll(mKeep) + __popcll(mSkip);
+      }
       if (mIns) posAcc = __shfl(pos, 63 - (int)__builtin_clzll(mIns));
     }
     if (lane == 0) {                                               // end marker: carries the wpos behind the last insert
@@ -1056,7 +1071,7 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt) {
     if (hc[5]) { c->l2Cap = (size_t)hc[4] + (size_t)hc[4] / 8 + 1024; continue; }
     break;
   }
-  if (hc[6] & 4ull) { c->err = "a gap of more than 2^27 bases between consecutive reference minmers inside an L1 candidate is not representable in the L2 stream"; return MM_ERR_ARG; }
+  if (hc[6] & 4ull) { c->err = "internal: an L2 stream outgrew the reservation k_l2_extents made for it"; return MM_ERR_CAPACITY; }
   if (hc[6] & 1ull) { c->err = "an L1 candidate with more tied L2 loci than 64 GiB of staging can hold"; return MM_ERR_CAPACITY; }
   if (hc[5]) { c->err = "L2 locus buffer overflow"; return MM_ERR_CAPACITY; }
   c->nL2 = (size_t)hc[4];

@@ -292,80 +292,21 @@ __device__ __forceinline__ int mm_l1_fused(uint64_t (&k)[R], FuseScratch& sc, in
 //   * otherwise (many points, -Y groups, a position group spanning contigs, or keepPoints for the parity API): reserves
 //     slots in the global point buffer, gathers there and queues the fragment for k_sort_points_* + k_l1_sweep.
 // ---------------------------------------------------------------------------------------------
-#define MM_LOOKUP_WPB 4             // waves (= fragments) per workgroup
-#define MM_L1_REGIONS 64            // L1 output cursors: a same-address atomic costs ~10 ns, so fragments spread over 64 of them
-#define MM_L1_CURSOR_STRIDE 32      // u64 words between cursors (256 bytes)
-template <int MAXPTS, bool TAGS>
-__global__ void __launch_bounds__(MM_LOOKUP_WPB * 64, MAXPTS <= 128 ? 8 : MAXPTS <= 256 ? 6 : 5)
-k_lookup_l1(int nFrags, int s, const DFrag* __restrict__ frags,
-            const uint64_t* __restrict__ skHash, const int8_t* __restrict__ skStrand, const uint32_t* __restrict__ skCount,
-            const HtSlot* __restrict__ ht, uint64_t htMask, const uint64_t* __restrict__ filter, uint64_t filterMask, const uint8_t* __restrict__ tags,
-            const uint64_t* __restrict__ ptKeys, const int32_t* __restrict__ refGroup,
-            const int32_t* __restrict__ readGroup, const int32_t* __restrict__ readSelf, int seqCounterBase, MapFlags fl, int keepPoints,
-            uint64_t* __restrict__ qHash, int8_t* __restrict__ qStrand, const uint64_t* __restrict__ pre, const uint64_t* __restrict__ preVal, int preStride,
-            mm_frag_stats* __restrict__ stats, int64_t* __restrict__ ptOff, uint64_t* __restrict__ pts, uint16_t* __restrict__ ptIds /* keepPoints == 2 */, unsigned long long ptsCap,
-            const int32_t* __restrict__ minHitsTab, const int32_t* __restrict__ cutoffs, int nCutoffs, int segLength,
-            mm_l1_candidate* __restrict__ l1, unsigned long long regionCap, unsigned long long* __restrict__ l1Cursors,
-            int64_t* __restrict__ l1Off, int32_t* __restrict__ bigList,
-            unsigned long long* __restrict__ counters /* [0] point cursor [1] pts overflow [3] l1 overflow [7] big count */) {
-  typedef FuseScratchT<MAXPTS> FuseScratch;
-  __shared__ FuseScratch scratch[MM_LOOKUP_WPB];
-  const int wv = threadIdx.x >> 6;
-  const int f = blockIdx.x * MM_LOOKUP_WPB + wv;
-  const bool live = f < nFrags;
-  FuseScratch& sc = scratch[wv];
-  const int lane = (int)mm_lane();
-  int nValid = 0, nOut = -1, outIdx = 0, P = 0, cnt = 0;
-  uint64_t lastHash = 0;
-  if (live) {
-  cnt = (int)skCount[f];
-  const size_t fo = (size_t)f * s;
-  // per-read metadata early: nothing below depends on the probes to fetch it
-  const int readId = frags[f].readId;
-  const int rg = readGroup[readId], self = readSelf[readId], seqCounter = seqCounterBase + readId;
-  lastHash = cnt ? skHash[fo + cnt - 1] : 0ull;
-  // Phase 1: probe.  Four sub-rounds (256 sketch entries) are in flight together: their hash loads, filter tests and first
-  // table slots are independent, so one memory round trip serves all of them instead of four.
-  uint64_t pv[4] = {0, 0, 0, 0};                                   // table value of this lane's kept + found seeds, sub-round u
-  const bool oneBatch = cnt <= 256;
-  // The interval points are gathered into LDS batch by batch, as long as they fit (MAXPTS): a sketch of more than 256 entries
-  // (several probing batches) stays on the fused path too.  The order of the points is irrelevant: they are sorted next.
-  bool fuseOk = !keepPoints && !fl.skipPrefix;                     // wave-uniform
-  int done = 0;                                                    // points in sc.a so far
-  auto put = [&](int at, uint64_t key) {
-    const int seqId = (int)(key >> 33);
-    bool drop = false;
-    if (fl.skipSelf && seqId == self) drop = true;
-    if (fl.lowerTri && !(seqCounter > seqId)) drop = true;
-    if (drop) key = MM_EMPTY; else nValid++;
-    sc.a[at] = key;
-  };
-  // the sketch kernel has probed this fragment already (MM_SKETCH_PROBE): found masks + the values of the found entries, in sketch order
-  const bool usePre = pre != nullptr && pre[(size_t)f * preStride] == 1ull;    // wave-uniform
-  int preRun = 0;                                                  // found entries before the batch being read (reset before every pass over the batches)
-  // the table values of the sketch entries [base, base + 256), four per lane: found[u] / val[u] for entry base + u * 64 + lane
-  auto probe = [&](int base, uint64_t (&h)[4], bool (&act)[4], bool (&found)[4], uint64_t (&val)[4]) {
-    if (usePre) {
+// The table values of the sketch entries [base, base + 256) of a fragment, four per lane (entry base + u * 64 + lane): found[u] / val[u].
+// Four sub-rounds are in flight together: their hash loads, filter tests / tag loads and first table slots are independent, so one
+// memory round trip serves all of them instead of four.  Shared by k_lookup_l1, k_gather_points and k_seed_probe.
+template <bool TAGS>
+__device__ __forceinline__ void mm_probe4(const SeedTable& T, const uint64_t* __restrict__ skHash, size_t fo, int cnt, int base, int lane,
+                                          uint64_t (&h)[4], bool (&act)[4], bool (&found)[4], uint64_t (&val)[4]) {
+  const HtSlot* __restrict__ ht = T.ht; const uint64_t htMask = T.mask;
+  bool open[4];
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int r = base + u * 64 + lane;
-        act[u] = r < cnt; h[u] = 0ull;
-        const int w = (base >> 6) + u;
-        const uint64_t word = (w * 64 < cnt) ? pre[(size_t)f * preStride + 1 + w] : 0ull;
-        found[u] = act[u] && ((word >> lane) & 1ull);
-        val[u] = found[u] ? preVal[fo + preRun + (int)mm_popc_below(word)] : 0ull;
-        preRun += (int)__popcll(word);
-      }
-      return;
-    }
-    bool open[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) { const int r = base + u * 64 + lane; act[u] = r < cnt; h[u] = act[u] ? skHash[fo + r] : 0ull; }
-    if constexpr (!TAGS) {
+  for (int u = 0; u < 4; u++) { const int r = base + u * 64 + lane; act[u] = r < cnt; h[u] = act[u] ? skHash[fo + r] : 0ull; }
+  if constexpr (!TAGS) {
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       open[u] = act[u];
-      if (filterMask && act[u]) { const uint64_t fb = mm_filter_bits(h[u]); open[u] = (filter[mm_filter_word(h[u], filterMask)] & fb) == fb; }
+      if (T.filterMask && act[u]) { const uint64_t fb = mm_filter_bits(h[u]); open[u] = (T.filter[mm_filter_word(h[u], T.filterMask)] & fb) == fb; }
     }
     HtSlot sl[4];
 #pragma unroll
@@ -381,13 +322,14 @@ k_lookup_l1(int nFrags, int s, const DFrag* __restrict__ frags,
         sl[u] = ht[slot];
       }
     }
-    } else {
+  } else {
     // Tagged table (human-scale index).  One 16-byte load per seed fetches the tag bytes of its home bucket, out of an array 1/16 the
-    // size of the table; the four sub-rounds' loads are in flight together.  A slot is fetched only where a tag matches (a present
-    // seed, or one absent seed in ~40 by chance); an absent seed ends at the first bucket with a free slot: its own, but for ~0.03 %.
+    // size of the table.  A slot is fetched only where a tag matches (a present seed, or one absent seed in ~40 by chance); an absent
+    // seed ends at the first bucket with a free slot: its own, but for ~0.03 %.
+    const uint8_t* __restrict__ tags = T.tags;
     uint4 tg[4];
 #pragma unroll
-    for (int u = 0; u < 4; u++) { open[u] = act[u]; tg[u] = make_uint4(0u, 0u, 0u, 0u); if (act[u]) tg[u] = *(const uint4*)(tags + ((h[u] & htMask) & ~(uint64_t)(MM_TAG_BUCKET - 1))); }
+    for (int u = 0; u < 4; u++) { tg[u] = make_uint4(0u, 0u, 0u, 0u); if (act[u]) tg[u] = *(const uint4*)(tags + ((h[u] & htMask) & ~(uint64_t)(MM_TAG_BUCKET - 1))); }
     uint32_t cand[4]; bool emp[4]; HtSlot sl[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
@@ -414,12 +356,76 @@ k_lookup_l1(int nFrags, int s, const DFrag* __restrict__ frags,
         }
       }
     }
-    }
+  }
+}
+// the same from what k_seed_probe / the sketch kernel left (mm_device.h: SeedPre): found masks + the values of the found entries in
+// sketch order.  preRun: found entries before `base` (the caller resets it before every pass over the batches)
+__device__ __forceinline__ void mm_probe4_pre(const uint64_t* __restrict__ preRow, const uint64_t* __restrict__ preValRow, int cnt, int base, int lane, int& preRun,
+                                              uint64_t (&h)[4], bool (&act)[4], bool (&found)[4], uint64_t (&val)[4]) {
+#pragma unroll
+  for (int u = 0; u < 4; u++) {
+    const int r = base + u * 64 + lane;
+    act[u] = r < cnt; h[u] = 0ull;
+    const int w = (base >> 6) + u;
+    const uint64_t word = (w * 64 < cnt) ? preRow[1 + w] : 0ull;
+    found[u] = act[u] && ((word >> lane) & 1ull);
+    val[u] = found[u] ? preValRow[preRun + (int)mm_popc_below(word)] : 0ull;
+    preRun += (int)__popcll(word);
+  }
+}
+
+#define MM_LOOKUP_WPB 4             // waves (= fragments) per workgroup
+#define MM_L1_REGIONS 64            // L1 output cursors: a same-address atomic costs ~10 ns, so fragments spread over 64 of them
+#define MM_L1_CURSOR_STRIDE 32      // u64 words between cursors (256 bytes)
+// MODE 0: probes the plain seed table (+ presence filter), 1: the tagged table, 2: reads what k_seed_probe left for EVERY fragment
+template <int MAXPTS, int MODE>
+__global__ void __launch_bounds__(MM_LOOKUP_WPB * 64, MAXPTS <= 128 ? 8 : MAXPTS <= 256 ? 6 : 5)
+k_lookup_l1(int nFrags, int s, const DFrag* __restrict__ frags,
+            const uint64_t* __restrict__ skHash, const int8_t* __restrict__ skStrand, const uint32_t* __restrict__ skCount,
+            const SeedTable T, const uint64_t* __restrict__ ptKeys,
+            const int32_t* __restrict__ readSelf, int seqCounterBase, MapFlags fl, int keepPoints,
+            uint64_t* __restrict__ qHash, int8_t* __restrict__ qStrand, const uint64_t* __restrict__ pre, const uint64_t* __restrict__ preVal, int preStride,
+            mm_frag_stats* __restrict__ stats, int64_t* __restrict__ ptOff, unsigned long long ptsCap,
+            const int32_t* __restrict__ minHitsTab, const int32_t* __restrict__ cutoffs, int nCutoffs, int segLength,
+            mm_l1_candidate* __restrict__ l1, unsigned long long regionCap, unsigned long long* __restrict__ l1Cursors,
+            int64_t* __restrict__ l1Off, int32_t* __restrict__ bigList,
+            unsigned long long* __restrict__ counters /* [0] point cursor [1] pts overflow [3] l1 overflow [7] big count */) {
+  typedef FuseScratchT<MAXPTS> FuseScratch;
+  __shared__ FuseScratch scratch[MM_LOOKUP_WPB];
+  const int wv = threadIdx.x >> 6;
+  const int f = blockIdx.x * MM_LOOKUP_WPB + wv;
+  const bool live = f < nFrags;
+  FuseScratch& sc = scratch[wv];
+  const int lane = (int)mm_lane();
+  int nValid = 0, nOut = -1, outIdx = 0, P = 0, cnt = 0;
+  uint64_t lastHash = 0;
+  if (live) {
+  cnt = (int)skCount[f];
+  const size_t fo = (size_t)f * s;
+  // per-read metadata early: nothing below depends on the probes to fetch it
+  const int readId = frags[f].readId;
+  const int self = readSelf[readId], seqCounter = seqCounterBase + readId;
+  lastHash = cnt ? skHash[fo + cnt - 1] : 0ull;
+  // The interval points are gathered into LDS batch by batch (256 sketch entries are probed at a time), as long as they fit (MAXPTS):
+  // a sketch of more than 256 entries stays on the fused path too.  The order of the points is irrelevant: they are sorted next.
+  bool fuseOk = !keepPoints && !fl.skipPrefix;                     // wave-uniform
+  int done = 0;                                                    // points in sc.a so far
+  auto put = [&](int at, uint64_t key) {
+    const int seqId = (int)(key >> 33);
+    bool drop = false;
+    if (fl.skipSelf && seqId == self) drop = true;
+    if (fl.lowerTri && !(seqCounter > seqId)) drop = true;
+    if (drop) key = MM_EMPTY; else nValid++;
+    sc.a[at] = key;
   };
+  // MODE 2: the seed look-ups were made ahead (k_seed_probe, MM_SKETCH_PROBE): found masks + values instead of probes
+  constexpr bool usePre = MODE == 2;
+  int preRun = 0;
   bool anyDrop = false;                                            // a frequent seed has been removed so far (wave-uniform)
   for (int base = 0; base < cnt; base += 256) {
     uint64_t h[4], val[4]; bool act[4], found[4];
-    probe(base, h, act, found, val);
+    if constexpr (usePre) mm_probe4_pre(pre + (size_t)f * preStride, preVal + fo, cnt, base, lane, preRun, h, act, found, val);
+    else mm_probe4<MODE == 1>(T, skHash, fo, cnt, base, lane, h, act, found, val);
     // The sketch after frequent-seed removal goes to qHash/qStrand only if a seed was removed: otherwise it equals the raw sketch, and
     // readers (k_l2_locate, mm_query_sketch_download) take that instead (rawSketchSize == sketchSize in the fragment's stats).  In a
     // sketch of several batches the first removal back-fills the batches before it, which were the raw sketch unchanged.
@@ -432,19 +438,18 @@ k_lookup_l1(int nFrags, int s, const DFrag* __restrict__ frags,
         anyDrop = true;
       }
     }
-    const bool writeQ = anyDrop;
-    int cU[4];
+    int cU[4]; uint64_t src[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       const int r = base + u * 64 + lane;
       const bool keep = act[u] && !(found[u] && (val[u] & 1ull));
       const uint64_t m = __ballot(keep);
-      if (keep && writeQ) {
+      if (keep && anyDrop) {
         const int idx = outIdx + (int)mm_popc_below(m);
         qHash[fo + idx] = usePre ? skHash[fo + r] : h[u]; qStrand[fo + idx] = skStrand[fo + r];
       }
       const bool kf = keep && found[u];
-      pv[u] = kf ? val[u] : 0ull;
+      src[u] = val[u] >> 24;
       cU[u] = kf ? (int)((val[u] >> 1) & 0x7fffffull) : 0;
       outIdx += __popcll(m);
     }
@@ -457,13 +462,12 @@ k_lookup_l1(int nFrags, int s, const DFrag* __restrict__ frags,
         for (int u = 0; u < 4; u++) {
           const int c = cU[u];
           const int my = done + mm_wave_excl_scan(c);
-          const uint64_t src = pv[u] >> 24;
           uint64_t k0 = MM_EMPTY, k1 = MM_EMPTY;
-          if (c > 0) k0 = ptKeys[src];
-          if (c > 1) k1 = ptKeys[src + 1];
+          if (c > 0) k0 = ptKeys[src[u]];
+          if (c > 1) k1 = ptKeys[src[u] + 1];
           if (c > 0) put(my, k0);
           if (c > 1) put(my + 1, k1);
-          for (int j = 2; j < c; j++) put(my + j, ptKeys[src + j]);
+          for (int j = 2; j < c; j++) put(my + j, ptKeys[src[u] + j]);
           done += mm_wave_sum(c);
         }
       }
@@ -501,40 +505,19 @@ k_lookup_l1(int nFrags, int s, const DFrag* __restrict__ frags,
     }
   }
   if (nOut < 0) {
-    // slow path: points go to HBM, sorted and swept by the follow-up kernels (slots: a power of two above 64 for the sorters)
+    // slow path: the fragment's points go to HBM -- gathered by k_gather_points (which looks the seeds up once more: this kernel keeps no
+    // per-seed value beyond the batch it is probing), sorted and swept by the follow-up kernels.  Here: the slots (a power of two above
+    // 64 for the sorters) and the queue entry.
     int slots = P;
     if (P > 64) { slots = 128; while (slots < P) slots <<= 1; }
     else if (keepPoints == 2 && P > 0) { slots = 2; while (slots < P) slots <<= 1; }      // windowed mode: every list goes through the LDS / HBM sorters
-    unsigned long long off = 0;
-    if (lane == 0 && slots > 0) off = atomicAdd(&counters[0], (unsigned long long)slots);
-    off = ((unsigned long long)(uint32_t)__shfl((int)(off >> 32), 0) << 32) | (uint32_t)__shfl((int)(uint32_t)off, 0);
-    bool ok = true;
-    if (slots > 0 && off + (unsigned long long)slots > ptsCap) { ok = false; if (lane == 0) atomicOr(&counters[1], 1ull); }
-    nValid = 0;
-    if (ok && slots > 0) {
-      // the table values are still in the probing lanes' registers (the order of the points is irrelevant: they are sorted next)
-      uint16_t* idDst = keepPoints == 2 ? ptIds + off : nullptr;
-      int at = 0;
-      if (oneBatch) nValid = mm_gather_points(pts + off, at, 0, 4, [&](int rd) { return rd == 0 ? pv[0] : rd == 1 ? pv[1] : rd == 2 ? pv[2] : pv[3]; },
-                                              ptKeys, refGroup, rg, self, seqCounter, fl, lane, idDst);
-      else {
-        // a sketch of several batches that leaves the fused path (rare: more points than the registers hold; every fragment under -Y
-        // groups, --noSplit and MM_OPT_KEEP_POINTS) is probed once more, batch by batch, instead of keeping 8 bytes per seed in HBM
-        preRun = 0;
-        for (int base = 0; base < cnt; base += 256) {
-          uint64_t h[4], val[4]; bool act[4], found[4];
-          probe(base, h, act, found, val);
-#pragma unroll
-          for (int u = 0; u < 4; u++) val[u] = (act[u] && found[u] && !(val[u] & 1ull)) ? val[u] : 0ull;
-          nValid += mm_gather_points(pts + off, at, base >> 6, 4, [&](int rd) { return rd == 0 ? val[0] : rd == 1 ? val[1] : rd == 2 ? val[2] : val[3]; },
-                                     ptKeys, refGroup, rg, self, seqCounter, fl, lane, idDst);
-        }
-      }
-      for (int j = P + lane; j < slots; j += 64) pts[off + j] = MM_EMPTY;
-    }
     if (lane == 0) {
+      unsigned long long off = 0;
+      if (slots > 0) off = atomicAdd(&counters[0], (unsigned long long)slots);
+      bool ok = true;
+      if (slots > 0 && off + (unsigned long long)slots > ptsCap) { ok = false; atomicOr(&counters[1], 1ull); }
       mm_frag_stats st;
-      st.rawSketchSize = cnt; st.sketchSize = outIdx; st.maxHash = lastHash; st.nPoints = nValid; st.nL1 = 0; stats[f] = st;
+      st.rawSketchSize = cnt; st.sketchSize = outIdx; st.maxHash = lastHash; st.nPoints = 0; st.nL1 = 0; stats[f] = st;
       ptOff[2 * f] = (int64_t)off; ptOff[2 * f + 1] = ok ? (int64_t)slots : 0; l1Off[f] = 0;
       if (slots > 0 && ok) bigList[atomicAdd(&counters[7], 1ull)] = f;
     }
@@ -560,6 +543,78 @@ k_lookup_l1(int nFrags, int s, const DFrag* __restrict__ frags,
       st.rawSketchSize = cnt; st.sketchSize = outIdx; st.maxHash = lastHash; st.nPoints = nValid; st.nL1 = nOut; stats[f] = st;
       ptOff[2 * f] = 0; ptOff[2 * f + 1] = 0; l1Off[f] = (int64_t)base;
     }
+  }
+}
+
+// k_gather_points: the interval points of the fragments k_lookup_l1 queued (more points than its registers hold, -Y reference groups,
+// --noSplit, MM_OPT_KEEP_POINTS) -> the slots it reserved for them in HBM, one wave per queued fragment: the sketch is looked up again,
+// batch by batch, and every surviving seed's point run is copied (getSeedIntervalPoints, computeMap.hpp:857-912, with the seqId
+// filters of :891-896).  ids (windowed mode): the seed every point came from.
+template <bool TAGS>
+__global__ void __launch_bounds__(256)
+k_gather_points(int nList, const int32_t* __restrict__ list, int s, const DFrag* __restrict__ frags, const uint64_t* __restrict__ skHash, const uint32_t* __restrict__ skCount,
+                const SeedTable T, const uint64_t* __restrict__ pre, const uint64_t* __restrict__ preVal, int preStride,
+                const uint64_t* __restrict__ ptKeys, const int32_t* __restrict__ refGroup, const int32_t* __restrict__ readGroup, const int32_t* __restrict__ readSelf,
+                int seqCounterBase, MapFlags fl, mm_frag_stats* __restrict__ stats, const int64_t* __restrict__ ptOff, uint64_t* __restrict__ pts, uint16_t* __restrict__ ptIds) {
+  const int li = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (li >= nList) return;
+  const int f = list[li];
+  const int lane = (int)mm_lane();
+  const int64_t off = ptOff[2 * f]; const int slots = (int)ptOff[2 * f + 1];
+  if (slots <= 0) return;
+  const int cnt = (int)skCount[f];
+  const size_t fo = (size_t)f * s;
+  const int readId = frags[f].readId;
+  const int rg = readGroup[readId], self = readSelf[readId], seqCounter = seqCounterBase + readId;
+  const bool usePre = pre != nullptr && pre[(size_t)f * preStride] == 1ull;
+  int preRun = 0, at = 0, nValid = 0;
+  uint16_t* idDst = ptIds ? ptIds + off : nullptr;
+  for (int base = 0; base < cnt; base += 256) {
+    uint64_t h[4], val[4]; bool act[4], found[4];
+    if (usePre) mm_probe4_pre(pre + (size_t)f * preStride, preVal + fo, cnt, base, lane, preRun, h, act, found, val);
+    else mm_probe4<TAGS>(T, skHash, fo, cnt, base, lane, h, act, found, val);
+#pragma unroll
+    for (int u = 0; u < 4; u++) val[u] = (act[u] && found[u] && !(val[u] & 1ull)) ? val[u] : 0ull;
+    nValid += mm_gather_points(pts + off, at, base >> 6, 4, [&](int rd) { return rd == 0 ? val[0] : rd == 1 ? val[1] : rd == 2 ? val[2] : val[3]; },
+                               ptKeys, refGroup, rg, self, seqCounter, fl, lane, idDst);
+  }
+  for (int j = at + lane; j < slots; j += 64) pts[off + j] = MM_EMPTY;
+  if (lane == 0) stats[f].nPoints = nValid;
+}
+
+// k_seed_probe (MM_SKETCH_PROBE): getSeedHits' table look-ups for the fragments [f0, f1) whose sketch the fast sketch kernel has
+// emitted (marker 2 in their SeedPre row), or for the listed fragments (the hard list, after k_sketch_hard) -- one wave per fragment,
+// nothing but probes: found masks and the values of the found entries in sketch order, for k_lookup_l1 to read instead of probing.
+// Launched chunk by chunk on a stream of its own while the sketch kernel -- bound by the vector ALU, HBM idle -- works on the next
+// chunk: against a human-scale table the probes are what puts k_lookup_l1 on the HBM roofline (one 128-byte line per probe).
+template <bool TAGS>
+__global__ void __launch_bounds__(256)
+k_seed_probe(int f0, int f1, const int32_t* __restrict__ list, const uint32_t* __restrict__ listCount, int s, const uint64_t* __restrict__ skHash, const uint32_t* __restrict__ skCount,
+             const SeedTable T, uint64_t* __restrict__ pre, uint64_t* __restrict__ preVal, int preStride) {
+  const int wpb = (int)(blockDim.x >> 6), lane = (int)mm_lane();
+  const int n = list ? (int)*listCount : f1 - f0;
+  for (int i = blockIdx.x * wpb + (int)(threadIdx.x >> 6); i < n; i += gridDim.x * wpb) {
+    const int f = list ? list[i] : f0 + i;
+    uint64_t* row = pre + (size_t)f * preStride;
+    if (!list && row[0] != 2ull) continue;                         // not emitted by the fast kernel: its sketch comes later, from the hard list
+    const int cnt = (int)skCount[f];
+    const size_t fo = (size_t)f * s;
+    int run = 0;
+    for (int base = 0; base < cnt; base += 256) {
+      uint64_t h[4], val[4]; bool act[4], found[4];
+      mm_probe4<TAGS>(T, skHash, fo, cnt, base, lane, h, act, found, val);
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        if ((base + u * 64) >= cnt) break;
+        const bool fnd = act[u] && found[u];
+        const uint64_t m = __ballot(fnd);
+        if (fnd) preVal[fo + run + (int)mm_popc_below(m)] = val[u];
+        if (lane == 0) row[1 + (base >> 6) + u] = m;
+        run += (int)__popcll(m);
+      }
+    }
+    __threadfence();
+    if (lane == 0) row[0] = 1ull;
   }
 }
 
@@ -1050,8 +1105,21 @@ k_l1_window(int nList, const int32_t* __restrict__ list, const DFrag* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------
-// launcher
+// launchers
 // ---------------------------------------------------------------------------------------------
+int mm_launch_seed_probe(mm_ctx* c, hipStream_t stream, int f0, int f1, const int32_t* dList, const uint32_t* dListCount) {
+  const DeviceIndex& I = c->idx;
+  const SeedTable seedTab{I.htSlots.as<HtSlot>(), (uint64_t)(I.htCap - 1), I.filter.as<uint64_t>(), (uint64_t)I.filterMask, I.tagged ? I.htTags.as<uint8_t>() : (const uint8_t*)nullptr};
+  const int n = dList ? 4096 : f1 - f0;                             // listed fragments: a fixed grid walks the device-resident list
+  if (n <= 0) return MM_OK;
+  int blocks = (n + 3) / 4; if (blocks > 256 * 16) blocks = 256 * 16;
+  auto k = I.tagged ? k_seed_probe<true> : k_seed_probe<false>;
+  hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, stream, f0, f1, dList, dListCount, c->P.sketchSize, c->dSkHash.as<uint64_t>(), c->dSkCount.as<uint32_t>(), seedTab,
+                     c->dPre.as<uint64_t>(), c->dPreVal.as<uint64_t>(), (int)c->preStride);
+  MM_HIP(c, hipGetLastError());
+  return MM_OK;
+}
+
 int mm_launch_map(mm_ctx* c) {
   const int nF = (int)c->nFrags, s = c->P.sketchSize;
   const DeviceIndex& I = c->idx;
@@ -1075,6 +1143,8 @@ int mm_launch_map(mm_ctx* c) {
   unsigned long long hc[8];
   unsigned long long* cnt = c->dCounters.as<unsigned long long>() + 8;   // [8..15]; [0..7] belong to the sketch launcher
 
+  const SeedTable seedTab{I.htSlots.as<HtSlot>(), (uint64_t)(I.htCap - 1), I.filter.as<uint64_t>(), (uint64_t)I.filterMask, I.tagged ? I.htTags.as<uint8_t>() : (const uint8_t*)nullptr};
+  const uint64_t* pre = c->preProbed ? c->dPre.as<uint64_t>() : (const uint64_t*)nullptr;
   unsigned long long hcur[MM_L1_REGIONS * MM_L1_CURSOR_STRIDE];
   L1Regions R;
   unsigned long long regionCap = 0;
@@ -1093,16 +1163,14 @@ int mm_launch_map(mm_ctx* c) {
       // larger ones (points come in proportion to the sketch: s = 310 averages ~176 per fragment with a long tail)
       int fuse = s > 256 ? 512 : s > 160 ? 256 : 128;
       if (const char* e = getenv("MM_FUSE_MAXPTS")) { const int v = atoi(e); fuse = v >= 512 ? 512 : v >= 256 ? 256 : 128; }
-      auto kern = I.tagged ? (fuse == 512 ? k_lookup_l1<512, true> : fuse == 256 ? k_lookup_l1<256, true> : k_lookup_l1<128, true>)
-                           : (fuse == 512 ? k_lookup_l1<512, false> : fuse == 256 ? k_lookup_l1<256, false> : k_lookup_l1<128, false>);
+      auto kern = pre ? (fuse == 512 ? k_lookup_l1<512, 2> : fuse == 256 ? k_lookup_l1<256, 2> : k_lookup_l1<128, 2>)
+                : I.tagged ? (fuse == 512 ? k_lookup_l1<512, 1> : fuse == 256 ? k_lookup_l1<256, 1> : k_lookup_l1<128, 1>)
+                           : (fuse == 512 ? k_lookup_l1<512, 0> : fuse == 256 ? k_lookup_l1<256, 0> : k_lookup_l1<128, 0>);
       hipLaunchKernelGGL(kern, dim3((nF + MM_LOOKUP_WPB - 1) / MM_LOOKUP_WPB), dim3(MM_LOOKUP_WPB * 64), 0, c->stream, nF, s, c->dFrags.as<DFrag>(),
-                         c->dSkHash.as<uint64_t>(), c->dSkStrand.as<int8_t>(), c->dSkCount.as<uint32_t>(),
-                         I.htSlots.as<HtSlot>(), (uint64_t)(I.htCap - 1), I.filter.as<uint64_t>(), (uint64_t)I.filterMask, I.htTags.as<uint8_t>(), I.ptKeys.as<uint64_t>(),
-                         I.refGroup.as<int32_t>(), c->dReadGroup.as<int32_t>(), c->dReadSelf.as<int32_t>(), c->seqCounterBase, fl,
-                         windowed ? 2 : (c->keepPoints ? 1 : 0),
-                         c->dQHash.as<uint64_t>(), c->dQStrand.as<int8_t>(), c->preProbed ? c->dPre.as<uint64_t>() : (const uint64_t*)nullptr, c->dPreVal.as<uint64_t>(), (int)c->preStride,
-                         c->dStats.as<mm_frag_stats>(),
-                         c->dPtOff.as<int64_t>(), c->dPts.as<uint64_t>(), c->dPtIds.as<uint16_t>(), (unsigned long long)c->ptsCap,
+                         c->dSkHash.as<uint64_t>(), c->dSkStrand.as<int8_t>(), c->dSkCount.as<uint32_t>(), seedTab, I.ptKeys.as<uint64_t>(),
+                         c->dReadSelf.as<int32_t>(), c->seqCounterBase, fl, windowed ? 2 : (c->keepPoints ? 1 : 0),
+                         c->dQHash.as<uint64_t>(), c->dQStrand.as<int8_t>(), pre, c->dPreVal.as<uint64_t>(), (int)c->preStride,
+                         c->dStats.as<mm_frag_stats>(), c->dPtOff.as<int64_t>(), (unsigned long long)c->ptsCap,
                          c->dMinHits.as<int32_t>(), c->dCutoffs.as<int32_t>(), (int)c->nCutoffs, c->P.segLength,
                          c->dL1.as<mm_l1_candidate>(), regionCap, c->dL1Cursors.as<unsigned long long>(), c->dL1Off.as<int64_t>(),
                          c->dBigList.as<int32_t>(), cnt);
@@ -1141,6 +1209,14 @@ int mm_launch_map(mm_ctx* c) {
     {
       KernelTimer t(c, MM_K_SORT);
       uint16_t* sortIds = windowed ? c->dPtIds.as<uint16_t>() : (uint16_t*)nullptr;
+      {
+        auto gk = I.tagged ? k_gather_points<true> : k_gather_points<false>;
+        hipLaunchKernelGGL(gk, dim3((nBig + 3) / 4), dim3(256), 0, c->stream, nBig, c->dBigList.as<int32_t>(), s, c->dFrags.as<DFrag>(), c->dSkHash.as<uint64_t>(),
+                           c->dSkCount.as<uint32_t>(), seedTab, pre, c->dPreVal.as<uint64_t>(), (int)c->preStride, I.ptKeys.as<uint64_t>(), I.refGroup.as<int32_t>(),
+                           c->dReadGroup.as<int32_t>(), c->dReadSelf.as<int32_t>(), c->seqCounterBase, fl, c->dStats.as<mm_frag_stats>(), c->dPtOff.as<int64_t>(),
+                           c->dPts.as<uint64_t>(), sortIds);
+        MM_HIP(c, hipGetLastError());
+      }
       if (!windowed) hipLaunchKernelGGL(k_sort_points_wave, dim3((nBig + 3) / 4), dim3(256), 0, c->stream, nBig, c->dBigList.as<int32_t>(), c->dPtOff.as<int64_t>(), c->dPts.as<uint64_t>());
       hipLaunchKernelGGL(k_classify_sort, dim3((nBig + 255) / 256), dim3(256), 0, c->stream, nBig, c->dBigList.as<int32_t>(), c->dPtOff.as<int64_t>(),
                          listB.as<int32_t>(), listC.as<int32_t>(), cls, windowed ? 1 : 64);

@@ -370,7 +370,7 @@ mm_sketch_fast(unsigned char* smem, const int f, const uint4* __restrict__ gTabs
                const DFrag* __restrict__ frags, const uint32_t* __restrict__ readHasN, int s, int wantFast, int HT, int PAD, int QC,
                uint64_t* __restrict__ skHash, int2* __restrict__ skPos, int8_t* __restrict__ skStrand,
                uint32_t* __restrict__ skCount, int32_t* __restrict__ hardList, uint32_t* __restrict__ hardCount,
-               unsigned long long* __restrict__ phaseStats, const SeedTable seedTab, const SeedPre seedPre) {
+               unsigned long long* __restrict__ phaseStats, const SeedPre seedPre) {
   // MM_SKETCH_STATS: shader-clock cycles thread 0 spends up to each phase boundary, summed over workgroups (diagnostics only)
   unsigned long long tPrev = phaseStats ? __builtin_amdgcn_s_memtime() : 0ull;
   auto mark = [&](int ph) {
@@ -573,30 +573,10 @@ mm_sketch_fast(unsigned char* smem, const int f, const uint4* __restrict__ gTabs
       // the reference accumulates the strand in an int16 (base_types.hpp:24, commonFunc.hpp:268)
       const int16_t acc = (int16_t)sum;
       skStrand[o] = acc > 0 ? 1 : (acc == 0 ? 0 : -1);
-      // MM_SKETCH_PROBE: the seed look-up of this entry, issued here -- the kernel is bound by the vector ALU and leaves HBM idle, while
-      // k_lookup_l1 against a human-scale table is bound by the lines its probes fetch.  Values meet in LDS (the queue memory is free).
-      if (seedPre.pre) qH[rank] = mm_seed_probe(seedTab, k);
     }
   }
   if (tid == 0) skCount[f] = D < (uint32_t)s ? D : (uint32_t)s;
-  if (seedPre.pre) {
-    __syncthreads();
-    if (tid < 64) {                                 // wave 0 compacts: found masks + the values of the found entries in sketch order
-      const int cntOut = (int)(D < (uint32_t)s ? D : (uint32_t)s);
-      uint64_t* pw = seedPre.pre + (size_t)f * seedPre.stride;
-      uint64_t* pv = seedPre.val + (size_t)f * s;
-      int run = 0;
-      for (int w = 0; w * 64 < cntOut; w++) {
-        const int r = w * 64 + tid;
-        const uint64_t v = r < cntOut ? qH[r] : 0ull;
-        const uint64_t m = __ballot(v != 0ull);
-        if (v != 0ull) pv[run + (int)mm_popc_below(m)] = v;
-        if (tid == 0) pw[1 + w] = m;
-        run += (int)__popcll(m);
-      }
-      if (tid == 0) pw[0] = 1ull;
-    }
-  }
+  if (seedPre.pre && tid == 0) seedPre.pre[(size_t)f * seedPre.stride] = 2ull;   // MM_SKETCH_PROBE: sketch emitted, k_seed_probe may take it
   mark(5);                                          // ranking + output (thread 0's share)
 }
 
@@ -606,10 +586,10 @@ k_sketch_fast(const uint4* __restrict__ gTabs, const uint32_t* __restrict__ base
               const DFrag* __restrict__ frags, const uint32_t* __restrict__ readHasN, int s, int wantFast, int HT, int PAD, int QC,
               uint64_t* __restrict__ skHash, int2* __restrict__ skPos, int8_t* __restrict__ skStrand,
               uint32_t* __restrict__ skCount, int32_t* __restrict__ hardList, uint32_t* __restrict__ hardCount,
-              unsigned long long* __restrict__ phaseStats, const SeedTable seedTab, const SeedPre seedPre) {
+              unsigned long long* __restrict__ phaseStats, const SeedPre seedPre, int f0) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  mm_sketch_fast<K, SL>(smem, (int)blockIdx.x, gTabs, bases2, nmask, frags, readHasN, s, wantFast, HT, PAD, QC, skHash, skPos, skStrand, skCount,
-                        hardList, hardCount, phaseStats, seedTab, seedPre);
+  mm_sketch_fast<K, SL>(smem, f0 + (int)blockIdx.x, gTabs, bases2, nmask, frags, readHasN, s, wantFast, HT, PAD, QC, skHash, skPos, skStrand, skCount,
+                        hardList, hardCount, phaseStats, seedPre);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -814,32 +794,57 @@ static int launch_sketch_k(mm_ctx* c, bool withProbe) {
   unsigned long long* phaseStats = nullptr;
   if (getenv("MM_SKETCH_STATS")) { phaseStats = c->dCounters.as<unsigned long long>() + 24; MM_HIP(c, hipMemsetAsync(phaseStats, 0, 64, c->stream)); }
   // MM_SKETCH_PROBE=1: the fast kernel probes the seed table for the sketch it emits (needs the queue memory to hold s values)
-  SeedTable seedTab{nullptr, 0, nullptr, 0, nullptr}; SeedPre seedPre{nullptr, nullptr, 0};
+  // MM_SKETCH_PROBE=1: getSeedHits' table look-ups leave k_lookup_l1 -- against a human-scale table they put it on the HBM roofline (one
+  // 128-byte line per probe) -- and run under the sketch kernel, which is bound by the vector ALU and leaves HBM idle: the fast kernel
+  // marks every fragment it emits, and k_seed_probe (mm_map.hip) looks the sketches up chunk by chunk on a stream of its own while the
+  // sketch kernel works on the next chunk.  k_lookup_l1 then reads found masks + values.
+  SeedPre seedPre{nullptr, nullptr, 0, 0};
   c->preProbed = false;
+  int probeMode = 0, nChunks = 1;
   {
-    static const bool probeOn = getenv("MM_SKETCH_PROBE") != nullptr && atoi(getenv("MM_SKETCH_PROBE")) != 0;
+    static const int probeEnv = getenv("MM_SKETCH_PROBE") ? atoi(getenv("MM_SKETCH_PROBE")) : 0;
     const DeviceIndex& I = c->idx;
-    if (probeOn && withProbe && I.ready && plan.useFast && (size_t)g.QC * (g.threads / 64) >= (size_t)s) {
+    if (probeEnv && withProbe && I.ready) {
+      probeMode = 2;
       c->preStride = (size_t)(s + 63) / 64 + 1;
       MM_HIP(c, c->dPre.ensure((size_t)nF * c->preStride * 8 + 64)); MM_HIP(c, c->dPreVal.ensure((size_t)nF * s * 8 + 64));
       MM_HIP(c, hipMemsetAsync(c->dPre.p, 0, (size_t)nF * c->preStride * 8, c->stream));
-      seedTab = SeedTable{I.htSlots.as<HtSlot>(), (uint64_t)(I.htCap - 1), I.filter.as<uint64_t>(), (uint64_t)I.filterMask, I.tagged ? I.htTags.as<uint8_t>() : (const uint8_t*)nullptr};
-      seedPre = SeedPre{c->dPre.as<uint64_t>(), c->dPreVal.as<uint64_t>(), (int)c->preStride};
+      seedPre = SeedPre{c->dPre.as<uint64_t>(), c->dPreVal.as<uint64_t>(), (int)c->preStride, probeMode};
       c->preProbed = true;
+      nChunks = 8;
+      if (const char* e = getenv("MM_PROBE_CHUNKS")) { const int v = atoi(e); if (v >= 1 && v <= 64) nChunks = v; }
+      if (nF < nChunks * 4096) nChunks = nF / 4096 > 0 ? nF / 4096 : 1;
+      if (!c->probeStream) {
+        int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi);          // hi = the numerically smallest = most urgent
+        MM_HIP(c, hipStreamCreateWithPriority(&c->probeStream, hipStreamNonBlocking, hi));
+        MM_HIP(c, hipEventCreateWithFlags(&c->probeDone, hipEventDisableTiming));
+      }
+      while ((int)c->probeEv.size() < nChunks) { hipEvent_t e; MM_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->probeEv.push_back(e); }
     }
   }
   if (plan.useFast) {
     KernelTimer t(c, MM_K_SKETCH);
+    int f0 = 0, f1 = nF;
     auto launch = [&](auto kern) {
       (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsFast);
-      hipLaunchKernelGGL(kern, dim3(nF), dim3(g.threads), ldsFast, c->stream,
+      hipLaunchKernelGGL(kern, dim3(f1 - f0), dim3(g.threads), ldsFast, c->stream,
                          c->dSketchTabs.as<uint4>(), c->dBases2.as<uint32_t>(), c->dNmask.as<uint32_t>(), c->dFrags.as<DFrag>(), c->dReadHasN.as<uint32_t>(),
                          s, g.wantFast, g.HT, PAD, g.QC, c->dSkHash.as<uint64_t>(), c->dSkPos.as<int2>(), c->dSkStrand.as<int8_t>(),
-                         c->dSkCount.as<uint32_t>(), c->dHardList.as<int32_t>(), c->dCounters.as<uint32_t>(), phaseStats, seedTab, seedPre);
+                         c->dSkCount.as<uint32_t>(), c->dHardList.as<int32_t>(), c->dCounters.as<uint32_t>(), phaseStats, seedPre, f0);
     };
-    if constexpr (MMHasSL20<K>::value) { if (g.SL == 20) launch(k_sketch_fast<K, 20>); else launch(k_sketch_fast<K, 16>); }
-    else launch(k_sketch_fast<K, 16>);
-    MM_HIP(c, hipGetLastError());
+    for (int ch = 0; ch < nChunks; ch++) {
+      f0 = (int)((int64_t)nF * ch / nChunks); f1 = (int)((int64_t)nF * (ch + 1) / nChunks);
+      if (f1 <= f0) continue;
+      if constexpr (MMHasSL20<K>::value) { if (g.SL == 20) launch(k_sketch_fast<K, 20>); else launch(k_sketch_fast<K, 16>); }
+      else launch(k_sketch_fast<K, 16>);
+      MM_HIP(c, hipGetLastError());
+      if (probeMode == 2) {                         // this chunk's look-ups start when its sketches are out, beside the next chunk's hashing
+        MM_HIP(c, hipEventRecord(c->probeEv[ch], c->stream));
+        MM_HIP(c, hipStreamWaitEvent(c->probeStream, c->probeEv[ch], 0));
+        const int rc = mm_launch_seed_probe(c, c->probeStream, f0, f1, nullptr, nullptr);
+        if (rc != MM_OK) return rc;
+      }
+    }
   } else {
     // the fast kernel's LDS geometry cannot hold this sketch: every fragment takes the exact path
     KernelTimer t(c, MM_K_SKETCH);
@@ -876,6 +881,15 @@ static int launch_sketch_k(mm_ctx* c, bool withProbe) {
       launchHard(k_sketch_hard<K, true>, c->dSketchSpill.as<int32_t>());
     } else launchHard(k_sketch_hard<K, false>, (int32_t*)nullptr);
     MM_HIP(c, hipGetLastError());
+  }
+  if (probeMode == 2) {
+    MM_HIP(c, hipEventRecord(c->probeDone, c->probeStream));
+    // join the probe stream (what is left of the last chunk's look-ups is the part that is not hidden), then the fragments of the hard
+    // list, whose sketches exist only now: every fragment has its row when k_lookup_l1 starts
+    KernelTimer t(c, MM_K_LOOKUP);
+    MM_HIP(c, hipStreamWaitEvent(c->stream, c->probeDone, 0));
+    const int rc = mm_launch_seed_probe(c, c->stream, 0, 0, c->dHardList.as<int32_t>(), c->dCounters.as<uint32_t>());
+    if (rc != MM_OK) return rc;
   }
   return MM_OK;
 }

@@ -31,23 +31,35 @@
 namespace skch {
 namespace hipseam {
 
-// one context per (device, k, segment length, sketch size): created on first use, kept for the life of the process
+// one context per (device, k, segment length, sketch size), created on first use.  A caller that sketches sequences of many different
+// lengths (the segment length is the sequence length rounded up) would otherwise pile up contexts -- each holds device buffers -- so the
+// cache keeps the MM_SEAM_CONTEXTS (8) most recently used and destroys the rest.  Callers hold callMutex() while they use a context,
+// which is also what makes the eviction safe.
+#ifndef MM_SEAM_CONTEXTS
+#define MM_SEAM_CONTEXTS 8
+#endif
 inline mm_ctx* context(int kmerSize, int segLength, int sketchSize) {
-  static std::mutex mu;
-  static std::map<std::tuple<int, int, int, int>, mm_ctx*> cache;
+  struct Entry { mm_ctx* ctx; uint64_t lastUse; };
+  static std::map<std::tuple<int, int, int, int>, Entry> cache;
+  static uint64_t tick = 0;
   const char* de = getenv("MASHMAP_HIP_DEVICE");
   const int dev = de ? atoi(de) : 0;
-  std::lock_guard<std::mutex> lk(mu);
   auto key = std::make_tuple(dev, kmerSize, segLength, sketchSize);
   auto it = cache.find(key);
-  if (it != cache.end()) return it->second;
+  if (it != cache.end()) { it->second.lastUse = ++tick; return it->second.ctx; }
+  if (cache.size() >= MM_SEAM_CONTEXTS) {                       // least recently used out
+    auto victim = cache.begin();
+    for (auto j = cache.begin(); j != cache.end(); ++j) if (j->second.lastUse < victim->second.lastUse) victim = j;
+    mm_destroy(victim->second.ctx);
+    cache.erase(victim);
+  }
   mm_params p; p.kmerSize = kmerSize; p.segLength = segLength; p.sketchSize = sketchSize; p.flags = MM_FLAG_NO_SPLIT;
   mm_ctx* c = nullptr;
   if (mm_create(&c, dev, &p) != MM_OK) {
     std::cerr << "[mashmap_hip::skch::CommonFunc] ERROR: " << mm_last_error(nullptr) << std::endl;
     exit(1);
   }
-  cache.emplace(key, c);
+  cache.emplace(key, Entry{c, ++tick});
   return c;
 }
 [[noreturn]] inline void die(const char* what, mm_ctx* c) {

@@ -104,6 +104,8 @@ class Map {
     std::deque<Batch> q; std::mutex mu; std::condition_variable cvFull, cvEmpty; bool done = false; size_t cap;
     explicit Channel(size_t c) : cap(c) {}
     void put(Batch&& b) { std::unique_lock<std::mutex> lk(mu); cvFull.wait(lk, [&] { return q.size() < cap; }); q.emplace_back(std::move(b)); lk.unlock(); cvEmpty.notify_one(); }
+    // blocks until there is room; with a single producer the put() that follows does not wait
+    void waitSpace() { std::unique_lock<std::mutex> lk(mu); cvFull.wait(lk, [&] { return q.size() < cap; }); }
     bool get(Batch& b) {
       std::unique_lock<std::mutex> lk(mu);
       cvEmpty.wait(lk, [&] { return !q.empty() || done; });
@@ -233,11 +235,14 @@ class Map {
           seqCounter++;
         }
         if (batch.size()) {
-          {                                               // idle staging slots: this batch's blocks start travelling now
-            std::lock_guard<std::mutex> lk(pfMu);
-            std::vector<size_t> cut;
-            for (size_t i = 0; i < ctxs.size(); i++) if (slotFree[i]) { if (cut.empty()) cut = blocksOf(batch); issuePrefetch(batch, i, cut); }
-          }
+          // idle staging slots: this batch's blocks start travelling now.  Prefetch and hand-over are ONE step under pfMu -- a batch that
+          // occupies a staging slot is always visible to the device stage's peekFront(), so a slot is never declared free (and given
+          // to a later batch) while a block still sits in it.  The wait for room in the queue comes first: the device stage takes pfMu
+          // between two get() calls, so a put() that blocked while holding it would never be served.
+          parsed.waitSpace();
+          std::lock_guard<std::mutex> lk(pfMu);
+          std::vector<size_t> cut;
+          for (size_t i = 0; i < ctxs.size(); i++) if (slotFree[i]) { if (cut.empty()) cut = blocksOf(batch); issuePrefetch(batch, i, cut); }
           parsed.put(std::move(batch));
         }
       }

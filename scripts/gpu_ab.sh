@@ -1,16 +1,21 @@
 #!/bin/bash
 # One GPU-box visit for an A/B of an env switch: parity suite, a parity subset with the switch on, bench lines both ways.
-# usage: scripts/gpu_ab.sh TAG "ENV=VAL ..." [suite|nosuite] [workloads...]
+# usage: scripts/gpu_ab.sh TAG "ENV=VAL ..." suite|subset|none [workloads...]   (workload "default" = the default bench line incl. north_star)
 TAG=${1:-ab}; SW=${2:-}; SUITE=${3:-suite}; shift 3
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
+SUBSET="tests/test_gpu_map.py tests/test_gpu_golden.py tests/test_gpu_paf.py tests/test_gpu_multigpu.py tests/test_gpu_fullsize.py"
+: > $OUT/log.txt
 if [ "$SUITE" = suite ]; then
-  echo "== pytest -m gpu" | tee $OUT/log.txt
-  timeout 1500 python -m pytest tests -m gpu -x -q -s 2>&1 | grep -v "^$" | tail -25 | tee -a $OUT/log.txt
+  echo "== pytest -m gpu" | tee -a $OUT/log.txt
+  timeout 1500 python -m pytest tests -m gpu -x -q -s 2>&1 | grep -v "^$" | grep -v "RCCL version\|HIP version\|ROCm version\|Hostname\|Librccl" | tail -25 | tee -a $OUT/log.txt
+elif [ "$SUITE" = subset ]; then
+  echo "== parity subset" | tee -a $OUT/log.txt
+  timeout 1500 python -m pytest $SUBSET -m gpu -x -q 2>&1 | grep -v "^$" | grep -v "RCCL version\|HIP version\|ROCm version\|Hostname\|Librccl" | tail -12 | tee -a $OUT/log.txt
 fi
 if [ -n "$SW" ]; then
   echo "== parity subset with $SW" | tee -a $OUT/log.txt
-  env $SW timeout 900 python -m pytest tests/test_gpu_map.py tests/test_gpu_golden.py tests/test_gpu_paf.py tests/test_gpu_multigpu.py -m gpu -x -q 2>&1 | tail -5 | tee -a $OUT/log.txt
+  env $SW timeout 1500 python -m pytest $SUBSET -m gpu -x -q 2>&1 | grep -v "^$" | grep -v "RCCL version\|HIP version\|ROCm version\|Hostname\|Librccl" | tail -12 | tee -a $OUT/log.txt
 fi
 summ() { python - "$1" <<'PY'
 import json, sys
