@@ -232,6 +232,13 @@ int mm_sketch_download(mm_ctx* ctx, mm_minmer* out, uint32_t* counts);
  * (identity, upper bound, complexity) are host work on these integers.  Results stay on the device until downloaded.
  */
 int mm_map_fragments(mm_ctx* ctx);
+/* How the last mm_map_fragments went: the number of times the host waited for the device inside it, and whether it was a steady-state
+ * pass -- the first pass of a context sizes every staging buffer from counts it reads back stage by stage (5-7 waits); the passes behind
+ * it launch against those capacities with the counts left on the device and wait once, at the end.  A pass that outgrows a buffer is
+ * redone the sized way (and counted as such here).  counts (4 entries, may be NULL): L1 candidates, L2 loci, fragments whose interval
+ * points went through HBM (more than the fused kernel holds; as of the last sized pass), entries reserved for the L2 streams (one per
+ * index event a candidate touches: what k_l2_locate reads 16 bytes for and k_l2_sweep at most 4). */
+int mm_pass_stats(const mm_ctx* ctx, uint64_t* hostSyncs, int* steady, uint64_t* counts);
 int mm_result_counts(const mm_ctx* ctx, size_t* nL1, size_t* nL2);
 /* any pointer may be NULL.  l1/l2 are sorted by (frag, emission order of the reference) */
 int mm_results_download(mm_ctx* ctx, mm_frag_stats* stats, mm_l1_candidate* l1, mm_l2_locus* l2);

@@ -125,6 +125,7 @@ def load():
         "mm_pack_read_portable": (sz, [vp, sz, vp, vp]),
         "mm_reads_packed_download": (C.c_int, [vp, vp, vp, vp, C.POINTER(sz)]),
         "mm_index_layout_get": (C.c_int, [vp, vp]),
+        "mm_pass_stats": (C.c_int, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_int), vp]),
         "mm_synchronize": (C.c_int, [vp]),
         "mm_stream": (vp, [vp]),
     }
@@ -149,7 +150,7 @@ EXPORTS = ["mm_abi_version", "mm_create", "mm_destroy", "mm_last_error", "mm_ind
            "mm_allgatherv_mappings_begin", "mm_allgatherv_mappings_end",
            "mm_gathered_counts", "mm_gathered_download", "mm_gathered_device", "mm_index_replicate", "mm_stat_replay_tables", "mm_host_alloc", "mm_host_free", "mm_reads_prefetch",
            "mm_reads_upload_packed", "mm_reads_prefetch_packed", "mm_pack_read", "mm_pack_read_portable", "mm_reads_packed_download",
-           "mm_index_layout_get"]
+           "mm_index_layout_get", "mm_pass_stats"]
 
 
 def stat_sketch_cutoffs(sketchSize, k, hg=True):
@@ -356,6 +357,18 @@ class Context:
 
     def map(self):
         self._ck(self.lib.mm_map_fragments(self.h), "mm_map_fragments")
+
+    def pass_stats(self):
+        """(host synchronisations inside the last map(), whether it was a steady-state pass)"""
+        n = C.c_uint64(); st = C.c_int()
+        self._ck(self.lib.mm_pass_stats(self.h, C.byref(n), C.byref(st), None), "mm_pass_stats")
+        return int(n.value), bool(st.value)
+
+    def pass_counts(self):
+        """dict(l1, l2, queued, stream_entries) of the last map()"""
+        a = np.zeros(4, dtype=np.uint64)
+        self._ck(self.lib.mm_pass_stats(self.h, None, None, _ptr(a)), "mm_pass_stats")
+        return dict(zip(("l1", "l2", "queued", "stream_entries"), (int(x) for x in a)))
 
     def results(self):
         n1, n2 = C.c_size_t(), C.c_size_t()

@@ -17,7 +17,7 @@ std::vector<DevBuf*> mm_ctx::allBufs() {
   return {&I.evKey, &I.evAux, &I.evHash, &I.contigOff, &I.opKey, &I.opAux, &I.opHash, &I.blockOff, &I.evBlock, &I.contigBlock, &I.contigLen, &I.refGroup,
           &I.htSlots, &I.htTags, &I.filter, &I.ptKeys, &I.keys, &I.keyOff, &I.keyFreq, &dMinHits, &dCutoffs, &dAscii, &dAsciiNext, &dReadSrcOff, &dReadPackOff, &dReadLen, &dReadGroup, &dReadSelf, &dReadHasN,
           &dBases2, &dNmask, &dFrags, &dSkHash, &dSkPos, &dSkStrand, &dSkCount, &dHardList, &dCounters, &dSketchSpill, &dSketchTabs, &dQHash, &dQStrand, &dPre, &dPreVal,
-          &dStats, &dPtOff, &dPts, &dPtIds, &dWinFreq, &dWinExt, &dWinHeap, &dWinKeys, &dWinVals, &dWinOffH, &dWinOffT, &dWinCntH, &dWinCntT, &dL1, &dL1b, &dL1Cursors, &dL1Off, &dL2, &dL2Info, &dL2Cnt, &dL2Off, &dL2Ops, &dScanTmp, &dL2Tmp, &dL2Wide, &dL2Exact, &dL2Cells,
+          &dStats, &dPtOff, &dPts, &dPtIds, &dWinFreq, &dWinExt, &dWinHeap, &dWinKeys, &dWinVals, &dWinOffH, &dWinOffT, &dWinCntH, &dWinCntT, &dL1, &dL1b, &dL1Cursors, &dL1Off, &dL1Regions, &dL2, &dL2Info, &dL2Cnt, &dL2Off, &dL2Ops, &dScanTmp, &dL2Tmp, &dL2Wide, &dL2Exact, &dL2Cells,
           &dListB, &dListC, &dBigList, &dL2Sort[0], &dL2Sort[1], &dL2Sort[2], &dL2Sort[3], &dL2Order, &dL2OrderPos, &dL2First, &dL2Num, &dAccept, &dMinIsz, &dSelCnt, &dSelOff, &dSelHeap, &dFragTab, &dMappings, &dCommCounts, &dGathered};
 }
 
@@ -72,6 +72,8 @@ void mm_destroy(mm_ctx* c) {
   for (hipEvent_t e : c->probeEv) (void)hipEventDestroy(e);
   if (c->probeDone) (void)hipEventDestroy(c->probeDone);
   for (DevBuf* b : c->allBufs()) b->release();
+  if (c->hPass) (void)hipHostFree(c->hPass);
+  for (auto& pr : c->evPool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   if (c->evA) (void)hipEventDestroy(c->evA);
   if (c->evB) (void)hipEventDestroy(c->evB);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -89,6 +91,7 @@ int mm_set_option(mm_ctx* c, int option, int value) {
 
 int mm_profile_enable(mm_ctx* c, int on) { c->profile = on != 0; return MM_OK; }
 int mm_profile_read(mm_ctx* c, double* ms, uint64_t* launches, int reset) {
+  if (!c->evPending.empty()) { MM_HIP(c, hipSetDevice(c->device)); MM_HIP(c, hipStreamSynchronize(c->stream)); mm_profile_collect(c); }
   for (int i = 0; i < MM_K_COUNT; i++) { if (ms) ms[i] = c->kMs[i]; if (launches) launches[i] = c->kLaunches[i]; }
   if (reset) for (int i = 0; i < MM_K_COUNT; i++) { c->kMs[i] = 0; c->kLaunches[i] = 0; }
   return MM_OK;
@@ -370,6 +373,7 @@ int mm_sketch_fragments(mm_ctx* c) {
   int rc = mm_launch_sketch(c);
   if (rc != MM_OK) return rc;
   MM_HIP(c, hipStreamSynchronize(c->stream));
+  if (c->profile) mm_profile_collect(c);
   c->sketched = true;
   return MM_OK;
 }
@@ -409,8 +413,17 @@ int mm_map_fragments(mm_ctx* c) {
   c->sketched = true;
   rc = mm_launch_map(c);
   if (rc != MM_OK) return rc;
-  MM_HIP(c, hipStreamSynchronize(c->stream));
+  if (!c->lastSteady) { MM_HIP(c, hipStreamSynchronize(c->stream)); c->nSyncs++; }   // a steady-state pass ends with its one synchronisation
+  if (c->profile) mm_profile_collect(c);
   c->mapped = true;
+  return MM_OK;
+}
+
+int mm_pass_stats(const mm_ctx* c, uint64_t* hostSyncs, int* steady, uint64_t* counts) {
+  if (!c->mapped) return MM_ERR_STATE;
+  if (hostSyncs) *hostSyncs = c->nSyncs;
+  if (steady) *steady = c->lastSteady ? 1 : 0;
+  if (counts) { counts[0] = c->nL1; counts[1] = c->nL2; counts[2] = c->lastBig; counts[3] = c->lastOps; }
   return MM_OK;
 }
 

@@ -112,6 +112,7 @@ struct mm_ctx {
   DevBuf dPtIds, dWinFreq, dWinExt, dWinHeap, dWinKeys, dWinVals, dWinOffH, dWinOffT, dWinCntH, dWinCntT;
   DevBuf dL1, dL1b, dL1Cursors; size_t l1Cap = 0, nL1 = 0;   // dL1b: the region-filled buffer k_l1_compact reads from
   DevBuf dL1Off;                                        // int64[nFrags] first candidate of a fragment
+  DevBuf dL1Regions;                                    // L1Regions: fill count + prefix position of the 64 output regions (k_l1_regions)
   DevBuf dL2; size_t l2Cap = 0, nL2 = 0;
   DevBuf dL2First, dL2Num;                              // per L1 candidate: first locus in dL2 (int64) and count (int32)
   // candidate mappings (mm_select.hip)
@@ -127,13 +128,20 @@ struct mm_ctx {
   DevBuf dL2Info, dL2Cnt, dL2Off, dL2Ops, dScanTmp, dL2Tmp, dL2Wide, dL2Exact, dL2Cells, dListB, dListC, dBigList;     // L2 staging: per-candidate stream extents, op counts/offsets, located ops
   DevBuf dL2Sort[4], dL2Order, dL2OrderPos;                          // candidates of a chunk in order of descending stream length (mm_order_desc)
   bool sketched = false, mapped = false;
+  // steady state: the previous pass of this context went through and left every buffer sized (mm_launch_map); what it saw
+  bool steadyOk = false, lastSteady = false; size_t prevBig = 0, candCap = 0; int prevLocap = 0;
+  unsigned long long* hPass = nullptr;                  // page-locked: the counters of a pass as read back at its end
+  size_t lastOps = 0, lastBig = 0;                      // L2 stream entries reserved / fragments queued for the HBM point path in the last pass
+  size_t nSyncs = 0;                                    // host synchronisations inside the last mm_map_fragments (diagnostics: mm_pass_syncs)
   bool keepPoints = false;                              // mm_set_option(MM_OPT_KEEP_POINTS): route every fragment through the HBM point list
 
   // profiling
   bool profile = false;
   double kMs[MM_K_COUNT] = {0};
   uint64_t kLaunches[MM_K_COUNT] = {0};
-  hipEvent_t evA = nullptr, evB = nullptr;
+  hipEvent_t evA = nullptr, evB = nullptr;              // mm_bench_hash_only's own pair
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> evPool; size_t evUsed = 0;   // KernelTimer brackets recorded since the last mm_profile_collect
+  std::vector<std::pair<int, size_t>> evPending;                              // (kernel, pool index)
 };
 
 #define MM_HIP(ctx, call)                                                                        \
@@ -145,17 +153,35 @@ struct mm_ctx {
     }                                                                                            \
   } while (0)
 
-struct KernelTimer {   // RAII hipEvent bracket on the ctx stream
-  mm_ctx* c; int which;
-  KernelTimer(mm_ctx* c_, int w) : c(c_), which(w) { if (c->profile) (void)hipEventRecord(c->evA, c->stream); }
+// RAII hipEvent bracket on the ctx stream.  The two events are only RECORDED here (a pair out of a pool that grows with the number of
+// brackets in flight); their times are read by mm_profile_collect once the stream has been synchronised anyway -- measuring a pass does
+// not add host waits to it (a steady-state pass stays at its one synchronisation with the per-kernel timers on).
+struct KernelTimer {
+  mm_ctx* c; int which; size_t idx = 0;
+  KernelTimer(mm_ctx* c_, int w) : c(c_), which(w) {
+    if (!c->profile) return;
+    if (c->evUsed == c->evPool.size()) {
+      hipEvent_t a = nullptr, b = nullptr;
+      (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+      c->evPool.emplace_back(a, b);
+    }
+    idx = c->evUsed++;
+    (void)hipEventRecord(c->evPool[idx].first, c->stream);
+  }
   ~KernelTimer() {
     if (!c->profile) return;
-    (void)hipEventRecord(c->evB, c->stream);
-    (void)hipEventSynchronize(c->evB);
-    float ms = 0; (void)hipEventElapsedTime(&ms, c->evA, c->evB);
-    c->kMs[which] += ms; c->kLaunches[which] += 1;
+    (void)hipEventRecord(c->evPool[idx].second, c->stream);
+    c->evPending.emplace_back(which, idx);
   }
 };
+// adds the recorded brackets to kMs / kLaunches; the stream must have been synchronised behind them
+inline void mm_profile_collect(mm_ctx* c) {
+  for (const auto& pr : c->evPending) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, c->evPool[pr.second].first, c->evPool[pr.second].second) == hipSuccess) { c->kMs[pr.first] += ms; c->kLaunches[pr.first] += 1; }
+  }
+  c->evPending.clear(); c->evUsed = 0;
+}
 
 // launchers implemented in the .hip files
 int mm_check_params(const mm_params* p, std::string& err);
@@ -164,11 +190,15 @@ int mm_launch_pack_raw(mm_ctx* c, const uint8_t* dAscii, const int64_t* dSrcOff,
                        int64_t nChunks, uint32_t* dB, uint32_t* dM, uint32_t* dHasN);
 int mm_launch_sketch(mm_ctx* c, bool withProbe = false);   // withProbe: look the sketches up in the resident seed table as well (MM_SKETCH_PROBE)
 int mm_launch_map(mm_ctx* c);
+// Steady state: once a pass of a context has sized every staging buffer, the next passes launch everything against
+// those capacities with the counts left on the device and read ONE block of counters back at the end (one host synchronisation per
+// pass); a pass that outgrows a buffer is detected there and redone the sized way (MM_PASS_REDO from the launchers).
+#define MM_PASS_REDO 1
 // k_seed_probe (mm_map.hip) for the fragments [f0, f1) the sketch kernel has marked, or (list != null) for the listed ones, on `stream`
 int mm_launch_seed_probe(mm_ctx* c, hipStream_t stream, int f0, int f1, const int32_t* dList, const uint32_t* dListCount);
-int mm_launch_select(mm_ctx* c);
+int mm_launch_select(mm_ctx* c, bool steady = false);
 void mm_comm_release(mm_ctx* c);
-int mm_launch_l2(mm_ctx* c, unsigned long long* cnt);   // cnt: device counters [4] cursor [5] overflow [6] slot overflow
+int mm_launch_l2(mm_ctx* c, unsigned long long* cnt, bool steady = false);   // cnt: device counters [2] candidates [4] cursor [5] overflow [6] flags
 int mm_build_device_index(mm_ctx* c, const int32_t* contigLen, const int32_t* refGroup, size_t nContigs);   // from the host mirrors
 int mm_flatten_device_index(mm_ctx* c, const mm_minmer* dRec, size_t n, size_t nk, size_t np, const int32_t* contigLen, const int32_t* refGroup, size_t nContigs);
 int mm_finalize_index_device(mm_ctx* c, const std::vector<std::pair<const mm_minmer*, size_t>>& parts, float kmerPctThreshold, const int32_t* contigLen,
@@ -176,5 +206,6 @@ int mm_finalize_index_device(mm_ctx* c, const std::vector<std::pair<const mm_min
 int mm_mirror_minmers(mm_ctx* c);
 int mm_mirror_map(mm_ctx* c);
 int mm_scan_i32_to_i64(mm_ctx* c, int64_t n, const int32_t* dIn, int64_t* dOut, int64_t* total);
+int mm_scan_i32_to_i64_dev(mm_ctx* c, int64_t n, const int32_t* dIn, int64_t* dOut, const int64_t** dTotal);   // the total stays on the device: no synchronisation
 int mm_order_desc(mm_ctx* c, const int32_t* dKey, int c0, int n, int shift, int32_t* dOrder);   // mm_index_dev.hip (rocPRIM radix sort)
 int mm_order_pairs(mm_ctx* c, int n, unsigned bits, int32_t* dOrder);                          // same file: pairs already in dL2Sort[0] / dL2Sort[2]

@@ -63,8 +63,14 @@ static inline int mm_l2_jb(int s) { return s > 2046 ? 13 : 11; }
 __global__ void __launch_bounds__(256)
 k_l2_extents(int nCand, int segLength, int deltaBits, const mm_l1_candidate* __restrict__ l1, const mm_frag_stats* __restrict__ stats, const uint32_t* __restrict__ evKey,
              const int64_t* __restrict__ contigBlock, const int64_t* __restrict__ blockOff,
-             const int64_t* __restrict__ evBlock, L2Info* __restrict__ info, int32_t* __restrict__ cnt) {
+             const int64_t* __restrict__ evBlock, L2Info* __restrict__ info, int32_t* __restrict__ cnt, const unsigned long long* __restrict__ nDev,
+             unsigned long long* __restrict__ counters /* [6] |= 32: more candidates than the buffers of this (steady-state) pass hold */) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (nDev) {                                                     // steady state: the launch covers the buffers' capacity, the count is on the device
+    const long long n = (long long)*nDev;
+    if (c == 0 && n > nCand) atomicOr(&counters[6], 32ull);
+    if (c >= n) { if (c < nCand) { cnt[c] = 0; info[c].e0 = 0; } return; }
+  }
   if (c >= nCand) return;
   const mm_l1_candidate cand = l1[c];
   const mm_frag_stats fst = stats[cand.frag];
@@ -154,10 +160,11 @@ k_scan_add(int64_t n, int64_t* __restrict__ out, const int64_t* __restrict__ til
 // order: taken as they come, every slice is fetched from HBM (16 B per event: the kernel sits on the HBM roofline against a human-scale
 // index); taken in reference order, the waves in flight at any moment read one neighbourhood of the index, which the Infinity Cache holds.
 __global__ void __launch_bounds__(256)
-k_l2_pos_keys(int c0, int n, int shift, const L2Info* __restrict__ info, uint32_t* __restrict__ kOut, int32_t* __restrict__ vOut) {
+k_l2_pos_keys(int c0, int n, int shift, const L2Info* __restrict__ info, uint32_t* __restrict__ kOut, int32_t* __restrict__ vOut, const unsigned long long* __restrict__ nDev) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  kOut[i] = (uint32_t)(info[c0 + i].e0 >> shift);
+  const bool real = !nDev || c0 + i < (int)*nDev;                 // steady state: n is the buffer's capacity, the entries behind the real ones sort last
+  kOut[i] = real ? (uint32_t)(info[c0 + i].e0 >> shift) : 0xFFFFu;
   vOut[i] = c0 + i;
 }
 
@@ -180,7 +187,8 @@ k_l2_locate(int cBase, int nCand, int64_t opsBase, int s, int NB, const mm_l1_ca
             const uint32_t* __restrict__ opKey, const uint32_t* __restrict__ opAux, const uint64_t* __restrict__ opHash,
             const int64_t* __restrict__ contigOff, const L2Info* __restrict__ info, const int64_t* __restrict__ opOff,
             const int32_t* __restrict__ opCnt, uint32_t* __restrict__ ops, const int32_t* __restrict__ order /* candidates in reference order, or null */,
-            unsigned long long* __restrict__ counters /* [6] |= 4: gap too wide */) {
+            unsigned long long* __restrict__ counters /* [6] |= 4: a stream outgrew its reservation, |= 8: the streams do not fit the buffer */,
+            const unsigned long long* __restrict__ nDev, int64_t opsCap) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   unsigned char* base = smem + (size_t)wave * mm_locate_lds_per_wave(s, NB);
@@ -189,14 +197,16 @@ k_l2_locate(int cBase, int nCand, int64_t opsBase, int s, int NB, const mm_l1_ca
   uint16_t* bkt = (uint16_t*)(base + (size_t)(s + 1) * 8 + (size_t)(s + 2) / 2 * 8);   // bkt[b] = #query hashes whose bucket is < b, b = 0..NB
   int8_t* qs = (int8_t*)(base + (size_t)(s + 1) * 8 + (size_t)(s + 2) / 2 * 8 + (size_t)(NB + 4) * 2);
   const int wpb = (int)(blockDim.x >> 6);                          // waves per workgroup: 4, fewer when a sketch's LDS share is large
+  if (nDev) nCand = (int)*nDev - cBase;                            // steady state: the count stayed on the device
   for (int ci = blockIdx.x * wpb + wave; ci < nCand; ci += gridDim.x * wpb) {
     const int c = order ? order[ci] : cBase + ci;                  // this launch covers the candidates [cBase, cBase + nCand): their streams start at ops[opOff - opsBase]
     const mm_l1_candidate cand = l1[c];
     const int f = cand.frag;
     const L2Info in = info[c];
     const int S = in.sketch & 0x7fffffff;
-    uint32_t* out = ops + (opOff[c] - opsBase);
     const int cap = opCnt[c];
+    if (opOff[c] - opsBase + cap > opsCap) { if (lane == 0) atomicOr(&counters[6], 8ull); continue; }   // only without the host's own sizing (steady state)
+    uint32_t* out = ops + (opOff[c] - opsBase);
     __threadfence_block();                                         // previous candidate's LDS reads are done
     // a fragment that lost no frequent seed has no copy in qHash/qStrand: its sketch is the raw one (k_lookup_l1)
     const bool raw = in.sketch < 0;
@@ -357,7 +367,8 @@ k_l2_sweep(int cBase, int nCand, int64_t opsBase, const int32_t* __restrict__ ca
            const int64_t* __restrict__ opOff, const int32_t* __restrict__ opCnt, const uint32_t* __restrict__ ops,
            const int64_t* __restrict__ l1Off, L2Tmp* __restrict__ tmp, int locap, mm_l2_locus* __restrict__ l2, unsigned long long l2Cap,
            int32_t* __restrict__ wideList, int32_t* __restrict__ exactList, int64_t* __restrict__ l2First, int32_t* __restrict__ l2Num,
-           unsigned long long* __restrict__ counters /* [0] candidates queued for the exact pass, [4] l2 cursor, [5] overflow, [6] flags, [7] queued for the wide pass */) {
+           unsigned long long* __restrict__ counters /* [0] candidates queued for the exact pass, [4] l2 cursor, [5] overflow, [6] flags, [7] queued for the wide pass */,
+           const unsigned long long* __restrict__ nDev /* non-null: the number of candidates (minus cBase) or of list entries lives there */, int64_t opsCap, int listCap) {
   typedef typename std::conditional<WIDE, uint16_t, uint8_t>::type CellT;
   constexpr int CB = WIDE ? 12 : 5;
   constexpr uint32_t CMASK = (1u << CB) - 1u;
@@ -368,13 +379,19 @@ k_l2_sweep(int cBase, int nCand, int64_t opsBase, const int32_t* __restrict__ ca
   CellT* cell = (CellT*)cellRaw;
   const int lane = threadIdx.x;
   const int li = blockIdx.x * LPW + lane;
+  if (nDev) {
+    const long long nd = (long long)*nDev - (listCap ? 0 : cBase);
+    if (listCap && nd > listCap && li == 0) atomicOr(&counters[6], 16ull);   // more listed candidates than this launch covers: the pass is redone with the host's sizing
+    nCand = (int)(nd < (listCap ? listCap : nCand) ? nd : (listCap ? listCap : nCand));
+  }
   if (lane >= LPW || li >= nCand) return;
   const int cIdx = candList ? candList[li] : cBase + li;   // candidates [cBase, cBase + nCand), or the listed ones (absolute indices); ops holds the streams from opsBase on
   const mm_l1_candidate cand = l1[cIdx];
   const int f = cand.frag;
   const int S = stats[f].sketchSize;
-  const uint4* src = (const uint4*)(ops + (opOff[cIdx] - opsBase));
-  const int nSteps = opCnt[cIdx] / E_STEP;             // 16 entries = 4 x 16 bytes per step
+  const bool fits = opOff[cIdx] - opsBase + opCnt[cIdx] <= opsCap;            // false only in a steady-state pass whose streams outgrew the buffer (k_l2_locate has flagged it)
+  const uint4* src = (const uint4*)(ops + (fits ? opOff[cIdx] - opsBase : 0));
+  const int nSteps = fits ? opCnt[cIdx] / E_STEP : 0;  // 16 entries = 4 x 16 bytes per step
   int posAcc = cand.rangeStartPos;                     // running position of the delta code
   const int lbase = WIDE ? (LPW == 64 ? (lane & 31) * 2 + (lane >> 5) : lane) : lane * 4;
 #define CELL(p) cell[WIDE ? (p) * LPW + lbase : ((p) >> 2) * (LPW * 4) + lbase + ((p) & 3)]
@@ -547,8 +564,13 @@ k_l2_sweep_exact(int jb, int nList, int64_t opsBase, const int32_t* __restrict__
                  const int64_t* __restrict__ opOff, const int32_t* __restrict__ opCnt, const uint32_t* __restrict__ ops,
                  const int64_t* __restrict__ l1Off, ExactCell* __restrict__ cells, int cellStride, L2Tmp* __restrict__ tmp, int locap,
                  mm_l2_locus* __restrict__ l2, unsigned long long l2Cap, int64_t* __restrict__ l2First, int32_t* __restrict__ l2Num,
-                 unsigned long long* __restrict__ counters) {
+                 unsigned long long* __restrict__ counters, const unsigned long long* __restrict__ nDev) {
   const int li = blockIdx.x * 64 + threadIdx.x;
+  if (nDev) {                                          // steady state: the launch covers nList entries, the list's length is on the device
+    const long long nd = (long long)*nDev;
+    if (nd > nList && li == 0) atomicOr(&counters[6], 16ull);
+    if (nd < nList) nList = (int)nd;
+  }
   if (li >= nList) return;
   const int cIdx = list[li];
   const mm_l1_candidate cand = l1[cIdx];
@@ -873,7 +895,8 @@ static int mm_launch_l2_window(mm_ctx* c, unsigned long long* cnt) {
 }
 
 // ---------------------------------------------------------------------------------------------
-int mm_scan_i32_to_i64(mm_ctx* c, int64_t n, const int32_t* dIn, int64_t* dOut, int64_t* total) {
+// exclusive scan; the total stays on the device at *dTotal (a word of dScanTmp, valid until the next scan of this context)
+int mm_scan_i32_to_i64_dev(mm_ctx* c, int64_t n, const int32_t* dIn, int64_t* dOut, const int64_t** dTotal) {
   const int64_t nTiles = (n + SCAN_TILE - 1) / SCAN_TILE;
   MM_HIP(c, c->dScanTmp.ensure((size_t)(nTiles + 2) * 8));
   int64_t* tileSum = c->dScanTmp.as<int64_t>();
@@ -881,30 +904,49 @@ int mm_scan_i32_to_i64(mm_ctx* c, int64_t n, const int32_t* dIn, int64_t* dOut, 
   hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, c->stream, nTiles, tileSum, tileSum + nTiles);
   hipLaunchKernelGGL(k_scan_add, dim3((unsigned)nTiles), dim3(256), 0, c->stream, n, dOut, tileSum);
   MM_HIP(c, hipGetLastError());
-  MM_HIP(c, hipMemcpyAsync(total, tileSum + nTiles, 8, hipMemcpyDeviceToHost, c->stream));
+  if (dTotal) *dTotal = tileSum + nTiles;
+  return MM_OK;
+}
+int mm_scan_i32_to_i64(mm_ctx* c, int64_t n, const int32_t* dIn, int64_t* dOut, int64_t* total) {
+  const int64_t* dTotal = nullptr;
+  const int rc = mm_scan_i32_to_i64_dev(c, n, dIn, dOut, &dTotal);
+  if (rc != MM_OK) return rc;
+  MM_HIP(c, hipMemcpyAsync(total, dTotal, 8, hipMemcpyDeviceToHost, c->stream));
   MM_HIP(c, hipStreamSynchronize(c->stream));
   return MM_OK;
 }
 
-int mm_launch_l2(mm_ctx* c, unsigned long long* cnt) {
+#define MM_SYNC(c) do { MM_HIP(c, hipStreamSynchronize((c)->stream)); (c)->nSyncs++; } while (0)
+#define MM_WIDE_CAP 4096     // steady-state passes: candidates the 16-bit re-run / the exact kernel are launched for without knowing their number
+#define MM_EXACT_CAP 1024
+
+int mm_launch_l2(mm_ctx* c, unsigned long long* cnt, bool steady) {
   if (c->windowed) return mm_launch_l2_window(c, cnt);               // fragments longer than segLength (--noSplit): the literal kernel
   const DeviceIndex& I = c->idx;
   const int s = c->P.sketchSize;
-  const int nC = (int)c->nL1;
+  // sized pass: the candidates are counted (c->nL1) and the candidate-indexed buffers get an eighth of head room, which is what a
+  // steady-state pass (count on the device: cnt[2]) launches against
+  if (!steady) c->candCap = c->nL1 + c->nL1 / 8 + 1024;
+  const int nC = steady ? (int)c->candCap : (int)c->nL1;              // candidates the launches cover
+  const int nCbuf = (int)c->candCap;
+  const unsigned long long* nDev = steady ? cnt + 2 : nullptr;
   const int JB = mm_l2_jb(s);                                              // width of the stream entries' sketch-position field
-  MM_HIP(c, c->dL2Info.ensure((size_t)nC * sizeof(L2Info) + 64));
-  MM_HIP(c, c->dL2Cnt.ensure((size_t)nC * 4 + 64));
-  MM_HIP(c, c->dL2Off.ensure((size_t)nC * 8 + 64));
+  MM_HIP(c, c->dL2Info.ensure((size_t)nCbuf * sizeof(L2Info) + 64));
+  MM_HIP(c, c->dL2Cnt.ensure((size_t)nCbuf * 4 + 64));
+  MM_HIP(c, c->dL2Off.ensure((size_t)nCbuf * 8 + 64));
   MM_HIP(c, hipMemsetAsync(cnt + 4, 0, 24, c->stream));
   int64_t totalOps = 0;
   {
     KernelTimer t(c, MM_K_L2_LOCATE);
     hipLaunchKernelGGL(k_l2_extents, dim3((nC + 255) / 256), dim3(256), 0, c->stream, nC, c->P.segLength, JB == 13 ? EF<13>::DELTA_BITS : EF<11>::DELTA_BITS, c->dL1.as<mm_l1_candidate>(), c->dStats.as<mm_frag_stats>(),
                        I.evKey.as<uint32_t>(), I.contigBlock.as<int64_t>(), I.blockOff.as<int64_t>(), I.evBlock.as<int64_t>(),
-                       c->dL2Info.as<L2Info>(), c->dL2Cnt.as<int32_t>());
+                       c->dL2Info.as<L2Info>(), c->dL2Cnt.as<int32_t>(), nDev, cnt);
     MM_HIP(c, hipGetLastError());
-    int rc = mm_scan_i32_to_i64(c, nC, c->dL2Cnt.as<int32_t>(), c->dL2Off.as<int64_t>(), &totalOps);
-    if (rc != MM_OK) return rc;
+    if (steady) {
+      const int64_t* dTotal = nullptr;
+      const int rc = mm_scan_i32_to_i64_dev(c, nC, c->dL2Cnt.as<int32_t>(), c->dL2Off.as<int64_t>(), &dTotal); if (rc != MM_OK) return rc;
+      MM_HIP(c, hipMemcpyAsync(c->dCounters.as<unsigned long long>() + 34, dTotal, 8, hipMemcpyDeviceToDevice, c->stream));   // read back with the pass's counters
+    } else { const int rc = mm_scan_i32_to_i64(c, nC, c->dL2Cnt.as<int32_t>(), c->dL2Off.as<int64_t>(), &totalOps); c->nSyncs++; if (rc != MM_OK) return rc; c->lastOps = (size_t)totalOps; }
   }
   // The located streams (4 bytes per event a candidate touches: ~5 KB per candidate at s = 130) live in HBM only between the locate and
   // the sweep kernels.  A batch with very many candidates -- reads out of repeat families -- is taken through the two in chunks of
@@ -912,7 +954,8 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt) {
   struct Chunk { int c0, n; int64_t base; };
   std::vector<Chunk> chunks;
   int64_t maxChunkOps = totalOps;
-  {
+  if (steady) chunks.push_back(Chunk{0, nC, 0});                           // one chunk: the streams must fit the buffer as it is (k_l2_locate flags it otherwise)
+  else {
     int64_t budget = (int64_t)24 << 28;                                    // in 4-byte entries
     if (const char* e = getenv("MM_L2_STREAM_MIB")) { const double v = atof(e); if (v > 0) budget = (int64_t)(v * 262144.0); }
     if (totalOps <= budget || nC <= 1) chunks.push_back(Chunk{0, nC, 0});
@@ -940,7 +983,9 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt) {
       if (getenv("MM_DEBUG")) fprintf(stderr, "[mm] L2: %lld stream entries of %d candidates in %zu chunks of at most %lld\n", (long long)totalOps, nC, chunks.size(), (long long)maxChunkOps);
     }
   }
-  MM_HIP(c, c->dL2Ops.ensure((size_t)maxChunkOps * 4 + 256));
+  if (!steady) MM_HIP(c, c->dL2Ops.ensure((size_t)(maxChunkOps + maxChunkOps / 16) * 4 + 256));   // a sixteenth of head room for the steady-state passes behind this one
+  const int64_t opsCap = steady || chunks.size() == 1 ? (int64_t)(c->dL2Ops.bytes / 4) - 64 : (int64_t)1 << 62;
+  if (steady && chunks.size() == 1 && c->dL2Ops.bytes == 0) return MM_PASS_REDO;
   // buckets of the query-sketch search: at least one per sketch entry (more buckets cost more to fill per candidate than the shorter
   // walks save: profiles/r02z_locate_buckets.txt)
   int NB = 256; while (NB < s) NB <<= 1;
@@ -956,10 +1001,10 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt) {
     KernelTimer t(c, MM_K_L2_LOCATE);
     const int32_t* order = nullptr;
     if (sortLocate && ch.n > 4096) {
-      MM_HIP(c, c->dL2OrderPos.ensure((size_t)ch.n * 4 + 64));
-      MM_HIP(c, c->dL2Sort[0].ensure((size_t)ch.n * 4 + 64)); MM_HIP(c, c->dL2Sort[2].ensure((size_t)ch.n * 4 + 64));
+      MM_HIP(c, c->dL2OrderPos.ensure((size_t)nCbuf * 4 + 64));
+      MM_HIP(c, c->dL2Sort[0].ensure((size_t)nCbuf * 4 + 64)); MM_HIP(c, c->dL2Sort[2].ensure((size_t)nCbuf * 4 + 64));
       hipLaunchKernelGGL(k_l2_pos_keys, dim3((unsigned)((ch.n + 255) / 256)), dim3(256), 0, c->stream, ch.c0, ch.n, posShift, c->dL2Info.as<L2Info>(),
-                         c->dL2Sort[0].as<uint32_t>(), c->dL2Sort[2].as<int32_t>());
+                         c->dL2Sort[0].as<uint32_t>(), c->dL2Sort[2].as<int32_t>(), nDev);
       MM_HIP(c, hipGetLastError());
       const int rc = mm_order_pairs(c, ch.n, 16u, c->dL2OrderPos.as<int32_t>());
       if (rc != MM_OK) return rc;
@@ -973,7 +1018,7 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt) {
                          I.evKey.as<uint32_t>(),
                          I.evAux.as<uint32_t>(), I.evHash.as<uint64_t>(), I.opKey.as<uint32_t>(), I.opAux.as<uint32_t>(), I.opHash.as<uint64_t>(),
                          I.contigOff.as<int64_t>(),
-                         c->dL2Info.as<L2Info>(), c->dL2Off.as<int64_t>(), c->dL2Cnt.as<int32_t>(), c->dL2Ops.as<uint32_t>(), order, cnt);
+                         c->dL2Info.as<L2Info>(), c->dL2Off.as<int64_t>(), c->dL2Cnt.as<int32_t>(), c->dL2Ops.as<uint32_t>(), order, cnt, nDev, opsCap);
     };
     if (JB == 13) go(k_l2_locate<13>); else go(k_l2_locate<11>);
     MM_HIP(c, hipGetLastError());
@@ -988,14 +1033,15 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt) {
   const size_t ldsWide = (size_t)(s + 1) * lpwW * 2;                       // cells 0..S, 16 bit
   const size_t ldsNarrow = (size_t)((s + 1 + 3) / 4) * lpwN * 4;           // 8 bit
   if (ldsWide > 160 * 1024 || ldsNarrow > 160 * 1024) { c->err = "sketchSize too large for the LDS-resident L2 state"; return MM_ERR_ARG; }
-  // one launch of a sweep kernel: n candidates starting at c0, or the n listed ones
-  auto sweep = [&](bool wide, int c0, int n, int64_t opsBase, const int32_t* list, int locap_) {
+  // one launch of a sweep kernel: n candidates starting at c0, or the n listed ones (countDev: their number lives on the device, the
+  // launch covers listCap of them)
+  auto sweep = [&](bool wide, int c0, int n, int64_t opsBase, const int32_t* list, int locap_, const unsigned long long* countDev, int listCap) {
     auto go = [&](auto kern, int lpw, size_t lds) {
       (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL(kern, dim3((unsigned)((n + lpw - 1) / lpw)), dim3(64), lds, c->stream, c0, n, opsBase, list, c->P.segLength,
                          c->dL1.as<mm_l1_candidate>(), c->dStats.as<mm_frag_stats>(), c->dL2Off.as<int64_t>(), c->dL2Cnt.as<int32_t>(), c->dL2Ops.as<uint32_t>(),
                          c->dL1Off.as<int64_t>(), c->dL2Tmp.as<L2Tmp>(), locap_, c->dL2.as<mm_l2_locus>(), (unsigned long long)c->l2Cap,
-                         c->dL2Wide.as<int32_t>(), c->dL2Exact.as<int32_t>(), c->dL2First.as<int64_t>(), c->dL2Num.as<int32_t>(), cnt);
+                         c->dL2Wide.as<int32_t>(), c->dL2Exact.as<int32_t>(), c->dL2First.as<int64_t>(), c->dL2Num.as<int32_t>(), cnt, countDev, opsCap, listCap);
     };
     if (!wide) {
       if (JB == 11) go(k_l2_sweep<false, 11, 64>, 64, ldsNarrow);
@@ -1006,15 +1052,15 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt) {
       else { if (lpwW == 16) go(k_l2_sweep<true, 13, 16>, 16, ldsWide); else go(k_l2_sweep<true, 13, 8>, 8, ldsWide); }
     }
   };
-  MM_HIP(c, c->dL2Wide.ensure((size_t)nC * 4 + 64)); MM_HIP(c, c->dL2Exact.ensure((size_t)nC * 4 + 64));
-  MM_HIP(c, c->dL2First.ensure((size_t)nC * 8 + 64)); MM_HIP(c, c->dL2Num.ensure((size_t)nC * 4 + 64));
-  if (c->l2Cap < c->nL1 * 2 + 1024) c->l2Cap = c->nL1 * 2 + 1024;
-  unsigned long long hc[8];
-  int locap = MM_LOCAP0;
+  MM_HIP(c, c->dL2Wide.ensure((size_t)nCbuf * 4 + 64)); MM_HIP(c, c->dL2Exact.ensure((size_t)nCbuf * 4 + 64));
+  MM_HIP(c, c->dL2First.ensure((size_t)nCbuf * 8 + 64)); MM_HIP(c, c->dL2Num.ensure((size_t)nCbuf * 4 + 64));
+  if (c->l2Cap < (size_t)nCbuf * 2 + 1024) c->l2Cap = (size_t)nCbuf * 2 + 1024;
+  unsigned long long hc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int locap = steady && c->prevLocap ? c->prevLocap : MM_LOCAP0;
   const bool sortSweep = getenv("MM_L2_NO_SORT") == nullptr;
   for (int attempt = 0; attempt < 24; attempt++) {
     MM_HIP(c, c->dL2.ensure(c->l2Cap * sizeof(mm_l2_locus) + 64));
-    MM_HIP(c, c->dL2Tmp.ensure((size_t)nC * locap * sizeof(L2Tmp) + 64));
+    MM_HIP(c, c->dL2Tmp.ensure((size_t)nCbuf * locap * sizeof(L2Tmp) + 64));
     MM_HIP(c, hipMemsetAsync(cnt + 4, 0, 16, c->stream));                  // [4] cursor [5] overflow; [6] keeps the locate kernel's flag
     for (const Chunk& ch : chunks) {
       if (!oneChunk) { const int rc = locate(ch); if (rc != MM_OK) return rc; }
@@ -1026,24 +1072,38 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt) {
         // (a wave runs as long as its longest; lengths spread ~ +-10 % around 45 steps: max of 64 is ~15 % above the mean)
         const int32_t* order = nullptr;
         if (sortSweep && ch.n > 64) {
-          MM_HIP(c, c->dL2Order.ensure((size_t)ch.n * 4 + 64));
+          MM_HIP(c, c->dL2Order.ensure((size_t)nCbuf * 4 + 64));
           const int rc = mm_order_desc(c, c->dL2Cnt.as<int32_t>(), ch.c0, ch.n, 4, c->dL2Order.as<int32_t>());
           if (rc != MM_OK) return rc;
           order = c->dL2Order.as<int32_t>();
         }
-        sweep(false, ch.c0, ch.n, ch.base, order, locap);
+        sweep(false, ch.c0, ch.n, ch.base, order, locap, nDev, 0);
         MM_HIP(c, hipGetLastError());
       }
+      if (steady) {
+        // the 16-bit re-run and the exact kernel for however many candidates the narrow sweep has queued (usually none): launched for
+        // a fixed number of them, the lists' lengths are read on the device
+        KernelTimer t(c, MM_K_L2);
+        sweep(true, 0, MM_WIDE_CAP, ch.base, c->dL2Wide.as<int32_t>(), locap, cnt + 7, MM_WIDE_CAP);
+        MM_HIP(c, hipGetLastError());
+        MM_HIP(c, c->dL2Cells.ensure((size_t)MM_EXACT_CAP * (size_t)(s + 1) * sizeof(ExactCell) + 64));
+        hipLaunchKernelGGL(k_l2_sweep_exact, dim3((unsigned)((MM_EXACT_CAP + 63) / 64)), dim3(64), 0, c->stream, JB, MM_EXACT_CAP, ch.base, c->dL2Exact.as<int32_t>(), c->P.segLength,
+                           c->dL1.as<mm_l1_candidate>(), c->dStats.as<mm_frag_stats>(), c->dL2Off.as<int64_t>(), c->dL2Cnt.as<int32_t>(), c->dL2Ops.as<uint32_t>(),
+                           c->dL1Off.as<int64_t>(), c->dL2Cells.as<ExactCell>(), s + 1, c->dL2Tmp.as<L2Tmp>(), locap, c->dL2.as<mm_l2_locus>(),
+                           (unsigned long long)c->l2Cap, c->dL2First.as<int64_t>(), c->dL2Num.as<int32_t>(), cnt, cnt);
+        MM_HIP(c, hipGetLastError());
+        continue;
+      }
       MM_HIP(c, hipMemcpyAsync(hc, cnt, 64, hipMemcpyDeviceToHost, c->stream));
-      MM_HIP(c, hipStreamSynchronize(c->stream));
+      MM_SYNC(c);
       if (hc[7] && !(hc[6] & 1ull) && !hc[5]) {                            // the few candidates whose 5-bit counters overflowed
         const int nWide = (int)hc[7];
         if (getenv("MM_DEBUG")) fprintf(stderr, "[mm] L2 sweep: %d of %d candidates redone with 16-bit cells\n", nWide, ch.n);
         KernelTimer t(c, MM_K_L2);
-        sweep(true, 0, nWide, ch.base, c->dL2Wide.as<int32_t>(), locap);
+        sweep(true, 0, nWide, ch.base, c->dL2Wide.as<int32_t>(), locap, nullptr, 0);
         MM_HIP(c, hipGetLastError());
         MM_HIP(c, hipMemcpyAsync(hc, cnt, 64, hipMemcpyDeviceToHost, c->stream));
-        MM_HIP(c, hipStreamSynchronize(c->stream));
+        MM_SYNC(c);
       }
       if (hc[0] && !(hc[6] & 1ull) && !hc[5]) {                            // candidates with a doubly open query hash: the literal sweep
         const int nExact = (int)hc[0];
@@ -1053,14 +1113,15 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt) {
         hipLaunchKernelGGL(k_l2_sweep_exact, dim3((unsigned)((nExact + 63) / 64)), dim3(64), 0, c->stream, JB, nExact, ch.base, c->dL2Exact.as<int32_t>(), c->P.segLength,
                            c->dL1.as<mm_l1_candidate>(), c->dStats.as<mm_frag_stats>(), c->dL2Off.as<int64_t>(), c->dL2Cnt.as<int32_t>(), c->dL2Ops.as<uint32_t>(),
                            c->dL1Off.as<int64_t>(), c->dL2Cells.as<ExactCell>(), s + 1, c->dL2Tmp.as<L2Tmp>(), locap, c->dL2.as<mm_l2_locus>(),
-                           (unsigned long long)c->l2Cap, c->dL2First.as<int64_t>(), c->dL2Num.as<int32_t>(), cnt);
+                           (unsigned long long)c->l2Cap, c->dL2First.as<int64_t>(), c->dL2Num.as<int32_t>(), cnt, (const unsigned long long*)nullptr);
         MM_HIP(c, hipGetLastError());
         MM_HIP(c, hipMemcpyAsync(hc, cnt, 64, hipMemcpyDeviceToHost, c->stream));
-        MM_HIP(c, hipStreamSynchronize(c->stream));
+        MM_SYNC(c);
       }
       if (hc[6] & 1ull) break;                                             // slots ran out: everything is redone below with more of them (a full locus
                                                                            // buffer lets the other chunks run on, so that the cursor ends at the total demand)
     }
+    if (steady) return MM_OK;                                              // the flags and the count are read when the pass is over
     if (hc[6] & 1ull) {                                                    // a candidate with more tied loci than slots (tandem repeats): more slots, again
       if ((size_t)nC * (size_t)locap * 2 * sizeof(L2Tmp) > ((size_t)64 << 30)) break;
       locap *= 2;
@@ -1075,5 +1136,6 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt) {
   if (hc[6] & 1ull) { c->err = "an L1 candidate with more tied L2 loci than 64 GiB of staging can hold"; return MM_ERR_CAPACITY; }
   if (hc[5]) { c->err = "L2 locus buffer overflow"; return MM_ERR_CAPACITY; }
   c->nL2 = (size_t)hc[4];
+  c->prevLocap = locap;
   return MM_OK;
 }

@@ -555,13 +555,14 @@ __global__ void __launch_bounds__(256)
 k_gather_points(int nList, const int32_t* __restrict__ list, int s, const DFrag* __restrict__ frags, const uint64_t* __restrict__ skHash, const uint32_t* __restrict__ skCount,
                 const SeedTable T, const uint64_t* __restrict__ pre, const uint64_t* __restrict__ preVal, int preStride,
                 const uint64_t* __restrict__ ptKeys, const int32_t* __restrict__ refGroup, const int32_t* __restrict__ readGroup, const int32_t* __restrict__ readSelf,
-                int seqCounterBase, MapFlags fl, mm_frag_stats* __restrict__ stats, const int64_t* __restrict__ ptOff, uint64_t* __restrict__ pts, uint16_t* __restrict__ ptIds) {
-  const int li = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (li >= nList) return;
+                int seqCounterBase, MapFlags fl, mm_frag_stats* __restrict__ stats, const int64_t* __restrict__ ptOff, uint64_t* __restrict__ pts, uint16_t* __restrict__ ptIds,
+                const unsigned long long* __restrict__ nDev) {
+  if (nDev) nList = (int)*nDev;
+  for (int li = blockIdx.x * 4 + (threadIdx.x >> 6); li < nList; li += gridDim.x * 4) {
   const int f = list[li];
   const int lane = (int)mm_lane();
   const int64_t off = ptOff[2 * f]; const int slots = (int)ptOff[2 * f + 1];
-  if (slots <= 0) return;
+  if (slots <= 0) continue;
   const int cnt = (int)skCount[f];
   const size_t fo = (size_t)f * s;
   const int readId = frags[f].readId;
@@ -580,6 +581,7 @@ k_gather_points(int nList, const int32_t* __restrict__ list, int s, const DFrag*
   }
   for (int j = at + lane; j < slots; j += 64) pts[off + j] = MM_EMPTY;
   if (lane == 0) stats[f].nPoints = nValid;
+  }
 }
 
 // k_seed_probe (MM_SKETCH_PROBE): getSeedHits' table look-ups for the fragments [f0, f1) whose sketch the fast sketch kernel has
@@ -621,95 +623,120 @@ k_seed_probe(int f0, int f1, const int32_t* __restrict__ list, const uint32_t* _
 // closes the gaps between the 64 regions of the L1 buffer: region r moves to its prefix position (into a second buffer), and
 // the fragments' first-candidate offsets follow
 struct L1Regions { unsigned long long prefix[MM_L1_REGIONS]; unsigned long long count[MM_L1_REGIONS]; };
-__global__ void __launch_bounds__(256)
-k_l1_compact(const mm_l1_candidate* __restrict__ src, mm_l1_candidate* __restrict__ dst, unsigned long long regionCap, L1Regions R) {
-  const int r = blockIdx.y;
-  for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < R.count[r]; i += (unsigned long long)gridDim.x * 256)
-    dst[R.prefix[r] + i] = src[(unsigned long long)r * regionCap + i];
+// the regions' fill counts -> their prefix positions in the dense buffer (device-resident: no host round trip between the lookup kernel
+// and the compaction) and the number of fused candidates (counters[2])
+__global__ void __launch_bounds__(64)
+k_l1_regions(const unsigned long long* __restrict__ l1Cursors, unsigned long long regionCap, L1Regions* __restrict__ R, unsigned long long* __restrict__ counters) {
+  const int r = threadIdx.x;
+  unsigned long long n = l1Cursors[(size_t)r * MM_L1_CURSOR_STRIDE];
+  if (n > regionCap) n = regionCap;                              // an overflowed region (counters[3] is set): what was written
+  const int ex = mm_wave_excl_scan((int)n);
+  R->count[r] = n; R->prefix[r] = (unsigned long long)ex;
+  if (r == 63) counters[2] = (unsigned long long)ex + n;
 }
 __global__ void __launch_bounds__(256)
-k_l1_fix_offsets(int nFrags, const mm_frag_stats* __restrict__ stats, int64_t* __restrict__ l1Off, unsigned long long regionCap, L1Regions R) {
+k_l1_compact(const mm_l1_candidate* __restrict__ src, mm_l1_candidate* __restrict__ dst, unsigned long long regionCap, const L1Regions* __restrict__ R) {
+  const int r = blockIdx.y;
+  const unsigned long long n = R->count[r], at = R->prefix[r];
+  for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256)
+    dst[at + i] = src[(unsigned long long)r * regionCap + i];
+}
+__global__ void __launch_bounds__(256)
+k_l1_fix_offsets(int nFrags, const mm_frag_stats* __restrict__ stats, int64_t* __restrict__ l1Off, unsigned long long regionCap, const L1Regions* __restrict__ R) {
   const int f = blockIdx.x * 256 + threadIdx.x;
   if (f >= nFrags || stats[f].nL1 <= 0) return;
   const int r = f & (MM_L1_REGIONS - 1);
-  l1Off[f] = l1Off[f] - (int64_t)((unsigned long long)r * regionCap) + (int64_t)R.prefix[r];
+  l1Off[f] = l1Off[f] - (int64_t)((unsigned long long)r * regionCap) + (int64_t)R->prefix[r];
 }
 
 // ---------------------------------------------------------------------------------------------
 // point sorters for the queued fragments (ascending packed key == ascending (seqId, pos, CLOSE-before-OPEN))
 // ---------------------------------------------------------------------------------------------
 // <= 64 points: one wave per fragment, bitonic network over the lanes
+// The kernels over the queued fragments take the list's length from the device when nDev is given (the launcher then has not read it
+// back: steady-state passes, one host synchronisation per pass) and walk the list with whatever grid they were given.
 __global__ void __launch_bounds__(256)
-k_sort_points_wave(int nList, const int32_t* __restrict__ list, const int64_t* __restrict__ ptOff, uint64_t* __restrict__ pts) {
-  const int li = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (li >= nList) return;
-  const int f = list[li];
-  const int64_t off = ptOff[2 * f]; const int n = (int)ptOff[2 * f + 1];
-  if (n <= 1 || n > 64) return;
-  const int lane = (int)mm_lane();
-  uint64_t k[1] = {lane < n ? pts[off + lane] : MM_EMPTY};
-  mm_wave_bitonic<1>(k, lane);
-  if (lane < n) pts[off + lane] = k[0];
+k_sort_points_wave(int nList, const unsigned long long* __restrict__ nDev, const int32_t* __restrict__ list, const int64_t* __restrict__ ptOff, uint64_t* __restrict__ pts) {
+  if (nDev) nList = (int)*nDev;
+  for (int li = blockIdx.x * 4 + (threadIdx.x >> 6); li < nList; li += gridDim.x * 4) {
+    const int f = list[li];
+    const int64_t off = ptOff[2 * f]; const int n = (int)ptOff[2 * f + 1];
+    if (n <= 1 || n > 64) continue;
+    const int lane = (int)mm_lane();
+    uint64_t k[1] = {lane < n ? pts[off + lane] : MM_EMPTY};
+    mm_wave_bitonic<1>(k, lane);
+    if (lane < n) pts[off + lane] = k[0];
+  }
 }
 
 // 65..LDSCAP points (power of two): one 256-thread workgroup per fragment, bitonic sort staged in LDS
 #define MM_SORT_LDSCAP 4096
 // ids (may be null): a 16-bit payload that travels with its key (windowed mode: the seed of every point)
 __global__ void __launch_bounds__(256)
-k_sort_points_block(const int64_t* __restrict__ ptOff, uint64_t* __restrict__ pts, const int32_t* __restrict__ list, uint16_t* __restrict__ ids) {
+k_sort_points_block(const unsigned int* __restrict__ nListDev, const int64_t* __restrict__ ptOff, uint64_t* __restrict__ pts, const int32_t* __restrict__ list, uint16_t* __restrict__ ids) {
   __shared__ uint64_t sk[MM_SORT_LDSCAP];
   __shared__ uint16_t si[MM_SORT_LDSCAP];
-  const int f = list[blockIdx.x];
-  const int64_t off = ptOff[2 * f]; const int n = (int)ptOff[2 * f + 1];
-  for (int i = threadIdx.x; i < n; i += 256) { sk[i] = pts[off + i]; if (ids) si[i] = ids[off + i]; }
-  __syncthreads();
-  for (int k = 2; k <= n; k <<= 1)
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = threadIdx.x; i < n; i += 256) {
-        const int p = i ^ j;
-        if (p > i) {
-          const uint64_t a = sk[i], b = sk[p];
-          if ((a > b) == ((i & k) == 0)) { sk[i] = b; sk[p] = a; if (ids) { const uint16_t t = si[i]; si[i] = si[p]; si[p] = t; } }
+  const int nList = (int)*nListDev;
+  for (int li = blockIdx.x; li < nList; li += gridDim.x) {
+    const int f = list[li];
+    const int64_t off = ptOff[2 * f]; const int n = (int)ptOff[2 * f + 1];
+    for (int i = threadIdx.x; i < n; i += 256) { sk[i] = pts[off + i]; if (ids) si[i] = ids[off + i]; }
+    __syncthreads();
+    for (int k = 2; k <= n; k <<= 1)
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int i = threadIdx.x; i < n; i += 256) {
+          const int p = i ^ j;
+          if (p > i) {
+            const uint64_t a = sk[i], b = sk[p];
+            if ((a > b) == ((i & k) == 0)) { sk[i] = b; sk[p] = a; if (ids) { const uint16_t t = si[i]; si[i] = si[p]; si[p] = t; } }
+          }
         }
+        __syncthreads();
       }
-      __syncthreads();
-    }
-  for (int i = threadIdx.x; i < n; i += 256) { pts[off + i] = sk[i]; if (ids) ids[off + i] = si[i]; }
+    for (int i = threadIdx.x; i < n; i += 256) { pts[off + i] = sk[i]; if (ids) ids[off + i] = si[i]; }
+    __syncthreads();
+  }
 }
 
 // > LDSCAP points: one 1024-thread workgroup per fragment, bitonic sort in global memory (rare: very repetitive seeds)
 __global__ void __launch_bounds__(1024)
-k_sort_points_global(const int64_t* __restrict__ ptOff, uint64_t* __restrict__ pts, const int32_t* __restrict__ list, uint16_t* __restrict__ ids) {
-  const int f = list[blockIdx.x];
-  const int64_t off = ptOff[2 * f]; const int64_t n = ptOff[2 * f + 1];
-  uint64_t* a = pts + off;
-  uint16_t* d = ids ? ids + off : nullptr;
-  for (int64_t k = 2; k <= n; k <<= 1)
-    for (int64_t j = k >> 1; j > 0; j >>= 1) {
-      for (int64_t i = threadIdx.x; i < n; i += 1024) {
-        const int64_t p = i ^ j;
-        if (p > i) { const uint64_t x = a[i], y = a[p]; if ((x > y) == ((i & k) == 0)) { a[i] = y; a[p] = x; if (d) { const uint16_t t = d[i]; d[i] = d[p]; d[p] = t; } } }
+k_sort_points_global(const unsigned int* __restrict__ nListDev, const int64_t* __restrict__ ptOff, uint64_t* __restrict__ pts, const int32_t* __restrict__ list, uint16_t* __restrict__ ids) {
+  const int nList = (int)*nListDev;
+  for (int li = blockIdx.x; li < nList; li += gridDim.x) {
+    const int f = list[li];
+    const int64_t off = ptOff[2 * f]; const int64_t n = ptOff[2 * f + 1];
+    uint64_t* a = pts + off;
+    uint16_t* d = ids ? ids + off : nullptr;
+    for (int64_t k = 2; k <= n; k <<= 1)
+      for (int64_t j = k >> 1; j > 0; j >>= 1) {
+        for (int64_t i = threadIdx.x; i < n; i += 1024) {
+          const int64_t p = i ^ j;
+          if (p > i) { const uint64_t x = a[i], y = a[p]; if ((x > y) == ((i & k) == 0)) { a[i] = y; a[p] = x; if (d) { const uint16_t t = d[i]; d[i] = d[p]; d[p] = t; } } }
+        }
+        __threadfence_block();
+        __syncthreads();
       }
-      __threadfence_block();
-      __syncthreads();
-    }
+  }
 }
 
 // splits the queued fragments into the block / global sorter lists (wave-aggregated cursors)
-__global__ void k_classify_sort(int nList, const int32_t* __restrict__ list, const int64_t* __restrict__ ptOff,
+__global__ void k_classify_sort(int nList, const unsigned long long* __restrict__ nDev, const int32_t* __restrict__ list, const int64_t* __restrict__ ptOff,
                                 int32_t* __restrict__ listB, int32_t* __restrict__ listC, unsigned int* __restrict__ cnt /* [0] B, [1] C */, int minB /* lists longer than this go to the LDS sorter */) {
-  const int li = blockIdx.x * blockDim.x + threadIdx.x;
-  int f = -1; int64_t n = 0;
-  if (li < nList) { f = list[li]; n = ptOff[2 * f + 1]; }
-  const bool isC = n > MM_SORT_LDSCAP, isB = !isC && n > minB;
-  const uint64_t mB = __ballot(isB), mC = __ballot(isC);
-  unsigned int bB = 0, bC = 0;
-  if (mB && mm_lane() == (uint32_t)__builtin_ctzll(mB)) bB = atomicAdd(&cnt[0], (unsigned int)__popcll(mB));
-  if (mC && mm_lane() == (uint32_t)__builtin_ctzll(mC)) bC = atomicAdd(&cnt[1], (unsigned int)__popcll(mC));
-  if (mB) bB = __shfl(bB, __builtin_ctzll(mB));
-  if (mC) bC = __shfl(bC, __builtin_ctzll(mC));
-  if (isB) listB[bB + mm_popc_below(mB)] = f;
-  if (isC) listC[bC + mm_popc_below(mC)] = f;
+  if (nDev) nList = (int)*nDev;
+  for (int base = blockIdx.x * blockDim.x; base < nList; base += gridDim.x * blockDim.x) {
+    const int li = base + threadIdx.x;
+    int f = -1; int64_t n = 0;
+    if (li < nList) { f = list[li]; n = ptOff[2 * f + 1]; }
+    const bool isC = n > MM_SORT_LDSCAP, isB = !isC && n > minB;
+    const uint64_t mB = __ballot(isB), mC = __ballot(isC);
+    unsigned int bB = 0, bC = 0;
+    if (mB && mm_lane() == (uint32_t)__builtin_ctzll(mB)) bB = atomicAdd(&cnt[0], (unsigned int)__popcll(mB));
+    if (mC && mm_lane() == (uint32_t)__builtin_ctzll(mC)) bC = atomicAdd(&cnt[1], (unsigned int)__popcll(mC));
+    if (mB) bB = __shfl(bB, __builtin_ctzll(mB));
+    if (mC) bC = __shfl(bC, __builtin_ctzll(mC));
+    if (isB) listB[bB + mm_popc_below(mB)] = f;
+    if (isC) listC[bC + mm_popc_below(mC)] = f;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -815,13 +842,13 @@ __global__ void __launch_bounds__(256)
 k_l1_stream(int nList, const int32_t* __restrict__ list, const int64_t* __restrict__ ptOff, const uint64_t* __restrict__ pts,
             mm_frag_stats* __restrict__ stats, const int32_t* __restrict__ minHitsTab, const int32_t* __restrict__ cutoffs, int nCutoffs,
             int sParam, int segLength, int hg, mm_l1_candidate* __restrict__ l1, unsigned long long l1Cap, int64_t* __restrict__ l1Off,
-            int32_t* __restrict__ lit, unsigned int* __restrict__ litCount, unsigned long long* __restrict__ counters /* [2] l1 cursor, [3] overflow */) {
+            int32_t* __restrict__ lit, unsigned int* __restrict__ litCount, unsigned long long* __restrict__ counters /* [2] l1 cursor, [3] overflow */,
+            const unsigned long long* __restrict__ nDev) {
   __shared__ L1RunS bufAll[4][MM_STREAM_BUF];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   L1RunS* buf = bufAll[wave];
-  const int li = blockIdx.x * 4 + wave;
-  if (li >= nList) return;
-  const int f = list[li];
+  if (nDev) nList = (int)*nDev;
+  auto one = [&](const int f) {
   const int nPts = stats[f].nPoints, S = stats[f].sketchSize;
   if (nPts <= 0 || S <= 0) { if (lane == 0) { stats[f].nL1 = 0; l1Off[f] = 0; } return; }
   const uint64_t* p = pts + ptOff[2 * f];
@@ -965,6 +992,8 @@ k_l1_stream(int nList, const int32_t* __restrict__ list, const int64_t* __restri
     }
   }
   if (lane == 0) { stats[f].nL1 = total; l1Off[f] = total > 0 ? base : 0; }
+  };
+  for (int li = blockIdx.x * 4 + wave; li < nList; li += gridDim.x * 4) { one(list[li]); __threadfence_block(); }
 }
 
 __global__ void __launch_bounds__(256)
@@ -973,10 +1002,11 @@ k_l1_sweep(int nList, const int32_t* __restrict__ list, const int64_t* __restric
            const int32_t* __restrict__ minHitsTab, const int32_t* __restrict__ cutoffs, int nCutoffs, int sParam, int segLength,
            MapFlags fl, const int32_t* __restrict__ refGroup, mm_l1_candidate* __restrict__ l1, unsigned long long l1Cap,
            int64_t* __restrict__ l1Off, unsigned long long* __restrict__ counters /* [2] l1 cursor, [3] overflow */,
-           const unsigned int* __restrict__ nListDev /* non-null: the list's length lives on the device (what k_l1_stream left over) */) {
-  const int li = blockIdx.x * blockDim.x + threadIdx.x;
+           const unsigned int* __restrict__ nListDev /* non-null: the list's length lives on the device (what k_l1_stream left over) */,
+           const unsigned long long* __restrict__ nDev64 /* non-null: the same as a 64-bit counter (the hand-over count of k_lookup_l1) */) {
   if (nListDev) nList = (int)*nListDev;
-  if (li >= nList) return;
+  if (nDev64) nList = (int)*nDev64;
+  for (int li = blockIdx.x * blockDim.x + threadIdx.x; li < nList; li += gridDim.x * blockDim.x) {
   const int f = list[li];
   const int nPts = stats[f].nPoints, S = stats[f].sketchSize;
   int nOut = 0; long long base = 0;
@@ -998,6 +1028,7 @@ k_l1_sweep(int nList, const int32_t* __restrict__ list, const int64_t* __restric
   }
   stats[f].nL1 = nOut;
   l1Off[f] = base;
+  }
 }
 
 
@@ -1112,23 +1143,28 @@ int mm_launch_seed_probe(mm_ctx* c, hipStream_t stream, int f0, int f1, const in
   const SeedTable seedTab{I.htSlots.as<HtSlot>(), (uint64_t)(I.htCap - 1), I.filter.as<uint64_t>(), (uint64_t)I.filterMask, I.tagged ? I.htTags.as<uint8_t>() : (const uint8_t*)nullptr};
   const int n = dList ? 4096 : f1 - f0;                             // listed fragments: a fixed grid walks the device-resident list
   if (n <= 0) return MM_OK;
-  int blocks = (n + 3) / 4; if (blocks > 256 * 16) blocks = 256 * 16;
+  int wpb = 4;                                                      // waves per workgroup (MM_PROBE_WPB: experiment)
+  if (const char* e = getenv("MM_PROBE_WPB")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) wpb = v; }
+  int blocks = (n + wpb - 1) / wpb; if (blocks > 256 * 64 / wpb) blocks = 256 * 64 / wpb;
   auto k = I.tagged ? k_seed_probe<true> : k_seed_probe<false>;
-  hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, stream, f0, f1, dList, dListCount, c->P.sketchSize, c->dSkHash.as<uint64_t>(), c->dSkCount.as<uint32_t>(), seedTab,
+  hipLaunchKernelGGL(k, dim3(blocks), dim3(wpb * 64), 0, stream, f0, f1, dList, dListCount, c->P.sketchSize, c->dSkHash.as<uint64_t>(), c->dSkCount.as<uint32_t>(), seedTab,
                      c->dPre.as<uint64_t>(), c->dPreVal.as<uint64_t>(), (int)c->preStride);
   MM_HIP(c, hipGetLastError());
   return MM_OK;
 }
 
-int mm_launch_map(mm_ctx* c) {
+#define MM_SYNC(c) do { MM_HIP(c, hipStreamSynchronize((c)->stream)); (c)->nSyncs++; } while (0)
+
+// One pass of seed lookup + L1 + L2 + selection over the resident sketches.
+//   steady == false: every stage is sized from the counts of the one before it, read back from the device (and grown + retried when a
+//                    buffer overflows): five to seven host synchronisations per pass.
+//   steady == true : the previous pass of this context has sized every buffer; everything is launched against those capacities with
+//                    the counts left on the device (kernels over lists take their lengths from there, kernels over candidates cover the
+//                    buffers' capacity), and one block of counters is read back at the end: ONE synchronisation per pass.  A pass that
+//                    outgrew a buffer has its overflow flag set there and is redone the sized way (MM_PASS_REDO).
+static int map_pass(mm_ctx* c, const bool steady) {
   const int nF = (int)c->nFrags, s = c->P.sketchSize;
   const DeviceIndex& I = c->idx;
-  MM_HIP(c, c->dQHash.ensure((size_t)nF * s * 8 + 64)); MM_HIP(c, c->dQStrand.ensure((size_t)nF * s + 64));
-  MM_HIP(c, c->dStats.ensure((size_t)nF * sizeof(mm_frag_stats) + 64));
-  MM_HIP(c, c->dPtOff.ensure((size_t)nF * 16 + 64)); MM_HIP(c, c->dL1Off.ensure((size_t)nF * 8 + 64));
-  MM_HIP(c, c->dCounters.ensure(256));
-  c->nL1 = c->nL2 = 0; c->nMappings = 0;
-  if (nF == 0) return MM_OK;
   MapFlags fl{(c->P.flags & MM_FLAG_HG_FILTER) ? 1 : 0, (c->P.flags & MM_FLAG_SKIP_SELF) ? 1 : 0,
               (c->P.flags & MM_FLAG_SKIP_PREFIX) ? 1 : 0, (c->P.flags & MM_FLAG_LOWER_TRIANGULAR) ? 1 : 0};
   // fragments longer than segLength (--noSplit): windowLen != 0 -- every fragment takes the literal path with its points (and their
@@ -1139,14 +1175,16 @@ int mm_launch_map(mm_ctx* c) {
   if (c->l1Cap == 0) c->l1Cap = (size_t)nF * 2 + 1024;
   DevBuf& listB = c->dListB; DevBuf& listC = c->dListC;
   MM_HIP(c, listB.ensure((size_t)nF * 4 + 16)); MM_HIP(c, listC.ensure((size_t)nF * 4 + 16)); MM_HIP(c, c->dBigList.ensure((size_t)nF * 4 + 16));
+  MM_HIP(c, c->dL1Regions.ensure(sizeof(L1Regions)));
   int rc = MM_OK;
-  unsigned long long hc[8];
+  unsigned long long hc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long* cnt = c->dCounters.as<unsigned long long>() + 8;   // [8..15]; [0..7] belong to the sketch launcher
+  unsigned long long* cnt2 = c->dCounters.as<unsigned long long>() + 32; // [32..]: [0] candidate mappings [1] their buffer overflowed
+  const unsigned long long* nBigDev = steady ? cnt + 7 : nullptr;
 
   const SeedTable seedTab{I.htSlots.as<HtSlot>(), (uint64_t)(I.htCap - 1), I.filter.as<uint64_t>(), (uint64_t)I.filterMask, I.tagged ? I.htTags.as<uint8_t>() : (const uint8_t*)nullptr};
   const uint64_t* pre = c->preProbed ? c->dPre.as<uint64_t>() : (const uint64_t*)nullptr;
   unsigned long long hcur[MM_L1_REGIONS * MM_L1_CURSOR_STRIDE];
-  L1Regions R;
   unsigned long long regionCap = 0;
   for (int attempt = 0; attempt < 10; attempt++) {          // grow-and-retry on capacity overflow (points or L1 candidates)
     regionCap = (c->l1Cap + MM_L1_REGIONS - 1) / MM_L1_REGIONS + 64;
@@ -1156,6 +1194,7 @@ int mm_launch_map(mm_ctx* c) {
     MM_HIP(c, c->dL1b.ensure(regionCap * MM_L1_REGIONS * sizeof(mm_l1_candidate) + 64));
     MM_HIP(c, c->dL1Cursors.ensure(sizeof hcur));
     MM_HIP(c, hipMemsetAsync(c->dCounters.p, 0, 256, c->stream));
+    MM_HIP(c, hipMemsetAsync(cnt2, 0, 64, c->stream));
     MM_HIP(c, hipMemsetAsync(c->dL1Cursors.p, 0, sizeof hcur, c->stream));
     {
       KernelTimer t(c, MM_K_LOOKUP);
@@ -1176,9 +1215,10 @@ int mm_launch_map(mm_ctx* c) {
                          c->dBigList.as<int32_t>(), cnt);
       MM_HIP(c, hipGetLastError());
     }
+    if (steady) break;                                        // overflow flags ([1], [3]) are looked at when the pass is over
     MM_HIP(c, hipMemcpyAsync(hc, cnt, 64, hipMemcpyDeviceToHost, c->stream));
     MM_HIP(c, hipMemcpyAsync(hcur, c->dL1Cursors.p, sizeof hcur, hipMemcpyDeviceToHost, c->stream));
-    MM_HIP(c, hipStreamSynchronize(c->stream));
+    MM_SYNC(c);
     if (hc[1]) { c->ptsCap = (size_t)hc[0] + (size_t)hc[0] / 8 + 4096; continue; }
     if (hc[3]) {                                              // some region overflowed: size for the largest one seen
       unsigned long long mx = 0;
@@ -1190,13 +1230,16 @@ int mm_launch_map(mm_ctx* c) {
   if (hc[1]) { c->err = "interval-point buffer overflow"; return MM_ERR_CAPACITY; }
   if (hc[3]) { c->err = "L1 candidate buffer overflow"; return MM_ERR_CAPACITY; }
   {
+    // the regions' prefix positions and the number of fused candidates (cnt[2]) are computed on the device; the sized pass knows them
+    // from the cursors it has read
     unsigned long long tot = 0;
-    for (int r = 0; r < MM_L1_REGIONS; r++) { R.count[r] = hcur[(size_t)r * MM_L1_CURSOR_STRIDE]; R.prefix[r] = tot; tot += R.count[r]; }
-    hc[2] = tot;
-    if (tot) {
+    for (int r = 0; r < MM_L1_REGIONS; r++) tot += hcur[(size_t)r * MM_L1_CURSOR_STRIDE];
+    hc[2] = steady ? 0 : tot;
+    if (steady || tot) {
       KernelTimer t(c, MM_K_L1);
-      hipLaunchKernelGGL(k_l1_compact, dim3(64, MM_L1_REGIONS), dim3(256), 0, c->stream, c->dL1.as<mm_l1_candidate>(), c->dL1b.as<mm_l1_candidate>(), regionCap, R);
-      hipLaunchKernelGGL(k_l1_fix_offsets, dim3((nF + 255) / 256), dim3(256), 0, c->stream, nF, c->dStats.as<mm_frag_stats>(), c->dL1Off.as<int64_t>(), regionCap, R);
+      hipLaunchKernelGGL(k_l1_regions, dim3(1), dim3(64), 0, c->stream, c->dL1Cursors.as<unsigned long long>(), regionCap, c->dL1Regions.as<L1Regions>(), cnt);
+      hipLaunchKernelGGL(k_l1_compact, dim3(64, MM_L1_REGIONS), dim3(256), 0, c->stream, c->dL1.as<mm_l1_candidate>(), c->dL1b.as<mm_l1_candidate>(), regionCap, c->dL1Regions.as<L1Regions>());
+      hipLaunchKernelGGL(k_l1_fix_offsets, dim3((nF + 255) / 256), dim3(256), 0, c->stream, nF, c->dStats.as<mm_frag_stats>(), c->dL1Off.as<int64_t>(), regionCap, c->dL1Regions.as<L1Regions>());
       MM_HIP(c, hipGetLastError());
     }
     std::swap(c->dL1, c->dL1b);                               // dL1 is the dense buffer from here on
@@ -1204,35 +1247,43 @@ int mm_launch_map(mm_ctx* c) {
   size_t denseCap = c->dL1.bytes / sizeof(mm_l1_candidate) - 4;   // room behind the fused candidates for the sweep path's
   const int nBig = (int)hc[7];
   if (getenv("MM_DEBUG")) fprintf(stderr, "[mm] lookup+L1: %d fragments, %d to the sort+sweep path, %llu fused candidates\n", nF, nBig, hc[2]);
-  if (nBig > 0) {
+  if (steady || nBig > 0) {
     unsigned int* cls = (unsigned int*)(c->dCounters.as<unsigned long long>() + 16);   // [16] two 32-bit class counters
+    // grids over the queued fragments: exact when their number is known, otherwise sized by what the previous pass saw (the kernels
+    // walk the list with whatever grid they get)
+    const int nB = steady ? (int)std::min<size_t>(c->prevBig + c->prevBig / 2 + 1024, (size_t)nF) : nBig;
+    const unsigned gWave = (unsigned)((nB + 3) / 4), gThread = (unsigned)((nB + 255) / 256);
     {
       KernelTimer t(c, MM_K_SORT);
       uint16_t* sortIds = windowed ? c->dPtIds.as<uint16_t>() : (uint16_t*)nullptr;
       {
         auto gk = I.tagged ? k_gather_points<true> : k_gather_points<false>;
-        hipLaunchKernelGGL(gk, dim3((nBig + 3) / 4), dim3(256), 0, c->stream, nBig, c->dBigList.as<int32_t>(), s, c->dFrags.as<DFrag>(), c->dSkHash.as<uint64_t>(),
+        hipLaunchKernelGGL(gk, dim3(gWave), dim3(256), 0, c->stream, nBig, c->dBigList.as<int32_t>(), s, c->dFrags.as<DFrag>(), c->dSkHash.as<uint64_t>(),
                            c->dSkCount.as<uint32_t>(), seedTab, pre, c->dPreVal.as<uint64_t>(), (int)c->preStride, I.ptKeys.as<uint64_t>(), I.refGroup.as<int32_t>(),
                            c->dReadGroup.as<int32_t>(), c->dReadSelf.as<int32_t>(), c->seqCounterBase, fl, c->dStats.as<mm_frag_stats>(), c->dPtOff.as<int64_t>(),
-                           c->dPts.as<uint64_t>(), sortIds);
+                           c->dPts.as<uint64_t>(), sortIds, nBigDev);
         MM_HIP(c, hipGetLastError());
       }
-      if (!windowed) hipLaunchKernelGGL(k_sort_points_wave, dim3((nBig + 3) / 4), dim3(256), 0, c->stream, nBig, c->dBigList.as<int32_t>(), c->dPtOff.as<int64_t>(), c->dPts.as<uint64_t>());
-      hipLaunchKernelGGL(k_classify_sort, dim3((nBig + 255) / 256), dim3(256), 0, c->stream, nBig, c->dBigList.as<int32_t>(), c->dPtOff.as<int64_t>(),
+      if (!windowed) hipLaunchKernelGGL(k_sort_points_wave, dim3(gWave), dim3(256), 0, c->stream, nBig, nBigDev, c->dBigList.as<int32_t>(), c->dPtOff.as<int64_t>(), c->dPts.as<uint64_t>());
+      hipLaunchKernelGGL(k_classify_sort, dim3(gThread), dim3(256), 0, c->stream, nBig, nBigDev, c->dBigList.as<int32_t>(), c->dPtOff.as<int64_t>(),
                          listB.as<int32_t>(), listC.as<int32_t>(), cls, windowed ? 1 : 64);
       MM_HIP(c, hipGetLastError());
-      unsigned int hcls[2];
-      MM_HIP(c, hipMemcpyAsync(hcls, cls, 8, hipMemcpyDeviceToHost, c->stream));
-      MM_HIP(c, hipStreamSynchronize(c->stream));
-      if (hcls[0]) hipLaunchKernelGGL(k_sort_points_block, dim3(hcls[0]), dim3(256), 0, c->stream, c->dPtOff.as<int64_t>(), c->dPts.as<uint64_t>(), listB.as<int32_t>(), sortIds);
-      if (hcls[1]) hipLaunchKernelGGL(k_sort_points_global, dim3(hcls[1]), dim3(1024), 0, c->stream, c->dPtOff.as<int64_t>(), c->dPts.as<uint64_t>(), listC.as<int32_t>(), sortIds);
+      unsigned int hcls[2] = {1024u, 16u};                    // steady: fixed grids over the two lists (their lengths stay on the device)
+      if (!steady) {
+        MM_HIP(c, hipMemcpyAsync(hcls, cls, 8, hipMemcpyDeviceToHost, c->stream));
+        MM_SYNC(c);
+      }
+      if (hcls[0]) hipLaunchKernelGGL(k_sort_points_block, dim3(hcls[0]), dim3(256), 0, c->stream, cls, c->dPtOff.as<int64_t>(), c->dPts.as<uint64_t>(), listB.as<int32_t>(), sortIds);
+      if (hcls[1]) hipLaunchKernelGGL(k_sort_points_global, dim3(hcls[1]), dim3(1024), 0, c->stream, cls + 1, c->dPtOff.as<int64_t>(), c->dPts.as<uint64_t>(), listC.as<int32_t>(), sortIds);
       MM_HIP(c, hipGetLastError());
     }
     for (int attempt = 0; attempt < 8; attempt++) {
       // candidates of the fused path sit at [0, fusedL1); the sweep appends behind them, so a retry only rewinds to fusedL1
       const unsigned long long fusedL1 = hc[2];
-      MM_HIP(c, hipMemcpyAsync(cnt + 2, &fusedL1, 8, hipMemcpyHostToDevice, c->stream));
-      MM_HIP(c, hipMemsetAsync(cnt + 3, 0, 8, c->stream));
+      if (!steady) {
+        MM_HIP(c, hipMemcpyAsync(cnt + 2, &fusedL1, 8, hipMemcpyHostToDevice, c->stream));
+        MM_HIP(c, hipMemsetAsync(cnt + 3, 0, 8, c->stream));
+      }
       {
         KernelTimer t(c, MM_K_L1);
         // a wave per fragment streams the sorted points; what it cannot take (a position group across two contigs, minimumHits 0) and
@@ -1240,7 +1291,7 @@ int mm_launch_map(mm_ctx* c) {
         const bool stream = !fl.skipPrefix && !getenv("MM_L1_LITERAL") && !windowed;
         const int32_t* sweepList = c->dBigList.as<int32_t>(); const unsigned int* sweepCount = nullptr;
         if (windowed) {
-          const int nFreq = s > 256 ? s : 256;                                     // seeds are numbered round * 64 + lane
+          const int nFreq = s > 256 ? s : 256;                                     // seeds are numbered by their index in the raw sketch
           MM_HIP(c, c->dWinFreq.ensure((size_t)nBig * nFreq * 4 + 64));
           hipLaunchKernelGGL(k_l1_window, dim3((nBig + 63) / 64), dim3(64), 0, c->stream, nBig, c->dBigList.as<int32_t>(), c->dFrags.as<DFrag>(), c->dPtOff.as<int64_t>(),
                              c->dPts.as<uint64_t>(), c->dPtIds.as<uint16_t>(), c->dStats.as<mm_frag_stats>(), c->dMinHits.as<int32_t>(), c->dCutoffs.as<int32_t>(),
@@ -1248,31 +1299,33 @@ int mm_launch_map(mm_ctx* c) {
                              (unsigned long long)denseCap, c->dL1Off.as<int64_t>(), cnt);
           MM_HIP(c, hipGetLastError());
         } else {
+        unsigned int* lit = cls + 2;                                               // [17]: the list k_l1_stream leaves over (cls itself still feeds the sorters in flight)
         if (stream) {
-          MM_HIP(c, hipMemsetAsync(cls, 0, 8, c->stream));
-          hipLaunchKernelGGL(k_l1_stream, dim3((nBig + 3) / 4), dim3(256), 0, c->stream, nBig, c->dBigList.as<int32_t>(), c->dPtOff.as<int64_t>(),
+          MM_HIP(c, hipMemsetAsync(lit, 0, 8, c->stream));
+          hipLaunchKernelGGL(k_l1_stream, dim3(gWave), dim3(256), 0, c->stream, nBig, c->dBigList.as<int32_t>(), c->dPtOff.as<int64_t>(),
                              c->dPts.as<uint64_t>(), c->dStats.as<mm_frag_stats>(), c->dMinHits.as<int32_t>(), c->dCutoffs.as<int32_t>(),
                              (int)c->nCutoffs, s, c->P.segLength, fl.hg, c->dL1.as<mm_l1_candidate>(), (unsigned long long)denseCap,
-                             c->dL1Off.as<int64_t>(), listB.as<int32_t>(), cls, cnt);
+                             c->dL1Off.as<int64_t>(), listB.as<int32_t>(), lit, cnt, nBigDev);
           MM_HIP(c, hipGetLastError());
-          sweepList = listB.as<int32_t>(); sweepCount = cls;
+          sweepList = listB.as<int32_t>(); sweepCount = lit;
         }
-        hipLaunchKernelGGL(k_l1_sweep, dim3((nBig + 255) / 256), dim3(256), 0, c->stream, nBig, sweepList, c->dPtOff.as<int64_t>(),
+        hipLaunchKernelGGL(k_l1_sweep, dim3(stream && steady ? 64u : gThread), dim3(256), 0, c->stream, nBig, sweepList, c->dPtOff.as<int64_t>(),
                            c->dPts.as<uint64_t>(), c->dStats.as<mm_frag_stats>(), c->dMinHits.as<int32_t>(), c->dCutoffs.as<int32_t>(),
                            (int)c->nCutoffs, s, c->P.segLength, fl, I.refGroup.as<int32_t>(), c->dL1.as<mm_l1_candidate>(),
-                           (unsigned long long)denseCap, c->dL1Off.as<int64_t>(), cnt, sweepCount);
+                           (unsigned long long)denseCap, c->dL1Off.as<int64_t>(), cnt, sweepCount, sweepCount ? (const unsigned long long*)nullptr : nBigDev);
         MM_HIP(c, hipGetLastError());
         }
       }
+      if (steady) break;
       unsigned long long h2[2];
       MM_HIP(c, hipMemcpyAsync(h2, cnt + 2, 16, hipMemcpyDeviceToHost, c->stream));
-      MM_HIP(c, hipStreamSynchronize(c->stream));
+      MM_SYNC(c);
       if (h2[1]) {
         // grow, keeping the fused candidates already in the buffer
         const size_t newCap = (size_t)h2[0] + (size_t)h2[0] / 8 + 1024;
         DevBuf nb; MM_HIP(c, nb.ensure(newCap * sizeof(mm_l1_candidate) + 64));
         if (fusedL1) MM_HIP(c, hipMemcpyAsync(nb.p, c->dL1.p, (size_t)fusedL1 * sizeof(mm_l1_candidate), hipMemcpyDeviceToDevice, c->stream));
-        MM_HIP(c, hipStreamSynchronize(c->stream));
+        MM_SYNC(c);
         c->dL1.release(); c->dL1 = nb; denseCap = newCap;
         if (c->l1Cap < newCap) c->l1Cap = newCap;                  // the next pass sizes both candidate buffers for it: no retry, no reallocation
         hc[3] = 1; continue;
@@ -1282,12 +1335,48 @@ int mm_launch_map(mm_ctx* c) {
     }
     if (hc[3]) { c->err = "L1 candidate buffer overflow"; return MM_ERR_CAPACITY; }
   }
-  c->nL1 = (size_t)hc[2];
-  if (c->nL1 == 0) { c->nL2 = 0; return rc; }
-
-  rc = mm_launch_l2(c, cnt);
+  if (!steady) {
+    c->nL1 = (size_t)hc[2];
+    c->prevBig = c->lastBig = (size_t)nBig;
+    if (c->nL1 == 0) { c->nL2 = 0; return rc; }
+  }
+  rc = mm_launch_l2(c, cnt, steady);
   if (rc != MM_OK) return rc;
-  return mm_launch_select(c);
+  rc = mm_launch_select(c, steady);
+  if (rc != MM_OK) return rc;
+  if (steady) {
+    // the pass is over: one block of counters comes back
+    unsigned long long* h = c->hPass;
+    MM_HIP(c, hipMemcpyAsync(h, cnt, 64, hipMemcpyDeviceToHost, c->stream));
+    MM_HIP(c, hipMemcpyAsync(h + 8, cnt2, 64, hipMemcpyDeviceToHost, c->stream));
+    MM_SYNC(c);
+    if (h[1] || h[3] || h[5] || (h[6] & ~0ull) || h[9]) return MM_PASS_REDO;   // some buffer was too small for this batch: the sized pass grows it
+    c->nL1 = (size_t)h[2]; c->nL2 = (size_t)h[4]; c->nMappings = c->haveReplayTables ? (size_t)h[8] : 0;
+    c->lastOps = (size_t)h[10]; c->lastBig = c->prevBig;          // (the queue's length was overwritten by the L2 stage's list counter: the sized pass's stands in)
+  }
+  return MM_OK;
+}
+
+int mm_launch_map(mm_ctx* c) {
+  const int nF = (int)c->nFrags, s = c->P.sketchSize;
+  MM_HIP(c, c->dQHash.ensure((size_t)nF * s * 8 + 64)); MM_HIP(c, c->dQStrand.ensure((size_t)nF * s + 64));
+  MM_HIP(c, c->dStats.ensure((size_t)nF * sizeof(mm_frag_stats) + 64));
+  MM_HIP(c, c->dPtOff.ensure((size_t)nF * 16 + 64)); MM_HIP(c, c->dL1Off.ensure((size_t)nF * 8 + 64));
+  MM_HIP(c, c->dCounters.ensure(512));
+  if (!c->hPass) { MM_HIP(c, hipHostMalloc((void**)&c->hPass, 256, hipHostMallocDefault)); }
+  c->nL1 = c->nL2 = 0; c->nMappings = 0; c->nSyncs = 0; c->lastSteady = false;
+  if (nF == 0) return MM_OK;
+  const bool allSlow = c->keepPoints || (c->P.flags & MM_FLAG_SKIP_PREFIX) || c->windowed;
+  static const bool noSteady = getenv("MM_NO_STEADY") != nullptr;
+  if (c->steadyOk && !allSlow && !noSteady && !getenv("MM_DEBUG")) {
+    const int rc = map_pass(c, true);
+    if (rc == MM_OK) { c->lastSteady = true; return MM_OK; }
+    if (rc != MM_PASS_REDO) return rc;
+    c->steadyOk = false;
+  }
+  const int rc = map_pass(c, false);
+  c->steadyOk = rc == MM_OK && !allSlow && c->nL1 > 0;
+  return rc;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -12,6 +12,7 @@
 // Two passes: count, exclusive scan, write -- so the records come out fragment-major without a sort.
 #include "mm_internal.h"
 #include "mm_select_core.h"
+#include <algorithm>
 
 struct SelectArgs {
   int nFrags, stride, hg, skipPrefix, seqCounterBase;
@@ -24,8 +25,14 @@ struct SelectArgs {
 
 template <bool WRITE>
 __global__ void __launch_bounds__(256)
-k_l2_select(SelectArgs A, int32_t* __restrict__ counts, const int64_t* __restrict__ outOff, mm_mapping* __restrict__ out) {
+k_l2_select(SelectArgs A, int32_t* __restrict__ counts, const int64_t* __restrict__ outOff, mm_mapping* __restrict__ out,
+            const int64_t* __restrict__ totalDev, long long outCap, unsigned long long* __restrict__ result /* steady-state passes: [0] = total, [1] = 1 if it exceeds outCap */) {
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (WRITE && totalDev) {
+    const long long total = (long long)*totalDev;
+    if (f == 0) { result[0] = (unsigned long long)total; if (total > outCap) result[1] = 1ull; }
+    if (total > outCap) return;                              // the records do not fit the buffer as it is: the pass is redone with the host's sizing
+  }
   if (f >= A.nFrags) return;
   const mm_frag_stats st = A.stats[f];
   const int Qs = st.sketchSize, nC = st.nL1;
@@ -53,12 +60,12 @@ k_l2_select(SelectArgs A, int32_t* __restrict__ counts, const int64_t* __restric
 
 int mm_scan_i32_to_i64(mm_ctx* c, int64_t n, const int32_t* dIn, int64_t* dOut, int64_t* total);   // mm_l2.hip
 
-int mm_launch_select(mm_ctx* c) {
+int mm_launch_select(mm_ctx* c, bool steady) {
   c->nMappings = 0;
   const int nF = (int)c->nFrags;
-  if (!c->haveReplayTables || nF == 0 || c->nL1 == 0) return MM_OK;
+  if (!c->haveReplayTables || nF == 0 || (!steady && c->nL1 == 0)) return MM_OK;
   MM_HIP(c, c->dSelCnt.ensure((size_t)nF * 4 + 64)); MM_HIP(c, c->dSelOff.ensure((size_t)nF * 8 + 64));
-  MM_HIP(c, c->dSelHeap.ensure(c->nL1 * 4 + 64));
+  MM_HIP(c, c->dSelHeap.ensure((steady ? c->candCap : std::max(c->nL1, c->candCap)) * 4 + 64));
   MM_HIP(c, c->dFragTab.ensure((size_t)nF * sizeof(mm_fragment) + 64));
   if (c->fragTabStale) {
     MM_HIP(c, hipMemcpyAsync(c->dFragTab.p, c->hFrags.data(), (size_t)nF * sizeof(mm_fragment), hipMemcpyHostToDevice, c->stream));
@@ -73,14 +80,29 @@ int mm_launch_select(mm_ctx* c) {
   A.refGroup = c->idx.refGroup.as<int32_t>(); A.accept = c->dAccept.as<uint8_t>(); A.minIsz = c->dMinIsz.as<int16_t>();
   A.heap = c->dSelHeap.as<int32_t>();
   KernelTimer t(c, MM_K_SELECT);
-  hipLaunchKernelGGL((k_l2_select<false>), dim3((nF + 255) / 256), dim3(256), 0, c->stream, A, c->dSelCnt.as<int32_t>(), (const int64_t*)nullptr, (mm_mapping*)nullptr);
+  hipLaunchKernelGGL((k_l2_select<false>), dim3((nF + 255) / 256), dim3(256), 0, c->stream, A, c->dSelCnt.as<int32_t>(), (const int64_t*)nullptr, (mm_mapping*)nullptr,
+                     (const int64_t*)nullptr, 0ll, (unsigned long long*)nullptr);
   MM_HIP(c, hipGetLastError());
+  if (steady) {
+    // the records' number stays on the device: the writing pass checks it against the buffer as the previous pass left it and
+    // reports both in the counters the launcher reads when the pass is over (dCounters[32], [33])
+    const int64_t* dTotal = nullptr;
+    const int rc = mm_scan_i32_to_i64_dev(c, nF, c->dSelCnt.as<int32_t>(), c->dSelOff.as<int64_t>(), &dTotal);
+    if (rc != MM_OK) return rc;
+    const long long cap = (long long)(c->dMappings.bytes / sizeof(mm_mapping)) - 2;
+    hipLaunchKernelGGL((k_l2_select<true>), dim3((nF + 255) / 256), dim3(256), 0, c->stream, A, (int32_t*)nullptr, c->dSelOff.as<int64_t>(), c->dMappings.as<mm_mapping>(),
+                       dTotal, cap, c->dCounters.as<unsigned long long>() + 32);
+    MM_HIP(c, hipGetLastError());
+    return MM_OK;
+  }
   int64_t total = 0;
   const int rc = mm_scan_i32_to_i64(c, nF, c->dSelCnt.as<int32_t>(), c->dSelOff.as<int64_t>(), &total);
+  c->nSyncs++;
   if (rc != MM_OK) return rc;
-  MM_HIP(c, c->dMappings.ensure((size_t)total * sizeof(mm_mapping) + 64));
+  MM_HIP(c, c->dMappings.ensure((size_t)(total + total / 16) * sizeof(mm_mapping) + 4096));   // head room for the steady-state passes behind this one
   if (total) {
-    hipLaunchKernelGGL((k_l2_select<true>), dim3((nF + 255) / 256), dim3(256), 0, c->stream, A, (int32_t*)nullptr, c->dSelOff.as<int64_t>(), c->dMappings.as<mm_mapping>());
+    hipLaunchKernelGGL((k_l2_select<true>), dim3((nF + 255) / 256), dim3(256), 0, c->stream, A, (int32_t*)nullptr, c->dSelOff.as<int64_t>(), c->dMappings.as<mm_mapping>(),
+                       (const int64_t*)nullptr, 0ll, (unsigned long long*)nullptr);
     MM_HIP(c, hipGetLastError());
   }
   c->nMappings = (size_t)total;

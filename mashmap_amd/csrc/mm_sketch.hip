@@ -816,7 +816,9 @@ static int launch_sketch_k(mm_ctx* c, bool withProbe) {
       if (nF < nChunks * 4096) nChunks = nF / 4096 > 0 ? nF / 4096 : 1;
       if (!c->probeStream) {
         int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi);          // hi = the numerically smallest = most urgent
-        MM_HIP(c, hipStreamCreateWithPriority(&c->probeStream, hipStreamNonBlocking, hi));
+        const char* pe = getenv("MM_PROBE_PRIO");                                     // experiment: 1 = most urgent, -1 = least, 0 / unset = default
+        const int prio = pe && atoi(pe) > 0 ? hi : pe && atoi(pe) < 0 ? lo : 0;
+        MM_HIP(c, hipStreamCreateWithPriority(&c->probeStream, hipStreamNonBlocking, prio));
         MM_HIP(c, hipEventCreateWithFlags(&c->probeDone, hipEventDisableTiming));
       }
       while ((int)c->probeEv.size() < nChunks) { hipEvent_t e; MM_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->probeEv.push_back(e); }

@@ -40,3 +40,10 @@ def ref():
     if not mmutil.Ref.available():
         pytest.skip("oracle/_ref not built (needs /root/reference)")
     return mmutil.Ref()
+
+
+@pytest.fixture(scope="session")
+def human(tmp_path_factory):
+    """the human-scale inputs + the stock binary's background runs (tests/humanscale.py)"""
+    import humanscale
+    yield from humanscale.start(tmp_path_factory)

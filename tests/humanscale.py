@@ -1,4 +1,6 @@
-"""Parity at human scale, where other code runs than in the small cases: a 3 Gbp reference indexed on the device (the tagged seed
+"""tests/humanscale.py -- shared by tests/test_gpu_00_humanscale_start.py and tests/test_gpu_zz_humanscale.py.
+
+Parity at human scale, where other code runs than in the small cases: a 3 Gbp reference indexed on the device (the tagged seed
 table above 1 GiB -> k_lookup_l1<.., true>, ~14 GB of open-record lists, candidates located in reference order), mapped through the
 `mashmap_hip` command line and compared BYTE FOR BYTE with the PAF of the stock binary (oracle/_ref/mashmap_ref: the reference's own
 sources, compiled by oracle/Makefile; it travels to the GPU box like the library does) on the same FASTA files:
@@ -10,8 +12,9 @@ sources, compiled by oracle/Makefile; it travels to the GPU box like the library
 
 What is matched: Map::mapQuery end to end (computeMap.hpp:263-413) with the parameters parseCmdArgs.hpp:620-641 derives.
 The reference sequence is generated once and shared by the three cases; the stock binary indexes 3 Gbp in ~1.5 minutes per case on
-the GPU box's 16 CPUs -- the three runs are started together when the files are written and the GPU runs happen meanwhile, which
-is what keeps this module's run time at a few minutes.  MASHMAP_TEST_HUMAN_GBP scales the reference (default 3),
+the GPU box's 16 CPUs.  The three runs are started together, as background processes, by the FIRST test of the GPU suite
+(test_gpu_00_humanscale_start.py: it makes the files and returns) and are collected by the LAST (test_gpu_zz_humanscale.py), so they
+run beside the ~130 other GPU tests instead of in front of them; run alone, the comparison module starts them itself and waits.  MASHMAP_TEST_HUMAN_GBP scales the reference (default 3),
 MASHMAP_TEST_HUMAN_READS the read sets."""
 import os
 import re
@@ -25,7 +28,6 @@ import pytest
 
 import mmutil as U
 
-pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIP_BIN = os.path.join(ROOT, "mashmap_amd", "lib", "mashmap_hip")
 GBP = float(os.environ.get("MASHMAP_TEST_HUMAN_GBP", "3"))
@@ -41,8 +43,17 @@ def _threads():
     return str(max(4, min(32, 2 * B.usable_cpus())))
 
 
-@pytest.fixture(scope="module")
-def human(tmp_path_factory):
+# name -> command line ("@key": a path of the fixture)
+CASES = {
+    "northstar": ["-r", "@ref", "-q", "@ns"],
+    "configs2": ["-r", "@ref", "-q", "@asm", "--pi", "95", "-s", "10000", "-f", "one-to-one"],
+    "configs4": ["--rl", "@rl", "-q", "@c4", "--dense", "--pi", "80"],
+}
+
+
+
+def start(tmp_path_factory):
+    """generator behind the session-scoped `human` fixture (conftest.py)"""
     if not os.path.exists(U.REF_BIN):
         pytest.skip("oracle/_ref/mashmap_ref (the stock binary) is not here: it is built where /root/reference exists and shipped by gpurun")
     assert os.path.exists(HIP_BIN), "mashmap_hip not built (python -c 'import __graft_entry__ as g; g.build()')"
@@ -138,7 +149,7 @@ def _tagged(stderr):
     return int(m.group(3)) == 1, int(m.group(2))
 
 
-def _case(human, name, min_lines, expect_tagged, sharded=False):
+def case(human, name, min_lines, expect_tagged, sharded=False):
     td = human["td"]
     proc, ref_out, log, t_start, full = human["stock"][name]
     got, err, wall_h, tm_h = _run(HIP_BIN, full, os.path.join(td, name + ".hip.paf"))
@@ -162,25 +173,3 @@ def _case(human, name, min_lines, expect_tagged, sharded=False):
         assert got2 == exp, "MASHMAP_HIP_DEVICES=0,0: " + _diff(got2, exp)
 
 
-# name -> command line ("@key": a path of the fixture)
-CASES = {
-    "northstar": ["-r", "@ref", "-q", "@ns"],
-    "configs2": ["-r", "@ref", "-q", "@asm", "--pi", "95", "-s", "10000", "-f", "one-to-one"],
-    "configs4": ["--rl", "@rl", "-q", "@c4", "--dense", "--pi", "80"],
-}
-
-
-def test_north_star_target_defaults(human):
-    """10 kbp reads, pi 85, segLength 5000 (the stock binary derives sketchSize 310 for the 3 GB file); one context, then two"""
-    _case(human, "northstar", int(0.9 * N_READS_NS), True, sharded=True)
-
-
-def test_configs2_shape_one_to_one(human):
-    """assembly vs reference: --pi 95 -s 10000 -f one-to-one (a sketch of ~40 per 10 kbp: the seed table stays below the 1 GiB where the
-    tag layer starts)"""
-    _case(human, "configs2", N_ASM, False)
-
-
-def test_configs4_shape_dense_reference_list(human):
-    """--dense --pi 80, 20 kbp reads at 15-20 % error, --rl list of 10 reference files sharing one seqId space (winSketch.hpp:174-214)"""
-    _case(human, "configs4", int(0.8 * N_READS_C4), True)

@@ -423,3 +423,47 @@ def test_map_many_candidates_per_fragment(oracle, monkeypatch):
     a, b = once(False), once(True)
     assert a[0]["nL1"].max() > 64
     assert a[0].tobytes() == b[0].tobytes() and a[1].tobytes() == b[1].tobytes() and a[2].tobytes() == b[2].tobytes()
+
+
+def test_steady_state_passes_wait_for_the_device_once(oracle):
+    """The first pass of a context sizes every staging buffer from counts it reads back stage by stage; the passes behind it launch
+    everything against those capacities with the counts left on the device and wait ONCE (mm_pass_stats).  Same bytes either way
+    -- including fragments with more interval points than the fused path holds (a repeated reference: gather + sort + stream kernels
+    walk a list whose length stays on the device) -- and a batch that outgrows the buffers is redone the sized way."""
+    from mashmap_amd import capi
+    unit = U.random_dna(811, 20000)
+    rep = np.concatenate([U.mutate(unit, 900 + i, 0.01) for i in range(12)])
+    g = U.random_dna(812, 600000)
+    contigs = [rep, g]
+    small = [a for _, a, _ in U.sample_reads(contigs, 813, 80, 10000, 0.08)]
+    big = [a for _, a, _ in U.sample_reads(contigs, 814, 400, 10000, 0.08)]
+
+    def fresh(reads):
+        c = capi.Context(k=19, segLength=5000, sketchSize=130, flags=capi.MM_FLAG_HG_FILTER)
+        c.index_build(contigs, kmerPct=0.0); c.set_tables_default(0.85)
+        c.reads_upload(reads); c.map()
+        out = tuple(x.tobytes() for x in c.results()) + (c.mappings().tobytes(),)
+        c.close()
+        return out
+
+    want_small, want_big = fresh(small), fresh(big)
+    assert len(want_small[3]) > 48 * 100
+    ctx = capi.Context(k=19, segLength=5000, sketchSize=130, flags=capi.MM_FLAG_HG_FILTER)
+    ctx.index_build(contigs, kmerPct=0.0); ctx.set_tables_default(0.85)
+
+    def run(reads):
+        ctx.reads_upload(reads); ctx.map()
+        return tuple(x.tobytes() for x in ctx.results()) + (ctx.mappings().tobytes(),), ctx.pass_stats()
+
+    got, (syncs, steady) = run(small)
+    assert got == want_small and not steady and syncs >= 4            # the sizing pass
+    for _ in range(2):
+        got, (syncs, steady) = run(small)
+        assert got == want_small and steady and syncs == 1, (syncs, steady)
+    got, (syncs, steady) = run(big)                                    # five times the batch: the buffers are too small -> redone, sized
+    assert got == want_big and not steady and syncs >= 5
+    got, (syncs, steady) = run(big)
+    assert got == want_big and steady and syncs == 1
+    got, (syncs, steady) = run(small)                                  # a smaller batch fits what is there
+    assert got == want_small and steady and syncs == 1
+    ctx.close()

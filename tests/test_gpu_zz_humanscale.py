@@ -1,0 +1,23 @@
+"""Last module of the GPU suite: the human-scale PAF comparisons (tests/humanscale.py has the what and why).  The stock binary's three
+runs were started by tests/test_gpu_00_humanscale_start.py and have had the rest of the suite's run time to finish."""
+import pytest
+
+from humanscale import N_ASM, N_READS_C4, N_READS_NS, case as _case
+
+pytestmark = pytest.mark.gpu
+
+
+def test_north_star_target_defaults(human):
+    """10 kbp reads, pi 85, segLength 5000 (the stock binary derives sketchSize 310 for the 3 GB file); one context, then two"""
+    _case(human, "northstar", int(0.9 * N_READS_NS), True, sharded=True)
+
+
+def test_configs2_shape_one_to_one(human):
+    """assembly vs reference: --pi 95 -s 10000 -f one-to-one (a sketch of ~40 per 10 kbp: the seed table stays below the 1 GiB where the
+    tag layer starts)"""
+    _case(human, "configs2", N_ASM, False)
+
+
+def test_configs4_shape_dense_reference_list(human):
+    """--dense --pi 80, 20 kbp reads at 15-20 % error, --rl list of 10 reference files sharing one seqId space (winSketch.hpp:174-214)"""
+    _case(human, "configs4", int(0.8 * N_READS_C4), True)
