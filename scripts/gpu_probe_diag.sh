@@ -2,8 +2,10 @@
 # MM_SKETCH_PROBE diagnostics: do k_sketch_fast (stream A) and k_seed_probe (stream B) overlap?  kernel trace with timestamps + bench variants
 TAG=${1:-pd}; OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
 B="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-path --no-north-star"
-for V in "MM_SKETCH_PROBE=0" "MM_SKETCH_PROBE=1" "MM_SKETCH_PROBE=1 MM_PROBE_PRIO=1" "MM_SKETCH_PROBE=1 MM_PROBE_PRIO=-1" "MM_SKETCH_PROBE=1 MM_PROBE_WPB=1" "MM_SKETCH_PROBE=1 MM_PROBE_CHUNKS=32"; do
-  env $V timeout 600 $B > $OUT/b.json 2> $OUT/b.err
+NS="--workload northstar"
+for V in "MM_SKETCH_PROBE=0" "MM_SKETCH_PROBE=0 MM_NO_STEADY=1" "MM_SKETCH_PROBE=1" "MM_SKETCH_PROBE=1 MM_PROBE_PRIO=1" "MM_SKETCH_PROBE=1 MM_PROBE_CHUNKS=16" "MM_SKETCH_PROBE=1 MM_PROBE_CHUNKS=4" "NS MM_SKETCH_PROBE=0" "NS MM_SKETCH_PROBE=0 MM_NO_STEADY=1" "NS MM_SKETCH_PROBE=1" "NS MM_SKETCH_PROBE=1 MM_PROBE_CHUNKS=16"; do
+  X=""; E="$V"; case "$V" in NS*) X="$NS"; E="${V#NS }";; esac
+  env $E timeout 600 $B $X > $OUT/b.json 2> $OUT/b.err
   python - "$V" $OUT/b.json <<'PY' | tee -a $OUT/log.txt
 import json, sys
 d = json.load(open(sys.argv[2]))
