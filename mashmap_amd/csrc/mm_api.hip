@@ -16,7 +16,7 @@ std::vector<DevBuf*> mm_ctx::allBufs() {
   DeviceIndex& I = idx;
   return {&I.evKey, &I.evAux, &I.evHash, &I.contigOff, &I.opKey, &I.opAux, &I.opHash, &I.blockOff, &I.evBlock, &I.contigBlock, &I.contigLen, &I.refGroup,
           &I.htSlots, &I.htTags, &I.filter, &I.ptKeys, &I.keys, &I.keyOff, &I.keyFreq, &dMinHits, &dCutoffs, &dAscii, &dAsciiNext, &dReadSrcOff, &dReadPackOff, &dReadLen, &dReadGroup, &dReadSelf, &dReadHasN,
-          &dBases2, &dNmask, &dFrags, &dSkHash, &dSkPos, &dSkStrand, &dSkCount, &dHardList, &dCounters, &dSketchSpill, &dSketchTabs, &dQHash, &dQStrand, &dPre, &dPreVal,
+          &dBases2, &dNmask, &dFrags, &dSkHash, &dSkPos, &dSkStrand, &dSkCount, &dHardList, &dCounters, &dSketchSpill, &dSketchTabs, &dQHash, &dQStrand,
           &dStats, &dPtOff, &dPts, &dPtIds, &dWinFreq, &dWinExt, &dWinHeap, &dWinKeys, &dWinVals, &dWinOffH, &dWinOffT, &dWinCntH, &dWinCntT, &dL1, &dL1b, &dL1Cursors, &dL1Off, &dL1Regions, &dL2, &dL2Info, &dL2Cnt, &dL2Off, &dL2Ops, &dScanTmp, &dL2Tmp, &dL2Wide, &dL2Exact, &dL2Cells,
           &dListB, &dListC, &dBigList, &dL2Sort[0], &dL2Sort[1], &dL2Sort[2], &dL2Sort[3], &dL2Order, &dL2OrderPos, &dL2First, &dL2Num, &dAccept, &dMinIsz, &dSelCnt, &dSelOff, &dSelHeap, &dFragTab, &dMappings, &dCommCounts, &dGathered};
 }
@@ -68,9 +68,6 @@ void mm_destroy(mm_ctx* c) {
   if (c->commStream) (void)hipStreamDestroy(c->commStream);
   if (c->copyStream) { (void)hipStreamSynchronize(c->copyStream); (void)hipStreamDestroy(c->copyStream); }
   if (c->copyDone) (void)hipEventDestroy(c->copyDone);
-  if (c->probeStream) { (void)hipStreamSynchronize(c->probeStream); (void)hipStreamDestroy(c->probeStream); }
-  for (hipEvent_t e : c->probeEv) (void)hipEventDestroy(e);
-  if (c->probeDone) (void)hipEventDestroy(c->probeDone);
   for (DevBuf* b : c->allBufs()) b->release();
   if (c->hPass) (void)hipHostFree(c->hPass);
   for (auto& pr : c->evPool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -408,7 +405,7 @@ int mm_map_fragments(mm_ctx* c) {
   if (!c->idx.ready) { c->err = "mm_map_fragments: no index resident (mm_index_upload / mm_index_build first)"; return MM_ERR_STATE; }
   if (!c->nMinHits) { c->err = "mm_map_fragments: mm_set_tables first"; return MM_ERR_STATE; }
   MM_HIP(c, hipSetDevice(c->device));
-  int rc = mm_launch_sketch(c, true);
+  int rc = mm_launch_sketch(c);
   if (rc != MM_OK) return rc;
   c->sketched = true;
   rc = mm_launch_map(c);

@@ -172,12 +172,8 @@ __device__ __forceinline__ void mm_tag_scan(uint4 t, uint32_t tag, uint32_t& can
   cand16 = c; hasEmpty = e != 0;
 }
 
-// the seed table as a kernel argument (k_lookup_l1, k_gather_points, k_seed_probe: mm_map.hip)
+// the seed table as a kernel argument (k_lookup_l1, k_gather_points: mm_map.hip)
 struct SeedTable { const HtSlot* ht; uint64_t mask; const uint64_t* filter; uint64_t filterMask; const uint8_t* tags; };
-// MM_SKETCH_PROBE -- what k_seed_probe leaves for k_lookup_l1: per fragment `stride` 64-bit words in pre -- word 0: 2 = sketch emitted by
-// the fast sketch kernel, 1 = looked up; words 1.. : bit r of the concatenation = sketch entry r is in the table -- and in val, at
-// f * s, the table values of the entries that are, in sketch order
-struct SeedPre { uint64_t* pre; uint64_t* val; int stride; int mode; };
 
 // ---------------------------------------------------------------------------------------------
 // Strip hasher.  For K = 17..19 (one 16-byte block + a tail of K-16 <= 3 bytes; K = 19 is MashMap's default) the tail has

@@ -102,9 +102,6 @@ struct mm_ctx {
   DevBuf dHardList, dCounters, dSketchSpill;            // dSketchSpill: first / last / strand-sum arrays of k_sketch_hard<K, true> (large sketches)
   DevBuf dSketchTabs; int sketchTabsK = 0;        // strip-hasher tables for kmerSize sketchTabsK (built once, copied into LDS by every workgroup)
   DevBuf dQHash, dQStrand;                              // post-removal sketch (written only for fragments that lose a frequent seed)
-  // MM_SKETCH_PROBE: the sketch kernel looks a fragment's sketch up in the seed table where it emits it (mm_device.h: SeedPre)
-  DevBuf dPre, dPreVal; size_t preStride = 0; bool preProbed = false;
-  hipStream_t probeStream = nullptr; std::vector<hipEvent_t> probeEv; hipEvent_t probeDone = nullptr;   // mode 2: k_seed_probe runs chunk by chunk beside the sketch kernel
   DevBuf dStats;                                        // mm_frag_stats[nFrags]
   DevBuf dPtOff, dPts; size_t ptsCap = 0;               // per-fragment offset (int64) + sorted keys
   // --noSplit with reads longer than segLength (windowLen != 0, computeMap.hpp:933): the literal kernels' state
@@ -188,14 +185,12 @@ int mm_check_params(const mm_params* p, std::string& err);
 int mm_launch_pack(mm_ctx* c);
 int mm_launch_pack_raw(mm_ctx* c, const uint8_t* dAscii, const int64_t* dSrcOff, const int64_t* dPackOff, const int32_t* dLen, int nReads,
                        int64_t nChunks, uint32_t* dB, uint32_t* dM, uint32_t* dHasN);
-int mm_launch_sketch(mm_ctx* c, bool withProbe = false);   // withProbe: look the sketches up in the resident seed table as well (MM_SKETCH_PROBE)
+int mm_launch_sketch(mm_ctx* c);
 int mm_launch_map(mm_ctx* c);
 // Steady state: once a pass of a context has sized every staging buffer, the next passes launch everything against
 // those capacities with the counts left on the device and read ONE block of counters back at the end (one host synchronisation per
 // pass); a pass that outgrows a buffer is detected there and redone the sized way (MM_PASS_REDO from the launchers).
 #define MM_PASS_REDO 1
-// k_seed_probe (mm_map.hip) for the fragments [f0, f1) the sketch kernel has marked, or (list != null) for the listed ones, on `stream`
-int mm_launch_seed_probe(mm_ctx* c, hipStream_t stream, int f0, int f1, const int32_t* dList, const uint32_t* dListCount);
 int mm_launch_select(mm_ctx* c, bool steady = false);
 void mm_comm_release(mm_ctx* c);
 int mm_launch_l2(mm_ctx* c, unsigned long long* cnt, bool steady = false);   // cnt: device counters [2] candidates [4] cursor [5] overflow [6] flags

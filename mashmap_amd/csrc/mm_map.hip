@@ -294,7 +294,7 @@ __device__ __forceinline__ int mm_l1_fused(uint64_t (&k)[R], FuseScratch& sc, in
 // ---------------------------------------------------------------------------------------------
 // The table values of the sketch entries [base, base + 256) of a fragment, four per lane (entry base + u * 64 + lane): found[u] / val[u].
 // Four sub-rounds are in flight together: their hash loads, filter tests / tag loads and first table slots are independent, so one
-// memory round trip serves all of them instead of four.  Shared by k_lookup_l1, k_gather_points and k_seed_probe.
+// memory round trip serves all of them instead of four.  Shared by k_lookup_l1 and k_gather_points.
 template <bool TAGS>
 __device__ __forceinline__ void mm_probe4(const SeedTable& T, const uint64_t* __restrict__ skHash, size_t fo, int cnt, int base, int lane,
                                           uint64_t (&h)[4], bool (&act)[4], bool (&found)[4], uint64_t (&val)[4]) {
@@ -358,33 +358,16 @@ __device__ __forceinline__ void mm_probe4(const SeedTable& T, const uint64_t* __
     }
   }
 }
-// the same from what k_seed_probe / the sketch kernel left (mm_device.h: SeedPre): found masks + the values of the found entries in
-// sketch order.  preRun: found entries before `base` (the caller resets it before every pass over the batches)
-__device__ __forceinline__ void mm_probe4_pre(const uint64_t* __restrict__ preRow, const uint64_t* __restrict__ preValRow, int cnt, int base, int lane, int& preRun,
-                                              uint64_t (&h)[4], bool (&act)[4], bool (&found)[4], uint64_t (&val)[4]) {
-#pragma unroll
-  for (int u = 0; u < 4; u++) {
-    const int r = base + u * 64 + lane;
-    act[u] = r < cnt; h[u] = 0ull;
-    const int w = (base >> 6) + u;
-    const uint64_t word = (w * 64 < cnt) ? preRow[1 + w] : 0ull;
-    found[u] = act[u] && ((word >> lane) & 1ull);
-    val[u] = found[u] ? preValRow[preRun + (int)mm_popc_below(word)] : 0ull;
-    preRun += (int)__popcll(word);
-  }
-}
-
 #define MM_LOOKUP_WPB 4             // waves (= fragments) per workgroup
 #define MM_L1_REGIONS 64            // L1 output cursors: a same-address atomic costs ~10 ns, so fragments spread over 64 of them
 #define MM_L1_CURSOR_STRIDE 32      // u64 words between cursors (256 bytes)
-// MODE 0: probes the plain seed table (+ presence filter), 1: the tagged table, 2: reads what k_seed_probe left for EVERY fragment
-template <int MAXPTS, int MODE>
+template <int MAXPTS, bool TAGS>
 __global__ void __launch_bounds__(MM_LOOKUP_WPB * 64, MAXPTS <= 128 ? 8 : MAXPTS <= 256 ? 6 : 5)
 k_lookup_l1(int nFrags, int s, const DFrag* __restrict__ frags,
             const uint64_t* __restrict__ skHash, const int8_t* __restrict__ skStrand, const uint32_t* __restrict__ skCount,
             const SeedTable T, const uint64_t* __restrict__ ptKeys,
             const int32_t* __restrict__ readSelf, int seqCounterBase, MapFlags fl, int keepPoints,
-            uint64_t* __restrict__ qHash, int8_t* __restrict__ qStrand, const uint64_t* __restrict__ pre, const uint64_t* __restrict__ preVal, int preStride,
+            uint64_t* __restrict__ qHash, int8_t* __restrict__ qStrand,
             mm_frag_stats* __restrict__ stats, int64_t* __restrict__ ptOff, unsigned long long ptsCap,
             const int32_t* __restrict__ minHitsTab, const int32_t* __restrict__ cutoffs, int nCutoffs, int segLength,
             mm_l1_candidate* __restrict__ l1, unsigned long long regionCap, unsigned long long* __restrict__ l1Cursors,
@@ -418,14 +401,10 @@ k_lookup_l1(int nFrags, int s, const DFrag* __restrict__ frags,
     if (drop) key = MM_EMPTY; else nValid++;
     sc.a[at] = key;
   };
-  // MODE 2: the seed look-ups were made ahead (k_seed_probe, MM_SKETCH_PROBE): found masks + values instead of probes
-  constexpr bool usePre = MODE == 2;
-  int preRun = 0;
   bool anyDrop = false;                                            // a frequent seed has been removed so far (wave-uniform)
   for (int base = 0; base < cnt; base += 256) {
     uint64_t h[4], val[4]; bool act[4], found[4];
-    if constexpr (usePre) mm_probe4_pre(pre + (size_t)f * preStride, preVal + fo, cnt, base, lane, preRun, h, act, found, val);
-    else mm_probe4<MODE == 1>(T, skHash, fo, cnt, base, lane, h, act, found, val);
+    mm_probe4<TAGS>(T, skHash, fo, cnt, base, lane, h, act, found, val);
     // The sketch after frequent-seed removal goes to qHash/qStrand only if a seed was removed: otherwise it equals the raw sketch, and
     // readers (k_l2_locate, mm_query_sketch_download) take that instead (rawSketchSize == sketchSize in the fragment's stats).  In a
     // sketch of several batches the first removal back-fills the batches before it, which were the raw sketch unchanged.
@@ -446,7 +425,7 @@ k_lookup_l1(int nFrags, int s, const DFrag* __restrict__ frags,
       const uint64_t m = __ballot(keep);
       if (keep && anyDrop) {
         const int idx = outIdx + (int)mm_popc_below(m);
-        qHash[fo + idx] = usePre ? skHash[fo + r] : h[u]; qStrand[fo + idx] = skStrand[fo + r];
+        qHash[fo + idx] = h[u]; qStrand[fo + idx] = skStrand[fo + r];
       }
       const bool kf = keep && found[u];
       src[u] = val[u] >> 24;
@@ -553,8 +532,7 @@ k_lookup_l1(int nFrags, int s, const DFrag* __restrict__ frags,
 template <bool TAGS>
 __global__ void __launch_bounds__(256)
 k_gather_points(int nList, const int32_t* __restrict__ list, int s, const DFrag* __restrict__ frags, const uint64_t* __restrict__ skHash, const uint32_t* __restrict__ skCount,
-                const SeedTable T, const uint64_t* __restrict__ pre, const uint64_t* __restrict__ preVal, int preStride,
-                const uint64_t* __restrict__ ptKeys, const int32_t* __restrict__ refGroup, const int32_t* __restrict__ readGroup, const int32_t* __restrict__ readSelf,
+                const SeedTable T, const uint64_t* __restrict__ ptKeys, const int32_t* __restrict__ refGroup, const int32_t* __restrict__ readGroup, const int32_t* __restrict__ readSelf,
                 int seqCounterBase, MapFlags fl, mm_frag_stats* __restrict__ stats, const int64_t* __restrict__ ptOff, uint64_t* __restrict__ pts, uint16_t* __restrict__ ptIds,
                 const unsigned long long* __restrict__ nDev) {
   if (nDev) nList = (int)*nDev;
@@ -567,13 +545,11 @@ k_gather_points(int nList, const int32_t* __restrict__ list, int s, const DFrag*
   const size_t fo = (size_t)f * s;
   const int readId = frags[f].readId;
   const int rg = readGroup[readId], self = readSelf[readId], seqCounter = seqCounterBase + readId;
-  const bool usePre = pre != nullptr && pre[(size_t)f * preStride] == 1ull;
-  int preRun = 0, at = 0, nValid = 0;
+  int at = 0, nValid = 0;
   uint16_t* idDst = ptIds ? ptIds + off : nullptr;
   for (int base = 0; base < cnt; base += 256) {
     uint64_t h[4], val[4]; bool act[4], found[4];
-    if (usePre) mm_probe4_pre(pre + (size_t)f * preStride, preVal + fo, cnt, base, lane, preRun, h, act, found, val);
-    else mm_probe4<TAGS>(T, skHash, fo, cnt, base, lane, h, act, found, val);
+    mm_probe4<TAGS>(T, skHash, fo, cnt, base, lane, h, act, found, val);
 #pragma unroll
     for (int u = 0; u < 4; u++) val[u] = (act[u] && found[u] && !(val[u] & 1ull)) ? val[u] : 0ull;
     nValid += mm_gather_points(pts + off, at, base >> 6, 4, [&](int rd) { return rd == 0 ? val[0] : rd == 1 ? val[1] : rd == 2 ? val[2] : val[3]; },
@@ -581,43 +557,6 @@ k_gather_points(int nList, const int32_t* __restrict__ list, int s, const DFrag*
   }
   for (int j = at + lane; j < slots; j += 64) pts[off + j] = MM_EMPTY;
   if (lane == 0) stats[f].nPoints = nValid;
-  }
-}
-
-// k_seed_probe (MM_SKETCH_PROBE): getSeedHits' table look-ups for the fragments [f0, f1) whose sketch the fast sketch kernel has
-// emitted (marker 2 in their SeedPre row), or for the listed fragments (the hard list, after k_sketch_hard) -- one wave per fragment,
-// nothing but probes: found masks and the values of the found entries in sketch order, for k_lookup_l1 to read instead of probing.
-// Launched chunk by chunk on a stream of its own while the sketch kernel -- bound by the vector ALU, HBM idle -- works on the next
-// chunk: against a human-scale table the probes are what puts k_lookup_l1 on the HBM roofline (one 128-byte line per probe).
-template <bool TAGS>
-__global__ void __launch_bounds__(256)
-k_seed_probe(int f0, int f1, const int32_t* __restrict__ list, const uint32_t* __restrict__ listCount, int s, const uint64_t* __restrict__ skHash, const uint32_t* __restrict__ skCount,
-             const SeedTable T, uint64_t* __restrict__ pre, uint64_t* __restrict__ preVal, int preStride) {
-  const int wpb = (int)(blockDim.x >> 6), lane = (int)mm_lane();
-  const int n = list ? (int)*listCount : f1 - f0;
-  for (int i = blockIdx.x * wpb + (int)(threadIdx.x >> 6); i < n; i += gridDim.x * wpb) {
-    const int f = list ? list[i] : f0 + i;
-    uint64_t* row = pre + (size_t)f * preStride;
-    if (!list && row[0] != 2ull) continue;                         // not emitted by the fast kernel: its sketch comes later, from the hard list
-    const int cnt = (int)skCount[f];
-    const size_t fo = (size_t)f * s;
-    int run = 0;
-    for (int base = 0; base < cnt; base += 256) {
-      uint64_t h[4], val[4]; bool act[4], found[4];
-      mm_probe4<TAGS>(T, skHash, fo, cnt, base, lane, h, act, found, val);
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        if ((base + u * 64) >= cnt) break;
-        const bool fnd = act[u] && found[u];
-        const uint64_t m = __ballot(fnd);
-        if (fnd) preVal[fo + run + (int)mm_popc_below(m)] = val[u];
-        if (lane == 0) row[1 + (base >> 6) + u] = m;
-        run += (int)__popcll(m);
-      }
-    }
-    // (no fence: k_lookup_l1 is a later kernel.  An agent-scope fence here writes back and invalidates the XCD's L2 -- per fragment,
-    // under the sketch kernel running beside this one: measured 2.5x on BOTH kernels, profiles/r11e_probe_overlap_trace.txt)
-    if (lane == 0) row[0] = 1ull;
   }
 }
 
@@ -1139,21 +1078,6 @@ k_l1_window(int nList, const int32_t* __restrict__ list, const DFrag* __restrict
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
-int mm_launch_seed_probe(mm_ctx* c, hipStream_t stream, int f0, int f1, const int32_t* dList, const uint32_t* dListCount) {
-  const DeviceIndex& I = c->idx;
-  const SeedTable seedTab{I.htSlots.as<HtSlot>(), (uint64_t)(I.htCap - 1), I.filter.as<uint64_t>(), (uint64_t)I.filterMask, I.tagged ? I.htTags.as<uint8_t>() : (const uint8_t*)nullptr};
-  const int n = dList ? 4096 : f1 - f0;                             // listed fragments: a fixed grid walks the device-resident list
-  if (n <= 0) return MM_OK;
-  int wpb = 4;                                                      // waves per workgroup (MM_PROBE_WPB: experiment)
-  if (const char* e = getenv("MM_PROBE_WPB")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) wpb = v; }
-  int blocks = (n + wpb - 1) / wpb; if (blocks > 256 * 64 / wpb) blocks = 256 * 64 / wpb;
-  auto k = I.tagged ? k_seed_probe<true> : k_seed_probe<false>;
-  hipLaunchKernelGGL(k, dim3(blocks), dim3(wpb * 64), 0, stream, f0, f1, dList, dListCount, c->P.sketchSize, c->dSkHash.as<uint64_t>(), c->dSkCount.as<uint32_t>(), seedTab,
-                     c->dPre.as<uint64_t>(), c->dPreVal.as<uint64_t>(), (int)c->preStride);
-  MM_HIP(c, hipGetLastError());
-  return MM_OK;
-}
-
 #define MM_SYNC(c) do { MM_HIP(c, hipStreamSynchronize((c)->stream)); (c)->nSyncs++; } while (0)
 
 // One pass of seed lookup + L1 + L2 + selection over the resident sketches.
@@ -1184,7 +1108,6 @@ static int map_pass(mm_ctx* c, const bool steady) {
   const unsigned long long* nBigDev = steady ? cnt + 7 : nullptr;
 
   const SeedTable seedTab{I.htSlots.as<HtSlot>(), (uint64_t)(I.htCap - 1), I.filter.as<uint64_t>(), (uint64_t)I.filterMask, I.tagged ? I.htTags.as<uint8_t>() : (const uint8_t*)nullptr};
-  const uint64_t* pre = c->preProbed ? c->dPre.as<uint64_t>() : (const uint64_t*)nullptr;
   unsigned long long hcur[MM_L1_REGIONS * MM_L1_CURSOR_STRIDE];
   unsigned long long regionCap = 0;
   for (int attempt = 0; attempt < 10; attempt++) {          // grow-and-retry on capacity overflow (points or L1 candidates)
@@ -1203,13 +1126,12 @@ static int map_pass(mm_ctx* c, const bool steady) {
       // larger ones (points come in proportion to the sketch: s = 310 averages ~176 per fragment with a long tail)
       int fuse = s > 256 ? 512 : s > 160 ? 256 : 128;
       if (const char* e = getenv("MM_FUSE_MAXPTS")) { const int v = atoi(e); fuse = v >= 512 ? 512 : v >= 256 ? 256 : 128; }
-      auto kern = pre ? (fuse == 512 ? k_lookup_l1<512, 2> : fuse == 256 ? k_lookup_l1<256, 2> : k_lookup_l1<128, 2>)
-                : I.tagged ? (fuse == 512 ? k_lookup_l1<512, 1> : fuse == 256 ? k_lookup_l1<256, 1> : k_lookup_l1<128, 1>)
-                           : (fuse == 512 ? k_lookup_l1<512, 0> : fuse == 256 ? k_lookup_l1<256, 0> : k_lookup_l1<128, 0>);
+      auto kern = I.tagged ? (fuse == 512 ? k_lookup_l1<512, true> : fuse == 256 ? k_lookup_l1<256, true> : k_lookup_l1<128, true>)
+                           : (fuse == 512 ? k_lookup_l1<512, false> : fuse == 256 ? k_lookup_l1<256, false> : k_lookup_l1<128, false>);
       hipLaunchKernelGGL(kern, dim3((nF + MM_LOOKUP_WPB - 1) / MM_LOOKUP_WPB), dim3(MM_LOOKUP_WPB * 64), 0, c->stream, nF, s, c->dFrags.as<DFrag>(),
                          c->dSkHash.as<uint64_t>(), c->dSkStrand.as<int8_t>(), c->dSkCount.as<uint32_t>(), seedTab, I.ptKeys.as<uint64_t>(),
                          c->dReadSelf.as<int32_t>(), c->seqCounterBase, fl, windowed ? 2 : (c->keepPoints ? 1 : 0),
-                         c->dQHash.as<uint64_t>(), c->dQStrand.as<int8_t>(), pre, c->dPreVal.as<uint64_t>(), (int)c->preStride,
+                         c->dQHash.as<uint64_t>(), c->dQStrand.as<int8_t>(),
                          c->dStats.as<mm_frag_stats>(), c->dPtOff.as<int64_t>(), (unsigned long long)c->ptsCap,
                          c->dMinHits.as<int32_t>(), c->dCutoffs.as<int32_t>(), (int)c->nCutoffs, c->P.segLength,
                          c->dL1.as<mm_l1_candidate>(), regionCap, c->dL1Cursors.as<unsigned long long>(), c->dL1Off.as<int64_t>(),
@@ -1260,7 +1182,7 @@ static int map_pass(mm_ctx* c, const bool steady) {
       {
         auto gk = I.tagged ? k_gather_points<true> : k_gather_points<false>;
         hipLaunchKernelGGL(gk, dim3(gWave), dim3(256), 0, c->stream, nBig, c->dBigList.as<int32_t>(), s, c->dFrags.as<DFrag>(), c->dSkHash.as<uint64_t>(),
-                           c->dSkCount.as<uint32_t>(), seedTab, pre, c->dPreVal.as<uint64_t>(), (int)c->preStride, I.ptKeys.as<uint64_t>(), I.refGroup.as<int32_t>(),
+                           c->dSkCount.as<uint32_t>(), seedTab, I.ptKeys.as<uint64_t>(), I.refGroup.as<int32_t>(),
                            c->dReadGroup.as<int32_t>(), c->dReadSelf.as<int32_t>(), c->seqCounterBase, fl, c->dStats.as<mm_frag_stats>(), c->dPtOff.as<int64_t>(),
                            c->dPts.as<uint64_t>(), sortIds, nBigDev);
         MM_HIP(c, hipGetLastError());

@@ -370,7 +370,7 @@ mm_sketch_fast(unsigned char* smem, const int f, const uint4* __restrict__ gTabs
                const DFrag* __restrict__ frags, const uint32_t* __restrict__ readHasN, int s, int wantFast, int HT, int PAD, int QC,
                uint64_t* __restrict__ skHash, int2* __restrict__ skPos, int8_t* __restrict__ skStrand,
                uint32_t* __restrict__ skCount, int32_t* __restrict__ hardList, uint32_t* __restrict__ hardCount,
-               unsigned long long* __restrict__ phaseStats, const SeedPre seedPre) {
+               unsigned long long* __restrict__ phaseStats) {
   // MM_SKETCH_STATS: shader-clock cycles thread 0 spends up to each phase boundary, summed over workgroups (diagnostics only)
   unsigned long long tPrev = phaseStats ? __builtin_amdgcn_s_memtime() : 0ull;
   auto mark = [&](int ph) {
@@ -576,7 +576,6 @@ mm_sketch_fast(unsigned char* smem, const int f, const uint4* __restrict__ gTabs
     }
   }
   if (tid == 0) skCount[f] = D < (uint32_t)s ? D : (uint32_t)s;
-  if (seedPre.pre && tid == 0) seedPre.pre[(size_t)f * seedPre.stride] = 2ull;   // MM_SKETCH_PROBE: sketch emitted, k_seed_probe may take it
   mark(5);                                          // ranking + output (thread 0's share)
 }
 
@@ -586,10 +585,10 @@ k_sketch_fast(const uint4* __restrict__ gTabs, const uint32_t* __restrict__ base
               const DFrag* __restrict__ frags, const uint32_t* __restrict__ readHasN, int s, int wantFast, int HT, int PAD, int QC,
               uint64_t* __restrict__ skHash, int2* __restrict__ skPos, int8_t* __restrict__ skStrand,
               uint32_t* __restrict__ skCount, int32_t* __restrict__ hardList, uint32_t* __restrict__ hardCount,
-              unsigned long long* __restrict__ phaseStats, const SeedPre seedPre, int f0) {
+              unsigned long long* __restrict__ phaseStats) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  mm_sketch_fast<K, SL>(smem, f0 + (int)blockIdx.x, gTabs, bases2, nmask, frags, readHasN, s, wantFast, HT, PAD, QC, skHash, skPos, skStrand, skCount,
-                        hardList, hardCount, phaseStats, seedPre);
+  mm_sketch_fast<K, SL>(smem, (int)blockIdx.x, gTabs, bases2, nmask, frags, readHasN, s, wantFast, HT, PAD, QC, skHash, skPos, skStrand, skCount,
+                        hardList, hardCount, phaseStats);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -771,7 +770,7 @@ int mm_check_params(const mm_params* p, std::string& err) {
 template <int K> struct MMHasSL20 { static constexpr bool value = (K >= 16 && K <= 21); };   // strips of 20 positions are built for these k-mer sizes
 
 template <int K>
-static int launch_sketch_k(mm_ctx* c, bool withProbe) {
+static int launch_sketch_k(mm_ctx* c) {
   const int s = c->P.sketchSize;
   const int nF = (int)c->nFrags;
   using Tabs = typename MMTabsFor<K>::type;
@@ -794,59 +793,18 @@ static int launch_sketch_k(mm_ctx* c, bool withProbe) {
   unsigned long long* phaseStats = nullptr;
   if (getenv("MM_SKETCH_STATS")) { phaseStats = c->dCounters.as<unsigned long long>() + 24; MM_HIP(c, hipMemsetAsync(phaseStats, 0, 64, c->stream)); }
   // MM_SKETCH_PROBE=1: the fast kernel probes the seed table for the sketch it emits (needs the queue memory to hold s values)
-  // MM_SKETCH_PROBE=1: getSeedHits' table look-ups leave k_lookup_l1 -- against a human-scale table they put it on the HBM roofline (one
-  // 128-byte line per probe) -- and run under the sketch kernel, which is bound by the vector ALU and leaves HBM idle: the fast kernel
-  // marks every fragment it emits, and k_seed_probe (mm_map.hip) looks the sketches up chunk by chunk on a stream of its own while the
-  // sketch kernel works on the next chunk.  k_lookup_l1 then reads found masks + values.
-  SeedPre seedPre{nullptr, nullptr, 0, 0};
-  c->preProbed = false;
-  int probeMode = 0, nChunks = 1;
-  {
-    static const int probeEnv = getenv("MM_SKETCH_PROBE") ? atoi(getenv("MM_SKETCH_PROBE")) : 0;
-    const DeviceIndex& I = c->idx;
-    if (probeEnv && withProbe && I.ready) {
-      probeMode = 2;
-      c->preStride = (size_t)(s + 63) / 64 + 1;
-      MM_HIP(c, c->dPre.ensure((size_t)nF * c->preStride * 8 + 64)); MM_HIP(c, c->dPreVal.ensure((size_t)nF * s * 8 + 64));
-      MM_HIP(c, hipMemsetAsync(c->dPre.p, 0, (size_t)nF * c->preStride * 8, c->stream));
-      seedPre = SeedPre{c->dPre.as<uint64_t>(), c->dPreVal.as<uint64_t>(), (int)c->preStride, probeMode};
-      c->preProbed = true;
-      nChunks = 8;
-      if (const char* e = getenv("MM_PROBE_CHUNKS")) { const int v = atoi(e); if (v >= 1 && v <= 64) nChunks = v; }
-      if (nF < nChunks * 4096) nChunks = nF / 4096 > 0 ? nF / 4096 : 1;
-      if (!c->probeStream) {
-        int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi);          // hi = the numerically smallest = most urgent
-        const char* pe = getenv("MM_PROBE_PRIO");                                     // experiment: 1 = most urgent, -1 = least, 0 / unset = default
-        const int prio = pe && atoi(pe) > 0 ? hi : pe && atoi(pe) < 0 ? lo : 0;
-        MM_HIP(c, hipStreamCreateWithPriority(&c->probeStream, hipStreamNonBlocking, prio));
-        MM_HIP(c, hipEventCreateWithFlags(&c->probeDone, hipEventDisableTiming));
-      }
-      while ((int)c->probeEv.size() < nChunks) { hipEvent_t e; MM_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->probeEv.push_back(e); }
-    }
-  }
   if (plan.useFast) {
     KernelTimer t(c, MM_K_SKETCH);
-    int f0 = 0, f1 = nF;
     auto launch = [&](auto kern) {
       (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsFast);
-      hipLaunchKernelGGL(kern, dim3(f1 - f0), dim3(g.threads), ldsFast, c->stream,
+      hipLaunchKernelGGL(kern, dim3(nF), dim3(g.threads), ldsFast, c->stream,
                          c->dSketchTabs.as<uint4>(), c->dBases2.as<uint32_t>(), c->dNmask.as<uint32_t>(), c->dFrags.as<DFrag>(), c->dReadHasN.as<uint32_t>(),
                          s, g.wantFast, g.HT, PAD, g.QC, c->dSkHash.as<uint64_t>(), c->dSkPos.as<int2>(), c->dSkStrand.as<int8_t>(),
-                         c->dSkCount.as<uint32_t>(), c->dHardList.as<int32_t>(), c->dCounters.as<uint32_t>(), phaseStats, seedPre, f0);
+                         c->dSkCount.as<uint32_t>(), c->dHardList.as<int32_t>(), c->dCounters.as<uint32_t>(), phaseStats);
     };
-    for (int ch = 0; ch < nChunks; ch++) {
-      f0 = (int)((int64_t)nF * ch / nChunks); f1 = (int)((int64_t)nF * (ch + 1) / nChunks);
-      if (f1 <= f0) continue;
-      if constexpr (MMHasSL20<K>::value) { if (g.SL == 20) launch(k_sketch_fast<K, 20>); else launch(k_sketch_fast<K, 16>); }
-      else launch(k_sketch_fast<K, 16>);
-      MM_HIP(c, hipGetLastError());
-      if (probeMode == 2) {                         // this chunk's look-ups start when its sketches are out, beside the next chunk's hashing
-        MM_HIP(c, hipEventRecord(c->probeEv[ch], c->stream));
-        MM_HIP(c, hipStreamWaitEvent(c->probeStream, c->probeEv[ch], 0));
-        const int rc = mm_launch_seed_probe(c, c->probeStream, f0, f1, nullptr, nullptr);
-        if (rc != MM_OK) return rc;
-      }
-    }
+    if constexpr (MMHasSL20<K>::value) { if (g.SL == 20) launch(k_sketch_fast<K, 20>); else launch(k_sketch_fast<K, 16>); }
+    else launch(k_sketch_fast<K, 16>);
+    MM_HIP(c, hipGetLastError());
   } else {
     // the fast kernel's LDS geometry cannot hold this sketch: every fragment takes the exact path
     KernelTimer t(c, MM_K_SKETCH);
@@ -883,15 +841,6 @@ static int launch_sketch_k(mm_ctx* c, bool withProbe) {
       launchHard(k_sketch_hard<K, true>, c->dSketchSpill.as<int32_t>());
     } else launchHard(k_sketch_hard<K, false>, (int32_t*)nullptr);
     MM_HIP(c, hipGetLastError());
-  }
-  if (probeMode == 2) {
-    MM_HIP(c, hipEventRecord(c->probeDone, c->probeStream));
-    // join the probe stream (what is left of the last chunk's look-ups is the part that is not hidden), then the fragments of the hard
-    // list, whose sketches exist only now: every fragment has its row when k_lookup_l1 starts
-    KernelTimer t(c, MM_K_LOOKUP);
-    MM_HIP(c, hipStreamWaitEvent(c->stream, c->probeDone, 0));
-    const int rc = mm_launch_seed_probe(c, c->stream, 0, 0, c->dHardList.as<int32_t>(), c->dCounters.as<uint32_t>());
-    if (rc != MM_OK) return rc;
   }
   return MM_OK;
 }
@@ -946,7 +895,7 @@ extern "C" int mm_bench_hash_only(mm_ctx* c, int reps, double* msAvg) {
   }
 }
 
-int mm_launch_sketch(mm_ctx* c, bool withProbe) {
+int mm_launch_sketch(mm_ctx* c) {
   const size_t nF = c->nFrags, s = (size_t)c->P.sketchSize;
   MM_HIP(c, c->dSkHash.ensure(nF * s * 8 + 64));
   MM_HIP(c, c->dSkPos.ensure(nF * s * 8 + 64));
@@ -956,7 +905,7 @@ int mm_launch_sketch(mm_ctx* c, bool withProbe) {
   MM_HIP(c, c->dCounters.ensure(256));
   if (nF == 0) return MM_OK;
   switch (c->P.kmerSize) {
-#define MM_CASE(KK) case KK: return launch_sketch_k<KK>(c, withProbe);
+#define MM_CASE(KK) case KK: return launch_sketch_k<KK>(c);
     MM_CASE(1) MM_CASE(2) MM_CASE(3) MM_CASE(4) MM_CASE(5) MM_CASE(6) MM_CASE(7) MM_CASE(8) MM_CASE(9) MM_CASE(10) MM_CASE(11) MM_CASE(12) MM_CASE(13) MM_CASE(14) MM_CASE(15) MM_CASE(16) MM_CASE(17) MM_CASE(18) MM_CASE(19) MM_CASE(20) MM_CASE(21) MM_CASE(22) MM_CASE(23) MM_CASE(24) MM_CASE(25) MM_CASE(26) MM_CASE(27) MM_CASE(28) MM_CASE(29) MM_CASE(30) MM_CASE(31) MM_CASE(32)
 #undef MM_CASE
     default: c->err = "kmerSize outside 1..32"; return MM_ERR_ARG;
