@@ -278,7 +278,43 @@ def pmc_entry(workload_key, kernel="k_sketch_fast"):
         return None, None
 
 
-def roofline_block(ctx, capi, W, workload_key, nF, prof, step_ms, pmc_ok):
+def kernel_rooflines(ctx, W, workload_key, nF, prof, mean_points, pmc_ok):
+    """one roofline object per kernel behind the sketch kernel (SURVEY section 8d's B_frag, term by term): algorithmic bytes per launch over the
+    kernel's average HIP-event duration in the timed region, against the HBM peak; fabric traffic and VALU instructions per launch from the
+    committed PMC passes of the same workload when there are any.  What actually binds each kernel is in `binds`."""
+    SKETCH = W["sketch"]
+    try:
+        cnts = ctx.pass_counts()
+    except Exception:
+        cnts = {"l1": 0, "l2": 0, "queued": 0, "stream_entries": 0}
+    ops = float(cnts["stream_entries"])
+    spec = [
+        ("k_lookup_l1", "lookup", (16.0 * SKETCH + 24.0 * mean_points) * nF,
+         "16 B per sketch entry (hash in, table answer) + 24 B per interval point (SURVEY 8d) x fragments",
+         "HBM bandwidth at 128-byte line granularity against a human-scale seed table (one line per probe); the Infinity Cache's gather rate against a 100 Mbp one (DESIGN.md section 3.3)"),
+        ("k_l2_locate", "l2_locate", 20.0 * ops,
+         "16 B read per index event a candidate touches + at most 4 B written per stream entry, x the %d entries reserved for the %d candidates' streams" % (int(ops), cnts["l1"]),
+         "VALU issue + exposed latency (LDS sketch search per event); its slices of the index come mostly from the Infinity Cache (candidates are taken in reference order)"),
+        ("k_l2_sweep", "l2", 4.0 * ops,
+         "4 B per stream entry read by the lane that owns the candidate (state lives in LDS)",
+         "VALU issue: ~110 straight-line lane-mask instructions per stream entry for 64 candidates at a time; LDS-limited occupancy at large sketches"),
+    ]
+    out = []
+    for kern, key, bytes_launch, what, binds in spec:
+        ms, n = prof.get(key, (0.0, 0))
+        if not n or ms <= 0 or bytes_launch <= 0:
+            continue
+        avg = ms / n * (n / max(1, prof["sketch"][1]))          # several brackets per pass (e.g. extents + locate): per pass
+        ach = bytes_launch / (avg / 1e3) / 1e9
+        ent, src = pmc_entry(workload_key, kern) if pmc_ok else (None, None)
+        out.append({"kernel": kern, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
+                    "avg_ms_per_pass": round(avg, 3), "algorithmic_bytes_per_launch": bytes_launch, "algorithmic_bytes": what, "binds": binds,
+                    "traffic": ent.get("hbm_bytes_per_launch") if ent else None,
+                    "valu_wave_instructions_per_launch": ent.get("SQ_INSTS_VALU") if ent else None, "source": src})
+    return out
+
+
+def roofline_block(ctx, capi, W, workload_key, nF, prof, step_ms, pmc_ok, mean_points=0.0):
     """roofline of the dominant kernel (k_sketch_fast): algorithmic bytes per fragment = L/4 packed bases in + 24 B per sketch entry out
     (SURVEY section 8d), divided by its average HIP-event duration in the timed region; the integer yardstick; VALU issue peaks"""
     SEG, SKETCH = W["seg"], W["sketch"]
@@ -313,7 +349,8 @@ def roofline_block(ctx, capi, W, workload_key, nF, prof, step_ms, pmc_ok):
                         "model": "1024 SIMDs x 2.4 GHz; three issue peaks: 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md nominal, SIMD-32), "
                                  "%.2f cycles (this kernel's mix of VOP3 integer ops at ~4.2 and VOP2 ops at ~2.3 cycles measured by "
                                  "scripts/probes/valu_rate.hip, output in profiles/), 4 cycles (every instruction at the VOP3 rate)" % mix}
-    return {"bound": "hbm", "kernel": "k_sketch_fast", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    kernels = kernel_rooflines(ctx, W, workload_key, nF, prof, mean_points, pmc_ok)
+    return {"bound": "hbm", "kernel": "k_sketch_fast", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernels": kernels,
             "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": source,
             "algorithmic_bytes_per_fragment": frag_bytes, "avg_launch_ms": round(sk_avg, 3),
             "algorithmic_bytes_per_launch": frag_bytes * nF,
@@ -338,7 +375,39 @@ def timed_passes(ctx, warmup, steps):
     return dt, prof
 
 
-def north_star_target(torch, dev, capi, local, warmup, steps):
+def human_scale_cpu_baseline(W, ref_np, reads_t, n_sample):
+    """the stock binary (oracle/_ref/mashmap_ref, built from the reference's sources) on a sample of the target's reads against the SAME
+    3 Gbp reference, defaults (it derives sketchSize 310 itself), on this box's host cores: index build and 'time spent mapping the query'"""
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "mashmap_ref")
+    if not os.path.exists(ref_bin):
+        return {"error": "oracle/_ref/mashmap_ref not here"}
+    L = W["read_len"]
+    sample = reads_t[:n_sample * L].cpu().numpy().reshape(n_sample, L)
+    nt = max(4, min(64, 2 * usable_cpus()))
+    with tempfile.TemporaryDirectory() as td:
+        rp, qp, op = os.path.join(td, "ref.fa"), os.path.join(td, "q.fa"), os.path.join(td, "o.paf")
+        write_fasta(rp, ["chr%d" % i for i in range(len(ref_np))], ref_np)
+        write_fasta(qp, ["read%d" % i for i in range(n_sample)], list(sample), width=L)
+        t0 = time.time()
+        p = subprocess.run([ref_bin, "-r", rp, "-q", qp, "-o", op, "-t", str(nt)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        wall = time.time() - t0
+        tm = {}
+        for line in p.stderr.splitlines():
+            for key in ("computing the reference index", "mapping the query"):
+                if "time spent " + key in line:
+                    tm[key] = float(line.split(":")[-1].split()[0])
+        lines = sum(1 for _ in open(op)) if os.path.exists(op) else 0
+    if p.returncode != 0 or "mapping the query" not in tm:
+        return {"error": "mashmap_ref exited with %d: %s" % (p.returncode, p.stderr[-300:])}
+    log("[north_star] stock binary: index %.1f s, mapping %.2f s (%d reads, -t %d)" % (tm.get("computing the reference index", 0), tm["mapping the query"], n_sample, nt))
+    return {"value": round(n_sample * L / tm["mapping the query"] / 1e9, 4), "unit": "Gbp/s", "cores": nt, "kind": "reference",
+            "index_build_s": round(tm.get("computing the reference index", 0.0), 1), "wall_s": round(wall, 1), "paf_lines": lines,
+            "sample": "%d of the target's reads (%.0f Mbp) vs the same %.0f Mbp reference written as FASTA; mashmap_ref (the reference's sources, GSL stand-in) with its "
+                      "defaults, -t %d: %d host hardware threads, of which this process may use %d CPUs at once (container quota); 'time spent mapping the query' includes its "
+                      "single-threaded FASTA reader" % (n_sample, n_sample * L / 1e6, sum(len(a) for a in ref_np) / 1e6, nt, os.cpu_count() or 1, usable_cpus())}
+
+
+def north_star_target(torch, dev, capi, local, warmup, steps, cpu_reads=0):
     """BASELINE.json's north_star target sentence on one GPU: 1 M x 10 kbp ONT-like reads, pi 85, against a human-scale index (3 Gbp,
     24 x 125 Mbp), device-resident packed bases in -> candidate mappings out.  Two variants on the same data: the stock command line
     (segLength 5000, the metric's "s=5000": two fragments per read) and segLength 10000 ("10 kbp segments": one fragment per read);
@@ -372,7 +441,7 @@ def north_star_target(torch, dev, capi, local, warmup, steps):
         res[key] = {
             "value": round(nreads * READ_LEN * steps / dt / 1e9, 4), "unit": "Gbp/s", "ms_per_step": round(step_ms, 3), "steps": steps, "warmup": warmup,
             "kernels": {k: {"ms_per_step": v[0] / steps, "launches_per_step": v[1] / steps} for k, v in prof.items() if v[1]},
-            "roofline": roofline_block(ctx, capi, W, wl_key, nF, prof, step_ms, True),
+            "roofline": roofline_block(ctx, capi, W, wl_key, nF, prof, step_ms, True, float(stats["nPoints"].mean())),
             "index_build_s": round(index_s, 2),
             "workload": "%d x %d bp reads (10%% ONT-like error) vs %.0f Mbp synthetic reference (%d contigs), k %d, segLength %d, sketchSize %d, pi %.2f: "
                         "%d fragments, %.1f interval points per fragment, %d L1 candidates, %d L2 loci, %d candidate mappings"
@@ -382,6 +451,11 @@ def north_star_target(torch, dev, capi, local, warmup, steps):
         ctx.close()
         del ctx
     out = dict(res["segLength5000"])
+    if cpu_reads > 0:
+        try:
+            out["cpu_baseline"] = human_scale_cpu_baseline(base, ref_np, reads_t, cpu_reads)
+        except Exception as e:
+            log("[north_star] cpu_baseline failed:", repr(e)); out["cpu_baseline"] = {"error": repr(e)}
     out["what"] = ("BASELINE.json north_star target (>= 50 query Gbp/s sketch+map on 1 x MI355X, 10 kbp reads at pi 85 against a human-scale index), measured in "
                    "this run behind the headline configuration; inputs resident in HBM, same timed region as `value`")
     out["target_gbps"] = 50.0
@@ -437,7 +511,7 @@ def main():
         import torch
         from mashmap_amd import capi
         torch.cuda.set_device(0)
-        print(json.dumps(north_star_target(torch, torch.device("cuda", 0), capi, 0, args.warmup, args.steps)), flush=True)
+        print(json.dumps(north_star_target(torch, torch.device("cuda", 0), capi, 0, args.warmup, args.steps, 0 if args.no_cpu_baseline else args.cpu_sample)), flush=True)
         return
 
     # ---- N ranks: start them ourselves unless a launcher already did
@@ -525,10 +599,15 @@ def main():
     del reads_t
     torch.cuda.empty_cache()
 
+    rccl = None
     if world > 1:                                       # the product's RCCL communicator: the id travels through torch's store
         box = [capi.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         ctx.comm_init_rank(box[0], rank, world)
+        try:
+            rccl = ctx.comm_info()                      # what the communicator itself reports: ranks seen (ncclCommCount), library bound
+        except Exception as e:
+            rccl = {"error": repr(e)}
 
     inflight = [False]
 
@@ -575,9 +654,9 @@ def main():
         bases_step = nreads * READ_LEN * world
         value = bases_step * args.steps / dt / 1e9
         step_ms = dt / args.steps * 1e3
-        roofline = roofline_block(ctx, capi, W, args.workload, nF, prof, step_ms, not scaled)
-        kernels = {k: {"ms_per_step": v[0] / args.steps, "launches_per_step": v[1] / args.steps} for k, v in prof.items() if v[1]}
         P = float(stats["nPoints"].mean())
+        roofline = roofline_block(ctx, capi, W, args.workload, nF, prof, step_ms, not scaled, P)
+        kernels = {k: {"ms_per_step": v[0] / args.steps, "launches_per_step": v[1] / args.steps} for k, v in prof.items() if v[1]}
         ref_mbp = sum(ref_lens) / 1e6
         out = {
             "metric": "query Gbp/s sketch+L1/L2 map (pi=85, s=5000)", "value": round(value, 4), "unit": "Gbp/s",
@@ -592,7 +671,8 @@ def main():
                        "parallelism": "reads sharded, index replicated, RCCL all-gatherv of candidate mappings (libmashmap_hip: mm_allgatherv_mappings_begin/_end, overlapped with the next batch)"
                        if world > 1 else "single GPU", "mean_interval_points_per_fragment": round(P, 1),
                        "l1_candidates_per_gpu": n1, "l2_loci_per_gpu": n2, "candidate_mappings_per_gpu": nmap,
-                       "index_build_s": round(index_s, 2),
+                       "index_build_s": round(index_s, 2), "rccl": rccl,
+                       "host_synchronisations_per_pass": ctx.pass_stats()[0],
                        "identity_tables": "minimumHits / sketchCutoffs / acceptance from mm_stats.hpp's re-derivation of GSL's binomial and hypergeometric "
                                           "CDFs (GSL is not in the image; SURVEY section 8c: the one unpinned boundary)"},
             "roofline": roofline,
@@ -615,9 +695,9 @@ def main():
             del reads_np, ref_np
             torch.cuda.empty_cache()
             cmd = [sys.executable, os.path.abspath(__file__), "--north-star-child", "--steps", str(max(1, min(args.steps, args.north_star_steps))),
-                   "--warmup", str(min(args.warmup, 2))]
+                   "--warmup", str(min(args.warmup, 2)), "--cpu-sample", str(args.cpu_sample)] + (["--no-cpu-baseline"] if args.no_cpu_baseline else [])
             try:
-                p = subprocess.run(cmd, stdout=subprocess.PIPE, timeout=600, env=dict(os.environ, HIP_VISIBLE_DEVICES=os.environ.get("HIP_VISIBLE_DEVICES", str(local))))
+                p = subprocess.run(cmd, stdout=subprocess.PIPE, timeout=900, env=dict(os.environ, HIP_VISIBLE_DEVICES=os.environ.get("HIP_VISIBLE_DEVICES", str(local))))
                 line = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
                 out["north_star_target"] = json.loads(line[-1]) if p.returncode == 0 and line else {"error": "child exited with %d" % p.returncode}
             except Exception as e:

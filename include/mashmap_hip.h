@@ -322,6 +322,9 @@ int mm_comm_unique_id(void* id);
 int mm_comm_init_rank(mm_ctx* ctx, const void* id, int rank, int world);
 int mm_comm_init_local(mm_ctx** ctxs, int n);
 int mm_comm_world(const mm_ctx* ctx, int* rank, int* world);
+/* what the communicator itself says: the number of ranks RCCL sees in it (ncclCommCount; -1 if the bound library does not export it) and
+ * the file its entry points were bound from -- for a record of a multi-GPU run to show that RCCL, and which one, carried the exchange */
+int mm_comm_info(const mm_ctx* ctx, int* worldSeen, char* libraryPath, size_t cap);
 int mm_allgatherv_mappings(mm_ctx* ctx);
 /* The same exchange overlapped with the next batch: _begin snapshots the resident candidate mappings and returns at once (the exchange
  * runs on a stream and a host thread of its own); the caller may upload and map the next batch; _end waits for the exchange, after

@@ -110,6 +110,7 @@ def load():
         "mm_comm_init_rank": (C.c_int, [vp, vp, C.c_int, C.c_int]),
         "mm_comm_init_local": (C.c_int, [C.POINTER(vp), C.c_int]),
         "mm_comm_world": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+        "mm_comm_info": (C.c_int, [vp, C.POINTER(C.c_int), C.c_char_p, sz]),
         "mm_allgatherv_mappings": (C.c_int, [vp]),
         "mm_allgatherv_mappings_local": (C.c_int, [C.POINTER(vp), C.c_int]),
         "mm_allgatherv_mappings_begin": (C.c_int, [vp]),
@@ -150,7 +151,7 @@ EXPORTS = ["mm_abi_version", "mm_create", "mm_destroy", "mm_last_error", "mm_ind
            "mm_allgatherv_mappings_begin", "mm_allgatherv_mappings_end",
            "mm_gathered_counts", "mm_gathered_download", "mm_gathered_device", "mm_index_replicate", "mm_stat_replay_tables", "mm_host_alloc", "mm_host_free", "mm_reads_prefetch",
            "mm_reads_upload_packed", "mm_reads_prefetch_packed", "mm_pack_read", "mm_pack_read_portable", "mm_reads_packed_download",
-           "mm_index_layout_get", "mm_pass_stats"]
+           "mm_index_layout_get", "mm_pass_stats", "mm_comm_info"]
 
 
 def stat_sketch_cutoffs(sketchSize, k, hg=True):
@@ -426,6 +427,12 @@ class Context:
     def comm_init_rank(self, comm_id, rank, world):
         buf = (C.c_char * COMM_ID_BYTES).from_buffer_copy(bytes(comm_id))
         self._ck(self.lib.mm_comm_init_rank(self.h, C.cast(buf, C.c_void_p), rank, world), "mm_comm_init_rank")
+
+    def comm_info(self):
+        """dict(world_seen, library_path) of this context's communicator"""
+        n = C.c_int(); buf = C.create_string_buffer(512)
+        self._ck(self.lib.mm_comm_info(self.h, C.byref(n), buf, 512), "mm_comm_info")
+        return {"world_seen": int(n.value), "library_path": buf.value.decode(errors="replace")}
 
     def allgatherv_mappings(self):
         self._ck(self.lib.mm_allgatherv_mappings(self.h), "mm_allgatherv_mappings")

@@ -38,7 +38,8 @@ struct Rccl {
   decltype(&ncclGroupStart) GroupStart = nullptr;
   decltype(&ncclGroupEnd) GroupEnd = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
-  std::string err;
+  decltype(&ncclCommCount) CommCount = nullptr;        // optional
+  std::string err, path;                               // path: the file the entry points were bound from
 };
 Rccl g_rccl;
 std::mutex g_rcclMu;
@@ -55,9 +56,10 @@ Rccl* rccl_open(std::string& err) {
   for (const char* n : names) { if (n && *n && (h = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD))) break; }
   if (!h) { how = "loaded"; for (const char* n : names) { if (n && *n && (h = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break; } }
   if (!h) { g_rccl.err = std::string("cannot load RCCL (librccl.so.1): ") + (dlerror() ? dlerror() : "not found"); err = g_rccl.err; return nullptr; }
-  if (getenv("MM_DEBUG") || getenv("MASHMAP_HIP_TIMING")) {
+  {
     Dl_info di; void* f = dlsym(h, "ncclGetUniqueId");
-    fprintf(stderr, "[mm] RCCL bound to %s (%s)\n", (f && dladdr(f, &di) && di.dli_fname) ? di.dli_fname : "?", how);
+    g_rccl.path = (f && dladdr(f, &di) && di.dli_fname) ? di.dli_fname : "?";
+    if (getenv("MM_DEBUG") || getenv("MASHMAP_HIP_TIMING")) fprintf(stderr, "[mm] RCCL bound to %s (%s)\n", g_rccl.path.c_str(), how);
   }
   bool ok = true;
   auto sym = [&](const char* n) { void* p = dlsym(h, n); if (!p) ok = false; return p; };
@@ -71,6 +73,7 @@ Rccl* rccl_open(std::string& err) {
   g_rccl.GroupStart = (decltype(g_rccl.GroupStart))sym("ncclGroupStart");
   g_rccl.GroupEnd = (decltype(g_rccl.GroupEnd))sym("ncclGroupEnd");
   g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))sym("ncclGetErrorString");
+  g_rccl.CommCount = (decltype(g_rccl.CommCount))dlsym(h, "ncclCommCount");
   if (!ok) { g_rccl.err = "RCCL library lacks a required entry point"; err = g_rccl.err; dlclose(h); return nullptr; }
   g_rccl.h = h;
   return &g_rccl;
@@ -184,6 +187,15 @@ int mm_comm_init_local(mm_ctx** ctxs, int n) {
       fprintf(stderr, "[mm] warning: no RCCL communicator for the local group (%s); candidate mappings are exchanged by peer copies\n", why.c_str());
     }
   }
+  return MM_OK;
+}
+
+int mm_comm_info(const mm_ctx* c, int* worldSeen, char* libraryPath, size_t cap) {
+  if (!c->commWorld) return MM_ERR_STATE;
+  int n = c->commCopy ? c->commWorld : -1;             // contexts sharing a device exchange by copies: no communicator to ask
+  if (!c->commCopy && c->comm && g_rccl.h && g_rccl.CommCount) { int k = 0; if (g_rccl.CommCount((ncclComm_t)c->comm, &k) == ncclSuccess) n = k; }
+  if (worldSeen) *worldSeen = n;
+  if (libraryPath && cap) { const std::string& p = c->commCopy ? std::string("(device copies, no RCCL)") : g_rccl.path; snprintf(libraryPath, cap, "%s", p.c_str()); }
   return MM_OK;
 }
 

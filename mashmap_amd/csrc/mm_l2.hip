@@ -154,6 +154,13 @@ k_scan_add(int64_t n, int64_t* __restrict__ out, const int64_t* __restrict__ til
   for (int i = 0; i < SCAN_ITEMS; i++) if (base + i < n) out[base + i] += add;
 }
 
+// steady-state passes: the streams' total (the scan's last word) against the buffer as the previous pass left it; a batch that does not
+// fit is flagged and its candidate count zeroed, so that the kernels behind this one do nothing (the pass is then redone with the
+// host's sizing)
+__global__ void k_l2_gate(const int64_t* __restrict__ total, int64_t opsCap, unsigned long long* __restrict__ counters /* [2] candidates, [6] |= 8 */) {
+  if (*total > opsCap) { counters[6] |= 8ull; counters[2] = 0ull; }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Sort keys that put the candidates of a chunk in REFERENCE order (the event index where a candidate's slice starts, coarsened).
 // k_l2_locate streams ~3 segment lengths of the index per candidate and the reads cover the reference several times over, in random
@@ -187,8 +194,8 @@ k_l2_locate(int cBase, int nCand, int64_t opsBase, int s, int NB, const mm_l1_ca
             const uint32_t* __restrict__ opKey, const uint32_t* __restrict__ opAux, const uint64_t* __restrict__ opHash,
             const int64_t* __restrict__ contigOff, const L2Info* __restrict__ info, const int64_t* __restrict__ opOff,
             const int32_t* __restrict__ opCnt, uint32_t* __restrict__ ops, const int32_t* __restrict__ order /* candidates in reference order, or null */,
-            unsigned long long* __restrict__ counters /* [6] |= 4: a stream outgrew its reservation, |= 8: the streams do not fit the buffer */,
-            const unsigned long long* __restrict__ nDev, int64_t opsCap) {
+            unsigned long long* __restrict__ counters /* [6] |= 4: a stream outgrew its reservation */,
+            const unsigned long long* __restrict__ nDev) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   unsigned char* base = smem + (size_t)wave * mm_locate_lds_per_wave(s, NB);
@@ -197,16 +204,15 @@ k_l2_locate(int cBase, int nCand, int64_t opsBase, int s, int NB, const mm_l1_ca
   uint16_t* bkt = (uint16_t*)(base + (size_t)(s + 1) * 8 + (size_t)(s + 2) / 2 * 8);   // bkt[b] = #query hashes whose bucket is < b, b = 0..NB
   int8_t* qs = (int8_t*)(base + (size_t)(s + 1) * 8 + (size_t)(s + 2) / 2 * 8 + (size_t)(NB + 4) * 2);
   const int wpb = (int)(blockDim.x >> 6);                          // waves per workgroup: 4, fewer when a sketch's LDS share is large
-  if (nDev) nCand = (int)*nDev - cBase;                            // steady state: the count stayed on the device
+  if (nDev) { const int nd = (int)*nDev - cBase; if (nd < nCand) nCand = nd; }   // steady state: the count stayed on the device (k_l2_gate has zeroed it if the streams do not fit)
   for (int ci = blockIdx.x * wpb + wave; ci < nCand; ci += gridDim.x * wpb) {
     const int c = order ? order[ci] : cBase + ci;                  // this launch covers the candidates [cBase, cBase + nCand): their streams start at ops[opOff - opsBase]
     const mm_l1_candidate cand = l1[c];
     const int f = cand.frag;
     const L2Info in = info[c];
     const int S = in.sketch & 0x7fffffff;
-    const int cap = opCnt[c];
-    if (opOff[c] - opsBase + cap > opsCap) { if (lane == 0) atomicOr(&counters[6], 8ull); continue; }   // only without the host's own sizing (steady state)
     uint32_t* out = ops + (opOff[c] - opsBase);
+    const int cap = opCnt[c];
     __threadfence_block();                                         // previous candidate's LDS reads are done
     // a fragment that lost no frequent seed has no copy in qHash/qStrand: its sketch is the raw one (k_lookup_l1)
     const bool raw = in.sketch < 0;
@@ -368,7 +374,7 @@ k_l2_sweep(int cBase, int nCand, int64_t opsBase, const int32_t* __restrict__ ca
            const int64_t* __restrict__ l1Off, L2Tmp* __restrict__ tmp, int locap, mm_l2_locus* __restrict__ l2, unsigned long long l2Cap,
            int32_t* __restrict__ wideList, int32_t* __restrict__ exactList, int64_t* __restrict__ l2First, int32_t* __restrict__ l2Num,
            unsigned long long* __restrict__ counters /* [0] candidates queued for the exact pass, [4] l2 cursor, [5] overflow, [6] flags, [7] queued for the wide pass */,
-           const unsigned long long* __restrict__ nDev /* non-null: the number of candidates (minus cBase) or of list entries lives there */, int64_t opsCap, int listCap) {
+           const unsigned long long* __restrict__ nDev /* non-null: the number of candidates (minus cBase) or of list entries lives there */, int listCap) {
   typedef typename std::conditional<WIDE, uint16_t, uint8_t>::type CellT;
   constexpr int CB = WIDE ? 12 : 5;
   constexpr uint32_t CMASK = (1u << CB) - 1u;
@@ -389,9 +395,8 @@ k_l2_sweep(int cBase, int nCand, int64_t opsBase, const int32_t* __restrict__ ca
   const mm_l1_candidate cand = l1[cIdx];
   const int f = cand.frag;
   const int S = stats[f].sketchSize;
-  const bool fits = opOff[cIdx] - opsBase + opCnt[cIdx] <= opsCap;            // false only in a steady-state pass whose streams outgrew the buffer (k_l2_locate has flagged it)
-  const uint4* src = (const uint4*)(ops + (fits ? opOff[cIdx] - opsBase : 0));
-  const int nSteps = fits ? opCnt[cIdx] / E_STEP : 0;  // 16 entries = 4 x 16 bytes per step
+  const uint4* src = (const uint4*)(ops + (opOff[cIdx] - opsBase));
+  const int nSteps = opCnt[cIdx] / E_STEP;             // 16 entries = 4 x 16 bytes per step
   int posAcc = cand.rangeStartPos;                     // running position of the delta code
   const int lbase = WIDE ? (LPW == 64 ? (lane & 31) * 2 + (lane >> 5) : lane) : lane * 4;
 #define CELL(p) cell[WIDE ? (p) * LPW + lbase : ((p) >> 2) * (LPW * 4) + lbase + ((p) & 3)]
@@ -946,6 +951,8 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt, bool steady) {
       const int64_t* dTotal = nullptr;
       const int rc = mm_scan_i32_to_i64_dev(c, nC, c->dL2Cnt.as<int32_t>(), c->dL2Off.as<int64_t>(), &dTotal); if (rc != MM_OK) return rc;
       MM_HIP(c, hipMemcpyAsync(c->dCounters.as<unsigned long long>() + 34, dTotal, 8, hipMemcpyDeviceToDevice, c->stream));   // read back with the pass's counters
+      hipLaunchKernelGGL(k_l2_gate, dim3(1), dim3(1), 0, c->stream, dTotal, (int64_t)(c->dL2Ops.bytes / 4) - 64, cnt);
+      MM_HIP(c, hipGetLastError());
     } else { const int rc = mm_scan_i32_to_i64(c, nC, c->dL2Cnt.as<int32_t>(), c->dL2Off.as<int64_t>(), &totalOps); c->nSyncs++; if (rc != MM_OK) return rc; c->lastOps = (size_t)totalOps; }
   }
   // The located streams (4 bytes per event a candidate touches: ~5 KB per candidate at s = 130) live in HBM only between the locate and
@@ -984,8 +991,7 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt, bool steady) {
     }
   }
   if (!steady) MM_HIP(c, c->dL2Ops.ensure((size_t)(maxChunkOps + maxChunkOps / 16) * 4 + 256));   // a sixteenth of head room for the steady-state passes behind this one
-  const int64_t opsCap = steady || chunks.size() == 1 ? (int64_t)(c->dL2Ops.bytes / 4) - 64 : (int64_t)1 << 62;
-  if (steady && chunks.size() == 1 && c->dL2Ops.bytes == 0) return MM_PASS_REDO;
+  if (steady && c->dL2Ops.bytes == 0) return MM_PASS_REDO;
   // buckets of the query-sketch search: at least one per sketch entry (more buckets cost more to fill per candidate than the shorter
   // walks save: profiles/r02z_locate_buckets.txt)
   int NB = 256; while (NB < s) NB <<= 1;
@@ -1018,7 +1024,7 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt, bool steady) {
                          I.evKey.as<uint32_t>(),
                          I.evAux.as<uint32_t>(), I.evHash.as<uint64_t>(), I.opKey.as<uint32_t>(), I.opAux.as<uint32_t>(), I.opHash.as<uint64_t>(),
                          I.contigOff.as<int64_t>(),
-                         c->dL2Info.as<L2Info>(), c->dL2Off.as<int64_t>(), c->dL2Cnt.as<int32_t>(), c->dL2Ops.as<uint32_t>(), order, cnt, nDev, opsCap);
+                         c->dL2Info.as<L2Info>(), c->dL2Off.as<int64_t>(), c->dL2Cnt.as<int32_t>(), c->dL2Ops.as<uint32_t>(), order, cnt, nDev);
     };
     if (JB == 13) go(k_l2_locate<13>); else go(k_l2_locate<11>);
     MM_HIP(c, hipGetLastError());
@@ -1041,7 +1047,7 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt, bool steady) {
       hipLaunchKernelGGL(kern, dim3((unsigned)((n + lpw - 1) / lpw)), dim3(64), lds, c->stream, c0, n, opsBase, list, c->P.segLength,
                          c->dL1.as<mm_l1_candidate>(), c->dStats.as<mm_frag_stats>(), c->dL2Off.as<int64_t>(), c->dL2Cnt.as<int32_t>(), c->dL2Ops.as<uint32_t>(),
                          c->dL1Off.as<int64_t>(), c->dL2Tmp.as<L2Tmp>(), locap_, c->dL2.as<mm_l2_locus>(), (unsigned long long)c->l2Cap,
-                         c->dL2Wide.as<int32_t>(), c->dL2Exact.as<int32_t>(), c->dL2First.as<int64_t>(), c->dL2Num.as<int32_t>(), cnt, countDev, opsCap, listCap);
+                         c->dL2Wide.as<int32_t>(), c->dL2Exact.as<int32_t>(), c->dL2First.as<int64_t>(), c->dL2Num.as<int32_t>(), cnt, countDev, listCap);
     };
     if (!wide) {
       if (JB == 11) go(k_l2_sweep<false, 11, 64>, 64, ldsNarrow);

@@ -26,8 +26,13 @@ struct SelectArgs {
 template <bool WRITE>
 __global__ void __launch_bounds__(256)
 k_l2_select(SelectArgs A, int32_t* __restrict__ counts, const int64_t* __restrict__ outOff, mm_mapping* __restrict__ out,
-            const int64_t* __restrict__ totalDev, long long outCap, unsigned long long* __restrict__ result /* steady-state passes: [0] = total, [1] = 1 if it exceeds outCap */) {
+            const int64_t* __restrict__ totalDev, long long outCap, unsigned long long* __restrict__ result /* steady-state passes: [0] = total, [1] = 1 if it exceeds outCap */,
+            const unsigned long long* __restrict__ passCnt /* steady-state passes: the pass's counters; any overflow flag = the stages before this one are incomplete */) {
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (passCnt && (passCnt[1] | passCnt[3] | passCnt[5] | passCnt[6])) {     // the pass will be redone with the host's sizing: nothing here may be trusted (or dereferenced)
+    if (!WRITE && f < A.nFrags) counts[f] = 0;
+    return;
+  }
   if (WRITE && totalDev) {
     const long long total = (long long)*totalDev;
     if (f == 0) { result[0] = (unsigned long long)total; if (total > outCap) result[1] = 1ull; }
@@ -81,7 +86,7 @@ int mm_launch_select(mm_ctx* c, bool steady) {
   A.heap = c->dSelHeap.as<int32_t>();
   KernelTimer t(c, MM_K_SELECT);
   hipLaunchKernelGGL((k_l2_select<false>), dim3((nF + 255) / 256), dim3(256), 0, c->stream, A, c->dSelCnt.as<int32_t>(), (const int64_t*)nullptr, (mm_mapping*)nullptr,
-                     (const int64_t*)nullptr, 0ll, (unsigned long long*)nullptr);
+                     (const int64_t*)nullptr, 0ll, (unsigned long long*)nullptr, steady ? (const unsigned long long*)(c->dCounters.as<unsigned long long>() + 8) : (const unsigned long long*)nullptr);
   MM_HIP(c, hipGetLastError());
   if (steady) {
     // the records' number stays on the device: the writing pass checks it against the buffer as the previous pass left it and
@@ -91,7 +96,7 @@ int mm_launch_select(mm_ctx* c, bool steady) {
     if (rc != MM_OK) return rc;
     const long long cap = (long long)(c->dMappings.bytes / sizeof(mm_mapping)) - 2;
     hipLaunchKernelGGL((k_l2_select<true>), dim3((nF + 255) / 256), dim3(256), 0, c->stream, A, (int32_t*)nullptr, c->dSelOff.as<int64_t>(), c->dMappings.as<mm_mapping>(),
-                       dTotal, cap, c->dCounters.as<unsigned long long>() + 32);
+                       dTotal, cap, c->dCounters.as<unsigned long long>() + 32, (const unsigned long long*)(c->dCounters.as<unsigned long long>() + 8));
     MM_HIP(c, hipGetLastError());
     return MM_OK;
   }
@@ -102,7 +107,7 @@ int mm_launch_select(mm_ctx* c, bool steady) {
   MM_HIP(c, c->dMappings.ensure((size_t)(total + total / 16) * sizeof(mm_mapping) + 4096));   // head room for the steady-state passes behind this one
   if (total) {
     hipLaunchKernelGGL((k_l2_select<true>), dim3((nF + 255) / 256), dim3(256), 0, c->stream, A, (int32_t*)nullptr, c->dSelOff.as<int64_t>(), c->dMappings.as<mm_mapping>(),
-                       (const int64_t*)nullptr, 0ll, (unsigned long long*)nullptr);
+                       (const int64_t*)nullptr, 0ll, (unsigned long long*)nullptr, (const unsigned long long*)nullptr);
     MM_HIP(c, hipGetLastError());
   }
   c->nMappings = (size_t)total;
