@@ -7,7 +7,6 @@
 #include "../host/pack2bit.hpp"
 
 static thread_local std::string g_createErr;
-#define MM_LINE_SLOTS_HOST 7
 
 static const char* kKernelNames[MM_K_COUNT] = {
   "k_pack2bit", "k_sketch_fast", "k_sketch_hard", "k_seed_lookup", "k_sort_points",
@@ -461,10 +460,9 @@ int mm_index_sizes(const mm_ctx* c, size_t* nMinmers, size_t* nKeys, size_t* nPo
 int mm_index_layout_get(const mm_ctx* c, mm_index_layout* o) {
   if (!c->idx.ready || !o) return MM_ERR_STATE;
   const DeviceIndex& I = c->idx;
-  o->seedTableSlots = I.tagMode == 2 ? (uint64_t)I.htLines * MM_LINE_SLOTS_HOST : I.htCap;
-  o->seedTableBytes = I.tagMode == 2 ? (uint64_t)I.htLines * 128 : (uint64_t)I.htCap * 16;
-  o->tagged = I.tagMode; o->pad_ = 0;                    // 0 plain, 1 tag array in front of 16-slot buckets, 2 tags inside 128-byte line buckets
-  o->tagBytes = I.tagMode == 1 ? (uint64_t)I.htCap : I.tagMode == 2 ? (uint64_t)I.htLines * 8 : 0;
+  o->seedTableSlots = I.htCap; o->seedTableBytes = (uint64_t)I.htCap * 16;
+  o->tagged = I.tagged ? 1 : 0; o->pad_ = 0;
+  o->tagBytes = I.tagged ? (uint64_t)I.htCap : 0;
   o->filterBytes = I.filterMask ? (I.filterMask + 1) * 8 : 0;
   o->events = 2 * (uint64_t)I.nRec; o->openRecords = I.nOpen;
   return MM_OK;

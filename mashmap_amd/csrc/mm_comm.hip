@@ -351,7 +351,7 @@ int mm_index_replicate(mm_ctx* dst, mm_ctx* src) {
     else MM_HIP(dst, hipMemcpyPeerAsync(d[i]->p, dst->device, s[i]->p, src->device, s[i]->bytes, dst->stream));
   }
   MM_HIP(dst, hipStreamSynchronize(dst->stream));
-  D.nRec = S.nRec; D.nKeys = S.nKeys; D.nPoints = S.nPoints; D.nContigs = S.nContigs; D.htCap = S.htCap; D.htLines = S.htLines; D.tagMode = S.tagMode; D.nOpen = S.nOpen; D.filterMask = S.filterMask; D.tagged = S.tagged;
+  D.nRec = S.nRec; D.nKeys = S.nKeys; D.nPoints = S.nPoints; D.nContigs = S.nContigs; D.htCap = S.htCap; D.nOpen = S.nOpen; D.filterMask = S.filterMask; D.tagged = S.tagged;
   D.ready = true;
   dst->freqThreshold = src->freqThreshold;
   dst->mapped = false;

@@ -172,19 +172,7 @@ __device__ __forceinline__ void mm_tag_scan(uint4 t, uint32_t tag, uint32_t& can
   cand16 = c; hasEmpty = e != 0;
 }
 
-// Line layout of the tagged table (MM_SEED_LAYOUT=line): a bucket IS one 128-byte line -- word 0: the tag bytes of its 7 slots (byte 7 is
-// 0xFF: never empty, never a candidate), word 1 spare, then the 7 slots of 16 bytes.  A probe fetches the line for the tags; the slot
-// of a matching tag is in the same line (a cache hit instead of a second line from HBM).
-#define MM_LINE_SLOTS 7
-#define MM_LINE_WORDS 16
-__device__ __forceinline__ void mm_line_scan(uint64_t tags8, uint32_t tag, uint32_t& cand7, bool& hasEmpty) {
-  const uint64_t ones = 0x0101010101010101ull, high = 0x8080808080808080ull;
-  const uint64_t x = tags8 ^ ((uint64_t)tag * ones);
-  const uint64_t zc = (x - ones) & ~x & high;                            // zero bytes of x (a flag above a real zero byte may be spurious: candidates are verified)
-  cand7 = (uint32_t)((((zc >> 7) * 0x0102040810204081ull) >> 56) & 0x7Full);
-  hasEmpty = ((tags8 - ones) & ~tags8 & high) != 0ull;
-}
-// the seed table as a kernel argument (k_lookup_l1, k_gather_points: mm_map.hip).  mask: slot mask (plain / 16-slot buckets) or line mask
+// the seed table as a kernel argument (k_lookup_l1, k_gather_points: mm_map.hip)
 struct SeedTable { const HtSlot* ht; uint64_t mask; const uint64_t* filter; uint64_t filterMask; const uint8_t* tags; };
 
 // ---------------------------------------------------------------------------------------------

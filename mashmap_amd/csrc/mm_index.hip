@@ -268,7 +268,8 @@ extern "C" int mm_index_build(mm_ctx* c, const char* bases, const int64_t* conti
   std::vector<DevBuf> dPer(nContigs);
   const bool earlyUpload = getenv("MM_INDEX_NO_EARLY_UPLOAD") == nullptr;
   const int device = c->device;
-  std::deque<std::future<void>> inflight;
+  std::deque<std::shared_future<void>> inflight;
+  std::shared_future<void> stagedBusy[2];               // the finishing job that still reads the page-locked landing buffer of that turn
   DevBuf dAscii, dB, dM, dMeta, dH, dS;
   WinnowBuffers wb;
   int rc = MM_OK;
@@ -282,12 +283,16 @@ extern "C" int mm_index_build(mm_ctx* c, const char* bases, const int64_t* conti
     if (rc != MM_OK) break;
     auto rec = std::make_shared<std::vector<mm_minmer>>(); auto tc = std::make_shared<std::vector<int32_t>>();
     auto runs = std::make_shared<std::vector<WnOpenRun>>(); auto oc = std::make_shared<std::vector<int32_t>>();
-    rc = mm_winnow_contig_device(c, wb, dH.as<uint64_t>(), dS.as<int8_t>(), (int64_t)len - k + 1, len, *rec, *tc, *runs, *oc);
+    const int turn = wb.turn;
+    if (stagedBusy[turn].valid()) stagedBusy[turn].wait();        // contig ci-2 has copied its records out of this landing buffer
+    WnStaged staged;
+    rc = mm_winnow_contig_device(c, wb, dH.as<uint64_t>(), dS.as<int8_t>(), (int64_t)len - k + 1, len, *rec, *tc, *runs, *oc, &staged);
     if (rc != MM_OK) break;
     while (inflight.size() >= maxJobs) { inflight.front().get(); inflight.pop_front(); }
     std::vector<mm_minmer>* dst = &per[ci];
     DevBuf* dDst = earlyUpload ? &dPer[ci] : nullptr;
-    inflight.push_back(std::async(std::launch::async, [rec, tc, runs, oc, w, s, ci, dst, dDst, device]() {
+    inflight.push_back(std::async(std::launch::async, [rec, tc, runs, oc, w, s, ci, dst, dDst, device, staged]() {
+      staged.take(*rec, *runs);                                     // out of the page-locked landing buffer, off the device's critical path
       finish_contig(*rec, *tc, *runs, *oc, s, w, (int)ci);
       dst->swap(*rec);
       if (dDst && !dst->empty() && hipSetDevice(device) == hipSuccess) {
@@ -296,7 +301,8 @@ extern "C" int mm_index_build(mm_ctx* c, const char* bases, const int64_t* conti
             hipMemcpyAsync(dDst->p, dst->data(), bytes, hipMemcpyHostToDevice, hipStreamPerThread) != hipSuccess ||
             hipStreamSynchronize(hipStreamPerThread) != hipSuccess) { (void)hipGetLastError(); dDst->release(); }
       }
-    }));
+    }).share());
+    if (staged.hs) { stagedBusy[turn] = inflight.back(); wb.turn ^= 1; }
   }
   if (dbg) fprintf(stderr, "[mm] index: hash + winnow of %zu contigs issued at %.2f s\n", nContigs, since());
   while (!inflight.empty()) { inflight.front().get(); inflight.pop_front(); }

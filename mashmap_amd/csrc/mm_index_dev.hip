@@ -234,19 +234,10 @@ k_ht_clear(size_t cap, HtSlot* __restrict__ ht) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i < cap) { ht[i].key = MM_EMPTY; ht[i].val = 0; }
 }
-// line layout: per 128-byte line the tag word (7 empty tags, byte 7 = 0xFF), a spare word, 7 empty slots
-__global__ void __launch_bounds__(256)
-k_ht_clear_lines(size_t nLines, uint64_t* __restrict__ lines) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;         // one thread per 16-byte unit
-  if (i >= nLines * 8) return;
-  const size_t unit = i & 7;
-  uint64_t* p = lines + (i >> 3) * MM_LINE_WORDS + unit * 2;
-  if (unit == 0) { p[0] = 0xFF00000000000000ull; p[1] = 0ull; } else { p[0] = MM_EMPTY; p[1] = 0ull; }
-}
 __global__ void __launch_bounds__(256)
 k_ht_insert(size_t nk, const uint64_t* __restrict__ keys, const uint64_t* __restrict__ keyOff, const uint8_t* __restrict__ freq, HtSlot* __restrict__ ht,
             uint64_t mask, unsigned long long* __restrict__ filter, uint64_t filterMask, uint8_t* __restrict__ tags /* non-null: bucketised placement + tag bytes */,
-            unsigned long long* __restrict__ diag /* [3] |= 1 value overflow, |= 2 duplicate key */, int lineMode) {
+            unsigned long long* __restrict__ diag /* [3] |= 1 value overflow, |= 2 duplicate key */) {
   const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (k >= nk) return;
   const uint64_t key = keys[k];
@@ -270,23 +261,6 @@ k_ht_insert(size_t nk, const uint64_t* __restrict__ keys, const uint64_t* __rest
         if (prev == key) { atomicOr(&diag[3], 2ull); return; }
       }
       b = (b + MM_TAG_BUCKET) & mask;
-    }
-  }
-  if (lineMode) {
-    // line buckets: 7 slots behind their 8 tag bytes in one 128-byte line; a key goes into the first line, from its home line on, that
-    // still has a free slot
-    uint64_t* lines = (uint64_t*)ht;
-    uint64_t b = key & mask;                                           // mask = lines - 1
-    const uint32_t start = (uint32_t)((key >> 40) % MM_LINE_SLOTS);
-    while (true) {
-      HtSlot* sl = (HtSlot*)(lines + b * MM_LINE_WORDS + 2);
-      for (uint32_t i = 0; i < MM_LINE_SLOTS; i++) {
-        const uint32_t j = (start + i) % MM_LINE_SLOTS;
-        const unsigned long long prev = atomicCAS((unsigned long long*)&sl[j].key, (unsigned long long)MM_EMPTY, (unsigned long long)key);
-        if (prev == MM_EMPTY) { sl[j].val = val; ((uint8_t*)(lines + b * MM_LINE_WORDS))[j] = (uint8_t)mm_seed_tag(key); return; }
-        if (prev == key) { atomicOr(&diag[3], 2ull); return; }
-      }
-      b = (b + 1) & mask;
     }
   }
   uint64_t slot = key & mask;
@@ -424,21 +398,14 @@ int mm_flatten_device_index(mm_ctx* c, const mm_minmer* dRec, size_t n, size_t n
   if (const char* e = getenv("MM_SEED_TAGS")) tagged = atoi(e) != 0;
   if (cap < 4 * MM_TAG_BUCKET) tagged = false;
   if (tagged) fbits = 0;
-  // MM_SEED_LAYOUT=line / bucket16: where the tags of a tagged table live -- inside 128-byte line buckets of 7 slots (a tag match is
-  // then a cache hit, not a second line from HBM) or in an array of their own in front of 16-slot buckets
-  int tagMode = tagged ? 2 : 0;
-  if (const char* e = getenv("MM_SEED_LAYOUT")) { if (tagged && !strcmp(e, "bucket16")) tagMode = 1; else if (tagged && !strcmp(e, "line")) tagMode = 2; }
-  size_t nLines = 0;
-  if (tagMode == 2) { nLines = 16; while (nLines * MM_LINE_SLOTS < 2 * nk + 2) nLines <<= 1; }   // load <= 0.5 as for the other layouts
-  MM_HIP(c, I.htSlots.ensure(tagMode == 2 ? nLines * 128 + 128 : cap * 16)); MM_HIP(c, I.filter.ensure((fbits ? fbits / 8 : 4) + 64));
-  MM_HIP(c, I.htTags.ensure(tagMode == 1 ? cap + 64 : 64));
-  if (tagMode == 2) K_LAUNCH(k_ht_clear_lines, nLines * 8, nLines, I.htSlots.as<uint64_t>());
-  else K_LAUNCH(k_ht_clear, cap, cap, I.htSlots.as<HtSlot>());
+  MM_HIP(c, I.htSlots.ensure(cap * 16)); MM_HIP(c, I.filter.ensure((fbits ? fbits / 8 : 4) + 64));
+  MM_HIP(c, I.htTags.ensure(tagged ? cap + 64 : 64));
+  K_LAUNCH(k_ht_clear, cap, cap, I.htSlots.as<HtSlot>());
   MM_HIP(c, hipMemsetAsync(I.filter.p, 0, (fbits ? fbits / 8 : 4), c->stream));
-  if (tagMode == 1) MM_HIP(c, hipMemsetAsync(I.htTags.p, 0, cap + 64, c->stream));
-  if (nk) K_LAUNCH(k_ht_insert, nk, nk, I.keys.as<uint64_t>(), I.keyOff.as<uint64_t>(), I.keyFreq.as<uint8_t>(), I.htSlots.as<HtSlot>(), (uint64_t)((tagMode == 2 ? nLines : cap) - 1),
-                   I.filter.as<unsigned long long>(), fbits ? fbits / 64 - 1 : 0ull, tagMode == 1 ? I.htTags.as<uint8_t>() : (uint8_t*)nullptr, diag, tagMode == 2 ? 1 : 0);
-  I.tagged = tagged; I.tagMode = tagMode; I.htLines = nLines;
+  if (tagged) MM_HIP(c, hipMemsetAsync(I.htTags.p, 0, cap + 64, c->stream));
+  if (nk) K_LAUNCH(k_ht_insert, nk, nk, I.keys.as<uint64_t>(), I.keyOff.as<uint64_t>(), I.keyFreq.as<uint8_t>(), I.htSlots.as<HtSlot>(), (uint64_t)(cap - 1),
+                   I.filter.as<unsigned long long>(), fbits ? fbits / 64 - 1 : 0ull, tagged ? I.htTags.as<uint8_t>() : (uint8_t*)nullptr, diag);
+  I.tagged = tagged;
   MM_HIP(c, hipGetLastError());
   std::vector<int32_t> grp(nContigs, 0);
   if (refGroup) grp.assign(refGroup, refGroup + nContigs);

@@ -42,7 +42,7 @@ struct DFrag {
 #define MM_OPEN_BLOCK_SHIFT 10
 
 struct DeviceIndex {
-  size_t nRec = 0, nKeys = 0, nPoints = 0, nContigs = 0, htCap = 0, htLines = 0, nOpen = 0;
+  size_t nRec = 0, nKeys = 0, nPoints = 0, nContigs = 0, htCap = 0, nOpen = 0;
   // minmerIndex as the L2 event stream (see mm_build_device_index): per contig, one insert event per record at wpos and one
   // eviction event at wpos_end, merged by position
   DevBuf evKey;                // uint32 pos*2 + isInsert
@@ -63,7 +63,6 @@ struct DeviceIndex {
   // a probe reads the 16 tags of the seed's home bucket -- one 16-byte load out of an array 1/16 the size of the table -- and touches
   // the 16-byte slot only where a tag matches (~86 % of query seeds are absent from the index: sequencing errors)
   DevBuf htTags; bool tagged = false;
-  int tagMode = 0;             // 0 plain table + filter, 1 16-slot buckets + tag array (htTags), 2 one 128-byte line per 7-slot bucket, tags inside (htLines lines in htSlots)
   DevBuf ptKeys;               // uint64[nPoints]: seqId<<33 | pos<<1 | (side==OPEN)
   DevBuf keys, keyOff, keyFreq; // the lookup map's key table in the order of ptKeys: uint64 key, uint64 first point (nKeys + 1), uint8 isFrequent
   bool ready = false;

@@ -295,46 +295,14 @@ __device__ __forceinline__ int mm_l1_fused(uint64_t (&k)[R], FuseScratch& sc, in
 // The table values of the sketch entries [base, base + 256) of a fragment, four per lane (entry base + u * 64 + lane): found[u] / val[u].
 // Four sub-rounds are in flight together: their hash loads, filter tests / tag loads and first table slots are independent, so one
 // memory round trip serves all of them instead of four.  Shared by k_lookup_l1 and k_gather_points.
-// TAGS 0: the plain table behind the presence filter, 1: 16-slot buckets fronted by a tag array, 2: one 128-byte line per bucket
-template <int TAGS>
+template <bool TAGS>
 __device__ __forceinline__ void mm_probe4(const SeedTable& T, const uint64_t* __restrict__ skHash, size_t fo, int cnt, int base, int lane,
                                           uint64_t (&h)[4], bool (&act)[4], bool (&found)[4], uint64_t (&val)[4]) {
   const HtSlot* __restrict__ ht = T.ht; const uint64_t htMask = T.mask;
   bool open[4];
 #pragma unroll
   for (int u = 0; u < 4; u++) { const int r = base + u * 64 + lane; act[u] = r < cnt; h[u] = act[u] ? skHash[fo + r] : 0ull; }
-  if constexpr (TAGS == 2) {
-    const uint64_t* __restrict__ lines = (const uint64_t*)ht;
-    uint64_t tg[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) { tg[u] = ~0ull; if (act[u]) tg[u] = lines[(h[u] & htMask) * MM_LINE_WORDS]; }
-    uint32_t cand[4]; bool emp[4]; HtSlot sl[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      mm_line_scan(tg[u], mm_seed_tag(h[u]), cand[u], emp[u]);
-      if (!act[u]) { cand[u] = 0; emp[u] = true; }
-      sl[u].key = MM_EMPTY; sl[u].val = 0;
-      if (cand[u]) sl[u] = ((const HtSlot*)(lines + (h[u] & htMask) * MM_LINE_WORDS + 2))[(uint32_t)__builtin_ctz(cand[u])];   // same line: a cache hit
-    }
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      found[u] = false; val[u] = 0;
-      uint64_t b = h[u] & htMask;
-      uint32_t cd = cand[u]; bool em = emp[u]; bool have = cd != 0;
-      while (cd || !em) {
-        while (cd) {
-          const uint32_t i = (uint32_t)__builtin_ctz(cd); cd &= cd - 1u;
-          const HtSlot x = have ? sl[u] : ((const HtSlot*)(lines + b * MM_LINE_WORDS + 2))[i];
-          have = false;
-          if (x.key == h[u]) { found[u] = true; val[u] = x.val; cd = 0; em = true; }
-        }
-        if (!em) {                                                   // a full line without the key: on to the next one
-          b = (b + 1) & htMask;
-          mm_line_scan(lines[b * MM_LINE_WORDS], mm_seed_tag(h[u]), cd, em);
-        }
-      }
-    }
-  } else if constexpr (TAGS == 0) {
+  if constexpr (!TAGS) {
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       open[u] = act[u];
@@ -393,7 +361,7 @@ __device__ __forceinline__ void mm_probe4(const SeedTable& T, const uint64_t* __
 #define MM_LOOKUP_WPB 4             // waves (= fragments) per workgroup
 #define MM_L1_REGIONS 64            // L1 output cursors: a same-address atomic costs ~10 ns, so fragments spread over 64 of them
 #define MM_L1_CURSOR_STRIDE 32      // u64 words between cursors (256 bytes)
-template <int MAXPTS, int TAGS>
+template <int MAXPTS, bool TAGS>
 __global__ void __launch_bounds__(MM_LOOKUP_WPB * 64, MAXPTS <= 128 ? 8 : MAXPTS <= 256 ? 6 : 5)
 k_lookup_l1(int nFrags, int s, const DFrag* __restrict__ frags,
             const uint64_t* __restrict__ skHash, const int8_t* __restrict__ skStrand, const uint32_t* __restrict__ skCount,
@@ -561,7 +529,7 @@ k_lookup_l1(int nFrags, int s, const DFrag* __restrict__ frags,
 // --noSplit, MM_OPT_KEEP_POINTS) -> the slots it reserved for them in HBM, one wave per queued fragment: the sketch is looked up again,
 // batch by batch, and every surviving seed's point run is copied (getSeedIntervalPoints, computeMap.hpp:857-912, with the seqId
 // filters of :891-896).  ids (windowed mode): the seed every point came from.
-template <int TAGS>
+template <bool TAGS>
 __global__ void __launch_bounds__(256)
 k_gather_points(int nList, const int32_t* __restrict__ list, int s, const DFrag* __restrict__ frags, const uint64_t* __restrict__ skHash, const uint32_t* __restrict__ skCount,
                 const SeedTable T, const uint64_t* __restrict__ ptKeys, const int32_t* __restrict__ refGroup, const int32_t* __restrict__ readGroup, const int32_t* __restrict__ readSelf,
@@ -1139,8 +1107,7 @@ static int map_pass(mm_ctx* c, const bool steady) {
   unsigned long long* cnt2 = c->dCounters.as<unsigned long long>() + 32; // [32..]: [0] candidate mappings [1] their buffer overflowed
   const unsigned long long* nBigDev = steady ? cnt + 7 : nullptr;
 
-  const SeedTable seedTab{I.htSlots.as<HtSlot>(), (uint64_t)((I.tagMode == 2 ? I.htLines : I.htCap) - 1), I.filter.as<uint64_t>(), (uint64_t)I.filterMask,
-                          I.tagMode == 1 ? I.htTags.as<uint8_t>() : (const uint8_t*)nullptr};
+  const SeedTable seedTab{I.htSlots.as<HtSlot>(), (uint64_t)(I.htCap - 1), I.filter.as<uint64_t>(), (uint64_t)I.filterMask, I.tagged ? I.htTags.as<uint8_t>() : (const uint8_t*)nullptr};
   unsigned long long hcur[MM_L1_REGIONS * MM_L1_CURSOR_STRIDE];
   unsigned long long regionCap = 0;
   for (int attempt = 0; attempt < 10; attempt++) {          // grow-and-retry on capacity overflow (points or L1 candidates)
@@ -1159,9 +1126,8 @@ static int map_pass(mm_ctx* c, const bool steady) {
       // larger ones (points come in proportion to the sketch: s = 310 averages ~176 per fragment with a long tail)
       int fuse = s > 256 ? 512 : s > 160 ? 256 : 128;
       if (const char* e = getenv("MM_FUSE_MAXPTS")) { const int v = atoi(e); fuse = v >= 512 ? 512 : v >= 256 ? 256 : 128; }
-      auto kern = I.tagMode == 2 ? (fuse == 512 ? k_lookup_l1<512, 2> : fuse == 256 ? k_lookup_l1<256, 2> : k_lookup_l1<128, 2>)
-                : I.tagMode == 1 ? (fuse == 512 ? k_lookup_l1<512, 1> : fuse == 256 ? k_lookup_l1<256, 1> : k_lookup_l1<128, 1>)
-                                 : (fuse == 512 ? k_lookup_l1<512, 0> : fuse == 256 ? k_lookup_l1<256, 0> : k_lookup_l1<128, 0>);
+      auto kern = I.tagged ? (fuse == 512 ? k_lookup_l1<512, true> : fuse == 256 ? k_lookup_l1<256, true> : k_lookup_l1<128, true>)
+                           : (fuse == 512 ? k_lookup_l1<512, false> : fuse == 256 ? k_lookup_l1<256, false> : k_lookup_l1<128, false>);
       hipLaunchKernelGGL(kern, dim3((nF + MM_LOOKUP_WPB - 1) / MM_LOOKUP_WPB), dim3(MM_LOOKUP_WPB * 64), 0, c->stream, nF, s, c->dFrags.as<DFrag>(),
                          c->dSkHash.as<uint64_t>(), c->dSkStrand.as<int8_t>(), c->dSkCount.as<uint32_t>(), seedTab, I.ptKeys.as<uint64_t>(),
                          c->dReadSelf.as<int32_t>(), c->seqCounterBase, fl, windowed ? 2 : (c->keepPoints ? 1 : 0),
@@ -1214,7 +1180,7 @@ static int map_pass(mm_ctx* c, const bool steady) {
       KernelTimer t(c, MM_K_SORT);
       uint16_t* sortIds = windowed ? c->dPtIds.as<uint16_t>() : (uint16_t*)nullptr;
       {
-        auto gk = I.tagMode == 2 ? k_gather_points<2> : I.tagMode == 1 ? k_gather_points<1> : k_gather_points<0>;
+        auto gk = I.tagged ? k_gather_points<true> : k_gather_points<false>;
         hipLaunchKernelGGL(gk, dim3(gWave), dim3(256), 0, c->stream, nBig, c->dBigList.as<int32_t>(), s, c->dFrags.as<DFrag>(), c->dSkHash.as<uint64_t>(),
                            c->dSkCount.as<uint32_t>(), seedTab, I.ptKeys.as<uint64_t>(), I.refGroup.as<int32_t>(),
                            c->dReadGroup.as<int32_t>(), c->dReadSelf.as<int32_t>(), c->seqCounterBase, fl, c->dStats.as<mm_frag_stats>(), c->dPtOff.as<int64_t>(),

@@ -336,7 +336,7 @@ int mm_scan_i32_to_i64(mm_ctx* c, int64_t n, const int32_t* dIn, int64_t* dOut, 
 
 int mm_winnow_contig_device(mm_ctx* c, WinnowBuffers& B, const uint64_t* dH, const int8_t* dS, int64_t nPos, int len,
                             std::vector<mm_minmer>& records, std::vector<int32_t>& tileCount, std::vector<WnOpenRun>& openRuns,
-                            std::vector<int32_t>& openCount) {
+                            std::vector<int32_t>& openCount, WnStaged* staged) {
   const int k = c->P.kmerSize, w = c->P.segLength, s = c->P.sketchSize;
   const int nW = len - w + 1;
   const int wk = w - k + 1;
@@ -409,6 +409,11 @@ int mm_winnow_contig_device(mm_ctx* c, WinnowBuffers& B, const uint64_t* dH, con
   MM_HIP(c, hipMemcpyAsync(tileCount.data(), B.outCount.p, (size_t)nTiles * 4, hipMemcpyDeviceToHost, c->stream));
   MM_HIP(c, hipMemcpyAsync(openCount.data(), B.openCount.p, (size_t)nTiles * 4, hipMemcpyDeviceToHost, c->stream));
   MM_HIP(c, hipStreamSynchronize(c->stream));
+  if (hs && staged && redo.empty()) {             // the common case: the caller's finishing thread copies the two arrays out
+    staged->hs = hs; staged->total = (size_t)total; staged->recPad = recPad; staged->nRuns = (size_t)nTiles * s;
+    records.clear(); openRuns.clear();
+    return MM_OK;
+  }
   if (hs) {
     const mm_minmer* r0 = (const mm_minmer*)hs; const WnOpenRun* o0 = (const WnOpenRun*)(hs + recPad);
     first.assign(r0, r0 + (size_t)total);

@@ -146,7 +146,7 @@ def _diff(a, b):
 def _tagged(stderr):
     m = re.search(r"index layout: seed table (\d+) slots \((\d+) MiB\), tagged=(\d)", stderr)
     assert m, "no index layout line in the MASHMAP_HIP_TIMING log:\n" + stderr[-1500:]
-    return int(m.group(3)) >= 1, int(m.group(2))                     # 1: tag array + 16-slot buckets, 2: 128-byte line buckets
+    return int(m.group(3)) >= 1, int(m.group(2))
 
 
 def case(human, name, min_lines, expect_tagged, sharded=False):

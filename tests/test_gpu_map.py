@@ -47,15 +47,11 @@ def test_map_against_the_device_built_index(oracle, flags, delim, kmerPct):
     assert nF > 200 and nl > 100
 
 
-@pytest.mark.parametrize("layout", ["line", "bucket16"])
 @pytest.mark.parametrize("case", ["default", "device_index_freq", "sketch310", "skip_self"])
-def test_map_with_the_tagged_seed_table(oracle, monkeypatch, case, layout):
-    """the seed table of a human-scale index forced onto small indexes, in both layouts -- `line`: buckets of 7 slots with their tag
-    bytes in one 128-byte line (k_lookup_l1<.., 2>, the default above 1 GiB; ~3 % of the buckets are full at this load and send a look-up
-    on to the next line); `bucket16`: 16 slots behind one tag byte per slot in an array of its own (k_lookup_l1<.., 1>) -- same integers
-    as the oracle at every stage"""
+def test_map_with_the_tagged_seed_table(oracle, monkeypatch, case):
+    """the seed table of a human-scale index (buckets of 16 slots behind one tag byte per slot, k_lookup_l1<.., true>) forced onto small
+    indexes: same integers as the oracle at every stage; ~0.4 % of the buckets overflow into the next one at this load"""
     monkeypatch.setenv("MM_SEED_TAGS", "1")
-    monkeypatch.setenv("MM_SEED_LAYOUT", layout)
     contigs = genome(211, [400000, 300000, 200000])
     reads = reads_for(contigs, 25, 100, 10000, 0.10) + [("unrelated", U.random_dna(12, 15000)), ("short", U.random_dna(9, 700))]
     if case == "default":
