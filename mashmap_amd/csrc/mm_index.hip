@@ -291,8 +291,11 @@ extern "C" int mm_index_build(mm_ctx* c, const char* bases, const int64_t* conti
     while (inflight.size() >= maxJobs) { inflight.front().get(); inflight.pop_front(); }
     std::vector<mm_minmer>* dst = &per[ci];
     DevBuf* dDst = earlyUpload ? &dPer[ci] : nullptr;
-    inflight.push_back(std::async(std::launch::async, [rec, tc, runs, oc, w, s, ci, dst, dDst, device, staged]() {
+    auto copiedOut = std::make_shared<std::promise<void>>();
+    std::shared_future<void> copiedOutF = copiedOut->get_future().share();
+    inflight.push_back(std::async(std::launch::async, [rec, tc, runs, oc, w, s, ci, dst, dDst, device, staged, copiedOut]() {
       staged.take(*rec, *runs);                                     // out of the page-locked landing buffer, off the device's critical path
+      copiedOut->set_value();                                       // the buffer may take the contig after next from here on
       finish_contig(*rec, *tc, *runs, *oc, s, w, (int)ci);
       dst->swap(*rec);
       if (dDst && !dst->empty() && hipSetDevice(device) == hipSuccess) {
@@ -302,7 +305,7 @@ extern "C" int mm_index_build(mm_ctx* c, const char* bases, const int64_t* conti
             hipStreamSynchronize(hipStreamPerThread) != hipSuccess) { (void)hipGetLastError(); dDst->release(); }
       }
     }).share());
-    if (staged.hs) { stagedBusy[turn] = inflight.back(); wb.turn ^= 1; }
+    if (staged.hs) { stagedBusy[turn] = copiedOutF; wb.turn ^= 1; }
   }
   if (dbg) fprintf(stderr, "[mm] index: hash + winnow of %zu contigs issued at %.2f s\n", nContigs, since());
   while (!inflight.empty()) { inflight.front().get(); inflight.pop_front(); }

@@ -126,7 +126,7 @@ struct mm_ctx {
   DevBuf dL2Sort[4], dL2Order, dL2OrderPos;                          // candidates of a chunk in order of descending stream length (mm_order_desc)
   bool sketched = false, mapped = false;
   // steady state: the previous pass of this context went through and left every buffer sized (mm_launch_map); what it saw
-  bool steadyOk = false, lastSteady = false; size_t prevBig = 0, candCap = 0; int prevLocap = 0;
+  bool steadyOk = false, lastSteady = false; size_t prevBig = 0, candCap = 0, l2Chunks = 1; int prevLocap = 0, steadyFails = 0;
   unsigned long long* hPass = nullptr;                  // page-locked: the counters of a pass as read back at its end
   size_t lastOps = 0, lastBig = 0;                      // L2 stream entries reserved / fragments queued for the HBM point path in the last pass
   size_t nSyncs = 0;                                    // host synchronisations inside the last mm_map_fragments (diagnostics: mm_pass_syncs)

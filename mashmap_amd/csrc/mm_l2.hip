@@ -990,7 +990,10 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt, bool steady) {
       if (getenv("MM_DEBUG")) fprintf(stderr, "[mm] L2: %lld stream entries of %d candidates in %zu chunks of at most %lld\n", (long long)totalOps, nC, chunks.size(), (long long)maxChunkOps);
     }
   }
-  if (!steady) MM_HIP(c, c->dL2Ops.ensure((size_t)(maxChunkOps + maxChunkOps / 16) * 4 + 256));   // a sixteenth of head room for the steady-state passes behind this one
+  if (!steady) {
+    MM_HIP(c, c->dL2Ops.ensure((size_t)(maxChunkOps + maxChunkOps / 16) * 4 + 256));   // a sixteenth of head room for the steady-state passes behind this one
+    c->l2Chunks = chunks.size();                                                          // a batch that needs several chunks stays with the sized passes
+  }
   if (steady && c->dL2Ops.bytes == 0) return MM_PASS_REDO;
   // buckets of the query-sketch search: at least one per sketch entry (more buckets cost more to fill per candidate than the shorter
   // walks save: profiles/r02z_locate_buckets.txt)

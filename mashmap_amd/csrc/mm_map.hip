@@ -1291,14 +1291,14 @@ int mm_launch_map(mm_ctx* c) {
   if (nF == 0) return MM_OK;
   const bool allSlow = c->keepPoints || (c->P.flags & MM_FLAG_SKIP_PREFIX) || c->windowed;
   static const bool noSteady = getenv("MM_NO_STEADY") != nullptr;
-  if (c->steadyOk && !allSlow && !noSteady && !getenv("MM_DEBUG")) {
+  if (c->steadyOk && c->steadyFails < 3 && !allSlow && !noSteady && !getenv("MM_DEBUG")) {
     const int rc = map_pass(c, true);
-    if (rc == MM_OK) { c->lastSteady = true; return MM_OK; }
+    if (rc == MM_OK) { c->lastSteady = true; c->steadyFails = 0; return MM_OK; }
     if (rc != MM_PASS_REDO) return rc;
-    c->steadyOk = false;
+    c->steadyOk = false; c->steadyFails++;                        // three redone passes in a row: this context's batches keep outgrowing what the one before left
   }
   const int rc = map_pass(c, false);
-  c->steadyOk = rc == MM_OK && !allSlow && c->nL1 > 0;
+  c->steadyOk = rc == MM_OK && !allSlow && c->nL1 > 0 && c->l2Chunks == 1;   // (a batch whose L2 streams go through in chunks needs the host between them)
   return rc;
 }
 
