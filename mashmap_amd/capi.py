@@ -249,7 +249,13 @@ class Context:
         """contigs: list of uint8 arrays (ASCII)"""
         offs = np.zeros(len(contigs) + 1, dtype=np.int64)
         offs[1:] = np.cumsum([len(c) for c in contigs])
-        buf = np.concatenate(contigs) if len(contigs) else np.zeros(0, dtype=np.uint8)
+        # contigs that are consecutive views of one array (bench.py lays its reference out that way) are passed as they lie
+        ptr = [c.ctypes.data for c in contigs]
+        if len(contigs) and all(c.dtype == np.uint8 and c.flags["C_CONTIGUOUS"] for c in contigs) and all(ptr[i] + len(contigs[i]) == ptr[i + 1] for i in range(len(contigs) - 1)):
+            buf = np.ctypeslib.as_array(C.cast(ptr[0], C.POINTER(C.c_uint8)), shape=(int(offs[-1]),)) if offs[-1] else np.zeros(0, dtype=np.uint8)
+            self._keep = contigs                       # (the views own the memory for the duration of the call)
+        else:
+            buf = np.concatenate(contigs) if len(contigs) else np.zeros(0, dtype=np.uint8)
         rg = np.ascontiguousarray(refGroup, dtype=np.int32) if refGroup is not None else None
         self._ck(self.lib.mm_index_build(self.h, _ptr(buf), _ptr(offs), len(contigs), _ptr(rg), kmerPct), "mm_index_build")
 

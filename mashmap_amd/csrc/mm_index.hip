@@ -200,19 +200,13 @@ static HashContigFn pick_hasher(int k) {
 // ---------------------------------------------------------------------------------------------
 // mm_index_build: Sketch::index, the frequency filter and the flat index on the device (mm_index_dev.hip), from the contigs' record
 // arrays as they are; the host copies behind mm_index_download are filled from the device on request
-static int finalize_built_index(mm_ctx* c, std::vector<std::vector<mm_minmer>>& per, const std::vector<DevBuf>& dPer, float kmerPctThreshold, const int32_t* contigLen,
+static int finalize_built_index(mm_ctx* c, std::vector<std::vector<mm_minmer>>& per, float kmerPctThreshold, const int32_t* contigLen,
                                 const int32_t* refGroup, size_t nContigs) {
   c->hKeys.clear(); c->hOffsets.clear(); c->hPoints.clear(); c->hFreq.clear(); c->hMinmers.clear();
   c->mirrorMinmers = c->mirrorMap = false;
-  // a contig's records are on the device already when its host tail uploaded them (dPer[i]); otherwise they go up from the host array
   std::vector<std::pair<const mm_minmer*, size_t>> parts;
-  std::vector<bool> onDevice;
-  for (size_t i = 0; i < per.size(); i++) {
-    const bool dev = i < dPer.size() && dPer[i].p != nullptr;
-    parts.emplace_back(dev ? dPer[i].as<mm_minmer>() : per[i].data(), per[i].size());
-    onDevice.push_back(dev);
-  }
-  const int rc = mm_finalize_index_device(c, parts, kmerPctThreshold, contigLen, refGroup, nContigs, &onDevice);
+  for (const auto& v : per) parts.emplace_back(v.data(), v.size());
+  const int rc = mm_finalize_index_device(c, parts, kmerPctThreshold, contigLen, refGroup, nContigs);
   std::vector<mm_minmer>().swap(c->hMinmersAll);
   if (c->keepFullIndex) for (const auto& v : per) c->hMinmersAll.insert(c->hMinmersAll.end(), v.begin(), v.end());   // --saveIndex wants minmerIndex before the drop
   return rc;
@@ -262,12 +256,6 @@ extern "C" int mm_index_build(mm_ctx* c, const char* bases, const int64_t* conti
   auto since = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - tStart).count(); };
   std::vector<int32_t> clen(nContigs);
   std::vector<std::vector<mm_minmer>> per(nContigs);
-  // the finished records of a contig go back up from the thread that finished them, under the device work of the contigs behind it
-  // (own stream per thread; a failed allocation or copy just leaves the part to the upload at the end): at human scale the 8.7 GB of
-  // records otherwise travel from pageable memory after the last contig, 0.7 - 3.3 s of a 7 - 10 s build
-  std::vector<DevBuf> dPer(nContigs);
-  const bool earlyUpload = getenv("MM_INDEX_NO_EARLY_UPLOAD") == nullptr;
-  const int device = c->device;
   std::deque<std::shared_future<void>> inflight;
   std::shared_future<void> stagedBusy[2];               // the finishing job that still reads the page-locked landing buffer of that turn
   DevBuf dAscii, dB, dM, dMeta, dH, dS;
@@ -290,20 +278,13 @@ extern "C" int mm_index_build(mm_ctx* c, const char* bases, const int64_t* conti
     if (rc != MM_OK) break;
     while (inflight.size() >= maxJobs) { inflight.front().get(); inflight.pop_front(); }
     std::vector<mm_minmer>* dst = &per[ci];
-    DevBuf* dDst = earlyUpload ? &dPer[ci] : nullptr;
     auto copiedOut = std::make_shared<std::promise<void>>();
     std::shared_future<void> copiedOutF = copiedOut->get_future().share();
-    inflight.push_back(std::async(std::launch::async, [rec, tc, runs, oc, w, s, ci, dst, dDst, device, staged, copiedOut]() {
+    inflight.push_back(std::async(std::launch::async, [rec, tc, runs, oc, w, s, ci, dst, staged, copiedOut]() {
       staged.take(*rec, *runs);                                     // out of the page-locked landing buffer, off the device's critical path
       copiedOut->set_value();                                       // the buffer may take the contig after next from here on
       finish_contig(*rec, *tc, *runs, *oc, s, w, (int)ci);
       dst->swap(*rec);
-      if (dDst && !dst->empty() && hipSetDevice(device) == hipSuccess) {
-        const size_t bytes = dst->size() * sizeof(mm_minmer);
-        if (dDst->ensure(bytes + 64) != hipSuccess ||
-            hipMemcpyAsync(dDst->p, dst->data(), bytes, hipMemcpyHostToDevice, hipStreamPerThread) != hipSuccess ||
-            hipStreamSynchronize(hipStreamPerThread) != hipSuccess) { (void)hipGetLastError(); dDst->release(); }
-      }
     }).share());
     if (staged.hs) { stagedBusy[turn] = copiedOutF; wb.turn ^= 1; }
   }
@@ -311,12 +292,11 @@ extern "C" int mm_index_build(mm_ctx* c, const char* bases, const int64_t* conti
   while (!inflight.empty()) { inflight.front().get(); inflight.pop_front(); }
   if (dbg) fprintf(stderr, "[mm] index: host tails (stitch, sort, unique) done at %.2f s\n", since());
   dAscii.release(); dB.release(); dM.release(); dMeta.release(); dH.release(); dS.release(); wb.release();
-  if (rc != MM_OK) { for (DevBuf& b : dPer) b.release(); return rc; }
+  if (rc != MM_OK) return rc;
 
   size_t nRecords = 0; for (const auto& v : per) nRecords += v.size();
   if (dbg) fprintf(stderr, "[mm] index: %zu records in %zu per-contig arrays at %.2f s\n", nRecords, nContigs, since());
-  const int frc = finalize_built_index(c, per, dPer, kmerPctThreshold, clen.data(), refGroup, nContigs);
-  for (DevBuf& b : dPer) b.release();
+  const int frc = finalize_built_index(c, per, kmerPctThreshold, clen.data(), refGroup, nContigs);
   if (dbg) fprintf(stderr, "[mm] index: Sketch::index + frequency filter + flat index on the device done at %.2f s (%zu keys, %zu points)\n", since(), c->idx.nKeys, c->idx.nPoints);
   return frc;
 }

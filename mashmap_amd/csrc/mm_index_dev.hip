@@ -424,7 +424,7 @@ int mm_flatten_device_index(mm_ctx* c, const mm_minmer* dRec, size_t n, size_t n
 // Sketch::index + the frequency filter on the device, from minmerIndex BEFORE the drop (host array, reference layout), then the flat
 // device index.  Leaves nothing on the host but the frequent-seed list (small) and, with MM_OPT_KEEP_FULL_INDEX, the caller's records.
 int mm_finalize_index_device(mm_ctx* c, const std::vector<std::pair<const mm_minmer*, size_t>>& parts, float kmerPctThreshold, const int32_t* contigLen,
-                             const int32_t* refGroup, size_t nContigs, const std::vector<bool>* partOnDevice) {
+                             const int32_t* refGroup, size_t nContigs) {
   DeviceIndex& I = c->idx;
   I.ready = false;
   size_t nAll = 0;
@@ -440,8 +440,7 @@ int mm_finalize_index_device(mm_ctx* c, const std::vector<std::pair<const mm_min
   {
     size_t at = 0;                                     // the contigs' records go up one after the other: no concatenated host copy
     for (const auto& p : parts) {
-      const bool dev = partOnDevice && (*partOnDevice)[(size_t)(&p - parts.data())];
-      if (p.second) MM_HIP(c, hipMemcpyAsync(dAll.as<mm_minmer>() + at, p.first, p.second * sizeof(mm_minmer), dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+      if (p.second) MM_HIP(c, hipMemcpyAsync(dAll.as<mm_minmer>() + at, p.first, p.second * sizeof(mm_minmer), hipMemcpyHostToDevice, c->stream));
       at += p.second;
     }
   }

@@ -197,7 +197,7 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt, bool steady = false);   // 
 int mm_build_device_index(mm_ctx* c, const int32_t* contigLen, const int32_t* refGroup, size_t nContigs);   // from the host mirrors
 int mm_flatten_device_index(mm_ctx* c, const mm_minmer* dRec, size_t n, size_t nk, size_t np, const int32_t* contigLen, const int32_t* refGroup, size_t nContigs);
 int mm_finalize_index_device(mm_ctx* c, const std::vector<std::pair<const mm_minmer*, size_t>>& parts, float kmerPctThreshold, const int32_t* contigLen,
-                             const int32_t* refGroup, size_t nContigs, const std::vector<bool>* partOnDevice = nullptr);   // partOnDevice[i]: parts[i].first is a device pointer
+                             const int32_t* refGroup, size_t nContigs);
 int mm_mirror_minmers(mm_ctx* c);
 int mm_mirror_map(mm_ctx* c);
 int mm_scan_i32_to_i64(mm_ctx* c, int64_t n, const int32_t* dIn, int64_t* dOut, int64_t* total);
