@@ -511,6 +511,8 @@ def main():
     ap.add_argument("--ref-contigs", type=int, default=0, help="contigs of the synthetic reference (default: the workload's)")
     ap.add_argument("--ref-contig-len", type=int, default=0)
     ap.add_argument("--kmer", type=int, default=0, help="k-mer size (default: the reference's 19; other sizes are not the BASELINE configuration)")
+    ap.add_argument("--seg", type=int, default=0, help="segLength (default: the workload's; `--workload northstar --seg 10000` is the north_star sentence's 10 kbp segments, "
+                                                       "sketchSize unchanged, as north_star_target.segLength_10000 measures it)")
     ap.add_argument("--cpu-sample", type=int, default=30000)
     ap.add_argument("--sync-exchange", action="store_true", help="N>1: all-gatherv on the compute stream instead of overlapped with the next batch")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)
@@ -546,7 +548,11 @@ def main():
     if args.ref_contigs: W["ref_contigs"] = args.ref_contigs; scaled.append("ref-contigs")
     if args.ref_contig_len: W["ref_contig_len"] = args.ref_contig_len; scaled.append("ref-contig-len")
     if args.kmer: W["k"] = args.kmer; scaled.append("kmer")
-    is_default = args.workload == "configs1" and not scaled
+    wl_key = args.workload
+    if args.seg and args.seg != W["seg"]:
+        W["seg"] = args.seg; W["label"] += ", segLength %d" % args.seg
+        wl_key = "%s_seg%d" % (args.workload, args.seg)
+    is_default = args.workload == "configs1" and not scaled and wl_key == args.workload
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -665,7 +671,7 @@ def main():
         value = bases_step * args.steps / dt / 1e9
         step_ms = dt / args.steps * 1e3
         P = float(stats["nPoints"].mean())
-        roofline = roofline_block(ctx, capi, W, args.workload, nF, prof, step_ms, not scaled, P)
+        roofline = roofline_block(ctx, capi, W, wl_key, nF, prof, step_ms, not scaled, P)
         kernels = {k: {"ms_per_step": v[0] / args.steps, "launches_per_step": v[1] / args.steps} for k, v in prof.items() if v[1]}
         ref_mbp = sum(ref_lens) / 1e6
         out = {
