@@ -45,10 +45,11 @@ enum {
 };
 
 typedef struct {
-  int32_t kmerSize;       /* Parameters::kmerSize   (1..32) */
+  int32_t kmerSize;       /* Parameters::kmerSize   (1..64; 16..32 take the tuned strip hasher, 19 -- the reference's default -- the tuned tail as well) */
   int32_t segLength;      /* Parameters::segLength  */
-  int32_t sketchSize;     /* Parameters::sketchSize (1 .. ~5000 at segLength <= 50 kbp: the exact sketch kernel's key table and the L2 kernels'
-                             per-wave state must fit one CU's 160 KB of LDS; mm_create checks and says what does not fit) */
+  int32_t sketchSize;     /* Parameters::sketchSize (1 .. 20000.  Up to 8190 the sketch and L2 kernels keep their state in a CU's 160 KB of LDS -- mm_create
+                             checks the combination with segLength and says what does not fit --; beyond, every fragment takes a global-memory sketch
+                             kernel and the literal L2 kernels: exact, not fast) */
   int32_t flags;          /* MM_FLAG_* */
 } mm_params;
 

@@ -31,8 +31,8 @@ const char* mm_last_error(const mm_ctx* ctx) { return ctx ? ctx->err.c_str() : g
 int mm_create(mm_ctx** out, int device, const mm_params* p) {
   if (!out || !p) { g_createErr = "mm_create: null argument"; return MM_ERR_ARG; }
   *out = nullptr;
-  if (p->kmerSize < 1 || p->kmerSize > 32 || p->sketchSize < 1 || p->segLength < p->kmerSize) {
-    g_createErr = "mm_create: unsupported parameters (need 1 <= kmerSize <= 32, sketchSize >= 1, segLength >= kmerSize)";
+  if (p->kmerSize < 1 || p->kmerSize > 64 || p->sketchSize < 1 || p->segLength < p->kmerSize) {
+    g_createErr = "mm_create: unsupported parameters (need 1 <= kmerSize <= 64, sketchSize >= 1, segLength >= kmerSize)";
     return MM_ERR_ARG;
   }
   if (mm_check_params(p, g_createErr) != MM_OK) return MM_ERR_ARG;

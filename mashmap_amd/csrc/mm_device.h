@@ -58,7 +58,7 @@ __device__ __forceinline__ uint64_t mm_bytes(const uint32_t* A, int off) {
   return ((uint64_t)hi << 32) | lo;
 }
 
-// MurmurHash3_x64_128(key = K ASCII bytes at byte offset off of A, seed 42), low 64 bits.  1 <= K <= 32.
+// MurmurHash3_x64_128(key = K ASCII bytes at byte offset off of A, seed 42), low 64 bits.  Any K >= 1 (A must hold the bytes + one word of run-off).
 template <int K>
 __device__ __forceinline__ uint64_t mm_murmur_kmer(const uint32_t* A, int off) {
   uint64_t h1 = MM_SEED, h2 = MM_SEED;
@@ -259,6 +259,37 @@ __device__ __forceinline__ void mm_strip_hashes(uint32_t w0, uint32_t w1, uint32
 #pragma unroll
     for (int j = 0; j < 16; j++) use(j, mm_murmur_kmer<K>(st.F, j), mm_murmur_kmer<K>(st.R, 48 - K - j));
   }
+}
+
+// k-mers of 33..64 bases (the reference hashes any length, commonFunc.hpp:138): the 16 positions of a strip need 16 + K - 1 <= 79 bases,
+// i.e. NW = 4 packed words for K <= 48, 5 beyond; the two ASCII streams of the window are expanded as in MMStrip and every position is
+// hashed by the plain block-by-block MurmurHash3 (mm_murmur_kmer<K>: two to four 16-byte blocks + tail).  Not tuned: these sizes are
+// off the reference's beaten path (k = 19), the point is that they run and are bit-exact.
+template <int K> struct MMWideK { static constexpr bool value = (K > 32); static constexpr int NW = K <= 48 ? 4 : 5; };
+template <int K, class Use>
+__device__ __forceinline__ void mm_strip_hashes_wide(const uint32_t (&w)[MMWideK<K>::NW], const MMTables& T, Use&& use) {
+  constexpr int NW = MMWideK<K>::NW, NQ = 4 * NW, W = 16 * NW;
+  uint32_t F[NQ + 1], R[NQ + 1];
+#pragma unroll
+  for (int q = 0; q < NQ; q++) {
+    const uint2 e = T.ascii4[(w[q >> 2] >> (8 * (q & 3))) & 0xFFu];
+    F[q] = e.x; R[NQ - 1 - q] = e.y;
+  }
+  F[NQ] = 0; R[NQ] = 0;
+#pragma unroll
+  for (int j = 0; j < 16; j++) use(j, mm_murmur_kmer<K>(F, j), mm_murmur_kmer<K>(R, W - K - j));
+}
+// bit j (j = 0..15) of the result: any of the mask bits j .. j+K-1 of the 128-bit value hi:lo is set (the N test of a wide strip)
+template <int K>
+__device__ __forceinline__ uint32_t mm_window_or_wide(uint64_t lo, uint64_t hi) {
+  const uint64_t km = K >= 64 ? ~0ull : ((1ull << (K & 63)) - 1ull);
+  uint32_t r = 0;
+#pragma unroll
+  for (int j = 0; j < 16; j++) {
+    const uint64_t v = j ? ((lo >> j) | (hi << (64 - j))) : lo;
+    r |= ((v & km) != 0ull ? 1u : 0u) << j;
+  }
+  return r;
 }
 
 __device__ __forceinline__ void MMStrip::load(uint32_t w0, uint32_t w1, uint32_t w2, const MMTables& T) {

@@ -38,20 +38,31 @@ k_ref_hash(const uint32_t* __restrict__ bases2, const uint32_t* __restrict__ nma
   mm_tables_init<K>(tabs, threadIdx.x, blockDim.x);
   __syncthreads();
   const int64_t nStrips = (nPos + 15) >> 4;
-  const uint64_t kmask = (1ull << K) - 1ull;
+  const uint64_t kmask = K >= 64 ? ~0ull : (1ull << (K & 63)) - 1ull;
   for (int64_t strip = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; strip < nStrips; strip += (int64_t)gridDim.x * blockDim.x) {
-    uint64_t nm = 0;
+    uint64_t nm = 0; uint32_t bad = 0;                              // bad (k-mers of more than 32 bases): bit j = position j's k-mer holds an N
     if (hasN) {
       const uint64_t m64 = (uint64_t)nmask[strip >> 1] | ((uint64_t)nmask[(strip >> 1) + 1] << 32);
       nm = m64 >> ((strip & 1) * 16);
+      if constexpr (MMWideK<K>::value) {
+        const uint64_t h64 = (uint64_t)nmask[(strip >> 1) + 2] | ((uint64_t)nmask[(strip >> 1) + 3] << 32);
+        const int sh = (int)(strip & 1) * 16;
+        bad = mm_window_or_wide<K>(sh ? ((m64 >> sh) | (h64 << (64 - sh))) : m64, sh ? (h64 >> sh) : h64);
+      }
     }
     uint64_t hs[16]; uint32_t sbits = 0;
-    mm_strip_hashes<K>(bases2[strip], bases2[strip + 1], bases2[strip + 2], tabs, [&](int j, uint64_t hf, uint64_t hr) {
+    auto onPos = [&](int j, uint64_t hf, uint64_t hr) {
       bool ok = hf != hr;
-      if (hasN) ok = ok & (((nm >> j) & kmask) == 0);
+      if (hasN) ok = ok & (MMWideK<K>::value ? ((bad >> j) & 1u) == 0u : ((nm >> j) & kmask) == 0);
       hs[j] = ok ? (hf < hr ? hf : hr) : MM_HASH_MAX;
       sbits |= (hf < hr ? 1u : 0u) << j;
-    });
+    };
+    if constexpr (MMWideK<K>::value) {
+      uint32_t ww[MMWideK<K>::NW];
+#pragma unroll
+      for (int i = 0; i < MMWideK<K>::NW; i++) ww[i] = bases2[strip + i];
+      mm_strip_hashes_wide<K>(ww, tabs, onPos);
+    } else mm_strip_hashes<K>(bases2[strip], bases2[strip + 1], bases2[strip + 2], tabs, onPos);
     const int64_t p0 = strip * 16;
 #pragma unroll
     for (int j = 0; j < 16; j++)
@@ -188,6 +199,8 @@ static HashContigFn pick_hasher(int k) {
   switch (k) {
 #define MM_CASE(KK) case KK: return &hash_contig<KK>;
     MM_CASE(1) MM_CASE(2) MM_CASE(3) MM_CASE(4) MM_CASE(5) MM_CASE(6) MM_CASE(7) MM_CASE(8) MM_CASE(9) MM_CASE(10) MM_CASE(11) MM_CASE(12) MM_CASE(13) MM_CASE(14) MM_CASE(15) MM_CASE(16) MM_CASE(17) MM_CASE(18) MM_CASE(19) MM_CASE(20) MM_CASE(21) MM_CASE(22) MM_CASE(23) MM_CASE(24) MM_CASE(25) MM_CASE(26) MM_CASE(27) MM_CASE(28) MM_CASE(29) MM_CASE(30) MM_CASE(31) MM_CASE(32)
+    MM_CASE(33) MM_CASE(34) MM_CASE(35) MM_CASE(36) MM_CASE(37) MM_CASE(38) MM_CASE(39) MM_CASE(40) MM_CASE(41) MM_CASE(42) MM_CASE(43) MM_CASE(44) MM_CASE(45) MM_CASE(46) MM_CASE(47) MM_CASE(48)
+    MM_CASE(49) MM_CASE(50) MM_CASE(51) MM_CASE(52) MM_CASE(53) MM_CASE(54) MM_CASE(55) MM_CASE(56) MM_CASE(57) MM_CASE(58) MM_CASE(59) MM_CASE(60) MM_CASE(61) MM_CASE(62) MM_CASE(63) MM_CASE(64)
 #undef MM_CASE
     default: return nullptr;
   }

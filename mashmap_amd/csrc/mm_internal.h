@@ -186,6 +186,9 @@ int mm_launch_pack(mm_ctx* c);
 int mm_launch_pack_raw(mm_ctx* c, const uint8_t* dAscii, const int64_t* dSrcOff, const int64_t* dPackOff, const int32_t* dLen, int nReads,
                        int64_t nChunks, uint32_t* dB, uint32_t* dM, uint32_t* dHasN);
 int mm_launch_sketch(mm_ctx* c);
+int mm_launch_sketch_global(mm_ctx* c);   // mm_sketch_global.hip: sketches no LDS table holds (sketchSize > MM_LDS_MAX_SKETCH)
+#define MM_LDS_MAX_SKETCH 8190             // beyond: the global-memory sketch kernel and the literal L2 kernels (any size up to MM_MAX_SKETCH)
+#define MM_MAX_SKETCH 20000                // the (sketchSize + 1)^2 acceptance tables of doL2Mapping's walk: 1.2 GB at this size
 int mm_launch_map(mm_ctx* c);
 // Steady state: once a pass of a context has sized every staging buffer, the next passes launch everything against
 // those capacities with the counts left on the device and read ONE block of counters back at the end (one host synchronisation per

@@ -926,7 +926,7 @@ int mm_scan_i32_to_i64(mm_ctx* c, int64_t n, const int32_t* dIn, int64_t* dOut, 
 #define MM_EXACT_CAP 1024
 
 int mm_launch_l2(mm_ctx* c, unsigned long long* cnt, bool steady) {
-  if (c->windowed) return mm_launch_l2_window(c, cnt);               // fragments longer than segLength (--noSplit): the literal kernel
+  if (c->windowed || c->P.sketchSize > MM_LDS_MAX_SKETCH) return mm_launch_l2_window(c, cnt);   // fragments longer than segLength (--noSplit), or a sketch no LDS state holds: the literal kernel
   const DeviceIndex& I = c->idx;
   const int s = c->P.sketchSize;
   // sized pass: the candidates are counted (c->nL1) and the candidate-indexed buffers get an eighth of head room, which is what a

@@ -1289,7 +1289,7 @@ int mm_launch_map(mm_ctx* c) {
   if (!c->hPass) { MM_HIP(c, hipHostMalloc((void**)&c->hPass, 256, hipHostMallocDefault)); }
   c->nL1 = c->nL2 = 0; c->nMappings = 0; c->nSyncs = 0; c->lastSteady = false;
   if (nF == 0) return MM_OK;
-  const bool allSlow = c->keepPoints || (c->P.flags & MM_FLAG_SKIP_PREFIX) || c->windowed;
+  const bool allSlow = c->keepPoints || (c->P.flags & MM_FLAG_SKIP_PREFIX) || c->windowed || c->P.sketchSize > MM_LDS_MAX_SKETCH;
   static const bool noSteady = getenv("MM_NO_STEADY") != nullptr;
   if (c->steadyOk && c->steadyFails < 3 && !allSlow && !noSteady && !getenv("MM_DEBUG")) {
     const int rc = map_pass(c, true);

@@ -217,15 +217,25 @@ mm_sketch_hard(unsigned char* smem, const int f, const uint4* __restrict__ gTabs
       uint32_t ok = rem >= 16 ? 0xFFFFu : ((1u << rem) - 1u);
       if (hasN) {
         const uint64_t m64 = (uint64_t)maskAt(strip >> 1) | ((uint64_t)maskAt((strip >> 1) + 1) << 32);
-        ok &= ~(uint32_t)mm_window_or<K>(m64 >> ((strip & 1) * 16));
+        if constexpr (MMWideK<K>::value) {
+          const uint64_t h64 = (uint64_t)maskAt((strip >> 1) + 2) | ((uint64_t)maskAt((strip >> 1) + 3) << 32);
+          const int sh = (strip & 1) * 16;
+          ok &= ~mm_window_or_wide<K>(sh ? ((m64 >> sh) | (h64 << (64 - sh))) : m64, sh ? (h64 >> sh) : h64);
+        } else ok &= ~(uint32_t)mm_window_or<K>(m64 >> ((strip & 1) * 16));
       }
-      mm_strip_hashes<K>(wordAt(strip), wordAt(strip + 1), wordAt(strip + 2), *tabs, [&](int j, uint64_t hf, uint64_t hr) {
+      auto onPos = [&](int j, uint64_t hf, uint64_t hr) {
         const int pos = strip * 16 + j;
         const uint64_t h = hf < hr ? hf : hr;
         bool pass = false;                          // nested ifs: the compiler keeps the three tests as exec masks
         if ((ok & (1u << j)) != 0) { if (hf != hr) { if (allPass || h < T) pass = true; } }
         if (pass) tab.insert(h, pos, hf < hr ? 1 : -1);
-      });
+      };
+      if constexpr (MMWideK<K>::value) {
+        uint32_t ww[MMWideK<K>::NW];
+#pragma unroll
+        for (int i = 0; i < MMWideK<K>::NW; i++) ww[i] = wordAt(strip + i);
+        mm_strip_hashes_wide<K>(ww, *tabs, onPos);
+      } else mm_strip_hashes<K>(wordAt(strip), wordAt(strip + 1), wordAt(strip + 2), *tabs, onPos);
     }
     if constexpr (SPILL) __threadfence();                 // the atomics on the spilled arrays, before the ranking threads read them
     __syncthreads();
@@ -441,21 +451,22 @@ mm_sketch_fast(unsigned char* smem, const int f, const uint4* __restrict__ gTabs
   for (int strip = tid; strip < nStrips; strip += nthr) {
     const int b0 = strip * SL;                      // first base of the strip: the 48-base window is cut out of four LDS words
     const int wi = b0 >> 4, bsh = (b0 & 15) * 2;
-    uint32_t w0 = sW[wi], w1 = sW[wi + 1], w2 = sW[wi + 2];
-    if (SL % 16 != 0) {
-      const uint32_t w3 = sW[wi + 3];
-      if (bsh) { w0 = __builtin_amdgcn_alignbit(w1, w0, bsh); w1 = __builtin_amdgcn_alignbit(w2, w1, bsh); w2 = __builtin_amdgcn_alignbit(w3, w2, bsh); }
-    }
     // bit j: position b0 + j exists and its k-mer holds no N
     const int rem = n - b0;
     uint32_t ok = rem >= SL ? (uint32_t)((1ull << SL) - 1ull) : ((1u << rem) - 1u);
     if (hasN) {
       const int mi = b0 >> 5, msh = b0 & 31;
       const uint64_t lo64 = (uint64_t)sM[mi] | ((uint64_t)sM[mi + 1] << 32);
-      const uint64_t m64 = msh ? ((lo64 >> msh) | ((uint64_t)sM[mi + 2] << (64 - msh))) : lo64;
-      ok &= ~(uint32_t)mm_window_or<K>(m64);
+      if constexpr (MMWideK<K>::value) {            // 16 + K - 1 > 64 mask bits: a 128-bit window
+        const uint64_t hi64 = (uint64_t)sM[mi + 2] | ((uint64_t)sM[mi + 3] << 32);
+        const uint64_t lo = msh ? ((lo64 >> msh) | (hi64 << (64 - msh))) : lo64, hi = msh ? (hi64 >> msh) : hi64;
+        ok &= ~mm_window_or_wide<K>(lo, hi);
+      } else {
+        const uint64_t m64 = msh ? ((lo64 >> msh) | ((uint64_t)sM[mi + 2] << (64 - msh))) : lo64;
+        ok &= ~(uint32_t)mm_window_or<K>(m64);
+      }
     }
-    mm_strip_hashes<K, SL>(w0, w1, w2, *tabs, [&](int j, uint64_t hf, uint64_t hr) {
+    auto onPos = [&](int j, uint64_t hf, uint64_t hr) {
       const int pos = b0 + j;
       // the tests as lane masks in scalar registers (mm_device.h): nothing but the two selects of the minimum touches a vector register
       // (the compiler's own `hf < hr ? hf : hr` is as fast at s = 130 and 0.5 ms per 2 M fragments slower at s = 310: profiles/r06b, r06c)
@@ -465,7 +476,20 @@ mm_sketch_fast(unsigned char* smem, const int f, const uint4* __restrict__ gTabs
       const uint32_t idx = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, qHead));
       if (__builtin_amdgcn_inverse_ballot_w64(m) && idx < qEnd) { qH[idx] = h; qM[idx] = ((uint32_t)pos << 1) | (__builtin_amdgcn_inverse_ballot_w64(mLt) ? 1u : 0u); }
       qHead += (uint32_t)__popcll(m);
-    });
+    };
+    if constexpr (MMWideK<K>::value) {              // k-mers of 33..64 bases: 4 or 5 words per strip (SL == 16: the strip starts on a word)
+      uint32_t ww[MMWideK<K>::NW];
+#pragma unroll
+      for (int i = 0; i < MMWideK<K>::NW; i++) ww[i] = sW[wi + i];
+      mm_strip_hashes_wide<K>(ww, *tabs, onPos);
+    } else {
+      uint32_t w0 = sW[wi], w1 = sW[wi + 1], w2 = sW[wi + 2];
+      if (SL % 16 != 0) {
+        const uint32_t w3 = sW[wi + 3];
+        if (bsh) { w0 = __builtin_amdgcn_alignbit(w1, w0, bsh); w1 = __builtin_amdgcn_alignbit(w2, w1, bsh); w2 = __builtin_amdgcn_alignbit(w3, w2, bsh); }
+      }
+      mm_strip_hashes<K, SL>(w0, w1, w2, *tabs, onPos);
+    }
   }
   mark(1);                                          // thread 0's hash loop
   {
@@ -749,7 +773,7 @@ static SketchPlan sketch_plan(int K, int s, int maxLen, size_t tabBytes, bool sl
 // index has been built): the sketch tables + a staged fragment of segLength bases, and the 16-bit L2 state cells of k_l2_sweep.
 int mm_check_params(const mm_params* p, std::string& err) {
   const int s = p->sketchSize, L = p->segLength;
-  const size_t tabBytes = p->kmerSize >= 16 ? sizeof(MMProdTables) : sizeof(MMTables);
+  const size_t tabBytes = (p->kmerSize >= 16 && p->kmerSize <= 32) ? sizeof(MMProdTables) : sizeof(MMTables);
   const SketchPlan P = sketch_plan(p->kmerSize, s, L, tabBytes, false);
   const size_t lim = 160 * 1024;
   // L2: the 16-bit state cells of as few as 8 candidates per wave, the query sketch + bucket table of one wave of k_l2_locate, and the
@@ -757,7 +781,13 @@ int mm_check_params(const mm_params* p, std::string& err) {
   const size_t ldsL2 = (size_t)(s + 1) * 8 * 2;
   int NB = 256; while (NB < s) NB <<= 1;
   const size_t ldsLoc = (size_t)(s + 1) * 8 + (size_t)(s + 2) / 2 * 8 + (size_t)(NB + 4) * 2 + (size_t)s + 32;
-  if (!P.ok || ldsL2 > lim || ldsLoc > lim || s > 8190) {
+  if (s > MM_LDS_MAX_SKETCH) {
+    // no LDS kernel holds this sketch: the global-memory sketch kernel (mm_sketch_global.hip) and the literal L2 kernels take every
+    // fragment -- exact, slow; the stock binary runs these sizes (--dense at segments of 100 kbp), so they run here too
+    if (s > MM_MAX_SKETCH) { err = "mm_create: sketchSize " + std::to_string(s) + " is beyond " + std::to_string(MM_MAX_SKETCH) + " (the (sketchSize + 1)^2 tables of the L2 walk)"; return MM_ERR_ARG; }
+    return MM_OK;
+  }
+  if (!P.ok || ldsL2 > lim || ldsLoc > lim) {
     char b[400];
     snprintf(b, sizeof b, "mm_create: segLength %d with sketchSize %d needs %zu bytes of LDS in the sketch kernel (table of the exact path, spilled form), %zu in the L2 "
              "sweep and %zu in the L2 locate kernel; a CU has %zu (sketchSize up to ~5000)",
@@ -897,6 +927,12 @@ extern "C" int mm_bench_hash_only(mm_ctx* c, int reps, double* msAvg) {
 
 int mm_launch_sketch(mm_ctx* c) {
   const size_t nF = c->nFrags, s = (size_t)c->P.sketchSize;
+  if (s > MM_LDS_MAX_SKETCH) {
+    MM_HIP(c, c->dSkHash.ensure(nF * s * 8 + 64)); MM_HIP(c, c->dSkPos.ensure(nF * s * 8 + 64));
+    MM_HIP(c, c->dSkStrand.ensure(nF * s + 64)); MM_HIP(c, c->dSkCount.ensure(nF * 4 + 64));
+    MM_HIP(c, c->dHardList.ensure(nF * 4 + 64)); MM_HIP(c, c->dCounters.ensure(512));
+    return mm_launch_sketch_global(c);
+  }
   MM_HIP(c, c->dSkHash.ensure(nF * s * 8 + 64));
   MM_HIP(c, c->dSkPos.ensure(nF * s * 8 + 64));
   MM_HIP(c, c->dSkStrand.ensure(nF * s + 64));
@@ -907,8 +943,10 @@ int mm_launch_sketch(mm_ctx* c) {
   switch (c->P.kmerSize) {
 #define MM_CASE(KK) case KK: return launch_sketch_k<KK>(c);
     MM_CASE(1) MM_CASE(2) MM_CASE(3) MM_CASE(4) MM_CASE(5) MM_CASE(6) MM_CASE(7) MM_CASE(8) MM_CASE(9) MM_CASE(10) MM_CASE(11) MM_CASE(12) MM_CASE(13) MM_CASE(14) MM_CASE(15) MM_CASE(16) MM_CASE(17) MM_CASE(18) MM_CASE(19) MM_CASE(20) MM_CASE(21) MM_CASE(22) MM_CASE(23) MM_CASE(24) MM_CASE(25) MM_CASE(26) MM_CASE(27) MM_CASE(28) MM_CASE(29) MM_CASE(30) MM_CASE(31) MM_CASE(32)
+    MM_CASE(33) MM_CASE(34) MM_CASE(35) MM_CASE(36) MM_CASE(37) MM_CASE(38) MM_CASE(39) MM_CASE(40) MM_CASE(41) MM_CASE(42) MM_CASE(43) MM_CASE(44) MM_CASE(45) MM_CASE(46) MM_CASE(47) MM_CASE(48)
+    MM_CASE(49) MM_CASE(50) MM_CASE(51) MM_CASE(52) MM_CASE(53) MM_CASE(54) MM_CASE(55) MM_CASE(56) MM_CASE(57) MM_CASE(58) MM_CASE(59) MM_CASE(60) MM_CASE(61) MM_CASE(62) MM_CASE(63) MM_CASE(64)
 #undef MM_CASE
-    default: c->err = "kmerSize outside 1..32"; return MM_ERR_ARG;
+    default: c->err = "kmerSize outside 1..64"; return MM_ERR_ARG;
   }
 }
 

@@ -50,7 +50,7 @@ def test_index_frequent_seeds(oracle):
     assert nf > 0
 
 
-@pytest.mark.parametrize("k,s,L", [(16, 50, 1000), (19, 498, 5000), (19, 20, 10000), (21, 100, 500)])
+@pytest.mark.parametrize("k,s,L", [(16, 50, 1000), (19, 498, 5000), (19, 20, 10000), (21, 100, 500), (40, 60, 1000), (64, 100, 2000)])
 def test_index_parameter_grid(oracle, k, s, L):
     contigs = [("x", U.random_dna(7 + k, 150000)), ("y", U.tandem_repeat(8, 60000, 311)), ("z", U.with_n_runs(U.random_dna(9, 50000), 2, 6, 40))]
     _compare(oracle, contigs, k, L, s)

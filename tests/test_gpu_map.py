@@ -67,6 +67,16 @@ def test_map_with_the_tagged_seed_table(oracle, monkeypatch, case):
         run_and_compare(oracle, contigs, rs, flags=U.FLAG_HG | U.FLAG_SKIP_SELF)
 
 
+@pytest.mark.parametrize("k", [40, 57])
+def test_map_kmers_longer_than_32_bases(oracle, k):
+    """-k 40 / 57: every integer of every stage against the oracle (whose getHash is pinned to the reference's at k = 40,
+    tests/test_oracle_vs_ref.py); low error so that k-mers of that length still match"""
+    contigs = genome(301 + k, [300000, 200000])
+    reads = reads_for(contigs, 31, 60, 10000, 0.02) + [("n_runs", U.with_n_runs(contigs[0][1][5000:17000], 3, 6, 40))]
+    nF, nl = run_and_compare(oracle, contigs, reads, k=k, device_index=True)
+    assert nF > 100 and nl > 50
+
+
 def test_map_frequent_seeds(oracle):
     contigs = genome(21, [300000, 250000, 200000])
     reads = reads_for(contigs, 7, 80, 10000, 0.08)
@@ -226,6 +236,17 @@ def test_map_sketch_beyond_1279(oracle, L, s, pi, err):
     contigs = genome(551, [500000, 400000], repeats=False)
     reads = reads_for(contigs, 53, 10, 2 * L + 777, err) + reads_for(contigs, 54, 4, L, err / 2)
     run_and_compare(oracle, contigs, reads, L=L, s=s, pi=pi, check_points=False)
+
+
+def test_map_sketch_beyond_8190(oracle):
+    """--dense --pi 80 -s 100000 derives sketchSize 9 998 and the stock binary runs it; here no LDS kernel holds such a sketch, so every
+    fragment takes the global-memory sketch kernel (k_sketch_global: all k-mers hashed, sorted, de-duplicated in HBM scratch) and every
+    candidate the literal L2 kernel (k_l2_window with windowLen 0).  Every integer of every stage against the oracle, at s = 9 000."""
+    L, s = 90000, 9000
+    contigs = genome(561, [700000, 500000], repeats=False)
+    reads = reads_for(contigs, 55, 6, 2 * L + 1234, 0.12) + reads_for(contigs, 56, 3, L, 0.06) + [("n_runs", U.with_n_runs(contigs[0][1][100000:100000 + L], 3, 5, 60))]
+    nF, nl = run_and_compare(oracle, contigs, reads, L=L, s=s, pi=0.80, flags=0, check_points=False)   # (no HG filter: its O(s^3) cut-off table takes the oracle half a minute at this size)
+    assert nF >= 20 and nl >= 10
 
 
 @pytest.mark.parametrize("mode", ["default", "dup_nohg", "prefix"])

@@ -68,7 +68,7 @@ def test_sketch_adversarial(oracle):
     _check(oracle, reads)
 
 
-# every k-mer size 1..32 (the kernels are compiled for all of them): the word layout of the hash (blocks, 8-byte and shorter tail
+# k-mer sizes 1..32 all, 33..64 sampled (the kernels are compiled for every one of them): the word layout of the hash (blocks, 8-byte and shorter tail
 # words, the one group shorter than 4 bases) differs for each of them
 @pytest.mark.parametrize("k,s,L", [(16, 60, 1000), (19, 498, 5000), (19, 40, 10000), (15, 200, 3000), (21, 130, 5000), (32, 100, 2500), (11, 30, 500),
                                    (17, 70, 1200), (18, 90, 2000), (20, 80, 2000), (22, 64, 1500), (23, 75, 2500), (24, 100, 4000), (25, 50, 1000),
@@ -78,7 +78,11 @@ def test_sketch_adversarial(oracle):
                                    (2, 3, 64), (1, 2, 64),                                             # the reference takes any -k (parseCmdArgs.hpp:435)
                                    (19, 1100, 10000), (19, 1279, 12000),                               # sketches beyond 1024 entries
                                    (19, 1998, 20000),                                                  # --dense --pi 80 -s 20000 (parseCmdArgs.hpp:626-630): hard table spilled to HBM
-                                   (19, 4000, 40000), (16, 2500, 15000)])                              # beyond the fast kernel's geometry: every fragment on the exact path
+                                   (19, 4000, 40000), (16, 2500, 15000),                               # beyond the fast kernel's geometry: every fragment on the exact path
+                                   (33, 90, 3000), (40, 130, 5000), (47, 60, 2000), (48, 100, 4000),   # k-mers of more than 32 bases: four packed words per strip,
+                                   (49, 80, 3000), (56, 120, 5000), (63, 70, 2500), (64, 100, 4000),   # five from 49 on (the reference hashes any length, commonFunc.hpp:138)
+                                   (40, 1998, 20000),                                                  # ... on the exact path as well
+                                   (19, 9000, 60000), (40, 8500, 50000)])                              # beyond 8 190: the global-memory sketch kernel
 def test_sketch_parameter_grid(oracle, k, s, L):
     g = U.random_dna(11, 200000)
     reads = [a for _, a, _ in U.sample_reads([g], 5 + k, 12, 2 * L + 123, 0.08)]

@@ -11,7 +11,7 @@ import mmutil as U
 
 def test_get_hash(oracle, ref):
     a = U.random_dna(1, 4000)
-    for k in (8, 15, 16, 17, 19, 23, 24, 31, 32, 40):
+    for k in (8, 15, 16, 17, 19, 23, 24, 31, 32, 33, 40, 47, 48, 49, 57, 63, 64):
         for i in range(0, 60):
             s = bytes(a[i * 41:i * 41 + k])
             assert oracle.get_hash(s) == ref.get_hash(s)
@@ -25,6 +25,14 @@ def test_sketch_sequence(oracle, ref, seed):
     for v in variants:
         for k, s in ((19, 130), (19, 498), (16, 50), (21, 20)):
             assert oracle.sketch_sequence(v, k, s, seed) == ref.sketch_sequence(v, k, s, seed)
+
+
+@pytest.mark.parametrize("k,s,n", [(33, 90, 3000), (40, 130, 5000), (57, 80, 4000), (64, 100, 4000), (19, 9000, 60000), (40, 8500, 50000)])
+def test_sketch_sequence_long_kmers_and_large_sketches(oracle, ref, k, s, n):
+    """the parameter ranges the HIP path covers with its wide-strip kernels (k 33..64) and its global-memory sketch kernel (s > 8 190)"""
+    a = U.random_dna(300 + k, n)
+    for v in (a, U.with_n_runs(a, 2, 4, 25)):
+        assert oracle.sketch_sequence(v, k, s, 1) == ref.sketch_sequence(v, k, s, 1)
 
 
 @pytest.mark.parametrize("cfg", [(5000, 130, 200000, "random"), (5000, 130, 120000, "repeat"), (1000, 50, 100000, "nruns"),
