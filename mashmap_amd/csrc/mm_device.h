@@ -106,6 +106,9 @@ __device__ __forceinline__ uint64_t mm_mask_select64(uint64_t mask, uint64_t a, 
   asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(hi) : "v"((uint32_t)(b >> 32)), "v"((uint32_t)(a >> 32)), "s"(mask));
   return ((uint64_t)hi << 32) | lo;
 }
+// the wave's ballot of a predicate.  (__ballot() of the HIP headers takes an int: a bool that already lives in a lane mask is first
+// turned into 0 / 1 and compared again -- two VALU instructions per ballot that this form does not have)
+__device__ __forceinline__ uint64_t mm_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __device__ __forceinline__ uint32_t mm_popc_below(uint64_t mask) {    // set bits of mask strictly below this lane
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }

@@ -197,7 +197,7 @@ k_l2_locate(int cBase, int nCand, int64_t opsBase, int s, int NB, const mm_l1_ca
             unsigned long long* __restrict__ counters /* [6] |= 4: a stream outgrew its reservation */,
             const unsigned long long* __restrict__ nDev) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;   // (readfirstlane: the candidate's extents then live in scalar registers)
   unsigned char* base = smem + (size_t)wave * mm_locate_lds_per_wave(s, NB);
   uint64_t* q = (uint64_t*)base;                                   // the query sketch + one sentinel
   uint32_t* qhi = (uint32_t*)(base + (size_t)(s + 1) * 8);         // its high words (the bucket walk compares these)
@@ -213,6 +213,30 @@ k_l2_locate(int cBase, int nCand, int64_t opsBase, int s, int NB, const mm_l1_ca
     const int S = in.sketch & 0x7fffffff;
     uint32_t* out = ops + (opOff[c] - opsBase);
     const int cap = opCnt[c];
+    const int nOpen = in.nOpen, nPre = in.nPre, nAll = in.nAll;
+    // The kernel is bound by the latency of its global reads, not by their volume (the slices come from the Infinity Cache) nor by
+    // instruction issue: round 3 walked a chain of ~20 dependent round trips per candidate (sketch, tail scan, the record behind the
+    // tail, then one per 64 events).  Everything that depends only on the candidate's extents is therefore requested up front -- the
+    // last 64 events of the slice, the 64 behind it, the first chunk of the stream -- and every later chunk while its predecessor
+    // is being processed.
+    const int64_t ce = contigOff[cand.seqId + 1];
+    const int iT = nAll - 64 + lane;
+    const uint32_t tailKey = (iT >= nPre && iT < nAll) ? evKey[in.e0 + iT] : 0u;           // insert flag = bit 0; 0 outside the slide
+    const uint32_t behindKey = in.e0 + nAll + lane < ce ? evKey[in.e0 + nAll + lane] : 0u;
+    // the stream in chunks of 64: the block's open records (all inserts, all before rangeStart), then the events [0, nPre) before
+    // rangeStart, then the slide [nPre, nEv).  A chunk reads from wave-uniform arrays (one loop over a concatenation cost a per-lane
+    // choice between two sets of three 64-bit pointers in every chunk)
+    const int nChO = (nOpen + 63) >> 6, nChPre = nChO + ((nPre + 63) >> 6);
+    auto loadChunk = [&](int ch, uint32_t& key, uint32_t& aux, uint64_t& h) {
+      key = 0; aux = 0; h = 0;                                       // a lane without a record: no insert flag, nothing kept
+      if (ch < nChO) { const int i = ch * 64 + lane; if (i < nOpen) { key = opKey[in.open0 + i]; aux = opAux[in.open0 + i]; h = opHash[in.open0 + i]; } }
+      else {
+        const int i = ch < nChPre ? (ch - nChO) * 64 + lane : nPre + (ch - nChPre) * 64 + lane;
+        if (i < (ch < nChPre ? nPre : nAll)) { key = evKey[in.e0 + i]; aux = evAux[in.e0 + i]; h = evHash[in.e0 + i]; }
+      }
+    };
+    uint32_t nKey, nAux; uint64_t nHash;
+    loadChunk(0, nKey, nAux, nHash);
     __threadfence_block();                                         // previous candidate's LDS reads are done
     // a fragment that lost no frequent seed has no copy in qHash/qStrand: its sketch is the raw one (k_lookup_l1)
     const bool raw = in.sketch < 0;
@@ -225,8 +249,9 @@ k_l2_locate(int cBase, int nCand, int64_t opsBase, int s, int NB, const mm_l1_ca
     // bucket(h): monotone map of [0, qmax] onto 0..NB-1: the top 24 significant bits times M >> 32, M <= 2^32 * NB / (top24(qmax) + 1)
     // (any smaller M stays monotone and below NB; the float estimate is shaded down)
     const int sh = qmax ? (int)__builtin_clzll(qmax) : 63;
-    const uint32_t bM = (uint32_t)((float)NB * 4294967296.0f / ((float)(uint32_t)((qmax << sh) >> 40) + 1.0f) * 0.99999f);
-    auto bucket = [&](uint64_t h) -> int { return (int)__umulhi((uint32_t)((h << sh) >> 40), bM); };
+    // (NB <= 16384 and the top bit of top24(qmax) is set, so M < 2^24 as well: a 24 x 24-bit multiply, which issues at full rate)
+    const uint32_t bM = (uint32_t)((float)NB * 4294967296.0f / ((float)(uint32_t)((qmax << sh) >> 40) + 1.0f) * 0.99999f) & 0xFFFFFFu;
+    auto bucket = [&](uint64_t h) -> int { return (int)(((uint64_t)((uint32_t)((h << sh) >> 40) & 0xFFFFFFu) * (uint64_t)bM) >> 32); };
     // bkt[b] = #{p : bucket(q[p]) < b}.  q is sorted, so entry p owns the buckets (bucket(q[p-1]), bucket(q[p])] and the
     // sentinel p = S owns the rest up to NB: a scatter of ~NB/S stores per lane instead of NB + 1 binary searches
     for (int p0 = 0; p0 <= S; p0 += 64) {
@@ -242,64 +267,77 @@ k_l2_locate(int cBase, int nCand, int64_t opsBase, int s, int NB, const mm_l1_ca
       if (h > qmax) return 0u;
       const int b = bucket(h);
       // lower_bound(q, h): everything in earlier buckets is smaller and h <= qmax < sentinel, so the walk from the bucket's first entry
-      // ends by itself; it runs on the 32-bit high words (32-bit LDS reads and compares) and only a tie there looks at all 64 bits
-      int lo = bkt[b];
+      // ends by itself; it runs on the 32-bit high words (32-bit LDS reads and compares) and only a tie there looks at all 64 bits.
+      // One induction variable (the byte offset into qhi), made opaque behind the loop: left to itself the optimiser carries four
+      // (index, index - 1 and two addresses), each with its own add and copy per step of a loop every lane of the wave waits for
+      uint32_t off = (uint32_t)bkt[b] * 4u;
       const uint32_t hh = (uint32_t)(h >> 32);
-      while (qhi[lo] < hh) lo++;
-      if (qhi[lo] == hh) { while (q[lo] < h) lo++; }
+      const unsigned char* qhiB = (const unsigned char*)qhi;
+      uint32_t v = *(const uint32_t*)(qhiB + off);
+      while (v < hh) { off += 4u; v = *(const uint32_t*)(qhiB + off); }
+      asm volatile("" : "+v"(off));
+      int lo = (int)(off >> 2);
+      if (v == hh) { while (q[lo] < h) lo++; }
       return (uint32_t)(lo + 1) | (q[lo] == h ? (1u << EF<JB>::MATCH_BIT) : 0u) | ((uint32_t)((int)qs[lo] + 1) << EF<JB>::VOTE_SHIFT);   // query strand + 1
     };
-    // the slide ends with the last insert at or before rangeEnd (evictions behind it are never reached, :1340)
-    int lastRel = -1;                                              // index of that insert relative to e0
-    for (int hiEnd = in.nAll; hiEnd > in.nPre && lastRel < 0; hiEnd -= 64) {
-      const int i = hiEnd - 64 + lane;
-      const uint64_t m = __ballot(i >= in.nPre && i < hiEnd && (evKey[in.e0 + i] & 1u));
-      if (m) lastRel = hiEnd - 64 + 63 - (int)__builtin_clzll(m);
+    // the slide ends with the last insert at or before rangeEnd (evictions behind it are never reached, :1340); nextW: the wpos of the
+    // record after it in the same contig, else its own (:1387-1390)
+    int lastRel = -1, nextW = 0;                                   // lastRel: index of that insert relative to e0
+    {
+      const uint64_t m = mm_ballot((tailKey & 1u) != 0);
+      if (m) { const int l = 63 - (int)__builtin_clzll(m); lastRel = nAll - 64 + l; nextW = (int)((uint32_t)__shfl((int)tailKey, l) >> 1); }
     }
-    // wpos of the record after it in the same contig, else its own (:1387-1390)
-    int nextW = 0;
-    if (lastRel >= 0) {
-      nextW = (int)(evKey[in.e0 + lastRel] >> 1);
-      const int64_t ce = contigOff[cand.seqId + 1];
-      for (int64_t e = in.e0 + lastRel + 1; e < ce; e += 64) {
-        const uint64_t m = __ballot(e + lane < ce && (evKey[e + lane] & 1u));
-        if (m) { nextW = (int)(evKey[e + (int)__builtin_ctzll(m)] >> 1); break; }
+    for (int hiEnd = nAll - 64; hiEnd > nPre && lastRel < 0; hiEnd -= 64) {               // (rare: 64 evictions at the end of a slice)
+      const int i = hiEnd - 64 + lane;
+      const uint32_t k2 = (i >= nPre && i < hiEnd) ? evKey[in.e0 + i] : 0u;
+      const uint64_t m = mm_ballot((k2 & 1u) != 0);
+      if (m) { const int l = 63 - (int)__builtin_clzll(m); lastRel = hiEnd - 64 + l; nextW = (int)((uint32_t)__shfl((int)k2, l) >> 1); }
+    }
+    if (lastRel >= 0) {                                            // everything of the slice behind lastRel is an eviction: go on behind the slice
+      const uint64_t m0 = mm_ballot((behindKey & 1u) != 0);
+      if (m0) nextW = (int)((uint32_t)__shfl((int)behindKey, (int)__builtin_ctzll(m0)) >> 1);
+      else for (int64_t e = in.e0 + nAll + 64; e < ce; e += 64) {
+        const uint32_t k2 = e + lane < ce ? evKey[e + lane] : 0u;
+        const uint64_t m = mm_ballot((k2 & 1u) != 0);
+        if (m) { nextW = (int)((uint32_t)__shfl((int)k2, (int)__builtin_ctzll(m)) >> 1); break; }
       }
     }
     int outN = 0;                                                  // entries written so far (wave-uniform)
     int posAcc = cand.rangeStartPos;                               // running position of the delta code (wave-uniform)
     bool tooWide = false;
     const int nEv = lastRel + 1;                                   // events [0, nEv) of the slice are streamed
-    // the stream: first the block's open records (all inserts), then the events [e0, e0 + nEv) of which the first nPre lie
-    // before rangeStart
-    const int nOpen = in.nOpen;
-    for (int b0 = 0; b0 < nOpen + (nEv > in.nPre ? nEv : in.nPre); b0 += 64) {
-      const int iAll = b0 + lane;
-      const bool inOpen = iAll < nOpen;
-      const int i = iAll - nOpen;
-      const bool inPre = inOpen || i < in.nPre;
-      const bool live = inPre ? true : i < nEv;
-      uint32_t key = 0, aux = 0; uint64_t h = 0;
-      if (live) {
-        if (inOpen) { key = opKey[in.open0 + iAll]; aux = opAux[in.open0 + iAll]; h = opHash[in.open0 + iAll]; }
-        else { key = evKey[in.e0 + i]; aux = evAux[in.e0 + i]; h = evHash[in.e0 + i]; }
-      }
+    const int nCh = nChPre + ((nEv > nPre ? nEv - nPre : 0) + 63) / 64;
+    asm volatile("" : "+v"(nKey), "+v"(nAux), "+v"(nHash));        // chunk 0 has arrived (no wait is then needed at the loop's head, where it would also cover the previous chunk's writes)
+    for (int ch = 0; ch < nCh; ch++) {
+      const uint32_t key = nKey, aux = nAux; const uint64_t h = nHash;
+      if (ch + 1 < nCh) loadChunk(ch + 1, nKey, nAux, nHash);       // in flight while this chunk is located
       const bool isIns = (key & 1u) != 0;
       const int pos = (int)(key >> 1);
-      uint32_t op = 0; bool keep = false, evalIns = false;
-      if (live) {
-        if (inPre) keep = isIns && (int)(aux & 0x7fffffffu) > cand.rangeStartPos && pos >= in.target;   // still open at rangeStart (:1323-1338)
-        else keep = isIns || h <= qmax;                                                 // an eviction outside the sketch's range changes nothing
-        if (keep) {
-          op = locate(h);
-          // vote of a matching insert = query strand x reference strand: a REV record (aux bit 31) mirrors the field around 1
-          if (isIns && (aux >> 31)) op = (op & ~(3u << EF<JB>::VOTE_SHIFT)) | ((2u - ((op >> EF<JB>::VOTE_SHIFT) & 3u)) << EF<JB>::VOTE_SHIFT);
-          op |= 1u << (inPre ? E_PRE_BIT : (isIns ? E_INS_BIT : E_DEL_BIT));
-          evalIns = !inPre && isIns;
-        }
+      const bool slide = ch >= nChPre;                               // wave-uniform
+      bool keep, evalIns = false;
+      if (!slide) keep = isIns && (int)(aux & 0x7fffffffu) > cand.rangeStartPos && pos >= in.target;   // still open at rangeStart (:1323-1338)
+      else {
+        const bool live = nPre + (ch - nChPre) * 64 + lane < nEv;
+        keep = live && (isIns || h <= qmax);                         // an eviction outside the sketch's range changes nothing
+        evalIns = live && isIns;
+      }
+      uint32_t op = 0;
+      if (keep) {
+        op = locate(h);
+        // vote of a matching insert = query strand x reference strand: a REV record (aux bit 31) mirrors the field around 1
+        if (isIns && (aux >> 31)) op = (op & ~(3u << EF<JB>::VOTE_SHIFT)) | ((2u - ((op >> EF<JB>::VOTE_SHIFT) & 3u)) << EF<JB>::VOTE_SHIFT);
+        op |= 1u << (!slide ? E_PRE_BIT : (isIns ? E_INS_BIT : E_DEL_BIT));
+      }
+      const uint64_t mKeep = mm_ballot(keep);
+      if (!slide) {                                                  // before rangeStart nothing is evaluated: no position code
+        asm volatile("" : "+v"(nKey), "+v"(nAux), "+v"(nHash));      // (the next chunk's reads are waited for here, ahead of this chunk's writes)
+        const int at = outN + (int)mm_popc_below(mKeep);
+        if (keep) { if (at < cap) out[at] = op; else tooWide = true; }
+        outN += __popcll(mKeep);
+        continue;
       }
       // delta against the previous evaluated insert (lower lanes of this chunk, else the carry)
-      const uint64_t mIns = __ballot(evalIns);
+      const uint64_t mIns = mm_ballot(evalIns);
       int prevPos = posAcc;
       {
         const uint64_t below = mIns & ((1ull << lane) - 1ull);
@@ -309,8 +347,10 @@ k_l2_locate(int cBase, int nCand, int64_t opsBase, int s, int NB, const mm_l1_ca
       }
       const int delta = evalIns ? pos - prevPos : 0;
       const bool needSkip = evalIns && delta > (int)EF<JB>::MAXDELTA;
-      const uint64_t mKeep = __ballot(keep), mSkip = __ballot(needSkip);          // slots before this lane: one per kept event, one more per skip
-      if (__ballot(needSkip && (uint32_t)(delta - (int)EF<JB>::MAXDELTA) > E_SKIP_MAX)) {
+      const uint64_t mSkip = mm_ballot(needSkip);                                  // slots before this lane: one per kept event, one more per skip
+      const bool bigSkip = mm_ballot(needSkip && (uint32_t)(delta - (int)EF<JB>::MAXDELTA) > E_SKIP_MAX) != 0;
+      asm volatile("" : "+v"(nKey), "+v"(nAux), "+v"(nHash));
+      if (bigSkip) {
         // a gap that one skip entry (27 bits) cannot carry -- two reference minmers of one candidate more than 2^27 bases apart: the gap
         // is spread over as many skip entries as it takes (the reservation holds one per 2^DELTA_BITS bases of the range).  Round 3
         // failed the batch here.
@@ -320,21 +360,21 @@ k_l2_locate(int cBase, int nCand, int64_t opsBase, int s, int NB, const mm_l1_ca
         int at = outN + mm_wave_excl_scan(mineW);
         if (keep && at + mineW <= cap) {
           uint32_t left = extra;
-          for (int i = 0; i < nSkip; i++) { const uint32_t part = left > E_SKIP_MAX ? E_SKIP_MAX : left; out[at++] = (1u << E_SKIP_BIT) | part; left -= part; }
+          for (int i2 = 0; i2 < nSkip; i2++) { const uint32_t part = left > E_SKIP_MAX ? E_SKIP_MAX : left; out[at++] = (1u << E_SKIP_BIT) | part; left -= part; }
           out[at] = op | ((needSkip ? EF<JB>::MAXDELTA : (uint32_t)delta) << EF<JB>::DELTA_SHIFT);
         } else if (keep) tooWide = true;                                          // cannot happen: see the reservation in k_l2_extents
         outN += mm_wave_sum(mineW);
       } else {
-      const int mine = keep ? (needSkip ? 2 : 1) : 0;
-      const int at = outN + (int)mm_popc_below(mKeep) + (int)mm_popc_below(mSkip);
-      if (keep && at + mine <= cap) {
-        if (needSkip) {
-          const uint32_t extra = (uint32_t)(delta - (int)EF<JB>::MAXDELTA);
-          out[at] = (1u << E_SKIP_BIT) | (extra & E_SKIP_MAX);
-          out[at + 1] = op | (EF<JB>::MAXDELTA << EF<JB>::DELTA_SHIFT);
-        } else out[at] = op | ((uint32_t)delta << EF<JB>::DELTA_SHIFT);
-      }
-      outN += __popcll(mKeep) + __popcll(mSkip);
+        const int mine = keep ? (needSkip ? 2 : 1) : 0;
+        const int at = outN + (int)mm_popc_below(mKeep) + (int)mm_popc_below(mSkip);
+        if (keep && at + mine <= cap) {
+          if (needSkip) {
+            const uint32_t extra = (uint32_t)(delta - (int)EF<JB>::MAXDELTA);
+            out[at] = (1u << E_SKIP_BIT) | (extra & E_SKIP_MAX);
+            out[at + 1] = op | (EF<JB>::MAXDELTA << EF<JB>::DELTA_SHIFT);
+          } else out[at] = op | ((uint32_t)delta << EF<JB>::DELTA_SHIFT);
+        }
+        outN += __popcll(mKeep) + __popcll(mSkip);
       }
       if (mIns) posAcc = __shfl(pos, 63 - (int)__builtin_clzll(mIns));
     }
@@ -349,7 +389,7 @@ k_l2_locate(int cBase, int nCand, int64_t opsBase, int s, int NB, const mm_l1_ca
       if (at < cap) out[at] = (1u << E_END_BIT) | (delta << EF<JB>::DELTA_SHIFT);
       else tooWide = true;                                         // cannot happen: the reservation covers every event + skips
     }
-    if (__ballot(tooWide) && lane == 0) atomicOr(&counters[6], 4ull);
+    if (mm_ballot(tooWide) && lane == 0) atomicOr(&counters[6], 4ull);
   }
 }
 
@@ -362,8 +402,12 @@ template <int B> __device__ __forceinline__ int mm_bit_mask(uint32_t x) { int m;
 // The LDS that 64 such states need is what limits the waves per CU, and the kernel is latency bound, so the first pass uses
 // 8-bit cells (CB = 5: 18 waves/CU at s = 130).  num_before_inc counts the open reference-only hashes between two neighbouring
 // query hashes -- about one on average; a candidate where one exceeds 31 is queued and redone with 16-bit cells (CB = 12).
-// Every lane owns an LDS bank: 8-bit cell p of lane l is byte p & 3 of dword (p >> 2) * 64 + l; 16-bit cell p of lane l is
-// half l >> 5 of dword p * 32 + (l & 31).  Both 32-lane halves of a DS instruction then see 32 distinct banks.
+// Cell p of lane l sits at p * LPW + l (16-bit cells of a full wave: half l >> 5 of dword p * 32 + (l & 31)), so that a cell's LDS
+// address is one shift-add of its position, the pivot's right neighbour is the same address with an immediate offset, and no address
+// arithmetic is left in the per-entry instruction budget -- the kernel is bound by VALU issue, not by LDS: four lanes share a bank of
+// the 8-bit layout, which costs the DS pipe a second pass now and then and the SIMDs nothing (round 4; until then every lane owned a
+// bank, byte p & 3 of dword (p >> 2) * 64 + l, at five more VALU instructions per cell access).  One cell of padding behind position S
+// lets the neighbour be read without clamping (its value is masked when the pivot is at S).
 // ---------------------------------------------------------------------------------------------
 // LPW lanes of a wave carry a candidate (64; fewer for sketches whose 64 states would not fit a CU's LDS: 32, 16 or 8 -- the other
 // lanes leave at once); JB: width of the stream entries' sketch-position field.
@@ -398,9 +442,9 @@ k_l2_sweep(int cBase, int nCand, int64_t opsBase, const int32_t* __restrict__ ca
   const uint4* src = (const uint4*)(ops + (opOff[cIdx] - opsBase));
   const int nSteps = opCnt[cIdx] / E_STEP;             // 16 entries = 4 x 16 bytes per step
   int posAcc = cand.rangeStartPos;                     // running position of the delta code
-  const int lbase = WIDE ? (LPW == 64 ? (lane & 31) * 2 + (lane >> 5) : lane) : lane * 4;
-#define CELL(p) cell[WIDE ? (p) * LPW + lbase : ((p) >> 2) * (LPW * 4) + lbase + ((p) & 3)]
-  CELL(0) = 0;
+  const int lbase = WIDE && LPW == 64 ? (lane & 31) * 2 + (lane >> 5) : lane;
+#define CELL(p) cell[(p) * LPW + lbase]
+  CELL(0) = 0; CELL(S + 1) = 0;
   for (int p = 1; p <= S; p++) CELL(p) = (CellT)(1u | (1u << (CB + 1)));       // num_before_inc = 1, inactive, vote 0
   int pivot = S, pivRank = S, shared = 0, votes = 0;
 
@@ -423,7 +467,7 @@ k_l2_sweep(int cBase, int nCand, int64_t opsBase, const int32_t* __restrict__ ca
     const int valid = neg(-j) & ~cntOverflow;          // after a counter overflow the lane only idles to the end
     const int mt = BITM(e, EF<JB>::MATCH_BIT);
     const int ltS = neg(pivot - S);                    // pivot + 1 <= S
-    const int pn = pivot - ltS;                        // min(pivot + 1, S)
+    const int pn = pivot + 1;                          // at pivot == S: the padding cell, masked by ltS below
     const uint32_t cw = CELL(j), pw = CELL(pivot), nw = CELL(pn);
     const int vi = valid & insM, vd = valid & delM;
     const int IM = vi & mt, IN = vi & ~mt, DM = vd & mt, DN = vd & ~mt;
@@ -495,11 +539,11 @@ k_l2_sweep(int cBase, int nCand, int64_t opsBase, const int32_t* __restrict__ ca
 #pragma unroll
     for (int k = 0; k < E_STEP; k++) {
       const uint4 v = cur[k >> 2];
-      const uint32_t e = (k & 3) == 0 ? v.x : (k & 3) == 1 ? v.y : (k & 3) == 2 ? v.z : v.w;
-      // straight-line per entry: a finished lane (done) and the entry kinds are masks, not branches
-      const int act = ~done;
-      const int mIns = BITM(e, 27) & act, mDel = BITM(e, 28) & act, mPre = BITM(e, 29) & act, mEnd = BITM(e, 30) & act;
-      const int mSkip = neg((int)e) & act;
+      const uint32_t eRaw = (k & 3) == 0 ? v.x : (k & 3) == 1 ? v.y : (k & 3) == 2 ? v.z : v.w;
+      const uint32_t e = eRaw & (uint32_t)~done;         // a finished lane reads on behind its end marker: no kind bit, no effect
+      // straight-line per entry: the entry kinds are masks, not branches
+      const int mIns = BITM(e, 27), mDel = BITM(e, 28), mPre = BITM(e, 29), mEnd = BITM(e, 30);
+      const int mSkip = neg((int)e);
       const int ie = mIns | mEnd;
       posAcc += ((int)((e >> EF<JB>::DELTA_SHIFT) & EF<JB>::MAXDELTA) & ie) | ((int)(e & E_SKIP_MAX) & mSkip);
       const int wpos = posAcc;
@@ -1037,10 +1081,10 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt, bool steady) {
   if (oneChunk) { const int rc = locate(chunks[0]); if (rc != MM_OK) return rc; }      // its streams stay put over the retries below
   // candidates per wave of the sweeps (LPW): 64, fewer when the LDS state of 64 does not fit a CU -- 8-bit cells first, 16-bit cells
   // for the rare candidate whose 5-bit counters overflow
-  const int lpwN = JB == 11 ? 64 : ((size_t)((s + 4) / 4) * 128 <= 160 * 1024 ? 32 : 16);
-  const int lpwW = JB == 11 ? ((size_t)(s + 1) * 128 <= 160 * 1024 ? 64 : 32) : ((size_t)(s + 1) * 32 <= 160 * 1024 ? 16 : 8);
-  const size_t ldsWide = (size_t)(s + 1) * lpwW * 2;                       // cells 0..S, 16 bit
-  const size_t ldsNarrow = (size_t)((s + 1 + 3) / 4) * lpwN * 4;           // 8 bit
+  const int lpwN = JB == 11 ? 64 : ((size_t)(s + 2) * 32 <= 160 * 1024 ? 32 : 16);
+  const int lpwW = JB == 11 ? ((size_t)(s + 2) * 128 <= 160 * 1024 ? 64 : 32) : ((size_t)(s + 2) * 32 <= 160 * 1024 ? 16 : 8);
+  const size_t ldsWide = (size_t)(s + 2) * lpwW * 2;                       // cells 0..S + one of padding, 16 bit
+  const size_t ldsNarrow = (((size_t)(s + 2) * lpwN) + 15) & ~(size_t)15;  // 8 bit
   if (ldsWide > 160 * 1024 || ldsNarrow > 160 * 1024) { c->err = "sketchSize too large for the LDS-resident L2 state"; return MM_ERR_ARG; }
   // one launch of a sweep kernel: n candidates starting at c0, or the n listed ones (countDev: their number lives on the device, the
   // launch covers listCap of them)
