@@ -176,6 +176,36 @@ inline const char* next_record(const char* base, const char* p, const char* e, b
   return q;
 }
 
+// The record scanner both window parsers share (the one-pass packer and the two-pass form): seqiter's record semantics in one place.
+// record_name: the name of the record whose header line starts at hdr and whose body starts at body -- the header without its marker,
+// cut at the first ' ' only (a '\r' stays, like the reference's reader keeps it).
+inline void record_name(const char* hdr, const char* body, const char*& nb, const char*& ne) {
+  nb = hdr + 1;
+  const char* he = body > hdr && body[-1] == '\n' ? body - 1 : body;   // header line without its '\n'
+  if (he < nb) he = nb;
+  const char* sp = (const char*)memchr(nb, ' ', (size_t)(he - nb));
+  ne = sp ? sp : he;
+}
+// record_lines: hands every non-empty sequence line of the record whose body starts at body to onLine(line, bytes) and returns where the
+// next record starts.  FASTA: lines up to the next '>' at a line start; FASTQ: one sequence line, then the '+' line and the quality line.
+template <class F>
+inline const char* record_lines(const char* body, const char* e, bool fasta, F&& onLine) {
+  if (fasta) {
+    const char* l = body;
+    while (l < e && *l != '>') {
+      const char* nl = (const char*)memchr(l, '\n', (size_t)(e - l));
+      const char* le = nl ? nl : e;
+      if (le > l) onLine(l, (size_t)(le - l));
+      l = nl ? nl + 1 : e;
+    }
+    return l;
+  }
+  const char* nl = (const char*)memchr(body, '\n', (size_t)(e - body));
+  const char* le = nl ? nl : e;
+  if (body < e && le > body) onLine(body, (size_t)(le - body));
+  return next_line(next_line(nl ? nl + 1 : e, e), e);                                   // '+' line and quality line skipped
+}
+
 struct Rec { const char* hdr; const char* body; const char* end; int64_t seqLen; bool keep; size_t seg0, seg1; };   // seg0..seg1: its sequence lines (Seg list of its thread)
 struct Seg { const char* p; size_t n; };   // one line of sequence bytes (without the line break)
 
@@ -506,35 +536,18 @@ class BatchReader {
       int64_t cur = G[t];
       while (q < pe) {
         const char* body = detail::next_line(q, e);
-        const char* hb = q + 1; const char* he = body > q && body[-1] == '\n' ? body - 1 : body;   // header line without its '\n'
-        if (he < hb) he = hb;
-        const char* sp = (const char*)memchr(hb, ' ', (size_t)(he - hb));
-        Lite r; r.name.assign(hb, sp ? sp : he); r.start = cur; r.len = 0; r.hasN = 0;
+        const char* nb; const char* ne;
+        detail::record_name(q, body, nb, ne);
+        Lite r; r.name.assign(nb, ne); r.start = cur; r.len = 0; r.hasN = 0;
         const bool keep = (keepPrefix_.empty() || r.name.compare(0, keepPrefix_.size(), keepPrefix_) == 0) && (keepSeq_.empty() || keepSeq_.count(r.name));
-        const char* end;
         // room for the longest record this piece could still hold is not known in advance: stop at the region's end, line by line
         Pack2bitStream st(b2 + cur / 16, nm + cur / 32);
         int64_t len = 0; bool fits = true;
-        auto feed = [&](const char* l, size_t m) {
-          if (!keep || !m || !fits) return;
+        const char* end = detail::record_lines(body, e, fasta, [&](const char* l, size_t m) {
+          if (!keep || !fits) return;
           if (cur + (len + (int64_t)m + 31) / 32 * 32 > G[t + 1]) { fits = false; return; }
           st.feed(l, m); len += (int64_t)m;
-        };
-        if (fasta) {
-          const char* l = body;
-          while (l < e && *l != '>') {
-            const char* nl = (const char*)memchr(l, '\n', (size_t)(e - l));
-            const char* le = nl ? nl : e;
-            feed(l, (size_t)(le - l));
-            l = nl ? nl + 1 : e;
-          }
-          end = l;
-        } else {
-          const char* nl = (const char*)memchr(body, '\n', (size_t)(e - body));
-          const char* le = nl ? nl : e;
-          if (body < e) feed(body, (size_t)(le - body));
-          end = detail::next_line(detail::next_line(nl ? nl + 1 : e, e), e);                       // '+' line and quality line skipped
-        }
+        });
         if (!fits || len > 0x7fffffff) { overflow = 1; return; }
         r.hasN = st.finish() ? 1 : 0; r.len = (int32_t)len;
         cur += (len + 31) / 32 * 32;
@@ -589,23 +602,9 @@ class BatchReader {
         Rec r; r.hdr = q; r.keep = true; r.seg0 = S.size();
         const char* body = detail::next_line(q, e);
         r.body = body;
-        if (fasta) {
-          int64_t len = 0; const char* l = body;
-          while (l < e && *l != '>') {
-            const char* nl = (const char*)memchr(l, '\n', (size_t)(e - l));
-            const char* le = nl ? nl : e;
-            if (le > l) S.push_back(detail::Seg{l, (size_t)(le - l)});
-            len += le - l;
-            l = nl ? nl + 1 : e;
-          }
-          r.seqLen = len; r.end = l;
-        } else {
-          const char* nl = (const char*)memchr(body, '\n', (size_t)(e - body));
-          const char* le = nl ? nl : e;
-          r.seqLen = body < e ? le - body : 0;
-          if (r.seqLen) S.push_back(detail::Seg{body, (size_t)r.seqLen});
-          r.end = detail::next_line(detail::next_line(nl ? nl + 1 : e, e), e);   // '+' line and quality line skipped
-        }
+        int64_t len = 0;
+        r.end = detail::record_lines(body, e, fasta, [&](const char* l, size_t m) { S.push_back(detail::Seg{l, m}); len += (int64_t)m; });
+        r.seqLen = len;
         r.seg1 = S.size();
         R.push_back(r);
         q = r.end;
@@ -621,11 +620,10 @@ class BatchReader {
     detail::run_parallel(pool_, T, [&](unsigned t) {
       for (size_t i = 0; i < recs[t].size(); i++) {
         Rec& r = recs[t][i];
-        const char* hb = r.hdr + 1; const char* he = r.body > r.hdr && r.body[-1] == '\n' ? r.body - 1 : r.body;   // header line without its '\n'
-        if (he < hb) he = hb;
-        const char* sp = (const char*)memchr(hb, ' ', (size_t)(he - hb));
+        const char* nb; const char* ne;
+        detail::record_name(r.hdr, r.body, nb, ne);
         std::string& name = out.names[base + first[t] + i];
-        name.assign(hb, sp ? sp : he);
+        name.assign(nb, ne);
         r.keep = (keepPrefix_.empty() || name.compare(0, keepPrefix_.size(), keepPrefix_) == 0) && (keepSeq_.empty() || keepSeq_.count(name));
         if (!r.keep) r.seqLen = 0;
       }
