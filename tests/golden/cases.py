@@ -114,6 +114,9 @@ def paf_cases():
         ("dense_pi80_s20000", ref, long_reads, ["--dense", "--pi", "80", "-s", "20000"]),
         ("nosplit", ref, reads, ["--noSplit"]),                      # reads of 6.2, 10, 12 and 31 kbp at segLength 5000: windowLen != 0
         ("nosplit_pi90_n3", ref, reads + long_reads[:6], ["--noSplit", "--pi", "90", "-n", "3", "-s", "3000"]),
+        # k-mers of more than 32 bases (the reference hashes any length, commonFunc.hpp:138): assembly-like queries at 1-2 % divergence
+        ("k40_asm", ref, asm, ["-k", "40", "--pi", "95", "-s", "10000", "-f", "none"]),
+        ("k57_asm_pi97", ref, asm, ["-k", "57", "--pi", "97", "-s", "5000", "-n", "2"]),
     ]
 
 
