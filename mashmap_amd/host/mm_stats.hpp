@@ -38,8 +38,16 @@ inline double binomialUpperTail(unsigned k, double p, unsigned n) {
   // sum the smaller side to avoid cancellation
   const double mean = (double)n * p;
   if ((double)k + 1.0 >= mean) {
+    // At and beyond the mean the terms fall monotonically (t[i+1] / t[i] = (n - i) / (i + 1) * p / q <= np / (np + 1) < 1): once one is
+    // below 2^-64 of the running sum, adding it -- or any later one -- leaves every bit of the sum as it is (half an ulp is 2^-54 of it;
+    // the factor 2^10 between the two covers the ~1e-11 relative error of a computed term).  Same doubles as the full loop, which at
+    // sketch sizes of several thousand spends its time on terms that underflow (round 4: the tables behind sketchSize 9 998 took a minute).
     double acc = 0.0;
-    for (unsigned i = k + 1; i <= n; i++) acc += std::exp(lnChoose(n, i) + i * lp + (double)(n - i) * lq);
+    for (unsigned i = k + 1; i <= n; i++) {
+      const double t = std::exp(lnChoose(n, i) + i * lp + (double)(n - i) * lq);
+      acc += t;
+      if (t < acc * 0x1p-64) break;
+    }
     return acc > 1.0 ? 1.0 : acc;
   }
   double acc = 0.0;
@@ -225,9 +233,11 @@ inline void replayTables(int sketchSize, int k, float percentageIdentity, float 
         const double bestJaccardNumerator = best;
         const double cutoff_ani = std::max(0.0, double((1 - Stat::j2md(bestJaccardNumerator / Qs, k)) - ANIDiff));
         const double cutoff_j = Stat::md2j(1 - cutoff_ani, k);
-        int isz = 0;
-        while (isz <= Qs && double(isz) / Qs < cutoff_j) isz++;
-        minIsz[(size_t)Qs * stride + best] = (int16_t)isz;
+        // the smallest isz in [0, Qs + 1] for which double(isz) / Qs < cutoff_j no longer holds -- the reference counts up to it
+        // (:1196-1200); the predicate is monotone in isz (a division by a positive constant is), so a bisection finds the same one
+        int lo = 0, hi = Qs + 1;
+        while (lo < hi) { const int mid = lo + (hi - lo) / 2; if (double(mid) / Qs < cutoff_j) lo = mid + 1; else hi = mid; }
+        minIsz[(size_t)Qs * stride + best] = (int16_t)lo;
       }
     }
   };
