@@ -128,4 +128,66 @@ int hl_paf_formatters_agree(int n, unsigned long long seed) {
   return bad;
 }
 
+// The integer tables of mm_stats.hpp against their literal forms (round 4 shortened two loops of them without changing a bit): the
+// binomial tail summed over ALL its terms (what gsl_cdf_binomial_Q's stand-in did until then), md_lower_bound on that sum, and the L1
+// cut-off counted up as the reference does (computeMap.hpp:1196-1200).  Returns the number of entries that differ.
+namespace lit {
+inline double tailFull(unsigned k, double p, unsigned n) {
+  if (k >= n) return 0.0;
+  if (p <= 0.0) return 0.0;
+  if (p >= 1.0) return 1.0;
+  const double lp = std::log(p), lq = std::log1p(-p), mean = (double)n * p;
+  double acc = 0.0;
+  if ((double)k + 1.0 >= mean) { for (unsigned i = k + 1; i <= n; i++) acc += std::exp(mmhost::Stat::lnChoose(n, i) + i * lp + (double)(n - i) * lq); return acc > 1.0 ? 1.0 : acc; }
+  for (unsigned i = 0; i <= k; i++) acc += std::exp(mmhost::Stat::lnChoose(n, i) + i * lp + (double)(n - i) * lq);
+  return acc > 1.0 ? 0.0 : 1.0 - acc;
+}
+inline float mdLowerBound(float d, int s, int k, float ci) {
+  using namespace mmhost::Stat;
+  float q2 = (1.0 - ci) / 2;
+  int x = std::max(int(std::ceil(s * md2j(d, k))), 1);
+  while (x <= s) { double c = tailFull(x - 1, md2j(d, k), s); if (c < q2) { x--; break; } x++; }
+  return j2md(float(x) / s, k);
+}
+}  // namespace lit
+int hl_tables_vs_literal(int sketchSize, int k, float pi, int keepLow) {
+  using namespace mmhost;
+  std::vector<uint8_t> accept; std::vector<int16_t> minIsz;
+  replayTables(sketchSize, k, pi, fixed::ANIDiff, keepLow != 0, 4, accept, minIsz);
+  const size_t stride = (size_t)sketchSize + 1;
+  int bad = 0;
+  for (int Qs = 1; Qs <= sketchSize; Qs++) {
+    for (int shared = 0; shared <= Qs; shared++) {
+      const float md = Stat::j2md(1.0 * shared / Qs, k);
+      bool ok = (1 - md) >= pi;
+      if (!ok && keepLow) ok = (1 - lit::mdLowerBound(md, Qs, k, fixed::confidence_interval)) >= pi;
+      if (accept[(size_t)Qs * stride + shared] != (ok ? 1 : 0)) bad++;
+    }
+    for (int best = 0; best <= Qs; best++) {
+      const double cutoff_ani = std::max(0.0, double((1 - Stat::j2md((double)best / Qs, k)) - fixed::ANIDiff));
+      const double cutoff_j = Stat::md2j(1 - cutoff_ani, k);
+      int isz = 0; while (isz <= Qs && double(isz) / Qs < cutoff_j) isz++;
+      if (minIsz[(size_t)Qs * stride + best] != (int16_t)isz) bad++;
+    }
+  }
+  // the minimum-hits table walks md_lower_bound downwards from the first estimate (map_stats.hpp:144)
+  const std::vector<int32_t> mh = minHitsTable(sketchSize, k, pi);
+  for (int q = 1; q <= sketchSize; q++) {
+    const int first = Stat::estimateMinimumHits(q, k, pi);
+    int relaxed = first;
+    for (int i = first; i >= 0; i--) { const float d = Stat::j2md((float)(1.0 * i / q), k); if (1.0 - lit::mdLowerBound(d, q, k, fixed::confidence_interval) >= pi) relaxed = i; else break; }
+    if (mh[q] != relaxed) bad++;
+  }
+  return bad;
+}
+// the tail itself, bit for bit, on both of its branches; returns the number of (k, p, n) whose doubles differ
+int hl_tail_vs_full(void) {
+  int bad = 0;
+  for (unsigned n : {1u, 10u, 130u, 1000u, 4000u, 9998u}) for (double p : {1e-6, 0.001, 0.02, 0.3, 0.5, 0.7, 0.999}) for (unsigned k = 0; k < n; k += (n / 61 + 1)) {
+    const double a = mmhost::Stat::binomialUpperTail(k, p, n), b = lit::tailFull(k, p, n);
+    if (std::memcmp(&a, &b, sizeof a) != 0) bad++;
+  }
+  return bad;
+}
+
 }  // extern "C"

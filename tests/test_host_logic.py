@@ -150,3 +150,17 @@ def test_paf_text_by_to_chars_equals_the_stream_form(hl):
     hl.hl_paf_formatters_agree.argtypes = [C.c_int, C.c_ulonglong]
     for seed in (1, 2, 3):
         assert hl.hl_paf_formatters_agree(20000, seed) == 0
+
+
+@pytest.mark.parametrize("s,k,pi,keep_low", [(130, 19, 0.85, 1), (310, 19, 0.85, 1), (498, 16, 0.80, 1), (700, 19, 0.95, 1), (310, 40, 0.90, 0)])
+def test_integer_tables_equal_their_literal_forms(hl, s, k, pi, keep_low):
+    """replayTables / minHitsTable (mm_stats.hpp) against the literal loops: the binomial tail summed over all of its terms, the L1 cut-off
+    counted up as computeMap.hpp:1196-1200 does -- the shortened forms (tail sum stopped where a term can no longer change the sum, cut-off
+    bisected) must give every entry the same value"""
+    hl.hl_tables_vs_literal.restype = C.c_int
+    assert hl.hl_tables_vs_literal(C.c_int(s), C.c_int(k), C.c_float(pi), C.c_int(keep_low)) == 0
+
+
+def test_binomial_tail_equals_the_full_sum_bit_for_bit(hl):
+    hl.hl_tail_vs_full.restype = C.c_int
+    assert hl.hl_tail_vs_full() == 0
