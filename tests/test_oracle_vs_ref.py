@@ -52,6 +52,16 @@ def test_add_minmers(oracle, ref, cfg):
         assert np.array_equal(got[f], exp[f]), f
 
 
+@pytest.mark.parametrize("k,w,s", [(33, 1000, 40), (40, 5000, 130), (48, 2000, 60), (49, 3000, 75), (64, 5000, 100)])
+def test_add_minmers_long_kmers(oracle, ref, k, w, s):
+    """the reference side of the index at k-mer sizes beyond 32 (the winnow kernels' wide strips are checked against this oracle)"""
+    a = U.with_n_runs(U.random_dna(900 + k, 90000), 3, 8, 60)
+    got, exp = oracle.add_minmers(a, k, w, s, 1), ref.add_minmers(a, k, w, s, 1)
+    assert len(got) == len(exp) and len(exp) > 0
+    for f in ("hash", "wpos", "wpos_end", "seqId", "strand"):
+        assert np.array_equal(got[f], exp[f]), f
+
+
 @pytest.mark.parametrize("mode", ["default", "dense", "prefix"])
 def test_session_and_fragments(oracle, ref, mode):
     k, L, s, pi, flags, delim = 19, 5000, 130, 0.85, U.FLAG_HG, b"\0"
