@@ -64,3 +64,33 @@ def test_stats_match_real_reference(lib, ref):
             assert lib.mm_stat_j2md(j, 19) == ref.f("j2md")(j, 19)
         for q in range(1, s + 1, 3):
             assert lib.mm_stat_min_hits_relaxed(q, 19, 0.85) == ref.f("min_hits_relaxed")(q, 19, 0.85)
+
+
+# ---- the GSL boundary, pinned by a third derivation (tests/gslcheck.py: scipy's CDFs, the reference's float mixing restated in numpy)
+def test_gsl_boundary_minimum_hits_sketch_cutoffs_and_their_margins(lib):
+    """estimateMinimumHitsRelaxed (map_stats.hpp:81-169) for every Q.sketchSize and Map::sketchCutoffs (computeMap.hpp:178-258) at every
+    (k, pi, sketchSize) of BASELINE.json: equal to mm_stat_*, and no compared CDF value closer to its threshold than 1e-5 relative --
+    seven orders of magnitude more than any of the three CDF derivations (product, GSL stand-in, scipy) can be off."""
+    import gslcheck as G
+    M = G.Margins()
+    for k, pi, s in G.TABLE_CASES:
+        step = 1 if s <= 220 else 3                 # the two largest tables: every third Q.sketchSize (the whole table: python tests/gslcheck.py)
+        for q in list(range(1, s + 1, step)) + [s]:
+            assert G.estimate_minimum_hits_relaxed(q, k, pi, G.CI, M) == lib.mm_stat_min_hits_relaxed(q, k, pi), (k, pi, q)
+        assert G.sketch_cutoffs(s, k, M) == capi.stat_sketch_cutoffs(s, k).tolist(), (k, s)
+    assert set(M.best) == {"md_lower_bound: binomial_Q < q2", "sketchCutoffs: prAboveCutoff > min_p"}
+    assert M.floor() > 1e-5, M.best
+    # the closest comparison of each kind once more at 60 digits: same side of the threshold
+    for kind, (m, v, t, w) in M.best.items():
+        again = G.confirm_with_mpmath(kind, w)
+        assert (again > t) == (v > t) and abs(again - v) <= 1e-9 * t, (kind, v, again, t)
+
+
+def test_gsl_boundary_recommended_sketch_size(lib):
+    """recommendedSketchSize (map_stats.hpp:181-262) for SURVEY App. C's rows: the p-value crosses 1e-3 by at least a factor 5 at the
+    sketch size that is chosen and at the one before it"""
+    import gslcheck as G
+    for k, pi, L, R, exp in G.SKETCH_SIZE_ROWS:
+        M = G.Margins()
+        assert G.recommended_sketch_size(k, pi, L, R, M) == exp == lib.mm_stat_recommended_sketch_size(k, pi, L, R)
+        assert M.best["recommendedSketchSize: pValue <= 1e-3"][0] > 0.5, M.best
