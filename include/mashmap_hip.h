@@ -47,9 +47,9 @@ enum {
 typedef struct {
   int32_t kmerSize;       /* Parameters::kmerSize   (1..64; 16..32 take the tuned strip hasher, 19 -- the reference's default -- the tuned tail as well) */
   int32_t segLength;      /* Parameters::segLength  */
-  int32_t sketchSize;     /* Parameters::sketchSize (1 .. 20000.  Up to 8190 the sketch and L2 kernels keep their state in a CU's 160 KB of LDS -- mm_create
+  int32_t sketchSize;     /* Parameters::sketchSize (1 .. 10000.  Up to 8190 the sketch and L2 kernels keep their state in a CU's 160 KB of LDS -- mm_create
                              checks the combination with segLength and says what does not fit --; beyond, every fragment takes a global-memory sketch
-                             kernel and the literal L2 kernels: exact, not fast) */
+                             kernel and the literal L2 kernels: exact, not fast; 10000 is what the index build's LDS holds) */
   int32_t flags;          /* MM_FLAG_* */
 } mm_params;
 

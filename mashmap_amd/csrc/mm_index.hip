@@ -311,6 +311,7 @@ extern "C" int mm_index_build(mm_ctx* c, const char* bases, const int64_t* conti
   if (dbg) fprintf(stderr, "[mm] index: %zu records in %zu per-contig arrays at %.2f s\n", nRecords, nContigs, since());
   const int frc = finalize_built_index(c, per, kmerPctThreshold, clen.data(), refGroup, nContigs);
   if (dbg) fprintf(stderr, "[mm] index: Sketch::index + frequency filter + flat index on the device done at %.2f s (%zu keys, %zu points)\n", since(), c->idx.nKeys, c->idx.nPoints);
+  if (c->profile && frc == MM_OK) { MM_HIP(c, hipStreamSynchronize(c->stream)); mm_profile_collect(c); }   // the build's brackets (hash + winnow per contig) go back to the pool
   return frc;
 }
 

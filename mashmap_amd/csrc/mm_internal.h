@@ -154,21 +154,23 @@ struct mm_ctx {
 // brackets in flight); their times are read by mm_profile_collect once the stream has been synchronised anyway -- measuring a pass does
 // not add host waits to it (a steady-state pass stays at its one synchronisation with the per-kernel timers on).
 struct KernelTimer {
-  mm_ctx* c; int which; size_t idx = 0;
+  mm_ctx* c; int which; size_t idx = 0; bool on = false;
   KernelTimer(mm_ctx* c_, int w) : c(c_), which(w) {
     if (!c->profile) return;
     if (c->evUsed == c->evPool.size()) {
+      // the pool is recycled by mm_profile_collect (every profiled entry point that synchronises calls it); a caller that records
+      // thousands of brackets without one gets no more events than this, and a failing hipEventCreate switches the timers off
+      if (c->evPool.size() >= 8192) return;
       hipEvent_t a = nullptr, b = nullptr;
-      (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { if (a) (void)hipEventDestroy(a); c->profile = false; return; }
       c->evPool.emplace_back(a, b);
     }
     idx = c->evUsed++;
-    (void)hipEventRecord(c->evPool[idx].first, c->stream);
+    on = hipEventRecord(c->evPool[idx].first, c->stream) == hipSuccess;
   }
   ~KernelTimer() {
-    if (!c->profile) return;
-    (void)hipEventRecord(c->evPool[idx].second, c->stream);
-    c->evPending.emplace_back(which, idx);
+    if (!on) return;
+    if (hipEventRecord(c->evPool[idx].second, c->stream) == hipSuccess) c->evPending.emplace_back(which, idx);
   }
 };
 // adds the recorded brackets to kMs / kLaunches; the stream must have been synchronised behind them
@@ -188,7 +190,8 @@ int mm_launch_pack_raw(mm_ctx* c, const uint8_t* dAscii, const int64_t* dSrcOff,
 int mm_launch_sketch(mm_ctx* c);
 int mm_launch_sketch_global(mm_ctx* c);   // mm_sketch_global.hip: sketches no LDS table holds (sketchSize > MM_LDS_MAX_SKETCH)
 #define MM_LDS_MAX_SKETCH 8190             // beyond: the global-memory sketch kernel and the literal L2 kernels (any size up to MM_MAX_SKETCH)
-#define MM_MAX_SKETCH 20000                // the (sketchSize + 1)^2 acceptance tables of doL2Mapping's walk: 1.2 GB at this size
+#define MM_MAX_SKETCH 10000                // a window's sketch of the device index build (k_winnow_tiles: 16 bytes per entry + the candidate stage) must fit a CU's 160 KB of LDS;
+                                           // the reference's --dense at 100 kbp segments derives 9 998 (parseCmdArgs.hpp:626-630)
 int mm_launch_map(mm_ctx* c);
 // Steady state: once a pass of a context has sized every staging buffer, the next passes launch everything against
 // those capacities with the counts left on the device and read ONE block of counters back at the end (one host synchronisation per

@@ -589,6 +589,17 @@ k_l1_fix_offsets(int nFrags, const mm_frag_stats* __restrict__ stats, int64_t* _
   l1Off[f] = l1Off[f] - (int64_t)((unsigned long long)r * regionCap) + (int64_t)R->prefix[r];
 }
 
+// Steady-state passes read the L1 stage's overflow flags (counters[1] interval points, counters[3] L1 candidates) only when the whole
+// pass is over, so the L2 stage must be kept off what an overflowed L1 stage left behind: a region that overflowed has never-written
+// slots below its clamped count, the sweep path may have counted past the dense buffer, and more candidates than the previous pass
+// sized the candidate-indexed buffers for (candCap) do not fit them either.  One thread, behind the last L1 kernel: any of these zeroes
+// the candidate count -- every kernel of the L2 stage covers [0, counters[2]) and k_l2_select returns on a set flag -- and leaves (or
+// sets) the flag that makes the host redo the pass the sized way.
+__global__ void k_l1_gate(unsigned long long* __restrict__ counters, unsigned long long candCap) {
+  if (counters[1] | counters[3]) counters[2] = 0ull;
+  else if (counters[2] > candCap) { counters[3] = 1ull; counters[2] = 0ull; }
+}
+
 // ---------------------------------------------------------------------------------------------
 // point sorters for the queued fragments (ascending packed key == ascending (seqId, pos, CLOSE-before-OPEN))
 // ---------------------------------------------------------------------------------------------
@@ -1108,7 +1119,7 @@ static int map_pass(mm_ctx* c, const bool steady) {
   const unsigned long long* nBigDev = steady ? cnt + 7 : nullptr;
 
   const SeedTable seedTab{I.htSlots.as<HtSlot>(), (uint64_t)(I.htCap - 1), I.filter.as<uint64_t>(), (uint64_t)I.filterMask, I.tagged ? I.htTags.as<uint8_t>() : (const uint8_t*)nullptr};
-  unsigned long long hcur[MM_L1_REGIONS * MM_L1_CURSOR_STRIDE];
+  unsigned long long hcur[MM_L1_REGIONS * MM_L1_CURSOR_STRIDE] = {0};   // a steady-state pass never reads the cursors back
   unsigned long long regionCap = 0;
   for (int attempt = 0; attempt < 10; attempt++) {          // grow-and-retry on capacity overflow (points or L1 candidates)
     regionCap = (c->l1Cap + MM_L1_REGIONS - 1) / MM_L1_REGIONS + 64;
@@ -1169,7 +1180,10 @@ static int map_pass(mm_ctx* c, const bool steady) {
   }
   size_t denseCap = c->dL1.bytes / sizeof(mm_l1_candidate) - 4;   // room behind the fused candidates for the sweep path's
   const int nBig = (int)hc[7];
-  if (getenv("MM_DEBUG")) fprintf(stderr, "[mm] lookup+L1: %d fragments, %d to the sort+sweep path, %llu fused candidates\n", nF, nBig, hc[2]);
+  if (getenv("MM_DEBUG")) {
+    if (steady) fprintf(stderr, "[mm] lookup+L1: %d fragments, steady-state pass (the counts stay on the device)\n", nF);
+    else fprintf(stderr, "[mm] lookup+L1: %d fragments, %d to the sort+sweep path, %llu fused candidates\n", nF, nBig, hc[2]);
+  }
   if (steady || nBig > 0) {
     unsigned int* cls = (unsigned int*)(c->dCounters.as<unsigned long long>() + 16);   // [16] two 32-bit class counters
     // grids over the queued fragments: exact when their number is known, otherwise sized by what the previous pass saw (the kernels
@@ -1263,6 +1277,12 @@ static int map_pass(mm_ctx* c, const bool steady) {
     c->prevBig = c->lastBig = (size_t)nBig;
     if (c->nL1 == 0) { c->nL2 = 0; return rc; }
   }
+  if (steady) {
+    // candidates the buffers of this pass hold: what the previous (sized) pass left of candidate-indexed staging, and the dense L1 buffer itself
+    const unsigned long long cap = (unsigned long long)std::min(c->candCap, denseCap);
+    hipLaunchKernelGGL(k_l1_gate, dim3(1), dim3(1), 0, c->stream, cnt, cap);
+    MM_HIP(c, hipGetLastError());
+  }
   rc = mm_launch_l2(c, cnt, steady);
   if (rc != MM_OK) return rc;
   rc = mm_launch_select(c, steady);
@@ -1291,7 +1311,7 @@ int mm_launch_map(mm_ctx* c) {
   if (nF == 0) return MM_OK;
   const bool allSlow = c->keepPoints || (c->P.flags & MM_FLAG_SKIP_PREFIX) || c->windowed || c->P.sketchSize > MM_LDS_MAX_SKETCH;
   static const bool noSteady = getenv("MM_NO_STEADY") != nullptr;
-  if (c->steadyOk && c->steadyFails < 3 && !allSlow && !noSteady && !getenv("MM_DEBUG")) {
+  if (c->steadyOk && c->steadyFails < 3 && !allSlow && !noSteady) {
     const int rc = map_pass(c, true);
     if (rc == MM_OK) { c->lastSteady = true; c->steadyFails = 0; return MM_OK; }
     if (rc != MM_PASS_REDO) return rc;

@@ -784,7 +784,14 @@ int mm_check_params(const mm_params* p, std::string& err) {
   if (s > MM_LDS_MAX_SKETCH) {
     // no LDS kernel holds this sketch: the global-memory sketch kernel (mm_sketch_global.hip) and the literal L2 kernels take every
     // fragment -- exact, slow; the stock binary runs these sizes (--dense at segments of 100 kbp), so they run here too
-    if (s > MM_MAX_SKETCH) { err = "mm_create: sketchSize " + std::to_string(s) + " is beyond " + std::to_string(MM_MAX_SKETCH) + " (the (sketchSize + 1)^2 tables of the L2 walk)"; return MM_ERR_ARG; }
+    // ... except the index build: k_winnow_tiles (mm_winnow.hip) keeps the sketch of a reference window in LDS, 16 bytes per entry next to
+    // at least 64 candidates of 13 bytes -- checked here, so that a context mm_create accepts is one mm_index_build can serve
+    const size_t ldsWinnow = (size_t)(s + 1) * 16 + 64 * 13 + 16;
+    if (s > MM_MAX_SKETCH || ldsWinnow > lim) {
+      err = "mm_create: sketchSize " + std::to_string(s) + " is beyond " + std::to_string(MM_MAX_SKETCH) + " (the device index build holds a window's sketch in LDS: " +
+            std::to_string(ldsWinnow) + " bytes of a CU's " + std::to_string(lim) + ")";
+      return MM_ERR_ARG;
+    }
     return MM_OK;
   }
   if (!P.ok || ldsL2 > lim || ldsLoc > lim) {

@@ -37,6 +37,7 @@
 #include <fstream>
 #include <functional>
 #include <iostream>
+#include <limits>
 #include <memory>
 #include <mutex>
 #include <numeric>
@@ -222,6 +223,12 @@ class Map {
         if (!more) { HostBufferPool::instance().give(batch.in.bases, batch.in.cap); break; }
         batch.firstSeqCounter = seqCounter;
         for (size_t r = 0; r < batch.size(); r++) {
+          if (batch.in.offs[r + 1] - batch.in.offs[r] > (int64_t)std::numeric_limits<offset_t>::max()) {       // see Sketch::build: no LARGE_CONTIG variant
+            std::cerr << "[mashmap::skch::Map::mapQuery] ERROR: query sequence " << batch.in.names[r] << " has " << (batch.in.offs[r + 1] - batch.in.offs[r])
+                      << " bp; sequences of more than " << std::numeric_limits<offset_t>::max()
+                      << " bp need the reference's LARGE_CONTIG build (64-bit offset_t), which mashmap_hip does not provide" << std::endl;
+            exit(1);
+          }
           const offset_t len = (offset_t)(batch.in.offs[r + 1] - batch.in.offs[r]);
           totalBp += (uint64_t)len;
           if (param.filterMode == filter::ONETOONE) qmetadata.push_back(ContigInfo{batch.in.names[r], len});

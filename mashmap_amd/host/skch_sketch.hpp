@@ -16,7 +16,9 @@
 #include <filesystem>
 #include <fstream>
 #include <iostream>
+#include <limits>
 #include <sstream>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <unordered_set>
@@ -35,6 +37,7 @@ class Sketch {
   size_t nMinmers_ = 0;                            // |minmerIndex| on the device (after the frequent-seed drop)
   mm_ctx* ctx_ = nullptr;                          // the context the index is built on (first device of the list)
   std::vector<mm_ctx*> ctxs_;                      // one per entry of MASHMAP_HIP_DEVICES; ctxs_[0] == ctx_
+  mutable std::mutex materializeMu_; mutable bool minmerIndexReady_ = false;
   Sketch();
 
   [[noreturn]] void die(const char* what) const {
@@ -50,7 +53,7 @@ class Sketch {
   std::vector<ContigInfo> metadata;
   std::vector<int> sequencesByFileInfo;
   MI_Map_t minmerPosLookupIndex;                   // see materializeLookupIndex()
-  MI_Type minmerIndex;
+  mutable MI_Type minmerIndex;                     // filled on first use (materializeMinmerIndex)
 
   // MASHMAP_HIP_DEVICES=0,1,... : the GPUs query batches are sharded over (index replicated);
   // MASHMAP_HIP_DEVICE=n : a single one (default 0).  A device may be listed twice (two contexts on one GPU).
@@ -122,18 +125,22 @@ class Sketch {
   int getFreqThreshold() const { return freqThreshold; }
   bool isFreqSeed(hash_t h) const { return std::binary_search(frequentSeeds.begin(), frequentSeeds.end(), h); }
   // minmerIndex (winSketch.hpp:102) lives on the device; the host copy in reference layout is made on first use
-  void materializeMinmerIndex() {
-    if (minmerIndex.size() == nMinmers_) return;
+  // (the reference's callers read the index from many threads at once -- mapModule through searchIndex -- so the first use is serialised;
+  // code that reads the public member directly calls this first, or sets MASHMAP_HIP_EAGER_INDEX=1)
+  void materializeMinmerIndex() const {
+    std::lock_guard<std::mutex> lk(materializeMu_);
+    if (minmerIndexReady_) return;
     minmerIndex.resize(nMinmers_);
     if (nMinmers_ && mm_index_download(ctx_, reinterpret_cast<mm_minmer*>(minmerIndex.data()), nullptr, nullptr, nullptr, nullptr) != MM_OK) die("mm_index_download");
+    minmerIndexReady_ = true;
   }
   size_t minmerIndexSize() const { return nMinmers_; }
   MIIter_t searchIndex(seqno_t seqId, offset_t winpos) const {
-    const_cast<Sketch*>(this)->materializeMinmerIndex();
+    materializeMinmerIndex();
     return std::lower_bound(minmerIndex.begin(), minmerIndex.end(), MinmerInfo{0, winpos, 0, seqId, 0});
   }
   bool isMinmerIndexEnd(const MIIter_t& it) const { return it == minmerIndex.end(); }
-  MIIter_t getMinmerIndexEnd() const { const_cast<Sketch*>(this)->materializeMinmerIndex(); return minmerIndex.end(); }
+  MIIter_t getMinmerIndexEnd() const { materializeMinmerIndex(); return minmerIndex.end(); }
 
   // the hash -> interval points map of winSketch.hpp:100-101 on the host (only callers outside the device path need it)
   void materializeLookupIndex() {
@@ -264,6 +271,14 @@ class Sketch {
       mmhost::ParsedBatch b;
       while (rd.next(b)) {
         for (size_t r = 0; r < b.size(); r++) {
+          // offset_t is int32 here as in the reference's default build (base_types.hpp:17-22); its -DLARGE_CONTIG variant (int64
+          // coordinates, CMakeLists.txt:23) has no counterpart in the device layouts, so such a contig is refused, not truncated
+          if (b.offs[r + 1] - b.offs[r] > (int64_t)std::numeric_limits<offset_t>::max()) {
+            std::cerr << "[mashmap::skch::Sketch::build] ERROR: reference sequence " << b.names[r] << " has " << (b.offs[r + 1] - b.offs[r])
+                      << " bp; contigs of more than " << std::numeric_limits<offset_t>::max()
+                      << " bp need the reference's LARGE_CONTIG build (64-bit offset_t), which mashmap_hip does not provide" << std::endl;
+            exit(1);
+          }
           metadata.push_back(ContigInfo{b.names[r], (offset_t)(b.offs[r + 1] - b.offs[r])});
           seqCounter++;
         }

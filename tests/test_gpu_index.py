@@ -54,3 +54,16 @@ def test_index_frequent_seeds(oracle):
 def test_index_parameter_grid(oracle, k, s, L):
     contigs = [("x", U.random_dna(7 + k, 150000)), ("y", U.tandem_repeat(8, 60000, 311)), ("z", U.with_n_runs(U.random_dna(9, 50000), 2, 6, 40))]
     _compare(oracle, contigs, k, L, s)
+
+
+def test_index_at_the_largest_sketch_size_and_refusal_beyond(oracle):
+    """sketchSize 10 000 is the most mm_create accepts: the device index build keeps a window's sketch in LDS (k_winnow_tiles, 16 bytes per
+    entry), and a context that is accepted must be one mm_index_build can serve (round 4 accepted up to 20 000 and would have failed
+    inside the build).  The reference's --dense at 100 kbp segments derives 9 998 (parseCmdArgs.hpp:626-630).  Device-built index at the
+    limit against the oracle, record for record; one beyond it refused with the sizes in the message."""
+    from mashmap_amd import capi
+    contigs = [("c0", U.random_dna(901, 330000)), ("c1", U.with_n_runs(U.random_dna(902, 250000), 2, 20, 300))]
+    nm, _ = _compare(oracle, contigs, k=19, L=100000, s=10000)
+    assert nm > 10000
+    with pytest.raises(capi.MashmapError, match="sketchSize 10001 is beyond 10000"):
+        capi.Context(k=19, segLength=100000, sketchSize=10001)

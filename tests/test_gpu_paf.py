@@ -168,3 +168,28 @@ def test_save_and_load_index_interoperate_with_the_reference(tmp_path):
         assert mine[2] == theirs[2], "interval point lists differ"
         assert _run(HIP_BIN, td, "default", refrec, qrec, ["--loadIndex", td + "/refidx"], "hloadref") == exp
         assert _run(U.REF_BIN, td, "default", refrec, qrec, ["--loadIndex", td + "/hipidx"], "rloadhip") == exp
+
+
+def test_contig_beyond_int32_is_refused_not_truncated(tmp_path):
+    """offset_t is int32 here as in the reference's default build (base_types.hpp:17-22); its -DLARGE_CONTIG variant (64-bit
+    coordinates, CMakeLists.txt:23) is not provided.  A 2^31 + 1 bp contig -- as reference or as query -- must end the run with exit
+    code 1 and a message in the reference's style that names the sequence, not wrap its length into a negative int."""
+    big = os.path.join(str(tmp_path), "big.fa")
+    n = (1 << 31) + 1
+    with open(big, "wb") as f:
+        f.write(b">giant\n")
+        line = b"ACGTTGCA" * 8192 + b"\n"                      # 65 536 bases per line
+        full, rest = divmod(n, 65536)
+        blk = line * 256
+        for _ in range(full // 256):
+            f.write(blk)
+        f.write(line * (full % 256))
+        f.write(b"A" * rest + b"\n")
+    small = os.path.join(str(tmp_path), "small.fa")
+    U.write_fasta(small, [("chr0", U.random_dna(7, 60000))])
+    out = os.path.join(str(tmp_path), "o.paf")
+    for ref, qry, where in ((big, small, "Sketch::build] ERROR: reference sequence giant has 2147483649 bp"),
+                            (small, big, "Map::mapQuery] ERROR: query sequence giant has 2147483649 bp")):
+        p = subprocess.run([HIP_BIN, "-r", ref, "-q", qry, "-o", out, "-t", "4"], capture_output=True, text=True)
+        assert p.returncode == 1, (p.returncode, p.stderr[-600:])
+        assert where in p.stderr and "LARGE_CONTIG" in p.stderr, p.stderr[-600:]
