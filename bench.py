@@ -1,15 +1,19 @@
 #!/usr/bin/env python3
 """bench.py -- query Gbp/s of the sketch + L1/L2 hot path on N MI355X (one process per GPU).
 
-  python bench.py --gpus N --steps K --warmup W [--workload configs1|configs3|configs4]
+  python bench.py --gpus N --steps K --warmup W [--workload configs1|configs3|configs4|northstar] [--batches B]
 
 With N > 1 and no torch.distributed environment the script starts its own N ranks (torch.distributed.run, 127.0.0.1); started by
 a launcher it checks that WORLD_SIZE == N.  It never prints an `n_gpus` other than the N it was asked for.
 
-A "step" = one pass of the hot path (sketch -> seed lookup -> L1 -> L2 slide -> doL2Mapping's best-first selection) over the
-resident batch; inputs (2-bit packed bases + N mask) are already in HBM when the timed region starts.  For N > 1 every rank maps
-its own reads (weak scaling: `reads` per GPU, index replicated) and the step ends with the RCCL all-gatherv of the candidate
-mappings (mm_allgatherv_mappings, mashmap_amd/csrc/mm_comm.hip) -- the product's own exchange step, not a Python stand-in.
+A "step" = one pass of the hot path (sketch -> seed lookup -> L1 -> L2 slide -> doL2Mapping's best-first selection) over one resident
+batch; inputs (2-bit packed bases + N mask) are already in HBM when the timed region starts.  B = 3 DISTINCT batches of the workload
+(different reads, same shape) are resident and take turns (mm_reads_exchange: a pointer swap), so a pass is never sized by a previous
+pass over the same reads; `passes` in the line says how many of the timed passes went through as steady-state passes (one host wait)
+and how many outgrew a buffer and were redone.  For N > 1 every rank maps its own reads (weak scaling: `reads` per GPU and batch, index
+replicated) and the step ends with the RCCL all-gatherv of the candidate mappings (mm_allgatherv_mappings_begin/_end,
+mashmap_amd/csrc/mm_comm.hip) -- the product's own exchange step, overlapped with the next batch, the last one waited for inside the
+timed region.
 
 Workloads (BASELINE.json `configs`; the default is configs[1], the configuration the metric is quoted on):
   configs1  1 M x 10 kbp reads (10 % ONT-like error) vs 100 Mbp, pi 85, segLength 5000, sketchSize 130
@@ -20,10 +24,13 @@ Workloads (BASELINE.json `configs`; the default is configs[1], the configuration
             space, winSketch.hpp:174-214), --dense --pi 80 => sketchSize 498
 --reads / --ref-contigs / --ref-contig-len scale a workload down; the JSON line names what actually ran.
 
-The default run (configs1, nothing scaled, one GPU) also measures the north_star target sentence itself -- 1 M x 10 kbp reads at pi 85
-against the human-scale (3 Gbp) index -- after the headline measurement and attaches it as the extra key `north_star_target`
-(stock segLength 5000, and a segLength 10000 variant: the sentence says "10 kbp segments"); `value` / `config` / `roofline` stay the
-configs[1] figures.  --no-north-star skips it.
+The default run (configs1, nothing scaled, one GPU) carries three more measurements behind the headline one, as extra keys; `value` /
+`config` / `roofline` stay the configs[1] figures:
+  e2e                 the `mashmap_hip` command line FASTA -> PAF on configs[1] (10 GB of FASTA written to a temporary directory), per stage
+  north_star_target   the north_star sentence -- 1 M x 10 kbp reads at pi 85 against the human-scale (3 Gbp) index --, stock segLength 5000
+                      and the "10 kbp segments" variant, the stock binary beside it; and `repeat_rich`: the same workload on a reference
+                      with human-like repeat structure (make_repeat_rich_reference: ~45 % interspersed repeat families, satellites, N gaps)
+--no-e2e / --no-north-star skip them.
 """
 import argparse
 import json
@@ -71,6 +78,88 @@ def make_reference(torch, dev, ncontigs, clen, seed=1):
                    else torch.cat([lut[torch.randint(0, 4, (min(1 << 27, clen - o),), generator=g, device=dev, dtype=torch.int32).long()]
                                    for o in range(0, clen, 1 << 27)]))
     return out
+
+
+# Human-like repeat structure for `north_star_target.repeat_rich` and tests/humanscale.py (sizes are for a 3 Gbp reference; copy numbers scale
+# with the reference so that the covered fraction stays): interspersed repeat families over ~45 % of the sequence -- copy numbers from 10^2
+# to 10^5, copies diverged from their family's consensus by 10-20 % (i.i.d. substitutions, random strand), the numerous families the more
+# diverged ones as in real genomes (old families are both) --, one satellite array per contig (171 bp monomers in a 12-monomer higher-order
+# repeat, copies 2 % apart) and N gaps.  (family, families, consensus bp, copies per family at 3 Gbp, 5'-truncated copies)
+REPEAT_FAMILIES = [("SINE-like", 10, 300, 100_000, False),               # 300 Mbp
+                   ("LINE-like", 20, 6000, 10_000, True),                # copies keep the last 500..6000 bp: 650 Mbp
+                   ("LTR/DNA-like", 100, 2000, 1_000, False),            # 200 Mbp
+                   ("segmental-duplication-like", 200, 10_000, 100, False)]   # 200 Mbp
+SATELLITE_BP, SATELLITE_MONOMER, SATELLITE_HOR, SATELLITE_DIV = 250_000, 171, 12, 0.02
+NGAP_BP, NGAP_END_BP = 500_000, 10_000
+
+
+def repeat_divergence(copies_at_3gbp):
+    return 0.10 + 0.10 * (np.log10(copies_at_3gbp) - 2.0) / 3.0
+
+
+def make_repeat_rich_reference(torch, dev, ncontigs, clen, seed=11):
+    """a reference with the repeat structure described at REPEAT_FAMILIES, as `ncontigs` consecutive views of one uint8 tensor (ASCII);
+    returns (contigs, summary)"""
+    g = torch.Generator(device=dev); g.manual_seed(seed)
+    total = ncontigs * clen
+    scale = total / 3e9
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    whole = torch.empty(total, dtype=torch.uint8, device=dev)
+    for o in range(0, total, 1 << 27):
+        n = min(1 << 27, total - o)
+        whole[o:o + n] = torch.randint(0, 4, (n,), generator=g, device=dev, dtype=torch.int32).to(torch.uint8)      # codes 0..3 until the end
+    covered = 0
+    fams = []
+    for name, nfam, clen_f, copies3, trunc in REPEAT_FAMILIES:
+        copies = max(2, int(round(copies3 * scale)))
+        div = float(repeat_divergence(copies3))
+        ar = torch.arange(clen_f, device=dev)
+        for _ in range(nfam):
+            cons = torch.randint(0, 4, (clen_f,), generator=g, device=dev, dtype=torch.int32).to(torch.uint8)
+            for c0 in range(0, copies, 1 << 14):                      # 16 k copies at a time (a LINE-like block is 100 M cells)
+                n = min(1 << 14, copies - c0)
+                cp = cons[None, :].expand(n, clen_f).clone()
+                sub = torch.rand(n, clen_f, generator=g, device=dev) < div
+                cp = torch.where(sub, (cp + torch.randint(1, 4, (n, clen_f), generator=g, device=dev, dtype=torch.int32).to(torch.uint8)) & 3, cp)
+                keep = torch.ones(n, clen_f, dtype=torch.bool, device=dev)
+                if trunc:
+                    ln = torch.randint(min(500, clen_f), clen_f + 1, (n,), generator=g, device=dev)
+                    keep = ar[None, :] >= (clen_f - ln)[:, None]
+                rev = torch.rand(n, generator=g, device=dev) < 0.5
+                cp = torch.where(rev[:, None], (3 - cp).flip(1), cp)
+                keep = torch.where(rev[:, None], keep.flip(1), keep)
+                ci = torch.randint(0, ncontigs, (n,), generator=g, device=dev)
+                st = (torch.rand(n, generator=g, device=dev, dtype=torch.float64) * (clen - clen_f)).long()
+                idx = (ci * clen + st)[:, None] + ar[None, :]
+                whole[idx[keep]] = cp[keep]
+                covered += int(keep.sum())
+                del cp, sub, keep, idx
+        fams.append({"family": name, "families": nfam, "consensus_bp": clen_f, "copies_per_family": copies, "divergence": round(div, 3)})
+    # satellites: one array per contig at 40 % of its length
+    sat_bp = min(SATELLITE_BP, clen // 20)
+    hor_len = SATELLITE_MONOMER * SATELLITE_HOR
+    for c in range(ncontigs):
+        mono = torch.randint(0, 4, (SATELLITE_MONOMER,), generator=g, device=dev, dtype=torch.int32).to(torch.uint8)
+        hor = mono.repeat(SATELLITE_HOR)
+        m = torch.rand(hor_len, generator=g, device=dev) < 0.25           # the monomers of the higher-order unit differ from each other
+        hor = torch.where(m, (hor + torch.randint(1, 4, (hor_len,), generator=g, device=dev, dtype=torch.int32).to(torch.uint8)) & 3, hor)
+        arr = hor.repeat(sat_bp // hor_len + 1)[:sat_bp]
+        m = torch.rand(sat_bp, generator=g, device=dev) < SATELLITE_DIV
+        arr = torch.where(m, (arr + torch.randint(1, 4, (sat_bp,), generator=g, device=dev, dtype=torch.int32).to(torch.uint8)) & 3, arr)
+        o = c * clen + int(clen * 0.4)
+        whole[o:o + sat_bp] = arr
+    for o in range(0, total, 1 << 27):
+        n = min(1 << 27, total - o)
+        whole[o:o + n] = lut[whole[o:o + n].long()]
+    gap, end = min(NGAP_BP, clen // 50), min(NGAP_END_BP, clen // 1000)
+    for c in range(ncontigs):
+        o = c * clen
+        whole[o:o + end] = ord("N"); whole[o + clen - end:o + clen] = ord("N")
+        whole[o + int(clen * 0.6):o + int(clen * 0.6) + gap] = ord("N")
+    summary = {"generator": "bench.make_repeat_rich_reference(seed %d)" % seed, "interspersed_repeat_fraction": round(covered / total, 3), "families": fams,
+               "satellite": "%d bp array per contig: %d bp monomers in a %d-monomer higher-order repeat, copies %.0f %% apart" % (sat_bp, SATELLITE_MONOMER, SATELLITE_HOR, SATELLITE_DIV * 100),
+               "n_gaps": "%d bp inside every contig, %d bp at both ends" % (gap, end)}
+    return [whole[c * clen:(c + 1) * clen] for c in range(ncontigs)], summary
 
 
 def contiguous_views(torch, contigs):
@@ -218,9 +307,9 @@ def cpu_baseline(W, ref_np, reads_np, n_sample):
                                "gbps_usable_cpus_ideal": round(n_sample * read_len / tot / 1e9 * usable_cpus(), 3)}
             if best:
                 tmap, nt = best
-                return {"value": n_sample * read_len / tmap / 1e9, "unit": "Gbp/s", "cores": nt, "kind": "reference",
-                        "sample": desc + "; mashmap_ref (built from the reference sources) best of -t 8/32/64 = -t %d of %d host cores, "
-                                         "'time spent mapping the query' (includes its single-threaded FASTA reader); this process may use %d CPUs at once (affinity / container quota)" % (nt, ncores, usable_cpus()),
+                return {"value": n_sample * read_len / tmap / 1e9, "unit": "Gbp/s", "cores": usable_cpus(), "threads": nt, "host_hardware_threads": ncores, "kind": "reference",
+                        "sample": desc + "; mashmap_ref (built from the reference sources) best of -t 8/32/64 = -t %d; `cores` = the %d CPUs this process may use at once "
+                                         "(affinity / container quota) of the host's %d hardware threads; 'time spent mapping the query' (includes its single-threaded FASTA reader)" % (nt, usable_cpus(), ncores),
                         "fragment_compute": compute}
             log("[cpu_baseline] reference binary failed, falling back to the port:", p.stderr[-300:])
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -275,15 +364,30 @@ def host_path(ctx, W, nreads, ref_lens, steps_ms):
             "note": "skch::Map overlaps the host stage of batch i with the device stage of batch i+1 (pipelined); serial = no overlap"}
 
 
+def csrc_sha16():
+    """hash of the kernel sources (mashmap_amd/csrc/*.hip, *.h) as they lie: lets a line say whether committed PMC counters belong to this tree"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "mashmap_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "mashmap_amd", "csrc", "*.h"))):
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_entry(workload_key, kernel="k_sketch_fast"):
     """counters of one kernel from the committed PMC passes of this workload (profiles/pmc_traffic.json: per workload, per kernel,
-    per launch), and where they came from -- they are NOT measured in the bench run itself"""
+    per launch), and where they came from -- they are NOT measured in the bench run itself; `pmc_age` says which tree they were taken on
+    and whether the kernel sources have changed since"""
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         wl = json.load(open(pmc)).get(workload_key)
         if not wl or kernel not in wl:
             return None, None
-        return wl[kernel], "profiles/pmc_traffic.json [%s] (rocprofv3 --pmc passes %s of this workload; not measured in this run)" % (workload_key, wl.get("_source", "?"))
+        then, now = wl.get("_csrc_sha16"), csrc_sha16()
+        age = {"file": "profiles/pmc_traffic.json[%s]" % workload_key, "passes": "profiles/%s_pmc_*.csv" % wl.get("_source", "?"), "collected": wl.get("_collected", "?"),
+               "csrc_sha16_then": then, "csrc_sha16_now": now, "kernel_sources_unchanged": (then == now) if then else None,
+               "note": "rocprofv3 --pmc passes of this workload, committed; not measured in this run"}
+        return wl[kernel], age
     except Exception:
         return None, None
 
@@ -316,17 +420,24 @@ def kernel_rooflines(ctx, W, workload_key, nF, prof, mean_points, pmc_ok):
             continue
         avg = ms / n * (n / max(1, prof["sketch"][1]))          # several brackets per pass (e.g. extents + locate): per pass
         ach = bytes_launch / (avg / 1e3) / 1e9
-        ent, src = pmc_entry(workload_key, kern) if pmc_ok else (None, None)
+        ent, age = pmc_entry(workload_key, kern) if pmc_ok else (None, None)
         out.append({"kernel": kern, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
                     "avg_ms_per_pass": round(avg, 3), "algorithmic_bytes_per_launch": bytes_launch, "algorithmic_bytes": what, "binds": binds,
                     "traffic": ent.get("hbm_bytes_per_launch") if ent else None,
-                    "valu_wave_instructions_per_launch": ent.get("SQ_INSTS_VALU") if ent else None, "source": src})
+                    "valu_wave_instructions_per_launch": ent.get("SQ_INSTS_VALU") if ent else None, "pmc_age": age})
     return out
 
 
+VALU_PEAK_GINST = SIMDS * CLOCK_HZ / 2.0 / 1e9   # wave64 VALU instructions per second the part can issue at the guide's nominal 2 cycles each (SIMD-32)
+VALU_MIX_CYCLES = 3.35                           # cycles per wave-instruction of the sketch kernel's VOP3/VOP2 mix (profiles/r02_valu_rate.txt, r02_sketch_instruction_mix.txt)
+
+
 def roofline_block(ctx, capi, W, workload_key, nF, prof, step_ms, pmc_ok, mean_points=0.0):
-    """roofline of the dominant kernel (k_sketch_fast): algorithmic bytes per fragment = L/4 packed bases in + 24 B per sketch entry out
-    (SURVEY section 8d), divided by its average HIP-event duration in the timed region; the integer yardstick; VALU issue peaks"""
+    """roofline of the dominant kernel (k_sketch_fast).  What binds it is VALU issue (2 x MurmurHash3_x64_128 per base, 0.25 B/bp in): `bound`
+    is "valu", `achieved` = wave64 VALU instructions per launch (PMC SQ_INSTS_VALU of the committed passes of this workload) / the kernel's
+    average HIP-event duration in THIS run, `peak` = 1024 SIMDs x 2.4 GHz / 2 cycles (MI355X_MICROARCH.md).  `hbm` is the secondary entry:
+    algorithmic bytes per fragment = L/4 packed bases in + 24 B per sketch entry out over the same duration against 8 TB/s,
+    and the PMC traffic.  `int` is the hash-only yardstick of SURVEY 8d(ii), measured in this run."""
     SEG, SKETCH = W["seg"], W["sketch"]
     sk_ms, sk_n = prof["sketch"]
     sk_avg = sk_ms / max(1, sk_n)
@@ -343,46 +454,85 @@ def roofline_block(ctx, capi, W, workload_key, nF, prof, step_ms, pmc_ok, mean_p
     except capi.MashmapError as e:
         log("[bench] hash-only microbenchmark unavailable:", e)
     # HBM bytes / VALU instructions per launch of that kernel from the committed PMC passes of the same workload
-    traffic = valu = source = None
+    traffic = ninst = age = None
     if pmc_ok:
-        ent, source = pmc_entry(workload_key)
+        ent, age = pmc_entry(workload_key)
         if ent:
             traffic = ent.get("hbm_bytes_per_launch")
             ninst = ent.get("SQ_INSTS_VALU")
-            if ninst and sk_avg > 0:
-                per_s = ninst / (sk_avg * 1e-3)
-                mix = 3.35                          # cycles per wave-instruction of this kernel's VOP3/VOP2 mix (profiles/r02_valu_rate.txt, r02_sketch_instruction_mix.txt)
-                valu = {"wave_instructions_per_launch": ninst,
-                        "util_vs_2_cycles_per_instr": round(per_s / (SIMDS * CLOCK_HZ / 2.0), 3),
-                        "util_vs_measured_mix": round(per_s / (SIMDS * CLOCK_HZ / mix), 3),
-                        "util_vs_4_cycles_per_instr": round(per_s / (SIMDS * CLOCK_HZ / 4.0), 3),
-                        "model": "1024 SIMDs x 2.4 GHz; three issue peaks: 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md nominal, SIMD-32), "
-                                 "%.2f cycles (this kernel's mix of VOP3 integer ops at ~4.2 and VOP2 ops at ~2.3 cycles measured by "
-                                 "scripts/probes/valu_rate.hip, output in profiles/), 4 cycles (every instruction at the VOP3 rate)" % mix}
+    hbm = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
+           "algorithmic_bytes_per_fragment": frag_bytes, "algorithmic_bytes_per_launch": frag_bytes * nF,
+           "note": "small by construction: the kernel reads 0.25 B/bp and evaluates two full MurmurHash3_x64_128 per base"}
     kernels = kernel_rooflines(ctx, W, workload_key, nF, prof, mean_points, pmc_ok)
-    return {"bound": "hbm", "kernel": "k_sketch_fast", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernels": kernels,
-            "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": source,
-            "algorithmic_bytes_per_fragment": frag_bytes, "avg_launch_ms": round(sk_avg, 3),
-            "algorithmic_bytes_per_launch": frag_bytes * nF,
-            "note": "integer-issue bound kernel (2 x MurmurHash3_x64_128 per base); the HBM fraction is small by construction -- "
-                    "`int` (hash-only yardstick) and `valu` (issue peaks) are the rooflines that bind, DESIGN.md section 3",
-            "int": integer, "valu": valu}
+    out = {"kernel": "k_sketch_fast", "avg_launch_ms": round(sk_avg, 3), "traffic": traffic, "pmc_age": age, "hbm": hbm, "int": integer, "kernels": kernels}
+    if ninst and sk_avg > 0:
+        per_s = ninst / (sk_avg * 1e-3) / 1e9
+        out.update({"bound": "valu", "achieved": round(per_s, 2), "peak": round(VALU_PEAK_GINST, 1), "unit": "G wave64 VALU instructions/s",
+                    "frac": round(per_s / VALU_PEAK_GINST, 4),
+                    "frac_vs_measured_mix": round(per_s / (VALU_PEAK_GINST * 2.0 / VALU_MIX_CYCLES), 4),
+                    "valu_wave_instructions_per_launch": ninst,
+                    "note": "VALU-issue bound kernel.  peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction (MI355X_MICROARCH.md nominal, what v_fma_f32 reaches); "
+                            "frac_vs_measured_mix = against %.2f cycles per instruction, this kernel's mix of VOP3 integer ops (~4.2 cycles) and VOP2 ops (~2.3) as "
+                            "scripts/probes/valu_rate.hip measures them on this part (profiles/r02_valu_rate.txt).  Instructions per launch from committed PMC passes "
+                            "(pmc_age), duration from this run's HIP events" % VALU_MIX_CYCLES})
+    else:                                    # no counters for this workload (scaled run): the HBM figures are all there is
+        out.update({"bound": "hbm", "achieved": hbm["achieved"], "peak": hbm["peak"], "unit": hbm["unit"], "frac": hbm["frac"],
+                    "note": "no committed SQ_INSTS_VALU pass for this workload: the HBM figures stand in; the kernel is VALU-issue bound (see `int`)"})
+    return out
 
 
-def timed_passes(ctx, warmup, steps):
-    """W untimed passes, then K timed ones bracketed by a stream synchronisation; returns (seconds, per-kernel HIP-event times)"""
+def load_batches(torch, dev, ctx, contigs, W, nreads, nb, seed, seq_base=0, keep_first=0):
+    """nb distinct batches of the workload's reads (same shape, different reads) uploaded and packed on the device; the last one stays
+    resident, the others are parked in slots 0 .. nb-2 (mm_reads_exchange).  Returns (fragments of the resident batch, the first
+    `keep_first` reads of batch 0 as a host array or None)."""
+    L = W["read_len"]
+    offs = np.arange(nreads + 1, dtype=np.int64) * L
+    first = None
+    nF = 0
+    for b in range(nb):
+        reads_t = make_reads(torch, dev, contigs, nreads, L, W["err"], seed=seed + 7919 * b)
+        torch.cuda.synchronize()
+        if b == 0 and keep_first:
+            first = reads_t[:keep_first * L].cpu().numpy()
+        nF = ctx.reads_upload_device(reads_t.data_ptr(), reads_t.numel(), offs, seqCounterBase=seq_base)
+        del reads_t
+        torch.cuda.empty_cache()
+        if b < nb - 1:
+            ctx.reads_exchange(b)
+    return nF, first
+
+
+class Rotation:
+    """the resident batches taking turns: before pass i the resident batch goes to slot i % (nb - 1) and the one parked there becomes
+    resident -- with nb batches and nb - 1 slots that visits all nb in a fixed cycle (nb = 3: C A B C A B ...)"""
+
+    def __init__(self, ctx, nb):
+        self.ctx, self.nb, self.i = ctx, nb, 0
+
+    def next(self):
+        if self.nb > 1:
+            self.ctx.reads_exchange(self.i % (self.nb - 1))
+        self.i += 1
+
+
+def timed_passes(ctx, warmup, steps, nb=1):
+    """W untimed passes, then K timed ones bracketed by a stream synchronisation, over nb resident batches in rotation; returns
+    (seconds, per-kernel HIP-event times, {"steady": passes of the timed region that went through with one host wait, "redone": ...})"""
+    rot = Rotation(ctx, nb)
     for _ in range(warmup):
-        ctx.map()
+        rot.next(); ctx.map()
     ctx.profile(True); ctx.profile_read(reset=True)
     ctx.synchronize()
+    t0p = ctx.pass_totals()
     t0 = time.perf_counter()
     for _ in range(steps):
-        ctx.map()
+        rot.next(); ctx.map()
     ctx.synchronize()
     dt = time.perf_counter() - t0
+    t1p = ctx.pass_totals()
     prof = ctx.profile_read(reset=True)
     ctx.profile(False)
-    return dt, prof
+    return dt, prof, {"timed": t1p["passes"] - t0p["passes"], "steady": t1p["steady"] - t0p["steady"], "redone": t1p["redone"] - t0p["redone"], "resident_batches": nb}
 
 
 def human_scale_cpu_baseline(W, ref_np, reads_t, n_sample):
@@ -410,60 +560,67 @@ def human_scale_cpu_baseline(W, ref_np, reads_t, n_sample):
     if p.returncode != 0 or "mapping the query" not in tm:
         return {"error": "mashmap_ref exited with %d: %s" % (p.returncode, p.stderr[-300:])}
     log("[north_star] stock binary: index %.1f s, mapping %.2f s (%d reads, -t %d)" % (tm.get("computing the reference index", 0), tm["mapping the query"], n_sample, nt))
-    return {"value": round(n_sample * L / tm["mapping the query"] / 1e9, 4), "unit": "Gbp/s", "cores": nt, "kind": "reference",
+    return {"value": round(n_sample * L / tm["mapping the query"] / 1e9, 4), "unit": "Gbp/s", "cores": usable_cpus(), "threads": nt, "kind": "reference",
             "index_build_s": round(tm.get("computing the reference index", 0.0), 1), "wall_s": round(wall, 1), "paf_lines": lines,
             "sample": "%d of the target's reads (%.0f Mbp) vs the same %.0f Mbp reference written as FASTA; mashmap_ref (the reference's sources, GSL stand-in) with its "
                       "defaults, -t %d: %d host hardware threads, of which this process may use %d CPUs at once (container quota); 'time spent mapping the query' includes its "
                       "single-threaded FASTA reader" % (n_sample, n_sample * L / 1e6, sum(len(a) for a in ref_np) / 1e6, nt, os.cpu_count() or 1, usable_cpus())}
 
 
-def north_star_target(torch, dev, capi, local, warmup, steps, cpu_reads=0):
+def north_star_target(torch, dev, capi, local, warmup, steps, cpu_reads=0, nb=3, repeat_rich=True):
     """BASELINE.json's north_star target sentence on one GPU: 1 M x 10 kbp ONT-like reads, pi 85, against a human-scale index (3 Gbp,
     24 x 125 Mbp), device-resident packed bases in -> candidate mappings out.  Two variants on the same data: the stock command line
     (segLength 5000, the metric's "s=5000": two fragments per read) and segLength 10000 ("10 kbp segments": one fragment per read);
-    sketchSize 310 = what the stock binary derives for a 3 GB reference file at either segment length."""
+    sketchSize 310 = what the stock binary derives for a 3 GB reference file at either segment length.  Then `repeat_rich`: the stock
+    variant once more against a reference of the same size with human-like repeat structure (make_repeat_rich_reference)."""
     base = dict(WORKLOADS["northstar"])
-    t0 = time.time()
-    contigs = make_reference(torch, dev, base["ref_contigs"], base["ref_contig_len"])
-    ref_np = contiguous_views(torch, contigs)
-    reads_t = make_reads(torch, dev, contigs, base["reads"], base["read_len"], base["err"], seed=1000)
-    torch.cuda.synchronize()
-    del contigs
-    torch.cuda.empty_cache()
-    gen_s = time.time() - t0
     nreads, READ_LEN = base["reads"], base["read_len"]
-    offs = np.arange(nreads + 1, dtype=np.int64) * READ_LEN
-    res = {}
-    for key, seg in (("segLength5000", 5000), ("segLength10000", 10000)):
-        W = dict(base, seg=seg)
-        ctx = capi.Context(k=W["k"], segLength=seg, sketchSize=W["sketch"], flags=capi.MM_FLAG_HG_FILTER, device=local)
+
+    def measure(contigs, ref_np, W, wl_key, pmc_ok):
+        ctx = capi.Context(k=W["k"], segLength=W["seg"], sketchSize=W["sketch"], flags=capi.MM_FLAG_HG_FILTER, device=local)
         t0 = time.time()
         ctx.index_build(ref_np, kmerPct=0.001)
         index_s = time.time() - t0
         ctx.set_tables_default(W["pi"])
-        nF = ctx.reads_upload_device(reads_t.data_ptr(), reads_t.numel(), offs, seqCounterBase=0)
-        dt, prof = timed_passes(ctx, warmup, steps)
+        nF, _ = load_batches(torch, dev, ctx, contigs, W, nreads, nb, seed=1000)
+        dt, prof, passes = timed_passes(ctx, warmup, steps, nb)
         step_ms = dt / steps * 1e3
         n1, n2 = ctx.result_counts()
         stats, _, _ = ctx.results()
         nmap = len(ctx.mappings())
-        wl_key = "northstar" if seg == 5000 else "northstar_seg10000"
-        res[key] = {
-            "value": round(nreads * READ_LEN * steps / dt / 1e9, 4), "unit": "Gbp/s", "ms_per_step": round(step_ms, 3), "steps": steps, "warmup": warmup,
-            "kernels": {k: {"ms_per_step": v[0] / steps, "launches_per_step": v[1] / steps} for k, v in prof.items() if v[1]},
-            "roofline": roofline_block(ctx, capi, W, wl_key, nF, prof, step_ms, True, float(stats["nPoints"].mean())),
-            "index_build_s": round(index_s, 2),
-            "workload": "%d x %d bp reads (10%% ONT-like error) vs %.0f Mbp synthetic reference (%d contigs), k %d, segLength %d, sketchSize %d, pi %.2f: "
-                        "%d fragments, %.1f interval points per fragment, %d L1 candidates, %d L2 loci, %d candidate mappings"
-                        % (nreads, READ_LEN, sum(len(a) for a in ref_np) / 1e6, len(ref_np), W["k"], seg, W["sketch"], W["pi"], nF,
-                           float(stats["nPoints"].mean()), n1, n2, nmap)}
-        log("[north_star] %s: %.1f Gbp/s, %.1f ms per pass, index %.1f s" % (key, res[key]["value"], step_ms, index_s))
+        cnts = ctx.pass_counts()
+        lay = ctx.index_layout() if hasattr(ctx, "index_layout") else None
+        r = {"value": round(nreads * READ_LEN * steps / dt / 1e9, 4), "unit": "Gbp/s", "ms_per_step": round(step_ms, 3), "steps": steps, "warmup": warmup, "passes": passes,
+             "kernels": {k: {"ms_per_step": v[0] / steps, "launches_per_step": v[1] / steps} for k, v in prof.items() if v[1]},
+             "roofline": roofline_block(ctx, capi, W, wl_key, nF, prof, step_ms, pmc_ok, float(stats["nPoints"].mean())),
+             "index_build_s": round(index_s, 2),
+             "fragments": nF, "interval_points_per_fragment": round(float(stats["nPoints"].mean()), 1), "l1_candidates_per_fragment": round(n1 / max(1, nF), 3),
+             "l2_loci_per_fragment": round(n2 / max(1, nF), 3), "candidate_mappings_per_fragment": round(nmap / max(1, nF), 3),
+             "hard_list_share": round(cnts.get("hard", 0) / max(1, nF), 5), "hbm_point_path_share": round(cnts["queued"] / max(1, nF), 5),
+             "workload": "%d x %d bp reads (10%% ONT-like error) vs %.0f Mbp synthetic reference (%d contigs), k %d, segLength %d, sketchSize %d, pi %.2f: "
+                         "%d fragments, %.1f interval points per fragment, %d L1 candidates, %d L2 loci, %d candidate mappings (last pass)"
+                         % (nreads, READ_LEN, sum(len(a) for a in ref_np) / 1e6, len(ref_np), W["k"], W["seg"], W["sketch"], W["pi"], nF,
+                            float(stats["nPoints"].mean()), n1, n2, nmap)}
+        if lay:
+            r["index_layout"] = lay
         ctx.close()
-        del ctx
+        return r
+
+    t0 = time.time()
+    contigs = make_reference(torch, dev, base["ref_contigs"], base["ref_contig_len"])
+    ref_np = contiguous_views(torch, contigs)
+    torch.cuda.synchronize()
+    gen_s = time.time() - t0
+    res = {}
+    for key, seg in (("segLength5000", 5000), ("segLength10000", 10000)):
+        res[key] = measure(contigs, ref_np, dict(base, seg=seg), "northstar" if seg == 5000 else "northstar_seg10000", True)
+        log("[north_star] %s: %.1f Gbp/s, %.1f ms per pass, index %.1f s" % (key, res[key]["value"], res[key]["ms_per_step"], res[key]["index_build_s"]))
     out = dict(res["segLength5000"])
     if cpu_reads > 0:
         try:
-            out["cpu_baseline"] = human_scale_cpu_baseline(base, ref_np, reads_t, cpu_reads)
+            sample = make_reads(torch, dev, contigs, cpu_reads, READ_LEN, base["err"], seed=1000)
+            out["cpu_baseline"] = human_scale_cpu_baseline(base, ref_np, sample, cpu_reads)
+            del sample
         except Exception as e:
             log("[north_star] cpu_baseline failed:", repr(e)); out["cpu_baseline"] = {"error": repr(e)}
     out["what"] = ("BASELINE.json north_star target (>= 50 query Gbp/s sketch+map on 1 x MI355X, 10 kbp reads at pi 85 against a human-scale index), measured in "
@@ -472,29 +629,248 @@ def north_star_target(torch, dev, capi, local, warmup, steps, cpu_reads=0):
     out["sketchSize_note"] = base["sketch_note"]
     out["synthetic_data_s"] = round(gen_s, 2)
     out["segLength_10000"] = res["segLength10000"]
+    del contigs, ref_np
+    torch.cuda.empty_cache()
+    if repeat_rich:
+        try:
+            t0 = time.time()
+            contigs, summary = make_repeat_rich_reference(torch, dev, base["ref_contigs"], base["ref_contig_len"])
+            ref_np = contiguous_views(torch, contigs)
+            torch.cuda.synchronize()
+            rr = measure(contigs, ref_np, dict(base), "northstar_repeat_rich", True)
+            rr["reference"] = summary
+            rr["synthetic_data_s"] = round(time.time() - t0, 2)
+            rr["what"] = ("the north_star target workload (same reads-per-batch, read length, error model, parameters) with reference AND reads drawn from a 3 Gbp sequence "
+                          "with human-like repeat structure instead of i.i.d. uniform ACGT; PAF parity at this shape: tests/test_gpu_zz_humanscale.py::test_repeat_rich_reference")
+            out["repeat_rich"] = rr
+            log("[north_star] repeat_rich: %.1f Gbp/s, %.1f ms per pass, %.2f L1 candidates per fragment, hard-list share %.4f" %
+                (rr["value"], rr["ms_per_step"], rr["l1_candidates_per_fragment"], rr["hard_list_share"]))
+        except Exception as e:
+            log("[north_star] repeat_rich failed:", repr(e)); out["repeat_rich"] = {"error": repr(e)}
     return out
 
 
 class StubContext:
-    """CPU stand-in used ONLY by tests/test_bench_spawn.py (--stub): lets the launcher / rank plumbing of this script run where there
-    is no GPU.  It maps nothing; a line produced with it says "data": "stub"."""
+    """CPU stand-in used ONLY by the CPU tests of this script's rank loop (--stub: tests/test_bench_spawn.py): the same StepLoop drives it
+    as drives a capi.Context, over gloo.  It maps nothing; a line produced with it says "data": "stub".  The exchange has the library's
+    shape -- _begin snapshots this rank's records, _end runs the collective (an all-gatherv through mashmap_amd/shard.py's plan) -- and
+    every call is logged with a timestamp (MM_STUB_LOG) so that a test can check the order the loop issues them in.
+    MM_STUB_EMPTY_RANK=r: rank r has no mappings at all; MM_STUB_FAIL_END=r:k: rank r's k-th _end raises."""
 
-    def __init__(self, rank):
-        self.rank = rank
+    def __init__(self, rank, dist=None):
+        self.rank, self.dist = rank, dist
+        self.pending = None
+        self.ends = 0
+        self.npass = 0
+        self.logf = open(os.environ["MM_STUB_LOG"] + ".%d" % rank, "w") if os.environ.get("MM_STUB_LOG") else None
+        self.empty = os.environ.get("MM_STUB_EMPTY_RANK") == str(rank)
+        fe = os.environ.get("MM_STUB_FAIL_END", "")
+        self.fail_end = int(fe.split(":")[1]) if fe and fe.split(":")[0] == str(rank) else None
+
+    def _log(self, what, **kw):
+        if self.logf:
+            self.logf.write(json.dumps(dict(t=time.perf_counter(), ev=what, **kw)) + "\n"); self.logf.flush()
+
+    def reads_exchange(self, slot):
+        self._log("exchange", slot=slot)
 
     def map(self):
         time.sleep(0.002)
+        self.npass += 1
+        self._log("map", n=self.npass)
 
-    def allgatherv(self, dist):
-        from mashmap_amd import capi, shard
-        mine = np.zeros(3 + self.rank, dtype=capi.MAPPING_DT); mine["querySeqId"] = self.rank
-        got, counts = shard.allgatherv_mappings(mine, dist)
+    def _records(self):
+        from mashmap_amd import capi
+        mine = np.zeros(0 if self.empty else 3 + self.rank, dtype=capi.MAPPING_DT)
+        mine["querySeqId"] = self.rank
+        mine["fragStart"] = self.npass
+        return mine
+
+    def _gather(self, mine):
+        from mashmap_amd import shard
+        got, counts = shard.allgatherv_mappings(mine, self.dist)
         assert len(got) == sum(counts) and (got["querySeqId"] == np.repeat(np.arange(len(counts)), counts)).all()
+        return got, counts
+
+    def allgatherv_mappings(self):
+        self._log("sync_gather"); self._gather(self._records())
+
+    def allgatherv_mappings_begin(self):
+        assert self.pending is None, "two exchanges in flight"
+        self.pending = self._records()
+        self._log("begin", n=self.npass)
+
+    def allgatherv_mappings_end(self):
+        assert self.pending is not None, "_end without _begin"
+        self.ends += 1
+        if self.fail_end is not None and self.ends == self.fail_end:
+            raise RuntimeError("stub: rank %d fails in its exchange %d" % (self.rank, self.ends))
+        got, counts = self._gather(self.pending)
+        of = sorted(set(int(x) for x in got["fragStart"]))          # every rank snapshots after the same pass: one pass number in the gathered records
+        assert len(of) <= 1, "records of several passes in one exchange: %s" % of
+        self._log("end", of=of[0] if of else -1, counts=[int(c) for c in counts])
+        self.pending = None
+
+    def synchronize(self):
+        pass
+
+    def profile(self, on):
+        pass
+
+    def profile_read(self, reset=False):
+        return {}
+
+    def pass_totals(self):
+        return {"passes": self.npass, "steady": max(0, self.npass - 1), "redone": 0}
+
+    def close(self):
+        if self.logf:
+            self.logf.close()
+
+
+class StepLoop:
+    """the timed loop of a rank: W warm-up steps, then exactly K timed ones between two fences.  A step = next resident batch in
+    (Rotation) + one pass of the hot path + -- N > 1 -- the exchange of that pass's candidate mappings: by default overlapped, i.e. _end of
+    the previous step's exchange and _begin of this one's (it then runs on the library's exchange stream under the kernels of the next
+    pass); --sync-exchange: the blocking form.  A fence waits for the exchange still in flight, meets the other ranks (barrier) and
+    drains the device, so the last exchange is INSIDE the timed region; the elapsed time is the max over ranks."""
+
+    def __init__(self, ctx, world, dist, torch, nb, sync_exchange=False, log_event=None):
+        self.ctx, self.world, self.dist, self.torch, self.sync_exchange = ctx, world, dist, torch, sync_exchange
+        self.rot = Rotation(ctx, nb)
+        self.inflight = False
+        self.log_event = log_event or (lambda *_: None)
+
+    def step(self):
+        self.rot.next()
+        self.ctx.map()
+        if self.world > 1:
+            if self.sync_exchange:
+                self.ctx.allgatherv_mappings()
+                return
+            if self.inflight:
+                self.ctx.allgatherv_mappings_end()
+            self.ctx.allgatherv_mappings_begin()
+            self.inflight = True
+
+    def fence(self):
+        if self.inflight:
+            self.ctx.allgatherv_mappings_end()
+            self.inflight = False
+        if self.world > 1:
+            self.dist.barrier()
+        if self.torch.cuda.is_available():
+            self.torch.cuda.synchronize()
+        self.ctx.synchronize()
+
+    def run(self, warmup, steps, device=None):
+        """returns (seconds = max over ranks, per-kernel HIP-event times, passes dict of the timed region)"""
+        for _ in range(warmup):
+            self.step()
+        self.ctx.profile(True); self.ctx.profile_read(reset=True)
+        self.fence()
+        p0 = self.ctx.pass_totals()
+        self.log_event("t0")
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        self.fence()
+        dt = time.perf_counter() - t0
+        self.log_event("t1")
+        p1 = self.ctx.pass_totals()
+        prof = self.ctx.profile_read(reset=True)
+        self.ctx.profile(False)
+        if self.world > 1:
+            tmax = self.torch.tensor([dt], dtype=self.torch.float64, device=device if device is not None else "cpu")
+            self.dist.all_reduce(tmax, op=self.dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        passes = {"timed": p1["passes"] - p0["passes"], "steady": p1["steady"] - p0["steady"], "redone": p1["redone"] - p0["redone"], "resident_batches": self.rot.nb}
+        return dt, prof, passes
 
 
 def free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
     return p
+
+
+def e2e_fasta_to_paf(torch, dev, W, ref_np, nreads, threads):
+    """the path a user runs, inside this run: the `mashmap_hip` command line (skch::Sketch + skch::Map on the C ABI) on the workload's
+    FASTA files -- parse + pack, upload, kernels, download, chaining + filters, PAF text --, its own 'time spent mapping the query' and
+    the per-stage seconds of its MASHMAP_HIP_TIMING log.  The FASTA is written first (reads regenerated with the headline's seed)."""
+    import re
+    import shutil
+    exe = os.path.join(ROOT, "mashmap_amd", "lib", "mashmap_hip")
+    if not os.path.exists(exe):
+        return {"error": "mashmap_amd/lib/mashmap_hip not built"}
+    L = W["read_len"]
+    td = tempfile.mkdtemp(prefix="mm_e2e_")
+    try:
+        need = nreads * (L + 14) + sum(len(a) for a in ref_np) * 1.02 + (1 << 30)
+        free = shutil.disk_usage(td).free
+        scaled = None
+        if free < need:
+            scaled = max(1000, int(nreads * (free - (2 << 30)) / need))
+            if free < (3 << 30):
+                return {"error": "only %.1f GB free under %s" % (free / 1e9, td)}
+            nreads = scaled
+        rp, qp, op = os.path.join(td, "ref.fa"), os.path.join(td, "reads.fa"), os.path.join(td, "out.paf")
+        t0 = time.time()
+        write_fasta(rp, ["chr%d" % i for i in range(len(ref_np))], ref_np)
+        contigs = [torch.from_numpy(a).to(dev) for a in ref_np]
+        with open(qp, "wb") as f:
+            chunk = 100_000
+            for r0 in range(0, nreads, chunk):
+                n = min(chunk, nreads - r0)
+                rd = make_reads(torch, dev, contigs, n, L, W["err"], seed=5000 + r0).cpu().numpy().reshape(n, L)
+                hdr = np.frombuffer(b"".join(b">read%07d\n" % (r0 + i) for i in range(n)), dtype=np.uint8).reshape(n, 13)      # fixed-width names
+                f.write(np.concatenate([hdr, rd, np.full((n, 1), 10, dtype=np.uint8)], axis=1).tobytes())
+        del contigs
+        torch.cuda.empty_cache()
+        write_s = time.time() - t0
+        env = dict(os.environ, MASHMAP_HIP_TIMING="1")
+        best = None
+        for rep in range(2):                                   # the second run finds the files in the page cache
+            t0 = time.time()
+            p = subprocess.run([exe, "-r", rp, "-q", qp, "-o", op, "-t", str(threads), "-s", str(W["seg"]), "--pi", str(int(round(W["pi"] * 100))), "-J", str(W["sketch"])],
+                               capture_output=True, text=True, env=env)
+            wall = time.time() - t0
+            if p.returncode != 0:
+                return {"error": "mashmap_hip exited with %d: %s" % (p.returncode, p.stderr[-400:])}
+            tmap = float(re.search(r"time spent mapping the query\s*:\s*([0-9.eE+-]+)", p.stderr).group(1))
+            tidx = float(re.search(r"time spent computing the reference index\s*:\s*([0-9.eE+-]+)", p.stderr).group(1))
+            dev_rows = re.findall(r"device stage \(.*?download of (\d+) candidate mappings\): ([0-9.eE+-]+) s \(upload ([0-9.eE+-]+), kernels ([0-9.eE+-]+), download ([0-9.eE+-]+)\)(?: \[bases (\d+)\])?", p.stderr)
+            rd_rows = re.findall(r"reader: parsed (\d+) records, (\d+) bases in ([0-9.eE+-]+) s", p.stderr)
+            post = [float(x) for x in re.findall(r"post stage: chain \+ filter \+ format ([0-9.eE+-]+) s", p.stderr)]
+            outp = [float(x) for x in re.findall(r", output ([0-9.eE+-]+) s", p.stderr)]
+            cur = dict(map_s=tmap, index_s=tidx, wall_s=wall, stderr=p.stderr, dev_rows=dev_rows, rd_rows=rd_rows, post_s=sum(post), output_s=sum(outp))
+            if best is None or tmap < best["map_s"]:
+                best = cur
+        bases = nreads * L
+        dev_rows = best["dev_rows"]
+        # a device-stage row covers one pass over one or several reader batches: its bases are in the row (skch_map.hpp), else the reader's batches in order
+        pass_bases = [int(r[5]) for r in dev_rows if r[5]]
+        if len(pass_bases) != len(dev_rows):
+            pass_bases = [int(r[1]) for r in best["rd_rows"]][:len(dev_rows)]
+        kern = [float(r[3]) for r in dev_rows]
+        full = max(pass_bases) if pass_bases else 0
+        fb = [(b, k) for b, k in zip(pass_bases, kern) if b >= 0.9 * full]
+        lines = sum(1 for _ in open(op, "rb"))
+        return {"what": "mashmap_hip -r ref.fa -q reads.fa -o out.paf (FASTA -> PAF) on this workload's files: %d x %d bp reads (%.2f GB of FASTA) vs %.0f Mbp; "
+                        "'time spent mapping the query' = parse + pack + upload + kernels + download + chain/filter + PAF text, the three stages (reader | device | post) "
+                        "overlapped on successive batches; best of two runs" % (nreads, L, os.path.getsize(qp) / 1e9, sum(len(a) for a in ref_np) / 1e6),
+                "value": round(bases / best["map_s"] / 1e9, 3), "unit": "Gbp/s", "map_s": round(best["map_s"], 4), "index_s": round(best["index_s"], 3), "wall_s": round(best["wall_s"], 3),
+                "paf_lines": lines, "threads": threads, "usable_cpus": usable_cpus(), "scaled_to_reads": scaled, "fasta_write_s": round(write_s, 1),
+                "stages": {"reader_s": round(sum(float(r[2]) for r in best["rd_rows"]), 4), "reader_batches": len(best["rd_rows"]),
+                           "device_stage_s": round(sum(float(r[1]) for r in dev_rows), 4), "device_upload_wait_s": round(sum(float(r[2]) for r in dev_rows), 4),
+                           "device_kernels_s": round(sum(kern), 4), "device_download_s": round(sum(float(r[4]) for r in dev_rows), 4), "device_passes": len(dev_rows),
+                           "post_s": round(best["post_s"], 4), "output_s": round(best["output_s"], 4)},
+                "device_stage": {"gbps_kernels_all_passes": round(sum(pass_bases) / max(1e-9, sum(kern)) / 1e9, 2),
+                                 "gbps_kernels_full_size_passes": round(sum(b for b, _ in fb) / max(1e-9, sum(k for _, k in fb)) / 1e9, 2) if fb else None,
+                                 "full_size_passes": len(fb), "bases_per_pass": pass_bases,
+                                 "note": "kernels = mm_map_fragments of a pass (sketch .. selection, its host waits included); a pass covers as many parsed batches as were "
+                                         "waiting, up to MASHMAP_HIP_COALESCE_MBP per GPU (skch_map.hpp); full-size passes = those within 10 % of the largest"}}
+    finally:
+        shutil.rmtree(td, ignore_errors=True)
 
 
 def main():
@@ -503,11 +879,14 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="configs1")
-    ap.add_argument("--reads", type=int, default=int(os.environ.get("MM_BENCH_READS", 0)), help="reads per GPU (default: the workload's)")
+    ap.add_argument("--batches", type=int, default=3, help="distinct resident batches taking turns in the timed loop (1..5)")
+    ap.add_argument("--reads", type=int, default=int(os.environ.get("MM_BENCH_READS", 0)), help="reads per GPU and batch (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true")
-    ap.add_argument("--no-north-star", action="store_true", help="default run only: skip the north_star target measurement (3 Gbp index) behind the headline one")
-    ap.add_argument("--north-star-steps", type=int, default=5, help="timed passes of each north_star variant (at most --steps)")
+    ap.add_argument("--no-e2e", action="store_true", help="default run only: skip the FASTA -> PAF run of the mashmap_hip command line")
+    ap.add_argument("--no-north-star", action="store_true", help="default run only: skip the north_star target measurements (3 Gbp index) behind the headline one")
+    ap.add_argument("--no-repeat-rich", action="store_true", help="default run only: skip north_star_target.repeat_rich")
+    ap.add_argument("--north-star-steps", type=int, default=6, help="timed passes of each north_star variant (at most --steps)")
     ap.add_argument("--ref-contigs", type=int, default=0, help="contigs of the synthetic reference (default: the workload's)")
     ap.add_argument("--ref-contig-len", type=int, default=0)
     ap.add_argument("--kmer", type=int, default=0, help="k-mer size (default: the reference's 19; other sizes are not the BASELINE configuration)")
@@ -515,15 +894,19 @@ def main():
                                                        "sketchSize unchanged, as north_star_target.segLength_10000 measures it)")
     ap.add_argument("--cpu-sample", type=int, default=30000)
     ap.add_argument("--sync-exchange", action="store_true", help="N>1: all-gatherv on the compute stream instead of overlapped with the next batch")
+    ap.add_argument("--repeat-rich-reference", action="store_true", help="draw reference and reads from make_repeat_rich_reference instead of uniform ACGT (not a BASELINE configuration)")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--north-star-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if not 1 <= args.batches <= 5:
+        raise SystemExit("--batches must be 1..5 (MM_BATCH_SLOTS + 1)")
 
     if args.north_star_child:                           # the default run's second measurement (see north_star_target), one GPU
         import torch
         from mashmap_amd import capi
         torch.cuda.set_device(0)
-        print(json.dumps(north_star_target(torch, torch.device("cuda", 0), capi, 0, args.warmup, args.steps, 0 if args.no_cpu_baseline else args.cpu_sample)), flush=True)
+        print(json.dumps(north_star_target(torch, torch.device("cuda", 0), capi, 0, args.warmup, args.steps, 0 if args.no_cpu_baseline else args.cpu_sample,
+                                           nb=args.batches, repeat_rich=not args.no_repeat_rich)), flush=True)
         return
 
     # ---- N ranks: start them ourselves unless a launcher already did
@@ -548,33 +931,29 @@ def main():
     if args.ref_contigs: W["ref_contigs"] = args.ref_contigs; scaled.append("ref-contigs")
     if args.ref_contig_len: W["ref_contig_len"] = args.ref_contig_len; scaled.append("ref-contig-len")
     if args.kmer: W["k"] = args.kmer; scaled.append("kmer")
+    if args.repeat_rich_reference: scaled.append("repeat-rich reference")
     wl_key = args.workload
     if args.seg and args.seg != W["seg"]:
         W["seg"] = args.seg; W["label"] += ", segLength %d" % args.seg
         wl_key = "%s_seg%d" % (args.workload, args.seg)
     is_default = args.workload == "configs1" and not scaled and wl_key == args.workload
+    nb = args.batches
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo" if args.stub else "nccl", rank=rank, world_size=world)
 
-    if args.stub:
-        ctx = StubContext(rank)
-        for _ in range(args.warmup):
-            ctx.map(); world > 1 and ctx.allgatherv(dist)
-        if world > 1: dist.barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            ctx.map(); world > 1 and ctx.allgatherv(dist)
-        if world > 1: dist.barrier()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            tm = torch.tensor([dt], dtype=torch.float64); dist.all_reduce(tm, op=dist.ReduceOp.MAX); dt = float(tm.item())
+    if args.stub:                                       # the real rank loop over a context that maps nothing (CPU tests)
+        ctx = StubContext(rank, dist)
+        loop = StepLoop(ctx, world, dist, torch, nb, args.sync_exchange, log_event=lambda ev: ctx._log(ev))
+        dt, _, passes = loop.run(args.warmup, args.steps)
         if rank == 0:
             print(json.dumps({"metric": "query Gbp/s sketch+L1/L2 map (pi=85, s=5000)", "value": 0.0, "unit": "Gbp/s", "n_gpus": world, "steps": args.steps,
                               "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-                              "vs_baseline": None, "dtype": "u64", "data": "stub", "config": {"workload": "STUB: no kernels ran (launcher test)"}}), flush=True)
+                              "vs_baseline": None, "dtype": "u64", "data": "stub", "passes": passes, "config": {"workload": "STUB: no kernels ran (launcher test)"}}), flush=True)
+        ctx.close()
         if world > 1:
+            dist.barrier()
             dist.destroy_process_group()
         return
 
@@ -589,13 +968,14 @@ def main():
     nreads = W["reads"]
 
     t0 = time.time()
-    contigs = make_reference(torch, dev, W["ref_contigs"], W["ref_contig_len"])
+    ref_summary = None
+    if args.repeat_rich_reference:
+        contigs, ref_summary = make_repeat_rich_reference(torch, dev, W["ref_contigs"], W["ref_contig_len"])
+    else:
+        contigs = make_reference(torch, dev, W["ref_contigs"], W["ref_contig_len"])
     ref_np = contiguous_views(torch, contigs)
-    reads_t = make_reads(torch, dev, contigs, nreads, READ_LEN, W["err"], seed=1000 + rank)
     torch.cuda.synchronize()
-    log("[rank %d] synthetic data: %.1f s" % (rank, time.time() - t0))
-    del contigs
-    torch.cuda.empty_cache()
+    log("[rank %d] synthetic reference: %.1f s" % (rank, time.time() - t0))
 
     ctx = capi.Context(k=K, segLength=SEG, sketchSize=SKETCH, flags=capi.MM_FLAG_HG_FILTER, device=local)
     t0 = time.time()
@@ -604,15 +984,17 @@ def main():
     t0 = time.time()
     ctx.set_tables_default(PI)
     log("[rank %d] index build: %.1f s; integer tables: %.2f s" % (rank, index_s, time.time() - t0))
-    offs = np.arange(nreads + 1, dtype=np.int64) * READ_LEN
-    nF = ctx.reads_upload_device(reads_t.data_ptr(), reads_t.numel(), offs, seqCounterBase=rank * nreads)
     # the CPU leg indexes the reference with the stock binary: minutes beyond a few hundred Mbp, so it rides on the default workload only
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline and sum(len(a) for a in ref_np) <= 400e6
-    reads_np = reads_t[:min(nreads, args.cpu_sample) * READ_LEN].cpu().numpy() if want_cpu else None
+    want_e2e = is_default and rank == 0 and world == 1 and not args.no_e2e
+    t0 = time.time()
+    nF, reads_np = load_batches(torch, dev, ctx, contigs, W, nreads, nb, seed=1000 + rank, seq_base=rank * nreads,
+                                keep_first=min(nreads, args.cpu_sample) if want_cpu else 0)
+    log("[rank %d] %d batches of %d reads generated, packed and parked: %.1f s" % (rank, nb, nreads, time.time() - t0))
+    del contigs
     ref_lens = [len(a) for a in ref_np]
-    if not want_cpu:
+    if not (want_cpu or want_e2e):
         ref_np = None
-    del reads_t
     torch.cuda.empty_cache()
 
     rccl = None
@@ -625,48 +1007,14 @@ def main():
         except Exception as e:
             rccl = {"error": repr(e)}
 
-    inflight = [False]
-
-    def step():
-        ctx.map()
-        if world > 1:                                   # all-gatherv of the candidate mappings over RCCL/xGMI: the exchange of batch i
-            if args.sync_exchange:                      # runs on the library's exchange stream under the kernels of batch i+1
-                ctx.allgatherv_mappings()               # (--sync-exchange: on the compute stream, the step waits for it)
-                return
-            if inflight[0]:
-                ctx.allgatherv_mappings_end()
-            ctx.allgatherv_mappings_begin()
-            inflight[0] = True
-
-    def fence():                                        # the last exchange is waited for INSIDE the timed region
-        if inflight[0]:
-            ctx.allgatherv_mappings_end()
-            inflight[0] = False
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        ctx.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    ctx.profile(True); ctx.profile_read(reset=True)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    prof = ctx.profile_read(reset=True)
-    ctx.profile(False)
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    loop = StepLoop(ctx, world, dist, torch, nb, args.sync_exchange)
+    dt, prof, passes = loop.run(args.warmup, args.steps, device=dev)
     n1, n2 = ctx.result_counts()
 
     if rank == 0:
         stats, _, _ = ctx.results()
         nmap = len(ctx.mappings())
+        cnts = ctx.pass_counts()
         bases_step = nreads * READ_LEN * world
         value = bases_step * args.steps / dt / 1e9
         step_ms = dt / args.steps * 1e3
@@ -683,37 +1031,48 @@ def main():
                                       "%.0f%%" % (W["err"][0] * 100) if W["err"][0] == W["err"][1] else "%.0f-%.0f%%" % (W["err"][0] * 100, W["err"][1] * 100),
                                       ref_mbp, len(ref_lens)),
                        "k": K, "segLength": SEG, "sketchSize": SKETCH, "sketchSize_note": W["sketch_note"],
-                       "percentageIdentity": PI, "fragments_per_gpu": nF,
+                       "percentageIdentity": PI, "fragments_per_gpu": nF, "resident_batches": nb,
                        "parallelism": "reads sharded, index replicated, RCCL all-gatherv of candidate mappings (libmashmap_hip: mm_allgatherv_mappings_begin/_end, overlapped with the next batch)"
                        if world > 1 else "single GPU", "mean_interval_points_per_fragment": round(P, 1),
-                       "l1_candidates_per_gpu": n1, "l2_loci_per_gpu": n2, "candidate_mappings_per_gpu": nmap,
-                       "index_build_s": round(index_s, 2), "rccl": rccl,
-                       "host_synchronisations_per_pass": ctx.pass_stats()[0],
+                       "l1_candidates_per_gpu": n1, "l2_loci_per_gpu": n2, "candidate_mappings_per_gpu": nmap, "hard_list_fragments": cnts.get("hard", 0),
+                       "index_build_s": round(index_s, 2), "rccl": rccl, "reference": ref_summary,
+                       "host_synchronisations_last_pass": ctx.pass_stats()[0],
                        "identity_tables": "minimumHits / sketchCutoffs / acceptance from mm_stats.hpp's re-derivation of GSL's binomial and hypergeometric "
-                                          "CDFs (GSL is not in the image; SURVEY section 8c: the one unpinned boundary)"},
+                                          "CDFs (GSL is not in the image; pinned by a third derivation: tests/test_host_stats.py, profiles/r13_gsl_boundary_margins.txt)"},
+            "passes": dict(passes, note="the %d timed passes went over %d distinct resident batches in rotation: `steady` of them launched everything against the previous pass's buffer "
+                                        "sizes and waited for the device once, `redone` outgrew a buffer and were run again the sized way (both inside the timed region)" % (args.steps, nb)),
             "roofline": roofline,
             "kernels": kernels,
         }
-        # the two side measurements never take the headline with them
+        # the side measurements never take the headline with them
         if world == 1 and not args.no_host_path:
             try:
                 out["host_path"] = host_path(ctx, W, nreads, ref_lens, step_ms)
             except Exception as e:
                 log("[bench] host_path failed:", repr(e)); out["host_path"] = {"error": repr(e)}
+        ctx.close(); ctx = None                         # index, parked batches and staging go back to the device before the side measurements
+        torch.cuda.empty_cache()
         if want_cpu:
             try:
                 out["cpu_baseline"] = cpu_baseline(W, ref_np, reads_np, min(args.cpu_sample, nreads))
             except Exception as e:
                 log("[bench] cpu_baseline failed:", repr(e)); out["cpu_baseline"] = {"error": repr(e)}
+        if want_e2e:
+            try:
+                t0 = time.time()
+                out["e2e"] = e2e_fasta_to_paf(torch, dev, W, ref_np, nreads, max(4, min(128, os.cpu_count() or 1)))
+                log("[bench] e2e FASTA -> PAF: %s (%.0f s)" % ({k: out["e2e"].get(k) for k in ("value", "map_s", "device_stage", "error")}, time.time() - t0))
+            except Exception as e:
+                log("[bench] e2e failed:", repr(e)); out["e2e"] = {"error": repr(e)}
         if is_default and world == 1 and not args.no_north_star:
             # in a process of its own, after this one has let go of its index and reads: whatever happens there, the headline line is printed
-            ctx.close(); ctx = None
-            del reads_np, ref_np
+            reads_np = ref_np = None
             torch.cuda.empty_cache()
             cmd = [sys.executable, os.path.abspath(__file__), "--north-star-child", "--steps", str(max(1, min(args.steps, args.north_star_steps))),
-                   "--warmup", str(min(args.warmup, 2)), "--cpu-sample", str(args.cpu_sample)] + (["--no-cpu-baseline"] if args.no_cpu_baseline else [])
+                   "--warmup", str(min(max(args.warmup, args.batches), 4)), "--cpu-sample", str(args.cpu_sample), "--batches", str(args.batches)] \
+                  + (["--no-cpu-baseline"] if args.no_cpu_baseline else []) + (["--no-repeat-rich"] if args.no_repeat_rich else [])
             try:
-                p = subprocess.run(cmd, stdout=subprocess.PIPE, timeout=900, env=dict(os.environ, HIP_VISIBLE_DEVICES=os.environ.get("HIP_VISIBLE_DEVICES", str(local))))
+                p = subprocess.run(cmd, stdout=subprocess.PIPE, timeout=1200, env=dict(os.environ, HIP_VISIBLE_DEVICES=os.environ.get("HIP_VISIBLE_DEVICES", str(local))))
                 line = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
                 out["north_star_target"] = json.loads(line[-1]) if p.returncode == 0 and line else {"error": "child exited with %d" % p.returncode}
             except Exception as e:

@@ -216,6 +216,17 @@ int mm_reads_prefetch_packed(mm_ctx* ctx, const uint32_t* bases2, const uint32_t
 size_t mm_pack_read(const char* ascii, size_t len, uint32_t* bases2, uint32_t* nmask);
 size_t mm_pack_read_portable(const char* ascii, size_t len, uint32_t* bases2, uint32_t* nmask);
 int mm_reads_packed_download(mm_ctx* ctx, uint32_t* bases2, uint32_t* nmask, uint32_t* readHasN, size_t* nPackedBases);
+/*
+ * Batch slots.  A context maps its RESIDENT batch (what the last mm_reads_upload* left); beside it, it can hold MM_BATCH_SLOTS parked
+ * batches.  mm_reads_exchange swaps the resident batch with the one in `slot` -- either may be empty; device pointers change hands, nothing
+ * is copied -- so that several uploaded batches stay in HBM and take turns (bench.py rotates three; a caller that maps a batch twice with
+ * something else in between).  Results of the previous mm_map_fragments belong to the batch that was resident then and are gone after
+ * the swap (an overlapped exchange works on its own snapshot of the records and is not affected); the context's staging buffers keep
+ * their sizes, so the next pass is a steady-state pass if the incoming batch fits them and is redone the sized way if not
+ * (mm_pass_totals counts both).
+ */
+#define MM_BATCH_SLOTS 4
+int mm_reads_exchange(mm_ctx* ctx, int slot);
 size_t mm_num_fragments(const mm_ctx* ctx);
 int mm_fragments_download(mm_ctx* ctx, mm_fragment* out);
 
@@ -236,10 +247,14 @@ int mm_map_fragments(mm_ctx* ctx);
 /* How the last mm_map_fragments went: the number of times the host waited for the device inside it, and whether it was a steady-state
  * pass -- the first pass of a context sizes every staging buffer from counts it reads back stage by stage (5-7 waits); the passes behind
  * it launch against those capacities with the counts left on the device and wait once, at the end.  A pass that outgrows a buffer is
- * redone the sized way (and counted as such here).  counts (4 entries, may be NULL): L1 candidates, L2 loci, fragments whose interval
+ * redone the sized way (and counted as such here).  counts (5 entries, may be NULL): L1 candidates, L2 loci, fragments whose interval
  * points went through HBM (more than the fused kernel holds; as of the last sized pass), entries reserved for the L2 streams (one per
- * index event a candidate touches: what k_l2_locate reads 16 bytes for and k_l2_sweep at most 4). */
+ * index event a candidate touches: what k_l2_locate reads 16 bytes for and k_l2_sweep at most 4), fragments the fast sketch kernel handed to
+ * the exact one (the hard list: fewer than sketchSize distinct survivors below the cut, or an LDS structure overflowed). */
 int mm_pass_stats(const mm_ctx* ctx, uint64_t* hostSyncs, int* steady, uint64_t* counts);
+/* The context's mm_map_fragments calls so far: all of them, those that went through as steady-state passes (one host wait), and the
+ * steady-state attempts that outgrew a buffer and were redone the sized way.  Any pointer may be NULL. */
+int mm_pass_totals(const mm_ctx* ctx, uint64_t* passes, uint64_t* steadyPasses, uint64_t* redonePasses);
 int mm_result_counts(const mm_ctx* ctx, size_t* nL1, size_t* nL2);
 /* any pointer may be NULL.  l1/l2 are sorted by (frag, emission order of the reference) */
 int mm_results_download(mm_ctx* ctx, mm_frag_stats* stats, mm_l1_candidate* l1, mm_l2_locus* l2);

@@ -127,6 +127,8 @@ def load():
         "mm_reads_packed_download": (C.c_int, [vp, vp, vp, vp, C.POINTER(sz)]),
         "mm_index_layout_get": (C.c_int, [vp, vp]),
         "mm_pass_stats": (C.c_int, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_int), vp]),
+        "mm_pass_totals": (C.c_int, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+        "mm_reads_exchange": (C.c_int, [vp, C.c_int]),
         "mm_synchronize": (C.c_int, [vp]),
         "mm_stream": (vp, [vp]),
     }
@@ -151,7 +153,7 @@ EXPORTS = ["mm_abi_version", "mm_create", "mm_destroy", "mm_last_error", "mm_ind
            "mm_allgatherv_mappings_begin", "mm_allgatherv_mappings_end",
            "mm_gathered_counts", "mm_gathered_download", "mm_gathered_device", "mm_index_replicate", "mm_stat_replay_tables", "mm_host_alloc", "mm_host_free", "mm_reads_prefetch",
            "mm_reads_upload_packed", "mm_reads_prefetch_packed", "mm_pack_read", "mm_pack_read_portable", "mm_reads_packed_download",
-           "mm_index_layout_get", "mm_pass_stats", "mm_comm_info"]
+           "mm_index_layout_get", "mm_pass_stats", "mm_comm_info", "mm_pass_totals", "mm_reads_exchange"]
 
 
 def stat_sketch_cutoffs(sketchSize, k, hg=True):
@@ -371,11 +373,22 @@ class Context:
         self._ck(self.lib.mm_pass_stats(self.h, C.byref(n), C.byref(st), None), "mm_pass_stats")
         return int(n.value), bool(st.value)
 
+    def pass_totals(self):
+        """dict(passes, steady, redone): this context's map() calls so far, how many went through as steady-state passes, and how many
+        steady-state attempts outgrew a buffer and were redone the sized way"""
+        a, b, c_ = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._ck(self.lib.mm_pass_totals(self.h, C.byref(a), C.byref(b), C.byref(c_)), "mm_pass_totals")
+        return {"passes": int(a.value), "steady": int(b.value), "redone": int(c_.value)}
+
+    def reads_exchange(self, slot):
+        """swaps the resident batch of reads with the one parked in `slot` (0 .. MM_BATCH_SLOTS - 1); no copy"""
+        self._ck(self.lib.mm_reads_exchange(self.h, slot), "mm_reads_exchange")
+
     def pass_counts(self):
-        """dict(l1, l2, queued, stream_entries) of the last map()"""
-        a = np.zeros(4, dtype=np.uint64)
+        """dict(l1, l2, queued, stream_entries, hard) of the last map()"""
+        a = np.zeros(5, dtype=np.uint64)
         self._ck(self.lib.mm_pass_stats(self.h, None, None, _ptr(a)), "mm_pass_stats")
-        return dict(zip(("l1", "l2", "queued", "stream_entries"), (int(x) for x in a)))
+        return dict(zip(("l1", "l2", "queued", "stream_entries", "hard"), (int(x) for x in a)))
 
     def results(self):
         n1, n2 = C.c_size_t(), C.c_size_t()

@@ -69,6 +69,9 @@ void mm_destroy(mm_ctx* c) {
   if (c->copyStream) { (void)hipStreamSynchronize(c->copyStream); (void)hipStreamDestroy(c->copyStream); }
   if (c->copyDone) (void)hipEventDestroy(c->copyDone);
   for (DevBuf* b : c->allBufs()) b->release();
+  c->dGatherSrc.release();
+  for (auto& p : c->parked)
+    for (DevBuf* b : {&p.dReadSrcOff, &p.dReadPackOff, &p.dReadLen, &p.dReadGroup, &p.dReadSelf, &p.dReadHasN, &p.dBases2, &p.dNmask, &p.dFrags}) b->release();
   if (c->hPass) (void)hipHostFree(c->hPass);
   for (auto& pr : c->evPool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   if (c->evA) (void)hipEventDestroy(c->evA);
@@ -356,6 +359,22 @@ void* mm_host_alloc(size_t bytes) {
 }
 void mm_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
+int mm_reads_exchange(mm_ctx* c, int slot) {
+  if (slot < 0 || slot >= MM_BATCH_SLOTS) { c->err = "mm_reads_exchange: slot out of range"; return MM_ERR_ARG; }
+  std::lock_guard<std::mutex> prefetchLock(c->prefetchMu);   // an upload of the resident batch is not under way
+  MM_HIP(c, hipSetDevice(c->device));
+  MM_HIP(c, hipStreamSynchronize(c->stream));                // nothing queued still reads the outgoing batch
+  mm_ctx::ParkedReads& p = c->parked[slot];
+  std::swap(c->nReads, p.nReads); std::swap(c->nFrags, p.nFrags); std::swap(c->nPackedBases, p.nPackedBases);
+  std::swap(c->seqCounterBase, p.seqCounterBase); std::swap(c->maxFragLen, p.maxFragLen); std::swap(c->windowed, p.windowed);
+  std::swap(c->dReadSrcOff, p.dReadSrcOff); std::swap(c->dReadPackOff, p.dReadPackOff); std::swap(c->dReadLen, p.dReadLen);
+  std::swap(c->dReadGroup, p.dReadGroup); std::swap(c->dReadSelf, p.dReadSelf); std::swap(c->dReadHasN, p.dReadHasN);
+  std::swap(c->dBases2, p.dBases2); std::swap(c->dNmask, p.dNmask); std::swap(c->dFrags, p.dFrags);
+  c->hFrags.swap(p.hFrags);
+  c->sketched = false; c->mapped = false; c->fragTabStale = true; c->gathered = false;
+  return MM_OK;
+}
+
 size_t mm_num_fragments(const mm_ctx* c) { return c->nFrags; }
 int mm_fragments_download(mm_ctx* c, mm_fragment* out) {
   if (c->nFrags) std::memcpy(out, c->hFrags.data(), c->nFrags * sizeof(mm_fragment));
@@ -413,6 +432,14 @@ int mm_map_fragments(mm_ctx* c) {
   if (!c->lastSteady) { MM_HIP(c, hipStreamSynchronize(c->stream)); c->nSyncs++; }   // a steady-state pass ends with its one synchronisation
   if (c->profile) mm_profile_collect(c);
   c->mapped = true;
+  c->nPasses++; if (c->lastSteady) c->nSteadyPasses++;
+  return MM_OK;
+}
+
+int mm_pass_totals(const mm_ctx* c, uint64_t* passes, uint64_t* steadyPasses, uint64_t* redonePasses) {
+  if (passes) *passes = c->nPasses;
+  if (steadyPasses) *steadyPasses = c->nSteadyPasses;
+  if (redonePasses) *redonePasses = c->nRedone;
   return MM_OK;
 }
 
@@ -420,7 +447,7 @@ int mm_pass_stats(const mm_ctx* c, uint64_t* hostSyncs, int* steady, uint64_t* c
   if (!c->mapped) return MM_ERR_STATE;
   if (hostSyncs) *hostSyncs = c->nSyncs;
   if (steady) *steady = c->lastSteady ? 1 : 0;
-  if (counts) { counts[0] = c->nL1; counts[1] = c->nL2; counts[2] = c->lastBig; counts[3] = c->lastOps; }
+  if (counts) { counts[0] = c->nL1; counts[1] = c->nL2; counts[2] = c->lastBig; counts[3] = c->lastOps; counts[4] = c->lastHard; }
   return MM_OK;
 }
 

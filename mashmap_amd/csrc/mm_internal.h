@@ -96,6 +96,13 @@ struct mm_ctx {
   std::mutex prefetchMu;                                // mm_reads_prefetch* may come from another thread than the uploads (a reader thread): the staging state is shared
   DevBuf dBases2, dNmask, dFrags;
   std::vector<mm_fragment> hFrags;
+  // batches parked beside the resident one (mm_reads_exchange): everything an upload leaves behind, swapped by pointer
+  struct ParkedReads {
+    size_t nReads = 0, nFrags = 0, nPackedBases = 0; int32_t seqCounterBase = 0, maxFragLen = 0; bool windowed = false;
+    DevBuf dReadSrcOff, dReadPackOff, dReadLen, dReadGroup, dReadSelf, dReadHasN, dBases2, dNmask, dFrags;
+    std::vector<mm_fragment> hFrags;
+  };
+  ParkedReads parked[MM_BATCH_SLOTS];
 
   // sketches: raw (a4) and after frequent-seed removal (a8)
   DevBuf dSkHash, dSkPos, dSkStrand, dSkCount;          // [nFrags*s] u64, int2, i8 ; [nFrags] u32
@@ -128,8 +135,10 @@ struct mm_ctx {
   // steady state: the previous pass of this context went through and left every buffer sized (mm_launch_map); what it saw
   bool steadyOk = false, lastSteady = false; size_t prevBig = 0, candCap = 0, l2Chunks = 1; int prevLocap = 0, steadyFails = 0;
   unsigned long long* hPass = nullptr;                  // page-locked: the counters of a pass as read back at its end
+  size_t lastHard = 0;                                  // fragments the fast sketch kernel handed to the hard list in the last pass
   size_t lastOps = 0, lastBig = 0;                      // L2 stream entries reserved / fragments queued for the HBM point path in the last pass
   size_t nSyncs = 0;                                    // host synchronisations inside the last mm_map_fragments (diagnostics: mm_pass_syncs)
+  uint64_t nPasses = 0, nSteadyPasses = 0, nRedone = 0; // mm_map_fragments calls of this context: all, those that went through as steady-state passes, steady attempts redone the sized way
   bool keepPoints = false;                              // mm_set_option(MM_OPT_KEEP_POINTS): route every fragment through the HBM point list
 
   // profiling

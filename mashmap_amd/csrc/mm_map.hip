@@ -1128,6 +1128,7 @@ static int map_pass(mm_ctx* c, const bool steady) {
     MM_HIP(c, c->dL1.ensure(regionCap * MM_L1_REGIONS * sizeof(mm_l1_candidate) + 64));
     MM_HIP(c, c->dL1b.ensure(regionCap * MM_L1_REGIONS * sizeof(mm_l1_candidate) + 64));
     MM_HIP(c, c->dL1Cursors.ensure(sizeof hcur));
+    if (attempt == 0) MM_HIP(c, hipMemcpyAsync(c->dCounters.as<unsigned long long>() + 48, c->dCounters.p, 8, hipMemcpyDeviceToDevice, c->stream));   // the sketch launcher's hard-list length ([0], 32 bits) survives the reset below
     MM_HIP(c, hipMemsetAsync(c->dCounters.p, 0, 256, c->stream));
     MM_HIP(c, hipMemsetAsync(cnt2, 0, 64, c->stream));
     MM_HIP(c, hipMemsetAsync(c->dL1Cursors.p, 0, sizeof hcur, c->stream));
@@ -1152,7 +1153,9 @@ static int map_pass(mm_ctx* c, const bool steady) {
     if (steady) break;                                        // overflow flags ([1], [3]) are looked at when the pass is over
     MM_HIP(c, hipMemcpyAsync(hc, cnt, 64, hipMemcpyDeviceToHost, c->stream));
     MM_HIP(c, hipMemcpyAsync(hcur, c->dL1Cursors.p, sizeof hcur, hipMemcpyDeviceToHost, c->stream));
+    MM_HIP(c, hipMemcpyAsync(c->hPass + 16, c->dCounters.as<unsigned long long>() + 48, 8, hipMemcpyDeviceToHost, c->stream));
     MM_SYNC(c);
+    c->lastHard = (size_t)(c->hPass[16] & 0xffffffffull);
     if (hc[1]) { c->ptsCap = (size_t)hc[0] + (size_t)hc[0] / 8 + 4096; continue; }
     if (hc[3]) {                                              // some region overflowed: size for the largest one seen
       unsigned long long mx = 0;
@@ -1292,7 +1295,9 @@ static int map_pass(mm_ctx* c, const bool steady) {
     unsigned long long* h = c->hPass;
     MM_HIP(c, hipMemcpyAsync(h, cnt, 64, hipMemcpyDeviceToHost, c->stream));
     MM_HIP(c, hipMemcpyAsync(h + 8, cnt2, 64, hipMemcpyDeviceToHost, c->stream));
+    MM_HIP(c, hipMemcpyAsync(h + 16, c->dCounters.as<unsigned long long>() + 48, 8, hipMemcpyDeviceToHost, c->stream));
     MM_SYNC(c);
+    c->lastHard = (size_t)(h[16] & 0xffffffffull);
     if (h[1] || h[3] || h[5] || (h[6] & ~0ull) || h[9]) return MM_PASS_REDO;   // some buffer was too small for this batch: the sized pass grows it
     c->nL1 = (size_t)h[2]; c->nL2 = (size_t)h[4]; c->nMappings = c->haveReplayTables ? (size_t)h[8] : 0;
     c->lastOps = (size_t)h[10]; c->lastBig = c->prevBig;          // (the queue's length was overwritten by the L2 stage's list counter: the sized pass's stands in)
@@ -1315,7 +1320,7 @@ int mm_launch_map(mm_ctx* c) {
     const int rc = map_pass(c, true);
     if (rc == MM_OK) { c->lastSteady = true; c->steadyFails = 0; return MM_OK; }
     if (rc != MM_PASS_REDO) return rc;
-    c->steadyOk = false; c->steadyFails++;                        // three redone passes in a row: this context's batches keep outgrowing what the one before left
+    c->steadyOk = false; c->steadyFails++; c->nRedone++;                        // three redone passes in a row: this context's batches keep outgrowing what the one before left
   }
   const int rc = map_pass(c, false);
   c->steadyOk = rc == MM_OK && !allSlow && c->nL1 > 0 && c->l2Chunks == 1;   // (a batch whose L2 streams go through in chunks needs the host between them)

@@ -30,6 +30,10 @@ for name, d in out.items():
     if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
         d["hbm_bytes_per_launch"] = (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0
 out["_source"] = tag
+sys.path.insert(0, root)
+import bench  # noqa: E402
+out["_csrc_sha16"] = bench.csrc_sha16()                      # the kernel sources these counters belong to (bench.py compares with the tree it runs on)
+out["_collected"] = os.environ.get("MM_PMC_COLLECTED", "round 5")
 out["_note"] = ("per launch at bench.py's `%s` workload; FETCH_SIZE/WRITE_SIZE in KiB as rocprofv3 reports them; read side doubled per the gfx950 "
                 "correction; from profiles/%s_pmc_*.csv" % (workload, tag))
 path = os.path.join(root, "profiles", "pmc_traffic.json")
