@@ -213,6 +213,22 @@ int mm_reads_upload_device(mm_ctx* ctx, const void* dBases, size_t nBases, const
 int mm_reads_upload_packed(mm_ctx* ctx, const uint32_t* bases2, const uint32_t* nmask, const uint8_t* readHasN, const int32_t* readLengths,
                            const int64_t* readStarts, size_t nReads, const int32_t* readRefGroup, const int32_t* readSelfSeqId, int32_t seqCounterBase);
 int mm_reads_prefetch_packed(mm_ctx* ctx, const uint32_t* bases2, const uint32_t* nmask, size_t nPackedBases);
+/*
+ * One resident batch out of several packed pieces.  A reader that hands over its input in pieces of a fixed size (one page-locked buffer
+ * each: skch::Map's 512 Mbp) can have several of them mapped by ONE pass -- the kernels of a pass fill the GPU only from a few Gbp
+ * on -- without ever holding them in one host buffer: part p is exactly what one mm_reads_upload_packed call takes, the parts are laid
+ * end to end in HBM and their reads numbered consecutively (read r of part p has readId = reads of the parts before it + r).
+ * mm_reads_prefetch_packed_append is mm_reads_prefetch_packed that ADDS a piece to what has been sent ahead instead of replacing it
+ * (same thread exception): the upload takes every part it finds staged from there and copies the others itself; staged pieces an upload
+ * does not name stay staged for the next one.  reservePackedBases: packed bases the staging area should hold when it has to be
+ * (re)allocated -- it can only grow while nothing is staged; a piece that does not fit is simply not staged.
+ */
+typedef struct {
+  const uint32_t* bases2; const uint32_t* nmask; const uint8_t* readHasN; const int32_t* readLengths; const int64_t* readStarts;
+  size_t nReads; const int32_t* readRefGroup; const int32_t* readSelfSeqId;
+} mm_packed_part;
+int mm_reads_upload_packed_parts(mm_ctx* ctx, const mm_packed_part* parts, size_t nParts, int32_t seqCounterBase);
+int mm_reads_prefetch_packed_append(mm_ctx* ctx, const uint32_t* bases2, const uint32_t* nmask, size_t nPackedBases, size_t reservePackedBases);
 size_t mm_pack_read(const char* ascii, size_t len, uint32_t* bases2, uint32_t* nmask);
 size_t mm_pack_read_portable(const char* ascii, size_t len, uint32_t* bases2, uint32_t* nmask);
 int mm_reads_packed_download(mm_ctx* ctx, uint32_t* bases2, uint32_t* nmask, uint32_t* readHasN, size_t* nPackedBases);

@@ -129,6 +129,8 @@ def load():
         "mm_pass_stats": (C.c_int, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_int), vp]),
         "mm_pass_totals": (C.c_int, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "mm_reads_exchange": (C.c_int, [vp, C.c_int]),
+        "mm_reads_upload_packed_parts": (C.c_int, [vp, vp, sz, C.c_int32]),
+        "mm_reads_prefetch_packed_append": (C.c_int, [vp, vp, vp, sz, sz]),
         "mm_synchronize": (C.c_int, [vp]),
         "mm_stream": (vp, [vp]),
     }
@@ -153,7 +155,8 @@ EXPORTS = ["mm_abi_version", "mm_create", "mm_destroy", "mm_last_error", "mm_ind
            "mm_allgatherv_mappings_begin", "mm_allgatherv_mappings_end",
            "mm_gathered_counts", "mm_gathered_download", "mm_gathered_device", "mm_index_replicate", "mm_stat_replay_tables", "mm_host_alloc", "mm_host_free", "mm_reads_prefetch",
            "mm_reads_upload_packed", "mm_reads_prefetch_packed", "mm_pack_read", "mm_pack_read_portable", "mm_reads_packed_download",
-           "mm_index_layout_get", "mm_pass_stats", "mm_comm_info", "mm_pass_totals", "mm_reads_exchange"]
+           "mm_index_layout_get", "mm_pass_stats", "mm_comm_info", "mm_pass_totals", "mm_reads_exchange", "mm_reads_upload_packed_parts",
+           "mm_reads_prefetch_packed_append"]
 
 
 def stat_sketch_cutoffs(sketchSize, k, hg=True):
@@ -206,6 +209,12 @@ def pack_reads(reads, portable=False):
         nN = fn(_ptr(a), len(a), C.c_void_p(b2.ctypes.data + 8 * int(start[i])), C.c_void_p(nm.ctypes.data + 4 * int(start[i])))
         hasn[i] = 1 if nN else 0
     return b2[:int(start[-1]) * 2] if start[-1] else b2[:0], nm[:int(start[-1])] if start[-1] else nm[:0], hasn[:len(reads)], lens
+
+
+class PackedPart(C.Structure):
+    """mm_packed_part (include/mashmap_hip.h)"""
+    _fields_ = [("bases2", C.c_void_p), ("nmask", C.c_void_p), ("readHasN", C.c_void_p), ("readLengths", C.c_void_p), ("readStarts", C.c_void_p),
+                ("nReads", C.c_size_t), ("readRefGroup", C.c_void_p), ("readSelfSeqId", C.c_void_p)]
 
 
 class Context:
@@ -319,6 +328,25 @@ class Context:
         self._ck(self.lib.mm_reads_upload_packed(self.h, _ptr(b2), _ptr(nm), _ptr(hasn), _ptr(lens), _ptr(st), len(lens), _ptr(rg), _ptr(ss), seqCounterBase),
                  "mm_reads_upload_packed")
         self._nreads = len(lens)
+        return self.num_fragments()
+
+    def reads_upload_packed_parts(self, parts, seqCounterBase=0, stage=()):
+        """parts: list of dicts(packed=(bases2, nmask, hasN, lengths), starts=None, refGroup=None, selfSeqId=None) laid end to end as one
+        resident batch (mm_reads_upload_packed_parts); stage: indices of the parts sent ahead first with mm_reads_prefetch_packed_append"""
+        arr = (PackedPart * len(parts))()
+        keep = []
+        for i, p in enumerate(parts):
+            b2, nm, hasn, lens = p["packed"]
+            st = np.ascontiguousarray(p["starts"], dtype=np.int64) if p.get("starts") is not None else None
+            rg = np.ascontiguousarray(p["refGroup"], dtype=np.int32) if p.get("refGroup") is not None else None
+            ss = np.ascontiguousarray(p["selfSeqId"], dtype=np.int32) if p.get("selfSeqId") is not None else None
+            keep.append((b2, nm, hasn, lens, st, rg, ss))
+            arr[i] = PackedPart(_ptr(b2), _ptr(nm), _ptr(hasn), _ptr(lens), _ptr(st), len(lens), _ptr(rg), _ptr(ss))
+        reserve = sum(k[1].size * 32 for k in keep)
+        for i in stage:
+            self._ck(self.lib.mm_reads_prefetch_packed_append(self.h, _ptr(keep[i][0]), _ptr(keep[i][1]), keep[i][1].size * 32, reserve), "mm_reads_prefetch_packed_append")
+        self._ck(self.lib.mm_reads_upload_packed_parts(self.h, arr, len(parts), seqCounterBase), "mm_reads_upload_packed_parts")
+        self._nreads = sum(len(k[3]) for k in keep)
         return self.num_fragments()
 
     def reads_packed_download(self):

@@ -170,24 +170,68 @@ int mm_stat_sketch_cutoffs(int sketchSize, int k, int hgFilter, int32_t* out, si
 // ---------------------------------------------------------------------------------------------
 // reads
 // ---------------------------------------------------------------------------------------------
-// where the bases of an upload come from: ASCII in host memory, ASCII in device memory, or already packed in host memory
-struct ReadSource {
-  const void* ascii = nullptr; bool onDevice = false;
-  const uint32_t* b2 = nullptr; const uint32_t* nm = nullptr; const uint8_t* hasN = nullptr; const int32_t* lengths = nullptr;   // packed form
-  const int64_t* starts = nullptr;                     // packed form with gaps: packed base at which every read starts (multiples of 32, ascending)
-  bool packed() const { return b2 != nullptr || lengths != nullptr; }
-};
+// fragments of one read as Map::mapModule cuts them (computeMap.hpp:587-671): pk = packed base of the read's first base
+static inline void cut_read(mm_ctx* c, std::vector<DFrag>& dfr, size_t r, int32_t len, int64_t pk, int32_t& maxLen, bool& anyLong) {
+  const int k = c->P.kmerSize, L = c->P.segLength;
+  const bool split = !(c->P.flags & MM_FLAG_NO_SPLIT);
+  if (len < k) return;                                // computeMap.hpp:325 (shorter reads are skipped)
+  if (!split || len <= L) {                           // :587 -- with split off a read longer than segLength is ONE fragment (windowLen = len - segLength, :933)
+    if (len > L) anyLong = true;
+    c->hFrags.push_back(mm_fragment{(int32_t)r, 0, len, 0});
+    dfr.push_back(DFrag{pk, len, (int32_t)r});
+    maxLen = std::max(maxLen, len);
+    return;
+  }
+  const int nfull = len / L;                          // :610
+  for (int i = 0; i < nfull; i++) {
+    c->hFrags.push_back(mm_fragment{(int32_t)r, i * L, L, 0});
+    dfr.push_back(DFrag{pk + (int64_t)i * L, L, (int32_t)r});
+  }
+  if (nfull >= 1 && len % L != 0) {                   // :644
+    c->hFrags.push_back(mm_fragment{(int32_t)r, len - L, L, 0});
+    dfr.push_back(DFrag{pk + (int64_t)(len - L), L, (int32_t)r});
+  }
+  maxLen = std::max(maxLen, L);
+}
 
-static int upload_reads_common(mm_ctx* c, const ReadSource& S, const int64_t* readOffsets, size_t nReads, const int32_t* readRefGroup,
-                               const int32_t* readSelfSeqId, int32_t seqCounterBase) {
-  const bool packed = S.packed();
-  if (packed ? (nReads && !S.lengths) : !readOffsets) { c->err = "mm_reads_upload: null argument"; return MM_ERR_ARG; }
+// the per-read arrays, the fragment table and the run-off words behind the packed bases; ends with the stream synchronised (the host
+// staging vectors go out of scope)
+static int finish_upload(mm_ctx* c, size_t nReads, int64_t pk, const std::vector<int64_t>& srcOff, const std::vector<int64_t>& packOff, const std::vector<int32_t>& rlen,
+                         const std::vector<int32_t>& grp, const std::vector<int32_t>& self, const std::vector<uint32_t>* hasN32, const std::vector<DFrag>& dfr, bool packOnDevice) {
+  MM_HIP(c, hipMemcpyAsync(c->dReadSrcOff.p, srcOff.data(), (nReads + 1) * 8, hipMemcpyHostToDevice, c->stream));
+  MM_HIP(c, hipMemcpyAsync(c->dReadPackOff.p, packOff.data(), (nReads + 1) * 8, hipMemcpyHostToDevice, c->stream));
+  if (nReads) {
+    MM_HIP(c, hipMemcpyAsync(c->dReadLen.p, rlen.data(), nReads * 4, hipMemcpyHostToDevice, c->stream));
+    MM_HIP(c, hipMemcpyAsync(c->dReadGroup.p, grp.data(), nReads * 4, hipMemcpyHostToDevice, c->stream));
+    MM_HIP(c, hipMemcpyAsync(c->dReadSelf.p, self.data(), nReads * 4, hipMemcpyHostToDevice, c->stream));
+  }
+  if (hasN32) MM_HIP(c, hipMemcpyAsync(c->dReadHasN.p, hasN32->data(), nReads * 4 + 4, hipMemcpyHostToDevice, c->stream));
+  else MM_HIP(c, hipMemsetAsync(c->dReadHasN.p, 0, nReads * 4 + 4, c->stream));
+  MM_HIP(c, hipMemsetAsync((char*)c->dBases2.p + pk / 4, 0, 64, c->stream));   // run-off words read by the last fragment
+  MM_HIP(c, hipMemsetAsync((char*)c->dNmask.p + pk / 8, 0, 64, c->stream));
+  if (!dfr.empty()) MM_HIP(c, hipMemcpyAsync(c->dFrags.p, dfr.data(), dfr.size() * sizeof(DFrag), hipMemcpyHostToDevice, c->stream));
+  if (packOnDevice) { const int rc = mm_launch_pack(c); if (rc != MM_OK) return rc; }
+  MM_HIP(c, hipStreamSynchronize(c->stream));
+  return MM_OK;
+}
+
+static int ensure_read_buffers(mm_ctx* c, size_t nReads, int64_t pk, size_t nFrags) {
+  MM_HIP(c, c->dReadSrcOff.ensure((nReads + 1) * 8)); MM_HIP(c, c->dReadPackOff.ensure((nReads + 1) * 8));
+  MM_HIP(c, c->dReadLen.ensure(nReads * 4 + 4)); MM_HIP(c, c->dReadGroup.ensure(nReads * 4 + 4)); MM_HIP(c, c->dReadSelf.ensure(nReads * 4 + 4));
+  MM_HIP(c, c->dReadHasN.ensure(nReads * 4 + 4));
+  MM_HIP(c, c->dBases2.ensure((size_t)pk / 4 + 64)); MM_HIP(c, c->dNmask.ensure((size_t)pk / 8 + 64));
+  MM_HIP(c, c->dFrags.ensure(nFrags * sizeof(DFrag) + 16));
+  return MM_OK;
+}
+
+// ASCII bases (host or device memory): normalised and packed on the device (k_pack2bit)
+static int upload_reads_ascii(mm_ctx* c, const void* ascii, bool onDevice, const int64_t* readOffsets, size_t nReads, const int32_t* readRefGroup,
+                              const int32_t* readSelfSeqId, int32_t seqCounterBase) {
+  if (!readOffsets) { c->err = "mm_reads_upload: null argument"; return MM_ERR_ARG; }
   // the prefetch state (staging buffer, its copy event, what it holds) is matched and consumed below, and the copies out of the staging
   // buffer have completed when this function returns: a mm_reads_prefetch* from another thread waits for that
   std::lock_guard<std::mutex> prefetchLock(c->prefetchMu);
   MM_HIP(c, hipSetDevice(c->device));
-  const int k = c->P.kmerSize, L = c->P.segLength;
-  const bool split = !(c->P.flags & MM_FLAG_NO_SPLIT);
   std::vector<int64_t> srcOff(nReads + 1), packOff(nReads + 1);
   std::vector<int32_t> rlen(nReads);
   c->hFrags.clear();
@@ -195,118 +239,132 @@ static int upload_reads_common(mm_ctx* c, const ReadSource& S, const int64_t* re
   dfr.reserve(c->hFrags.capacity() ? c->hFrags.capacity() : nReads * 2 + 16);
   int64_t pk = 0; int32_t maxLen = 0; bool anyLong = false;
   for (size_t r = 0; r < nReads; r++) {
-    const int64_t len64 = packed ? (int64_t)S.lengths[r] : readOffsets[r + 1] - readOffsets[r];
+    const int64_t len64 = readOffsets[r + 1] - readOffsets[r];
     if (len64 < 0 || len64 > 0x7fffffff) { c->err = "mm_reads_upload: read length out of range (offset_t is int32, base_types.hpp:21)"; return MM_ERR_ARG; }
-    const int32_t len = (int32_t)len64;
-    if (packed && S.starts) {                         // reads placed by the caller: gaps between them are allowed (and never read as bases)
-      const int64_t at = S.starts[r] - S.starts[0];
-      if (at < pk || (at & 31)) { c->err = "mm_reads_upload_packed: readStarts must be ascending multiples of 32 that leave room for every read"; return MM_ERR_ARG; }
-      pk = at;
-    }
-    srcOff[r] = packed ? 0 : readOffsets[r]; packOff[r] = pk; rlen[r] = len;
-    if (len >= k) {                                   // computeMap.hpp:325 (shorter reads are skipped)
-      if (!split || len <= L) {                       // :587 -- with split off a read longer than segLength is ONE fragment (windowLen = len - segLength, :933)
-        if (len > L) anyLong = true;
-        c->hFrags.push_back(mm_fragment{(int32_t)r, 0, len, 0});
-        dfr.push_back(DFrag{pk, len, (int32_t)r});
-        maxLen = std::max(maxLen, len);
-      } else {
-        const int nfull = len / L;                    // :610
-        for (int i = 0; i < nfull; i++) {
-          c->hFrags.push_back(mm_fragment{(int32_t)r, i * L, L, 0});
-          dfr.push_back(DFrag{pk + (int64_t)i * L, L, (int32_t)r});
-        }
-        if (nfull >= 1 && len % L != 0) {             // :644
-          c->hFrags.push_back(mm_fragment{(int32_t)r, len - L, L, 0});
-          dfr.push_back(DFrag{pk + (int64_t)(len - L), L, (int32_t)r});
-        }
-        maxLen = std::max(maxLen, L);
-      }
-    }
-    pk += ((int64_t)len + 31) / 32 * 32;
+    srcOff[r] = readOffsets[r]; packOff[r] = pk; rlen[r] = (int32_t)len64;
+    cut_read(c, dfr, r, (int32_t)len64, pk, maxLen, anyLong);
+    pk += (len64 + 31) / 32 * 32;
   }
-  if (packed && pk && (!S.b2 || !S.nm)) { c->err = "mm_reads_upload_packed: null argument"; return MM_ERR_ARG; }
-  srcOff[nReads] = packed ? 0 : readOffsets[nReads]; packOff[nReads] = pk;
+  srcOff[nReads] = readOffsets[nReads]; packOff[nReads] = pk;
   c->nReads = nReads; c->nFrags = dfr.size(); c->nPackedBases = (size_t)pk; c->seqCounterBase = seqCounterBase; c->maxFragLen = maxLen;
   c->sketched = false; c->mapped = false; c->fragTabStale = true; c->gathered = false;
   c->windowed = anyLong;
-
-  const size_t srcBase = packed ? 0 : (size_t)readOffsets[0];
-  const size_t nSrc = packed ? 0 : (size_t)(readOffsets[nReads] - readOffsets[0]);
-  if (!packed && nSrc && !S.ascii) { c->err = "mm_reads_upload: null argument"; return MM_ERR_ARG; }
+  const size_t srcBase = (size_t)readOffsets[0];
+  const size_t nSrc = (size_t)(readOffsets[nReads] - readOffsets[0]);
+  if (nSrc && !ascii) { c->err = "mm_reads_upload: null argument"; return MM_ERR_ARG; }
   for (size_t r = 0; r <= nReads; r++) srcOff[r] -= (int64_t)srcBase;
-  // bytes mm_reads_prefetch[_packed] has already sent (same host range): take that buffer and wait for its copy on the device
-  bool prefetched = false;
-  if (c->prefetchValid) {
-    if (!packed && !c->prefetchPacked && !S.onDevice && nSrc && c->prefetchPtr == (const void*)((const char*)S.ascii + srcBase) && c->prefetchBytes == nSrc) prefetched = true;
-    if (packed && c->prefetchPacked && pk && c->prefetchPtr == (const void*)S.b2 && c->prefetchPtr2 == (const void*)S.nm && c->prefetchBytes == (size_t)pk) prefetched = true;
-  }
+  // bytes mm_reads_prefetch has already sent (same host range): take that buffer and wait for its copy on the device
+  const bool prefetched = c->prefetchValid && !onDevice && nSrc && c->prefetchPtr == (const void*)((const char*)ascii + srcBase) && c->prefetchBytes == nSrc;
   c->prefetchValid = false;
-  if (prefetched) { if (!packed) std::swap(c->dAscii, c->dAsciiNext); MM_HIP(c, hipStreamWaitEvent(c->stream, c->copyDone, 0)); }
-  else if (!packed) MM_HIP(c, c->dAscii.ensure(nSrc + 64));
-  MM_HIP(c, c->dReadSrcOff.ensure((nReads + 1) * 8)); MM_HIP(c, c->dReadPackOff.ensure((nReads + 1) * 8));
-  MM_HIP(c, c->dReadLen.ensure(nReads * 4 + 4)); MM_HIP(c, c->dReadGroup.ensure(nReads * 4 + 4)); MM_HIP(c, c->dReadSelf.ensure(nReads * 4 + 4));
-  MM_HIP(c, c->dReadHasN.ensure(nReads * 4 + 4));
-  MM_HIP(c, c->dBases2.ensure((size_t)pk / 4 + 64)); MM_HIP(c, c->dNmask.ensure((size_t)pk / 8 + 64));
-  MM_HIP(c, c->dFrags.ensure(dfr.size() * sizeof(DFrag) + 16));
-  std::vector<uint32_t> hasN32;
-  if (packed) {
-    // the words are the device layout already: straight into dBases2 / dNmask (from the prefetch staging buffer if they travelled ahead)
-    if (pk) {
-      if (prefetched) {
-        MM_HIP(c, hipMemcpyAsync(c->dBases2.p, c->dAsciiNext.p, (size_t)pk / 4, hipMemcpyDeviceToDevice, c->stream));
-        MM_HIP(c, hipMemcpyAsync(c->dNmask.p, (const char*)c->dAsciiNext.p + (size_t)pk / 4, (size_t)pk / 8, hipMemcpyDeviceToDevice, c->stream));
-      } else {
-        MM_HIP(c, hipMemcpyAsync(c->dBases2.p, S.b2, (size_t)pk / 4, hipMemcpyHostToDevice, c->stream));
-        MM_HIP(c, hipMemcpyAsync(c->dNmask.p, S.nm, (size_t)pk / 8, hipMemcpyHostToDevice, c->stream));
-      }
-    }
-    hasN32.assign(nReads + 1, 0u);
-    for (size_t r = 0; r < nReads; r++) {
-      if (S.hasN) hasN32[r] = S.hasN[r] ? 1u : 0u;
-      else {                                            // the read's own mask words only: the words of a gap behind it are never read (header contract)
-        const uint32_t* w = S.nm + packOff[r] / 32; const size_t nw = ((size_t)rlen[r] + 31) / 32;
-        uint32_t any = 0; for (size_t i = 0; i < nw; i++) any |= w[i];
-        hasN32[r] = any ? 1u : 0u;
-      }
-    }
-    MM_HIP(c, hipMemcpyAsync(c->dReadHasN.p, hasN32.data(), nReads * 4 + 4, hipMemcpyHostToDevice, c->stream));
-  } else if (nSrc && !prefetched) MM_HIP(c, hipMemcpyAsync(c->dAscii.p, (const char*)S.ascii + srcBase, nSrc, S.onDevice ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
-  MM_HIP(c, hipMemcpyAsync(c->dReadSrcOff.p, srcOff.data(), (nReads + 1) * 8, hipMemcpyHostToDevice, c->stream));
-  MM_HIP(c, hipMemcpyAsync(c->dReadPackOff.p, packOff.data(), (nReads + 1) * 8, hipMemcpyHostToDevice, c->stream));
-  if (nReads) MM_HIP(c, hipMemcpyAsync(c->dReadLen.p, rlen.data(), nReads * 4, hipMemcpyHostToDevice, c->stream));
+  if (prefetched) { std::swap(c->dAscii, c->dAsciiNext); c->staged.clear(); c->stagedBytes = 0; MM_HIP(c, hipStreamWaitEvent(c->stream, c->copyDone, 0)); }
+  else MM_HIP(c, c->dAscii.ensure(nSrc + 64));
+  { const int rc = ensure_read_buffers(c, nReads, pk, dfr.size()); if (rc != MM_OK) return rc; }
+  if (nSrc && !prefetched) MM_HIP(c, hipMemcpyAsync(c->dAscii.p, (const char*)ascii + srcBase, nSrc, onDevice ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
   std::vector<int32_t> grp(nReads, -1), self(nReads, -1);
   if (readRefGroup) grp.assign(readRefGroup, readRefGroup + nReads);
   if (readSelfSeqId) self.assign(readSelfSeqId, readSelfSeqId + nReads);
-  if (nReads) {
-    MM_HIP(c, hipMemcpyAsync(c->dReadGroup.p, grp.data(), nReads * 4, hipMemcpyHostToDevice, c->stream));
-    MM_HIP(c, hipMemcpyAsync(c->dReadSelf.p, self.data(), nReads * 4, hipMemcpyHostToDevice, c->stream));
+  return finish_upload(c, nReads, pk, srcOff, packOff, rlen, grp, self, nullptr, dfr, true);
+}
+
+// Packed pieces laid end to end: part p owns the packed bases [base_p, base_p + P_p) of the resident batch
+static int upload_packed_parts(mm_ctx* c, const mm_packed_part* parts, size_t nParts, int32_t seqCounterBase) {
+  if (nParts && !parts) { c->err = "mm_reads_upload_packed: null argument"; return MM_ERR_ARG; }
+  std::lock_guard<std::mutex> prefetchLock(c->prefetchMu);
+  MM_HIP(c, hipSetDevice(c->device));
+  size_t nReads = 0;
+  for (size_t p = 0; p < nParts; p++) {
+    if (parts[p].nReads && !parts[p].readLengths) { c->err = "mm_reads_upload_packed: null argument"; return MM_ERR_ARG; }
+    nReads += parts[p].nReads;
   }
-  if (!packed) MM_HIP(c, hipMemsetAsync(c->dReadHasN.p, 0, nReads * 4 + 4, c->stream));
-  MM_HIP(c, hipMemsetAsync((char*)c->dBases2.p + pk / 4, 0, 64, c->stream));   // run-off words read by the last fragment
-  MM_HIP(c, hipMemsetAsync((char*)c->dNmask.p + pk / 8, 0, 64, c->stream));
-  if (!dfr.empty()) MM_HIP(c, hipMemcpyAsync(c->dFrags.p, dfr.data(), dfr.size() * sizeof(DFrag), hipMemcpyHostToDevice, c->stream));
-  if (!packed) { const int rc = mm_launch_pack(c); if (rc != MM_OK) return rc; }
-  MM_HIP(c, hipStreamSynchronize(c->stream));         // host staging vectors go out of scope
-  return MM_OK;
+  if (nReads > 0x7fffffff) { c->err = "mm_reads_upload_packed: more than 2^31 reads in one batch"; return MM_ERR_ARG; }
+  std::vector<int64_t> srcOff(nReads + 1, 0), packOff(nReads + 1);
+  std::vector<int32_t> rlen(nReads), grp(nReads, -1), self(nReads, -1);
+  std::vector<uint32_t> hasN32(nReads + 1, 0u);
+  std::vector<int64_t> partBase(nParts + 1, 0);
+  c->hFrags.clear();
+  std::vector<DFrag> dfr;
+  dfr.reserve(c->hFrags.capacity() ? c->hFrags.capacity() : nReads * 2 + 16);
+  int64_t pk = 0; int32_t maxLen = 0; bool anyLong = false;
+  size_t r = 0;
+  for (size_t p = 0; p < nParts; p++) {
+    const mm_packed_part& P = parts[p];
+    partBase[p] = pk;
+    int64_t at = 0;                                   // packed base inside the part
+    for (size_t i = 0; i < P.nReads; i++, r++) {
+      const int64_t len64 = (int64_t)P.readLengths[i];
+      if (len64 < 0) { c->err = "mm_reads_upload_packed: negative read length"; return MM_ERR_ARG; }
+      if (P.readStarts) {                             // reads placed by the caller: gaps between them are allowed (and never read as bases)
+        const int64_t want = P.readStarts[i] - P.readStarts[0];
+        if (want < at || (want & 31)) { c->err = "mm_reads_upload_packed: readStarts must be ascending multiples of 32 that leave room for every read"; return MM_ERR_ARG; }
+        at = want;
+      }
+      packOff[r] = pk + at; rlen[r] = (int32_t)len64;
+      if (P.readRefGroup) grp[r] = P.readRefGroup[i];
+      if (P.readSelfSeqId) self[r] = P.readSelfSeqId[i];
+      if (P.readHasN) hasN32[r] = P.readHasN[i] ? 1u : 0u;
+      else if (len64) {                               // the read's own mask words only: the words of a gap behind it are never read (header contract)
+        if (!P.nmask) { c->err = "mm_reads_upload_packed: null argument"; return MM_ERR_ARG; }
+        const uint32_t* w = P.nmask + at / 32; const size_t nw = ((size_t)len64 + 31) / 32;
+        uint32_t any = 0; for (size_t j = 0; j < nw; j++) any |= w[j];
+        hasN32[r] = any ? 1u : 0u;
+      }
+      cut_read(c, dfr, r, (int32_t)len64, pk + at, maxLen, anyLong);
+      at += (len64 + 31) / 32 * 32;
+    }
+    if (at && (!P.bases2 || !P.nmask)) { c->err = "mm_reads_upload_packed: null argument"; return MM_ERR_ARG; }
+    pk += at;
+  }
+  partBase[nParts] = pk; packOff[nReads] = pk;
+  c->nReads = nReads; c->nFrags = dfr.size(); c->nPackedBases = (size_t)pk; c->seqCounterBase = seqCounterBase; c->maxFragLen = maxLen;
+  c->sketched = false; c->mapped = false; c->fragTabStale = true; c->gathered = false;
+  c->windowed = anyLong;
+  c->prefetchValid = false;                           // (an ASCII prefetch, if any, is not for this upload)
+  { const int rc = ensure_read_buffers(c, nReads, pk, dfr.size()); if (rc != MM_OK) return rc; }
+  // the words are the device layout already: straight into dBases2 / dNmask at the part's base -- from the staging area where the piece
+  // travelled ahead (mm_reads_prefetch_packed[_append]: same two pointers, same packed length), from the host otherwise
+  bool waited = false;
+  std::vector<char> used(c->staged.size(), 0);
+  for (size_t p = 0; p < nParts; p++) {
+    const int64_t n = partBase[p + 1] - partBase[p];
+    if (!n) continue;
+    char* dB = (char*)c->dBases2.p + partBase[p] / 4; char* dM = (char*)c->dNmask.p + partBase[p] / 8;
+    size_t hit = c->staged.size();
+    for (size_t q = 0; q < c->staged.size(); q++)
+      if (!used[q] && c->staged[q].b2 == (const void*)parts[p].bases2 && c->staged[q].nm == (const void*)parts[p].nmask && c->staged[q].nPacked == (size_t)n) { hit = q; break; }
+    if (hit < c->staged.size()) {
+      if (!waited) { MM_HIP(c, hipStreamWaitEvent(c->stream, c->copyDone, 0)); waited = true; }
+      used[hit] = 1;
+      const char* src = (const char*)c->dAsciiNext.p + c->staged[hit].off;
+      MM_HIP(c, hipMemcpyAsync(dB, src, (size_t)n / 4, hipMemcpyDeviceToDevice, c->stream));
+      MM_HIP(c, hipMemcpyAsync(dM, src + (size_t)n / 4, (size_t)n / 8, hipMemcpyDeviceToDevice, c->stream));
+    } else {
+      MM_HIP(c, hipMemcpyAsync(dB, parts[p].bases2, (size_t)n / 4, hipMemcpyHostToDevice, c->stream));
+      MM_HIP(c, hipMemcpyAsync(dM, parts[p].nmask, (size_t)n / 8, hipMemcpyHostToDevice, c->stream));
+    }
+  }
+  const int rc = finish_upload(c, nReads, pk, srcOff, packOff, rlen, grp, self, &hasN32, dfr, false);   // synchronises: the copies out of the staging area are done
+  // pieces this upload did not name stay staged; the area starts over once it is empty
+  std::vector<mm_ctx::StagedPart> left;
+  for (size_t q = 0; q < c->staged.size(); q++) if (!used[q]) left.push_back(c->staged[q]);
+  c->staged.swap(left);
+  return rc;
 }
 
 int mm_reads_upload(mm_ctx* c, const char* bases, const int64_t* readOffsets, size_t nReads, const int32_t* g, const int32_t* s, int32_t base) {
-  ReadSource S; S.ascii = bases;
-  return upload_reads_common(c, S, readOffsets, nReads, g, s, base);
+  return upload_reads_ascii(c, bases, false, readOffsets, nReads, g, s, base);
 }
 int mm_reads_upload_device(mm_ctx* c, const void* dBases, size_t nBases, const int64_t* readOffsets, size_t nReads, const int32_t* g,
                            const int32_t* s, int32_t base) {
   (void)nBases;
-  ReadSource S; S.ascii = dBases; S.onDevice = true;
-  return upload_reads_common(c, S, readOffsets, nReads, g, s, base);
+  return upload_reads_ascii(c, dBases, true, readOffsets, nReads, g, s, base);
 }
 int mm_reads_upload_packed(mm_ctx* c, const uint32_t* bases2, const uint32_t* nmask, const uint8_t* readHasN, const int32_t* readLengths, const int64_t* readStarts,
                            size_t nReads, const int32_t* g, const int32_t* s, int32_t base) {
   static const int32_t none = 0;
-  ReadSource S; S.b2 = bases2; S.nm = nmask; S.hasN = readHasN; S.lengths = readLengths ? readLengths : &none; S.starts = nReads ? readStarts : nullptr;
-  return upload_reads_common(c, S, nullptr, nReads, g, s, base);
+  mm_packed_part P{bases2, nmask, readHasN, readLengths ? readLengths : &none, nReads ? readStarts : nullptr, nReads, g, s};
+  return upload_packed_parts(c, &P, 1, base);
 }
+int mm_reads_upload_packed_parts(mm_ctx* c, const mm_packed_part* parts, size_t nParts, int32_t base) { return upload_packed_parts(c, parts, nParts, base); }
 size_t mm_pack_read(const char* ascii, size_t len, uint32_t* bases2, uint32_t* nmask) { return mmhost::pack2bit(ascii, len, bases2, nmask); }
 size_t mm_pack_read_portable(const char* ascii, size_t len, uint32_t* bases2, uint32_t* nmask) { return mmhost::pack2bit_scalar(ascii, len, bases2, nmask); }
 
@@ -320,14 +378,10 @@ int mm_reads_packed_download(mm_ctx* c, uint32_t* bases2, uint32_t* nmask, uint3
   return MM_OK;
 }
 
-static int prefetch_common(mm_ctx* c, const void* p0, size_t n0, const void* p1, size_t n1) {
+static int prefetch_streams(mm_ctx* c) {
   MM_HIP(c, hipSetDevice(c->device));
   if (!c->copyStream) MM_HIP(c, hipStreamCreateWithFlags(&c->copyStream, hipStreamNonBlocking));
   if (!c->copyDone) MM_HIP(c, hipEventCreateWithFlags(&c->copyDone, hipEventDisableTiming));
-  MM_HIP(c, c->dAsciiNext.ensure(n0 + n1 + 64));
-  MM_HIP(c, hipMemcpyAsync(c->dAsciiNext.p, p0, n0, hipMemcpyHostToDevice, c->copyStream));
-  if (n1) MM_HIP(c, hipMemcpyAsync((char*)c->dAsciiNext.p + n0, p1, n1, hipMemcpyHostToDevice, c->copyStream));
-  MM_HIP(c, hipEventRecord(c->copyDone, c->copyStream));
   return MM_OK;
 }
 
@@ -335,21 +389,58 @@ int mm_reads_prefetch(mm_ctx* c, const char* bases, size_t nBytes) {
   std::lock_guard<std::mutex> prefetchLock(c->prefetchMu);
   c->prefetchValid = false;
   if (!bases || !nBytes) return MM_OK;
-  const int rc = prefetch_common(c, bases, nBytes, nullptr, 0);
-  if (rc != MM_OK) return rc;
+  { const int rc = prefetch_streams(c); if (rc != MM_OK) return rc; }
+  c->staged.clear(); c->stagedBytes = 0;              // the staging area is one buffer: ASCII ahead replaces packed pieces ahead
+  MM_HIP(c, c->dAsciiNext.ensure(nBytes + 64));
+  MM_HIP(c, hipMemcpyAsync(c->dAsciiNext.p, bases, nBytes, hipMemcpyHostToDevice, c->copyStream));
+  MM_HIP(c, hipEventRecord(c->copyDone, c->copyStream));
   c->prefetchPtr = bases; c->prefetchPtr2 = nullptr; c->prefetchBytes = nBytes; c->prefetchPacked = false; c->prefetchValid = true;
+  return MM_OK;
+}
+
+// adds one packed piece to the staging area (prefetchMu held)
+static int stage_packed(mm_ctx* c, const uint32_t* bases2, const uint32_t* nmask, size_t nPackedBases, size_t reservePackedBases) {
+  if (nPackedBases % 32) { c->err = "mm_reads_prefetch_packed: the packed length of a batch is a multiple of 32 bases"; return MM_ERR_ARG; }
+  { const int rc = prefetch_streams(c); if (rc != MM_OK) return rc; }
+  c->prefetchValid = false;                           // (packed pieces replace an ASCII batch sent ahead)
+  const size_t bytes = nPackedBases / 4 + nPackedBases / 8;
+  if (c->staged.empty()) {                            // nothing on its way: the area may grow, and starts over
+    const size_t want = std::max(bytes, reservePackedBases / 4 + reservePackedBases / 8) + 64;
+    MM_HIP(c, c->dAsciiNext.ensure(want));
+    c->stagedBytes = 0;
+  }
+  // the area is used as a ring: pieces leave in the order they came (an upload takes the pieces of the oldest batches), so the next
+  // piece goes behind the newest one, or to the front again once the oldest ones have left
+  auto fits = [&](size_t off) {
+    if (off + bytes + 64 > c->dAsciiNext.bytes) return false;
+    for (const auto& q : c->staged) { const size_t qb = q.nPacked / 4 + q.nPacked / 8; if (off < q.off + qb && q.off < off + bytes) return false; }
+    return true;
+  };
+  if (!fits(c->stagedBytes)) {
+    if (!fits(0)) return MM_OK;                       // no room under the pieces that are on their way: this one travels with its upload
+    c->stagedBytes = 0;
+  }
+  char* dst = (char*)c->dAsciiNext.p + c->stagedBytes;
+  MM_HIP(c, hipMemcpyAsync(dst, bases2, nPackedBases / 4, hipMemcpyHostToDevice, c->copyStream));
+  MM_HIP(c, hipMemcpyAsync(dst + nPackedBases / 4, nmask, nPackedBases / 8, hipMemcpyHostToDevice, c->copyStream));
+  MM_HIP(c, hipEventRecord(c->copyDone, c->copyStream));   // the event always marks the last piece: an upload that waits for it has them all
+  c->staged.push_back(mm_ctx::StagedPart{bases2, nmask, nPackedBases, c->stagedBytes});
+  c->stagedBytes += bytes;                            // where the next piece goes
   return MM_OK;
 }
 
 int mm_reads_prefetch_packed(mm_ctx* c, const uint32_t* bases2, const uint32_t* nmask, size_t nPackedBases) {
   std::lock_guard<std::mutex> prefetchLock(c->prefetchMu);
   c->prefetchValid = false;
+  c->staged.clear(); c->stagedBytes = 0;
   if (!bases2 || !nmask || !nPackedBases) return MM_OK;
-  if (nPackedBases % 32) { c->err = "mm_reads_prefetch_packed: the packed length of a batch is a multiple of 32 bases"; return MM_ERR_ARG; }
-  const int rc = prefetch_common(c, bases2, nPackedBases / 4, nmask, nPackedBases / 8);
-  if (rc != MM_OK) return rc;
-  c->prefetchPtr = bases2; c->prefetchPtr2 = nmask; c->prefetchBytes = nPackedBases; c->prefetchPacked = true; c->prefetchValid = true;
-  return MM_OK;
+  return stage_packed(c, bases2, nmask, nPackedBases, nPackedBases);
+}
+
+int mm_reads_prefetch_packed_append(mm_ctx* c, const uint32_t* bases2, const uint32_t* nmask, size_t nPackedBases, size_t reservePackedBases) {
+  std::lock_guard<std::mutex> prefetchLock(c->prefetchMu);
+  if (!bases2 || !nmask || !nPackedBases) return MM_OK;
+  return stage_packed(c, bases2, nmask, nPackedBases, reservePackedBases);
 }
 
 void* mm_host_alloc(size_t bytes) {

@@ -93,6 +93,8 @@ struct mm_ctx {
   // mm_reads_prefetch: the next batch's ASCII bytes, copied on a stream of their own while the current batch is mapped
   DevBuf dAsciiNext; hipStream_t copyStream = nullptr; hipEvent_t copyDone = nullptr;
   const void* prefetchPtr = nullptr; const void* prefetchPtr2 = nullptr; size_t prefetchBytes = 0; bool prefetchValid = false, prefetchPacked = false;
+  struct StagedPart { const void* b2; const void* nm; size_t nPacked; size_t off; };   // packed parts sent ahead (mm_reads_prefetch_packed[_append]): [codes | mask] at dAsciiNext + off
+  std::vector<StagedPart> staged; size_t stagedBytes = 0;
   std::mutex prefetchMu;                                // mm_reads_prefetch* may come from another thread than the uploads (a reader thread): the staging state is shared
   DevBuf dBases2, dNmask, dFrags;
   std::vector<mm_fragment> hFrags;

@@ -15,6 +15,11 @@
 // The reference runs one pthread task per read (ThreadPool.hpp); here three stages run concurrently on successive batches
 // (MASHMAP_HIP_BATCH_MBP, default 512 Mbp): the reader thread parses batch i+2, the device stage maps batch i+1, the post stage
 // chains / filters / prints batch i on param.threads std::threads.  Output order == input order (ThreadPool.hpp:187-211).
+// A device PASS covers as many parsed batches as it takes to fill the GPU (MASHMAP_HIP_COALESCE_MBP, default 2048 Mbp; the kernels of a
+// 512 Mbp pass run at ~120 Gbp/s, those of a 2 Gbp pass at ~150): the batches of a pass are laid end to end in HBM by
+// mm_reads_upload_packed_parts, each from its own page-locked buffer, so the reader's unit (and the memory it locks) stays small.  The
+// pass size ramps up from one batch (1, 1, 2, 4, 4 ...: the pipeline fills at once) and, when the input size is known, down again at the
+// end (the last pass and its post stage are what the run waits for with nothing overlapping them).
 //
 // Device stage.  The kernels report, per fragment, the candidate mappings doL2Mapping would have pushed (mm_mapping, k_l2_select);
 // with several contexts (MASHMAP_HIP_DEVICES, one per GPU, index replicated by Sketch) a batch -- 512 Mbp PER CONTEXT -- is cut into
@@ -76,10 +81,11 @@ class Map {
   MapPost post;                                  // everything downstream of the device integers (skch_map_post.hpp)
   std::unique_ptr<mmhost::WorkerPool> postPool;  // the post stage's threads
   bool packedUpload = true;                      // batches travel as 2-bit codes + N mask (set in mapQuery)
-  // Host-to-device copies run ahead of the kernels: every context has ONE staging slot (mm_reads_prefetch[_packed]).  Whoever finds it
-  // free starts the copy of the next batch's block -- the device stage right after it has taken over the previous copy, or the reader
-  // the moment it has parsed a batch while the slot is idle -- so the copy of batch i+1 always runs under the kernels of batch i.
-  std::mutex pfMu; std::vector<char> slotFree; bool earlyPrefetch = true;
+  // Host-to-device copies run ahead of the kernels: every context has a staging area that takes the blocks of parsed batches in queue
+  // order (mm_reads_prefetch_packed_append), up to twice a pass's worth.  Whoever sees room sends the next block -- the reader the moment
+  // it has parsed a batch, the device stage right after an upload has emptied part of the area -- so the copies of the batches behind a
+  // pass always run under that pass's kernels.  stagedBases[i]: bases of queued batches already sent to context i (guarded by pfMu).
+  std::mutex pfMu; std::vector<size_t> stagedBases; size_t stageCapBases = 0; bool earlyPrefetch = true;
   skch::Time::time_point tStart = skch::Time::now();   // MASHMAP_HIP_TIMING lines carry the time since the Map was constructed
   // one write per diagnostic line: three stages log at once, and `std::cerr << a << b` from two threads interleaves inside a line
   struct LogLine {
@@ -91,9 +97,12 @@ class Map {
   struct Batch {
     mmhost::ParsedBatch in;                      // names, offsets, bases (page-locked buffer, recycled through bufferPool)
     seqno_t firstSeqCounter = 0;
-    PinnedRecs<mm_mapping> recs;                 // candidate mappings of the batch, read-major (filled by the device stage; page-locked, skch_types.hpp)
+    // candidate mappings of the batch, read-major: a slice of the records its device pass brought back (page-locked, skch_types.hpp;
+    // shared by the batches of the pass)
+    std::shared_ptr<PinnedRecs<mm_mapping>> recOwner; const mm_mapping* recs = nullptr; size_t nRecs = 0;
     mutable std::vector<char> prefetched;        // per context: the batch's block is already on its way to that GPU (guarded by pfMu)
     size_t size() const { return in.names.size(); }
+    size_t bases() const { return (size_t)in.totalBases(); }
   };
   // page-locked batch buffers come from skch::HostBufferPool (allocated while the index was being built) and are recycled
   [[noreturn]] void die(const char* what, mm_ctx* c = nullptr) const {
@@ -116,8 +125,23 @@ class Map {
       return true;
     }
     void close() { { std::lock_guard<std::mutex> lk(mu); done = true; } cvEmpty.notify_all(); }
-    // the batch the next get() will return, if it is already there (only the consumer removes elements, so it stays put)
-    const Batch* peekFront() { std::lock_guard<std::mutex> lk(mu); return q.empty() ? nullptr : &q.front(); }
+    // the batches of one device pass: waits until `want` bases are queued (or the producer is done, or the queue is full), then takes
+    // batches from the front until the pass holds `want` bases -- at least one, at most `maxBatches`
+    bool getGroup(std::vector<Batch>& g, size_t want, size_t maxBatches) {
+      std::unique_lock<std::mutex> lk(mu);
+      cvEmpty.wait(lk, [&] {
+        if (done || q.size() >= cap || q.size() >= maxBatches) return !q.empty() || done;
+        size_t have = 0; for (const auto& b : q) have += b.bases();
+        return !q.empty() && have >= want;
+      });
+      if (q.empty()) return false;
+      size_t have = 0;
+      while (!q.empty() && g.size() < maxBatches && (g.empty() || have < want)) { have += q.front().bases(); g.emplace_back(std::move(q.front())); q.pop_front(); }
+      lk.unlock(); cvFull.notify_all();
+      return true;
+    }
+    // every queued batch in order (only the consumer removes elements: what fn sees stays put until the consumer's next get)
+    template <class F> void forEach(F fn) { std::lock_guard<std::mutex> lk(mu); for (auto& b : q) fn(b); }
   };
 
  public:
@@ -166,7 +190,11 @@ class Map {
     // single-GPU run (tens of milliseconds of kernels), instead of an n-th of it
     const QueryBatchPlan plan = queryBatchPlan(param.querySequences, ctxs.size());
     const size_t batchBases = plan.batchBases;
-    Channel parsed(2), mapped(2);
+    packedUpload = getenv("MASHMAP_HIP_ASCII_UPLOAD") == nullptr;
+    // batches per device pass: only with one context (the blocks of a sharded batch are not consecutive reads across batches) and packed
+    // uploads; MASHMAP_HIP_COALESCE_MBP=0 maps every batch by itself
+    const size_t maxGroup = (ctxs.size() == 1 && packedUpload) ? std::max<size_t>(1, plan.passBases / std::max<size_t>(1, batchBases)) : 1;
+    Channel parsed(std::max<size_t>(2, maxGroup)), mapped(std::max<size_t>(2, 2 * maxGroup));
     if (!getenv("MASHMAP_HIP_NO_MALLOPT") && (!plan.inputKnown || plan.inputBytes > (256u << 20))) {
       // every batch allocates and frees a few megabyte-sized vectors (records, per-read results, PAF text) from three stages at once:
       // keep them on the heap instead of mmap/munmap per batch (each unmap interrupts every thread of the process), and keep the heap
@@ -174,9 +202,9 @@ class Map {
     }
     // the reader's workers normalise and pack the bases (2 bit + N mask, pack2bit.hpp) while they drop the line breaks, so that PCIe
     // carries 0.375 bytes per base instead of 1 (mm_reads_upload_packed); MASHMAP_HIP_ASCII_UPLOAD=1 ships ASCII to k_pack2bit instead
-    packedUpload = getenv("MASHMAP_HIP_ASCII_UPLOAD") == nullptr;
     earlyPrefetch = getenv("MASHMAP_HIP_NO_EARLY_PREFETCH") == nullptr;
-    slotFree.assign(ctxs.size(), earlyPrefetch ? 1 : 0);
+    stagedBases.assign(ctxs.size(), 0);
+    stageCapBases = 2 * std::max(plan.passBases, batchBases) / ctxs.size();           // per context: the pass being assembled and the one behind it
     // diagnostic (MASHMAP_HIP_STALL_TRACE=1): a thread that sleeps 0.5 ms at a time and reports when the sleep, a one-page mmap/munmap
     // (address-space lock) or a first touch of a fresh page took more than 3 ms -- tells a process-wide stall (scheduler, CPU quota)
     // from a lock inside the process when the stage timings show all three stages pausing at once
@@ -242,14 +270,16 @@ class Map {
           seqCounter++;
         }
         if (batch.size()) {
-          // idle staging slots: this batch's blocks start travelling now.  Prefetch and hand-over are ONE step under pfMu -- a batch that
-          // occupies a staging slot is always visible to the device stage's peekFront(), so a slot is never declared free (and given
-          // to a later batch) while a block still sits in it.  The wait for room in the queue comes first: the device stage takes pfMu
-          // between two get() calls, so a put() that blocked while holding it would never be served.
+          // room in the staging areas: this batch's blocks start travelling now.  Prefetch and hand-over are ONE step under pfMu -- the
+          // device stage tops the areas up from the queue under the same lock, in queue order, so a block is never sent twice or out of
+          // order.  The wait for room in the queue comes first: the device stage takes pfMu between two gets, so a put() that blocked
+          // while holding it would never be served.
           parsed.waitSpace();
           std::lock_guard<std::mutex> lk(pfMu);
-          std::vector<size_t> cut;
-          for (size_t i = 0; i < ctxs.size(); i++) if (slotFree[i]) { if (cut.empty()) cut = blocksOf(batch); issuePrefetch(batch, i, cut); }
+          if (earlyPrefetch && packedUpload) {
+            const std::vector<size_t> cut = blocksOf(batch);
+            for (size_t i = 0; i < ctxs.size(); i++) issuePrefetch(batch, i, cut);
+          }
           parsed.put(std::move(batch));
         }
       }
@@ -259,12 +289,24 @@ class Map {
       Batch cur;
       while (mapped.get(cur)) {
         postStage(cur, allReadMappings, totalReadsMapped, outstrm);
-        HostBufferPool::instance().give(cur.in.bases, cur.in.cap); cur.in.bases = nullptr;
+        if (cur.in.bases) { HostBufferPool::instance().give(cur.in.bases, cur.in.cap); cur.in.bases = nullptr; }   // (normally handed back by the device stage, right behind the upload)
+        cur = Batch();
       }
     });
     {
-      Batch cur;
-      while (parsed.get(cur)) { deviceStage(cur, parsed); mapped.put(std::move(cur)); cur = Batch(); }
+      // pass size: ramps up from one batch (so the post stage has work after one batch's worth of time), levels at the coalescing limit,
+      // and comes down again towards the end of an input whose size is known (the last pass is followed by nothing that could hide it)
+      std::vector<Batch> grp;
+      uint64_t doneBases = 0;
+      while (true) {
+        size_t want = std::min<uint64_t>(plan.passBases, std::max<uint64_t>(batchBases, doneBases));
+        if (plan.inputKnown && plan.inputBytes > doneBases) want = (size_t)std::min<uint64_t>(want, std::max<uint64_t>(batchBases, (plan.inputBytes - doneBases) / 3));
+        if (maxGroup == 1) want = 0;
+        if (!parsed.getGroup(grp, want, maxGroup)) break;
+        deviceStage(grp, parsed);
+        for (auto& b : grp) { doneBases += b.bases(); mapped.put(std::move(b)); }
+        grp.clear();
+      }
       mapped.close();
     }
     reader.join();
@@ -301,23 +343,22 @@ class Map {
               << ", total input bp = " << totalBp << std::endl;
   }
 
-  // starts the copy of context i's block of `b` into that context's staging slot (pfMu held)
+  // sends context i's block of `b` ahead into that context's staging area, if there is room (pfMu held)
   void issuePrefetch(const Batch& b, size_t i, const std::vector<size_t>& cut) {
-    mm_ctx* c = ctxs[i];
-    if (b.in.packed) {
-      const int64_t o0 = b.in.packOffs[cut[i]], o1 = b.in.packEnd(cut[i], cut[i + 1]);
-      if (mm_reads_prefetch_packed(c, b.in.bases2() + o0 / 16, b.in.nmask() + o0 / 32, (size_t)(o1 - o0)) != MM_OK) die("mm_reads_prefetch_packed", c);
-    } else {
-      const int64_t o0 = b.in.offs[cut[i]], o1 = b.in.offs[cut[i + 1]];
-      if (mm_reads_prefetch(c, b.in.bases + o0, (size_t)(o1 - o0)) != MM_OK) die("mm_reads_prefetch", c);
-    }
     if (b.prefetched.size() != ctxs.size()) b.prefetched.assign(ctxs.size(), 0);
-    b.prefetched[i] = 1; slotFree[i] = 0;
+    if (b.prefetched[i] || !b.in.packed) return;
+    const int64_t o0 = b.in.packOffs[cut[i]], o1 = b.in.packEnd(cut[i], cut[i + 1]);
+    const size_t blockBases = (size_t)(b.in.offs[cut[i + 1]] - b.in.offs[cut[i]]);
+    if (o1 <= o0 || stagedBases[i] + blockBases > stageCapBases) return;
+    mm_ctx* c = ctxs[i];
+    const size_t reserve = stageCapBases + stageCapBases / 4 + (1u << 22);             // packed bases incl. the 32-base alignment of every read and the parser's gaps
+    if (mm_reads_prefetch_packed_append(c, b.in.bases2() + o0 / 16, b.in.nmask() + o0 / 32, (size_t)(o1 - o0), reserve) != MM_OK) die("mm_reads_prefetch_packed_append", c);
+    b.prefetched[i] = 1; stagedBases[i] += blockBases;
   }
 
   // ------------------------------------------------------------------------------------------------------------------
-  // device stage: the batch's reads -> candidate mappings (batch.recs), on one GPU or sharded over all contexts
-  // contiguous blocks of about equal bases, one per context (a block may be empty)
+  // device stage: the reads of a pass (one batch; several with a single context) -> candidate mappings, on one GPU or sharded over all
+  // contexts in contiguous blocks of about equal bases, one per context (a block may be empty)
   std::vector<size_t> blocksOf(const Batch& batch) const {
     const size_t nReads = batch.size(), nCtx = ctxs.size();
     std::vector<size_t> cutAt(nCtx + 1, nReads);
@@ -332,18 +373,24 @@ class Map {
     return cutAt;
   }
 
-  void deviceStage(Batch& batch, Channel& parsed) {
-    const size_t nReads = batch.size();
-    const size_t nCtx = ctxs.size();
+  void deviceStage(std::vector<Batch>& grp, Channel& parsed) {
+    const size_t nCtx = ctxs.size(), nB = grp.size();
     const bool timing = getenv("MASHMAP_HIP_TIMING") != nullptr;
     const auto t0 = skch::Time::now();
+    size_t nReads = 0, passBases = 0;
+    for (const auto& b : grp) { nReads += b.size(); passBases += b.bases(); }
+    // per read of the pass (batches end to end): the reference group of its name, the reference contig of the same name
     std::vector<int32_t> readGroup, readSelf;
-    if (param.skip_prefix) { readGroup.resize(nReads); for (size_t r = 0; r < nReads; r++) readGroup[r] = getRefGroup(batch.in.names[r]); }
+    std::vector<size_t> first(nB + 1, 0);
+    for (size_t j = 0; j < nB; j++) first[j + 1] = first[j] + grp[j].size();
+    if (param.skip_prefix) { readGroup.resize(nReads); for (size_t j = 0; j < nB; j++) for (size_t r = 0; r < grp[j].size(); r++) readGroup[first[j] + r] = getRefGroup(grp[j].in.names[r]); }
     if (param.skip_self) {
       readSelf.resize(nReads);
-      for (size_t r = 0; r < nReads; r++) { auto it = refNameToId.find(batch.in.names[r]); readSelf[r] = it == refNameToId.end() ? -1 : it->second; }
+      for (size_t j = 0; j < nB; j++) for (size_t r = 0; r < grp[j].size(); r++) { auto it = refNameToId.find(grp[j].in.names[r]); readSelf[first[j] + r] = it == refNameToId.end() ? -1 : it->second; }
     }
-    const std::vector<size_t> cutAt = blocksOf(batch);
+    // several batches per pass only with one context (mapQuery): the blocks are then whole batches and the pass's reads are consecutive
+    std::vector<std::vector<size_t>> cutAt(nB);
+    for (size_t j = 0; j < nB; j++) cutAt[j] = blocksOf(grp[j]);
     // How the blocks' candidate mappings reach the host stage.  One process drives all contexts here, so the records are wanted in
     // host memory, once: by default every context downloads its own block (n copies in parallel, one per GPU's own link; rank-major
     // concatenation == input order), which serves every filter mode -- the one-to-one filter (:358-405) runs on the host over all
@@ -353,28 +400,37 @@ class Map {
     const char* xe = getenv("MASHMAP_HIP_EXCHANGE");
     const bool gatherOnDevice = nCtx > 1 && xe && std::string(xe) == "allgather";
     std::vector<PinnedRecs<mm_mapping>> blockRecs(gatherOnDevice || nCtx == 1 ? 0 : nCtx);
+    auto all = std::make_shared<PinnedRecs<mm_mapping>>();
     double phase[3] = {0, 0, 0};                           // context 0: upload, kernels, download (seconds)
+    auto releaseBuffers = [&]() {                           // the bases are in HBM: the page-locked buffers go back to the reader
+      for (auto& b : grp) if (b.in.bases) { HostBufferPool::instance().give(b.in.bases, b.in.cap); b.in.bases = nullptr; }
+    };
     auto runBlock = [&](size_t i) {
       mm_ctx* c = ctxs[i];
-      const size_t b = cutAt[i], e = cutAt[i + 1];
       const auto p0 = skch::Time::now();
-      if (batch.in.packed) {
-        const int64_t p0 = batch.in.packOffs[b];
-        if (mm_reads_upload_packed(c, batch.in.bases2() + p0 / 16, batch.in.nmask() + p0 / 32, batch.in.hasN.data() + b, batch.in.lens.data() + b,
-                                   batch.in.packOffs.data() + b, e - b,
-                                   param.skip_prefix ? readGroup.data() + b : nullptr, param.skip_self ? readSelf.data() + b : nullptr,
-                                   batch.firstSeqCounter + (seqno_t)b) != MM_OK) die("mm_reads_upload_packed", c);
-      } else {
-        if (mm_reads_upload(c, batch.in.bases, batch.in.offs.data() + b, e - b, param.skip_prefix ? readGroup.data() + b : nullptr,
-                            param.skip_self ? readSelf.data() + b : nullptr, batch.firstSeqCounter + (seqno_t)b) != MM_OK) die("mm_reads_upload", c);
+      const seqno_t seqBase = grp[0].firstSeqCounter + (seqno_t)cutAt[0][i];
+      if (grp[0].in.packed) {
+        std::vector<mm_packed_part> parts(nB);
+        for (size_t j = 0; j < nB; j++) {
+          const Batch& bt = grp[j];
+          const size_t b = cutAt[j][i], e = cutAt[j][i + 1];
+          const int64_t o = bt.in.packOffs[b];
+          parts[j] = mm_packed_part{bt.in.bases2() + o / 16, bt.in.nmask() + o / 32, bt.in.hasN.data() + b, bt.in.lens.data() + b, bt.in.packOffs.data() + b, e - b,
+                                    param.skip_prefix ? readGroup.data() + first[j] + b : nullptr, param.skip_self ? readSelf.data() + first[j] + b : nullptr};
+        }
+        if (mm_reads_upload_packed_parts(c, parts.data(), nB, seqBase) != MM_OK) die("mm_reads_upload_packed_parts", c);
+      } else {                                              // MASHMAP_HIP_ASCII_UPLOAD: one batch per pass, packed on the device
+        const size_t b = cutAt[0][i], e = cutAt[0][i + 1];
+        if (mm_reads_upload(c, grp[0].in.bases, grp[0].in.offs.data() + b, e - b, param.skip_prefix ? readGroup.data() + b : nullptr,
+                            param.skip_self ? readSelf.data() + b : nullptr, seqBase) != MM_OK) die("mm_reads_upload", c);
       }
+      if (nCtx == 1) releaseBuffers();
       {
-        // the staging slot of this context is free again: the batch the reader has already parsed behind this one starts travelling
-        // while this one is mapped; if there is none yet, the reader starts the copy itself as soon as it has one
+        // this context's staging area has room again: the batches the reader has parsed behind this pass start travelling, in queue
+        // order, while the pass is mapped; what the reader parses from now on it sends itself
         std::lock_guard<std::mutex> lk(pfMu);
-        const Batch* next = parsed.peekFront();
-        if (next && next->size() && !(next->prefetched.size() == ctxs.size() && next->prefetched[i])) issuePrefetch(*next, i, blocksOf(*next));
-        else if (!next && earlyPrefetch) slotFree[i] = 1;
+        for (const auto& bt : grp) if (bt.prefetched.size() == nCtx && bt.prefetched[i]) { const auto ct = blocksOf(bt); stagedBases[i] -= (size_t)(bt.in.offs[ct[i + 1]] - bt.in.offs[ct[i]]); }
+        if (earlyPrefetch && packedUpload) parsed.forEach([&](Batch& q) { issuePrefetch(q, i, blocksOf(q)); });
       }
       const auto p1 = skch::Time::now();
       if (mm_map_fragments(c) != MM_OK) die("mm_map_fragments", c);
@@ -392,27 +448,39 @@ class Map {
       for (size_t i = 1; i < nCtx; i++) th.emplace_back(runBlock, i);
       runBlock(0);
       for (auto& t : th) t.join();
+      releaseBuffers();
     }
     size_t n = 0;
     const auto p2 = skch::Time::now();
     if (nCtx == 1) {
       if (mm_mappings_count(ctx, &n) != MM_OK) die("mm_mappings_count");
-      batch.recs.resize(n);
-      if (mm_mappings_download(ctx, batch.recs.data(), n, &n) != MM_OK) die("mm_mappings_download");
+      all->resize(n);
+      if (n && mm_mappings_download(ctx, all->data(), n, &n) != MM_OK) die("mm_mappings_download");
     } else if (gatherOnDevice) {
       if (mm_allgatherv_mappings_local(ctxs.data(), (int)nCtx) != MM_OK) die("mm_allgatherv_mappings_local");
       if (mm_gathered_counts(ctx, nullptr, &n) != MM_OK) die("mm_gathered_counts");
-      batch.recs.resize(n);
-      if (mm_gathered_download(ctx, batch.recs.data(), n) != MM_OK) die("mm_gathered_download");
+      all->resize(n);
+      if (n && mm_gathered_download(ctx, all->data(), n) != MM_OK) die("mm_gathered_download");
     } else {
       for (const auto& v : blockRecs) n += v.size();
-      batch.recs.resize(n);
+      all->resize(n);
       size_t at = 0;
-      for (const auto& v : blockRecs) { if (!v.empty()) std::memcpy(batch.recs.data() + at, v.data(), v.size() * sizeof(mm_mapping)); at += v.size(); }
+      for (const auto& v : blockRecs) { if (!v.empty()) std::memcpy(all->data() + at, v.data(), v.size() * sizeof(mm_mapping)); at += v.size(); }
+    }
+    // the records are read-major in input order: every batch of the pass gets its slice
+    {
+      size_t at = 0;
+      for (size_t j = 0; j < nB; j++) {
+        const seqno_t endId = grp[j].firstSeqCounter + (seqno_t)grp[j].size();
+        const size_t b0 = at;
+        while (at < n && (*all)[at].querySeqId < endId) at++;
+        grp[j].recOwner = all; grp[j].recs = all->data() + b0; grp[j].nRecs = at - b0;
+      }
+      if (at != n) { std::cerr << "[mashmap_hip::skch::Map] ERROR: candidate mappings of a pass are not in input order" << std::endl; exit(1); }
     }
     if (timing) LogLine() << "[mashmap_hip::timing] device stage (upload + pack + kernels" << (gatherOnDevice ? " + all-gatherv" : "") << " + download of " << n
                           << " candidate mappings): " << std::chrono::duration<double>(skch::Time::now() - t0).count() << " s (upload " << phase[0] << ", kernels " << phase[1]
-                          << ", download " << std::chrono::duration<double>(skch::Time::now() - p2).count() << ")" << at();
+                          << ", download " << std::chrono::duration<double>(skch::Time::now() - p2).count() << ") [bases " << passBases << "] [batches " << nB << "]" << at();
   }
 
   // post stage: per read, chaining + filters + PAF text on param.threads threads; then output in input order
@@ -421,11 +489,11 @@ class Map {
     const bool timing = getenv("MASHMAP_HIP_TIMING") != nullptr;
     const auto t0 = skch::Time::now();
     // the records are read-major: first record of every read
-    std::vector<size_t> recBegin(nReads + 1, batch.recs.size());
+    std::vector<size_t> recBegin(nReads + 1, batch.nRecs);
     {
       size_t i = 0;
       for (size_t r = 0; r <= nReads; r++) {
-        while (i < batch.recs.size() && (size_t)(batch.recs[i].querySeqId - batch.firstSeqCounter) < r) i++;
+        while (i < batch.nRecs && (size_t)(batch.recs[i].querySeqId - batch.firstSeqCounter) < r) i++;
         recBegin[r] = i;
       }
     }
@@ -452,7 +520,7 @@ class Map {
           const offset_t len = (offset_t)(batch.in.offs[r + 1] - batch.in.offs[r]);
           if (len < param.kmerSize || recBegin[r] == recBegin[r + 1]) continue;
           one.clear();
-          post.mapModuleFromRecords(batch.recs.data() + recBegin[r], batch.recs.data() + recBegin[r + 1], len, one);
+          post.mapModuleFromRecords(batch.recs + recBegin[r], batch.recs + recBegin[r + 1], len, one);
           if (one.empty()) continue;
           mappedHere++;
           if (reportNow) post.appendReadMappings(one, batch.in.names[r], text);

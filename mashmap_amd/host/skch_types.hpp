@@ -225,16 +225,26 @@ class PinnedRecs {
   }
 };
 
-// How skch::Map takes the query files through the GPUs: bases per batch (MASHMAP_HIP_BATCH_MBP, default 512 Mbp, PER GPU CONTEXT -- a
-// batch is cut into one block per context, and a block is what keeps a GPU busy for tens of milliseconds), and the page-locked buffers
-// that go with it: as many as batches can be in flight at once (reader 1 + two queues of 2 + device 1 + post 1 + one spare), but no more
-// than the input needs, each no larger than the input.
-struct QueryBatchPlan { size_t batchBases; size_t bufferBytes; size_t buffers; uint64_t inputBytes; bool inputKnown; };
+// How skch::Map takes the query files through the GPUs.  The reader's unit is a BATCH: MASHMAP_HIP_BATCH_MBP (default 512 Mbp) PER GPU
+// CONTEXT, parsed and packed into one page-locked buffer -- small, so that locking its pages is cheap and the three stages overlap from
+// the first few milliseconds on.  The device's unit is a PASS: up to MASHMAP_HIP_COALESCE_MBP (default 2048 Mbp per context; 0 = one batch
+// per pass) of consecutive batches laid end to end in HBM (mm_reads_upload_packed_parts) -- the kernels of a 512 Mbp pass leave a third
+// of the GPU idle (1.5 waves per SIMD in the lane-per-candidate sweep), those of a 2 Gbp pass do not.  Page-locked buffers: a buffer is
+// busy from the reader's first byte until its batch's upload has completed (the post stage works on the records, not on the bases):
+// one being parsed + a pass's worth queued + a pass's worth uploading, but no more than the input needs, each no larger than the input.
+struct QueryBatchPlan { size_t batchBases; size_t passBases; size_t bufferBytes; size_t buffers; uint64_t inputBytes; bool inputKnown; };
 inline QueryBatchPlan queryBatchPlan(const std::vector<std::string>& queryFiles, size_t nContexts) {
   const bool packed = getenv("MASHMAP_HIP_ASCII_UPLOAD") == nullptr;   // the reader packs: a batch buffer holds 3/8 byte per base, not 1
   const char* be = getenv("MASHMAP_HIP_BATCH_MBP");
+  const char* ce = getenv("MASHMAP_HIP_COALESCE_MBP");
+  const size_t nCtx = nContexts ? nContexts : 1;
   QueryBatchPlan q;
-  q.batchBases = (size_t)((be ? atof(be) : 512.0) * 1e6) * (nContexts ? nContexts : 1);
+  q.batchBases = (size_t)((be ? atof(be) : 512.0) * 1e6) * nCtx;
+  if (q.batchBases < 1) q.batchBases = 1;
+  q.passBases = std::max(q.batchBases, (size_t)((ce ? atof(ce) : 2048.0) * 1e6) * nCtx);
+  if (nCtx > 1 || !packed) q.passBases = q.batchBases;               // (several batches per pass: one context, packed uploads -- skch_map.hpp)
+  q.passBases = std::min(q.passBases, q.batchBases * 64);            // at most 64 batches per pass, whatever the two variables say
+  const size_t perPass = q.passBases / q.batchBases;
   q.inputBytes = 0; q.inputKnown = !queryFiles.empty();
   for (const auto& f : queryFiles) {
     struct stat st;
@@ -245,11 +255,12 @@ inline QueryBatchPlan queryBatchPlan(const std::vector<std::string>& queryFiles,
   }
   const size_t ascii = q.batchBases + q.batchBases / 8 + (1u << 20);
   const size_t full = (packed && !getenv("MASHMAP_HIP_BIG_BUFFERS")) ? (ascii + (2u << 20)) / 8 * 3 + (1u << 20) : ascii;      // locking pages costs ~0.2 s per GB: no more than needed
-  if (!q.inputKnown) { q.bufferBytes = full; q.buffers = 8; return q; }
+  const size_t inFlight = std::min<size_t>(24, 2 * perPass + 2) + (perPass == 1 ? 4 : 0);   // one batch per pass: as before (reader 1 + two queues of 2 + device 1 + post 1 + one spare)
+  if (!q.inputKnown) { q.bufferBytes = full; q.buffers = inFlight; return q; }
   const uint64_t batches = q.inputBytes / q.batchBases + 1;
   const uint64_t whole = q.inputBytes + q.inputBytes / 8 + (1u << 20);
   q.bufferBytes = (size_t)std::min<uint64_t>(full, packed ? whole / 8 * 3 + (2u << 20) : whole);
-  q.buffers = (size_t)std::min<uint64_t>(8, batches + 1);
+  q.buffers = (size_t)std::min<uint64_t>(inFlight, batches + 1);
   return q;
 }
 }  // namespace skch

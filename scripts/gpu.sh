@@ -1,0 +1,83 @@
+#!/bin/bash
+# One visit to a GPU box (gpurun): scripts/gpu.sh TAG STEP [STEP ...]; everything lands under gpurun_out/TAG/ (log.txt has the gist).
+#   tests            pytest -m gpu (the whole suite)             t:PATTERN   pytest -m gpu -k PATTERN
+#   smoke            __graft_entry__.smoke()
+#   bench            the default bench line (configs[1] + e2e + north_star_target incl. repeat_rich), steps 20 / warmup 5
+#   bench:WL         bench.py --workload WL (configs3 | configs4 | northstar), steps 5 / warmup 3, no side measurements
+#   quick            configs[1] headline only (no cpu baseline / e2e / north star), steps 10 / warmup 3
+#   rr               the repeat-rich north_star workload alone (bench.py --workload northstar --repeat-rich-reference)
+#   trace:WL         rocprofv3 --kernel-trace --stats of two passes of WL      -> kernel_stats_WL.csv
+#   pmc:WL           FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU passes of WL (one rocprofv3 run each) -> pmc_WL_*.csv (scripts/pmc_summary.py reduces them)
+#   pcs:KERNEL[:WL]  rocprofv3 PC sampling of one pass, histogram of the sampled instructions of KERNEL
+#   e2e              FASTA -> PAF through the mashmap_hip command line only (bench.py's e2e leg)
+# Environment variables given on the command line reach every step (A/B switches: MM_*, MASHMAP_HIP_*).
+TAG=${1:-visit}; shift
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || true
+say() { echo "$@" | tee -a $OUT/log.txt; }
+wl_args() { case $1 in configs1|"") echo "";; *) echo "--workload $1";; esac; }
+for S in "$@"; do
+case $S in
+tests)
+  say "== pytest -m gpu"
+  timeout 1700 python -m pytest tests -m gpu -q --maxfail=12 --timeout 900 -s 2>&1 | grep -v "^$" | tail -80 | tee -a $OUT/log.txt ;;
+t:*)
+  say "== pytest -m gpu -k ${S#t:}"
+  timeout 1500 python -m pytest tests -m gpu -q --maxfail=12 --timeout 900 -k "${S#t:}" 2>&1 | tail -60 | tee -a $OUT/log.txt ;;
+smoke)
+  timeout 300 python __graft_entry__.py smoke 2>&1 | tail -3 | tee -a $OUT/log.txt ;;
+bench)
+  say "== bench (default line)"
+  timeout 1500 python bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
+  grep -v "^\[mm\]" $OUT/bench.err | tail -25 | tee -a $OUT/log.txt; python scripts/bench_digest.py $OUT/bench.json | tee -a $OUT/log.txt ;;
+bench:*)
+  WL=${S#bench:}
+  say "== bench --workload $WL"
+  timeout 1500 python bench.py --steps 5 --warmup 3 --workload $WL --no-cpu-baseline --no-host-path > $OUT/bench_$WL.json 2> $OUT/bench_$WL.err
+  tail -5 $OUT/bench_$WL.err | tee -a $OUT/log.txt; python scripts/bench_digest.py $OUT/bench_$WL.json | tee -a $OUT/log.txt ;;
+quick)
+  say "== configs[1] headline only"
+  timeout 900 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-e2e --no-north-star > $OUT/quick.json 2> $OUT/quick.err
+  tail -4 $OUT/quick.err | tee -a $OUT/log.txt; python scripts/bench_digest.py $OUT/quick.json | tee -a $OUT/log.txt ;;
+rr)
+  say "== repeat-rich north_star workload"
+  MM_DEBUG=${MM_DEBUG:-} timeout 1500 python bench.py --steps 5 --warmup 3 --workload northstar --repeat-rich-reference --no-cpu-baseline --no-host-path > $OUT/rr.json 2> $OUT/rr.err
+  grep -v "^\[mm\] sketch" $OUT/rr.err | tail -12 | tee -a $OUT/log.txt; python scripts/bench_digest.py $OUT/rr.json | tee -a $OUT/log.txt ;;
+trace:*)
+  WL=${S#trace:}
+  say "== $WL: rocprofv3 --kernel-trace --stats"
+  timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$WL -o trace -- python bench.py --steps 3 --warmup 3 $(wl_args $WL) --no-cpu-baseline --no-host-path --no-e2e --no-north-star > $OUT/trace_$WL.json 2> $OUT/trace_$WL.err
+  find $OUT/trace_$WL -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} $OUT/kernel_stats_$WL.csv
+  rm -rf $OUT/trace_$WL
+  grep -E '^"(void )?k_' $OUT/kernel_stats_$WL.csv | head -12 | cut -c1-160 | tee -a $OUT/log.txt ;;
+pmc:*)
+  WL=${S#pmc:}
+  for C in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU; do
+    say "== $WL: rocprofv3 --pmc $C"
+    timeout 1500 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_${WL}_$C -o pmc -- python bench.py --steps 1 --warmup 3 --batches 1 $(wl_args $WL) --no-cpu-baseline --no-host-path --no-e2e --no-north-star > /dev/null 2> $OUT/pmc_${WL}_$C.err
+    python scripts/pmc_summary.py $OUT/pmc_${WL}_$C $C > $OUT/pmc_${WL}_$C.csv 2>> $OUT/log.txt; rm -rf $OUT/pmc_${WL}_$C
+    head -8 $OUT/pmc_${WL}_$C.csv | cut -c1-160 | tee -a $OUT/log.txt
+  done ;;
+pcs:*)
+  IFS=: read -r _ KERNEL WL <<< "$S"
+  say "== PC sampling of $KERNEL (${WL:-configs1})"
+  timeout 900 rocprofv3 --pc-sampling-beta-enabled --pc-sampling-method host_trap --pc-sampling-unit time --pc-sampling-interval 100 \
+    --kernel-trace --output-format csv json -d $OUT/pcs_$KERNEL -o pcs -- python bench.py --steps 2 --warmup 3 $(wl_args $WL) --no-cpu-baseline --no-host-path --no-e2e --no-north-star > /dev/null 2> $OUT/pcs_$KERNEL.err
+  tail -3 $OUT/pcs_$KERNEL.err | tee -a $OUT/log.txt
+  python scripts/pcs_histogram.py $OUT/pcs_$KERNEL "$KERNEL" > $OUT/pcs_$KERNEL.txt 2>&1; head -70 $OUT/pcs_$KERNEL.txt | tee -a $OUT/log.txt
+  rm -rf $OUT/pcs_$KERNEL ;;
+e2e)
+  say "== e2e FASTA -> PAF"
+  timeout 900 python -c "
+import json, os, sys, torch
+sys.path.insert(0, '.')
+import bench as B
+dev = torch.device('cuda', 0); W = dict(B.WORKLOADS['configs1'])
+ref = B.contiguous_views(torch, B.make_reference(torch, dev, W['ref_contigs'], W['ref_contig_len']))
+print(json.dumps(B.e2e_fasta_to_paf(torch, dev, W, ref, W['reads'], max(4, min(128, os.cpu_count())))))" > $OUT/e2e.json 2> $OUT/e2e.err
+  tail -3 $OUT/e2e.err | tee -a $OUT/log.txt; cat $OUT/e2e.json | cut -c1-2500 | tee -a $OUT/log.txt ;;
+*) say "unknown step $S" ;;
+esac
+done

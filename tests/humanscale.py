@@ -8,7 +8,11 @@ sources, compiled by oracle/Makefile; it travels to the GPU box like the library
   * the north_star target workload: 10 kbp ONT-like reads, defaults (pi 85, segLength 5000), also sharded over two contexts
     (MASHMAP_HIP_DEVICES=0,0);
   * the BASELINE configs[2] shape: assembly contigs vs the reference, --pi 95 -s 10000 -f one-to-one (a reduced query);
-  * the BASELINE configs[4] shape: --dense --pi 80, 20 kbp reads at 15-20 % error, the reference as an --rl list of 10 files.
+  * the BASELINE configs[4] shape: --dense --pi 80, 20 kbp reads at 15-20 % error, the reference as an --rl list of 10 files;
+  * the north_star workload once more on a 3 Gbp reference with human-like repeat structure (bench.make_repeat_rich_reference: ~45 % in
+    interspersed repeat families of 10^2..10^5 copies at 10-20 % divergence, a satellite array and N gaps per contig) -- the shape
+    bench.py reports as north_star_target.repeat_rich: frequent seeds, many interval points and several L1 candidates per fragment,
+    fragments on the sketch kernel's hard list.
 
 What is matched: Map::mapQuery end to end (computeMap.hpp:263-413) with the parameters parseCmdArgs.hpp:620-641 derives.
 The reference sequence is generated once and shared by the three cases; the stock binary indexes 3 Gbp in ~1.5 minutes per case on
@@ -34,6 +38,8 @@ GBP = float(os.environ.get("MASHMAP_TEST_HUMAN_GBP", "3"))
 SCALE = float(os.environ.get("MASHMAP_TEST_HUMAN_READS", "1"))
 N_CONTIGS, N_FILES = 30, 10                      # 30 contigs of 100 Mbp; the --rl list holds three of them per file
 N_READS_NS, N_READS_C4, N_ASM = int(30000 * SCALE), int(6000 * SCALE), max(4, int(40 * SCALE))
+N_READS_RR = int(20000 * SCALE)
+RR_CONTIGS = 24                                   # 24 x 125 Mbp, as bench.py's north_star workloads
 ASM_LEN = 5_000_000
 
 
@@ -48,6 +54,7 @@ CASES = {
     "northstar": ["-r", "@ref", "-q", "@ns"],
     "configs2": ["-r", "@ref", "-q", "@asm", "--pi", "95", "-s", "10000", "-f", "one-to-one"],
     "configs4": ["--rl", "@rl", "-q", "@c4", "--dense", "--pi", "80"],
+    "repeat_rich": ["-r", "@rr_ref", "-q", "@rr"],
 }
 
 
@@ -105,10 +112,17 @@ def start(tmp_path_factory):
     B.write_fasta(asm_fa, ["ctg%d" % i for i in range(N_ASM)], asm)
     del contigs, asm
     torch.cuda.empty_cache()
+    # the repeat-rich reference and reads drawn from it
+    rr_ref, rr_fa = os.path.join(td, "ref_rr.fa"), os.path.join(td, "reads_rr.fa")
+    contigs, rr_summary = B.make_repeat_rich_reference(torch, dev, RR_CONTIGS, int(GBP * 1e9) // RR_CONTIGS)
+    B.write_fasta(rr_ref, ["chr%d" % i for i in range(RR_CONTIGS)], [c.cpu().numpy() for c in contigs])
+    reads_fasta(rr_fa, N_READS_RR, 10000, (0.10, 0.10), 3000)
+    del contigs
+    torch.cuda.empty_cache()
     print("\n[human scale] %.2f Gbp reference in %d contigs (+ %d --rl files), %d + %d reads, %d assembly contigs written in %.0f s"
           % (GBP, N_CONTIGS, N_FILES, N_READS_NS, N_READS_C4, N_ASM, time.time() - t0), flush=True)
-    H = dict(td=td, ref=ref_fa, rl=rl, ns=ns_fa, c4=c4_fa, asm=asm_fa, threads=_threads())
-    # the three runs of the stock binary start now and share the host's CPUs (its index build is single-threaded for most of its
+    H = dict(td=td, ref=ref_fa, rl=rl, ns=ns_fa, c4=c4_fa, asm=asm_fa, rr_ref=rr_ref, rr=rr_fa, rr_summary=rr_summary, threads=_threads())
+    # the four runs of the stock binary start now and share the host's CPUs (its index build is single-threaded for most of its
     # ~90 s: hash-map insertions of 0.36 G records); the GPU runs of the tests below happen meanwhile
     H["stock"] = {}
     for name, args in CASES.items():

@@ -488,3 +488,73 @@ def test_steady_state_passes_wait_for_the_device_once(oracle):
     got, (syncs, steady) = run(small)                                  # a smaller batch fits what is there
     assert got == want_small and steady and syncs == 1
     ctx.close()
+
+
+def test_resident_batches_take_turns_and_an_l1_overflow_in_a_steady_pass_is_redone(oracle):
+    """mm_reads_exchange: three uploaded batches stay in HBM and take turns (what bench.py's timed loop does) -- every pass returns the
+    bytes a fresh context gives for that batch, the passes behind the first one are steady-state passes as long as the incoming batch
+    fits the buffers, and mm_pass_totals counts the one that does not.  The batch that does not is built to overflow the L1 STAGE of a
+    steady pass (a read set out of a 12-copy repeat: several times the candidates per fragment the buffers were sized for): the L2 stage
+    must not run on what the overflowed L1 stage left (k_l1_gate; the advisor's round-4 finding), the pass is redone and exact."""
+    from mashmap_amd import capi
+    unit = U.random_dna(821, 20000)
+    rep = np.concatenate([U.mutate(unit, 910 + i, 0.01) for i in range(12)])
+    g = U.random_dna(822, 600000)
+    contigs = [rep, g]
+    uniq = lambda seed, n: [a for _, a, _ in U.sample_reads([g], seed, n, 10000, 0.08)]
+    A, B = uniq(823, 120), uniq(824, 120)
+    C = [a for _, a, _ in U.sample_reads([rep], 825, 600, 10000, 0.05)]          # every fragment has ~12 candidate loci and ~800 interval points: the sweep path's
+                                                                                 # candidates run past the dense L1 buffer of a pass sized for 240 unique fragments
+
+    def fresh(reads):
+        c = capi.Context(k=19, segLength=5000, sketchSize=130, flags=capi.MM_FLAG_HG_FILTER)
+        c.index_build(contigs, kmerPct=0.0); c.set_tables_default(0.85)
+        c.reads_upload(reads); c.map()
+        out = tuple(x.tobytes() for x in c.results()) + (c.mappings().tobytes(),)
+        n1 = c.result_counts()[0]
+        c.close()
+        return out, n1
+
+    (wantA, nA), (wantB, nB), (wantC, nC) = fresh(A), fresh(B), fresh(C)
+    assert nC > 4 * nA                                                           # the repeat batch really outgrows the candidate buffers
+    ctx = capi.Context(k=19, segLength=5000, sketchSize=130, flags=capi.MM_FLAG_HG_FILTER)
+    ctx.index_build(contigs, kmerPct=0.0); ctx.set_tables_default(0.85)
+    ctx.reads_upload(A); ctx.reads_exchange(0)                                   # slot 0 = A
+    ctx.reads_upload(C); ctx.reads_exchange(1)                                   # slot 1 = C
+    ctx.reads_upload(B)                                                          # resident = B
+    assert ctx.num_fragments() == 240
+    got = lambda: tuple(x.tobytes() for x in ctx.results()) + (ctx.mappings().tobytes(),)
+    ctx.map(); assert got() == wantB and not ctx.pass_stats()[1]                 # sizing pass
+    ctx.reads_exchange(0); ctx.map()                                             # resident A, slot 0 = B
+    assert got() == wantA and ctx.pass_stats() == (1, True)
+    ctx.reads_exchange(0); ctx.map()                                             # resident B again
+    assert got() == wantB and ctx.pass_stats() == (1, True)
+    t = ctx.pass_totals(); assert t == {"passes": 3, "steady": 2, "redone": 0}, t
+    ctx.reads_exchange(1); ctx.map()                                             # resident C: L1 candidates overflow the steady pass
+    assert got() == wantC and not ctx.pass_stats()[1]
+    t = ctx.pass_totals(); assert t == {"passes": 4, "steady": 2, "redone": 1}, t
+    ctx.map(); assert got() == wantC and ctx.pass_stats() == (1, True)           # sized for C now
+    ctx.reads_exchange(0); ctx.map(); assert got() == wantB and ctx.pass_stats() == (1, True)
+    ctx.reads_exchange(2); assert ctx.num_fragments() == 0                       # an empty slot: nothing resident
+    ctx.reads_exchange(2); assert ctx.num_fragments() == 240
+    with pytest.raises(capi.MashmapError):
+        ctx.reads_exchange(capi.load().mm_abi_version() + 99)
+    ctx.close()
+
+
+def test_pass_counts_report_the_hard_list(oracle):
+    """mm_pass_stats' fifth count: fragments the fast sketch kernel handed to the exact one -- none for random reads, every fragment that is
+    nothing but a short tandem repeat (fewer than sketchSize distinct k-mers)"""
+    from mashmap_amd import capi
+    g = U.random_dna(831, 300000)
+    reads = [a for _, a, _ in U.sample_reads([g], 832, 20, 10000, 0.05)]
+    sat = np.tile(U.random_dna(833, 171), 10000 // 171 + 1)[:10000]
+    ctx = capi.Context(k=19, segLength=5000, sketchSize=130, flags=capi.MM_FLAG_HG_FILTER)
+    ctx.index_build([g], kmerPct=0.0); ctx.set_tables_default(0.85)
+    ctx.reads_upload(reads); ctx.map()
+    assert ctx.pass_counts()["hard"] == 0
+    ctx.reads_upload(reads + [sat, sat]); ctx.map()
+    assert ctx.pass_counts()["hard"] == 4                                        # two fragments per satellite read
+    ctx.map()
+    assert ctx.pass_stats()[1] and ctx.pass_counts()["hard"] == 4                # the count comes back with a steady-state pass's counters too
+    ctx.close()

@@ -182,3 +182,53 @@ def test_packed_upload_equals_ascii_upload(oracle):
     for f in (0, 1, nF - 1):
         g = [(int(x["hash"]), int(x["wpos"]), int(x["wpos_end"]), int(x["seqId"]) - 40, int(x["strand"])) for x in sk_a[f, :cnt_a[f]]]
         assert g == exp[f]
+
+
+def test_packed_parts_equal_one_upload():
+    """mm_reads_upload_packed_parts: several packed pieces (one page-locked reader buffer each in skch::Map) laid end to end as ONE resident
+    batch -- the same words in HBM, the same fragments and the same sketches as one upload of the concatenated reads, whether the pieces
+    travelled ahead (mm_reads_prefetch_packed_append: all of them, some of them, one more than the upload names) or with the upload;
+    pieces with N runs, an empty piece, a gapped piece and reads shorter than k in between"""
+    from mashmap_amd import capi
+    pieces = [[U.random_dna(400 + i, n) for i, n in enumerate((10000, 4999, 33))],
+              [U.with_n_runs(U.random_dna(410, 12000), 4, 5, 200), U.random_dna(411, 18), U.random_dna(412, 7000)],
+              [],
+              [U.lowercase_some(U.random_dna(420, 15000), 3), U.random_dna(421, 5000)]]
+    flat = [r for p in pieces for r in p]
+    ctx = capi.Context(k=19, segLength=5000, sketchSize=130)
+    nF = ctx.reads_upload(flat, seqCounterBase=7)
+    a2, am, ah = ctx.reads_packed_download()
+    sk_a, cnt_a = ctx.sketch()
+    fr_a = ctx.fragments().tobytes()
+    packed = [capi.pack_reads(p) for p in pieces]
+    # piece 1 in the gapped layout (64 garbage bases behind every read)
+    b2, nm, hasn, lens = packed[1]
+    groups = (lens.astype(np.int64) + 31) // 32
+    cstart = np.concatenate([[0], np.cumsum(groups)])[:-1] * 32
+    gstart = cstart + np.arange(len(groups)) * 64
+    total = int(gstart[-1] + groups[-1] * 32)
+    g2 = np.full(total // 16, 0xFFFFFFFF, dtype=np.uint32); gm = np.full(total // 32, 0xFFFFFFFF, dtype=np.uint32)
+    for r in range(len(groups)):
+        n = int(groups[r])
+        g2[gstart[r] // 16:gstart[r] // 16 + 2 * n] = b2[cstart[r] // 16:cstart[r] // 16 + 2 * n]
+        gm[gstart[r] // 32:gstart[r] // 32 + n] = nm[cstart[r] // 32:cstart[r] // 32 + n]
+    parts = [dict(packed=packed[0]), dict(packed=(g2, gm, hasn, lens), starts=gstart + 320), dict(packed=packed[2]), dict(packed=packed[3])]
+    extra = capi.pack_reads([U.random_dna(430, 6000)])
+    for stage in ((), (0, 1, 2, 3), (1, 3), (3,)):
+        if stage == (3,):                                            # one more piece sent ahead than the upload names: it stays staged
+            ctx._ck(ctx.lib.mm_reads_prefetch_packed_append(ctx.h, capi._ptr(extra[0]), capi._ptr(extra[1]), extra[1].size * 32, 1 << 20), "append")
+        assert ctx.reads_upload_packed_parts(parts, seqCounterBase=7, stage=stage) == nF
+        sk_p, cnt_p = ctx.sketch()
+        assert ctx.fragments().tobytes() == fr_a
+        assert cnt_p.tobytes() == cnt_a.tobytes() and sk_p.tobytes() == sk_a.tobytes(), stage
+    # the piece left staged serves the next upload
+    assert ctx.reads_upload_packed_parts([dict(packed=extra)], seqCounterBase=0) == 1
+    one = capi.Context(k=19, segLength=5000, sketchSize=130)
+    one.reads_upload_packed(extra)
+    assert one.sketch()[0].tobytes() == ctx.sketch()[0].tobytes()
+    one.close()
+    # without gaps the resident words are those of the single upload, bit for bit
+    assert ctx.reads_upload_packed_parts([dict(packed=p) for p in packed], seqCounterBase=7, stage=(0, 3)) == nF
+    p2, pm, ph = ctx.reads_packed_download()
+    assert p2.tobytes() == a2.tobytes() and pm.tobytes() == am.tobytes() and ph.tobytes() == ah.tobytes()
+    ctx.close()

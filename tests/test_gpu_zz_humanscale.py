@@ -2,7 +2,7 @@
 runs were started by tests/test_gpu_00_humanscale_start.py and have had the rest of the suite's run time to finish."""
 import pytest
 
-from humanscale import N_ASM, N_READS_C4, N_READS_NS, case as _case
+from humanscale import N_ASM, N_READS_C4, N_READS_NS, N_READS_RR, case as _case
 
 pytestmark = pytest.mark.gpu
 
@@ -21,3 +21,11 @@ def test_configs2_shape_one_to_one(human):
 def test_configs4_shape_dense_reference_list(human):
     """--dense --pi 80, 20 kbp reads at 15-20 % error, --rl list of 10 reference files sharing one seqId space (winSketch.hpp:174-214)"""
     _case(human, "configs4", int(0.8 * N_READS_C4), True)
+
+
+def test_repeat_rich_reference(human):
+    """the shape bench.py reports as north_star_target.repeat_rich: 10 kbp reads at pi 85 against a 3 Gbp reference with human-like repeat
+    structure (interspersed repeat families over ~45 % of it, satellite arrays, N gaps; bench.make_repeat_rich_reference), defaults.
+    Reads that fall into an N gap or a satellite array may stay unmapped in both programs; the bytes must be the same."""
+    print("\n[human scale] repeat-rich reference:", human["rr_summary"], flush=True)
+    _case(human, "repeat_rich", int(0.7 * N_READS_RR), True)
