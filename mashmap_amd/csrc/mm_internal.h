@@ -113,6 +113,7 @@ struct mm_ctx {
   DevBuf dQHash, dQStrand;                              // post-removal sketch (written only for fragments that lose a frequent seed)
   DevBuf dStats;                                        // mm_frag_stats[nFrags]
   DevBuf dPtOff, dPts; size_t ptsCap = 0;               // per-fragment offset (int64) + sorted keys
+  DevBuf dPtKept;                                       // int32[nFrags]: points of a queued fragment that reach the L1 kernels (k_gather_points, k_filter_points)
   // --noSplit with reads longer than segLength (windowLen != 0, computeMap.hpp:933): the literal kernels' state
   bool windowed = false;                                // some resident fragment is longer than segLength
   DevBuf dPtIds, dWinFreq, dWinExt, dWinHeap, dWinKeys, dWinVals, dWinOffH, dWinOffT, dWinCntH, dWinCntT;
@@ -135,7 +136,7 @@ struct mm_ctx {
   DevBuf dL2Sort[4], dL2Order, dL2OrderPos;                          // candidates of a chunk in order of descending stream length (mm_order_desc)
   bool sketched = false, mapped = false;
   // steady state: the previous pass of this context went through and left every buffer sized (mm_launch_map); what it saw
-  bool steadyOk = false, lastSteady = false; size_t prevBig = 0, candCap = 0, l2Chunks = 1; int prevLocap = 0, steadyFails = 0;
+  bool steadyOk = false, lastSteady = false; size_t prevBig = 0, candCap = 0, l2Chunks = 1, sizedFrags = 0; int prevLocap = 0, steadyFails = 0;   // sizedFrags: fragments of the last sized pass
   unsigned long long* hPass = nullptr;                  // page-locked: the counters of a pass as read back at its end
   size_t lastHard = 0;                                  // fragments the fast sketch kernel handed to the hard list in the last pass
   size_t lastOps = 0, lastBig = 0;                      // L2 stream entries reserved / fragments queued for the HBM point path in the last pass

@@ -534,7 +534,7 @@ __global__ void __launch_bounds__(256)
 k_gather_points(int nList, const int32_t* __restrict__ list, int s, const DFrag* __restrict__ frags, const uint64_t* __restrict__ skHash, const uint32_t* __restrict__ skCount,
                 const SeedTable T, const uint64_t* __restrict__ ptKeys, const int32_t* __restrict__ refGroup, const int32_t* __restrict__ readGroup, const int32_t* __restrict__ readSelf,
                 int seqCounterBase, MapFlags fl, mm_frag_stats* __restrict__ stats, const int64_t* __restrict__ ptOff, uint64_t* __restrict__ pts, uint16_t* __restrict__ ptIds,
-                const unsigned long long* __restrict__ nDev) {
+                int32_t* __restrict__ ptKept, const unsigned long long* __restrict__ nDev) {
   if (nDev) nList = (int)*nDev;
   for (int li = blockIdx.x * 4 + (threadIdx.x >> 6); li < nList; li += gridDim.x * 4) {
   const int f = list[li];
@@ -556,7 +556,92 @@ k_gather_points(int nList, const int32_t* __restrict__ list, int s, const DFrag*
                                ptKeys, refGroup, rg, self, seqCounter, fl, lane, idDst);
   }
   for (int j = at + lane; j < slots; j += 64) pts[off + j] = MM_EMPTY;
-  if (lane == 0) stats[f].nPoints = nValid;
+  if (lane == 0) { stats[f].nPoints = nValid; ptKept[f] = nValid; }      // ptKept: the points the L1 kernels will find at the head of the sorted list
+  }
+}
+
+// k_filter_points: drops, BEFORE the sort, the interval points of a queued fragment that cannot matter to computeL1CandidateRegions
+// (computeMap.hpp:916-1116, windowLen == 0).  Against a repeat-rich reference a fragment brings hundreds of scattered single hits with it
+// (the lists that overflow the fused kernel are mostly those): the bitonic sorters paid for them with two thirds of a pass
+// (profiles/r13a: 75 of 183 ms at the repeat-rich north_star workload).  Rule (tests/l1filter.py is its model, tests/test_l1_point_filter.py
+// checks it against the oracle's literal L1 on fuzzed point sets): the gathered list is a sequence of (OPEN, CLOSE) pairs, one per
+// interval [o, c) of a contig; the overlap count of a position is at most the number of intervals that intersect its 4 096-position bin, so
+// an interval none of whose bins is intersected by minimumHits intervals covers no position that reaches minimumHits -- it neither starts,
+// ends nor raises a candidate -- and goes, unless it holds the first or the last point of its contig: the reference's sweep groups points
+// by `pos` alone (:967, :1047-1051), so the last point of one contig and the first of the next can share a group, and with both boundary
+// groups kept whole that seam behaves as it did.  Bins are counted in a hashed LDS table (collisions only raise counts: more is kept, never
+// less); a fragment with an interval over more than MM_FILT_MAXSPAN bins or with more contigs than the per-wave table holds is left as
+// it is.  One wave per queued fragment, in place; the list's length (ptOff[2f+1], what the sorters go by) shrinks with it.
+#define MM_FILT_SHIFT 12
+#define MM_FILT_SLOTS 2048
+#define MM_FILT_CONTIGS 128
+#define MM_FILT_MAXSPAN 64
+__device__ __forceinline__ uint32_t mm_bin_slot(uint32_t seq, uint32_t b) { return ((seq * 0x9E3779B1u + b * 0x85EBCA77u) >> 7) & (MM_FILT_SLOTS - 1); }
+__global__ void __launch_bounds__(256)
+k_filter_points(int nList, const int32_t* __restrict__ list, const mm_frag_stats* __restrict__ stats, const int32_t* __restrict__ minHitsTab,
+                int64_t* __restrict__ ptOff, uint64_t* __restrict__ pts, int32_t* __restrict__ ptKept, const unsigned long long* __restrict__ nDev) {
+  __shared__ uint32_t binCntAll[4][MM_FILT_SLOTS];
+  __shared__ int32_t cKeyAll[4][MM_FILT_CONTIGS];
+  __shared__ uint32_t cMinAll[4][MM_FILT_CONTIGS], cMaxAll[4][MM_FILT_CONTIGS];
+  const int wv = threadIdx.x >> 6, lane = (int)mm_lane();
+  uint32_t* binCnt = binCntAll[wv]; int32_t* cKey = cKeyAll[wv]; uint32_t* cMin = cMinAll[wv]; uint32_t* cMax = cMaxAll[wv];
+  if (nDev) nList = (int)*nDev;
+  for (int li = blockIdx.x * 4 + wv; li < nList; li += gridDim.x * 4) {
+    const int f = list[li];
+    const int64_t off = ptOff[2 * f]; const int slots = (int)ptOff[2 * f + 1];
+    if (slots <= 2) continue;
+    const mm_frag_stats st = stats[f];
+    const int minHits = st.sketchSize > 0 ? minHitsTab[st.sketchSize] : 0;
+    if (minHits <= 1) continue;                                    // every interval reaches a count of 1 (minimumHits 0: the literal sweep takes the list whole)
+    const int pairs = slots >> 1;
+    for (int i = lane; i < MM_FILT_SLOTS; i += 64) binCnt[i] = 0u;
+    for (int i = lane; i < MM_FILT_CONTIGS; i += 64) { cKey[i] = -1; cMin[i] = 0xFFFFFFFFu; cMax[i] = 0u; }
+    __threadfence_block();
+    uint64_t* a = pts + off;
+    bool giveUp = false;
+    for (int i = lane; i < pairs; i += 64) {
+      const uint64_t O = a[2 * i], C = a[2 * i + 1];
+      if (O == MM_EMPTY) continue;
+      const uint32_t seq = (uint32_t)(O >> 33), o = (uint32_t)(O >> 1), c = (uint32_t)(C >> 1);
+      const uint32_t b0 = o >> MM_FILT_SHIFT, b1 = (c - 1u) >> MM_FILT_SHIFT;
+      if (C == MM_EMPTY || c <= o || b1 - b0 >= (uint32_t)MM_FILT_MAXSPAN) { giveUp = true; continue; }
+      for (uint32_t b = b0; b <= b1; b++) atomicAdd(&binCnt[mm_bin_slot(seq, b)], 1u);
+      uint32_t sl = (seq * 0x9E3779B1u) >> 25;                       // 7 bits
+      int tries = 0;
+      for (; tries < MM_FILT_CONTIGS; tries++) {
+        const int32_t prev = atomicCAS(&cKey[sl], -1, (int32_t)seq);
+        if (prev == -1 || prev == (int32_t)seq) { atomicMin(&cMin[sl], o); atomicMax(&cMax[sl], c); break; }
+        sl = (sl + 1u) & (MM_FILT_CONTIGS - 1);
+      }
+      if (tries == MM_FILT_CONTIGS) giveUp = true;
+    }
+    __threadfence_block();
+    if (mm_ballot(giveUp)) continue;                               // left as it is (ptKept[f] is what k_gather_points wrote)
+    int cursor = 0;                                                // pairs kept so far (wave-uniform)
+    for (int base = 0; base < pairs; base += 64) {
+      const int i = base + lane;
+      uint64_t O = MM_EMPTY, C = MM_EMPTY;
+      if (i < pairs) { O = a[2 * i]; C = a[2 * i + 1]; }
+      bool keep = false;
+      if (O != MM_EMPTY) {
+        const uint32_t seq = (uint32_t)(O >> 33), o = (uint32_t)(O >> 1), c = (uint32_t)(C >> 1);
+        const uint32_t b0 = o >> MM_FILT_SHIFT, b1 = (c - 1u) >> MM_FILT_SHIFT;
+        for (uint32_t b = b0; b <= b1; b++) keep = keep || binCnt[mm_bin_slot(seq, b)] >= (uint32_t)minHits;
+        uint32_t sl = (seq * 0x9E3779B1u) >> 25;
+        while (cKey[sl] != (int32_t)seq) sl = (sl + 1u) & (MM_FILT_CONTIGS - 1);
+        keep = keep || o == cMin[sl] || c == cMax[sl];               // the contig's first / last position group stays whole
+      }
+      const uint64_t m = mm_ballot(keep);
+      // in place: every lane of this round has read its pair before anybody writes, and a pair only ever moves down
+      if (keep) { const int at = cursor + (int)mm_popc_below(m); a[2 * at] = O; a[2 * at + 1] = C; }
+      cursor += (int)__popcll(m);
+    }
+    const int kept = 2 * cursor;
+    int newSlots = kept;
+    if (kept > 64) { newSlots = 128; while (newSlots < kept) newSlots <<= 1; }
+    for (int j = kept + lane; j < newSlots; j += 64) a[j] = MM_EMPTY;
+    if (lane == 0) { ptOff[2 * f + 1] = (int64_t)newSlots; ptKept[f] = kept; }
+    __threadfence_block();
   }
 }
 
@@ -794,13 +879,13 @@ k_l1_stream(int nList, const int32_t* __restrict__ list, const int64_t* __restri
             mm_frag_stats* __restrict__ stats, const int32_t* __restrict__ minHitsTab, const int32_t* __restrict__ cutoffs, int nCutoffs,
             int sParam, int segLength, int hg, mm_l1_candidate* __restrict__ l1, unsigned long long l1Cap, int64_t* __restrict__ l1Off,
             int32_t* __restrict__ lit, unsigned int* __restrict__ litCount, unsigned long long* __restrict__ counters /* [2] l1 cursor, [3] overflow */,
-            const unsigned long long* __restrict__ nDev) {
+            const unsigned long long* __restrict__ nDev, const int32_t* __restrict__ ptKept /* points at the head of the sorted list (k_gather_points / k_filter_points) */) {
   __shared__ L1RunS bufAll[4][MM_STREAM_BUF];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   L1RunS* buf = bufAll[wave];
   if (nDev) nList = (int)*nDev;
   auto one = [&](const int f) {
-  const int nPts = stats[f].nPoints, S = stats[f].sketchSize;
+  const int nPts = ptKept[f], S = stats[f].sketchSize;
   if (nPts <= 0 || S <= 0) { if (lane == 0) { stats[f].nL1 = 0; l1Off[f] = 0; } return; }
   const uint64_t* p = pts + ptOff[2 * f];
   int minHits = minHitsTab[S];
@@ -954,12 +1039,13 @@ k_l1_sweep(int nList, const int32_t* __restrict__ list, const int64_t* __restric
            MapFlags fl, const int32_t* __restrict__ refGroup, mm_l1_candidate* __restrict__ l1, unsigned long long l1Cap,
            int64_t* __restrict__ l1Off, unsigned long long* __restrict__ counters /* [2] l1 cursor, [3] overflow */,
            const unsigned int* __restrict__ nListDev /* non-null: the list's length lives on the device (what k_l1_stream left over) */,
-           const unsigned long long* __restrict__ nDev64 /* non-null: the same as a 64-bit counter (the hand-over count of k_lookup_l1) */) {
+           const unsigned long long* __restrict__ nDev64 /* non-null: the same as a 64-bit counter (the hand-over count of k_lookup_l1) */,
+           const int32_t* __restrict__ ptKept) {
   if (nListDev) nList = (int)*nListDev;
   if (nDev64) nList = (int)*nDev64;
   for (int li = blockIdx.x * blockDim.x + threadIdx.x; li < nList; li += gridDim.x * blockDim.x) {
   const int f = list[li];
-  const int nPts = stats[f].nPoints, S = stats[f].sketchSize;
+  const int nPts = ptKept[f], S = stats[f].sketchSize;
   int nOut = 0; long long base = 0;
   if (nPts > 0 && S > 0) {
     const uint64_t* p = pts + ptOff[2 * f];
@@ -1201,8 +1287,15 @@ static int map_pass(mm_ctx* c, const bool steady) {
         hipLaunchKernelGGL(gk, dim3(gWave), dim3(256), 0, c->stream, nBig, c->dBigList.as<int32_t>(), s, c->dFrags.as<DFrag>(), c->dSkHash.as<uint64_t>(),
                            c->dSkCount.as<uint32_t>(), seedTab, I.ptKeys.as<uint64_t>(), I.refGroup.as<int32_t>(),
                            c->dReadGroup.as<int32_t>(), c->dReadSelf.as<int32_t>(), c->seqCounterBase, fl, c->dStats.as<mm_frag_stats>(), c->dPtOff.as<int64_t>(),
-                           c->dPts.as<uint64_t>(), sortIds, nBigDev);
+                           c->dPts.as<uint64_t>(), sortIds, c->dPtKept.as<int32_t>(), nBigDev);
         MM_HIP(c, hipGetLastError());
+        // split mode, plain L1: the points that cannot reach minimumHits go before the sort (k_filter_points; MM_NO_POINT_FILTER=1 is the A/B switch)
+        static const bool noFilter = getenv("MM_NO_POINT_FILTER") != nullptr;
+        if (!windowed && !c->keepPoints && !fl.skipPrefix && !noFilter) {
+          hipLaunchKernelGGL(k_filter_points, dim3(gWave), dim3(256), 0, c->stream, nBig, c->dBigList.as<int32_t>(), c->dStats.as<mm_frag_stats>(), c->dMinHits.as<int32_t>(),
+                             c->dPtOff.as<int64_t>(), c->dPts.as<uint64_t>(), c->dPtKept.as<int32_t>(), nBigDev);
+          MM_HIP(c, hipGetLastError());
+        }
       }
       if (!windowed) hipLaunchKernelGGL(k_sort_points_wave, dim3(gWave), dim3(256), 0, c->stream, nBig, nBigDev, c->dBigList.as<int32_t>(), c->dPtOff.as<int64_t>(), c->dPts.as<uint64_t>());
       hipLaunchKernelGGL(k_classify_sort, dim3(gThread), dim3(256), 0, c->stream, nBig, nBigDev, c->dBigList.as<int32_t>(), c->dPtOff.as<int64_t>(),
@@ -1245,14 +1338,14 @@ static int map_pass(mm_ctx* c, const bool steady) {
           hipLaunchKernelGGL(k_l1_stream, dim3(gWave), dim3(256), 0, c->stream, nBig, c->dBigList.as<int32_t>(), c->dPtOff.as<int64_t>(),
                              c->dPts.as<uint64_t>(), c->dStats.as<mm_frag_stats>(), c->dMinHits.as<int32_t>(), c->dCutoffs.as<int32_t>(),
                              (int)c->nCutoffs, s, c->P.segLength, fl.hg, c->dL1.as<mm_l1_candidate>(), (unsigned long long)denseCap,
-                             c->dL1Off.as<int64_t>(), listB.as<int32_t>(), lit, cnt, nBigDev);
+                             c->dL1Off.as<int64_t>(), listB.as<int32_t>(), lit, cnt, nBigDev, c->dPtKept.as<int32_t>());
           MM_HIP(c, hipGetLastError());
           sweepList = listB.as<int32_t>(); sweepCount = lit;
         }
         hipLaunchKernelGGL(k_l1_sweep, dim3(stream && steady ? 64u : gThread), dim3(256), 0, c->stream, nBig, sweepList, c->dPtOff.as<int64_t>(),
                            c->dPts.as<uint64_t>(), c->dStats.as<mm_frag_stats>(), c->dMinHits.as<int32_t>(), c->dCutoffs.as<int32_t>(),
                            (int)c->nCutoffs, s, c->P.segLength, fl, I.refGroup.as<int32_t>(), c->dL1.as<mm_l1_candidate>(),
-                           (unsigned long long)denseCap, c->dL1Off.as<int64_t>(), cnt, sweepCount, sweepCount ? (const unsigned long long*)nullptr : nBigDev);
+                           (unsigned long long)denseCap, c->dL1Off.as<int64_t>(), cnt, sweepCount, sweepCount ? (const unsigned long long*)nullptr : nBigDev, c->dPtKept.as<int32_t>());
         MM_HIP(c, hipGetLastError());
         }
       }
@@ -1309,20 +1402,22 @@ int mm_launch_map(mm_ctx* c) {
   const int nF = (int)c->nFrags, s = c->P.sketchSize;
   MM_HIP(c, c->dQHash.ensure((size_t)nF * s * 8 + 64)); MM_HIP(c, c->dQStrand.ensure((size_t)nF * s + 64));
   MM_HIP(c, c->dStats.ensure((size_t)nF * sizeof(mm_frag_stats) + 64));
-  MM_HIP(c, c->dPtOff.ensure((size_t)nF * 16 + 64)); MM_HIP(c, c->dL1Off.ensure((size_t)nF * 8 + 64));
+  MM_HIP(c, c->dPtOff.ensure((size_t)nF * 16 + 64)); MM_HIP(c, c->dL1Off.ensure((size_t)nF * 8 + 64)); MM_HIP(c, c->dPtKept.ensure((size_t)nF * 4 + 64));
   MM_HIP(c, c->dCounters.ensure(512));
   if (!c->hPass) { MM_HIP(c, hipHostMalloc((void**)&c->hPass, 256, hipHostMallocDefault)); }
   c->nL1 = c->nL2 = 0; c->nMappings = 0; c->nSyncs = 0; c->lastSteady = false;
   if (nF == 0) return MM_OK;
   const bool allSlow = c->keepPoints || (c->P.flags & MM_FLAG_SKIP_PREFIX) || c->windowed || c->P.sketchSize > MM_LDS_MAX_SKETCH;
   static const bool noSteady = getenv("MM_NO_STEADY") != nullptr;
-  if (c->steadyOk && c->steadyFails < 3 && !allSlow && !noSteady) {
+  // (a batch with a tenth more fragments than the one the buffers were sized for would only fail and be redone: it is sized right away)
+  if (c->steadyOk && c->steadyFails < 3 && !allSlow && !noSteady && (size_t)nF <= c->sizedFrags + c->sizedFrags / 10) {
     const int rc = map_pass(c, true);
     if (rc == MM_OK) { c->lastSteady = true; c->steadyFails = 0; return MM_OK; }
     if (rc != MM_PASS_REDO) return rc;
     c->steadyOk = false; c->steadyFails++; c->nRedone++;                        // three redone passes in a row: this context's batches keep outgrowing what the one before left
   }
   const int rc = map_pass(c, false);
+  c->sizedFrags = (size_t)nF;
   c->steadyOk = rc == MM_OK && !allSlow && c->nL1 > 0 && c->l2Chunks == 1;   // (a batch whose L2 streams go through in chunks needs the host between them)
   return rc;
 }

@@ -505,6 +505,17 @@ mm_sketch_fast(unsigned char* smem, const int f, const uint4* __restrict__ gTabs
 #pragma unroll
     for (int w = 0; w < 16; w++) pre[w + 1] = pre[w] + (w < nWaves ? qCnt[w] : 0u);
     const uint32_t total = pre[16];
+    if (nWaves <= 4) {
+      // the usual geometry (4 982 k-mers = 250 threads = 4 waves): three compares place an entry instead of the fifteen of the general form
+      // below, which were a sixth of the instructions a survivor costs behind the hash loop
+      const uint32_t p1 = pre[1], p2 = pre[2], p3 = pre[3];
+      for (uint32_t g = (uint32_t)tid; g < total; g += (uint32_t)nthr) {
+        const uint32_t w = (g >= p1 ? 1u : 0u) + (g >= p2 ? 1u : 0u) + (g >= p3 ? 1u : 0u);
+        const uint32_t start = g >= p3 ? p3 : (g >= p2 ? p2 : (g >= p1 ? p1 : 0u));
+        const uint32_t at = w * (uint32_t)QC + (g - start);
+        tab.insert(qH[at], qM[at]);
+      }
+    } else
     for (uint32_t g = (uint32_t)tid; g < total; g += (uint32_t)nthr) {
       uint32_t w = 0, start = 0;                    // the queue entry g falls into, and where that queue starts in the concatenation
 #pragma unroll

@@ -899,6 +899,18 @@ int orc_session_map_fragment(void* h, const char* seq, int len, int fullLen, int
   return 0;
 }
 
+/* computeL1CandidateRegions (l1_candidates above) on a point list the caller made, sorted by (seqId, pos, side): lets a test check that a
+ * transformation of the list (the device's pre-filter of points that cannot reach minimumHits, mm_map.hip k_filter_points) leaves the
+ * candidates as they are.  Uses the session's segLength, sketchSize, HG flag and cut-off table; fragLen <= segLength (windowLen == 0). */
+int orc_session_l1_from_points(void* h, const orc_point* pts, int64_t n, int qSketchSize, int fragLen, int minimumHits, orc_l1* out, int cap) {
+  const Session& S = *(const Session*)h;
+  Frag Q; Q.len = fragLen; Q.fullLen = fragLen; Q.seqCounter = 0; Q.refGroup = -1; Q.sketchSize = qSketchSize; Q.rawSketchSize = qSketchSize;
+  std::vector<orc_l1> l1;
+  if (n > 0) l1_candidates(S, Q, pts, pts + n, minimumHits, l1);
+  for (size_t i = 0; i < l1.size() && (int)i < cap; i++) out[i] = l1[i];
+  return (int)l1.size();
+}
+
 int orc_session_map_read(void*, const char*, int, int, const char*, orc_mapping*, int) { return -1; /* widened later */ }
 
 }  // extern "C"

@@ -86,6 +86,8 @@ int orc_session_map_fragment(void* h, const char* seq, int len, int fullLen, int
                              orc_minmer* qsk, int qskCap, orc_point* pts, int ptsCap, orc_l1* l1, int l1Cap,
                              orc_l2* l2, int* l2cand, int l2Cap, orc_mapping* maps, int mapsCap,
                              int64_t* counts, double* kmerComplexity);
+/* the literal L1 (computeMap.hpp:916-1116) on a caller-made, sorted point list */
+int orc_session_l1_from_points(void* h, const orc_point* pts, int64_t n, int qSketchSize, int fragLen, int minimumHits, orc_l1* out, int cap);
 /* a whole read through the mapModule logic (computeMap.hpp:570-714) */
 int orc_session_map_read(void* h, const char* seq, int len, int seqCounter, const char* seqName,
                          orc_mapping* maps, int mapsCap);

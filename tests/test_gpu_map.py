@@ -494,17 +494,18 @@ def test_resident_batches_take_turns_and_an_l1_overflow_in_a_steady_pass_is_redo
     """mm_reads_exchange: three uploaded batches stay in HBM and take turns (what bench.py's timed loop does) -- every pass returns the
     bytes a fresh context gives for that batch, the passes behind the first one are steady-state passes as long as the incoming batch
     fits the buffers, and mm_pass_totals counts the one that does not.  The batch that does not is built to overflow the L1 STAGE of a
-    steady pass (a read set out of a 12-copy repeat: several times the candidates per fragment the buffers were sized for): the L2 stage
+    steady pass (a read set out of a 30-copy repeat: several times the candidates per fragment the buffers were sized for): the L2 stage
     must not run on what the overflowed L1 stage left (k_l1_gate; the advisor's round-4 finding), the pass is redone and exact."""
     from mashmap_amd import capi
     unit = U.random_dna(821, 20000)
-    rep = np.concatenate([U.mutate(unit, 910 + i, 0.01) for i in range(12)])
+    rep = np.concatenate([U.mutate(unit, 910 + i, 0.01) for i in range(30)])
     g = U.random_dna(822, 600000)
     contigs = [rep, g]
     uniq = lambda seed, n: [a for _, a, _ in U.sample_reads([g], seed, n, 10000, 0.08)]
     A, B = uniq(823, 120), uniq(824, 120)
-    C = [a for _, a, _ in U.sample_reads([rep], 825, 600, 10000, 0.05)]          # every fragment has ~12 candidate loci and ~800 interval points: the sweep path's
-                                                                                 # candidates run past the dense L1 buffer of a pass sized for 240 unique fragments
+    # as many fragments as A and B (a batch with a tenth more is sized afresh without a steady attempt), but every one of them has ~30
+    # candidate loci and ~2 000 interval points: the sweep path's candidates run past the dense L1 buffer of a pass sized for 240 unique fragments
+    C = [a for _, a, _ in U.sample_reads([rep], 825, 120, 10000, 0.05)]
 
     def fresh(reads):
         c = capi.Context(k=19, segLength=5000, sketchSize=130, flags=capi.MM_FLAG_HG_FILTER)
