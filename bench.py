@@ -845,6 +845,9 @@ def e2e_fasta_to_paf(torch, dev, W, ref_np, nreads, threads):
             cur = dict(map_s=tmap, index_s=tidx, wall_s=wall, stderr=p.stderr, dev_rows=dev_rows, rd_rows=rd_rows, post_s=sum(post), output_s=sum(outp))
             if best is None or tmap < best["map_s"]:
                 best = cur
+        if os.environ.get("MM_E2E_LOG"):                       # the stage log of the best run, for profiles/
+            with open(os.environ["MM_E2E_LOG"], "w") as f:
+                f.write("\n".join(l for l in best["stderr"].splitlines() if "timing" in l or "time spent" in l) + "\n")
         bases = nreads * L
         dev_rows = best["dev_rows"]
         # a device-stage row covers one pass over one or several reader batches: its bases are in the row (skch_map.hpp), else the reader's batches in order

@@ -301,6 +301,7 @@ class Map {
       while (true) {
         size_t want = std::min<uint64_t>(plan.passBases, std::max<uint64_t>(batchBases, doneBases));
         if (plan.inputKnown && plan.inputBytes > doneBases) want = (size_t)std::min<uint64_t>(want, std::max<uint64_t>(batchBases, (plan.inputBytes - doneBases) / 3));
+        want -= want / 16;                                  // (a batch is a hair under MASHMAP_HIP_BATCH_MBP: the parser cuts at a record boundary)
         if (maxGroup == 1) want = 0;
         if (!parsed.getGroup(grp, want, maxGroup)) break;
         deviceStage(grp, parsed);

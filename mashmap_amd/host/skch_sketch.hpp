@@ -20,6 +20,7 @@
 #include <sstream>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <unordered_set>
 #include <vector>
@@ -38,6 +39,7 @@ class Sketch {
   mm_ctx* ctx_ = nullptr;                          // the context the index is built on (first device of the list)
   std::vector<mm_ctx*> ctxs_;                      // one per entry of MASHMAP_HIP_DEVICES; ctxs_[0] == ctx_
   mutable std::mutex materializeMu_; mutable bool minmerIndexReady_ = false;
+  std::thread recsPrefill_;                        // page-locks the record buffers of skch::Map's device passes while the index is built
   Sketch();
 
   [[noreturn]] void die(const char* what) const {
@@ -89,6 +91,12 @@ class Sketch {
       // counted by what the query files hold (skch_types.hpp: queryBatchPlan)
       const QueryBatchPlan plan = queryBatchPlan(p.querySequences, ctxs_.size());
       HostBufferPool::instance().prefetch(plan.buffers, plan.bufferBytes);
+      // ... and so are the buffers the candidate mappings of a device pass come back into (about one 48-byte record per segment; three
+      // passes can hold one at a time: device, queue, post stage)
+      if (!plan.inputKnown || plan.inputBytes > (64u << 20)) {
+        const size_t perPass = (size_t)(std::min<uint64_t>(plan.passBases, plan.inputKnown ? plan.inputBytes : plan.passBases) / (uint64_t)std::max<offset_t>(1, p.segLength));
+        recsPrefill_ = std::thread([perPass]() { PinnedRecs<mm_mapping>::prefill(3, perPass + perPass / 4 + 1024); });
+      }
       // ... and the query files' pages are mapped into this process meanwhile (seq_parse.hpp: MappedFileCache)
       if (!getenv("MASHMAP_HIP_NO_PREFAULT")) mmhost::MappedFileCache::instance().prefault(p.querySequences, 8);
     }
@@ -101,7 +109,7 @@ class Sketch {
       std::cerr << "[mashmap_hip::skch::Sketch] ERROR: mm_comm_init_local: " << mm_last_error(ctx_) << std::endl; exit(1);
     }
   }
-  ~Sketch() { for (mm_ctx* c : ctxs_) mm_destroy(c); }
+  ~Sketch() { if (recsPrefill_.joinable()) recsPrefill_.join(); for (mm_ctx* c : ctxs_) mm_destroy(c); }
   Sketch(const Sketch&) = delete;
   Sketch& operator=(const Sketch&) = delete;
 

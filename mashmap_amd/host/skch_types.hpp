@@ -206,6 +206,17 @@ class PinnedRecs {
   T* data() { return p_; } const T* data() const { return p_; }
   size_t size() const { return n_; } bool empty() const { return n_ == 0; }
   T& operator[](size_t i) { return p_[i]; } const T& operator[](size_t i) const { return p_[i]; }
+  // page-locks `count` buffers of `n` records each ahead of their use (skch::Sketch does it in the background of the index build: the
+  // records of a device pass then never wait for pages to be locked)
+  static void prefill(size_t count, size_t n) {
+    for (size_t i = 0; i < count; i++) {
+      const size_t bytes = std::max<size_t>(n * sizeof(T), (size_t)1 << 20);
+      void* q = mm_host_alloc(bytes);
+      if (!q) return;
+      std::lock_guard<std::mutex> lk(pool().mu);
+      pool().free_.emplace_back(q, bytes);
+    }
+  }
   // contents are NOT kept and NOT initialised
   void resize(size_t n) {
     if (n <= cap_) { n_ = n; return; }

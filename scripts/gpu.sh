@@ -30,7 +30,7 @@ smoke)
   timeout 300 python __graft_entry__.py smoke 2>&1 | tail -3 | tee -a $OUT/log.txt ;;
 bench)
   say "== bench (default line)"
-  timeout 1500 python bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
+  MM_E2E_LOG=$OUT/e2e_stage_log.txt timeout 1500 python bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
   grep -v "^\[mm\]" $OUT/bench.err | tail -25 | tee -a $OUT/log.txt; python scripts/bench_digest.py $OUT/bench.json | tee -a $OUT/log.txt ;;
 bench:*)
   WL=${S#bench:}
@@ -70,7 +70,7 @@ pcs:*)
   rm -rf $OUT/pcs_$KERNEL ;;
 e2e)
   say "== e2e FASTA -> PAF"
-  timeout 900 python -c "
+  MM_E2E_LOG=$OUT/e2e_stage_log.txt timeout 900 python -c "
 import json, os, sys, torch
 sys.path.insert(0, '.')
 import bench as B

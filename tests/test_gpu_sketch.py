@@ -222,7 +222,7 @@ def test_packed_parts_equal_one_upload():
         assert ctx.fragments().tobytes() == fr_a
         assert cnt_p.tobytes() == cnt_a.tobytes() and sk_p.tobytes() == sk_a.tobytes(), stage
     # the piece left staged serves the next upload
-    assert ctx.reads_upload_packed_parts([dict(packed=extra)], seqCounterBase=0) == 1
+    assert ctx.reads_upload_packed_parts([dict(packed=extra)], seqCounterBase=0) == 2          # a 6 000-base read: one full segment + the overlapping tail
     one = capi.Context(k=19, segLength=5000, sketchSize=130)
     one.reads_upload_packed(extra)
     assert one.sketch()[0].tobytes() == ctx.sketch()[0].tobytes()
