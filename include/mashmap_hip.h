@@ -290,8 +290,12 @@ int mm_query_sketch_download(mm_ctx* ctx, mm_minmer* out);
  * point list is also kept in HBM so that mm_points_download can return it (parity tests).
  * MM_OPT_KEEP_FULL_INDEX (default 0): keep minmerIndex as it is BEFORE dropFreqSeedSet (winSketch.hpp:497) on the host so that
  * mm_index_download_full can return it -- that is what --saveIndex writes (winSketch.hpp:127-134 run before the drop).
+ * MM_OPT_RESERVE_FRAGMENTS (default 0): the number of fragments of the largest batch the caller is going to upload.  The pass that sizes the
+ * context's staging buffers (the first one, or one that outgrew them) then sizes them for a batch of that many fragments -- per-fragment
+ * buffers directly, count-dependent ones (candidates, L2 streams, mappings) in proportion -- so that a caller whose batches grow (skch::Map
+ * ramps its device passes up from one reader batch to four) pays for sizing and allocation once.
  */
-enum { MM_OPT_KEEP_POINTS = 1, MM_OPT_KEEP_FULL_INDEX = 2 };
+enum { MM_OPT_KEEP_POINTS = 1, MM_OPT_KEEP_FULL_INDEX = 2, MM_OPT_RESERVE_FRAGMENTS = 3 };
 int mm_set_option(mm_ctx* ctx, int option, int value);
 /* sorted, filtered interval points of fragment f (needs MM_OPT_KEEP_POINTS; (seqId,pos,side) only, hash = 0) */
 int mm_points_download(mm_ctx* ctx, size_t frag, mm_interval_point* out, size_t cap, size_t* n);

@@ -441,6 +441,10 @@ class Context:
         self._ck(self.lib.mm_query_sketch_download(self.h, _ptr(out)), "mm_query_sketch_download")
         return out
 
+    def reserve_fragments(self, n):
+        """MM_OPT_RESERVE_FRAGMENTS: the next sized pass sizes every staging buffer for a batch of n fragments"""
+        self._ck(self.lib.mm_set_option(self.h, 3, int(n)), "mm_set_option")
+
     def keep_points(self, on=True):
         """MM_OPT_KEEP_POINTS: keep every fragment's sorted interval points in HBM (needed by points())"""
         self._ck(self.lib.mm_set_option(self.h, 1, 1 if on else 0), "mm_set_option")

@@ -86,6 +86,7 @@ void* mm_stream(const mm_ctx* c) { return (void*)c->stream; }
 int mm_set_option(mm_ctx* c, int option, int value) {
   if (option == MM_OPT_KEEP_POINTS) { c->keepPoints = value != 0; c->ptsCap = 0; return MM_OK; }
   if (option == MM_OPT_KEEP_FULL_INDEX) { c->keepFullIndex = value != 0; return MM_OK; }
+  if (option == MM_OPT_RESERVE_FRAGMENTS) { c->reserveFrags = value > 0 ? (size_t)value : 0; return MM_OK; }
   c->err = "mm_set_option: unknown option"; return MM_ERR_ARG;
 }
 
@@ -216,6 +217,11 @@ static int finish_upload(mm_ctx* c, size_t nReads, int64_t pk, const std::vector
 }
 
 static int ensure_read_buffers(mm_ctx* c, size_t nReads, int64_t pk, size_t nFrags) {
+  // MM_OPT_RESERVE_FRAGMENTS: room for the largest announced batch right away (its fragments are full segments; a read has at least one)
+  if (c->reserveFrags > nFrags) {
+    const int64_t pkR = (int64_t)c->reserveFrags * (int64_t)c->P.segLength; pk = pkR > pk ? pkR + pkR / 64 : pk;
+    nReads = std::max(nReads, c->reserveFrags); nFrags = c->reserveFrags;
+  }
   MM_HIP(c, c->dReadSrcOff.ensure((nReads + 1) * 8)); MM_HIP(c, c->dReadPackOff.ensure((nReads + 1) * 8));
   MM_HIP(c, c->dReadLen.ensure(nReads * 4 + 4)); MM_HIP(c, c->dReadGroup.ensure(nReads * 4 + 4)); MM_HIP(c, c->dReadSelf.ensure(nReads * 4 + 4));
   MM_HIP(c, c->dReadHasN.ensure(nReads * 4 + 4));

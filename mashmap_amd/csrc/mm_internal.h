@@ -143,6 +143,7 @@ struct mm_ctx {
   size_t nSyncs = 0;                                    // host synchronisations inside the last mm_map_fragments (diagnostics: mm_pass_syncs)
   uint64_t nPasses = 0, nSteadyPasses = 0, nRedone = 0; // mm_map_fragments calls of this context: all, those that went through as steady-state passes, steady attempts redone the sized way
   bool keepPoints = false;                              // mm_set_option(MM_OPT_KEEP_POINTS): route every fragment through the HBM point list
+  size_t reserveFrags = 0;                              // mm_set_option(MM_OPT_RESERVE_FRAGMENTS): fragments of the largest batch the caller will upload; sized passes size for it
 
   // profiling
   bool profile = false;
@@ -192,6 +193,15 @@ inline void mm_profile_collect(mm_ctx* c) {
     if (hipEventElapsedTime(&ms, c->evPool[pr.second].first, c->evPool[pr.second].second) == hipSuccess) { c->kMs[pr.first] += ms; c->kLaunches[pr.first] += 1; }
   }
   c->evPending.clear(); c->evUsed = 0;
+}
+
+// MM_OPT_RESERVE_FRAGMENTS: a sized pass over a small batch sizes every staging buffer for the largest batch the caller has announced, so
+// that the larger batches behind it are steady-state passes instead of being sized (and their buffers reallocated) again.
+//   mm_frag_cap: fragments to size per-fragment buffers for;  mm_scaled: a count of this pass scaled to what the announced batch would bring
+inline size_t mm_frag_cap(const mm_ctx* c, size_t nF) { return nF > c->reserveFrags ? nF : c->reserveFrags; }
+inline size_t mm_scaled(const mm_ctx* c, size_t count) {
+  const size_t nF = c->nFrags ? c->nFrags : 1;
+  return c->reserveFrags > nF ? (size_t)((double)count * (double)c->reserveFrags / (double)nF) + 1 : count;
 }
 
 // launchers implemented in the .hip files

@@ -1193,10 +1193,11 @@ static int map_pass(mm_ctx* c, const bool steady) {
   // seeds' numbers) in HBM: k_l1_window here, k_l2_window in mm_l2.hip
   const bool windowed = c->windowed;
   const bool allSlow = c->keepPoints || fl.skipPrefix || windowed;
-  if (c->ptsCap == 0) c->ptsCap = allSlow ? (size_t)nF * 128 + 4096 : (size_t)nF * 8 + 65536;
-  if (c->l1Cap == 0) c->l1Cap = (size_t)nF * 2 + 1024;
+  const size_t cF = mm_frag_cap(c, (size_t)nF);
+  if (c->ptsCap == 0) c->ptsCap = allSlow ? cF * 128 + 4096 : cF * 8 + 65536;
+  if (c->l1Cap < cF * 2 + 1024) c->l1Cap = cF * 2 + 1024;
   DevBuf& listB = c->dListB; DevBuf& listC = c->dListC;
-  MM_HIP(c, listB.ensure((size_t)nF * 4 + 16)); MM_HIP(c, listC.ensure((size_t)nF * 4 + 16)); MM_HIP(c, c->dBigList.ensure((size_t)nF * 4 + 16));
+  MM_HIP(c, listB.ensure(cF * 4 + 16)); MM_HIP(c, listC.ensure(cF * 4 + 16)); MM_HIP(c, c->dBigList.ensure(cF * 4 + 16));
   MM_HIP(c, c->dL1Regions.ensure(sizeof(L1Regions)));
   int rc = MM_OK;
   unsigned long long hc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1242,10 +1243,11 @@ static int map_pass(mm_ctx* c, const bool steady) {
     MM_HIP(c, hipMemcpyAsync(c->hPass + 16, c->dCounters.as<unsigned long long>() + 48, 8, hipMemcpyDeviceToHost, c->stream));
     MM_SYNC(c);
     c->lastHard = (size_t)(c->hPass[16] & 0xffffffffull);
-    if (hc[1]) { c->ptsCap = (size_t)hc[0] + (size_t)hc[0] / 8 + 4096; continue; }
+    if (hc[1]) { const size_t need = mm_scaled(c, (size_t)hc[0]); c->ptsCap = need + need / 8 + 4096; continue; }
     if (hc[3]) {                                              // some region overflowed: size for the largest one seen
       unsigned long long mx = 0;
       for (int r = 0; r < MM_L1_REGIONS; r++) mx = std::max(mx, hcur[(size_t)r * MM_L1_CURSOR_STRIDE]);
+      mx = (unsigned long long)mm_scaled(c, (size_t)mx);
       c->l1Cap = (size_t)(mx + mx / 4 + 256) * MM_L1_REGIONS; continue;
     }
     break;
@@ -1400,9 +1402,10 @@ static int map_pass(mm_ctx* c, const bool steady) {
 
 int mm_launch_map(mm_ctx* c) {
   const int nF = (int)c->nFrags, s = c->P.sketchSize;
-  MM_HIP(c, c->dQHash.ensure((size_t)nF * s * 8 + 64)); MM_HIP(c, c->dQStrand.ensure((size_t)nF * s + 64));
-  MM_HIP(c, c->dStats.ensure((size_t)nF * sizeof(mm_frag_stats) + 64));
-  MM_HIP(c, c->dPtOff.ensure((size_t)nF * 16 + 64)); MM_HIP(c, c->dL1Off.ensure((size_t)nF * 8 + 64)); MM_HIP(c, c->dPtKept.ensure((size_t)nF * 4 + 64));
+  const size_t cF = mm_frag_cap(c, (size_t)nF);
+  MM_HIP(c, c->dQHash.ensure(cF * s * 8 + 64)); MM_HIP(c, c->dQStrand.ensure(cF * s + 64));
+  MM_HIP(c, c->dStats.ensure(cF * sizeof(mm_frag_stats) + 64));
+  MM_HIP(c, c->dPtOff.ensure(cF * 16 + 64)); MM_HIP(c, c->dL1Off.ensure(cF * 8 + 64)); MM_HIP(c, c->dPtKept.ensure(cF * 4 + 64));
   MM_HIP(c, c->dCounters.ensure(512));
   if (!c->hPass) { MM_HIP(c, hipHostMalloc((void**)&c->hPass, 256, hipHostMallocDefault)); }
   c->nL1 = c->nL2 = 0; c->nMappings = 0; c->nSyncs = 0; c->lastSteady = false;
@@ -1417,7 +1420,7 @@ int mm_launch_map(mm_ctx* c) {
     c->steadyOk = false; c->steadyFails++; c->nRedone++;                        // three redone passes in a row: this context's batches keep outgrowing what the one before left
   }
   const int rc = map_pass(c, false);
-  c->sizedFrags = (size_t)nF;
+  c->sizedFrags = mm_frag_cap(c, (size_t)nF);
   c->steadyOk = rc == MM_OK && !allSlow && c->nL1 > 0 && c->l2Chunks == 1;   // (a batch whose L2 streams go through in chunks needs the host between them)
   return rc;
 }

@@ -69,9 +69,10 @@ int mm_launch_select(mm_ctx* c, bool steady) {
   c->nMappings = 0;
   const int nF = (int)c->nFrags;
   if (!c->haveReplayTables || nF == 0 || (!steady && c->nL1 == 0)) return MM_OK;
-  MM_HIP(c, c->dSelCnt.ensure((size_t)nF * 4 + 64)); MM_HIP(c, c->dSelOff.ensure((size_t)nF * 8 + 64));
+  const size_t cF = mm_frag_cap(c, (size_t)nF);
+  MM_HIP(c, c->dSelCnt.ensure(cF * 4 + 64)); MM_HIP(c, c->dSelOff.ensure(cF * 8 + 64));
   MM_HIP(c, c->dSelHeap.ensure((steady ? c->candCap : std::max(c->nL1, c->candCap)) * 4 + 64));
-  MM_HIP(c, c->dFragTab.ensure((size_t)nF * sizeof(mm_fragment) + 64));
+  MM_HIP(c, c->dFragTab.ensure(cF * sizeof(mm_fragment) + 64));
   if (c->fragTabStale) {
     MM_HIP(c, hipMemcpyAsync(c->dFragTab.p, c->hFrags.data(), (size_t)nF * sizeof(mm_fragment), hipMemcpyHostToDevice, c->stream));
     c->fragTabStale = false;
@@ -104,7 +105,7 @@ int mm_launch_select(mm_ctx* c, bool steady) {
   const int rc = mm_scan_i32_to_i64(c, nF, c->dSelCnt.as<int32_t>(), c->dSelOff.as<int64_t>(), &total);
   c->nSyncs++;
   if (rc != MM_OK) return rc;
-  MM_HIP(c, c->dMappings.ensure((size_t)(total + total / 16) * sizeof(mm_mapping) + 4096));   // head room for the steady-state passes behind this one
+  { const size_t tot = mm_scaled(c, (size_t)total); MM_HIP(c, c->dMappings.ensure((tot + tot / 16) * sizeof(mm_mapping) + 4096)); }   // head room for the steady-state passes behind this one
   if (total) {
     hipLaunchKernelGGL((k_l2_select<true>), dim3((nF + 255) / 256), dim3(256), 0, c->stream, A, (int32_t*)nullptr, c->dSelOff.as<int64_t>(), c->dMappings.as<mm_mapping>(),
                        (const int64_t*)nullptr, 0ll, (unsigned long long*)nullptr, (const unsigned long long*)nullptr);

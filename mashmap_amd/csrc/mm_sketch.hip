@@ -945,17 +945,18 @@ extern "C" int mm_bench_hash_only(mm_ctx* c, int reps, double* msAvg) {
 
 int mm_launch_sketch(mm_ctx* c) {
   const size_t nF = c->nFrags, s = (size_t)c->P.sketchSize;
+  const size_t cF = mm_frag_cap(c, nF);               // (the largest batch the caller has announced: no reallocation when it comes)
   if (s > MM_LDS_MAX_SKETCH) {
     MM_HIP(c, c->dSkHash.ensure(nF * s * 8 + 64)); MM_HIP(c, c->dSkPos.ensure(nF * s * 8 + 64));
     MM_HIP(c, c->dSkStrand.ensure(nF * s + 64)); MM_HIP(c, c->dSkCount.ensure(nF * 4 + 64));
     MM_HIP(c, c->dHardList.ensure(nF * 4 + 64)); MM_HIP(c, c->dCounters.ensure(512));
     return mm_launch_sketch_global(c);
   }
-  MM_HIP(c, c->dSkHash.ensure(nF * s * 8 + 64));
-  MM_HIP(c, c->dSkPos.ensure(nF * s * 8 + 64));
-  MM_HIP(c, c->dSkStrand.ensure(nF * s + 64));
-  MM_HIP(c, c->dSkCount.ensure(nF * 4 + 64));
-  MM_HIP(c, c->dHardList.ensure(nF * 4 + 64));
+  MM_HIP(c, c->dSkHash.ensure(cF * s * 8 + 64));
+  MM_HIP(c, c->dSkPos.ensure(cF * s * 8 + 64));
+  MM_HIP(c, c->dSkStrand.ensure(cF * s + 64));
+  MM_HIP(c, c->dSkCount.ensure(cF * 4 + 64));
+  MM_HIP(c, c->dHardList.ensure(cF * 4 + 64));
   MM_HIP(c, c->dCounters.ensure(256));
   if (nF == 0) return MM_OK;
   switch (c->P.kmerSize) {

@@ -195,6 +195,13 @@ class Map {
     // uploads; MASHMAP_HIP_COALESCE_MBP=0 maps every batch by itself
     const size_t maxGroup = (ctxs.size() == 1 && packedUpload) ? std::max<size_t>(1, plan.passBases / std::max<size_t>(1, batchBases)) : 1;
     Channel parsed(std::max<size_t>(2, maxGroup)), mapped(std::max<size_t>(2, 2 * maxGroup));
+    if (maxGroup > 1) {
+      // passes grow from one batch to maxGroup: the first pass sizes the contexts' staging buffers for the largest one (a quarter of head
+      // room for the overlapping tail fragments of reads that are not a multiple of segLength long), the others then launch against them
+      const uint64_t frags = plan.passBases / (uint64_t)std::max<offset_t>(1, param.segLength);
+      const int reserve = (int)std::min<uint64_t>(0x7fffffffu, frags + frags / 4 + 1024);
+      for (mm_ctx* c : ctxs) if (mm_set_option(c, MM_OPT_RESERVE_FRAGMENTS, reserve) != MM_OK) die("mm_set_option", c);
+    }
     if (!getenv("MASHMAP_HIP_NO_MALLOPT") && (!plan.inputKnown || plan.inputBytes > (256u << 20))) {
       // every batch allocates and frees a few megabyte-sized vectors (records, per-read results, PAF text) from three stages at once:
       // keep them on the heap instead of mmap/munmap per batch (each unmap interrupts every thread of the process), and keep the heap

@@ -8,9 +8,10 @@
 #   rr               the repeat-rich north_star workload alone (bench.py --workload northstar --repeat-rich-reference)
 #   trace:WL         rocprofv3 --kernel-trace --stats of two passes of WL      -> kernel_stats_WL.csv
 #   pmc:WL           FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU passes of WL (one rocprofv3 run each) -> pmc_WL_*.csv (scripts/pmc_summary.py reduces them)
-#   pcs:KERNEL[:WL]  rocprofv3 PC sampling of one pass, histogram of the sampled instructions of KERNEL
 #   e2e              FASTA -> PAF through the mashmap_hip command line only (bench.py's e2e leg)
-# Environment variables given on the command line reach every step (A/B switches: MM_*, MASHMAP_HIP_*).
+#   large            --dense -s 100000 (sketchSize 9 998) and k = 40 / 57 through mashmap_hip and the stock binary, with the stage log
+# Environment variables given on the command line reach every step (A/B switches: MM_*, MASHMAP_HIP_*); MM_BENCH_EXTRA: extra bench.py
+# arguments of the trace steps (e.g. --repeat-rich-reference).
 TAG=${1:-visit}; shift
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
@@ -48,7 +49,7 @@ rr)
 trace:*)
   WL=${S#trace:}
   say "== $WL: rocprofv3 --kernel-trace --stats"
-  timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$WL -o trace -- python bench.py --steps 3 --warmup 3 $(wl_args $WL) --no-cpu-baseline --no-host-path --no-e2e --no-north-star > $OUT/trace_$WL.json 2> $OUT/trace_$WL.err
+  timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$WL -o trace -- python bench.py --steps 3 --warmup 3 $(wl_args $WL) $MM_BENCH_EXTRA --no-cpu-baseline --no-host-path --no-e2e --no-north-star > $OUT/trace_$WL.json 2> $OUT/trace_$WL.err
   find $OUT/trace_$WL -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} $OUT/kernel_stats_$WL.csv
   rm -rf $OUT/trace_$WL
   grep -E '^"(void )?k_' $OUT/kernel_stats_$WL.csv | head -12 | cut -c1-160 | tee -a $OUT/log.txt ;;
@@ -60,14 +61,6 @@ pmc:*)
     python scripts/pmc_summary.py $OUT/pmc_${WL}_$C $C > $OUT/pmc_${WL}_$C.csv 2>> $OUT/log.txt; rm -rf $OUT/pmc_${WL}_$C
     head -8 $OUT/pmc_${WL}_$C.csv | cut -c1-160 | tee -a $OUT/log.txt
   done ;;
-pcs:*)
-  IFS=: read -r _ KERNEL WL <<< "$S"
-  say "== PC sampling of $KERNEL (${WL:-configs1})"
-  timeout 900 rocprofv3 --pc-sampling-beta-enabled --pc-sampling-method host_trap --pc-sampling-unit time --pc-sampling-interval 100 \
-    --kernel-trace --output-format csv json -d $OUT/pcs_$KERNEL -o pcs -- python bench.py --steps 2 --warmup 3 $(wl_args $WL) --no-cpu-baseline --no-host-path --no-e2e --no-north-star > /dev/null 2> $OUT/pcs_$KERNEL.err
-  tail -3 $OUT/pcs_$KERNEL.err | tee -a $OUT/log.txt
-  python scripts/pcs_histogram.py $OUT/pcs_$KERNEL "$KERNEL" > $OUT/pcs_$KERNEL.txt 2>&1; head -70 $OUT/pcs_$KERNEL.txt | tee -a $OUT/log.txt
-  rm -rf $OUT/pcs_$KERNEL ;;
 e2e)
   say "== e2e FASTA -> PAF"
   MM_E2E_LOG=$OUT/e2e_stage_log.txt timeout 900 python -c "
@@ -78,6 +71,9 @@ dev = torch.device('cuda', 0); W = dict(B.WORKLOADS['configs1'])
 ref = B.contiguous_views(torch, B.make_reference(torch, dev, W['ref_contigs'], W['ref_contig_len']))
 print(json.dumps(B.e2e_fasta_to_paf(torch, dev, W, ref, W['reads'], max(4, min(128, os.cpu_count())))))" > $OUT/e2e.json 2> $OUT/e2e.err
   tail -3 $OUT/e2e.err | tee -a $OUT/log.txt; cat $OUT/e2e.json | cut -c1-2500 | tee -a $OUT/log.txt ;;
+large)
+  say "== large sketches / long k-mers through both command lines (scripts/large_sketch_paf.py)"
+  LARGE_VERBOSE=1 timeout 900 python scripts/large_sketch_paf.py 2>&1 | tail -60 | tee -a $OUT/log.txt ;;
 *) say "unknown step $S" ;;
 esac
 done

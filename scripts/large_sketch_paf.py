@@ -21,7 +21,10 @@ for args in (["-s", "100000", "--pi", "80", "--dense"], ["-k", "40", "-s", "2000
     outs = {}
     for tag, exe in (("hip", HIP), ("ref", U.REF_BIN)):
         t0 = time.time()
-        p = subprocess.run([exe, "-r", rf, "-q", qf, "-t", "8", "-o", os.path.join(td, tag + ".paf")] + args, capture_output=True, text=True)
+        p = subprocess.run([exe, "-r", rf, "-q", qf, "-t", "8", "-o", os.path.join(td, tag + ".paf")] + args, capture_output=True, text=True,
+                           env=dict(os.environ, MASHMAP_HIP_TIMING="1", MM_DEBUG="1") if tag == "hip" and os.environ.get("LARGE_VERBOSE") else None)
+        if tag == "hip" and os.environ.get("LARGE_VERBOSE"):
+            print("\n".join(l[:220] for l in p.stderr.splitlines() if "timing" in l or "time spent" in l or l.startswith("[mm] index") or "L2" in l)[-6000:], flush=True)
         outs[tag] = (p.returncode, open(os.path.join(td, tag + ".paf"), "rb").read() if p.returncode == 0 else p.stderr[-400:], time.time() - t0)
     ok = outs["hip"][0] == 0 and outs["ref"][0] == 0 and outs["hip"][1] == outs["ref"][1]
     bad += 0 if ok else 1

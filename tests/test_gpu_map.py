@@ -522,8 +522,8 @@ def test_resident_batches_take_turns_and_an_l1_overflow_in_a_steady_pass_is_redo
     ctx.index_build(contigs, kmerPct=0.0); ctx.set_tables_default(0.85)
     ctx.reads_upload(A); ctx.reads_exchange(0)                                   # slot 0 = A
     ctx.reads_upload(C); ctx.reads_exchange(1)                                   # slot 1 = C
-    ctx.reads_upload(B)                                                          # resident = B
-    assert ctx.num_fragments() == 240
+    nFB = ctx.reads_upload(B)                                                    # resident = B
+    assert ctx.num_fragments() == nFB > 200
     got = lambda: tuple(x.tobytes() for x in ctx.results()) + (ctx.mappings().tobytes(),)
     ctx.map(); assert got() == wantB and not ctx.pass_stats()[1]                 # sizing pass
     ctx.reads_exchange(0); ctx.map()                                             # resident A, slot 0 = B
@@ -537,7 +537,7 @@ def test_resident_batches_take_turns_and_an_l1_overflow_in_a_steady_pass_is_redo
     ctx.map(); assert got() == wantC and ctx.pass_stats() == (1, True)           # sized for C now
     ctx.reads_exchange(0); ctx.map(); assert got() == wantB and ctx.pass_stats() == (1, True)
     ctx.reads_exchange(2); assert ctx.num_fragments() == 0                       # an empty slot: nothing resident
-    ctx.reads_exchange(2); assert ctx.num_fragments() == 240
+    ctx.reads_exchange(2); assert ctx.num_fragments() == nFB
     with pytest.raises(capi.MashmapError):
         ctx.reads_exchange(capi.load().mm_abi_version() + 99)
     ctx.close()
@@ -558,4 +558,39 @@ def test_pass_counts_report_the_hard_list(oracle):
     assert ctx.pass_counts()["hard"] == 4                                        # two fragments per satellite read
     ctx.map()
     assert ctx.pass_stats()[1] and ctx.pass_counts()["hard"] == 4                # the count comes back with a steady-state pass's counters too
+    ctx.close()
+
+
+def test_reserved_fragments_make_a_growing_batch_a_steady_pass(oracle):
+    """MM_OPT_RESERVE_FRAGMENTS: the pass that sizes the staging buffers sizes them for the announced batch, so a batch five times the first
+    one -- what skch::Map's device passes do when they grow from one reader batch to four -- goes through as a steady-state pass (one host
+    wait, no reallocation) with the bytes of a fresh context; without the announcement it is sized again (the test above)"""
+    from mashmap_amd import capi
+    unit = U.random_dna(841, 20000)
+    rep = np.concatenate([U.mutate(unit, 940 + i, 0.01) for i in range(6)])
+    g = U.random_dna(842, 600000)
+    contigs = [rep, g]
+    small = [a for _, a, _ in U.sample_reads(contigs, 843, 80, 10000, 0.08)]
+    big = [a for _, a, _ in U.sample_reads(contigs, 844, 400, 10000, 0.08)]
+
+    def fresh(reads):
+        c = capi.Context(k=19, segLength=5000, sketchSize=130, flags=capi.MM_FLAG_HG_FILTER)
+        c.index_build(contigs, kmerPct=0.0); c.set_tables_default(0.85)
+        n = c.reads_upload(reads); c.map()
+        out = tuple(x.tobytes() for x in c.results()) + (c.mappings().tobytes(),)
+        c.close()
+        return out, n
+
+    (want_small, _), (want_big, nBig) = fresh(small), fresh(big)
+    ctx = capi.Context(k=19, segLength=5000, sketchSize=130, flags=capi.MM_FLAG_HG_FILTER)
+    ctx.index_build(contigs, kmerPct=0.0); ctx.set_tables_default(0.85)
+    ctx.reserve_fragments(nBig + nBig // 8)
+    got = lambda: tuple(x.tobytes() for x in ctx.results()) + (ctx.mappings().tobytes(),)
+    ctx.reads_upload(small); ctx.map()
+    assert got() == want_small and not ctx.pass_stats()[1]
+    ctx.reads_upload(big); ctx.map()
+    assert got() == want_big and ctx.pass_stats() == (1, True), ctx.pass_stats()
+    ctx.reads_upload(small); ctx.map()
+    assert got() == want_small and ctx.pass_stats() == (1, True)
+    assert ctx.pass_totals() == {"passes": 3, "steady": 2, "redone": 0}
     ctx.close()
