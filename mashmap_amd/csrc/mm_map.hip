@@ -150,21 +150,31 @@ __device__ __forceinline__ int mm_gather_points(Dst dst, int& done, int rdBase, 
                                                 const uint64_t* __restrict__ ptKeys, const int32_t* __restrict__ refGroup,
                                                 int rg, int self, int seqCounter, MapFlags fl, int lane, uint16_t* __restrict__ ids = nullptr) {
   int nValid = 0;
+  auto one = [&](uint64_t key, int at, int seed) {
+    const int seqId = (int)(key >> 33);
+    bool drop = false;
+    if (fl.skipSelf && seqId == self) drop = true;
+    if (fl.skipPrefix && refGroup[seqId] == rg) drop = true;
+    if (fl.lowerTri && !(seqCounter > seqId)) drop = true;
+    if (drop) key = MM_EMPTY; else nValid++;
+    dst[at] = key;
+    if (ids) ids[at] = (uint16_t)seed;
+  };
   for (int rd = 0; rd < nRounds; rd++) {
     const uint64_t val = valAt(rd);                // table value of this lane's seed in round rd (0: none)
     const int c = (int)((val >> 1) & 0x7fffffull);
     const int my = done + mm_wave_excl_scan(c);
     const uint64_t src = val >> 24;
-    for (int j = 0; j < c; j++) {
-      uint64_t key = ptKeys[src + j];
-      const int seqId = (int)(key >> 33);
-      bool drop = false;
-      if (fl.skipSelf && seqId == self) drop = true;
-      if (fl.skipPrefix && refGroup[seqId] == rg) drop = true;
-      if (fl.lowerTri && !(seqCounter > seqId)) drop = true;
-      if (drop) key = MM_EMPTY; else nValid++;
-      dst[my + j] = key;
-      if (ids) ids[my + j] = (uint16_t)((rdBase + rd) * 64 + lane);
+    // a short run is copied by the lane that owns the seed; a long one -- a seed of a repeat family brings hundreds of points, and the
+    // other 63 lanes used to wait for the one that copied them point by point -- by the whole wave, 64 consecutive points at a time
+    const bool longRun = c > 8;
+    if (!longRun) for (int j = 0; j < c; j++) one(ptKeys[src + j], my + j, (rdBase + rd) * 64 + lane);
+    uint64_t mLong = mm_ballot(longRun);
+    while (mLong) {
+      const int l = (int)__builtin_ctzll(mLong); mLong &= mLong - 1ull;
+      const int cL = __shfl(c, l), myL = __shfl(my, l);
+      const uint64_t srcL = ((uint64_t)(uint32_t)__shfl((int)(src >> 32), l) << 32) | (uint32_t)__shfl((int)(uint32_t)src, l);
+      for (int j = lane; j < cL; j += 64) one(ptKeys[srcL + j], myL + j, (rdBase + rd) * 64 + l);
     }
     done += mm_wave_sum(c);
   }
@@ -688,7 +698,8 @@ __global__ void k_l1_gate(unsigned long long* __restrict__ counters, unsigned lo
 // ---------------------------------------------------------------------------------------------
 // point sorters for the queued fragments (ascending packed key == ascending (seqId, pos, CLOSE-before-OPEN))
 // ---------------------------------------------------------------------------------------------
-// <= 64 points: one wave per fragment, bitonic network over the lanes
+// <= 512 points: one wave per fragment, bitonic network over the lanes' registers
+#define MM_SORT_WAVECAP 512
 // The kernels over the queued fragments take the list's length from the device when nDev is given (the launcher then has not read it
 // back: steady-state passes, one host synchronisation per pass) and walk the list with whatever grid they were given.
 __global__ void __launch_bounds__(256)
@@ -697,11 +708,36 @@ k_sort_points_wave(int nList, const unsigned long long* __restrict__ nDev, const
   for (int li = blockIdx.x * 4 + (threadIdx.x >> 6); li < nList; li += gridDim.x * 4) {
     const int f = list[li];
     const int64_t off = ptOff[2 * f]; const int n = (int)ptOff[2 * f + 1];
-    if (n <= 1 || n > 64) continue;
+    if (n <= 1 || n > MM_SORT_WAVECAP) continue;
     const int lane = (int)mm_lane();
-    uint64_t k[1] = {lane < n ? pts[off + lane] : MM_EMPTY};
-    mm_wave_bitonic<1>(k, lane);
-    if (lane < n) pts[off + lane] = k[0];
+    // up to 512 points in the registers of one wave (the network of the fused kernel): no LDS, no barrier.  What k_filter_points leaves of
+    // a repeat-rich fragment's list is a few hundred points; the workgroup-per-fragment LDS sorter below took 16 ms per 0.6 M such lists
+    if (n <= 64) {
+      uint64_t k[1] = {lane < n ? pts[off + lane] : MM_EMPTY};
+      mm_wave_bitonic<1>(k, lane);
+      if (lane < n) pts[off + lane] = k[0];
+    } else if (n <= 128) {
+      uint64_t k[2];
+#pragma unroll
+      for (int r = 0; r < 2; r++) k[r] = lane * 2 + r < n ? pts[off + lane * 2 + r] : MM_EMPTY;
+      mm_wave_bitonic<2>(k, lane);
+#pragma unroll
+      for (int r = 0; r < 2; r++) if (lane * 2 + r < n) pts[off + lane * 2 + r] = k[r];
+    } else if (n <= 256) {
+      uint64_t k[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) k[r] = lane * 4 + r < n ? pts[off + lane * 4 + r] : MM_EMPTY;
+      mm_wave_bitonic<4>(k, lane);
+#pragma unroll
+      for (int r = 0; r < 4; r++) if (lane * 4 + r < n) pts[off + lane * 4 + r] = k[r];
+    } else {
+      uint64_t k[8];
+#pragma unroll
+      for (int r = 0; r < 8; r++) k[r] = lane * 8 + r < n ? pts[off + lane * 8 + r] : MM_EMPTY;
+      mm_wave_bitonic<8>(k, lane);
+#pragma unroll
+      for (int r = 0; r < 8; r++) if (lane * 8 + r < n) pts[off + lane * 8 + r] = k[r];
+    }
   }
 }
 
@@ -1301,7 +1337,7 @@ static int map_pass(mm_ctx* c, const bool steady) {
       }
       if (!windowed) hipLaunchKernelGGL(k_sort_points_wave, dim3(gWave), dim3(256), 0, c->stream, nBig, nBigDev, c->dBigList.as<int32_t>(), c->dPtOff.as<int64_t>(), c->dPts.as<uint64_t>());
       hipLaunchKernelGGL(k_classify_sort, dim3(gThread), dim3(256), 0, c->stream, nBig, nBigDev, c->dBigList.as<int32_t>(), c->dPtOff.as<int64_t>(),
-                         listB.as<int32_t>(), listC.as<int32_t>(), cls, windowed ? 1 : 64);
+                         listB.as<int32_t>(), listC.as<int32_t>(), cls, windowed ? 1 : MM_SORT_WAVECAP);
       MM_HIP(c, hipGetLastError());
       unsigned int hcls[2] = {1024u, 16u};                    // steady: fixed grids over the two lists (their lengths stay on the device)
       if (!steady) {
