@@ -9,6 +9,7 @@
 #   trace:WL         rocprofv3 --kernel-trace --stats of two passes of WL      -> kernel_stats_WL.csv
 #   pmc:WL           FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU passes of WL (one rocprofv3 run each) -> pmc_WL_*.csv (scripts/pmc_summary.py reduces them)
 #   e2e              FASTA -> PAF through the mashmap_hip command line only (bench.py's e2e leg)
+#   nosplit          --noSplit on 30 kbp reads through both command lines: same PAF, both times
 #   large            --dense -s 100000 (sketchSize 9 998) and k = 40 / 57 through mashmap_hip and the stock binary, with the stage log
 # Environment variables given on the command line reach every step (A/B switches: MM_*, MASHMAP_HIP_*); MM_BENCH_EXTRA: extra bench.py
 # arguments of the trace steps (e.g. --repeat-rich-reference).
@@ -74,6 +75,9 @@ print(json.dumps(B.e2e_fasta_to_paf(torch, dev, W, ref, W['reads'], max(4, min(1
 large)
   say "== large sketches / long k-mers through both command lines (scripts/large_sketch_paf.py)"
   LARGE_VERBOSE=1 timeout 900 python scripts/large_sketch_paf.py 2>&1 | tail -60 | tee -a $OUT/log.txt ;;
+nosplit)
+  say "== --noSplit, 30 kbp reads, both command lines (scripts/nosplit_paf.py)"
+  timeout 900 python scripts/nosplit_paf.py 2>&1 | tail -8 | tee -a $OUT/log.txt ;;
 *) say "unknown step $S" ;;
 esac
 done
