@@ -1082,10 +1082,9 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt, bool steady) {
   if (oneChunk) { const int rc = locate(chunks[0]); if (rc != MM_OK) return rc; }      // its streams stay put over the retries below
   // candidates per wave of the sweeps (LPW): 64, fewer when the LDS state of 64 does not fit a CU -- 8-bit cells first, 16-bit cells
   // for the rare candidate whose 5-bit counters overflow
-  // (JB == 11, 8-bit cells: 64 lanes, or 32 when MM_L2_LPW=32 asks for it -- at s = 498 the state of 64 candidates is 32 KB, five waves per
-  // CU; 32 lanes per wave double the waves at the price of half-empty instructions: the A/B switch of profiles/NOTES.md, round 5)
-  static const int lpwEnv = getenv("MM_L2_LPW") ? atoi(getenv("MM_L2_LPW")) : 0;
-  const int lpwN = JB == 11 ? (lpwEnv == 32 ? 32 : 64) : ((size_t)(s + 2) * 32 <= 160 * 1024 ? 32 : 16);
+  // (JB == 11: always 64 lanes.  At s = 498 the state of 64 candidates is 32 KB, five waves per CU; 32 lanes per wave double the waves and
+  // were measured slower all the same -- sweep 40.1 -> 55.7 ms at configs[4], profiles/NOTES.md round 5: the kernel is issue-bound even there)
+  const int lpwN = JB == 11 ? 64 : ((size_t)(s + 2) * 32 <= 160 * 1024 ? 32 : 16);
   const int lpwW = JB == 11 ? ((size_t)(s + 2) * 128 <= 160 * 1024 ? 64 : 32) : ((size_t)(s + 2) * 32 <= 160 * 1024 ? 16 : 8);
   const size_t ldsWide = (size_t)(s + 2) * lpwW * 2;                       // cells 0..S + one of padding, 16 bit
   const size_t ldsNarrow = (((size_t)(s + 2) * lpwN) + 15) & ~(size_t)15;  // 8 bit
@@ -1101,7 +1100,7 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt, bool steady) {
                          c->dL2Wide.as<int32_t>(), c->dL2Exact.as<int32_t>(), c->dL2First.as<int64_t>(), c->dL2Num.as<int32_t>(), cnt, countDev, listCap);
     };
     if (!wide) {
-      if (JB == 11) { if (lpwN == 64) go(k_l2_sweep<false, 11, 64>, 64, ldsNarrow); else go(k_l2_sweep<false, 11, 32>, 32, ldsNarrow); }
+      if (JB == 11) go(k_l2_sweep<false, 11, 64>, 64, ldsNarrow);
       else if (lpwN == 32) go(k_l2_sweep<false, 13, 32>, 32, ldsNarrow);
       else go(k_l2_sweep<false, 13, 16>, 16, ldsNarrow);
     } else {
