@@ -56,6 +56,7 @@
 
 #include "../../include/mashmap_hip.h"
 #include "mm_stats.hpp"
+#include "pass_plan.hpp"
 #include "seq_parse.hpp"
 #include "skch_map_post.hpp"
 #include "skch_sketch.hpp"
@@ -109,40 +110,7 @@ class Map {
     std::cerr << "[mashmap_hip::skch::Map] ERROR: " << what << ": " << mm_last_error(c ? c : ctx) << std::endl;
     exit(1);
   }
-  // hand-over between two stages: at most `cap` batches waiting
-  struct Channel {
-    std::deque<Batch> q; std::mutex mu; std::condition_variable cvFull, cvEmpty; bool done = false; size_t cap;
-    explicit Channel(size_t c) : cap(c) {}
-    void put(Batch&& b) { std::unique_lock<std::mutex> lk(mu); cvFull.wait(lk, [&] { return q.size() < cap; }); q.emplace_back(std::move(b)); lk.unlock(); cvEmpty.notify_one(); }
-    // blocks until there is room; with a single producer the put() that follows does not wait
-    void waitSpace() { std::unique_lock<std::mutex> lk(mu); cvFull.wait(lk, [&] { return q.size() < cap; }); }
-    bool get(Batch& b) {
-      std::unique_lock<std::mutex> lk(mu);
-      cvEmpty.wait(lk, [&] { return !q.empty() || done; });
-      if (q.empty()) return false;
-      b = std::move(q.front()); q.pop_front();
-      lk.unlock(); cvFull.notify_one();
-      return true;
-    }
-    void close() { { std::lock_guard<std::mutex> lk(mu); done = true; } cvEmpty.notify_all(); }
-    // the batches of one device pass: waits until `want` bases are queued (or the producer is done, or the queue is full), then takes
-    // batches from the front until the pass holds `want` bases -- at least one, at most `maxBatches`
-    bool getGroup(std::vector<Batch>& g, size_t want, size_t maxBatches) {
-      std::unique_lock<std::mutex> lk(mu);
-      cvEmpty.wait(lk, [&] {
-        if (done || q.size() >= cap || q.size() >= maxBatches) return !q.empty() || done;
-        size_t have = 0; for (const auto& b : q) have += b.bases();
-        return !q.empty() && have >= want;
-      });
-      if (q.empty()) return false;
-      size_t have = 0;
-      while (!q.empty() && g.size() < maxBatches && (g.empty() || have < want)) { have += q.front().bases(); g.emplace_back(std::move(q.front())); q.pop_front(); }
-      lk.unlock(); cvFull.notify_all();
-      return true;
-    }
-    // every queued batch in order (only the consumer removes elements: what fn sees stays put until the consumer's next get)
-    template <class F> void forEach(F fn) { std::lock_guard<std::mutex> lk(mu); for (auto& b : q) fn(b); }
-  };
+  typedef mmhost::BatchChannel<Batch> Channel;     // hand-over between two stages (pass_plan.hpp)
 
  public:
   Map(const skch::Parameters& p, const skch::Sketch& refsketch, PostProcessResultsFn_t f = nullptr)
@@ -306,10 +274,7 @@ class Map {
       std::vector<Batch> grp;
       uint64_t doneBases = 0;
       while (true) {
-        size_t want = std::min<uint64_t>(plan.passBases, std::max<uint64_t>(batchBases, doneBases));
-        if (plan.inputKnown && plan.inputBytes > doneBases) want = (size_t)std::min<uint64_t>(want, std::max<uint64_t>(batchBases, (plan.inputBytes - doneBases) / 3));
-        want -= want / 16;                                  // (a batch is a hair under MASHMAP_HIP_BATCH_MBP: the parser cuts at a record boundary)
-        if (maxGroup == 1) want = 0;
+        const size_t want = maxGroup == 1 ? 0 : mmhost::passWant(batchBases, plan.passBases, plan.inputKnown, plan.inputBytes, doneBases);
         if (!parsed.getGroup(grp, want, maxGroup)) break;
         deviceStage(grp, parsed);
         for (auto& b : grp) { doneBases += b.bases(); mapped.put(std::move(b)); }
