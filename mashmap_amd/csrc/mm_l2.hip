@@ -1007,7 +1007,17 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt, bool steady) {
   int64_t maxChunkOps = totalOps;
   if (steady) chunks.push_back(Chunk{0, nC, 0});                           // one chunk: the streams must fit the buffer as it is (k_l2_locate flags it otherwise)
   else {
-    int64_t budget = (int64_t)24 << 28;                                    // in 4-byte entries
+    int64_t budget = (int64_t)24 << 28;                                    // in 4-byte entries: 24 GiB ...
+    {
+      // ... or half of the device memory that is free (counting what the stream buffer already holds), up to 128 GiB: on a 288 GB part the
+      // streams of a configs[4] batch (57 GB: 2.7 M candidates at s = 498) then stay in one chunk, and the passes behind this one are
+      // steady-state passes instead of being sized, chunk by chunk, every time
+      size_t freeB = 0, totalB = 0;
+      if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
+        const size_t half = (freeB + c->dL2Ops.bytes) / 2;
+        budget = std::max<int64_t>(budget, (int64_t)(std::min<size_t>(half, (size_t)128 << 30) / 4));
+      }
+    }
     if (const char* e = getenv("MM_L2_STREAM_MIB")) { const double v = atof(e); if (v > 0) budget = (int64_t)(v * 262144.0); }
     if (totalOps <= budget || nC <= 1) chunks.push_back(Chunk{0, nC, 0});
     else {

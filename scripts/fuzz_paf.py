@@ -12,7 +12,7 @@ seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 bad = 0
 td = tempfile.mkdtemp()
 for it in range(n_iter):
-    r = U.splitmix64(seed0 * 104729 + it, 28)
+    r = U.splitmix64(seed0 * 104729 + it, 32)
     pick = lambda i, xs: xs[int(r[i] % np.uint64(len(xs)))]
     L = pick(0, [1000, 2000, 5000, 5000, 10000])
     nct = pick(1, [1, 2, 4])
@@ -21,6 +21,10 @@ for it in range(n_iter):
         blk = U.mutate(cs[0][:6 * L], 11, 0.03); cs[1][L:L + len(blk)] = blk[:len(cs[1]) - L]
     if pick(7, [0, 0, 1]):
         cs[0] = U.with_n_runs(cs[0], it, 3, L // 2)
+    if pick(24, [0, 0, 1]):                                 # a repeat family: reads out of it bring more interval points than the fused lookup holds (HBM point path, k_filter_points)
+        unit = cs[-1][L:3 * L].copy()
+        fam = np.concatenate([U.mutate(unit, 500 + j, 0.02) for j in range(int(pick(25, [6, 10, 16])))])
+        cs[0] = np.concatenate([cs[0], fam])
     allvsall = pick(8, [0, 0, 0, 1])
     if allvsall:
         names = ["S%d#1#c%d" % (i % 2, i) for i in range(nct)]
@@ -50,6 +54,8 @@ for it in range(n_iter):
     for tag, exe in (("hip", HIP), ("ref", U.REF_BIN)):
         env = dict(os.environ)
         if tag == "hip" and shard: env["MASHMAP_HIP_DEVICES"] = shard; env["MASHMAP_HIP_BATCH_MBP"] = pick(20, ["512", "0.04", "0.2"])
+        if tag == "hip" and not shard:                       # one context: small reader batches, several of them per device pass (or none: COALESCE 0)
+            env["MASHMAP_HIP_BATCH_MBP"] = pick(26, ["512", "0.03", "0.1", "0.01"]); env["MASHMAP_HIP_COALESCE_MBP"] = pick(27, ["2048", "0", "0.25", "1"])
         if tag == "hip" and pick(23, [0, 0, 1]): env["MM_SEED_TAGS"] = "1"                       # the human-scale seed table layout forced onto the small index
         if tag == "hip" and pick(23, [0, 1, 0]): env["MASHMAP_HIP_ASCII_UPLOAD"] = "1"           # the ASCII upload path instead of the packing parser
         p = subprocess.run([exe] + base + ["-o", os.path.join(td, tag + ".paf")], capture_output=True, text=True, env=env)

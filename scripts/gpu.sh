@@ -9,6 +9,7 @@
 #   trace:WL         rocprofv3 --kernel-trace --stats of two passes of WL      -> kernel_stats_WL.csv
 #   pmc:WL           FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU passes of WL (one rocprofv3 run each) -> pmc_WL_*.csv (scripts/pmc_summary.py reduces them)
 #   e2e              FASTA -> PAF through the mashmap_hip command line only (bench.py's e2e leg)
+#   fuzz:N           N random command lines through mashmap_hip and the stock binary, PAF bytes compared (MM_FUZZ_SEED)
 #   nosplit          --noSplit on 30 kbp reads through both command lines: same PAF, both times
 #   large            --dense -s 100000 (sketchSize 9 998) and k = 40 / 57 through mashmap_hip and the stock binary, with the stage log
 # Environment variables given on the command line reach every step (A/B switches: MM_*, MASHMAP_HIP_*); MM_BENCH_EXTRA: extra bench.py
@@ -78,6 +79,9 @@ large)
 nosplit)
   say "== --noSplit, 30 kbp reads, both command lines (scripts/nosplit_paf.py)"
   timeout 900 python scripts/nosplit_paf.py 2>&1 | tail -8 | tee -a $OUT/log.txt ;;
+fuzz:*)
+  say "== PAF fuzz, ${S#fuzz:} random command lines through both programs (scripts/fuzz_paf.py)"
+  timeout 1500 python scripts/fuzz_paf.py ${S#fuzz:} ${MM_FUZZ_SEED:-5} > $OUT/fuzz_paf.txt 2>&1; grep -c "^ok" $OUT/fuzz_paf.txt | tee -a $OUT/log.txt; grep -A6 "^FAIL" $OUT/fuzz_paf.txt | head -40 | tee -a $OUT/log.txt; tail -1 $OUT/fuzz_paf.txt | tee -a $OUT/log.txt ;;
 *) say "unknown step $S" ;;
 esac
 done
