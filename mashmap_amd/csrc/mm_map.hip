@@ -456,7 +456,17 @@ k_lookup_l1(int nFrags, int s, const DFrag* __restrict__ frags,
           if (c > 1) k1 = ptKeys[src[u] + 1];
           if (c > 0) put(my, k0);
           if (c > 1) put(my + 1, k1);
-          for (int j = 2; j < c; j++) put(my + j, ptKeys[src[u] + j]);
+          // the rest of a short run by the lane that owns the seed, of a long one (a seed of a repeat family: up to hundreds of points
+          // that still fit the fused list) by the whole wave, as in mm_gather_points
+          const bool longRun = c > 8;
+          if (!longRun) for (int j = 2; j < c; j++) put(my + j, ptKeys[src[u] + j]);
+          uint64_t mLong = mm_ballot(longRun);
+          while (mLong) {
+            const int l = (int)__builtin_ctzll(mLong); mLong &= mLong - 1ull;
+            const int cL = __shfl(c, l), myL = __shfl(my, l);
+            const uint64_t srcL = ((uint64_t)(uint32_t)__shfl((int)(src[u] >> 32), l) << 32) | (uint32_t)__shfl((int)(uint32_t)src[u], l);
+            for (int j = 2 + lane; j < cL; j += 64) put(myL + j, ptKeys[srcL + j]);
+          }
           done += mm_wave_sum(c);
         }
       }
