@@ -368,6 +368,28 @@ __device__ __forceinline__ void mm_probe4(const SeedTable& T, const uint64_t* __
     }
   }
 }
+// the long point runs of one probing sub-round of the fused kernel (lanes in mLong own a seed with more than 8 points), copied by the whole
+// wave into the fragment's LDS list from their third point on; returns this lane's count of points that passed the seqId filters.  Not
+// inlined: inside k_lookup_l1 the loop cost the uniform north_star workload 1.5 ms of registers and code layout (profiles/NOTES.md, round 5)
+__device__ __noinline__ int mm_fused_long_runs(uint64_t mLong, int c, int my, uint64_t src, uint64_t* __restrict__ dst, const uint64_t* __restrict__ ptKeys,
+                                               int self, int seqCounter, int skipSelf, int lowerTri, int lane) {
+  int nValid = 0;
+  while (mLong) {
+    const int l = (int)__builtin_ctzll(mLong); mLong &= mLong - 1ull;
+    const int cL = __shfl(c, l), myL = __shfl(my, l);
+    const uint64_t srcL = ((uint64_t)(uint32_t)__shfl((int)(src >> 32), l) << 32) | (uint32_t)__shfl((int)(uint32_t)src, l);
+    for (int j = 2 + lane; j < cL; j += 64) {
+      uint64_t key = ptKeys[srcL + j];
+      const int seqId = (int)(key >> 33);
+      bool drop = false;
+      if (skipSelf && seqId == self) drop = true;
+      if (lowerTri && !(seqCounter > seqId)) drop = true;
+      if (drop) key = MM_EMPTY; else nValid++;
+      dst[myL + j] = key;
+    }
+  }
+  return nValid;
+}
 #define MM_LOOKUP_WPB 4             // waves (= fragments) per workgroup
 #define MM_L1_REGIONS 64            // L1 output cursors: a same-address atomic costs ~10 ns, so fragments spread over 64 of them
 #define MM_L1_CURSOR_STRIDE 32      // u64 words between cursors (256 bytes)
@@ -460,13 +482,8 @@ k_lookup_l1(int nFrags, int s, const DFrag* __restrict__ frags,
           // that still fit the fused list) by the whole wave, as in mm_gather_points
           const bool longRun = c > 8;
           if (!longRun) for (int j = 2; j < c; j++) put(my + j, ptKeys[src[u] + j]);
-          uint64_t mLong = mm_ballot(longRun);
-          while (mLong) {
-            const int l = (int)__builtin_ctzll(mLong); mLong &= mLong - 1ull;
-            const int cL = __shfl(c, l), myL = __shfl(my, l);
-            const uint64_t srcL = ((uint64_t)(uint32_t)__shfl((int)(src[u] >> 32), l) << 32) | (uint32_t)__shfl((int)(uint32_t)src[u], l);
-            for (int j = 2 + lane; j < cL; j += 64) put(myL + j, ptKeys[srcL + j]);
-          }
+          const uint64_t mLong = mm_ballot(longRun);
+          if (mLong) nValid += mm_fused_long_runs(mLong, c, my, src[u], sc.a, ptKeys, self, seqCounter, fl.skipSelf, fl.lowerTri, lane);   // (out of line: the hot path keeps its registers)
           done += mm_wave_sum(c);
         }
       }
