@@ -8,6 +8,7 @@
 #include <string>
 #include <thread>
 #include "../../mashmap_amd/host/pass_plan.hpp"
+#include "../../mashmap_amd/host/skch_types.hpp"
 
 struct Item { size_t id; size_t n; size_t bases() const { return n; } };
 
@@ -57,7 +58,24 @@ static int scenario(const char* name, size_t items, size_t batchBases, size_t pa
   return bad ? 1 : 0;
 }
 
-int main() {
+// skch::queryBatchPlan (skch_types.hpp): batch / pass sizes and page-locked buffers for a query file of `bytes` bytes under the given
+// environment; prints what it decided
+static int plan_check(const char* path) {
+  auto show = [&](const char* what, size_t ctxs) {
+    const skch::QueryBatchPlan q = skch::queryBatchPlan({path}, ctxs);
+    printf("plan %s ctxs %zu batch %zu pass %zu buffers %zu bufferBytes %zu known %d\n", what, ctxs, q.batchBases, q.passBases, q.buffers, q.bufferBytes, (int)q.inputKnown);
+  };
+  show("default", 1); show("default", 2);
+  setenv("MASHMAP_HIP_COALESCE_MBP", "0", 1); show("coalesce0", 1);
+  setenv("MASHMAP_HIP_COALESCE_MBP", "4096", 1); setenv("MASHMAP_HIP_BATCH_MBP", "256", 1); show("b256c4096", 1);
+  setenv("MASHMAP_HIP_BATCH_MBP", "0.01", 1); setenv("MASHMAP_HIP_COALESCE_MBP", "2048", 1); show("tiny", 1);
+  unsetenv("MASHMAP_HIP_BATCH_MBP"); unsetenv("MASHMAP_HIP_COALESCE_MBP");
+  setenv("MASHMAP_HIP_ASCII_UPLOAD", "1", 1); show("ascii", 1); unsetenv("MASHMAP_HIP_ASCII_UPLOAD");
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  if (argc == 3 && std::string(argv[1]) == "plan") return plan_check(argv[2]);
   int rc = 0;
   // a fast producer (the device is the bottleneck): the ramp 1, 1, 2, 4, 4 ... and down again when the size is known
   rc |= scenario("fast-producer-known", 20, 512, 2048, true, 4, 0, 300, 1);
