@@ -15,7 +15,7 @@
 // The reference runs one pthread task per read (ThreadPool.hpp); here three stages run concurrently on successive batches
 // (MASHMAP_HIP_BATCH_MBP, default 512 Mbp): the reader thread parses batch i+2, the device stage maps batch i+1, the post stage
 // chains / filters / prints batch i on param.threads std::threads.  Output order == input order (ThreadPool.hpp:187-211).
-// A device PASS covers as many parsed batches as it takes to fill the GPU (MASHMAP_HIP_COALESCE_MBP, default 2048 Mbp; the kernels of a
+// A device PASS covers as many parsed batches as it takes to fill the GPU (MASHMAP_HIP_COALESCE_MBP, default 3072 Mbp; the kernels of a
 // 512 Mbp pass run at ~120 Gbp/s, those of a 2 Gbp pass at ~150): the batches of a pass are laid end to end in HBM by
 // mm_reads_upload_packed_parts, each from its own page-locked buffer, so the reader's unit (and the memory it locks) stays small.  The
 // pass size ramps up from one batch (1, 1, 2, 4, 4 ...: the pipeline fills at once) and, when the input size is known, down again at the

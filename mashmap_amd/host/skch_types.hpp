@@ -238,9 +238,10 @@ class PinnedRecs {
 
 // How skch::Map takes the query files through the GPUs.  The reader's unit is a BATCH: MASHMAP_HIP_BATCH_MBP (default 512 Mbp) PER GPU
 // CONTEXT, parsed and packed into one page-locked buffer -- small, so that locking its pages is cheap and the three stages overlap from
-// the first few milliseconds on.  The device's unit is a PASS: up to MASHMAP_HIP_COALESCE_MBP (default 2048 Mbp per context; 0 = one batch
+// the first few milliseconds on.  The device's unit is a PASS: up to MASHMAP_HIP_COALESCE_MBP (default 3072 Mbp per context; 0 = one batch
 // per pass) of consecutive batches laid end to end in HBM (mm_reads_upload_packed_parts) -- the kernels of a 512 Mbp pass leave a third
-// of the GPU idle (1.5 waves per SIMD in the lane-per-candidate sweep), those of a 2 Gbp pass do not.  Page-locked buffers: a buffer is
+// of the GPU idle (1.5 waves per SIMD in the lane-per-candidate sweep); measured inside the command line a 2 Gbp pass runs at 138-142 Gbp/s
+// (every kernel's tail and launch is paid once per pass), a 3 Gbp pass at ~145.  Page-locked buffers: a buffer is
 // busy from the reader's first byte until its batch's upload has completed (the post stage works on the records, not on the bases):
 // one being parsed + a pass's worth queued + a pass's worth uploading, but no more than the input needs, each no larger than the input.
 struct QueryBatchPlan { size_t batchBases; size_t passBases; size_t bufferBytes; size_t buffers; uint64_t inputBytes; bool inputKnown; };
@@ -252,7 +253,7 @@ inline QueryBatchPlan queryBatchPlan(const std::vector<std::string>& queryFiles,
   QueryBatchPlan q;
   q.batchBases = (size_t)((be ? atof(be) : 512.0) * 1e6) * nCtx;
   if (q.batchBases < 1) q.batchBases = 1;
-  q.passBases = std::max(q.batchBases, (size_t)((ce ? atof(ce) : 2048.0) * 1e6) * nCtx);
+  q.passBases = std::max(q.batchBases, (size_t)((ce ? atof(ce) : 3072.0) * 1e6) * nCtx);
   if (nCtx > 1 || !packed) q.passBases = q.batchBases;               // (several batches per pass: one context, packed uploads -- skch_map.hpp)
   q.passBases = std::min(q.passBases, q.batchBases * 64);            // at most 64 batches per pass, whatever the two variables say
   const size_t perPass = q.passBases / q.batchBases;

@@ -21,7 +21,7 @@ def test_pass_grouping_under_random_timing(tmp_path):
 
 
 def test_query_batch_plan(tmp_path):
-    """skch::queryBatchPlan: 512 Mbp batches and 2 048 Mbp passes per context by default, one batch per pass with several contexts, ASCII
+    """skch::queryBatchPlan: 512 Mbp batches and 3 072 Mbp passes per context by default, one batch per pass with several contexts, ASCII
     uploads or MASHMAP_HIP_COALESCE_MBP=0; at most 64 batches per pass; page-locked buffers for one pass queued + one uploading + the
     reader's, never more than the input needs"""
     exe = str(tmp_path / "pass_check")
@@ -36,7 +36,7 @@ def test_query_batch_plan(tmp_path):
         f = l.split()
         rows[(f[1], int(f[3]))] = dict(batch=int(f[5]), pas=int(f[7]), buffers=int(f[9]), bufferBytes=int(f[11]), known=int(f[13]))
     d = rows[("default", 1)]
-    assert d["batch"] == 512_000_000 and d["pas"] == 2_048_000_000 and d["buffers"] == 10 and d["known"] == 1
+    assert d["batch"] == 512_000_000 and d["pas"] == 3_072_000_000 and d["buffers"] == 14 and d["known"] == 1
     assert 0.375 * 512e6 < d["bufferBytes"] < 0.45 * 512e6            # packed: 3/8 byte per base + slack
     d2 = rows[("default", 2)]
     assert d2["batch"] == 1_024_000_000 and d2["pas"] == d2["batch"] and d2["buffers"] == 8
