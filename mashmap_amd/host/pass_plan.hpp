@@ -54,11 +54,12 @@ class BatchChannel {
 
 // Bases the next device pass should hold, given what has been mapped so far: one batch at first (the post stage has work after one
 // batch's worth of time), doubling up to `passBases` (1, 1, 2, 4, 4 ... batches), and, when the input's size is known, down again
-// towards its end (the last pass and its post stage are what the run waits for with nothing left to overlap them).  A sixteenth is
+// towards its end (a pass takes at most half of what is left: the last pass and its post stage are what the run waits for with nothing
+// left to overlap them).  A sixteenth is
 // taken off: a batch is a hair under `batchBases`, the parser cuts at a record boundary.
 inline size_t passWant(size_t batchBases, size_t passBases, bool inputKnown, uint64_t inputBytes, uint64_t doneBases) {
   uint64_t want = std::min<uint64_t>(passBases, std::max<uint64_t>(batchBases, doneBases));
-  if (inputKnown && inputBytes > doneBases) want = std::min<uint64_t>(want, std::max<uint64_t>(batchBases, (inputBytes - doneBases) / 3));
+  if (inputKnown && inputBytes > doneBases) want = std::min<uint64_t>(want, std::max<uint64_t>(batchBases, (inputBytes - doneBases) / 2));
   return (size_t)(want - want / 16);
 }
 
