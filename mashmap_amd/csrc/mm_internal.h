@@ -133,6 +133,7 @@ struct mm_ctx {
   DevBuf dGatherSrc; hipStream_t commStream = nullptr; std::thread gatherThread; int gatherRc = 0; std::string gatherErr;
   std::vector<DevBuf*> allBufs();
   DevBuf dL2Info, dL2Cnt, dL2Off, dL2Ops, dScanTmp, dL2Tmp, dL2Wide, dL2Exact, dL2Cells, dListB, dListC, dBigList;     // L2 staging: per-candidate stream extents, op counts/offsets, located ops
+  DevBuf dL2InitCells, dL2InitState;                                 // per candidate of a chunk: the SlideMapper state after the pre-load, as k_l2_locate leaves it for the sweeps
   DevBuf dL2Sort[4], dL2Order, dL2OrderPos;                          // candidates of a chunk in order of descending stream length (mm_order_desc)
   bool sketched = false, mapped = false;
   // steady state: the previous pass of this context went through and left every buffer sized (mm_launch_map); what it saw

@@ -36,6 +36,15 @@ struct L2Info { int64_t e0; int32_t nPre; int32_t nAll;         // slice [e0, e0
                 int32_t nOpen; int64_t open0;                   // records open at the block boundary before rangeStart: op*[open0, open0+nOpen)
                 int32_t target; int32_t pad; };                 // pre-load takes records with wpos >= target = rangeStart - segLength - 1 (:1290)
 struct L2Tmp { int32_t start, end, shared, strand; };
+// The SlideMapper state of a candidate once the pre-load (computeMap.hpp:1323-1338: the records still open at rangeStart) is in, in closed
+// form.  With inserts only the state does not depend on their order -- cell counts add up, the pivot is the largest p with
+// p + #{reference-only hashes below q[p]} <= S (slidingMap.hpp:155-160 keeps exactly that), shared / votes are sums over the active cells
+// up to it -- so k_l2_locate, which has the candidate's sketch in LDS anyway, builds it in parallel instead of writing ~s pre-load entries
+// that the sweep then applies one by one (a fifth to a third of a stream).  Cells: 16 bit each, count (12) | active << 12 | (vote + 1) << 13
+// = the wide sweep's cell format; row of s + 2 cells per candidate of a chunk.  flags: 1 = a query hash was open twice in the pre-load (the
+// 2-bit vote cannot hold it: k_l2_sweep_exact replays the pre-load from the index), 2 = a count beyond 12 bits (likewise).
+struct L2Init { int32_t pivot, pivRank, shared, votes; };
+#define L2INIT_FLAG_SHIFT 24        // flags travel in the top byte of `pivot` (pivot <= 8190)
 
 // stream entry (uint32), JB = width of the sketch-position field (11 for sketches of up to 2046 entries, 13 beyond):
 //   bits 0..JB-1        1-based position j of the hash in the query sketch (0: beyond the sketch -> no effect on the state)
@@ -95,7 +104,8 @@ k_l2_extents(int nCand, int segLength, int deltaBits, const mm_l1_candidate* __r
   info[c] = o;
   // upper bound of the stream: every event, the end marker, one skip per 2^deltaBits of range, slack for the end marker's own skips
   // (the record behind the last insert may be anywhere in the contig: up to 2^31 / 2^27 of them)
-  const int n = o.nAll + o.nOpen + 1 + ((cand.rangeEndPos - cand.rangeStartPos) >> deltaBits) + 20;
+  // (the pre-load is not part of the stream: it reaches the sweeps as a ready-made state, L2Init)
+  const int n = (o.nAll - o.nPre) + 1 + ((cand.rangeEndPos - cand.rangeStartPos) >> deltaBits) + 20;
   cnt[c] = (n + E_STEP - 1) & ~(E_STEP - 1);
 }
 
@@ -181,7 +191,7 @@ k_l2_pos_keys(int c0, int n, int shift, const L2Info* __restrict__ info, uint32_
 // plus a walk of ~1 entry (the hashes of a sketch are uniform, so equal-width buckets are balanced).
 // LDS of one wave of k_l2_locate: sketch + sentinel (8 B each), their high words (4 B), NB + 1 bucket starts (2 B), strands (1 B)
 __host__ __device__ static inline size_t mm_locate_lds_per_wave(int s, int NB) {
-  const size_t b = (size_t)(s + 1) * 8 + (size_t)(s + 2) / 2 * 8 + (size_t)(NB + 4) * 2 + (((size_t)s + 15) & ~(size_t)15);
+  const size_t b = (size_t)(s + 1) * 8 + (size_t)(s + 2) / 2 * 8 + (size_t)(NB + 4) * 2 + (((size_t)s + 15) & ~(size_t)15) + (((size_t)(s + 4) / 2 * 4 + 15) & ~(size_t)15);
   return (b + 15) & ~(size_t)15;
 }
 // ---------------------------------------------------------------------------------------------
@@ -195,7 +205,7 @@ k_l2_locate(int cBase, int nCand, int64_t opsBase, int s, int NB, const mm_l1_ca
             const int64_t* __restrict__ contigOff, const L2Info* __restrict__ info, const int64_t* __restrict__ opOff,
             const int32_t* __restrict__ opCnt, uint32_t* __restrict__ ops, const int32_t* __restrict__ order /* candidates in reference order, or null */,
             unsigned long long* __restrict__ counters /* [6] |= 4: a stream outgrew its reservation */,
-            const unsigned long long* __restrict__ nDev) {
+            const unsigned long long* __restrict__ nDev, uint16_t* __restrict__ initCells, L2Init* __restrict__ initState, int initStride) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;   // (readfirstlane: the candidate's extents then live in scalar registers)
   unsigned char* base = smem + (size_t)wave * mm_locate_lds_per_wave(s, NB);
@@ -203,6 +213,7 @@ k_l2_locate(int cBase, int nCand, int64_t opsBase, int s, int NB, const mm_l1_ca
   uint32_t* qhi = (uint32_t*)(base + (size_t)(s + 1) * 8);         // its high words (the bucket walk compares these)
   uint16_t* bkt = (uint16_t*)(base + (size_t)(s + 1) * 8 + (size_t)(s + 2) / 2 * 8);   // bkt[b] = #query hashes whose bucket is < b, b = 0..NB
   int8_t* qs = (int8_t*)(base + (size_t)(s + 1) * 8 + (size_t)(s + 2) / 2 * 8 + (size_t)(NB + 4) * 2);
+  uint32_t* ic = (uint32_t*)(base + (size_t)(s + 1) * 8 + (size_t)(s + 2) / 2 * 8 + (size_t)(NB + 4) * 2 + (((size_t)s + 15) & ~(size_t)15));   // pre-load state: two 16-bit cells per dword
   const int wpb = (int)(blockDim.x >> 6);                          // waves per workgroup: 4, fewer when a sketch's LDS share is large
   if (nDev) { const int nd = (int)*nDev - cBase; if (nd < nCand) nCand = nd; }   // steady state: the count stayed on the device (k_l2_gate has zeroed it if the streams do not fit)
   for (int ci = blockIdx.x * wpb + wave; ci < nCand; ci += gridDim.x * wpb) {
@@ -244,6 +255,10 @@ k_l2_locate(int cBase, int nCand, int64_t opsBase, int s, int NB, const mm_l1_ca
     const int8_t* srcS = (raw ? skStrand : qStrand) + (size_t)f * s;
     for (int p = lane; p < S; p += 64) { const uint64_t h = srcH[p]; q[p] = h; qhi[p] = (uint32_t)(h >> 32); qs[p] = srcS[p]; }
     if (lane == 0) { q[S] = ~0ull; qhi[S] = ~0u; }                 // sentinel: a walk for h <= qmax needs no end test
+    for (int d = lane; d <= (S + 1) / 2; d += 64) {                // cells 0 and S + 1: empty; 1 .. S: count 1, inactive, vote 0 (SlideMapper::init, slidingMap.hpp:103-121)
+      const int p0 = 2 * d, p1 = 2 * d + 1;
+      ic[d] = ((p0 >= 1 && p0 <= S) ? 0x2001u : 0u) | (((p1 >= 1 && p1 <= S) ? 0x2001u : 0u) << 16);
+    }
     __threadfence_block();
     const uint64_t qmax = q[S - 1];
     // bucket(h): monotone map of [0, qmax] onto 0..NB-1: the top 24 significant bits times M >> 32, M <= 2^32 * NB / (top24(qmax) + 1)
@@ -303,6 +318,7 @@ k_l2_locate(int cBase, int nCand, int64_t opsBase, int s, int NB, const mm_l1_ca
       }
     }
     int outN = 0;                                                  // entries written so far (wave-uniform)
+    uint32_t preFlags = 0;
     int posAcc = cand.rangeStartPos;                               // running position of the delta code (wave-uniform)
     bool tooWide = false;
     const int nEv = lastRel + 1;                                   // events [0, nEv) of the slice are streamed
@@ -328,14 +344,27 @@ k_l2_locate(int cBase, int nCand, int64_t opsBase, int s, int NB, const mm_l1_ca
         if (isIns && (aux >> 31)) op = (op & ~(3u << EF<JB>::VOTE_SHIFT)) | ((2u - ((op >> EF<JB>::VOTE_SHIFT) & 3u)) << EF<JB>::VOTE_SHIFT);
         op |= 1u << (!slide ? E_PRE_BIT : (isIns ? E_INS_BIT : E_DEL_BIT));
       }
-      const uint64_t mKeep = mm_ballot(keep);
-      if (!slide) {                                                  // before rangeStart nothing is evaluated: no position code
-        asm volatile("" : "+v"(nKey), "+v"(nAux), "+v"(nHash));      // (the next chunk's reads are waited for here, ahead of this chunk's writes)
-        const int at = outN + (int)mm_popc_below(mKeep);
-        if (keep) { if (at < cap) out[at] = op; else tooWide = true; }
-        outN += __popcll(mKeep);
+      if (!slide) {
+        // the pre-load (records still open at rangeStart) goes into the cell state, not into the stream: a reference-only hash raises the
+        // count of the cell it falls before, a matching one activates its cell with its vote (LDS atomics: the lanes of a chunk hit
+        // arbitrary cells; two cells share a dword)
+        asm volatile("" : "+v"(nKey), "+v"(nAux), "+v"(nHash));      // (the next chunk's reads are waited for here)
+        const uint32_t j = op & EF<JB>::JMASK;
+        if (keep && j) {
+          const uint32_t sh = (j & 1u) * 16u;
+          uint32_t* w = ic + (j >> 1);
+          if (op & (1u << EF<JB>::MATCH_BIT)) {
+            const uint32_t old = atomicOr(w, 0x1000u << sh);
+            if ((old >> sh) & 0x1000u) preFlags |= 1u;               // open twice: only the exact kernel can follow that
+            else atomicXor(w, ((1u ^ ((op >> EF<JB>::VOTE_SHIFT) & 3u)) << 13) << sh);   // vote + 1: from 1 (vote 0) to this record's
+          } else {
+            const uint32_t old = atomicAdd(w, 1u << sh);
+            if (((old >> sh) & 0xFFFu) >= 4094u) preFlags |= 2u;     // (beyond 12 bits)
+          }
+        }
         continue;
       }
+      const uint64_t mKeep = mm_ballot(keep);
       // delta against the previous evaluated insert (lower lanes of this chunk, else the carry)
       const uint64_t mIns = mm_ballot(evalIns);
       int prevPos = posAcc;
@@ -390,6 +419,31 @@ k_l2_locate(int cBase, int nCand, int64_t opsBase, int s, int NB, const mm_l1_ca
       else tooWide = true;                                         // cannot happen: the reservation covers every event + skips
     }
     if (mm_ballot(tooWide) && lane == 0) atomicOr(&counters[6], 4ull);
+    // ---- the state after the pre-load, in closed form (see L2Init): pivot = number of cells p with count(1) + .. + count(p) <= S (the sums
+    // grow with p), pivRank = that sum at the pivot, shared / votes over the active cells up to it
+    __threadfence_block();
+    {
+      int carry = 0, pivot = 0, pivRank = 0, shared = 0, votes = 0;
+      for (int p0 = 1; p0 <= S; p0 += 64) {
+        const int p = p0 + lane;
+        const uint32_t w = p <= S ? (ic[p >> 1] >> ((p & 1) * 16)) & 0xFFFFu : 0u;
+        const int cnt = (int)(w & 0xFFFu);
+        const int incl = carry + mm_wave_excl_scan(cnt) + cnt;
+        const bool ok = p <= S && incl <= S;
+        const uint64_t m = mm_ballot(ok);
+        if (m) { pivot += (int)__popcll(m); pivRank = __shfl(incl, 63 - (int)__builtin_clzll(m)); }
+        const bool act = ok && (w & 0x1000u);
+        shared += (int)__popcll(mm_ballot(act));
+        votes += mm_wave_sum(act ? (int)((w >> 13) & 3u) - 1 : 0);
+        carry = __shfl(incl, 63);
+      }
+      const uint64_t fl = mm_ballot(preFlags != 0);
+      uint32_t flags = 0;
+      if (fl) flags = (mm_ballot((preFlags & 1u) != 0) ? 1u : 0u) | (mm_ballot((preFlags & 2u) != 0) ? 2u : 0u);
+      uint16_t* row = initCells + (size_t)(c - cBase) * (size_t)initStride;
+      for (int p = lane; p < S + 2; p += 64) row[p] = (uint16_t)((ic[p >> 1] >> ((p & 1) * 16)) & 0xFFFFu);
+      if (lane == 0) initState[c - cBase] = L2Init{pivot | (int32_t)(flags << L2INIT_FLAG_SHIFT), pivRank, shared, votes};
+    }
   }
 }
 
@@ -418,7 +472,8 @@ k_l2_sweep(int cBase, int nCand, int64_t opsBase, const int32_t* __restrict__ ca
            const int64_t* __restrict__ l1Off, L2Tmp* __restrict__ tmp, int locap, mm_l2_locus* __restrict__ l2, unsigned long long l2Cap,
            int32_t* __restrict__ wideList, int32_t* __restrict__ exactList, int64_t* __restrict__ l2First, int32_t* __restrict__ l2Num,
            unsigned long long* __restrict__ counters /* [0] candidates queued for the exact pass, [4] l2 cursor, [5] overflow, [6] flags, [7] queued for the wide pass */,
-           const unsigned long long* __restrict__ nDev /* non-null: the number of candidates (minus cBase) or of list entries lives there */, int listCap) {
+           const unsigned long long* __restrict__ nDev /* non-null: the number of candidates (minus cBase) or of list entries lives there */, int listCap,
+           const uint16_t* __restrict__ initCells, const L2Init* __restrict__ initState, int initStride, int initBase /* rows of the chunk: candidate - initBase */) {
   typedef typename std::conditional<WIDE, uint16_t, uint8_t>::type CellT;
   constexpr int CB = WIDE ? 12 : 5;
   constexpr uint32_t CMASK = (1u << CB) - 1u;
@@ -434,19 +489,51 @@ k_l2_sweep(int cBase, int nCand, int64_t opsBase, const int32_t* __restrict__ ca
     if (listCap && nd > listCap && li == 0) atomicOr(&counters[6], 16ull);   // more listed candidates than this launch covers: the pass is redone with the host's sizing
     nCand = (int)(nd < (listCap ? listCap : nCand) ? nd : (listCap ? listCap : nCand));
   }
-  if (lane >= LPW || li >= nCand) return;
-  const int cIdx = candList ? candList[li] : cBase + li;   // candidates [cBase, cBase + nCand), or the listed ones (absolute indices); ops holds the streams from opsBase on
-  const mm_l1_candidate cand = l1[cIdx];
-  const int f = cand.frag;
-  const int S = stats[f].sketchSize;
+  const bool live = lane < LPW && li < nCand;          // (the other lanes of the wave only help with the initial state)
+  int cIdx = 0, S = 0, f = 0;
+  mm_l1_candidate cand{0, 0, 0, 0, 0};
+  if (live) {
+    cIdx = candList ? candList[li] : cBase + li;       // candidates [cBase, cBase + nCand), or the listed ones (absolute indices); ops holds the streams from opsBase on
+    cand = l1[cIdx]; f = cand.frag; S = stats[f].sketchSize;
+  }
+  auto lbaseOf = [](int l) -> int { return WIDE && LPW == 64 ? (l & 31) * 2 + (l >> 5) : l; };
+  const int lbase = lbaseOf(lane);
+#define CELL(p) cell[(p) * LPW + lbase]
+  // The state after the pre-load comes ready-made from k_l2_locate (L2Init): every candidate's row of s + 2 16-bit cells is read by the whole
+  // wave, 64 consecutive cells at a time, into that candidate's column of the LDS block; a count the 8-bit cells cannot hold flags the
+  // candidate for the 16-bit re-run, as an insert into a full cell would have
+  int cntOverflow = 0, doubleOpen = 0;
+  {
+    uint64_t rows = __ballot(live), over = 0;
+    while (rows) {
+      const int r = (int)__builtin_ctzll(rows); rows &= rows - 1ull;
+      const int cR = __shfl(cIdx, r), sR = __shfl(S, r);
+      const uint16_t* row = initCells + (size_t)(cR - initBase) * (size_t)initStride;
+      const int lb = lbaseOf(r);
+      bool tooBig = false;
+      for (int p = (int)threadIdx.x; p < sR + 2; p += 64) {
+        const uint32_t w = row[p];
+        if (WIDE) cell[p * LPW + lb] = (CellT)w;
+        else {
+          const uint32_t cnt = w & 0xFFFu;
+          tooBig |= cnt > CMASK;
+          cell[p * LPW + lb] = (CellT)((cnt & CMASK) | (((w >> 12) & 1u) << CB) | (((w >> 13) & 3u) << (CB + 1)));
+        }
+      }
+      if (__ballot(tooBig)) over |= 1ull << r;
+    }
+    __threadfence_block();
+    if (!live) return;
+    if ((over >> lane) & 1ull) cntOverflow = -1;
+  }
+  const L2Init ist = initState[cIdx - initBase];
+  const int iflags = (int)((uint32_t)ist.pivot >> L2INIT_FLAG_SHIFT);
+  if (iflags & 1) doubleOpen = -1;                     // a query hash open twice in the pre-load: k_l2_sweep_exact
+  if (iflags & 2) cntOverflow = -1;                    // a count beyond 12 bits: likewise (through the 16-bit re-run's own overflow)
   const uint4* src = (const uint4*)(ops + (opOff[cIdx] - opsBase));
   const int nSteps = opCnt[cIdx] / E_STEP;             // 16 entries = 4 x 16 bytes per step
   int posAcc = cand.rangeStartPos;                     // running position of the delta code
-  const int lbase = WIDE && LPW == 64 ? (lane & 31) * 2 + (lane >> 5) : lane;
-#define CELL(p) cell[(p) * LPW + lbase]
-  CELL(0) = 0; CELL(S + 1) = 0;
-  for (int p = 1; p <= S; p++) CELL(p) = (CellT)(1u | (1u << (CB + 1)));       // num_before_inc = 1, inactive, vote 0
-  int pivot = S, pivRank = S, shared = 0, votes = 0;
+  int pivot = ist.pivot & ((1 << L2INIT_FLAG_SHIFT) - 1), pivRank = ist.pivRank, shared = ist.shared, votes = ist.votes;
 
   // Lane masks.  The 64 lanes of a wave are at different candidates and take different cases at every entry, so the cases are
   // not branches (measured 5x slower) but all-ones / zero integers combined with and/or/add: a kind bit of the entry becomes
@@ -461,7 +548,6 @@ k_l2_sweep(int cBase, int nCand, int64_t opsBase, const int32_t* __restrict__ ca
   // SlideMapper::insert_minmer / delete_minmer (slidingMap.hpp:125-211): the four cases (insert or delete x hash matches a
   // query hash or not) as masks IM, IN, DM, DN.  The cell of the hash, of the pivot and of its right neighbour are read up
   // front, independent of the case.  insM: the entry inserts (insert or pre-load), delM: it evicts.
-  int doubleOpen = 0, cntOverflow = 0;
   auto apply = [&](uint32_t e, int insM, int delM) {
     const int j = (int)(e & EF<JB>::JMASK) & (insM | delM);   // 0: no hash / hash beyond the query sketch -> no effect (cell 0 is a dummy)
     const int valid = neg(-j) & ~cntOverflow;          // after a counter overflow the lane only idles to the end
@@ -511,7 +597,7 @@ k_l2_sweep(int cBase, int nCand, int64_t opsBase, const int32_t* __restrict__ ca
   // the evaluation of insert i needs the wpos of record i+1, so it is carried until the next insert / end entry arrives
   // lastVotes = strand_votes right after the most recent insert (pre-load included): the reference samples it before the
   // evictions that precede the next insert (:1342)
-  int evalPending = 0, evW = 0, evShared = 0, evPrevVotes = 0, lastVotes = 0;
+  int evalPending = 0, evW = 0, evShared = 0, evPrevVotes = 0, lastVotes = votes;      // (votes right after the last pre-load insert)
   // the three outcomes of an evaluation (:1376-1430) as masks; only the closing of a run -- rare -- is a branch
   auto evaluate = [&](int on, int nextW) {
     const int gt = on & neg(bestShared - evShared), lt = on & neg(evShared - bestShared), ge = on & ~lt;
@@ -542,7 +628,7 @@ k_l2_sweep(int cBase, int nCand, int64_t opsBase, const int32_t* __restrict__ ca
       const uint32_t eRaw = (k & 3) == 0 ? v.x : (k & 3) == 1 ? v.y : (k & 3) == 2 ? v.z : v.w;
       const uint32_t e = eRaw & (uint32_t)~done;         // a finished lane reads on behind its end marker: no kind bit, no effect
       // straight-line per entry: the entry kinds are masks, not branches
-      const int mIns = BITM(e, 27), mDel = BITM(e, 28), mPre = BITM(e, 29), mEnd = BITM(e, 30);
+      const int mIns = BITM(e, 27), mDel = BITM(e, 28), mEnd = BITM(e, 30);              // (no pre-load entries: the state starts behind them)
       const int mSkip = neg((int)e);
       const int ie = mIns | mEnd;
       posAcc += ((int)((e >> EF<JB>::DELTA_SHIFT) & EF<JB>::MAXDELTA) & ie) | ((int)(e & E_SKIP_MAX) & mSkip);
@@ -551,8 +637,8 @@ k_l2_sweep(int cBase, int nCand, int64_t opsBase, const int32_t* __restrict__ ca
       evalPending = (evalPending & ~ie) | mIns;
       done |= mEnd;
       evPrevVotes = sel(mIns, lastVotes, evPrevVotes);
-      apply(e, mIns | mPre, mDel);
-      lastVotes = sel(mIns | mPre, votes, lastVotes);
+      apply(e, mIns, mDel);
+      lastVotes = sel(mIns, votes, lastVotes);
       evW = sel(mIns, wpos, evW); evShared = sel(mIns, shared, evShared);
     }
 #pragma unroll
@@ -613,7 +699,11 @@ k_l2_sweep_exact(int jb, int nList, int64_t opsBase, const int32_t* __restrict__
                  const int64_t* __restrict__ opOff, const int32_t* __restrict__ opCnt, const uint32_t* __restrict__ ops,
                  const int64_t* __restrict__ l1Off, ExactCell* __restrict__ cells, int cellStride, L2Tmp* __restrict__ tmp, int locap,
                  mm_l2_locus* __restrict__ l2, unsigned long long l2Cap, int64_t* __restrict__ l2First, int32_t* __restrict__ l2Num,
-                 unsigned long long* __restrict__ counters, const unsigned long long* __restrict__ nDev) {
+                 unsigned long long* __restrict__ counters, const unsigned long long* __restrict__ nDev,
+                 const L2Info* __restrict__ info, int s, const uint64_t* __restrict__ qHash, const int8_t* __restrict__ qStrand,
+                 const uint64_t* __restrict__ skHash, const int8_t* __restrict__ skStrand,
+                 const uint32_t* __restrict__ evKey, const uint32_t* __restrict__ evAux, const uint64_t* __restrict__ evHash,
+                 const uint32_t* __restrict__ opKey, const uint32_t* __restrict__ opAux, const uint64_t* __restrict__ opHash) {
   const int li = blockIdx.x * 64 + threadIdx.x;
   if (nDev) {                                          // steady state: the launch covers nList entries, the list's length is on the device
     const long long nd = (long long)*nDev;
@@ -645,6 +735,43 @@ k_l2_sweep_exact(int jb, int nList, int64_t opsBase, const int32_t* __restrict__
     } else pend.end = curEnd;
   };
   bool evalPending = false; int evW = 0, evShared = 0, evPrevVotes = 0, lastVotes = 0;
+  // insert_minmer (slidingMap.hpp:125-165) for the hash at 1-based sketch position j (0: beyond the sketch, no effect)
+  auto insert = [&](int j, bool match, int vote) {
+    if (j <= 0) return;
+    ExactCell c = cell[j];
+    if (match) {
+      c.active = 1; c.vote = (int16_t)(c.vote + vote);
+      if (j <= pivot) { shared++; votes += c.vote; }
+      cell[j] = c;
+    } else {
+      c.cnt++; cell[j] = c;
+      if (j <= pivot) pivRank++;
+      if (pivRank > S) { const ExactCell pc = cell[pivot]; shared -= pc.active; votes -= pc.vote; pivRank -= pc.cnt; pivot--; }
+    }
+  };
+  {
+    // The pre-load (computeMap.hpp:1323-1338) is not in the stream (the fast kernels get its result in closed form, L2Init): it is replayed
+    // here from the index, record by record in index order -- the block's list of open records, then the events before rangeStart --, with
+    // k_l2_locate's rule for what is still open at rangeStart and a binary search of the query sketch in place of its LDS table
+    const L2Info in = info[cIdx];
+    const bool raw = in.sketch < 0;
+    const uint64_t* qh = (raw ? skHash : qHash) + (size_t)f * s;
+    const int8_t* qv = (raw ? skStrand : qStrand) + (size_t)f * s;
+    const uint64_t qmax = S > 0 ? qh[S - 1] : 0ull;
+    auto one = [&](uint32_t key, uint32_t aux, uint64_t h) {
+      const bool isInsert = (key & 1u) != 0; const int pos = (int)(key >> 1);
+      if (!(isInsert && (int)(aux & 0x7fffffffu) > cand.rangeStartPos && pos >= in.target)) return;
+      if (S > 0 && h <= qmax) {
+        int lo = 0, hi = S;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (qh[mid] < h) lo = mid + 1; else hi = mid; }
+        const bool match = qh[lo] == h;
+        insert(lo + 1, match, (aux >> 31) ? -(int)qv[lo] : (int)qv[lo]);        // vote = query strand x reference strand
+      }
+      lastVotes = votes;
+    };
+    for (int i = 0; i < in.nOpen; i++) one(opKey[in.open0 + i], opAux[in.open0 + i], opHash[in.open0 + i]);
+    for (int i = 0; i < in.nPre; i++) one(evKey[in.e0 + i], evAux[in.e0 + i], evHash[in.e0 + i]);
+  }
   for (int i = 0; i < nEnt; i++) {
     const uint32_t e = src[i];
     const bool isIns = (e >> E_INS_BIT) & 1u, isDel = (e >> E_DEL_BIT) & 1u, isPre = (e >> E_PRE_BIT) & 1u, isEnd = (e >> E_END_BIT) & 1u, isSkip = (e >> E_SKIP_BIT) & 1u;
@@ -1050,6 +1177,15 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt, bool steady) {
     c->l2Chunks = chunks.size();                                                          // a batch that needs several chunks stays with the sized passes
   }
   if (steady && c->dL2Ops.bytes == 0) return MM_PASS_REDO;
+  // the pre-load states k_l2_locate leaves for the sweeps: a row of s + 2 cells and four integers per candidate of a chunk
+  {
+    size_t rows = 0;
+    for (const Chunk& ch : chunks) rows = std::max(rows, (size_t)ch.n);
+    if (chunks.size() == 1) rows = std::max(rows, (size_t)nCbuf);
+    MM_HIP(c, c->dL2InitCells.ensure(rows * (size_t)(s + 2) * 2 + 64));
+    MM_HIP(c, c->dL2InitState.ensure(rows * sizeof(L2Init) + 64));
+  }
+  const int initStride = s + 2;
   // buckets of the query-sketch search: at least one per sketch entry (more buckets cost more to fill per candidate than the shorter
   // walks save: profiles/r02z_locate_buckets.txt)
   int NB = 256; while (NB < s) NB <<= 1;
@@ -1082,7 +1218,8 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt, bool steady) {
                          I.evKey.as<uint32_t>(),
                          I.evAux.as<uint32_t>(), I.evHash.as<uint64_t>(), I.opKey.as<uint32_t>(), I.opAux.as<uint32_t>(), I.opHash.as<uint64_t>(),
                          I.contigOff.as<int64_t>(),
-                         c->dL2Info.as<L2Info>(), c->dL2Off.as<int64_t>(), c->dL2Cnt.as<int32_t>(), c->dL2Ops.as<uint32_t>(), order, cnt, nDev);
+                         c->dL2Info.as<L2Info>(), c->dL2Off.as<int64_t>(), c->dL2Cnt.as<int32_t>(), c->dL2Ops.as<uint32_t>(), order, cnt, nDev,
+                         c->dL2InitCells.as<uint16_t>(), c->dL2InitState.as<L2Init>(), initStride);
     };
     if (JB == 13) go(k_l2_locate<13>); else go(k_l2_locate<11>);
     MM_HIP(c, hipGetLastError());
@@ -1101,13 +1238,14 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt, bool steady) {
   if (ldsWide > 160 * 1024 || ldsNarrow > 160 * 1024) { c->err = "sketchSize too large for the LDS-resident L2 state"; return MM_ERR_ARG; }
   // one launch of a sweep kernel: n candidates starting at c0, or the n listed ones (countDev: their number lives on the device, the
   // launch covers listCap of them)
-  auto sweep = [&](bool wide, int c0, int n, int64_t opsBase, const int32_t* list, int locap_, const unsigned long long* countDev, int listCap) {
+  auto sweep = [&](bool wide, int c0, int n, int64_t opsBase, const int32_t* list, int locap_, const unsigned long long* countDev, int listCap, int initBase) {
     auto go = [&](auto kern, int lpw, size_t lds) {
       (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL(kern, dim3((unsigned)((n + lpw - 1) / lpw)), dim3(64), lds, c->stream, c0, n, opsBase, list, c->P.segLength,
                          c->dL1.as<mm_l1_candidate>(), c->dStats.as<mm_frag_stats>(), c->dL2Off.as<int64_t>(), c->dL2Cnt.as<int32_t>(), c->dL2Ops.as<uint32_t>(),
                          c->dL1Off.as<int64_t>(), c->dL2Tmp.as<L2Tmp>(), locap_, c->dL2.as<mm_l2_locus>(), (unsigned long long)c->l2Cap,
-                         c->dL2Wide.as<int32_t>(), c->dL2Exact.as<int32_t>(), c->dL2First.as<int64_t>(), c->dL2Num.as<int32_t>(), cnt, countDev, listCap);
+                         c->dL2Wide.as<int32_t>(), c->dL2Exact.as<int32_t>(), c->dL2First.as<int64_t>(), c->dL2Num.as<int32_t>(), cnt, countDev, listCap,
+                         c->dL2InitCells.as<uint16_t>(), c->dL2InitState.as<L2Init>(), initStride, initBase);
     };
     if (!wide) {
       if (JB == 11) go(k_l2_sweep<false, 11, 64>, 64, ldsNarrow);
@@ -1143,20 +1281,22 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt, bool steady) {
           if (rc != MM_OK) return rc;
           order = c->dL2Order.as<int32_t>();
         }
-        sweep(false, ch.c0, ch.n, ch.base, order, locap, nDev, 0);
+        sweep(false, ch.c0, ch.n, ch.base, order, locap, nDev, 0, ch.c0);
         MM_HIP(c, hipGetLastError());
       }
       if (steady) {
         // the 16-bit re-run and the exact kernel for however many candidates the narrow sweep has queued (usually none): launched for
         // a fixed number of them, the lists' lengths are read on the device
         KernelTimer t(c, MM_K_L2);
-        sweep(true, 0, MM_WIDE_CAP, ch.base, c->dL2Wide.as<int32_t>(), locap, cnt + 7, MM_WIDE_CAP);
+        sweep(true, 0, MM_WIDE_CAP, ch.base, c->dL2Wide.as<int32_t>(), locap, cnt + 7, MM_WIDE_CAP, ch.c0);
         MM_HIP(c, hipGetLastError());
         MM_HIP(c, c->dL2Cells.ensure((size_t)MM_EXACT_CAP * (size_t)(s + 1) * sizeof(ExactCell) + 64));
         hipLaunchKernelGGL(k_l2_sweep_exact, dim3((unsigned)((MM_EXACT_CAP + 63) / 64)), dim3(64), 0, c->stream, JB, MM_EXACT_CAP, ch.base, c->dL2Exact.as<int32_t>(), c->P.segLength,
                            c->dL1.as<mm_l1_candidate>(), c->dStats.as<mm_frag_stats>(), c->dL2Off.as<int64_t>(), c->dL2Cnt.as<int32_t>(), c->dL2Ops.as<uint32_t>(),
                            c->dL1Off.as<int64_t>(), c->dL2Cells.as<ExactCell>(), s + 1, c->dL2Tmp.as<L2Tmp>(), locap, c->dL2.as<mm_l2_locus>(),
-                           (unsigned long long)c->l2Cap, c->dL2First.as<int64_t>(), c->dL2Num.as<int32_t>(), cnt, cnt);
+                           (unsigned long long)c->l2Cap, c->dL2First.as<int64_t>(), c->dL2Num.as<int32_t>(), cnt, cnt,
+                           c->dL2Info.as<L2Info>(), s, c->dQHash.as<uint64_t>(), c->dQStrand.as<int8_t>(), c->dSkHash.as<uint64_t>(), c->dSkStrand.as<int8_t>(),
+                           I.evKey.as<uint32_t>(), I.evAux.as<uint32_t>(), I.evHash.as<uint64_t>(), I.opKey.as<uint32_t>(), I.opAux.as<uint32_t>(), I.opHash.as<uint64_t>());
         MM_HIP(c, hipGetLastError());
         continue;
       }
@@ -1166,7 +1306,7 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt, bool steady) {
         const int nWide = (int)hc[7];
         if (getenv("MM_DEBUG")) fprintf(stderr, "[mm] L2 sweep: %d of %d candidates redone with 16-bit cells\n", nWide, ch.n);
         KernelTimer t(c, MM_K_L2);
-        sweep(true, 0, nWide, ch.base, c->dL2Wide.as<int32_t>(), locap, nullptr, 0);
+        sweep(true, 0, nWide, ch.base, c->dL2Wide.as<int32_t>(), locap, nullptr, 0, ch.c0);
         MM_HIP(c, hipGetLastError());
         MM_HIP(c, hipMemcpyAsync(hc, cnt, 64, hipMemcpyDeviceToHost, c->stream));
         MM_SYNC(c);
@@ -1179,7 +1319,9 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt, bool steady) {
         hipLaunchKernelGGL(k_l2_sweep_exact, dim3((unsigned)((nExact + 63) / 64)), dim3(64), 0, c->stream, JB, nExact, ch.base, c->dL2Exact.as<int32_t>(), c->P.segLength,
                            c->dL1.as<mm_l1_candidate>(), c->dStats.as<mm_frag_stats>(), c->dL2Off.as<int64_t>(), c->dL2Cnt.as<int32_t>(), c->dL2Ops.as<uint32_t>(),
                            c->dL1Off.as<int64_t>(), c->dL2Cells.as<ExactCell>(), s + 1, c->dL2Tmp.as<L2Tmp>(), locap, c->dL2.as<mm_l2_locus>(),
-                           (unsigned long long)c->l2Cap, c->dL2First.as<int64_t>(), c->dL2Num.as<int32_t>(), cnt, (const unsigned long long*)nullptr);
+                           (unsigned long long)c->l2Cap, c->dL2First.as<int64_t>(), c->dL2Num.as<int32_t>(), cnt, (const unsigned long long*)nullptr,
+                           c->dL2Info.as<L2Info>(), s, c->dQHash.as<uint64_t>(), c->dQStrand.as<int8_t>(), c->dSkHash.as<uint64_t>(), c->dSkStrand.as<int8_t>(),
+                           I.evKey.as<uint32_t>(), I.evAux.as<uint32_t>(), I.evHash.as<uint64_t>(), I.opKey.as<uint32_t>(), I.opAux.as<uint32_t>(), I.opHash.as<uint64_t>());
         MM_HIP(c, hipGetLastError());
         MM_HIP(c, hipMemcpyAsync(hc, cnt, 64, hipMemcpyDeviceToHost, c->stream));
         MM_SYNC(c);

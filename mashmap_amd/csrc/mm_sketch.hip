@@ -791,7 +791,7 @@ int mm_check_params(const mm_params* p, std::string& err) {
   // 13-bit sketch-position field of the located stream (mm_l2.hip)
   const size_t ldsL2 = (size_t)(s + 1) * 8 * 2;
   int NB = 256; while (NB < s) NB <<= 1;
-  const size_t ldsLoc = (size_t)(s + 1) * 8 + (size_t)(s + 2) / 2 * 8 + (size_t)(NB + 4) * 2 + (size_t)s + 32;
+  const size_t ldsLoc = (size_t)(s + 1) * 8 + (size_t)(s + 2) / 2 * 8 + (size_t)(NB + 4) * 2 + (size_t)s + 32 + (size_t)(s + 4) / 2 * 4 + 16;   // (one wave of k_l2_locate: mm_locate_lds_per_wave)
   if (s > MM_LDS_MAX_SKETCH) {
     // no LDS kernel holds this sketch: the global-memory sketch kernel (mm_sketch_global.hip) and the literal L2 kernels take every
     // fragment -- exact, slow; the stock binary runs these sizes (--dense at segments of 100 kbp), so they run here too
