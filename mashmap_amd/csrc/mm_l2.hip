@@ -318,7 +318,7 @@ k_l2_locate(int cBase, int nCand, int64_t opsBase, int s, int NB, const mm_l1_ca
       }
     }
     int outN = 0;                                                  // entries written so far (wave-uniform)
-    uint32_t preFlags = 0;
+    uint32_t preFlags = nOpen + nPre >= 4000 ? 2u : 0u;                    // a cell counts in 12 bits, and no cell can receive more than the pre-load holds: beyond that the exact kernel (32-bit counts) takes the candidate
     int posAcc = cand.rangeStartPos;                               // running position of the delta code (wave-uniform)
     bool tooWide = false;
     const int nEv = lastRel + 1;                                   // events [0, nEv) of the slice are streamed
@@ -357,10 +357,7 @@ k_l2_locate(int cBase, int nCand, int64_t opsBase, int s, int NB, const mm_l1_ca
             const uint32_t old = atomicOr(w, 0x1000u << sh);
             if ((old >> sh) & 0x1000u) preFlags |= 1u;               // open twice: only the exact kernel can follow that
             else atomicXor(w, ((1u ^ ((op >> EF<JB>::VOTE_SHIFT) & 3u)) << 13) << sh);   // vote + 1: from 1 (vote 0) to this record's
-          } else {
-            const uint32_t old = atomicAdd(w, 1u << sh);
-            if (((old >> sh) & 0xFFFu) >= 4094u) preFlags |= 2u;     // (beyond 12 bits)
-          }
+          } else atomicAdd(w, 1u << sh);                             // (nothing comes back; nPre bounds the count, see preFlags)
         }
         continue;
       }
@@ -440,8 +437,8 @@ k_l2_locate(int cBase, int nCand, int64_t opsBase, int s, int NB, const mm_l1_ca
       const uint64_t fl = mm_ballot(preFlags != 0);
       uint32_t flags = 0;
       if (fl) flags = (mm_ballot((preFlags & 1u) != 0) ? 1u : 0u) | (mm_ballot((preFlags & 2u) != 0) ? 2u : 0u);
-      uint16_t* row = initCells + (size_t)(c - cBase) * (size_t)initStride;
-      for (int p = lane; p < S + 2; p += 64) row[p] = (uint16_t)((ic[p >> 1] >> ((p & 1) * 16)) & 0xFFFFu);
+      uint32_t* row = (uint32_t*)(initCells + (size_t)(c - cBase) * (size_t)initStride);      // (initStride is even: two cells per dword, as they lie in LDS)
+      for (int d = lane; d <= (S + 1) / 2; d += 64) row[d] = ic[d];
       if (lane == 0) initState[c - cBase] = L2Init{pivot | (int32_t)(flags << L2INIT_FLAG_SHIFT), pivRank, shared, votes};
     }
   }
@@ -1182,10 +1179,10 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt, bool steady) {
     size_t rows = 0;
     for (const Chunk& ch : chunks) rows = std::max(rows, (size_t)ch.n);
     if (chunks.size() == 1) rows = std::max(rows, (size_t)nCbuf);
-    MM_HIP(c, c->dL2InitCells.ensure(rows * (size_t)(s + 2) * 2 + 64));
+    MM_HIP(c, c->dL2InitCells.ensure(rows * (size_t)((s + 3) & ~1) * 2 + 64));
     MM_HIP(c, c->dL2InitState.ensure(rows * sizeof(L2Init) + 64));
   }
-  const int initStride = s + 2;
+  const int initStride = (s + 3) & ~1;                                       // cells per row: s + 2, rounded up to whole dwords
   // buckets of the query-sketch search: at least one per sketch entry (more buckets cost more to fill per candidate than the shorter
   // walks save: profiles/r02z_locate_buckets.txt)
   int NB = 256; while (NB < s) NB <<= 1;
