@@ -205,7 +205,7 @@ k_l2_locate(int cBase, int nCand, int64_t opsBase, int s, int NB, const mm_l1_ca
             const int64_t* __restrict__ contigOff, const L2Info* __restrict__ info, const int64_t* __restrict__ opOff,
             const int32_t* __restrict__ opCnt, uint32_t* __restrict__ ops, const int32_t* __restrict__ order /* candidates in reference order, or null */,
             unsigned long long* __restrict__ counters /* [6] |= 4: a stream outgrew its reservation */,
-            const unsigned long long* __restrict__ nDev, uint16_t* __restrict__ initCells, L2Init* __restrict__ initState, int initStride) {
+            const unsigned long long* __restrict__ nDev, uint16_t* __restrict__ initCells, L2Init* __restrict__ initState, int initStride, int preLimit) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;   // (readfirstlane: the candidate's extents then live in scalar registers)
   unsigned char* base = smem + (size_t)wave * mm_locate_lds_per_wave(s, NB);
@@ -318,7 +318,7 @@ k_l2_locate(int cBase, int nCand, int64_t opsBase, int s, int NB, const mm_l1_ca
       }
     }
     int outN = 0;                                                  // entries written so far (wave-uniform)
-    uint32_t preFlags = nOpen + nPre >= 4000 ? 2u : 0u;                    // a cell counts in 12 bits, and no cell can receive more than the pre-load holds: beyond that the exact kernel (32-bit counts) takes the candidate
+    uint32_t preFlags = nOpen + nPre >= preLimit ? 2u : 0u;                    // a cell counts in 12 bits, and no cell can receive more than the pre-load holds: beyond that the exact kernel (32-bit counts) takes the candidate
     int posAcc = cand.rangeStartPos;                               // running position of the delta code (wave-uniform)
     bool tooWide = false;
     const int nEv = lastRel + 1;                                   // events [0, nEv) of the slice are streamed
@@ -1194,6 +1194,9 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt, bool steady) {
   // total events of the index -> a shift that leaves 16 bits of key (two radix passes)
   int posShift = 0; { const int64_t nEv = (int64_t)(I.evKey.bytes / 4); while ((nEv >> posShift) > 0xFFFF) posShift++; }
   static const bool sortLocate = getenv("MM_L2_LOCATE_NO_SORT") == nullptr;
+  // pre-loads of this many records or more go to the exact kernel (12-bit cell counts); MM_L2_PRE_LIMIT lowers it so that tests can send
+  // every candidate there
+  int preLimit = 4000; if (const char* e = getenv("MM_L2_PRE_LIMIT")) { const int v = atoi(e); if (v >= 0 && v < 4000) preLimit = v; }
   auto locate = [&](const Chunk& ch) -> int {
     KernelTimer t(c, MM_K_L2_LOCATE);
     const int32_t* order = nullptr;
@@ -1216,7 +1219,7 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt, bool steady) {
                          I.evAux.as<uint32_t>(), I.evHash.as<uint64_t>(), I.opKey.as<uint32_t>(), I.opAux.as<uint32_t>(), I.opHash.as<uint64_t>(),
                          I.contigOff.as<int64_t>(),
                          c->dL2Info.as<L2Info>(), c->dL2Off.as<int64_t>(), c->dL2Cnt.as<int32_t>(), c->dL2Ops.as<uint32_t>(), order, cnt, nDev,
-                         c->dL2InitCells.as<uint16_t>(), c->dL2InitState.as<L2Init>(), initStride);
+                         c->dL2InitCells.as<uint16_t>(), c->dL2InitState.as<L2Init>(), initStride, preLimit);
     };
     if (JB == 13) go(k_l2_locate<13>); else go(k_l2_locate<11>);
     MM_HIP(c, hipGetLastError());

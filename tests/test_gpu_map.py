@@ -418,6 +418,18 @@ def test_l2_in_chunks_of_candidates(oracle, monkeypatch):
         assert run(budget)[:4] == whole[:4], budget
 
 
+@pytest.mark.parametrize("limit", ["0", "150"])
+def test_l2_exact_kernel_takes_candidates_with_a_long_preload(oracle, monkeypatch, limit):
+    """k_l2_locate hands candidates whose pre-load (the records open at rangeStart) is too long for its 12-bit cell counts to
+    k_l2_sweep_exact, which replays the pre-load from the index; MM_L2_PRE_LIMIT lowers the limit from 4000 records to where every
+    candidate (0) or some of them (150) take that way: same integers as the oracle at every stage"""
+    monkeypatch.setenv("MM_L2_PRE_LIMIT", limit)
+    contigs = genome(611, [400000, 300000, 200000])
+    reads = reads_for(contigs, 35, 100, 10000, 0.10) + reads_for(contigs, 36, 20, 7000, 0.03) + [("unrelated", U.random_dna(12, 15000))]
+    nF, nl = run_and_compare(oracle, contigs, reads)
+    assert nF > 200 and nl > 150
+
+
 def test_map_many_candidates_per_fragment(oracle, monkeypatch):
     """a 1.5 kbp unit strewn 90 times over a contig, every copy further than segLength from the next: a read of the unit has ~90 L1
     candidates -- more than k_l1_stream keeps in LDS while counting (its second, writing pass), and the same bytes as the literal kernel"""
