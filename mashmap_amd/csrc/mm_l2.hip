@@ -437,8 +437,9 @@ k_l2_locate(int cBase, int nCand, int64_t opsBase, int s, int NB, const mm_l1_ca
       const uint64_t fl = mm_ballot(preFlags != 0);
       uint32_t flags = 0;
       if (fl) flags = (mm_ballot((preFlags & 1u) != 0) ? 1u : 0u) | (mm_ballot((preFlags & 2u) != 0) ? 2u : 0u);
-      uint32_t* row = (uint32_t*)(initCells + (size_t)(c - cBase) * (size_t)initStride);      // (initStride is even: two cells per dword, as they lie in LDS)
-      for (int d = lane; d <= (S + 1) / 2; d += 64) row[d] = ic[d];
+      // (16-bit stores: writing the row as the dwords it occupies in LDS made the kernel 10 % slower -- profiles/NOTES.md, r13s)
+      uint16_t* row = initCells + (size_t)(c - cBase) * (size_t)initStride;
+      for (int p = lane; p < S + 2; p += 64) row[p] = (uint16_t)((ic[p >> 1] >> ((p & 1) * 16)) & 0xFFFFu);
       if (lane == 0) initState[c - cBase] = L2Init{pivot | (int32_t)(flags << L2INIT_FLAG_SHIFT), pivRank, shared, votes};
     }
   }
