@@ -42,7 +42,8 @@ struct L2Tmp { int32_t start, end, shared, strand; };
 // up to it -- so k_l2_locate, which has the candidate's sketch in LDS anyway, builds it in parallel instead of writing ~s pre-load entries
 // that the sweep then applies one by one (a fifth to a third of a stream).  Cells: 16 bit each, count (12) | active << 12 | (vote + 1) << 13
 // = the wide sweep's cell format; row of s + 2 cells per candidate of a chunk.  flags: 1 = a query hash was open twice in the pre-load (the
-// 2-bit vote cannot hold it: k_l2_sweep_exact replays the pre-load from the index), 2 = a count beyond 12 bits (likewise).
+// 2-bit vote cannot hold it: k_l2_sweep_exact replays the pre-load from the index), 2 = a pre-load of 4000 records or more,
+// which the 12-bit counts might not hold (likewise).
 struct L2Init { int32_t pivot, pivRank, shared, votes; };
 #define L2INIT_FLAG_SHIFT 24        // flags travel in the top byte of `pivot` (pivot <= 8190)
 
@@ -527,7 +528,7 @@ k_l2_sweep(int cBase, int nCand, int64_t opsBase, const int32_t* __restrict__ ca
   const L2Init ist = initState[cIdx - initBase];
   const int iflags = (int)((uint32_t)ist.pivot >> L2INIT_FLAG_SHIFT);
   if (iflags & 1) doubleOpen = -1;                     // a query hash open twice in the pre-load: k_l2_sweep_exact
-  if (iflags & 2) cntOverflow = -1;                    // a count beyond 12 bits: likewise (through the 16-bit re-run's own overflow)
+  if (iflags & 2) cntOverflow = -1;                    // a pre-load too long for 12-bit counts: likewise (through the 16-bit re-run's own overflow)
   const uint4* src = (const uint4*)(ops + (opOff[cIdx] - opsBase));
   const int nSteps = opCnt[cIdx] / E_STEP;             // 16 entries = 4 x 16 bytes per step
   int posAcc = cand.rangeStartPos;                     // running position of the delta code
