@@ -788,6 +788,138 @@ class StepLoop:
         return dt, prof, passes
 
 
+LINE_LIMIT = 6000   # the driver keeps the last 8 000 characters of stdout: the final line has to fit with room to spare
+
+
+def _r(x, n=4):
+    return round(x, n) if isinstance(x, float) else x[:160] if isinstance(x, str) else x
+
+
+def _pick(d, keys):
+    return {k: _r(d[k]) for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def _compact_roofline(r):
+    """numbers only: what the driver and the review read; the prose stays in the full record"""
+    if not isinstance(r, dict):
+        return None
+    out = _pick(r, ("kernel", "avg_launch_ms", "bound", "achieved", "peak", "unit", "frac", "frac_vs_measured_mix", "traffic", "valu_wave_instructions_per_launch"))
+    hbm = r.get("hbm") or {}
+    out["hbm"] = _pick(hbm, ("achieved", "peak", "unit", "frac", "traffic"))
+    out["algorithmic_bytes_per_launch"] = hbm.get("algorithmic_bytes_per_launch")
+    out["int"] = _pick(r.get("int") or {}, ("hash_only_ms", "sketch_kernel_frac", "step_frac"))
+    age = r.get("pmc_age") or {}
+    out["pmc_tree"] = {"passes": age.get("passes"), "csrc_sha16": age.get("csrc_sha16_then"), "unchanged": age.get("kernel_sources_unchanged")} if age else None
+    out["kernels"] = [_pick(k, ("kernel", "avg_ms_per_pass", "achieved", "frac", "traffic", "algorithmic_bytes_per_launch")) for k in r.get("kernels") or []]
+    return out
+
+
+def _compact_side(d):
+    """one side measurement (north_star variants, configs2): value, time, the shares the review asks for, and its dominant kernel's fractions"""
+    if not isinstance(d, dict):
+        return None
+    if "error" in d and "value" not in d:
+        return {"error": str(d["error"])[:160]}
+    out = _pick(d, ("value", "ms_per_step", "hbm_point_path_share", "hard_list_share", "l1_candidates_per_fragment", "index_build_s"))
+    p = d.get("passes") or {}
+    if p:
+        out["redone"] = p.get("redone")
+    r = d.get("roofline") or {}
+    if r:
+        out["roofline"] = {"frac": r.get("frac"), "hbm_frac": (r.get("hbm") or {}).get("frac"), "sketch_kernel_frac": (r.get("int") or {}).get("sketch_kernel_frac"),
+                           "pmc_unchanged": (r.get("pmc_age") or {}).get("kernel_sources_unchanged")}
+    k = d.get("kernels") or {}
+    if k:
+        out["kernels_ms"] = {n: round(v["ms_per_step"], 2) for n, v in k.items() if v["ms_per_step"] >= 0.05}
+    return out
+
+
+def compact_line(full, full_path=None):
+    """the ONE line the driver parses, from the full record of a run: every key of the bench contract, `roofline` and `cpu_baseline`
+    as numbers, the side measurements as one small object each -- no prose.  Everything else is in `full_path`."""
+    line = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    c = full.get("config") or {}
+    cfg = _pick(c, ("workload", "k", "segLength", "sketchSize", "percentageIdentity", "fragments_per_gpu", "resident_batches", "mean_interval_points_per_fragment",
+                    "l1_candidates_per_gpu", "l2_loci_per_gpu", "candidate_mappings_per_gpu", "hard_list_fragments", "index_build_s", "host_synchronisations_last_pass"))
+    cfg["workload"] = str(cfg.get("workload", ""))[:200]
+    cfg["parallelism"] = "single GPU" if full.get("n_gpus", 1) == 1 else "reads sharded, index replicated, RCCL all-gatherv of candidate mappings"
+    if c.get("rccl"):
+        cfg["rccl"] = _pick(c["rccl"], ("world_seen", "error"))
+    line["config"] = cfg
+    line["passes"] = _pick(full.get("passes") or {}, ("timed", "steady", "redone", "resident_batches"))
+    line["roofline"] = _compact_roofline(full.get("roofline"))
+    line["kernels_ms"] = {n: round(v["ms_per_step"], 3) for n, v in (full.get("kernels") or {}).items()}
+    cb = full.get("cpu_baseline")
+    if isinstance(cb, dict):
+        line["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "threads", "kind"))
+        if "sample" in cb:
+            line["cpu_baseline"]["sample"] = str(cb["sample"])[:100]
+        fc = cb.get("fragment_compute") or {}
+        if fc:
+            line["cpu_baseline"]["gbps_per_core"] = fc.get("gbps_per_core")
+        if "error" in cb:
+            line["cpu_baseline"]["error"] = str(cb["error"])[:160]
+    hp = full.get("host_path")
+    if isinstance(hp, dict):
+        line["host_path"] = _pick(hp, ("device_ms", "download_ms", "host_ms", "host_threads", "gbps_pipelined", "error"))
+    e = full.get("e2e")
+    if isinstance(e, dict):
+        line["e2e"] = _pick(e, ("value", "map_s", "index_s", "paf_lines", "error"))
+        st = e.get("stages") or {}
+        line["e2e"].update(_pick(st, ("reader_s", "device_stage_s", "post_s")))
+    ns = full.get("north_star_target")
+    if isinstance(ns, dict):
+        t = _compact_side(ns) or {}
+        t["target_gbps"] = ns.get("target_gbps", 50.0)
+        t["seg10000"] = _compact_side(ns.get("segLength_10000"))
+        t["repeat_rich"] = _compact_side(ns.get("repeat_rich"))
+        cpu = ns.get("cpu_baseline")
+        t["cpu"] = _pick(cpu, ("value", "cores", "threads", "kind", "index_build_s", "error")) if isinstance(cpu, dict) else None
+        line["north_star_target"] = t
+    c2 = full.get("configs2")
+    if isinstance(c2, dict):
+        line["configs2"] = _compact_side(c2)
+    if full_path:
+        line["full"] = full_path
+    # whatever a future key adds, the line is never allowed past the limit: shed the optional objects, largest first
+    for drop in ("kernels_ms", "host_path", "e2e", "configs2"):
+        if len(json.dumps(line)) < LINE_LIMIT:
+            break
+        line.pop(drop, None)
+    if len(json.dumps(line)) >= LINE_LIMIT:
+        for t in (line.get("north_star_target") or {}, (line.get("north_star_target") or {}).get("seg10000") or {}, (line.get("north_star_target") or {}).get("repeat_rich") or {}):
+            t.pop("kernels_ms", None)
+        (line.get("roofline") or {}).pop("kernels", None)
+    return line
+
+
+def emit(full):
+    """stdout of rank 0: the full record goes to profiles/bench_last_full.json (and gpurun_out/, which travels back from a GPU box), the side
+    measurements one small object per line, and LAST the line the driver parses."""
+    paths = []
+    for d in ("profiles", "gpurun_out"):
+        try:
+            os.makedirs(os.path.join(ROOT, d), exist_ok=True)
+            with open(os.path.join(ROOT, d, "bench_last_full.json"), "w") as f:
+                json.dump(full, f, indent=1)
+            paths.append("%s/bench_last_full.json" % d)
+        except OSError as e:
+            log("[bench] could not write the full record under %s/: %r" % (d, e))
+    line = compact_line(full, paths[0] if paths else None)
+    for key in ("host_path", "e2e", "configs2"):
+        if key in line:
+            print(json.dumps({"side": key, **line[key]}), flush=True)
+    ns = line.get("north_star_target")
+    if ns:
+        print(json.dumps({"side": "north_star_target", **{k: v for k, v in ns.items() if k not in ("seg10000", "repeat_rich")}}), flush=True)
+        for key in ("seg10000", "repeat_rich"):
+            if ns.get(key):
+                print(json.dumps({"side": "north_star_target." + key, **ns[key]}), flush=True)
+    txt = json.dumps(line)
+    assert len(txt) < LINE_LIMIT, "bench line is %d characters" % len(txt)
+    print(txt, flush=True)
+
+
 def free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
     return p
@@ -1081,7 +1213,7 @@ def main():
             except Exception as e:
                 log("[bench] north_star target measurement failed:", repr(e))
                 out["north_star_target"] = {"error": repr(e)}
-        print(json.dumps(out), flush=True)
+        emit(out)
     if ctx is not None:
         ctx.close()
     if world > 1:
