@@ -53,6 +53,9 @@ WORKLOADS = {
     "configs1": dict(label="configs[1]", k=19, seg=5000, sketch=130, pi=0.85, read_len=10000, err=(0.10, 0.10), reads=1_000_000,
                      ref_contigs=10, ref_contig_len=10_000_000,
                      sketch_note="130 = recommendedSketchSize for a 100 Mbp reference file (SURVEY App. C)"),
+    "configs2": dict(label="configs[2]", k=19, seg=10000, sketch=40, pi=0.95, read_len=125_000_000, err=(0.01, 0.01), reads=24,
+                     ref_contigs=24, ref_contig_len=125_000_000, assembly=True, cli=["-f", "one-to-one"],
+                     sketch_note="40 = what the stock binary derives at pi 95, segLength 10000 for a 3 GB reference file (int32 referenceSize overflow); 20 mathematically (SURVEY App. C); pinned with -J 40"),
     "configs3": dict(label="configs[3] (per-GPU share of 10 M reads / 8 GPUs)", k=19, seg=5000, sketch=310, pi=0.85, read_len=15000,
                      err=(0.10, 0.10), reads=1_250_000, ref_contigs=24, ref_contig_len=125_000_000,
                      sketch_note="310 = what the stock binary derives for a 3 GB reference file (int32 referenceSize overflow); 220 mathematically (SURVEY App. C)"),
@@ -211,6 +214,39 @@ def make_reads(torch, dev, contigs, nreads, read_len, err, seed, chunk=8192):
         dst[rows[m], p2[m]] = base[m]
         assert int((pos[:, -1] + cnt[:, -1]).min()) >= read_len
         del seg, u, rb, cnt, pos, base, rows, m, p2
+    return out
+
+
+def make_assembly(torch, dev, contigs, div=0.01, seed=21):
+    """BASELINE configs[2]'s query: every reference contig with `div` i.i.d. substitutions and a few 1-5 Mbp
+    rearrangements -- an inversion (contig i % 3 == 0), a translocation inside the contig (i % 3 == 1), both and the whole contig on the
+    other strand (i % 3 == 2).  Lengths stay; returns one uint8 tensor per contig, on the device."""
+    g = torch.Generator(device=dev); g.manual_seed(seed)
+    rs = np.random.RandomState(seed)
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    comp = torch.arange(256, dtype=torch.uint8, device=dev)
+    for a, b in zip(b"ACGT", b"TGCA"):
+        comp[a] = b
+    out = []
+    for i, c in enumerate(contigs):
+        n = len(c)
+        q = c.clone()
+        for o in range(0, n, 1 << 27):                         # substitutions, in pieces (the masks are 4 bytes per base)
+            m = min(1 << 27, n - o)
+            hit = torch.rand(m, generator=g, device=dev) < div * 4.0 / 3.0          # a drawn base equals the old one a quarter of the time
+            q[o:o + m] = torch.where(hit, lut[torch.randint(0, 4, (m,), generator=g, device=dev)], q[o:o + m])
+            del hit
+        unit = max(1, min(1_000_000, n // 125))               # 1 Mbp at 125 Mbp contigs; scaled-down contigs keep the proportions
+        if i % 3 in (0, 2) and n > 12 * unit:                 # inversion of 1..5 units
+            ln = int(rs.randint(1, 6)) * unit; at = int(rs.randint(unit, n - ln - unit))
+            q[at:at + ln] = comp[q[at:at + ln].flip(0).long()]
+        if i % 3 in (1, 2) and n > 12 * unit:                 # translocation: a 1..5 unit piece moves towards the other end of the contig
+            ln = int(rs.randint(1, 6)) * unit; at = int(rs.randint(unit, n // 2 - ln)); to = int(rs.randint(n // 2, n - unit))
+            q = torch.cat([q[:at], q[at + ln:to], q[at:at + ln], q[to:]])
+        if i % 3 == 2:
+            q = comp[q.flip(0).long()]
+        assert len(q) == n
+        out.append(q)
     return out
 
 
@@ -490,7 +526,11 @@ def load_batches(torch, dev, ctx, contigs, W, nreads, nb, seed, seq_base=0, keep
     first = None
     nF = 0
     for b in range(nb):
-        reads_t = make_reads(torch, dev, contigs, nreads, L, W["err"], seed=seed + 7919 * b)
+        if W.get("assembly"):                                  # the query is the reference's contigs, diverged and rearranged (configs[2])
+            reads_t = torch.cat(make_assembly(torch, dev, contigs[:nreads], W["err"][0], seed=seed + 7919 * b))
+            offs = np.cumsum([0] + [len(c) for c in contigs[:nreads]]).astype(np.int64)
+        else:
+            reads_t = make_reads(torch, dev, contigs, nreads, L, W["err"], seed=seed + 7919 * b)
         torch.cuda.synchronize()
         if b == 0 and keep_first:
             first = reads_t[:keep_first * L].cpu().numpy()
@@ -925,6 +965,91 @@ def free_port():
     return p
 
 
+def run_cli_staged(exe, argv, reps=2, log_env="MM_E2E_LOG"):
+    """runs the mashmap_hip command line `reps` times with MASHMAP_HIP_TIMING=1 (the second run finds the files in the page cache) and returns
+    the best run's 'time spent' figures and the rows of its stage log"""
+    import re
+    env = dict(os.environ, MASHMAP_HIP_TIMING="1")
+    best = None
+    for rep in range(reps):
+        t0 = time.time()
+        p = subprocess.run([exe] + argv, capture_output=True, text=True, env=env)
+        wall = time.time() - t0
+        if p.returncode != 0:
+            return {"error": "mashmap_hip exited with %d: %s" % (p.returncode, p.stderr[-400:])}
+        tmap = float(re.search(r"time spent mapping the query\s*:\s*([0-9.eE+-]+)", p.stderr).group(1))
+        tidx = float(re.search(r"time spent computing the reference index\s*:\s*([0-9.eE+-]+)", p.stderr).group(1))
+        dev_rows = re.findall(r"device stage \(.*?download of (\d+) candidate mappings\): ([0-9.eE+-]+) s \(upload ([0-9.eE+-]+), kernels ([0-9.eE+-]+), download ([0-9.eE+-]+)\)(?: \[bases (\d+)\])?", p.stderr)
+        rd_rows = re.findall(r"reader: parsed (\d+) records, (\d+) bases in ([0-9.eE+-]+) s", p.stderr)
+        post = [float(x) for x in re.findall(r"post stage: chain \+ filter \+ format ([0-9.eE+-]+) s", p.stderr)]
+        outp = [float(x) for x in re.findall(r", output ([0-9.eE+-]+) s", p.stderr)]
+        final = [float(x) for x in re.findall(r"one-to-one filter \+ output ([0-9.eE+-]+) s", p.stderr)]
+        cur = dict(map_s=tmap, index_s=tidx, wall_s=wall, stderr=p.stderr, dev_rows=dev_rows, rd_rows=rd_rows, post_s=sum(post), output_s=sum(outp), final_s=sum(final))
+        if best is None or tmap < best["map_s"]:
+            best = cur
+    if os.environ.get(log_env):                            # the stage log of the best run, for profiles/
+        with open(os.environ[log_env], "w") as f:
+            f.write("\n".join(l for l in best["stderr"].splitlines() if "timing" in l or "time spent" in l) + "\n")
+    return best
+
+
+def stage_summary(best):
+    dev_rows = best["dev_rows"]
+    return {"reader_s": round(sum(float(r[2]) for r in best["rd_rows"]), 4), "reader_batches": len(best["rd_rows"]),
+            "device_stage_s": round(sum(float(r[1]) for r in dev_rows), 4), "device_upload_wait_s": round(sum(float(r[2]) for r in dev_rows), 4),
+            "device_kernels_s": round(sum(float(r[3]) for r in dev_rows), 4), "device_download_s": round(sum(float(r[4]) for r in dev_rows), 4), "device_passes": len(dev_rows),
+            "post_s": round(best["post_s"], 4), "output_s": round(best["output_s"], 4), "final_filter_s": round(best.get("final_s", 0.0), 4)}
+
+
+def e2e_assembly(torch, dev, W, contigs, threads, stock=False, keep_dir=None):
+    """configs[2] through the command line: the 3 Gbp reference and the assembly (make_assembly of the same contigs) written as FASTA,
+    `mashmap_hip --pi 95 -s 10000 -f one-to-one -J 40`, its 'time spent mapping the query' and stage log; with `stock` the reference's
+    own binary on the same files, PAF bytes compared."""
+    import shutil
+    exe = os.path.join(ROOT, "mashmap_amd", "lib", "mashmap_hip")
+    if not os.path.exists(exe):
+        return {"error": "mashmap_amd/lib/mashmap_hip not built"}
+    td = keep_dir or tempfile.mkdtemp(prefix="mm_e2e2_")
+    try:
+        bases = sum(len(c) for c in contigs)
+        if shutil.disk_usage(td).free < 2.1 * bases + (2 << 30):
+            return {"error": "only %.1f GB free under %s" % (shutil.disk_usage(td).free / 1e9, td)}
+        rp, qp, op = os.path.join(td, "ref.fa"), os.path.join(td, "asm.fa"), os.path.join(td, "out.paf")
+        t0 = time.time()
+        write_fasta(rp, ["chr%d" % i for i in range(len(contigs))], [c.cpu().numpy() for c in contigs])
+        asm = make_assembly(torch, dev, contigs, W["err"][0], seed=2021)
+        write_fasta(qp, ["ctg%d" % i for i in range(len(asm))], [c.cpu().numpy() for c in asm])
+        del asm
+        torch.cuda.empty_cache()
+        write_s = time.time() - t0
+        argv = ["-s", str(W["seg"]), "--pi", str(int(round(W["pi"] * 100))), "-J", str(W["sketch"])] + list(W.get("cli", []))
+        best = run_cli_staged(exe, ["-r", rp, "-q", qp, "-o", op, "-t", str(threads)] + argv, log_env="MM_E2E2_LOG")
+        if "error" in best:
+            return best
+        lines = sum(1 for _ in open(op, "rb"))
+        out = {"what": "mashmap_hip -r ref.fa -q asm.fa %s (FASTA -> PAF): %d contigs, %.2f Gbp assembly vs the %.2f Gbp reference it was derived from" % (" ".join(argv), len(contigs), bases / 1e9, bases / 1e9),
+               "value": round(bases / best["map_s"] / 1e9, 3), "unit": "Gbp/s", "map_s": round(best["map_s"], 4), "index_s": round(best["index_s"], 3), "wall_s": round(best["wall_s"], 3),
+               "paf_lines": lines, "threads": threads, "usable_cpus": usable_cpus(), "fasta_write_s": round(write_s, 1), "stages": stage_summary(best)}
+        ref_bin = os.path.join(ROOT, "oracle", "_ref", "mashmap_ref")
+        if stock and os.path.exists(ref_bin):
+            sp = os.path.join(td, "stock.paf")
+            nt = max(4, min(64, 2 * usable_cpus()))
+            t0 = time.time()
+            p = subprocess.run([ref_bin, "-r", rp, "-q", qp, "-o", sp, "-t", str(nt)] + argv, capture_output=True, text=True)
+            tm = {}
+            for line in p.stderr.splitlines():
+                for key in ("computing the reference index", "mapping the query"):
+                    if "time spent " + key in line:
+                        tm[key] = float(line.split(":")[-1].split()[0])
+            out["stock"] = {"rc": p.returncode, "threads": nt, "wall_s": round(time.time() - t0, 1), "index_s": tm.get("computing the reference index"), "map_s": tm.get("mapping the query"),
+                            "value": round(bases / tm["mapping the query"] / 1e9, 4) if "mapping the query" in tm else None,
+                            "paf_identical": p.returncode == 0 and open(sp, "rb").read() == open(op, "rb").read()}
+        return out
+    finally:
+        if not keep_dir:
+            shutil.rmtree(td, ignore_errors=True)
+
+
 def e2e_fasta_to_paf(torch, dev, W, ref_np, nreads, threads):
     """the path a user runs, inside this run: the `mashmap_hip` command line (skch::Sketch + skch::Map on the C ABI) on the workload's
     FASTA files -- parse + pack, upload, kernels, download, chaining + filters, PAF text --, its own 'time spent mapping the query' and
@@ -959,27 +1084,9 @@ def e2e_fasta_to_paf(torch, dev, W, ref_np, nreads, threads):
         del contigs
         torch.cuda.empty_cache()
         write_s = time.time() - t0
-        env = dict(os.environ, MASHMAP_HIP_TIMING="1")
-        best = None
-        for rep in range(2):                                   # the second run finds the files in the page cache
-            t0 = time.time()
-            p = subprocess.run([exe, "-r", rp, "-q", qp, "-o", op, "-t", str(threads), "-s", str(W["seg"]), "--pi", str(int(round(W["pi"] * 100))), "-J", str(W["sketch"])],
-                               capture_output=True, text=True, env=env)
-            wall = time.time() - t0
-            if p.returncode != 0:
-                return {"error": "mashmap_hip exited with %d: %s" % (p.returncode, p.stderr[-400:])}
-            tmap = float(re.search(r"time spent mapping the query\s*:\s*([0-9.eE+-]+)", p.stderr).group(1))
-            tidx = float(re.search(r"time spent computing the reference index\s*:\s*([0-9.eE+-]+)", p.stderr).group(1))
-            dev_rows = re.findall(r"device stage \(.*?download of (\d+) candidate mappings\): ([0-9.eE+-]+) s \(upload ([0-9.eE+-]+), kernels ([0-9.eE+-]+), download ([0-9.eE+-]+)\)(?: \[bases (\d+)\])?", p.stderr)
-            rd_rows = re.findall(r"reader: parsed (\d+) records, (\d+) bases in ([0-9.eE+-]+) s", p.stderr)
-            post = [float(x) for x in re.findall(r"post stage: chain \+ filter \+ format ([0-9.eE+-]+) s", p.stderr)]
-            outp = [float(x) for x in re.findall(r", output ([0-9.eE+-]+) s", p.stderr)]
-            cur = dict(map_s=tmap, index_s=tidx, wall_s=wall, stderr=p.stderr, dev_rows=dev_rows, rd_rows=rd_rows, post_s=sum(post), output_s=sum(outp))
-            if best is None or tmap < best["map_s"]:
-                best = cur
-        if os.environ.get("MM_E2E_LOG"):                       # the stage log of the best run, for profiles/
-            with open(os.environ["MM_E2E_LOG"], "w") as f:
-                f.write("\n".join(l for l in best["stderr"].splitlines() if "timing" in l or "time spent" in l) + "\n")
+        best = run_cli_staged(exe, ["-r", rp, "-q", qp, "-o", op, "-t", str(threads), "-s", str(W["seg"]), "--pi", str(int(round(W["pi"] * 100))), "-J", str(W["sketch"])])
+        if "error" in best:
+            return best
         bases = nreads * L
         dev_rows = best["dev_rows"]
         # a device-stage row covers one pass over one or several reader batches: its bases are in the row (skch_map.hpp), else the reader's batches in order
@@ -995,10 +1102,7 @@ def e2e_fasta_to_paf(torch, dev, W, ref_np, nreads, threads):
                         "overlapped on successive batches; best of two runs" % (nreads, L, os.path.getsize(qp) / 1e9, sum(len(a) for a in ref_np) / 1e6),
                 "value": round(bases / best["map_s"] / 1e9, 3), "unit": "Gbp/s", "map_s": round(best["map_s"], 4), "index_s": round(best["index_s"], 3), "wall_s": round(best["wall_s"], 3),
                 "paf_lines": lines, "threads": threads, "usable_cpus": usable_cpus(), "scaled_to_reads": scaled, "fasta_write_s": round(write_s, 1),
-                "stages": {"reader_s": round(sum(float(r[2]) for r in best["rd_rows"]), 4), "reader_batches": len(best["rd_rows"]),
-                           "device_stage_s": round(sum(float(r[1]) for r in dev_rows), 4), "device_upload_wait_s": round(sum(float(r[2]) for r in dev_rows), 4),
-                           "device_kernels_s": round(sum(kern), 4), "device_download_s": round(sum(float(r[4]) for r in dev_rows), 4), "device_passes": len(dev_rows),
-                           "post_s": round(best["post_s"], 4), "output_s": round(best["output_s"], 4)},
+                "stages": stage_summary(best),
                 "device_stage": {"gbps_kernels_all_passes": round(sum(pass_bases) / max(1e-9, sum(kern)) / 1e9, 2),
                                  "gbps_kernels_full_size_passes": round(sum(b for b, _ in fb) / max(1e-9, sum(k for _, k in fb)) / 1e9, 2) if fb else None,
                                  "full_size_passes": len(fb), "bases_per_pass": pass_bases,
@@ -1030,6 +1134,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=30000)
     ap.add_argument("--sync-exchange", action="store_true", help="N>1: all-gatherv on the compute stream instead of overlapped with the next batch")
     ap.add_argument("--repeat-rich-reference", action="store_true", help="draw reference and reads from make_repeat_rich_reference instead of uniform ACGT (not a BASELINE configuration)")
+    ap.add_argument("--stock", action="store_true", help="configs2: also run the stock binary on the same FASTA files (index ~30 s + mapping) and compare the PAF bytes")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--north-star-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -1071,6 +1176,8 @@ def main():
     if args.seg and args.seg != W["seg"]:
         W["seg"] = args.seg; W["label"] += ", segLength %d" % args.seg
         wl_key = "%s_seg%d" % (args.workload, args.seg)
+    if W.get("assembly"):                               # the query is the reference's contigs, diverged and rearranged: same count, same lengths
+        W["reads"], W["read_len"] = min(W["reads"], W["ref_contigs"]), W["ref_contig_len"]
     is_default = args.workload == "configs1" and not scaled and wl_key == args.workload
     nb = args.batches
 
@@ -1122,6 +1229,14 @@ def main():
     # the CPU leg indexes the reference with the stock binary: minutes beyond a few hundred Mbp, so it rides on the default workload only
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline and sum(len(a) for a in ref_np) <= 400e6
     want_e2e = is_default and rank == 0 and world == 1 and not args.no_e2e
+    want_e2e2 = bool(W.get("assembly")) and rank == 0 and world == 1 and not args.no_e2e
+    e2e2 = None
+    if want_e2e2:                                       # before the reads take the room: needs the reference on the device once more
+        try:
+            e2e2 = e2e_assembly(torch, dev, W, contigs, max(4, min(128, os.cpu_count() or 1)), stock=args.stock)
+            log("[bench] configs[2] FASTA -> PAF: %s" % {k: e2e2.get(k) for k in ("value", "map_s", "stages", "stock", "error")})
+        except Exception as e:
+            log("[bench] e2e_assembly failed:", repr(e)); e2e2 = {"error": repr(e)}
     t0 = time.time()
     nF, reads_np = load_batches(torch, dev, ctx, contigs, W, nreads, nb, seed=1000 + rank, seq_base=rank * nreads,
                                 keep_first=min(nreads, args.cpu_sample) if want_cpu else 0)
@@ -1161,7 +1276,8 @@ def main():
             "metric": "query Gbp/s sketch+L1/L2 map (pi=85, s=5000)", "value": round(value, 4), "unit": "Gbp/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "%s%s: %d x %d bp reads/GPU (%s ONT-like error) vs %.0f Mbp synthetic reference (%d contigs)"
+            "config": {"workload": ("%s%s: %d x %d bp assembly contigs/GPU (the reference + %s substitutions + 1-5 Mbp inversions / translocations) vs %.0f Mbp synthetic reference (%d contigs)"
+                                    if W.get("assembly") else "%s%s: %d x %d bp reads/GPU (%s ONT-like error) vs %.0f Mbp synthetic reference (%d contigs)")
                                    % (W["label"], " SCALED (%s)" % ", ".join(scaled) if scaled else "", nreads, READ_LEN,
                                       "%.0f%%" % (W["err"][0] * 100) if W["err"][0] == W["err"][1] else "%.0f-%.0f%%" % (W["err"][0] * 100, W["err"][1] * 100),
                                       ref_mbp, len(ref_lens)),
@@ -1180,7 +1296,9 @@ def main():
             "kernels": kernels,
         }
         # the side measurements never take the headline with them
-        if world == 1 and not args.no_host_path:
+        if e2e2 is not None:
+            out["e2e"] = e2e2
+        if world == 1 and not args.no_host_path and not W.get("assembly"):
             try:
                 out["host_path"] = host_path(ctx, W, nreads, ref_lens, step_ms)
             except Exception as e:

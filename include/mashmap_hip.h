@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define MM_ABI_VERSION 1
+#define MM_ABI_VERSION 2     /* 2: mm_pass_stats writes 5 counts; mm_reads_prefetch_packed_append reports whether it staged; mm_reads_prefetch_drop */
 
 enum {
   MM_OK = 0,
@@ -221,14 +221,21 @@ int mm_reads_prefetch_packed(mm_ctx* ctx, const uint32_t* bases2, const uint32_t
  * mm_reads_prefetch_packed_append is mm_reads_prefetch_packed that ADDS a piece to what has been sent ahead instead of replacing it
  * (same thread exception): the upload takes every part it finds staged from there and copies the others itself; staged pieces an upload
  * does not name stay staged for the next one.  reservePackedBases: packed bases the staging area should hold when it has to be
- * (re)allocated -- it can only grow while nothing is staged; a piece that does not fit is simply not staged.
+ * (re)allocated -- it can only grow while nothing is staged; a piece that does not fit is simply not staged: *staged (may be NULL)
+ * says which happened, and a piece that was declined travels with its upload.
+ * A staged piece is recognised by its two host pointers and its packed length: between the call that stages it and the upload that names
+ * it (or mm_reads_prefetch_drop) the host words must neither change nor be handed to another batch -- a caller that recycles page-locked
+ * buffers gives a buffer back only after the upload of its batch has returned (skch::Map does), or drops what it staged.  An ASCII upload
+ * (mm_reads_upload / _device) and mm_reads_prefetch / mm_reads_prefetch_packed drop every staged piece; mm_reads_prefetch_drop does
+ * nothing else.
  */
 typedef struct {
   const uint32_t* bases2; const uint32_t* nmask; const uint8_t* readHasN; const int32_t* readLengths; const int64_t* readStarts;
   size_t nReads; const int32_t* readRefGroup; const int32_t* readSelfSeqId;
 } mm_packed_part;
 int mm_reads_upload_packed_parts(mm_ctx* ctx, const mm_packed_part* parts, size_t nParts, int32_t seqCounterBase);
-int mm_reads_prefetch_packed_append(mm_ctx* ctx, const uint32_t* bases2, const uint32_t* nmask, size_t nPackedBases, size_t reservePackedBases);
+int mm_reads_prefetch_packed_append(mm_ctx* ctx, const uint32_t* bases2, const uint32_t* nmask, size_t nPackedBases, size_t reservePackedBases, int* staged);
+int mm_reads_prefetch_drop(mm_ctx* ctx);
 size_t mm_pack_read(const char* ascii, size_t len, uint32_t* bases2, uint32_t* nmask);
 size_t mm_pack_read_portable(const char* ascii, size_t len, uint32_t* bases2, uint32_t* nmask);
 int mm_reads_packed_download(mm_ctx* ctx, uint32_t* bases2, uint32_t* nmask, uint32_t* readHasN, size_t* nPackedBases);
@@ -263,7 +270,7 @@ int mm_map_fragments(mm_ctx* ctx);
 /* How the last mm_map_fragments went: the number of times the host waited for the device inside it, and whether it was a steady-state
  * pass -- the first pass of a context sizes every staging buffer from counts it reads back stage by stage (5-7 waits); the passes behind
  * it launch against those capacities with the counts left on the device and wait once, at the end.  A pass that outgrows a buffer is
- * redone the sized way (and counted as such here).  counts (5 entries, may be NULL): L1 candidates, L2 loci, fragments whose interval
+ * redone the sized way (and counted as such here).  counts (FIVE entries since MM_ABI_VERSION 2 -- the caller's array holds at least 5 --, may be NULL): L1 candidates, L2 loci, fragments whose interval
  * points went through HBM (more than the fused kernel holds; as of the last sized pass), entries reserved for the L2 streams (one per
  * index event a candidate touches: what k_l2_locate reads 16 bytes for and k_l2_sweep at most 4), fragments the fast sketch kernel handed to
  * the exact one (the hard list: fewer than sketchSize distinct survivors below the cut, or an LDS structure overflowed). */

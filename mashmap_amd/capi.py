@@ -130,7 +130,8 @@ def load():
         "mm_pass_totals": (C.c_int, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "mm_reads_exchange": (C.c_int, [vp, C.c_int]),
         "mm_reads_upload_packed_parts": (C.c_int, [vp, vp, sz, C.c_int32]),
-        "mm_reads_prefetch_packed_append": (C.c_int, [vp, vp, vp, sz, sz]),
+        "mm_reads_prefetch_packed_append": (C.c_int, [vp, vp, vp, sz, sz, C.POINTER(C.c_int)]),
+        "mm_reads_prefetch_drop": (C.c_int, [vp]),
         "mm_synchronize": (C.c_int, [vp]),
         "mm_stream": (vp, [vp]),
     }
@@ -156,7 +157,7 @@ EXPORTS = ["mm_abi_version", "mm_create", "mm_destroy", "mm_last_error", "mm_ind
            "mm_gathered_counts", "mm_gathered_download", "mm_gathered_device", "mm_index_replicate", "mm_stat_replay_tables", "mm_host_alloc", "mm_host_free", "mm_reads_prefetch",
            "mm_reads_upload_packed", "mm_reads_prefetch_packed", "mm_pack_read", "mm_pack_read_portable", "mm_reads_packed_download",
            "mm_index_layout_get", "mm_pass_stats", "mm_comm_info", "mm_pass_totals", "mm_reads_exchange", "mm_reads_upload_packed_parts",
-           "mm_reads_prefetch_packed_append"]
+           "mm_reads_prefetch_packed_append", "mm_reads_prefetch_drop"]
 
 
 def stat_sketch_cutoffs(sketchSize, k, hg=True):
@@ -344,7 +345,7 @@ class Context:
             arr[i] = PackedPart(_ptr(b2), _ptr(nm), _ptr(hasn), _ptr(lens), _ptr(st), len(lens), _ptr(rg), _ptr(ss))
         reserve = sum(k[1].size * 32 for k in keep)
         for i in stage:
-            self._ck(self.lib.mm_reads_prefetch_packed_append(self.h, _ptr(keep[i][0]), _ptr(keep[i][1]), keep[i][1].size * 32, reserve), "mm_reads_prefetch_packed_append")
+            self._ck(self.lib.mm_reads_prefetch_packed_append(self.h, _ptr(keep[i][0]), _ptr(keep[i][1]), keep[i][1].size * 32, reserve, None), "mm_reads_prefetch_packed_append")
         self._ck(self.lib.mm_reads_upload_packed_parts(self.h, arr, len(parts), seqCounterBase), "mm_reads_upload_packed_parts")
         self._nreads = sum(len(k[3]) for k in keep)
         return self.num_fragments()

@@ -1,4 +1,5 @@
 // mashmap_amd/csrc/mm_api.hip -- the extern "C" surface declared in include/mashmap_hip.h.
+#include <chrono>
 #include "mm_internal.h"
 #include <algorithm>
 #include <cstring>
@@ -262,7 +263,8 @@ static int upload_reads_ascii(mm_ctx* c, const void* ascii, bool onDevice, const
   // bytes mm_reads_prefetch has already sent (same host range): take that buffer and wait for its copy on the device
   const bool prefetched = c->prefetchValid && !onDevice && nSrc && c->prefetchPtr == (const void*)((const char*)ascii + srcBase) && c->prefetchBytes == nSrc;
   c->prefetchValid = false;
-  if (prefetched) { std::swap(c->dAscii, c->dAsciiNext); c->staged.clear(); c->stagedBytes = 0; MM_HIP(c, hipStreamWaitEvent(c->stream, c->copyDone, 0)); }
+  c->staged.clear(); c->stagedBytes = 0;             // an ASCII upload drops whatever packed pieces were sent ahead (header contract): nothing stale can match later
+  if (prefetched) { std::swap(c->dAscii, c->dAsciiNext); MM_HIP(c, hipStreamWaitEvent(c->stream, c->copyDone, 0)); }
   else MM_HIP(c, c->dAscii.ensure(nSrc + 64));
   { const int rc = ensure_read_buffers(c, nReads, pk, dfr.size()); if (rc != MM_OK) return rc; }
   if (nSrc && !prefetched) MM_HIP(c, hipMemcpyAsync(c->dAscii.p, (const char*)ascii + srcBase, nSrc, onDevice ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
@@ -405,7 +407,8 @@ int mm_reads_prefetch(mm_ctx* c, const char* bases, size_t nBytes) {
 }
 
 // adds one packed piece to the staging area (prefetchMu held)
-static int stage_packed(mm_ctx* c, const uint32_t* bases2, const uint32_t* nmask, size_t nPackedBases, size_t reservePackedBases) {
+static int stage_packed(mm_ctx* c, const uint32_t* bases2, const uint32_t* nmask, size_t nPackedBases, size_t reservePackedBases, int* stagedOut = nullptr) {
+  if (stagedOut) *stagedOut = 0;
   if (nPackedBases % 32) { c->err = "mm_reads_prefetch_packed: the packed length of a batch is a multiple of 32 bases"; return MM_ERR_ARG; }
   { const int rc = prefetch_streams(c); if (rc != MM_OK) return rc; }
   c->prefetchValid = false;                           // (packed pieces replace an ASCII batch sent ahead)
@@ -432,6 +435,7 @@ static int stage_packed(mm_ctx* c, const uint32_t* bases2, const uint32_t* nmask
   MM_HIP(c, hipEventRecord(c->copyDone, c->copyStream));   // the event always marks the last piece: an upload that waits for it has them all
   c->staged.push_back(mm_ctx::StagedPart{bases2, nmask, nPackedBases, c->stagedBytes});
   c->stagedBytes += bytes;                            // where the next piece goes
+  if (stagedOut) *stagedOut = 1;
   return MM_OK;
 }
 
@@ -443,10 +447,18 @@ int mm_reads_prefetch_packed(mm_ctx* c, const uint32_t* bases2, const uint32_t* 
   return stage_packed(c, bases2, nmask, nPackedBases, nPackedBases);
 }
 
-int mm_reads_prefetch_packed_append(mm_ctx* c, const uint32_t* bases2, const uint32_t* nmask, size_t nPackedBases, size_t reservePackedBases) {
+int mm_reads_prefetch_packed_append(mm_ctx* c, const uint32_t* bases2, const uint32_t* nmask, size_t nPackedBases, size_t reservePackedBases, int* staged) {
   std::lock_guard<std::mutex> prefetchLock(c->prefetchMu);
+  if (staged) *staged = 0;
   if (!bases2 || !nmask || !nPackedBases) return MM_OK;
-  return stage_packed(c, bases2, nmask, nPackedBases, reservePackedBases);
+  return stage_packed(c, bases2, nmask, nPackedBases, reservePackedBases, staged);
+}
+
+int mm_reads_prefetch_drop(mm_ctx* c) {
+  std::lock_guard<std::mutex> prefetchLock(c->prefetchMu);
+  c->prefetchValid = false;
+  c->staged.clear(); c->stagedBytes = 0;
+  return MM_OK;
 }
 
 void* mm_host_alloc(size_t bytes) {
@@ -521,12 +533,21 @@ int mm_map_fragments(mm_ctx* c) {
   if (!c->idx.ready) { c->err = "mm_map_fragments: no index resident (mm_index_upload / mm_index_build first)"; return MM_ERR_STATE; }
   if (!c->nMinHits) { c->err = "mm_map_fragments: mm_set_tables first"; return MM_ERR_STATE; }
   MM_HIP(c, hipSetDevice(c->device));
+  static const bool timing = getenv("MASHMAP_HIP_TIMING") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
+  const double a0 = g_mmAllocSeconds;
   int rc = mm_launch_sketch(c);
   if (rc != MM_OK) return rc;
   c->sketched = true;
+  const auto t1 = std::chrono::steady_clock::now();
   rc = mm_launch_map(c);
   if (rc != MM_OK) return rc;
   if (!c->lastSteady) { MM_HIP(c, hipStreamSynchronize(c->stream)); c->nSyncs++; }   // a steady-state pass ends with its one synchronisation
+  if (timing && !c->lastSteady) {
+    auto sec = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    fprintf(stderr, "[mashmap_hip::timing] sized pass (%zu fragments, %llu host waits): sketch launch %.4f s, lookup .. selection %.4f s, of both in hipMalloc / hipFree %.4f s\n",
+            c->nFrags, (unsigned long long)c->nSyncs, sec(t0, t1), sec(t1, std::chrono::steady_clock::now()), g_mmAllocSeconds - a0);
+  }
   if (c->profile) mm_profile_collect(c);
   c->mapped = true;
   c->nPasses++; if (c->lastSteady) c->nSteadyPasses++;

@@ -1,6 +1,7 @@
 // mashmap_amd/csrc/mm_internal.h -- shared between the translation units of libmashmap_hip.so.
 // gfx950 (MI355X, wave64) only.  No CUDA, no portability macros.
 #pragma once
+#include <chrono>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <mutex>
@@ -15,15 +16,28 @@
 // ---------------------------------------------------------------------------------------------
 // host-side helpers
 // ---------------------------------------------------------------------------------------------
+inline double g_mmAllocSeconds = 0.0;       // wall time inside hipMalloc / hipFree of DevBuf::ensure (MASHMAP_HIP_TIMING reports it per sized pass; one stream-ordered batch per context)
 struct DevBuf {
   void* p = nullptr;
   size_t bytes = 0;
   hipError_t ensure(size_t need) {          // grow-only; contents are NOT preserved
     if (need <= bytes) return hipSuccess;
-    if (p) { hipError_t e = hipFree(p); p = nullptr; bytes = 0; if (e != hipSuccess) return e; }
+    const auto t0 = std::chrono::steady_clock::now();
+    // the new buffer first, with an eighth of head room; the old one is given up only once the new one is there -- or, when the device
+    // cannot hold both, before a second attempt at the exact size (a failed growth leaves the buffer as it was whenever it can)
+    void* q = nullptr;
     size_t cap = need + need / 8 + 256;
-    hipError_t e = hipMalloc(&p, cap);
-    if (e == hipSuccess) bytes = cap;
+    hipError_t e = hipMalloc(&q, cap);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+      e = hipMalloc(&q, cap);
+      if (e != hipSuccess) { (void)hipGetLastError(); cap = need + 256; e = hipMalloc(&q, cap); }
+    } else if (p) {
+      (void)hipFree(p);
+    }
+    if (e == hipSuccess) { p = q; bytes = cap; }
+    g_mmAllocSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return e;
   }
   void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
@@ -200,9 +214,18 @@ inline void mm_profile_collect(mm_ctx* c) {
 // that the larger batches behind it are steady-state passes instead of being sized (and their buffers reallocated) again.
 //   mm_frag_cap: fragments to size per-fragment buffers for;  mm_scaled: a count of this pass scaled to what the announced batch would bring
 inline size_t mm_frag_cap(const mm_ctx* c, size_t nF) { return nF > c->reserveFrags ? nF : c->reserveFrags; }
-inline size_t mm_scaled(const mm_ctx* c, size_t count) {
+// A scaled count never claims more than an eighth of the device memory that is free when it is asked for (`bytesPer` = bytes the buffer
+// holds per counted item): the scaling is a convenience for the passes behind this one -- a repeat-rich first batch must not turn a pass
+// that fits into an out-of-memory error; a later, larger batch that outgrows the clamped buffer is redone the sized way, as without scaling.
+inline size_t mm_scaled(const mm_ctx* c, size_t count, size_t bytesPer) {
   const size_t nF = c->nFrags ? c->nFrags : 1;
-  return c->reserveFrags > nF ? (size_t)((double)count * (double)c->reserveFrags / (double)nF) + 1 : count;
+  if (c->reserveFrags <= nF) return count;
+  size_t scaled = (size_t)((double)count * (double)c->reserveFrags / (double)nF) + 1;
+  size_t freeB = 0, totalB = 0;
+  if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) { (void)hipGetLastError(); return count; }
+  const size_t most = freeB / 8 / (bytesPer ? bytesPer : 1);
+  if (scaled > most) scaled = most > count ? most : count;
+  return scaled;
 }
 
 // launchers implemented in the .hip files

@@ -1060,7 +1060,7 @@ static int mm_launch_l2_window(mm_ctx* c, unsigned long long* cnt) {
     MM_HIP(c, hipMemcpyAsync(hc, cnt, 64, hipMemcpyDeviceToHost, c->stream));
     MM_HIP(c, hipStreamSynchronize(c->stream));
     if (hc[6] & 1ull) { if ((size_t)nC * (size_t)locap * 2 * sizeof(L2Tmp) > ((size_t)64 << 30)) break; locap *= 2; continue; }
-    if (hc[5]) { const size_t need = mm_scaled(c, (size_t)hc[4]); c->l2Cap = need + need / 8 + 1024; continue; }
+    if (hc[5]) { const size_t need = mm_scaled(c, (size_t)hc[4], sizeof(mm_l2_locus)); c->l2Cap = need + need / 8 + 1024; continue; }
     break;
   }
   if (hc[6] & 1ull) { c->err = "an L1 candidate with more tied L2 loci than 64 GiB of staging can hold"; return MM_ERR_CAPACITY; }
@@ -1101,7 +1101,7 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt, bool steady) {
   const int s = c->P.sketchSize;
   // sized pass: the candidates are counted (c->nL1) and the candidate-indexed buffers get an eighth of head room, which is what a
   // steady-state pass (count on the device: cnt[2]) launches against
-  if (!steady) { const size_t n1 = mm_scaled(c, c->nL1); c->candCap = n1 + n1 / 8 + 1024; }
+  if (!steady) { const size_t n1 = mm_scaled(c, c->nL1, 96 + 2 * (size_t)((c->P.sketchSize + 3) & ~1)); c->candCap = n1 + n1 / 8 + 1024; }
   const int nC = steady ? (int)c->candCap : (int)c->nL1;              // candidates the launches cover
   const int nCbuf = (int)c->candCap;
   const unsigned long long* nDev = steady ? cnt + 2 : nullptr;
@@ -1171,7 +1171,7 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt, bool steady) {
     }
   }
   if (!steady) {
-    const size_t opsFor = chunks.size() == 1 ? mm_scaled(c, (size_t)maxChunkOps) : (size_t)maxChunkOps;
+    const size_t opsFor = chunks.size() == 1 ? mm_scaled(c, (size_t)maxChunkOps, 4) : (size_t)maxChunkOps;
     MM_HIP(c, c->dL2Ops.ensure((opsFor + opsFor / 16) * 4 + 256));   // a sixteenth of head room for the steady-state passes behind this one
     c->l2Chunks = chunks.size();                                                          // a batch that needs several chunks stays with the sized passes
   }
@@ -1339,7 +1339,7 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt, bool steady) {
       MM_HIP(c, hipMemcpyAsync(cnt + 6, &flags, 8, hipMemcpyHostToDevice, c->stream));
       continue;
     }
-    if (hc[5]) { const size_t need = mm_scaled(c, (size_t)hc[4]); c->l2Cap = need + need / 8 + 1024; continue; }
+    if (hc[5]) { const size_t need = mm_scaled(c, (size_t)hc[4], sizeof(mm_l2_locus)); c->l2Cap = need + need / 8 + 1024; continue; }
     break;
   }
   if (hc[6] & 4ull) { c->err = "internal: an L2 stream outgrew the reservation k_l2_extents made for it"; return MM_ERR_CAPACITY; }

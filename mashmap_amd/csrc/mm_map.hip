@@ -1306,11 +1306,11 @@ static int map_pass(mm_ctx* c, const bool steady) {
     MM_HIP(c, hipMemcpyAsync(c->hPass + 16, c->dCounters.as<unsigned long long>() + 48, 8, hipMemcpyDeviceToHost, c->stream));
     MM_SYNC(c);
     c->lastHard = (size_t)(c->hPass[16] & 0xffffffffull);
-    if (hc[1]) { const size_t need = mm_scaled(c, (size_t)hc[0]); c->ptsCap = need + need / 8 + 4096; continue; }
+    if (hc[1]) { const size_t need = mm_scaled(c, (size_t)hc[0], 16); c->ptsCap = need + need / 8 + 4096; continue; }
     if (hc[3]) {                                              // some region overflowed: size for the largest one seen
       unsigned long long mx = 0;
       for (int r = 0; r < MM_L1_REGIONS; r++) mx = std::max(mx, hcur[(size_t)r * MM_L1_CURSOR_STRIDE]);
-      mx = (unsigned long long)mm_scaled(c, (size_t)mx);
+      mx = (unsigned long long)mm_scaled(c, (size_t)mx, sizeof(mm_l1_candidate) * MM_L1_REGIONS);
       c->l1Cap = (size_t)(mx + mx / 4 + 256) * MM_L1_REGIONS; continue;
     }
     break;
@@ -1370,6 +1370,7 @@ static int map_pass(mm_ctx* c, const bool steady) {
       if (!steady) {
         MM_HIP(c, hipMemcpyAsync(hcls, cls, 8, hipMemcpyDeviceToHost, c->stream));
         MM_SYNC(c);
+        if (getenv("MM_DEBUG")) fprintf(stderr, "[mm] point path: %d queued fragments, after the filter %u lists of more than %d points (LDS sorter), %u beyond the LDS sorter\n", nBig, hcls[0], MM_SORT_WAVECAP, hcls[1]);
       }
       if (hcls[0]) hipLaunchKernelGGL(k_sort_points_block, dim3(hcls[0]), dim3(256), 0, c->stream, cls, c->dPtOff.as<int64_t>(), c->dPts.as<uint64_t>(), listB.as<int32_t>(), sortIds);
       if (hcls[1]) hipLaunchKernelGGL(k_sort_points_global, dim3(hcls[1]), dim3(1024), 0, c->stream, cls + 1, c->dPtOff.as<int64_t>(), c->dPts.as<uint64_t>(), listC.as<int32_t>(), sortIds);

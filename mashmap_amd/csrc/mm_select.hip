@@ -105,7 +105,7 @@ int mm_launch_select(mm_ctx* c, bool steady) {
   const int rc = mm_scan_i32_to_i64(c, nF, c->dSelCnt.as<int32_t>(), c->dSelOff.as<int64_t>(), &total);
   c->nSyncs++;
   if (rc != MM_OK) return rc;
-  { const size_t tot = mm_scaled(c, (size_t)total); MM_HIP(c, c->dMappings.ensure((tot + tot / 16) * sizeof(mm_mapping) + 4096)); }   // head room for the steady-state passes behind this one
+  { const size_t tot = mm_scaled(c, (size_t)total, sizeof(mm_mapping)); MM_HIP(c, c->dMappings.ensure((tot + tot / 16) * sizeof(mm_mapping) + 4096)); }   // head room for the steady-state passes behind this one
   if (total) {
     hipLaunchKernelGGL((k_l2_select<true>), dim3((nF + 255) / 256), dim3(256), 0, c->stream, A, (int32_t*)nullptr, c->dSelOff.as<int64_t>(), c->dMappings.as<mm_mapping>(),
                        (const int64_t*)nullptr, 0ll, (unsigned long long*)nullptr, (const unsigned long long*)nullptr);

@@ -116,6 +116,66 @@ static inline size_t pack2bit(const char* ascii, size_t n, uint32_t* bases2, uin
   return pack2bit_scalar(ascii, n, bases2, nmask);
 }
 
+// ---- line breaks.  A FASTA body is sequence bytes with a '\n' every so many columns; the parser wants them gone before the packer sees
+// the bytes.  Per-line memchr + memcpy costs more than the packing at 60..100 columns, so: strip_newlines() compacts a range with
+// AVX-512 VBMI2 (vpcompressb, 64 bytes per step) where the CPU has it, count_newlines() counts with AVX2 (the sizing pass of the
+// split-record parser, seq_parse.hpp); plain loops otherwise.
+static inline size_t strip_newlines_scalar(const char* p, size_t n, char* dst) {
+  const char* e = p + n; char* d = dst;
+  while (p < e) {
+    const char* nl = (const char*)memchr(p, '\n', (size_t)(e - p));
+    const size_t m = (size_t)((nl ? nl : e) - p);
+    memcpy(d, p, m); d += m;
+    p = nl ? nl + 1 : e;
+  }
+  return (size_t)(d - dst);
+}
+static inline size_t count_newlines_scalar(const char* p, size_t n) {
+  size_t c = 0;
+  for (size_t i = 0; i < n; i++) c += p[i] == '\n';
+  return c;
+}
+#if defined(__x86_64__)
+__attribute__((target("avx512f,avx512bw,avx512vbmi2")))
+static inline size_t strip_newlines_vbmi2(const char* p, size_t n, char* dst) {     // dst needs room for n + 64 bytes
+  const __m512i nlv = _mm512_set1_epi8('\n');
+  char* d = dst;
+  size_t i = 0;
+  for (; i + 64 <= n; i += 64) {
+    const __m512i v = _mm512_loadu_si512((const void*)(p + i));
+    const __mmask64 keep = _mm512_cmpneq_epi8_mask(v, nlv);
+    _mm512_storeu_si512((void*)d, _mm512_maskz_compress_epi8(keep, v));
+    d += __builtin_popcountll((unsigned long long)keep);
+  }
+  for (; i < n; i++) if (p[i] != '\n') *d++ = p[i];
+  return (size_t)(d - dst);
+}
+__attribute__((target("avx2")))
+static inline size_t count_newlines_avx2(const char* p, size_t n) {
+  const __m256i nlv = _mm256_set1_epi8('\n');
+  size_t c = 0, i = 0;
+  for (; i + 32 <= n; i += 32) c += (size_t)__builtin_popcount((unsigned)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256((const __m256i*)(p + i)), nlv)));
+  for (; i < n; i++) c += p[i] == '\n';
+  return c;
+}
+static inline bool have_vbmi2() {
+  static const bool v = __builtin_cpu_supports("avx512vbmi2") && __builtin_cpu_supports("avx512bw") && pack2bit_isa() == 2;   // MASHMAP_HIP_PACK_ISA narrows this too
+  return v;
+}
+#endif
+static inline size_t strip_newlines(const char* p, size_t n, char* dst) {
+#if defined(__x86_64__)
+  if (have_vbmi2()) return strip_newlines_vbmi2(p, n, dst);
+#endif
+  return strip_newlines_scalar(p, n, dst);
+}
+static inline size_t count_newlines(const char* p, size_t n) {
+#if defined(__x86_64__)
+  if (pack2bit_isa() >= 1) return count_newlines_avx2(p, n);
+#endif
+  return count_newlines_scalar(p, n);
+}
+
 // Streaming form for input that arrives in pieces (FASTA lines): feed() any number of byte ranges, finish() once.  Groups of 32 bases
 // are packed as soon as they are complete; at most 31 bases wait in `carry`.
 struct Pack2bitStream {

@@ -23,6 +23,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdint>
 #include <cstdio>
@@ -171,6 +172,14 @@ inline bool record_starts_at(const char* p, const char* e, bool fasta) {
 }
 // first record start at or after p (p need not be a line start), or e
 inline const char* next_record(const char* base, const char* p, const char* e, bool fasta) {
+  if (fasta) {                                               // a '>' right behind a line break (or at the very start): one memchr per '>' in the data, not per line
+    for (const char* q = p; q < e; q++) {
+      q = (const char*)memchr(q, '>', (size_t)(e - q));
+      if (!q) return e;
+      if (q == base || q[-1] == '\n') return q;
+    }
+    return e;
+  }
   const char* q = (p == base || p[-1] == '\n') ? p : next_line(p, e);
   while (q < e && !record_starts_at(q, e, fasta)) q = next_line(q, e);
   return q;
@@ -295,7 +304,20 @@ class MmapSource : public RawSource {
     const char* b = data_ + pos_; const char* e = data_ + size_;
     const char* cut = e;
     if ((size_t)(e - b) > window_) {
-      cut = next_record(data_, b + window_, e, fasta);           // the window grows to the next record boundary (a record is never split)
+      // a record is never split between windows.  FASTA: the window ends at the last record start it holds (so that it fits the buffers
+      // sized for one window: with 125 Mbp contigs the next boundary may be a quarter of a window away), and grows to the next one only
+      // when a single record is longer than the window; FASTQ records are short: the next boundary
+      cut = nullptr;
+      if (fasta) {
+        const char* q = b + window_;
+        while (q > b + 1) {
+          const char* g = (const char*)memrchr(b + 1, '>', (size_t)(q - (b + 1)));
+          if (!g) break;
+          if (g[-1] == '\n') { cut = g; break; }
+          q = g;
+        }
+      }
+      if (!cut) cut = next_record(data_, b + window_, e, fasta);
     }
     p = b; n = (size_t)(cut - b); pos_ += n;
     return true;
@@ -422,6 +444,7 @@ class BatchReader {
   // index of the file the batch returned last came from, and whether it was that file's last batch
   size_t fileIndex() const { return curFile_; }
   bool fileDone() const { return fileDone_; }
+  size_t splitWindows() const { return splitWindows_; }   // windows that went through parseWindowPackedSplit (records cut across threads)
   void release(ParsedBatch& b) { if (b.bases) free_(b.bases); b.bases = nullptr; b.cap = 0; }
 
   bool next(ParsedBatch& out) {
@@ -446,6 +469,7 @@ class BatchReader {
   std::unordered_set<std::string> keepSeq_; std::string keepPrefix_;
   WorkerPool pool_;
   Alloc alloc_; Free free_;
+  size_t splitWindows_ = 0;
   bool packOutput_ = false;          // batches carry 2-bit codes + N mask (what mm_reads_upload_packed takes) instead of ASCII
   detail::RawSource* src_ = nullptr; size_t nextFile_ = 0, curFile_ = 0; bool fasta_ = true, firstWindow_ = true, fileDone_ = false;
 
@@ -495,6 +519,128 @@ class BatchReader {
     });
   }
 
+  // FASTA windows whose records are longer than a thread's piece (assembly contigs, chromosomes: a 512 MB window of 125 Mbp records
+  // holds four of them): the pieces are cut at LINE boundaries instead, anywhere inside a record.  Pass A, every thread over its piece:
+  // the records that start there and how many sequence bytes each (partial) record has in the piece -- a line scan, no packing.  A prefix
+  // sum over the parts gives every part its place inside its record and every record its 32-aligned place in the batch.  Pass B, every
+  // thread over its piece again: packs its parts where they belong.  The packed words hold 32 bases each, so a part that does not start
+  // on a 32-base boundary of its record leaves its first few bases to the thread of the part before it, which reads on past its piece's
+  // end until its last word is full (or the record ends).  Same ParsedBatch as the one-pass form, without gaps between records.
+  struct SplitPart { const char* hdr; const char* body; const char* end; int64_t bases; size_t rec; int64_t off; uint8_t hasN; };
+  bool parseWindowPackedSplit(const char* p, size_t n, unsigned T, ParsedBatch& out) {
+    const char* b = p; const char* e = p + n;
+    std::vector<const char*> cut(T + 1, e);
+    cut[0] = b;
+    for (unsigned t = 1; t < T; t++) { const char* q = b + n / T * t; cut[t] = q[-1] == '\n' ? q : detail::next_line(q, e); }
+    for (unsigned t = 1; t <= T; t++) if (cut[t] < cut[t - 1]) cut[t] = cut[t - 1];
+    const bool mapped = src_ && src_->fileMapped();
+    const bool trace = getenv("MASHMAP_HIP_PARSE_TRACE") != nullptr;
+    const auto tA = std::chrono::steady_clock::now();
+    std::vector<std::vector<SplitPart>> parts(T);
+    detail::run_parallel(pool_, T, [&](unsigned t) {
+      const char* q = cut[t]; const char* pe = cut[t + 1];
+      if (mapped && pe > q) {
+        const uintptr_t a = (uintptr_t)q & ~(uintptr_t)4095, z = ((uintptr_t)pe + 4095) & ~(uintptr_t)4095;
+        (void)madvise((void*)a, (size_t)(z - a), 22 /* MADV_POPULATE_READ */);
+      }
+      auto& P = parts[t];
+      if (q < pe && *q != '>') P.push_back(SplitPart{nullptr, q, pe, 0, 0, 0, 0});          // the piece starts inside a record
+      while (q < pe) {
+        if (*q == '>') {                                       // q is a line start: a header line
+          if (!P.empty()) P.back().end = q;
+          const char* nl = (const char*)memchr(q, '\n', (size_t)(pe - q));
+          const char* nx = nl ? nl + 1 : pe;
+          P.push_back(SplitPart{q, nx, pe, 0, 0, 0, 0});
+          q = nx;
+          continue;
+        }
+        // sequence lines up to the next header line ('>' right behind a line break) or the piece's end: bytes minus line breaks
+        const char* h = q;
+        for (;;) {
+          h = (const char*)memchr(h, '>', (size_t)(pe - h));
+          if (!h) { h = pe; break; }
+          if (h[-1] == '\n') break;                            // h > q here: q itself is not '>'
+          h++;
+        }
+        P.back().bases += (int64_t)(h - q) - (int64_t)count_newlines(q, (size_t)(h - q));
+        q = h;
+      }
+    });
+    const auto tB = std::chrono::steady_clock::now();
+    // parts -> records
+    size_t nRec = 0;
+    for (unsigned t = 0; t < T; t++) for (auto& pt : parts[t]) if (pt.hdr) nRec++;
+    out.names.resize(nRec); out.offs.assign(nRec + 1, 0); out.packOffs.assign(nRec + 1, 0); out.lens.assign(nRec, 0); out.hasN.assign(nRec, 0);
+    std::vector<int64_t> recLen(nRec, 0);
+    std::vector<uint8_t> keep(nRec, 1);
+    size_t r = 0; bool any = false;
+    for (unsigned t = 0; t < T; t++) for (auto& pt : parts[t]) {
+      if (pt.hdr) {
+        if (any) r++;
+        any = true;
+        const char* nb; const char* ne;
+        detail::record_name(pt.hdr, pt.body, nb, ne);
+        out.names[r].assign(nb, ne);
+        keep[r] = (keepPrefix_.empty() || out.names[r].compare(0, keepPrefix_.size(), keepPrefix_) == 0) && (keepSeq_.empty() || keepSeq_.count(out.names[r]));
+      } else if (!any) return false;                         // a window always starts with a header line
+      pt.rec = r; pt.off = recLen[r]; recLen[r] += pt.bases;
+    }
+    int64_t at = 0, pk = 0;
+    for (size_t i = 0; i < nRec; i++) {
+      if (!keep[i]) recLen[i] = 0;
+      if (recLen[i] > 0x7fffffff) return false;              // refused further up with the reference's message (the two-pass form keeps 64-bit lengths)
+      out.offs[i] = at; out.lens[i] = (int32_t)recLen[i]; out.packOffs[i] = pk;
+      at += recLen[i]; pk += (recLen[i] + 31) / 32 * 32;
+    }
+    out.offs[nRec] = at; out.packOffs[nRec] = pk; out.packedBases = pk; out.maskBase = pk;
+    const size_t need = (size_t)pk / 4 + (size_t)pk / 8 + 64;
+    if (need > out.cap) {
+      if (out.bases) free_(out.bases);
+      out.bases = alloc_(need + (need >> 4) + 4096);
+      if (!out.bases) { std::cerr << "[mashmap_hip] out of host memory for a batch of " << pk << " packed bases" << std::endl; exit(1); }
+      out.cap = need + (need >> 4) + 4096;
+    }
+    uint32_t* b2 = out.bases2(); uint32_t* nm = out.nmask();
+    const auto tC = std::chrono::steady_clock::now();
+    detail::run_parallel(pool_, T, [&](unsigned t) {
+      char tmp[16384 + 64];
+      for (auto& pt : parts[t]) {
+        if (!keep[pt.rec] || !pt.bases) continue;
+        const int64_t D = out.packOffs[pt.rec] + pt.off;
+        int64_t skip = (32 - D % 32) % 32;                    // these bases complete the previous part's last word: its thread packs them
+        if (pt.bases <= skip) continue;
+        Pack2bitStream st(b2 + (D + skip) / 16, nm + (D + skip) / 32);
+        const char* q = pt.body;
+        while (skip && q < pt.end) { if (*q != '\n') skip--; q++; }
+        while (q < pt.end) {                                  // line breaks out, 16 KB at a time (stays in L1), then packed
+          const size_t m = std::min<size_t>((size_t)(pt.end - q), sizeof(tmp) - 64);
+          const size_t k = strip_newlines(q, m, tmp);
+          if (k) st.feed(tmp, k);
+          q += m;
+        }
+        int64_t want = (32 - (D + pt.bases) % 32) % 32;       // fill the last word from the lines behind the piece, if the record goes on
+        q = pt.end;
+        while (want && q < e && *q != '>') {
+          const char* nl = (const char*)memchr(q, '\n', (size_t)(e - q));
+          const char* le = nl ? nl : e;
+          const size_t m = std::min<size_t>((size_t)(le - q), (size_t)want);
+          if (m) { st.feed(q, m); want -= (int64_t)m; }
+          q = nl ? nl + 1 : e;
+        }
+        pt.hasN = st.finish() ? 1 : 0;
+      }
+    });
+    for (unsigned t = 0; t < T; t++) for (auto& pt : parts[t]) if (pt.hasN) out.hasN[pt.rec] = 1;
+    out.packed = true;
+    splitWindows_++;
+    if (trace) {
+      auto sec = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+      fprintf(stderr, "[mashmap_hip::parse] split window: %zu bytes, %zu records, %u threads: scan %.4f s, place + buffer %.4f s, pack %.4f s\n", n, nRec, T, sec(tA, tB), sec(tB, tC),
+              sec(tC, std::chrono::steady_clock::now()));
+    }
+    return true;
+  }
+
   // Packed batches in ONE pass over the window (the parser is bound by memory traffic: the two-pass form reads every byte twice).  Every
   // thread takes its piece of the window and, record by record, finds the lines and packs them straight into the batch buffer, into a
   // region of its own that starts where the piece's first byte would land plus some slack per thread -- a record's packed length is at
@@ -507,7 +653,20 @@ class BatchReader {
     std::vector<const char*> cut(T + 1, e);
     cut[0] = b;
     const bool fasta = fasta_;
-    detail::run_parallel(pool_, T, [&](unsigned t) { if (t) cut[t] = detail::next_record(b, b + n / T * t, e, fasta); });
+    // a thread looks for the first record of its piece inside the piece only: when some piece holds no record start (records longer than
+    // a piece: contigs, chromosomes) the window goes through the split form instead, which cuts inside records
+    std::atomic<int> bare(0);
+    detail::run_parallel(pool_, T, [&](unsigned t) {
+      if (!t) return;
+      const char* lim = t + 1 < T ? b + n / T * (t + 1) : e;
+      cut[t] = detail::next_record(b, b + n / T * t, lim, fasta);
+      if (cut[t] >= lim) { if (fasta && lim < e) bare = 1; if (lim < e) cut[t] = detail::next_record(b, lim, e, fasta); }
+    });
+    if (bare && fasta && !getenv("MASHMAP_HIP_NO_SPLIT_RECORDS")) {
+      if (parseWindowPackedSplit(p, n, T, out)) return true;
+      out.names.clear(); out.offs.assign(1, 0);               // (a record beyond int32: the two-pass form keeps 64-bit lengths for the caller's message)
+      return false;
+    }
     for (unsigned t = 1; t <= T; t++) if (cut[t] < cut[t - 1]) cut[t] = cut[t - 1];
     const int64_t slack = 1 << 16;
     std::vector<int64_t> G(T + 1);

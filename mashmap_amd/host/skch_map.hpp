@@ -288,6 +288,7 @@ class Map {
     HostBufferPool::instance().stop();                      // nobody asks for page-locked buffers any more
 
     if (param.filterMode == filter::ONETOONE) {            // :358-406
+      const auto tf0 = skch::Time::now();
       const int n_mappings = (int)param.numMappingsForSegment - 1;
       MappingResultsVector_t tmp, filtered;
       auto b = allReadMappings.begin();
@@ -310,6 +311,7 @@ class Map {
       post.appendReadMappings(allReadMappings, "", text);
       outstrm.write(text.data(), (std::streamsize)text.size());
       if (processMappingResults) for (const auto& e : allReadMappings) processMappingResults(e);
+      if (getenv("MASHMAP_HIP_TIMING")) LogLine() << "[mashmap_hip::timing] one-to-one filter + output " << std::chrono::duration<double>(skch::Time::now() - tf0).count() << " s" << at();
     }
     std::cerr << "[mashmap::skch::Map::mapQuery] count of mapped reads = " << totalReadsMapped
               << ", reads qualified for mapping = " << totalReadsPickedForMapping << ", total input reads = " << seqCounter
@@ -325,7 +327,9 @@ class Map {
     if (o1 <= o0 || stagedBases[i] + blockBases > stageCapBases) return;
     mm_ctx* c = ctxs[i];
     const size_t reserve = stageCapBases + stageCapBases / 4 + (1u << 22);             // packed bases incl. the 32-base alignment of every read and the parser's gaps
-    if (mm_reads_prefetch_packed_append(c, b.in.bases2() + o0 / 16, b.in.nmask() + o0 / 32, (size_t)(o1 - o0), reserve) != MM_OK) die("mm_reads_prefetch_packed_append", c);
+    int staged = 0;
+    if (mm_reads_prefetch_packed_append(c, b.in.bases2() + o0 / 16, b.in.nmask() + o0 / 32, (size_t)(o1 - o0), reserve, &staged) != MM_OK) die("mm_reads_prefetch_packed_append", c);
+    if (!staged) return;                                    // the ring had no room under the pieces on their way: asked again when an upload has emptied part of it
     b.prefetched[i] = 1; stagedBases[i] += blockBases;
   }
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""the gist of a bench.py JSON line on a few terminal lines (gpurun only returns the tail of the output).  usage: bench_digest.py FILE"""
+"""the gist of a bench.py full record (or an old one-line record) on a few terminal lines (gpurun only returns the tail of the output).  usage: bench_digest.py FILE"""
 import json
 import sys
 
@@ -24,10 +24,14 @@ def one(tag, d):
             print("   %s: %s" % (k, d[k]))
 
 
-txt = [l for l in open(sys.argv[1]).read().splitlines() if l.startswith("{")]
-if not txt:
-    print("no JSON line in", sys.argv[1]); sys.exit(0)
-d = json.loads(txt[-1])
+raw = open(sys.argv[1]).read()
+try:
+    d = json.loads(raw)                                    # the full record (profiles/bench_last_full.json), indented
+except ValueError:
+    txt = [l for l in raw.splitlines() if l.startswith("{")]
+    if not txt:
+        print("no JSON line in", sys.argv[1]); sys.exit(0)
+    d = json.loads(txt[-1])
 print("workload:", d["config"]["workload"])
 one("headline", d)
 print("   config:", {k: d["config"].get(k) for k in ("fragments_per_gpu", "resident_batches", "l1_candidates_per_gpu", "candidate_mappings_per_gpu", "hard_list_fragments", "index_build_s", "host_synchronisations_last_pass")})

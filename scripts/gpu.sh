@@ -20,6 +20,8 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || true
 say() { echo "$@" | tee -a $OUT/log.txt; }
+# bench.py prints the short line the driver parses and writes the full record to gpurun_out/bench_last_full.json: keep it per run, digest that
+full() { cp gpurun_out/bench_last_full.json $OUT/$1_full.json 2>/dev/null && python scripts/bench_digest.py $OUT/$1_full.json | tee -a $OUT/log.txt; tail -c 6000 $OUT/$1.json | tail -1 | wc -c | sed 's/^/   final line bytes: /' | tee -a $OUT/log.txt; }
 wl_args() { case $1 in configs1|"") echo "";; *) echo "--workload $1";; esac; }
 for S in "$@"; do
 case $S in
@@ -34,20 +36,24 @@ smoke)
 bench)
   say "== bench (default line)"
   MM_E2E_LOG=$OUT/e2e_stage_log.txt timeout 1500 python bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
-  grep -v "^\[mm\]" $OUT/bench.err | tail -25 | tee -a $OUT/log.txt; python scripts/bench_digest.py $OUT/bench.json | tee -a $OUT/log.txt ;;
+  grep -v "^\[mm\]" $OUT/bench.err | tail -25 | tee -a $OUT/log.txt; full bench ;;
 bench:*)
   WL=${S#bench:}
   say "== bench --workload $WL"
   timeout 1500 python bench.py --steps 5 --warmup 3 --workload $WL --no-cpu-baseline --no-host-path > $OUT/bench_$WL.json 2> $OUT/bench_$WL.err
-  tail -5 $OUT/bench_$WL.err | tee -a $OUT/log.txt; python scripts/bench_digest.py $OUT/bench_$WL.json | tee -a $OUT/log.txt ;;
+  tail -5 $OUT/bench_$WL.err | tee -a $OUT/log.txt; full bench_$WL ;;
+c2)
+  say "== bench --workload configs2 (resident passes + FASTA -> PAF through the command line; C2_EXTRA=--stock adds the stock binary)"
+  MM_E2E2_LOG=$OUT/e2e_configs2_stage_log.txt timeout 1700 python bench.py --steps 5 --warmup 3 --workload configs2 --no-cpu-baseline $C2_EXTRA > $OUT/bench_configs2.json 2> $OUT/bench_configs2.err
+  grep -v "^\[mm\]" $OUT/bench_configs2.err | tail -8 | cut -c1-1200 | tee -a $OUT/log.txt; cat $OUT/e2e_configs2_stage_log.txt | tee -a $OUT/log.txt; full bench_configs2 ;;
 quick)
   say "== configs[1] headline only"
   timeout 900 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-e2e --no-north-star > $OUT/quick.json 2> $OUT/quick.err
-  tail -4 $OUT/quick.err | tee -a $OUT/log.txt; python scripts/bench_digest.py $OUT/quick.json | tee -a $OUT/log.txt ;;
+  tail -4 $OUT/quick.err | tee -a $OUT/log.txt; full quick ;;
 rr)
   say "== repeat-rich north_star workload"
   MM_DEBUG=${MM_DEBUG:-} timeout 1500 python bench.py --steps 5 --warmup 3 --workload northstar --repeat-rich-reference --no-cpu-baseline --no-host-path > $OUT/rr.json 2> $OUT/rr.err
-  grep -v "^\[mm\] sketch" $OUT/rr.err | tail -12 | tee -a $OUT/log.txt; python scripts/bench_digest.py $OUT/rr.json | tee -a $OUT/log.txt ;;
+  grep -v "^\[mm\] sketch" $OUT/rr.err | tail -12 | tee -a $OUT/log.txt; full rr ;;
 trace:*)
   WL=${S#trace:}
   say "== $WL: rocprofv3 --kernel-trace --stats"

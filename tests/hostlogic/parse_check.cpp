@@ -60,6 +60,6 @@ int main(int argc, char** argv) {
     }
   }
   rd.release(b);
-  fprintf(stderr, "batches %zu\n", batches);
+  fprintf(stderr, "batches %zu split %zu\n", batches, rd.splitWindows());
   return 0;
 }

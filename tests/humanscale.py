@@ -7,7 +7,10 @@ sources, compiled by oracle/Makefile; it travels to the GPU box like the library
 
   * the north_star target workload: 10 kbp ONT-like reads, defaults (pi 85, segLength 5000), also sharded over two contexts
     (MASHMAP_HIP_DEVICES=0,0);
-  * the BASELINE configs[2] shape: assembly contigs vs the reference, --pi 95 -s 10000 -f one-to-one (a reduced query);
+  * the BASELINE configs[2] shape: assembly contigs vs the reference, --pi 95 -s 10000 -f one-to-one -- a reduced query with an N gap
+    (40 x 5 Mbp pieces), and the configuration at FULL size: every contig of the 3 Gbp reference with 1 % substitutions and 1-5 Mbp
+    inversions / translocations (bench.make_assembly, what `bench.py --workload configs2` measures), 3 Gbp of query whose records are
+    longer than a reader thread's piece of a window (seq_parse.hpp: parseWindowPackedSplit);
   * the BASELINE configs[4] shape: --dense --pi 80, 20 kbp reads at 15-20 % error, the reference as an --rl list of 10 files;
   * the north_star workload once more on a 3 Gbp reference with human-like repeat structure (bench.make_repeat_rich_reference: ~45 % in
     interspersed repeat families of 10^2..10^5 copies at 10-20 % divergence, a satellite array and N gaps per contig) -- the shape
@@ -53,6 +56,7 @@ def _threads():
 CASES = {
     "northstar": ["-r", "@ref", "-q", "@ns"],
     "configs2": ["-r", "@ref", "-q", "@asm", "--pi", "95", "-s", "10000", "-f", "one-to-one"],
+    "configs2_full": ["-r", "@ref", "-q", "@asm_full", "--pi", "95", "-s", "10000", "-f", "one-to-one"],
     "configs4": ["--rl", "@rl", "-q", "@c4", "--dense", "--pi", "80"],
     "repeat_rich": ["-r", "@rr_ref", "-q", "@rr"],
 }
@@ -110,7 +114,10 @@ def start(tmp_path_factory):
             c[ASM_LEN // 2:ASM_LEN // 2 + 50000] = ord("N")
         asm.append(c.cpu().numpy())
     B.write_fasta(asm_fa, ["ctg%d" % i for i in range(N_ASM)], asm)
-    del contigs, asm
+    asm_full_fa = os.path.join(td, "asm_full.fa")
+    full_asm = B.make_assembly(torch, dev, contigs, 0.01, seed=2021)
+    B.write_fasta(asm_full_fa, ["asm%d" % i for i in range(len(full_asm))], [c.cpu().numpy() for c in full_asm])
+    del contigs, asm, full_asm
     torch.cuda.empty_cache()
     # the repeat-rich reference and reads drawn from it
     rr_ref, rr_fa = os.path.join(td, "ref_rr.fa"), os.path.join(td, "reads_rr.fa")
@@ -121,7 +128,7 @@ def start(tmp_path_factory):
     torch.cuda.empty_cache()
     print("\n[human scale] %.2f Gbp reference in %d contigs (+ %d --rl files), %d + %d reads, %d assembly contigs written in %.0f s"
           % (GBP, N_CONTIGS, N_FILES, N_READS_NS, N_READS_C4, N_ASM, time.time() - t0), flush=True)
-    H = dict(td=td, ref=ref_fa, rl=rl, ns=ns_fa, c4=c4_fa, asm=asm_fa, rr_ref=rr_ref, rr=rr_fa, rr_summary=rr_summary, threads=_threads())
+    H = dict(td=td, ref=ref_fa, rl=rl, ns=ns_fa, c4=c4_fa, asm=asm_fa, asm_full=asm_full_fa, rr_ref=rr_ref, rr=rr_fa, rr_summary=rr_summary, threads=_threads())
     # the four runs of the stock binary start now and share the host's CPUs (its index build is single-threaded for most of its
     # ~90 s: hash-map insertions of 0.36 G records); the GPU runs of the tests below happen meanwhile
     H["stock"] = {}

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     for name in _declared():
         assert hasattr(lib, name), name
     capi.load()
-    assert capi.load().mm_abi_version() == 1
+    assert capi.load().mm_abi_version() == 2      # include/mashmap_hip.h MM_ABI_VERSION (2: five pass counts, staged flag, mm_reads_prefetch_drop)
 
 
 def test_create_fails_loudly_without_gpu():

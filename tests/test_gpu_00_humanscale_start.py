@@ -9,6 +9,6 @@ pytestmark = pytest.mark.gpu
 
 
 def test_human_scale_inputs_written_and_stock_runs_started(human):
-    for k in ("ref", "rl", "ns", "c4", "asm", "rr_ref", "rr"):
+    for k in ("ref", "rl", "ns", "c4", "asm", "asm_full", "rr_ref", "rr"):
         assert os.path.getsize(human[k]) > 0
-    assert set(human["stock"]) == {"northstar", "configs2", "configs4", "repeat_rich"}
+    assert set(human["stock"]) == {"northstar", "configs2", "configs2_full", "configs4", "repeat_rich"}

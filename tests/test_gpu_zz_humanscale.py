@@ -2,7 +2,7 @@
 runs were started by tests/test_gpu_00_humanscale_start.py and have had the rest of the suite's run time to finish."""
 import pytest
 
-from humanscale import N_ASM, N_READS_C4, N_READS_NS, N_READS_RR, case as _case
+from humanscale import N_ASM, N_CONTIGS, N_READS_C4, N_READS_NS, N_READS_RR, case as _case
 
 pytestmark = pytest.mark.gpu
 
@@ -16,6 +16,13 @@ def test_configs2_shape_one_to_one(human):
     """assembly vs reference: --pi 95 -s 10000 -f one-to-one (a sketch of ~40 per 10 kbp: the seed table stays below the 1 GiB where the
     tag layer starts)"""
     _case(human, "configs2", N_ASM, False)
+
+
+def test_configs2_full_size_one_to_one(human):
+    """BASELINE configs[2] at its own size: the whole 3 Gbp assembly (every reference contig diverged by 1 %, with 1-5 Mbp inversions and
+    translocations, a third of them on the other strand) against the 3 Gbp reference, --pi 95 -s 10000 -f one-to-one: 300 000 fragments
+    chained into a few mappings per contig, bytes equal to the stock binary's"""
+    _case(human, "configs2_full", N_CONTIGS, False)
 
 
 def test_configs4_shape_dense_reference_list(human):

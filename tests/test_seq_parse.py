@@ -216,3 +216,46 @@ def test_available_cpus_follows_override_affinity_and_quota(exe):
         one = sorted(os.sched_getaffinity(0))[:1]
         out = subprocess.check_output(["python3", "-c", "import os,subprocess,sys; os.sched_setaffinity(0, {%d}); sys.stdout.write(subprocess.check_output([%r, 'cpus']).decode())" % (one[0], exe)], env=env)
         assert int(out.split()[0]) == 1
+
+
+@pytest.mark.parametrize("width", [1, 7, 31, 32, 33, 60, 61, 0])
+def test_packing_reader_splits_long_records_across_threads(exe, tmp_path, width):
+    """records longer than a thread's piece of the window (contigs, chromosomes): the packed parser cuts INSIDE them, at line boundaries
+    (parseWindowPackedSplit) -- parts that do not start on a 32-base boundary of their record hand their first bases to the thread before
+    them.  Line widths around 32, tiny records and empty records between the long ones, '\\r', blank lines, N runs, no final line break:
+    every record decodes to makeUpperCaseAndValidDNA of its sequence, and the split form was really taken."""
+    rng = np.random.default_rng(width + 3)
+    rs = []
+    for i, n in enumerate([700001, 5, 0, 333333, 1, 31, 32, 33, 250000, 64, 1200000, 17]):
+        a = U.random_dna(50 + i, max(n, 1))[:n].copy()
+        if n > 1000:
+            a[n // 3:n // 3 + 777] = ord("N"); a[5] = ord("n"); a[n - 1] = ord("R")
+            if i % 2:
+                a = U.lowercase_some(a, i)
+        rs.append(("ctg%d some words" % i, a.tobytes()))
+    raw = fasta_bytes(rs, width)
+    if width == 60:                                            # blank lines and a carriage return inside a long record (a '\r' is a base: it becomes N)
+        cut = raw.index(b"\n", 200000) + 1
+        raw = raw[:cut] + b"\n\n" + raw[cut:cut + 30] + b"\r\n" + raw[cut + 30:]
+        k = 0
+        for j, (h, sq) in enumerate(rs):                       # the same edit in the expectation
+            k += len(h) + 2
+            nl = (len(sq) + width - 1) // width
+            if k + len(sq) + nl > cut:
+                o = (cut - k) // (width + 1) * width + 30
+                rs[j] = (h, sq[:o] + b"\r" + sq[o:]); break
+            k += len(sq) + nl
+    raw = raw.rstrip(b"\n")
+    path = str(tmp_path / "long.fa")
+    open(path, "wb").write(raw)
+    want = ["%s\t%d\t%d" % (h.split(" ")[0], len(s), fnv(_normalise(s))) for h, s in rs]
+    took_split = 0
+    for window, threads in ((1 << 40, 8), (1 << 40, 3), (400000, 5), (65536, 16), (1 << 40, 1)):
+        p = subprocess.run([exe, str(window), str(threads), "--packed", path], capture_output=True, text=True)
+        assert p.returncode == 0, p.stdout[-300:] + p.stderr
+        got = p.stdout.splitlines()
+        assert got == want, (width, window, threads, [x for x in zip(got, want) if x[0] != x[1]][:3])
+        took_split += int(p.stderr.split("split")[1])
+        q = subprocess.run([exe, str(window), str(threads), "--packed", path], capture_output=True, text=True, env=dict(os.environ, MASHMAP_HIP_NO_SPLIT_RECORDS="1"))
+        assert q.stdout == p.stdout and int(q.stderr.split("split")[1]) == 0
+    assert took_split >= 3
