@@ -294,7 +294,9 @@ int mm_query_sketch_download(mm_ctx* ctx, mm_minmer* out);
 /*
  * Options.  MM_OPT_KEEP_POINTS (default 0): by default the interval points of a fragment (getSeedIntervalPoints,
  * computeMap.hpp:857) live only in LDS/registers between the seed lookup and the L1 sweep; with 1 every fragment's sorted
- * point list is also kept in HBM so that mm_points_download can return it (parity tests).
+ * point list is also kept in HBM so that mm_points_download can return it (parity tests); with 2 the list additionally goes through the
+ * interval-point pre-filter the HBM point path applies to the fragments queued for it (k_filter_points: the intervals that cannot reach
+ * minimumHits are dropped before the sort -- L1 candidates unchanged), and mm_points_download returns what the filter left.
  * MM_OPT_KEEP_FULL_INDEX (default 0): keep minmerIndex as it is BEFORE dropFreqSeedSet (winSketch.hpp:497) on the host so that
  * mm_index_download_full can return it -- that is what --saveIndex writes (winSketch.hpp:127-134 run before the drop).
  * MM_OPT_RESERVE_FRAGMENTS (default 0): the number of fragments of the largest batch the caller is going to upload.  The pass that sizes the
@@ -304,7 +306,7 @@ int mm_query_sketch_download(mm_ctx* ctx, mm_minmer* out);
  */
 enum { MM_OPT_KEEP_POINTS = 1, MM_OPT_KEEP_FULL_INDEX = 2, MM_OPT_RESERVE_FRAGMENTS = 3 };
 int mm_set_option(mm_ctx* ctx, int option, int value);
-/* sorted, filtered interval points of fragment f (needs MM_OPT_KEEP_POINTS; (seqId,pos,side) only, hash = 0) */
+/* sorted interval points of fragment f after the seqId filters of computeMap.hpp:891-896 (needs MM_OPT_KEEP_POINTS; (seqId,pos,side) only, hash = 0) */
 int mm_points_download(mm_ctx* ctx, size_t frag, mm_interval_point* out, size_t cap, size_t* n);
 /* copies the L2 loci (fragment-major device order, not re-sorted) into caller-owned DEVICE memory, e.g. a torch tensor
  * that is then exchanged with RCCL; *n receives the count, cap is the capacity of dst in records */

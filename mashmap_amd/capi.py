@@ -447,8 +447,9 @@ class Context:
         self._ck(self.lib.mm_set_option(self.h, 3, int(n)), "mm_set_option")
 
     def keep_points(self, on=True):
-        """MM_OPT_KEEP_POINTS: keep every fragment's sorted interval points in HBM (needed by points())"""
-        self._ck(self.lib.mm_set_option(self.h, 1, 1 if on else 0), "mm_set_option")
+        """MM_OPT_KEEP_POINTS: keep every fragment's sorted interval points in HBM (needed by points()); on=2: ... after the interval-point
+        pre-filter of the HBM point path (k_filter_points) has run on them"""
+        self._ck(self.lib.mm_set_option(self.h, 1, int(on) if on in (0, 1, 2) else 1), "mm_set_option")
 
     def points(self, frag, cap=1 << 16):
         out = np.zeros(cap, dtype=POINT_DT); n = C.c_size_t()

@@ -19,7 +19,7 @@ std::vector<DevBuf*> mm_ctx::allBufs() {
           &I.htSlots, &I.htTags, &I.filter, &I.ptKeys, &I.keys, &I.keyOff, &I.keyFreq, &dMinHits, &dCutoffs, &dAscii, &dAsciiNext, &dReadSrcOff, &dReadPackOff, &dReadLen, &dReadGroup, &dReadSelf, &dReadHasN,
           &dBases2, &dNmask, &dFrags, &dSkHash, &dSkPos, &dSkStrand, &dSkCount, &dHardList, &dCounters, &dSketchSpill, &dSketchTabs, &dQHash, &dQStrand,
           &dStats, &dPtOff, &dPts, &dPtKept, &dPtIds, &dWinFreq, &dWinExt, &dWinHeap, &dWinKeys, &dWinVals, &dWinOffH, &dWinOffT, &dWinCntH, &dWinCntT, &dL1, &dL1b, &dL1Cursors, &dL1Off, &dL1Regions, &dL2, &dL2Info, &dL2Cnt, &dL2Off, &dL2Ops, &dScanTmp, &dL2Tmp, &dL2Wide, &dL2Exact, &dL2Cells,
-          &dListB, &dListC, &dBigList, &dL2Sort[0], &dL2Sort[1], &dL2Sort[2], &dL2Sort[3], &dL2Order, &dL2OrderPos, &dL2InitCells, &dL2InitState, &dL2First, &dL2Num, &dAccept, &dMinIsz, &dSelCnt, &dSelOff, &dSelHeap, &dFragTab, &dMappings, &dCommCounts, &dGathered};
+          &dListB, &dListC, &dBigList, &dMidList, &dL2Sort[0], &dL2Sort[1], &dL2Sort[2], &dL2Sort[3], &dL2Order, &dL2OrderPos, &dL2InitCells, &dL2InitState, &dL2First, &dL2Num, &dAccept, &dMinIsz, &dSelCnt, &dSelOff, &dSelHeap, &dFragTab, &dMappings, &dCommCounts, &dGathered};
 }
 
 extern "C" {
@@ -85,7 +85,7 @@ int mm_synchronize(mm_ctx* c) { MM_HIP(c, hipStreamSynchronize(c->stream)); retu
 void* mm_stream(const mm_ctx* c) { return (void*)c->stream; }
 
 int mm_set_option(mm_ctx* c, int option, int value) {
-  if (option == MM_OPT_KEEP_POINTS) { c->keepPoints = value != 0; c->ptsCap = 0; return MM_OK; }
+  if (option == MM_OPT_KEEP_POINTS) { c->keepPoints = value != 0; c->keepFiltered = value == 2; c->ptsCap = 0; return MM_OK; }
   if (option == MM_OPT_KEEP_FULL_INDEX) { c->keepFullIndex = value != 0; return MM_OK; }
   if (option == MM_OPT_RESERVE_FRAGMENTS) { c->reserveFrags = value > 0 ? (size_t)value : 0; return MM_OK; }
   c->err = "mm_set_option: unknown option"; return MM_ERR_ARG;

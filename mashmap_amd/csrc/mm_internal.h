@@ -146,7 +146,7 @@ struct mm_ctx {
   // runs the exchange while the caller maps the next batch
   DevBuf dGatherSrc; hipStream_t commStream = nullptr; std::thread gatherThread; int gatherRc = 0; std::string gatherErr;
   std::vector<DevBuf*> allBufs();
-  DevBuf dL2Info, dL2Cnt, dL2Off, dL2Ops, dScanTmp, dL2Tmp, dL2Wide, dL2Exact, dL2Cells, dListB, dListC, dBigList;     // L2 staging: per-candidate stream extents, op counts/offsets, located ops
+  DevBuf dL2Info, dL2Cnt, dL2Off, dL2Ops, dScanTmp, dL2Tmp, dL2Wide, dL2Exact, dL2Cells, dListB, dListC, dBigList, dMidList;     // L2 staging: per-candidate stream extents, op counts/offsets, located ops
   DevBuf dL2InitCells, dL2InitState;                                 // per candidate of a chunk: the SlideMapper state after the pre-load, as k_l2_locate leaves it for the sweeps
   DevBuf dL2Sort[4], dL2Order, dL2OrderPos;                          // candidates of a chunk in order of descending stream length (mm_order_desc)
   bool sketched = false, mapped = false;
@@ -154,9 +154,11 @@ struct mm_ctx {
   bool steadyOk = false, lastSteady = false; size_t prevBig = 0, candCap = 0, l2Chunks = 1, sizedFrags = 0; int prevLocap = 0, steadyFails = 0;   // sizedFrags: fragments of the last sized pass
   unsigned long long* hPass = nullptr;                  // page-locked: the counters of a pass as read back at its end
   size_t lastHard = 0;                                  // fragments the fast sketch kernel handed to the hard list in the last pass
+  size_t prevMid = 0, lastMid = 0; bool midKnown = false;   // fragments k_lookup_mid took in the last sized pass (its grid in the steady-state passes behind it)
   size_t lastOps = 0, lastBig = 0;                      // L2 stream entries reserved / fragments queued for the HBM point path in the last pass
   size_t nSyncs = 0;                                    // host synchronisations inside the last mm_map_fragments (diagnostics: mm_pass_syncs)
   uint64_t nPasses = 0, nSteadyPasses = 0, nRedone = 0; // mm_map_fragments calls of this context: all, those that went through as steady-state passes, steady attempts redone the sized way
+  bool keepFiltered = false;                            // MM_OPT_KEEP_POINTS = 2: ... and k_filter_points runs on them as it does on a queued fragment's (mm_points_download returns what it leaves)
   bool keepPoints = false;                              // mm_set_option(MM_OPT_KEEP_POINTS): route every fragment through the HBM point list
   size_t reserveFrags = 0;                              // mm_set_option(MM_OPT_RESERVE_FRAGMENTS): fragments of the largest batch the caller will upload; sized passes size for it
 

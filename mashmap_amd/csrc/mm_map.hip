@@ -391,6 +391,8 @@ __device__ __noinline__ int mm_fused_long_runs(uint64_t mLong, int c, int my, ui
   return nValid;
 }
 #define MM_LOOKUP_WPB 4             // waves (= fragments) per workgroup
+#define MM_MID_MAXSKETCH 512        // k_lookup_mid (below): sketch entries whose table answers its LDS holds,
+#define MM_MID_MAXPTS 16384         // and interval points of a fragment it takes (8 192 intervals: its 16-bit bin counters cannot overflow)
 #define MM_L1_REGIONS 64            // L1 output cursors: a same-address atomic costs ~10 ns, so fragments spread over 64 of them
 #define MM_L1_CURSOR_STRIDE 32      // u64 words between cursors (256 bytes)
 template <int MAXPTS, bool TAGS>
@@ -403,8 +405,8 @@ k_lookup_l1(int nFrags, int s, const DFrag* __restrict__ frags,
             mm_frag_stats* __restrict__ stats, int64_t* __restrict__ ptOff, unsigned long long ptsCap,
             const int32_t* __restrict__ minHitsTab, const int32_t* __restrict__ cutoffs, int nCutoffs, int segLength,
             mm_l1_candidate* __restrict__ l1, unsigned long long regionCap, unsigned long long* __restrict__ l1Cursors,
-            int64_t* __restrict__ l1Off, int32_t* __restrict__ bigList,
-            unsigned long long* __restrict__ counters /* [0] point cursor [1] pts overflow [3] l1 overflow [7] big count */) {
+            int64_t* __restrict__ l1Off, int32_t* __restrict__ bigList, int32_t* __restrict__ midList,
+            unsigned long long* __restrict__ counters /* [0] point cursor [1] pts overflow [3] l1 overflow [7] big count [16] mid count */) {
   typedef FuseScratchT<MAXPTS> FuseScratch;
   __shared__ FuseScratch scratch[MM_LOOKUP_WPB];
   const int wv = threadIdx.x >> 6;
@@ -520,7 +522,17 @@ k_lookup_l1(int nFrags, int s, const DFrag* __restrict__ frags,
       }
     }
   }
-  if (nOut < 0) {
+  // more points than the registers sort, nothing else in the way: k_lookup_mid filters them in LDS first (the fragment stays off the HBM
+  // path unless more than 512 of its points can matter to L1)
+  const bool toMid = nOut < 0 && midList && !fuseOk && !keepPoints && !fl.skipPrefix && minHits0 > 1 && cnt <= MM_MID_MAXSKETCH && P <= MM_MID_MAXPTS;
+  if (toMid) {
+    if (lane == 0) {
+      mm_frag_stats st;
+      st.rawSketchSize = cnt; st.sketchSize = outIdx; st.maxHash = lastHash; st.nPoints = 0; st.nL1 = 0; stats[f] = st;
+      ptOff[2 * f] = 0; ptOff[2 * f + 1] = 0; l1Off[f] = 0;
+      midList[atomicAdd(&counters[16], 1ull)] = f;
+    }
+  } else if (nOut < 0) {
     // slow path: the fragment's points go to HBM -- gathered by k_gather_points (which looks the seeds up once more: this kernel keeps no
     // per-seed value beyond the batch it is probing), sorted and swept by the follow-up kernels.  Here: the slots (a power of two above
     // 64 for the sorters) and the queue entry.
@@ -678,6 +690,192 @@ k_filter_points(int nList, const int32_t* __restrict__ list, const mm_frag_stats
     if (kept > 64) { newSlots = 128; while (newSlots < kept) newSlots <<= 1; }
     for (int j = kept + lane; j < newSlots; j += 64) a[j] = MM_EMPTY;
     if (lane == 0) { ptOff[2 * f + 1] = (int64_t)newSlots; ptKept[f] = kept; }
+    __threadfence_block();
+  }
+}
+
+// k_lookup_mid: the fragments whose interval points outnumber what k_lookup_l1 sorts in registers (against a repeat-rich reference 31 % of
+// the north_star fragments: hundreds of scattered single hits each) -- WITHOUT the trip through HBM (k_gather_points -> k_filter_points ->
+// sorters -> k_l1_stream: 33 of that workload's 125 ms).  One wave per queued fragment: the seeds are probed once more and their table
+// answers kept in LDS; a first sweep over the seeds' point runs counts, per 4 096-position bin, the intervals that intersect it (and per
+// contig the first and last position), a second sweep keeps the intervals k_filter_points' rule keeps (same bins, same hashed table, same
+// boundary rule: tests/l1filter.py is the model) and writes them into the LDS list; at most 512 survivors are sorted in registers and
+// swept by mm_l1_fused exactly as in k_lookup_l1, and the candidates go to the same region cursors.  A fragment with more survivors, with
+// an interval the filter gives up on, or whose sorted list needs the literal sweep is queued for the HBM path as k_lookup_l1 would have.
+template <bool TAGS>
+__global__ void __launch_bounds__(64)
+k_lookup_mid(int nList, const unsigned long long* __restrict__ nDev, const int32_t* __restrict__ list, int s, const DFrag* __restrict__ frags,
+             const uint64_t* __restrict__ skHash, const uint32_t* __restrict__ skCount, const SeedTable T, const uint64_t* __restrict__ ptKeys,
+             const int32_t* __restrict__ readSelf, int seqCounterBase, MapFlags fl, mm_frag_stats* __restrict__ stats, int64_t* __restrict__ ptOff,
+             unsigned long long ptsCap, const int32_t* __restrict__ minHitsTab, const int32_t* __restrict__ cutoffs, int nCutoffs, int segLength,
+             mm_l1_candidate* __restrict__ l1, unsigned long long regionCap, unsigned long long* __restrict__ l1Cursors, int64_t* __restrict__ l1Off,
+             int32_t* __restrict__ bigList, unsigned long long* __restrict__ counters) {
+  typedef FuseScratchT<512> FuseScratch;
+  __shared__ FuseScratch sc;
+  __shared__ uint64_t seedVal[MM_MID_MAXSKETCH];                 // table answer of every surviving seed (offset << 24 | count << 1), 0: none
+  __shared__ uint32_t binCnt[MM_FILT_SLOTS / 2];                 // two 16-bit counters per word
+  __shared__ int32_t cKey[MM_FILT_CONTIGS];
+  __shared__ uint32_t cMin[MM_FILT_CONTIGS], cMax[MM_FILT_CONTIGS];
+  const int lane = (int)mm_lane();
+  if (nDev) nList = (int)*nDev;
+  for (int li = blockIdx.x; li < nList; li += gridDim.x) {
+    const int f = list[li];
+    const int cnt = (int)skCount[f];
+    const size_t fo = (size_t)f * s;
+    const int readId = frags[f].readId;
+    const int self = readSelf[readId], seqCounter = seqCounterBase + readId;
+    const mm_frag_stats st0 = stats[f];
+    const int outIdx = st0.sketchSize;
+    const int minHits = outIdx > 0 ? minHitsTab[outIdx] : 0;
+    for (int i = lane; i < MM_FILT_SLOTS / 2; i += 64) binCnt[i] = 0u;
+    for (int i = lane; i < MM_FILT_CONTIGS; i += 64) { cKey[i] = -1; cMin[i] = 0xFFFFFFFFu; cMax[i] = 0u; }
+    int P = 0;
+    for (int base = 0; base < cnt; base += 256) {
+      uint64_t h[4], val[4]; bool act[4], found[4];
+      mm_probe4<TAGS>(T, skHash, fo, cnt, base, lane, h, act, found, val);
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const bool kf = act[u] && found[u] && !(val[u] & 1ull);
+        if (base + u * 64 + lane < MM_MID_MAXSKETCH) seedVal[base + u * 64 + lane] = kf ? val[u] : 0ull;
+        P += kf ? (int)((val[u] >> 1) & 0x7fffffull) : 0;
+      }
+    }
+    P = mm_wave_sum(P);
+    __threadfence_block();
+    auto dropped = [&](uint64_t key) {
+      const int seqId = (int)(key >> 33);
+      return (fl.skipSelf && seqId == self) || (fl.lowerTri && !(seqCounter > seqId));
+    };
+    // sweep 1: bins and contig extents.  A seed's run is a sequence of (OPEN, CLOSE) pairs; short runs by the lane that owns the seed, long
+    // ones by the whole wave
+    bool giveUp = false; int nValid = 0;
+    auto count = [&](uint64_t O, uint64_t C) {
+      if (dropped(O)) return;
+      nValid += 2;
+      const uint32_t seq = (uint32_t)(O >> 33), o = (uint32_t)(O >> 1), c = (uint32_t)(C >> 1);
+      const uint32_t b0 = o >> MM_FILT_SHIFT, b1 = (c - 1u) >> MM_FILT_SHIFT;
+      if (c <= o || b1 - b0 >= (uint32_t)MM_FILT_MAXSPAN || (uint32_t)(C >> 33) != seq) { giveUp = true; return; }
+      for (uint32_t b = b0; b <= b1; b++) { const uint32_t sl = mm_bin_slot(seq, b); atomicAdd(&binCnt[sl >> 1], 1u << (16 * (sl & 1u))); }
+      uint32_t sl = (seq * 0x9E3779B1u) >> 25;
+      int tries = 0;
+      for (; tries < MM_FILT_CONTIGS; tries++) {
+        const int32_t prev = atomicCAS(&cKey[sl], -1, (int32_t)seq);
+        if (prev == -1 || prev == (int32_t)seq) { atomicMin(&cMin[sl], o); atomicMax(&cMax[sl], c); break; }
+        sl = (sl + 1u) & (MM_FILT_CONTIGS - 1);
+      }
+      if (tries == MM_FILT_CONTIGS) giveUp = true;
+    };
+    const int nRounds = (cnt + 63) >> 6;
+    for (int rd = 0; rd < nRounds; rd++) {
+      const uint64_t val = seedVal[rd * 64 + lane < MM_MID_MAXSKETCH ? rd * 64 + lane : 0];
+      const int c = rd * 64 + lane < cnt ? (int)((val >> 1) & 0x7fffffull) : 0;
+      const uint64_t src = val >> 24;
+      if (c & 1) giveUp = true;                                   // (never: a hash's points are its intervals' two ends)
+      const bool longRun = c > 8;
+      if (!longRun) for (int j = 0; j + 1 < c; j += 2) count(ptKeys[src + j], ptKeys[src + j + 1]);
+      uint64_t mLong = mm_ballot(longRun);
+      while (mLong) {
+        const int l = (int)__builtin_ctzll(mLong); mLong &= mLong - 1ull;
+        const int cL = __shfl(c, l);
+        const uint64_t srcL = ((uint64_t)(uint32_t)__shfl((int)(src >> 32), l) << 32) | (uint32_t)__shfl((int)(uint32_t)src, l);
+        for (int j = 2 * lane; j + 1 < cL; j += 128) count(ptKeys[srcL + j], ptKeys[srcL + j + 1]);
+      }
+    }
+    __threadfence_block();
+    nValid = mm_wave_sum(nValid);
+    bool fallback = mm_ballot(giveUp) != 0ull;
+    // sweep 2: the intervals that can matter, into the LDS list
+    int cursor = 0;                                                // pairs kept so far (wave-uniform)
+    auto keeps = [&](uint64_t O, uint64_t C) {
+      if (dropped(O)) return false;
+      const uint32_t seq = (uint32_t)(O >> 33), o = (uint32_t)(O >> 1), c = (uint32_t)(C >> 1);
+      const uint32_t b0 = o >> MM_FILT_SHIFT, b1 = (c - 1u) >> MM_FILT_SHIFT;
+      bool keep = false;
+      for (uint32_t b = b0; b <= b1; b++) { const uint32_t sl = mm_bin_slot(seq, b); keep = keep || ((binCnt[sl >> 1] >> (16 * (sl & 1u))) & 0xFFFFu) >= (uint32_t)minHits; }
+      uint32_t sl = (seq * 0x9E3779B1u) >> 25;
+      while (cKey[sl] != (int32_t)seq) sl = (sl + 1u) & (MM_FILT_CONTIGS - 1);
+      return keep || o == cMin[sl] || c == cMax[sl];
+    };
+    for (int rd = 0; rd < nRounds && !fallback; rd++) {
+      const uint64_t val = seedVal[rd * 64 + lane < MM_MID_MAXSKETCH ? rd * 64 + lane : 0];
+      const int c = rd * 64 + lane < cnt ? (int)((val >> 1) & 0x7fffffull) : 0;
+      const uint64_t src = val >> 24;
+      const bool longRun = c > 8;
+      uint32_t km = 0;                                             // short run (at most 4 pairs): which of them stay
+      if (!longRun) for (int j = 0; j + 1 < c; j += 2) if (keeps(ptKeys[src + j], ptKeys[src + j + 1])) km |= 1u << (j >> 1);
+      const int mine = __popc(km);
+      const int at0 = cursor + mm_wave_excl_scan(mine);
+      const int tot = mm_wave_sum(mine);
+      if (cursor + tot > 256) { fallback = true; break; }
+      { int at = at0; for (int j = 0; j + 1 < c && !longRun; j += 2) if (km & (1u << (j >> 1))) { sc.a[2 * at] = ptKeys[src + j]; sc.a[2 * at + 1] = ptKeys[src + j + 1]; at++; } }
+      cursor += tot;
+      uint64_t mLong = mm_ballot(longRun);
+      while (mLong && !fallback) {
+        const int l = (int)__builtin_ctzll(mLong); mLong &= mLong - 1ull;
+        const int cL = __shfl(c, l);
+        const uint64_t srcL = ((uint64_t)(uint32_t)__shfl((int)(src >> 32), l) << 32) | (uint32_t)__shfl((int)(uint32_t)src, l);
+        for (int j0 = 0; j0 < cL; j0 += 128) {
+          const int j = j0 + 2 * lane;
+          uint64_t O = MM_EMPTY, C = MM_EMPTY; bool keep = false;
+          if (j + 1 < cL) { O = ptKeys[srcL + j]; C = ptKeys[srcL + j + 1]; keep = keeps(O, C); }
+          const uint64_t m = mm_ballot(keep);
+          const int k = (int)__popcll(m);
+          if (cursor + k > 256) { fallback = true; break; }
+          if (keep) { const int at = cursor + (int)mm_popc_below(m); sc.a[2 * at] = O; sc.a[2 * at + 1] = C; }
+          cursor += k;
+        }
+      }
+    }
+    int nOut = -1;
+    if (!fallback) {
+      const int K = 2 * cursor;
+      if (K == 0) nOut = 0;
+      else {
+        const int padTo = K <= 64 ? 64 : K <= 128 ? 128 : K <= 256 ? 256 : 512;
+        for (int j = K + lane; j < padTo; j += 64) sc.a[j] = MM_EMPTY;
+        __threadfence_block();
+        if (K <= 64) { uint64_t k[1] = {sc.a[lane]}; mm_wave_bitonic<1>(k, lane); nOut = mm_l1_fused<1>(k, sc, outIdx, minHits, fl.hg, cutoffs, nCutoffs, s, segLength, lane); }
+        else if (K <= 128) { uint64_t k[2] = {sc.a[lane * 2], sc.a[lane * 2 + 1]}; mm_wave_bitonic<2>(k, lane); nOut = mm_l1_fused<2>(k, sc, outIdx, minHits, fl.hg, cutoffs, nCutoffs, s, segLength, lane); }
+        else if (K <= 256) {
+          uint64_t k[4] = {sc.a[lane * 4], sc.a[lane * 4 + 1], sc.a[lane * 4 + 2], sc.a[lane * 4 + 3]};
+          mm_wave_bitonic<4>(k, lane); nOut = mm_l1_fused<4>(k, sc, outIdx, minHits, fl.hg, cutoffs, nCutoffs, s, segLength, lane);
+        } else {
+          uint64_t k[8];
+#pragma unroll
+          for (int e = 0; e < 8; e++) k[e] = sc.a[lane * 8 + e];
+          mm_wave_bitonic<8>(k, lane); nOut = mm_l1_fused<8>(k, sc, outIdx, minHits, fl.hg, cutoffs, nCutoffs, s, segLength, lane);
+        }
+      }
+    }
+    if (nOut < 0) {                                                // to the HBM path after all, as k_lookup_l1 queues a fragment
+      int slots = 128; while (slots < P) slots <<= 1;
+      if (lane == 0) {
+        const unsigned long long off = atomicAdd(&counters[0], (unsigned long long)slots);
+        bool ok = true;
+        if (off + (unsigned long long)slots > ptsCap) { ok = false; atomicOr(&counters[1], 1ull); }
+        ptOff[2 * f] = (int64_t)off; ptOff[2 * f + 1] = ok ? (int64_t)slots : 0; l1Off[f] = 0;
+        if (ok) bigList[atomicAdd(&counters[7], 1ull)] = f;
+      }
+    } else {
+      const int region = f & (MM_L1_REGIONS - 1);
+      unsigned long long at = 0;
+      if (nOut > 0) {
+        if (lane == 0) at = atomicAdd(&l1Cursors[(size_t)region * MM_L1_CURSOR_STRIDE], (unsigned long long)nOut);
+        at = ((unsigned long long)(uint32_t)__shfl((int)(at >> 32), 0) << 32) | (uint32_t)__shfl((int)(uint32_t)at, 0);
+        if (at + (unsigned long long)nOut > regionCap) { if (lane == 0) atomicOr(&counters[3], 1ull); nOut = 0; }
+      }
+      const unsigned long long base = (unsigned long long)region * regionCap + at;
+      for (int i = lane; i < nOut; i += 64) {
+        const L1Run x = sc.run[i];
+        mm_l1_candidate o; o.frag = f; o.seqId = x.seq; o.rangeStartPos = x.start; o.rangeEndPos = x.end; o.intersectionSize = x.isize;
+        l1[base + i] = o;
+      }
+      if (lane == 0) {
+        mm_frag_stats st = st0;
+        st.nPoints = nValid; st.nL1 = nOut; stats[f] = st;
+        ptOff[2 * f] = 0; ptOff[2 * f + 1] = 0; l1Off[f] = (int64_t)base;
+      }
+    }
     __threadfence_block();
   }
 }
@@ -1261,6 +1459,11 @@ static int map_pass(mm_ctx* c, const bool steady) {
   if (c->l1Cap < cF * 2 + 1024) c->l1Cap = cF * 2 + 1024;
   DevBuf& listB = c->dListB; DevBuf& listC = c->dListC;
   MM_HIP(c, listB.ensure(cF * 4 + 16)); MM_HIP(c, listC.ensure(cF * 4 + 16)); MM_HIP(c, c->dBigList.ensure(cF * 4 + 16));
+  // fragments with more interval points than k_lookup_l1 sorts go through k_lookup_mid first (MM_NO_MID=1: straight to the HBM path, the A/B switch)
+  static const bool noMid = getenv("MM_NO_MID") != nullptr;
+  const bool useMid = !allSlow && !noMid && s <= MM_MID_MAXSKETCH;
+  if (useMid) MM_HIP(c, c->dMidList.ensure(cF * 4 + 16));
+  unsigned long long hMid = 0;
   MM_HIP(c, c->dL1Regions.ensure(sizeof(L1Regions)));
   int rc = MM_OK;
   unsigned long long hc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1297,11 +1500,25 @@ static int map_pass(mm_ctx* c, const bool steady) {
                          c->dStats.as<mm_frag_stats>(), c->dPtOff.as<int64_t>(), (unsigned long long)c->ptsCap,
                          c->dMinHits.as<int32_t>(), c->dCutoffs.as<int32_t>(), (int)c->nCutoffs, c->P.segLength,
                          c->dL1.as<mm_l1_candidate>(), regionCap, c->dL1Cursors.as<unsigned long long>(), c->dL1Off.as<int64_t>(),
-                         c->dBigList.as<int32_t>(), cnt);
+                         c->dBigList.as<int32_t>(), useMid ? c->dMidList.as<int32_t>() : (int32_t*)nullptr, cnt);
+      MM_HIP(c, hipGetLastError());
+    }
+    if (useMid) {
+      // its list's length stays on the device (cnt[16]); the grid is what the last sized pass saw plus a half (the kernel walks the list
+      // with whatever grid it gets), every fragment when nothing is known yet
+      KernelTimer t(c, MM_K_SORT);
+      const size_t guess = c->midKnown ? c->prevMid + c->prevMid / 2 + 256 : (size_t)nF;
+      const unsigned grid = (unsigned)std::max<size_t>(1, std::min<size_t>(guess, (size_t)nF));
+      auto mk = I.tagged ? k_lookup_mid<true> : k_lookup_mid<false>;
+      hipLaunchKernelGGL(mk, dim3(grid), dim3(64), 0, c->stream, 0, cnt + 16, c->dMidList.as<int32_t>(), s, c->dFrags.as<DFrag>(), c->dSkHash.as<uint64_t>(),
+                         c->dSkCount.as<uint32_t>(), seedTab, I.ptKeys.as<uint64_t>(), c->dReadSelf.as<int32_t>(), c->seqCounterBase, fl, c->dStats.as<mm_frag_stats>(),
+                         c->dPtOff.as<int64_t>(), (unsigned long long)c->ptsCap, c->dMinHits.as<int32_t>(), c->dCutoffs.as<int32_t>(), (int)c->nCutoffs, c->P.segLength,
+                         c->dL1.as<mm_l1_candidate>(), regionCap, c->dL1Cursors.as<unsigned long long>(), c->dL1Off.as<int64_t>(), c->dBigList.as<int32_t>(), cnt);
       MM_HIP(c, hipGetLastError());
     }
     if (steady) break;                                        // overflow flags ([1], [3]) are looked at when the pass is over
     MM_HIP(c, hipMemcpyAsync(hc, cnt, 64, hipMemcpyDeviceToHost, c->stream));
+    MM_HIP(c, hipMemcpyAsync(&hMid, cnt + 16, 8, hipMemcpyDeviceToHost, c->stream));
     MM_HIP(c, hipMemcpyAsync(hcur, c->dL1Cursors.p, sizeof hcur, hipMemcpyDeviceToHost, c->stream));
     MM_HIP(c, hipMemcpyAsync(c->hPass + 16, c->dCounters.as<unsigned long long>() + 48, 8, hipMemcpyDeviceToHost, c->stream));
     MM_SYNC(c);
@@ -1336,7 +1553,7 @@ static int map_pass(mm_ctx* c, const bool steady) {
   const int nBig = (int)hc[7];
   if (getenv("MM_DEBUG")) {
     if (steady) fprintf(stderr, "[mm] lookup+L1: %d fragments, steady-state pass (the counts stay on the device)\n", nF);
-    else fprintf(stderr, "[mm] lookup+L1: %d fragments, %d to the sort+sweep path, %llu fused candidates\n", nF, nBig, hc[2]);
+    else fprintf(stderr, "[mm] lookup+L1: %d fragments, %llu through k_lookup_mid, %d to the sort+sweep path, %llu fused candidates\n", nF, hMid, nBig, hc[2]);
   }
   if (steady || nBig > 0) {
     unsigned int* cls = (unsigned int*)(c->dCounters.as<unsigned long long>() + 16);   // [16] two 32-bit class counters
@@ -1356,7 +1573,7 @@ static int map_pass(mm_ctx* c, const bool steady) {
         MM_HIP(c, hipGetLastError());
         // split mode, plain L1: the points that cannot reach minimumHits go before the sort (k_filter_points; MM_NO_POINT_FILTER=1 is the A/B switch)
         static const bool noFilter = getenv("MM_NO_POINT_FILTER") != nullptr;
-        if (!windowed && !c->keepPoints && !fl.skipPrefix && !noFilter) {
+        if (!windowed && (!c->keepPoints || c->keepFiltered) && !fl.skipPrefix && !noFilter) {
           hipLaunchKernelGGL(k_filter_points, dim3(gWave), dim3(256), 0, c->stream, nBig, c->dBigList.as<int32_t>(), c->dStats.as<mm_frag_stats>(), c->dMinHits.as<int32_t>(),
                              c->dPtOff.as<int64_t>(), c->dPts.as<uint64_t>(), c->dPtKept.as<int32_t>(), nBigDev);
           MM_HIP(c, hipGetLastError());
@@ -1437,6 +1654,7 @@ static int map_pass(mm_ctx* c, const bool steady) {
   if (!steady) {
     c->nL1 = (size_t)hc[2];
     c->prevBig = c->lastBig = (size_t)nBig;
+    c->prevMid = c->lastMid = (size_t)hMid; c->midKnown = useMid;
     if (c->nL1 == 0) { c->nL2 = 0; return rc; }
   }
   if (steady) {
@@ -1559,7 +1777,12 @@ int mm_points_download(mm_ctx* c, size_t frag, mm_interval_point* out, size_t ca
   int64_t po[2]; mm_frag_stats fs;
   MM_HIP(c, hipMemcpy(po, c->dPtOff.as<int64_t>() + 2 * frag, 16, hipMemcpyDeviceToHost));
   MM_HIP(c, hipMemcpy(&fs, c->dStats.as<mm_frag_stats>() + frag, sizeof fs, hipMemcpyDeviceToHost));
-  const size_t np = (size_t)fs.nPoints;
+  size_t np = (size_t)fs.nPoints;
+  if (c->keepFiltered) {                                            // the head of the sorted list k_filter_points left (dropped points sort behind it)
+    int32_t kept = 0;
+    MM_HIP(c, hipMemcpy(&kept, c->dPtKept.as<int32_t>() + frag, 4, hipMemcpyDeviceToHost));
+    if (po[1] > 0) np = (size_t)kept;
+  }
   if (n) *n = np;
   if (np > cap) { c->err = "mm_points_download: capacity"; return MM_ERR_ARG; }
   std::vector<uint64_t> k(np);

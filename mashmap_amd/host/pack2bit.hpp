@@ -163,11 +163,62 @@ static inline bool have_vbmi2() {
   return v;
 }
 #endif
+// scan_to_header: from q (a line start that is not a header line) to the next header line -- a '>' right behind a '\n' -- or to e; returns
+// where it stopped and adds the line breaks of [q, there) to *newlines.  One sweep: the sizing pass of the split-record parser reads every
+// byte of a chromosome once.
+static inline const char* scan_to_header_scalar(const char* q, const char* e, size_t* newlines) {
+  const char* h = q;
+  for (;;) {
+    h = (const char*)memchr(h, '>', (size_t)(e - h));
+    if (!h) { h = e; break; }
+    if (h > q && h[-1] == '\n') break;
+    h++;
+  }
+  *newlines += count_newlines_scalar(q, (size_t)(h - q));
+  return h;
+}
+#if defined(__x86_64__)
+__attribute__((target("avx512f,avx512bw")))
+static inline const char* scan_to_header_avx512(const char* q, const char* e, size_t* newlines) {
+  const __m512i nlv = _mm512_set1_epi8('\n'), gtv = _mm512_set1_epi8('>');
+  size_t c = 0;
+  const char* p = q;
+  for (; p + 64 <= e; p += 64) {
+    const __m512i v = _mm512_loadu_si512((const void*)p);
+    const uint64_t mnl = _mm512_cmpeq_epi8_mask(v, nlv);
+    uint64_t mgt = _mm512_cmpeq_epi8_mask(v, gtv);
+    if (mgt) {
+      // a '>' is a header's first byte iff the byte before it is a line break (inside the block: the bit below; at bit 0: the byte before the block)
+      uint64_t cand = mgt & (mnl << 1);
+      if ((mgt & 1ull) && p > q && p[-1] == '\n') cand |= 1ull;
+      if (cand) {
+        const int i = __builtin_ctzll(cand);
+        c += (size_t)__builtin_popcountll(mnl & ((1ull << i) - 1ull));
+        *newlines += c;
+        return p + i;
+      }
+    }
+    c += (size_t)__builtin_popcountll(mnl);
+  }
+  *newlines += c;
+  for (; p < e; p++) {                                     // the last partial block
+    if (*p == '\n') (*newlines)++;
+    else if (*p == '>' && p > q && p[-1] == '\n') return p;
+  }
+  return e;
+}
+#endif
 static inline size_t strip_newlines(const char* p, size_t n, char* dst) {
 #if defined(__x86_64__)
   if (have_vbmi2()) return strip_newlines_vbmi2(p, n, dst);
 #endif
   return strip_newlines_scalar(p, n, dst);
+}
+static inline const char* scan_to_header(const char* q, const char* e, size_t* newlines) {
+#if defined(__x86_64__)
+  if (pack2bit_isa() == 2) return scan_to_header_avx512(q, e, newlines);
+#endif
+  return scan_to_header_scalar(q, e, newlines);
 }
 static inline size_t count_newlines(const char* p, size_t n) {
 #if defined(__x86_64__)

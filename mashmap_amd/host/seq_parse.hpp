@@ -555,14 +555,9 @@ class BatchReader {
           continue;
         }
         // sequence lines up to the next header line ('>' right behind a line break) or the piece's end: bytes minus line breaks
-        const char* h = q;
-        for (;;) {
-          h = (const char*)memchr(h, '>', (size_t)(pe - h));
-          if (!h) { h = pe; break; }
-          if (h[-1] == '\n') break;                            // h > q here: q itself is not '>'
-          h++;
-        }
-        P.back().bases += (int64_t)(h - q) - (int64_t)count_newlines(q, (size_t)(h - q));
+        size_t nls = 0;
+        const char* h = scan_to_header(q, pe, &nls);           // one sweep: line breaks counted on the way to the next header line
+        P.back().bases += (int64_t)(h - q) - (int64_t)nls;
         q = h;
       }
     });

@@ -87,6 +87,7 @@ class Map {
   // it has parsed a batch, the device stage right after an upload has emptied part of the area -- so the copies of the batches behind a
   // pass always run under that pass's kernels.  stagedBases[i]: bases of queued batches already sent to context i (guarded by pfMu).
   std::mutex pfMu; std::vector<size_t> stagedBases; size_t stageCapBases = 0; bool earlyPrefetch = true;
+  bool exchangeFellBack = false;                 // a default RCCL all-gatherv failed once: per-context downloads for the rest of the run
   skch::Time::time_point tStart = skch::Time::now();   // MASHMAP_HIP_TIMING lines carry the time since the Map was constructed
   // one write per diagnostic line: three stages log at once, and `std::cerr << a << b` from two threads interleaves inside a line
   struct LogLine {
@@ -368,15 +369,18 @@ class Map {
     // several batches per pass only with one context (mapQuery): the blocks are then whole batches and the pass's reads are consecutive
     std::vector<std::vector<size_t>> cutAt(nB);
     for (size_t j = 0; j < nB; j++) cutAt[j] = blocksOf(grp[j]);
-    // How the blocks' candidate mappings reach the host stage.  One process drives all contexts here, so the records are wanted in
-    // host memory, once: by default every context downloads its own block (n copies in parallel, one per GPU's own link; rank-major
-    // concatenation == input order), which serves every filter mode -- the one-to-one filter (:358-405) runs on the host over all
-    // records either way.  MASHMAP_HIP_EXCHANGE=allgather keeps the device-side all-gatherv (mm_allgatherv_mappings_local: RCCL over
-    // xGMI between distinct GPUs) in front of a single download from context 0 -- the layout one-process-per-GPU runs need
-    // (bench.py --gpus N, mm_allgatherv_mappings_begin/_end).
+    // How the blocks' candidate mappings reach the host stage.  With a GPU per context (MASHMAP_HIP_DEVICES names distinct devices) the
+    // exchange step is the one north_star describes: the RCCL all-gatherv of the candidate mappings over xGMI
+    // (mm_allgatherv_mappings_local: count all-gather + one grouped broadcast per rank) in front of a single download from context 0 --
+    // the layout one-process-per-GPU runs use (bench.py --gpus N, mm_allgatherv_mappings_begin/_end).  Contexts that share a GPU cannot
+    // form an RCCL communicator: there every context downloads its own block (rank-major concatenation == input order), which serves
+    // every filter mode just as well -- the one-to-one filter (:358-405) runs on the host over all records either way.
+    // MASHMAP_HIP_EXCHANGE=allgather | download picks one explicitly; a default all-gatherv that RCCL refuses falls back to the
+    // downloads with one warning (an explicit one is fatal).
     const char* xe = getenv("MASHMAP_HIP_EXCHANGE");
-    const bool gatherOnDevice = nCtx > 1 && xe && std::string(xe) == "allgather";
-    std::vector<PinnedRecs<mm_mapping>> blockRecs(gatherOnDevice || nCtx == 1 ? 0 : nCtx);
+    const bool gatherAsked = xe && std::string(xe) == "allgather";
+    bool gatherOnDevice = nCtx > 1 && !exchangeFellBack && (xe ? gatherAsked : refSketch.distinctDevices());
+    std::vector<PinnedRecs<mm_mapping>> blockRecs(nCtx == 1 ? 0 : nCtx);
     auto all = std::make_shared<PinnedRecs<mm_mapping>>();
     double phase[3] = {0, 0, 0};                           // context 0: upload, kernels, download (seconds)
     auto releaseBuffers = [&]() {                           // the bases are in HBM: the page-locked buffers go back to the reader
@@ -412,7 +416,7 @@ class Map {
       const auto p1 = skch::Time::now();
       if (mm_map_fragments(c) != MM_OK) die("mm_map_fragments", c);
       if (i == 0) { phase[0] = std::chrono::duration<double>(p1 - p0).count(); phase[1] = std::chrono::duration<double>(skch::Time::now() - p1).count(); }
-      if (!blockRecs.empty()) {
+      if (!blockRecs.empty() && !gatherOnDevice) {
         size_t nb = 0;
         if (mm_mappings_count(c, &nb) != MM_OK) die("mm_mappings_count", c);
         blockRecs[i].resize(nb);
@@ -433,12 +437,26 @@ class Map {
       if (mm_mappings_count(ctx, &n) != MM_OK) die("mm_mappings_count");
       all->resize(n);
       if (n && mm_mappings_download(ctx, all->data(), n, &n) != MM_OK) die("mm_mappings_download");
-    } else if (gatherOnDevice) {
-      if (mm_allgatherv_mappings_local(ctxs.data(), (int)nCtx) != MM_OK) die("mm_allgatherv_mappings_local");
-      if (mm_gathered_counts(ctx, nullptr, &n) != MM_OK) die("mm_gathered_counts");
-      all->resize(n);
-      if (n && mm_gathered_download(ctx, all->data(), n) != MM_OK) die("mm_gathered_download");
-    } else {
+    }
+    if (nCtx > 1 && gatherOnDevice) {
+      if (mm_allgatherv_mappings_local(ctxs.data(), (int)nCtx) != MM_OK) {
+        if (gatherAsked) die("mm_allgatherv_mappings_local");
+        std::cerr << "[mashmap_hip::skch::Map] WARNING: the RCCL all-gatherv of the candidate mappings failed (" << mm_last_error(ctx)
+                  << "); every context downloads its own block from here on" << std::endl;
+        exchangeFellBack = true; gatherOnDevice = false;
+        for (size_t i = 0; i < nCtx; i++) {
+          size_t nb = 0;
+          if (mm_mappings_count(ctxs[i], &nb) != MM_OK) die("mm_mappings_count", ctxs[i]);
+          blockRecs[i].resize(nb);
+          if (nb && mm_mappings_download(ctxs[i], blockRecs[i].data(), nb, &nb) != MM_OK) die("mm_mappings_download", ctxs[i]);
+        }
+      } else {
+        if (mm_gathered_counts(ctx, nullptr, &n) != MM_OK) die("mm_gathered_counts");
+        all->resize(n);
+        if (n && mm_gathered_download(ctx, all->data(), n) != MM_OK) die("mm_gathered_download");
+      }
+    }
+    if (nCtx > 1 && !gatherOnDevice) {
       for (const auto& v : blockRecs) n += v.size();
       all->resize(n);
       size_t at = 0;

@@ -115,6 +115,12 @@ class Sketch {
 
   mm_ctx* ctx() const { return ctx_; }
   const std::vector<mm_ctx*>& contexts() const { return ctxs_; }
+  // every context has a GPU of its own: what an RCCL communicator over them needs (two contexts on one GPU exchange by device copies)
+  bool distinctDevices() const {
+    std::vector<int> d = devicesFromEnv();
+    std::sort(d.begin(), d.end());
+    return d.size() > 1 && std::adjacent_find(d.begin(), d.end()) == d.end();
+  }
 
   // Map::setRefGroups (computeMap.hpp:144): consecutive contigs with equal name prefix share a group
   std::vector<int> refGroups() const {

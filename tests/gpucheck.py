@@ -2,7 +2,39 @@
 inputs and compare every integer the reference's L1/L2 produce, fragment by fragment."""
 import numpy as np
 
+import l1filter
 import mmutil as U
+
+FILT_SLOTS, FILT_MAXSPAN, FILT_CONTIGS = 2048, 64, 128      # mm_map.hip: MM_FILT_SLOTS / MM_FILT_MAXSPAN / MM_FILT_CONTIGS
+
+
+def expected_filtered_points(ix_by_key, ix_points, hashes, min_hits, self_id, seq_counter, flags):
+    """what k_filter_points (and k_lookup_mid, same rule) leaves of a fragment's interval points, from the index's per-seed point lists
+    (pairs of OPEN, CLOSE in index order, as the device holds them) and tests/l1filter.py's model with the device's hashed bin table;
+    sorted as the device sorts them (seqId, pos, CLOSE before OPEN)"""
+    seq, o, c = [], [], []
+    for hsh in hashes:
+        sl = ix_by_key.get(hsh)
+        if sl is None:
+            continue
+        pts = ix_points[sl[0]:sl[1]]
+        for j in range(0, len(pts) - 1, 2):
+            q = int(pts[j]["seqId"])
+            if (flags & U.FLAG_SKIP_SELF) and q == self_id:
+                continue
+            if (flags & U.FLAG_LOWER_TRI) and not (seq_counter > q):
+                continue
+            seq.append(q); o.append(int(pts[j]["pos"])); c.append(int(pts[j + 1]["pos"]))
+    n = len(seq)
+    keep = np.ones(n, dtype=bool)
+    gives_up = any(cc <= oo or ((cc - 1) >> l1filter.BIN_SHIFT) - (oo >> l1filter.BIN_SHIFT) >= FILT_MAXSPAN for oo, cc in zip(o, c)) or len(set(seq)) > FILT_CONTIGS
+    if n > 1 and min_hits > 1 and not gives_up:
+        keep = l1filter.keep_mask(seq, o, c, min_hits, table_slots=FILT_SLOTS)
+    out = []
+    for i in range(n):
+        if keep[i]:
+            out.append((seq[i], o[i], 1)); out.append((seq[i], c[i], -1))
+    return sorted(out), n - int(keep.sum())
 
 
 def prefix_groups(names, delim):
@@ -75,6 +107,7 @@ def run_and_compare(oracle, contigs, reads, k=19, L=5000, s=130, pi=0.85, flags=
         l2_by_c.setdefault(int(x["cand"]), []).append(x)
     bad = {}
     nloci = 0
+    per_frag = {}                                        # fragment -> (post-removal sketch hashes, Q.sketchSize, readId) for the filtered-list check below
 
     def note(kind, f, got, exp):
         bad[kind] = bad.get(kind, 0) + 1
@@ -92,6 +125,7 @@ def run_and_compare(oracle, contigs, reads, k=19, L=5000, s=130, pi=0.85, flags=
         g_sk = [(int(x["hash"]), int(x["strand"])) for x in qsk[f, :int(st["sketchSize"])]]
         e_sk = [(x[0], x[4]) for x in e["sketch"]]
         if g_sk != e_sk: note("sketch", f, g_sk[:4], e_sk[:4])
+        per_frag[f] = ([x[0] for x in e_sk], e["sketchSize"], int(fr["readId"]))
         if e["sketchSize"] > 0:
             if check_points:
                 gp = [(int(p["seqId"]), int(p["pos"]), int(p["side"])) for p in ctx.points(f)]
@@ -118,6 +152,26 @@ def run_and_compare(oracle, contigs, reads, k=19, L=5000, s=130, pi=0.85, flags=
                 if gm != em: note("mappings", f, gm[:3], em[:3])
                 for m in recs_by_f.get(f, []):
                     if int(m["rawSketchSize"]) != e["rawSketchSize"] or int(m["fragLen"]) != ql: note("mapping.meta", f, m, e["rawSketchSize"])
+    # third run: every list through the HBM path WITH the interval-point pre-filter (MM_OPT_KEEP_POINTS = 2) -- the list the filter leaves
+    # must be the model's (tests/l1filter.py with the device's hashed bin table), and L1 / L2 must not notice
+    dropped_total = 0
+    if check_points and not (flags & (U.FLAG_SKIP_PREFIX | U.FLAG_NOSPLIT)) and not bad:
+        ctx.keep_points(2)
+        ctx.map()
+        for a, b, what in zip(ctx.results(), (stats, l1, l2), ("stats", "l1", "l2")):
+            assert len(a) == len(b) and a.tobytes() == b.tobytes(), "the pre-filtered HBM point path disagrees on " + what
+        by_key = {int(kk): (int(ix["offsets"][i]), int(ix["offsets"][i + 1])) for i, kk in enumerate(ix["keys"])}
+        mh = oracle.min_hits_table(s, k, pi)
+        for f in range(nF):
+            hashes, qs, rid = per_frag[f]
+            if qs <= 0:
+                continue
+            exp, ndrop = expected_filtered_points(by_key, ix["points"], hashes, int(mh[qs]), selfId[rid], seqCounterBase + rid, flags)
+            dropped_total += ndrop
+            gp = [(int(p["seqId"]), int(p["pos"]), int(p["side"])) for p in ctx.points(f)]
+            if gp != exp: note("filtered points", f, (len(gp), gp[:6]), (len(exp), exp[:6]))
+        if verbose:
+            print("pre-filter: %d intervals dropped over %d fragments, every filtered list equal to the model's" % (dropped_total, nF))
     ctx.close()
     oracle.free(h)
     assert not bad, "GPU vs oracle mismatches: %r over %d fragments" % (bad, nF)

@@ -230,6 +230,9 @@ def test_packing_reader_splits_long_records_across_threads(exe, tmp_path, width)
         a = U.random_dna(50 + i, max(n, 1))[:n].copy()
         if n > 1000:
             a[n // 3:n // 3 + 777] = ord("N"); a[5] = ord("n"); a[n - 1] = ord("R")
+            if width != 1:                                     # '>' inside a line is a base (it becomes N), not a header: only a line's first byte makes one
+                for j in (1, 70, 129, n // 2):
+                    a[(j // width * width + 1) if width > 1 else j] = ord(">")
             if i % 2:
                 a = U.lowercase_some(a, i)
         rs.append(("ctg%d some words" % i, a.tobytes()))
