@@ -607,16 +607,17 @@ def human_scale_cpu_baseline(W, ref_np, reads_t, n_sample):
                       "single-threaded FASTA reader" % (n_sample, n_sample * L / 1e6, sum(len(a) for a in ref_np) / 1e6, nt, os.cpu_count() or 1, usable_cpus())}
 
 
-def north_star_target(torch, dev, capi, local, warmup, steps, cpu_reads=0, nb=3, repeat_rich=True):
+def north_star_target(torch, dev, capi, local, warmup, steps, cpu_reads=0, nb=3, repeat_rich=True, configs2=True):
     """BASELINE.json's north_star target sentence on one GPU: 1 M x 10 kbp ONT-like reads, pi 85, against a human-scale index (3 Gbp,
     24 x 125 Mbp), device-resident packed bases in -> candidate mappings out.  Two variants on the same data: the stock command line
     (segLength 5000, the metric's "s=5000": two fragments per read) and segLength 10000 ("10 kbp segments": one fragment per read);
     sketchSize 310 = what the stock binary derives for a 3 GB reference file at either segment length.  Then `repeat_rich`: the stock
     variant once more against a reference of the same size with human-like repeat structure (make_repeat_rich_reference)."""
     base = dict(WORKLOADS["northstar"])
-    nreads, READ_LEN = base["reads"], base["read_len"]
+    READ_LEN = base["read_len"]
 
     def measure(contigs, ref_np, W, wl_key, pmc_ok):
+        nreads, READ_LEN = W["reads"], W["read_len"]
         ctx = capi.Context(k=W["k"], segLength=W["seg"], sketchSize=W["sketch"], flags=capi.MM_FLAG_HG_FILTER, device=local)
         t0 = time.time()
         ctx.index_build(ref_np, kmerPct=0.001)
@@ -637,7 +638,7 @@ def north_star_target(torch, dev, capi, local, warmup, steps, cpu_reads=0, nb=3,
              "fragments": nF, "interval_points_per_fragment": round(float(stats["nPoints"].mean()), 1), "l1_candidates_per_fragment": round(n1 / max(1, nF), 3),
              "l2_loci_per_fragment": round(n2 / max(1, nF), 3), "candidate_mappings_per_fragment": round(nmap / max(1, nF), 3),
              "hard_list_share": round(cnts.get("hard", 0) / max(1, nF), 5), "hbm_point_path_share": round(cnts["queued"] / max(1, nF), 5),
-             "workload": "%d x %d bp reads (10%% ONT-like error) vs %.0f Mbp synthetic reference (%d contigs), k %d, segLength %d, sketchSize %d, pi %.2f: "
+             "workload": "%d x %d bp " + ("assembly contigs (the reference + 1%% substitutions + rearrangements)" if W.get("assembly") else "reads (10%% ONT-like error)") + " vs %.0f Mbp synthetic reference (%d contigs), k %d, segLength %d, sketchSize %d, pi %.2f: "
                          "%d fragments, %.1f interval points per fragment, %d L1 candidates, %d L2 loci, %d candidate mappings (last pass)"
                          % (nreads, READ_LEN, sum(len(a) for a in ref_np) / 1e6, len(ref_np), W["k"], W["seg"], W["sketch"], W["pi"], nF,
                             float(stats["nPoints"].mean()), n1, n2, nmap)}
@@ -669,6 +670,17 @@ def north_star_target(torch, dev, capi, local, warmup, steps, cpu_reads=0, nb=3,
     out["sketchSize_note"] = base["sketch_note"]
     out["synthetic_data_s"] = round(gen_s, 2)
     out["segLength_10000"] = res["segLength10000"]
+    if configs2:
+        # BASELINE configs[2] on the same reference: the 3 Gbp assembly against it, --pi 95 -s 10000 -J 40 -f one-to-one -- resident passes, then
+        # FASTA -> PAF through the command line (`bench.py --workload configs2` is the same measurement by itself)
+        try:
+            W2 = dict(WORKLOADS["configs2"])
+            c2 = measure(contigs, ref_np, W2, "configs2", True)
+            c2["e2e"] = e2e_assembly(torch, dev, W2, contigs, max(4, min(128, os.cpu_count() or 1)))
+            out["configs2"] = c2
+            log("[north_star] configs2: %.1f Gbp/s resident, %.1f ms per pass; FASTA -> PAF %s" % (c2["value"], c2["ms_per_step"], {k: c2["e2e"].get(k) for k in ("value", "map_s", "error")}))
+        except Exception as e:
+            log("[north_star] configs2 failed:", repr(e)); out["configs2"] = {"error": repr(e)}
     del contigs, ref_np
     torch.cuda.empty_cache()
     if repeat_rich:
@@ -919,6 +931,8 @@ def compact_line(full, full_path=None):
     c2 = full.get("configs2")
     if isinstance(c2, dict):
         line["configs2"] = _compact_side(c2)
+        if isinstance(c2.get("e2e"), dict) and line["configs2"] is not None:
+            line["configs2"]["e2e"] = _pick(c2["e2e"], ("value", "map_s", "paf_lines", "error"))
     if full_path:
         line["full"] = full_path
     # whatever a future key adds, the line is never allowed past the limit: shed the optional objects, largest first
@@ -1125,6 +1139,7 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="default run only: skip the FASTA -> PAF run of the mashmap_hip command line")
     ap.add_argument("--no-north-star", action="store_true", help="default run only: skip the north_star target measurements (3 Gbp index) behind the headline one")
     ap.add_argument("--no-repeat-rich", action="store_true", help="default run only: skip north_star_target.repeat_rich")
+    ap.add_argument("--no-configs2", action="store_true", help="default run only: skip the configs[2] measurement (3 Gbp assembly vs the 3 Gbp reference) behind the north_star ones")
     ap.add_argument("--north-star-steps", type=int, default=6, help="timed passes of each north_star variant (at most --steps)")
     ap.add_argument("--ref-contigs", type=int, default=0, help="contigs of the synthetic reference (default: the workload's)")
     ap.add_argument("--ref-contig-len", type=int, default=0)
@@ -1146,7 +1161,7 @@ def main():
         from mashmap_amd import capi
         torch.cuda.set_device(0)
         print(json.dumps(north_star_target(torch, torch.device("cuda", 0), capi, 0, args.warmup, args.steps, 0 if args.no_cpu_baseline else args.cpu_sample,
-                                           nb=args.batches, repeat_rich=not args.no_repeat_rich)), flush=True)
+                                           nb=args.batches, repeat_rich=not args.no_repeat_rich, configs2=not args.no_configs2)), flush=True)
         return
 
     # ---- N ranks: start them ourselves unless a launcher already did
@@ -1323,11 +1338,13 @@ def main():
             torch.cuda.empty_cache()
             cmd = [sys.executable, os.path.abspath(__file__), "--north-star-child", "--steps", str(max(1, min(args.steps, args.north_star_steps))),
                    "--warmup", str(min(max(args.warmup, args.batches), 4)), "--cpu-sample", str(args.cpu_sample), "--batches", str(args.batches)] \
-                  + (["--no-cpu-baseline"] if args.no_cpu_baseline else []) + (["--no-repeat-rich"] if args.no_repeat_rich else [])
+                  + (["--no-cpu-baseline"] if args.no_cpu_baseline else []) + (["--no-repeat-rich"] if args.no_repeat_rich else []) + (["--no-configs2"] if args.no_configs2 else [])
             try:
                 p = subprocess.run(cmd, stdout=subprocess.PIPE, timeout=1200, env=dict(os.environ, HIP_VISIBLE_DEVICES=os.environ.get("HIP_VISIBLE_DEVICES", str(local))))
                 line = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
                 out["north_star_target"] = json.loads(line[-1]) if p.returncode == 0 and line else {"error": "child exited with %d" % p.returncode}
+                if isinstance(out["north_star_target"], dict) and "configs2" in out["north_star_target"]:
+                    out["configs2"] = out["north_star_target"].pop("configs2")
             except Exception as e:
                 log("[bench] north_star target measurement failed:", repr(e))
                 out["north_star_target"] = {"error": repr(e)}

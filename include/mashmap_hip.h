@@ -47,9 +47,9 @@ enum {
 typedef struct {
   int32_t kmerSize;       /* Parameters::kmerSize   (1..64; 16..32 take the tuned strip hasher, 19 -- the reference's default -- the tuned tail as well) */
   int32_t segLength;      /* Parameters::segLength  */
-  int32_t sketchSize;     /* Parameters::sketchSize (1 .. 10000.  Up to 8190 the sketch and L2 kernels keep their state in a CU's 160 KB of LDS -- mm_create
+  int32_t sketchSize;     /* Parameters::sketchSize (1 .. 65535.  Up to 8190 the sketch and L2 kernels keep their state in a CU's 160 KB of LDS -- mm_create
                              checks the combination with segLength and says what does not fit --; beyond, every fragment takes a global-memory sketch
-                             kernel and the literal L2 kernels: exact, not fast; 10000 is what the index build's LDS holds) */
+                             kernel and the literal L2 kernels, and beyond 10000 the index build keeps a window's sketch in HBM as well: exact, not fast) */
   int32_t flags;          /* MM_FLAG_* */
 } mm_params;
 
@@ -236,6 +236,9 @@ typedef struct {
 int mm_reads_upload_packed_parts(mm_ctx* ctx, const mm_packed_part* parts, size_t nParts, int32_t seqCounterBase);
 int mm_reads_prefetch_packed_append(mm_ctx* ctx, const uint32_t* bases2, const uint32_t* nmask, size_t nPackedBases, size_t reservePackedBases, int* staged);
 int mm_reads_prefetch_drop(mm_ctx* ctx);
+/* allocates the staging area (and the copy stream) for reservePackedBases ahead of the first piece, e.g. while the index is being built:
+ * the first mm_reads_prefetch_packed_append then does not stop for a multi-gigabyte hipMalloc.  Only while nothing is staged. */
+int mm_reads_prefetch_reserve(mm_ctx* ctx, size_t reservePackedBases);
 size_t mm_pack_read(const char* ascii, size_t len, uint32_t* bases2, uint32_t* nmask);
 size_t mm_pack_read_portable(const char* ascii, size_t len, uint32_t* bases2, uint32_t* nmask);
 int mm_reads_packed_download(mm_ctx* ctx, uint32_t* bases2, uint32_t* nmask, uint32_t* readHasN, size_t* nPackedBases);

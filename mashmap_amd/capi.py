@@ -132,6 +132,7 @@ def load():
         "mm_reads_upload_packed_parts": (C.c_int, [vp, vp, sz, C.c_int32]),
         "mm_reads_prefetch_packed_append": (C.c_int, [vp, vp, vp, sz, sz, C.POINTER(C.c_int)]),
         "mm_reads_prefetch_drop": (C.c_int, [vp]),
+        "mm_reads_prefetch_reserve": (C.c_int, [vp, sz]),
         "mm_synchronize": (C.c_int, [vp]),
         "mm_stream": (vp, [vp]),
     }
@@ -157,7 +158,7 @@ EXPORTS = ["mm_abi_version", "mm_create", "mm_destroy", "mm_last_error", "mm_ind
            "mm_gathered_counts", "mm_gathered_download", "mm_gathered_device", "mm_index_replicate", "mm_stat_replay_tables", "mm_host_alloc", "mm_host_free", "mm_reads_prefetch",
            "mm_reads_upload_packed", "mm_reads_prefetch_packed", "mm_pack_read", "mm_pack_read_portable", "mm_reads_packed_download",
            "mm_index_layout_get", "mm_pass_stats", "mm_comm_info", "mm_pass_totals", "mm_reads_exchange", "mm_reads_upload_packed_parts",
-           "mm_reads_prefetch_packed_append", "mm_reads_prefetch_drop"]
+           "mm_reads_prefetch_packed_append", "mm_reads_prefetch_drop", "mm_reads_prefetch_reserve"]
 
 
 def stat_sketch_cutoffs(sketchSize, k, hg=True):

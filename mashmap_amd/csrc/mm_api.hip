@@ -15,7 +15,7 @@ static const char* kKernelNames[MM_K_COUNT] = {
 
 std::vector<DevBuf*> mm_ctx::allBufs() {
   DeviceIndex& I = idx;
-  return {&I.evKey, &I.evAux, &I.evHash, &I.contigOff, &I.opKey, &I.opAux, &I.opHash, &I.blockOff, &I.evBlock, &I.contigBlock, &I.contigLen, &I.refGroup,
+  return {&I.evKey, &I.evAux, &I.evHash, &I.evRev, &I.contigOff, &I.opKey, &I.opAux, &I.opHash, &I.blockOff, &I.evBlock, &I.contigBlock, &I.contigLen, &I.refGroup,
           &I.htSlots, &I.htTags, &I.filter, &I.ptKeys, &I.keys, &I.keyOff, &I.keyFreq, &dMinHits, &dCutoffs, &dAscii, &dAsciiNext, &dReadSrcOff, &dReadPackOff, &dReadLen, &dReadGroup, &dReadSelf, &dReadHasN,
           &dBases2, &dNmask, &dFrags, &dSkHash, &dSkPos, &dSkStrand, &dSkCount, &dHardList, &dCounters, &dSketchSpill, &dSketchTabs, &dQHash, &dQStrand,
           &dStats, &dPtOff, &dPts, &dPtKept, &dPtIds, &dWinFreq, &dWinExt, &dWinHeap, &dWinKeys, &dWinVals, &dWinOffH, &dWinOffT, &dWinCntH, &dWinCntT, &dL1, &dL1b, &dL1Cursors, &dL1Off, &dL1Regions, &dL2, &dL2Info, &dL2Cnt, &dL2Off, &dL2Ops, &dScanTmp, &dL2Tmp, &dL2Wide, &dL2Exact, &dL2Cells,
@@ -452,6 +452,14 @@ int mm_reads_prefetch_packed_append(mm_ctx* c, const uint32_t* bases2, const uin
   if (staged) *staged = 0;
   if (!bases2 || !nmask || !nPackedBases) return MM_OK;
   return stage_packed(c, bases2, nmask, nPackedBases, reservePackedBases, staged);
+}
+
+int mm_reads_prefetch_reserve(mm_ctx* c, size_t reservePackedBases) {
+  std::lock_guard<std::mutex> prefetchLock(c->prefetchMu);
+  if (!c->staged.empty() || c->prefetchValid) return MM_OK;
+  { const int rc = prefetch_streams(c); if (rc != MM_OK) return rc; }
+  MM_HIP(c, c->dAsciiNext.ensure(reservePackedBases / 4 + reservePackedBases / 8 + 64));
+  return MM_OK;
 }
 
 int mm_reads_prefetch_drop(mm_ctx* c) {

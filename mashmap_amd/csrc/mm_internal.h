@@ -62,6 +62,7 @@ struct DeviceIndex {
   DevBuf evKey;                // uint32 pos*2 + isInsert
   DevBuf evAux;                // uint32 insert: wpos_end | REV<<31 ; eviction: 0
   DevBuf evHash;               // uint64 hash of the record
+  DevBuf evRev;                // uint64 words, bit e = event e is the insert of a REV record (evAux bit 31 once more, 1 bit instead of 4 bytes: all the slide of k_l2_locate needs of evAux)
   DevBuf contigOff;            // int64[nContigs+1] event offsets
   // records still open at every MM_OPEN_BLOCK-th position (wpos < B < wpos_end, index order), as insert events: the L2 pre-load of a
   // candidate starts from the list of its block instead of streaming a whole segLength of events (computeMap.hpp:1323-1338)
@@ -238,8 +239,9 @@ int mm_launch_pack_raw(mm_ctx* c, const uint8_t* dAscii, const int64_t* dSrcOff,
 int mm_launch_sketch(mm_ctx* c);
 int mm_launch_sketch_global(mm_ctx* c);   // mm_sketch_global.hip: sketches no LDS table holds (sketchSize > MM_LDS_MAX_SKETCH)
 #define MM_LDS_MAX_SKETCH 8190             // beyond: the global-memory sketch kernel and the literal L2 kernels (any size up to MM_MAX_SKETCH)
-#define MM_MAX_SKETCH 10000                // a window's sketch of the device index build (k_winnow_tiles: 16 bytes per entry + the candidate stage) must fit a CU's 160 KB of LDS;
-                                           // the reference's --dense at 100 kbp segments derives 9 998 (parseCmdArgs.hpp:626-630)
+#define MM_WINNOW_LDS_SKETCH 10000         // the device index build keeps a window's sketch in LDS up to here (k_winnow_tiles: 16 bytes per entry + the candidate stage in a CU's
+                                           // 160 KB; the reference's --dense at 100 kbp segments derives 9 998, parseCmdArgs.hpp:626-630), in HBM beyond (k_winnow_tiles<.., GSK>)
+#define MM_MAX_SKETCH 65535                // seeds are numbered in 16 bits where the literal kernels count windows per seed (mm_map.hip: ptIds); the reference takes any size
 int mm_launch_map(mm_ctx* c);
 // Steady state: once a pass of a context has sized every staging buffer, the next passes launch everything against
 // those capacities with the counts left on the device and read ONE block of counters back at the end (one host synchronisation per

@@ -391,7 +391,9 @@ __device__ __noinline__ int mm_fused_long_runs(uint64_t mLong, int c, int my, ui
   return nValid;
 }
 #define MM_LOOKUP_WPB 4             // waves (= fragments) per workgroup
-#define MM_MID_MAXSKETCH 512        // k_lookup_mid (below): sketch entries whose table answers its LDS holds,
+#define MM_MID_MAXSKETCH 512        // k_lookup_mid (below): sketch sizes it serves,
+#define MM_MID_MAXSEEDS 256         // surviving seeds WITH points whose runs its LDS lists (a fragment with more goes to the HBM path),
+#define MM_MID_MAXKEEP 1024         // interval points that may survive its filter (sorted in registers, 16 per lane),
 #define MM_MID_MAXPTS 16384         // and interval points of a fragment it takes (8 192 intervals: its 16-bit bin counters cannot overflow)
 #define MM_L1_REGIONS 64            // L1 output cursors: a same-address atomic costs ~10 ns, so fragments spread over 64 of them
 #define MM_L1_CURSOR_STRIDE 32      // u64 words between cursors (256 bytes)
@@ -702,6 +704,16 @@ k_filter_points(int nList, const int32_t* __restrict__ list, const mm_frag_stats
 // boundary rule: tests/l1filter.py is the model) and writes them into the LDS list; at most 512 survivors are sorted in registers and
 // swept by mm_l1_fused exactly as in k_lookup_l1, and the candidates go to the same region cursors.  A fragment with more survivors, with
 // an interval the filter gives up on, or whose sorted list needs the literal sweep is queued for the HBM path as k_lookup_l1 would have.
+// 513 .. 1 024 surviving points: sixteen per lane.  Out of line: the common sizes keep their registers.
+__device__ __noinline__ int mm_mid_sort16(FuseScratchT<MM_MID_MAXKEEP>& sc, int sketchSizeQ, int minHits, int hg, const int32_t* __restrict__ cutoffs, int nCutoffs,
+                                          int sParam, int segLength, int lane) {
+  uint64_t k[16];
+#pragma unroll
+  for (int e = 0; e < 16; e++) k[e] = sc.a[lane * 16 + e];
+  mm_wave_bitonic<16>(k, lane);
+  return mm_l1_fused<16>(k, sc, sketchSizeQ, minHits, hg, cutoffs, nCutoffs, sParam, segLength, lane);
+}
+
 template <bool TAGS>
 __global__ void __launch_bounds__(64)
 k_lookup_mid(int nList, const unsigned long long* __restrict__ nDev, const int32_t* __restrict__ list, int s, const DFrag* __restrict__ frags,
@@ -710,12 +722,20 @@ k_lookup_mid(int nList, const unsigned long long* __restrict__ nDev, const int32
              unsigned long long ptsCap, const int32_t* __restrict__ minHitsTab, const int32_t* __restrict__ cutoffs, int nCutoffs, int segLength,
              mm_l1_candidate* __restrict__ l1, unsigned long long regionCap, unsigned long long* __restrict__ l1Cursors, int64_t* __restrict__ l1Off,
              int32_t* __restrict__ bigList, unsigned long long* __restrict__ counters) {
-  typedef FuseScratchT<512> FuseScratch;
-  __shared__ FuseScratch sc;
-  __shared__ uint64_t seedVal[MM_MID_MAXSKETCH];                 // table answer of every surviving seed (offset << 24 | count << 1), 0: none
-  __shared__ uint32_t binCnt[MM_FILT_SLOTS / 2];                 // two 16-bit counters per word
-  __shared__ int32_t cKey[MM_FILT_CONTIGS];
-  __shared__ uint32_t cMin[MM_FILT_CONTIGS], cMax[MM_FILT_CONTIGS];
+  // LDS of the one wave: the survivors' list (FuseScratch::a) lives through both phases; the seeds' runs, the bins and the contig extents
+  // are dead when the sort starts and share their bytes with what mm_l1_fused needs then (FuseScratch::v, ::run)
+  typedef FuseScratchT<MM_MID_MAXKEEP> FuseScratch;
+  struct Phase1 {
+    uint64_t src[MM_MID_MAXSEEDS];                                 // first point of every surviving seed's run
+    uint32_t pre[MM_MID_MAXSEEDS + 1];                             // intervals (point pairs) of the seeds before it
+    uint32_t binCnt[MM_FILT_SLOTS / 2];                            // two 16-bit counters per word
+    int32_t cKey[MM_FILT_CONTIGS]; uint32_t cMin[MM_FILT_CONTIGS], cMax[MM_FILT_CONTIGS];
+  };
+  constexpr size_t kTail = sizeof(FuseScratch) - offsetof(FuseScratch, v);
+  constexpr size_t kBytes = offsetof(FuseScratch, v) + (sizeof(Phase1) > kTail ? sizeof(Phase1) : kTail);
+  __shared__ __attribute__((aligned(16))) unsigned char smem[kBytes];
+  FuseScratch& sc = *(FuseScratch*)smem;
+  Phase1& ph = *(Phase1*)(smem + offsetof(FuseScratch, v));
   const int lane = (int)mm_lane();
   if (nDev) nList = (int)*nDev;
   for (int li = blockIdx.x; li < nList; li += gridDim.x) {
@@ -727,114 +747,102 @@ k_lookup_mid(int nList, const unsigned long long* __restrict__ nDev, const int32
     const mm_frag_stats st0 = stats[f];
     const int outIdx = st0.sketchSize;
     const int minHits = outIdx > 0 ? minHitsTab[outIdx] : 0;
-    for (int i = lane; i < MM_FILT_SLOTS / 2; i += 64) binCnt[i] = 0u;
-    for (int i = lane; i < MM_FILT_CONTIGS; i += 64) { cKey[i] = -1; cMin[i] = 0xFFFFFFFFu; cMax[i] = 0u; }
-    int P = 0;
+    for (int i = lane; i < MM_FILT_SLOTS / 2; i += 64) ph.binCnt[i] = 0u;
+    for (int i = lane; i < MM_FILT_CONTIGS; i += 64) { ph.cKey[i] = -1; ph.cMin[i] = 0xFFFFFFFFu; ph.cMax[i] = 0u; }
+    // the seeds once more; those with points are listed densely: run start + intervals before it
+    int nSeeds = 0, nPairs = 0, P = 0; bool giveUp = false;
     for (int base = 0; base < cnt; base += 256) {
       uint64_t h[4], val[4]; bool act[4], found[4];
       mm_probe4<TAGS>(T, skHash, fo, cnt, base, lane, h, act, found, val);
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         const bool kf = act[u] && found[u] && !(val[u] & 1ull);
-        if (base + u * 64 + lane < MM_MID_MAXSKETCH) seedVal[base + u * 64 + lane] = kf ? val[u] : 0ull;
-        P += kf ? (int)((val[u] >> 1) & 0x7fffffull) : 0;
+        const int c = kf ? (int)((val[u] >> 1) & 0x7fffffull) : 0;
+        if (c & 1) giveUp = true;                                  // (never: a hash's points are its intervals' two ends)
+        const uint64_t m = mm_ballot(c > 0);
+        const int at = nSeeds + (int)mm_popc_below(m);
+        const int before = nPairs + mm_wave_excl_scan(c >> 1);
+        if (c > 0 && at < MM_MID_MAXSEEDS) { ph.src[at] = val[u] >> 24; ph.pre[at] = (uint32_t)before; }
+        nSeeds += (int)__popcll(m); nPairs += mm_wave_sum(c >> 1); P += mm_wave_sum(c);
       }
     }
-    P = mm_wave_sum(P);
+    if (nSeeds > MM_MID_MAXSEEDS) { giveUp = true; nSeeds = MM_MID_MAXSEEDS; nPairs = 0; }
+    if (lane == 0) ph.pre[nSeeds] = (uint32_t)nPairs;
     __threadfence_block();
+    // interval g of the fragment = pair (g - pre[j]) of seed j's run, j by binary search: every lane of every round has one
+    auto pairAt = [&](int g, uint64_t& O, uint64_t& C) {
+      int lo = 0, hi = nSeeds - 1;
+      while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if ((int)ph.pre[mid] <= g) lo = mid; else hi = mid - 1; }
+      const ulonglong2 oc = *(const ulonglong2*)(ptKeys + ph.src[lo] + 2 * (uint64_t)(g - (int)ph.pre[lo]));
+      O = oc.x; C = oc.y;
+    };
     auto dropped = [&](uint64_t key) {
       const int seqId = (int)(key >> 33);
       return (fl.skipSelf && seqId == self) || (fl.lowerTri && !(seqCounter > seqId));
     };
-    // sweep 1: bins and contig extents.  A seed's run is a sequence of (OPEN, CLOSE) pairs; short runs by the lane that owns the seed, long
-    // ones by the whole wave
-    bool giveUp = false; int nValid = 0;
-    auto count = [&](uint64_t O, uint64_t C) {
-      if (dropped(O)) return;
-      nValid += 2;
-      const uint32_t seq = (uint32_t)(O >> 33), o = (uint32_t)(O >> 1), c = (uint32_t)(C >> 1);
-      const uint32_t b0 = o >> MM_FILT_SHIFT, b1 = (c - 1u) >> MM_FILT_SHIFT;
-      if (c <= o || b1 - b0 >= (uint32_t)MM_FILT_MAXSPAN || (uint32_t)(C >> 33) != seq) { giveUp = true; return; }
-      for (uint32_t b = b0; b <= b1; b++) { const uint32_t sl = mm_bin_slot(seq, b); atomicAdd(&binCnt[sl >> 1], 1u << (16 * (sl & 1u))); }
-      uint32_t sl = (seq * 0x9E3779B1u) >> 25;
-      int tries = 0;
-      for (; tries < MM_FILT_CONTIGS; tries++) {
-        const int32_t prev = atomicCAS(&cKey[sl], -1, (int32_t)seq);
-        if (prev == -1 || prev == (int32_t)seq) { atomicMin(&cMin[sl], o); atomicMax(&cMax[sl], c); break; }
-        sl = (sl + 1u) & (MM_FILT_CONTIGS - 1);
-      }
-      if (tries == MM_FILT_CONTIGS) giveUp = true;
-    };
-    const int nRounds = (cnt + 63) >> 6;
-    for (int rd = 0; rd < nRounds; rd++) {
-      const uint64_t val = seedVal[rd * 64 + lane < MM_MID_MAXSKETCH ? rd * 64 + lane : 0];
-      const int c = rd * 64 + lane < cnt ? (int)((val >> 1) & 0x7fffffull) : 0;
-      const uint64_t src = val >> 24;
-      if (c & 1) giveUp = true;                                   // (never: a hash's points are its intervals' two ends)
-      const bool longRun = c > 8;
-      if (!longRun) for (int j = 0; j + 1 < c; j += 2) count(ptKeys[src + j], ptKeys[src + j + 1]);
-      uint64_t mLong = mm_ballot(longRun);
-      while (mLong) {
-        const int l = (int)__builtin_ctzll(mLong); mLong &= mLong - 1ull;
-        const int cL = __shfl(c, l);
-        const uint64_t srcL = ((uint64_t)(uint32_t)__shfl((int)(src >> 32), l) << 32) | (uint32_t)__shfl((int)(uint32_t)src, l);
-        for (int j = 2 * lane; j + 1 < cL; j += 128) count(ptKeys[srcL + j], ptKeys[srcL + j + 1]);
+    // sweep 1: intervals per 4 096-position bin, first / last position per contig
+    int nValid = 0;
+    for (int g0 = 0; g0 < nPairs; g0 += 128) {
+      uint64_t O[2], C[2]; bool on[2];
+#pragma unroll
+      for (int u = 0; u < 2; u++) { const int g = g0 + u * 64 + lane; on[u] = g < nPairs; O[u] = C[u] = MM_EMPTY; if (on[u]) pairAt(g, O[u], C[u]); }
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        if (!on[u] || dropped(O[u])) continue;
+        nValid += 2;
+        const uint32_t seq = (uint32_t)(O[u] >> 33), o = (uint32_t)(O[u] >> 1), c = (uint32_t)(C[u] >> 1);
+        const uint32_t b0 = o >> MM_FILT_SHIFT, b1 = (c - 1u) >> MM_FILT_SHIFT;
+        if (c <= o || b1 - b0 >= (uint32_t)MM_FILT_MAXSPAN || (uint32_t)(C[u] >> 33) != seq) { giveUp = true; continue; }
+        for (uint32_t b = b0; b <= b1; b++) { const uint32_t sl = mm_bin_slot(seq, b); atomicAdd(&ph.binCnt[sl >> 1], 1u << (16 * (sl & 1u))); }
+        uint32_t sl = (seq * 0x9E3779B1u) >> 25;
+        int tries = 0;
+        for (; tries < MM_FILT_CONTIGS; tries++) {
+          const int32_t prev = atomicCAS(&ph.cKey[sl], -1, (int32_t)seq);
+          if (prev == -1 || prev == (int32_t)seq) { atomicMin(&ph.cMin[sl], o); atomicMax(&ph.cMax[sl], c); break; }
+          sl = (sl + 1u) & (MM_FILT_CONTIGS - 1);
+        }
+        if (tries == MM_FILT_CONTIGS) giveUp = true;
       }
     }
     __threadfence_block();
     nValid = mm_wave_sum(nValid);
     bool fallback = mm_ballot(giveUp) != 0ull;
-    // sweep 2: the intervals that can matter, into the LDS list
+    // sweep 2: the intervals that can matter (k_filter_points' rule), into the LDS list
     int cursor = 0;                                                // pairs kept so far (wave-uniform)
-    auto keeps = [&](uint64_t O, uint64_t C) {
-      if (dropped(O)) return false;
-      const uint32_t seq = (uint32_t)(O >> 33), o = (uint32_t)(O >> 1), c = (uint32_t)(C >> 1);
-      const uint32_t b0 = o >> MM_FILT_SHIFT, b1 = (c - 1u) >> MM_FILT_SHIFT;
-      bool keep = false;
-      for (uint32_t b = b0; b <= b1; b++) { const uint32_t sl = mm_bin_slot(seq, b); keep = keep || ((binCnt[sl >> 1] >> (16 * (sl & 1u))) & 0xFFFFu) >= (uint32_t)minHits; }
-      uint32_t sl = (seq * 0x9E3779B1u) >> 25;
-      while (cKey[sl] != (int32_t)seq) sl = (sl + 1u) & (MM_FILT_CONTIGS - 1);
-      return keep || o == cMin[sl] || c == cMax[sl];
-    };
-    for (int rd = 0; rd < nRounds && !fallback; rd++) {
-      const uint64_t val = seedVal[rd * 64 + lane < MM_MID_MAXSKETCH ? rd * 64 + lane : 0];
-      const int c = rd * 64 + lane < cnt ? (int)((val >> 1) & 0x7fffffull) : 0;
-      const uint64_t src = val >> 24;
-      const bool longRun = c > 8;
-      uint32_t km = 0;                                             // short run (at most 4 pairs): which of them stay
-      if (!longRun) for (int j = 0; j + 1 < c; j += 2) if (keeps(ptKeys[src + j], ptKeys[src + j + 1])) km |= 1u << (j >> 1);
-      const int mine = __popc(km);
-      const int at0 = cursor + mm_wave_excl_scan(mine);
-      const int tot = mm_wave_sum(mine);
-      if (cursor + tot > 256) { fallback = true; break; }
-      { int at = at0; for (int j = 0; j + 1 < c && !longRun; j += 2) if (km & (1u << (j >> 1))) { sc.a[2 * at] = ptKeys[src + j]; sc.a[2 * at + 1] = ptKeys[src + j + 1]; at++; } }
-      cursor += tot;
-      uint64_t mLong = mm_ballot(longRun);
-      while (mLong && !fallback) {
-        const int l = (int)__builtin_ctzll(mLong); mLong &= mLong - 1ull;
-        const int cL = __shfl(c, l);
-        const uint64_t srcL = ((uint64_t)(uint32_t)__shfl((int)(src >> 32), l) << 32) | (uint32_t)__shfl((int)(uint32_t)src, l);
-        for (int j0 = 0; j0 < cL; j0 += 128) {
-          const int j = j0 + 2 * lane;
-          uint64_t O = MM_EMPTY, C = MM_EMPTY; bool keep = false;
-          if (j + 1 < cL) { O = ptKeys[srcL + j]; C = ptKeys[srcL + j + 1]; keep = keeps(O, C); }
-          const uint64_t m = mm_ballot(keep);
-          const int k = (int)__popcll(m);
-          if (cursor + k > 256) { fallback = true; break; }
-          if (keep) { const int at = cursor + (int)mm_popc_below(m); sc.a[2 * at] = O; sc.a[2 * at + 1] = C; }
-          cursor += k;
+    for (int g0 = 0; g0 < nPairs && !fallback; g0 += 128) {
+      uint64_t O[2], C[2]; bool keep[2];
+#pragma unroll
+      for (int u = 0; u < 2; u++) { const int g = g0 + u * 64 + lane; keep[u] = g < nPairs; O[u] = C[u] = MM_EMPTY; if (keep[u]) pairAt(g, O[u], C[u]); }
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        if (keep[u]) keep[u] = !dropped(O[u]);
+        if (keep[u]) {
+          const uint32_t seq = (uint32_t)(O[u] >> 33), o = (uint32_t)(O[u] >> 1), c = (uint32_t)(C[u] >> 1);
+          const uint32_t b0 = o >> MM_FILT_SHIFT, b1 = (c - 1u) >> MM_FILT_SHIFT;
+          bool k = false;
+          for (uint32_t b = b0; b <= b1; b++) { const uint32_t sl = mm_bin_slot(seq, b); k = k || ((ph.binCnt[sl >> 1] >> (16 * (sl & 1u))) & 0xFFFFu) >= (uint32_t)minHits; }
+          uint32_t sl = (seq * 0x9E3779B1u) >> 25;
+          while (ph.cKey[sl] != (int32_t)seq) sl = (sl + 1u) & (MM_FILT_CONTIGS - 1);
+          keep[u] = k || o == ph.cMin[sl] || c == ph.cMax[sl];
         }
+        const uint64_t m = mm_ballot(keep[u]);
+        const int k = (int)__popcll(m);
+        if (cursor + k > MM_MID_MAXKEEP / 2) { fallback = true; break; }
+        if (keep[u]) { const int at = cursor + (int)mm_popc_below(m); sc.a[2 * at] = O[u]; sc.a[2 * at + 1] = C[u]; }
+        cursor += k;
       }
     }
+    __threadfence_block();                                         // phase 1's LDS is free from here on
     int nOut = -1;
     if (!fallback) {
       const int K = 2 * cursor;
       if (K == 0) nOut = 0;
       else {
-        const int padTo = K <= 64 ? 64 : K <= 128 ? 128 : K <= 256 ? 256 : 512;
+        const int padTo = K <= 64 ? 64 : K <= 128 ? 128 : K <= 256 ? 256 : K <= 512 ? 512 : 1024;
         for (int j = K + lane; j < padTo; j += 64) sc.a[j] = MM_EMPTY;
         __threadfence_block();
-        if (K <= 64) { uint64_t k[1] = {sc.a[lane]}; mm_wave_bitonic<1>(k, lane); nOut = mm_l1_fused<1>(k, sc, outIdx, minHits, fl.hg, cutoffs, nCutoffs, s, segLength, lane); }
+        if (K > 512) nOut = mm_mid_sort16(sc, outIdx, minHits, fl.hg, cutoffs, nCutoffs, s, segLength, lane);
+        else if (K <= 64) { uint64_t k[1] = {sc.a[lane]}; mm_wave_bitonic<1>(k, lane); nOut = mm_l1_fused<1>(k, sc, outIdx, minHits, fl.hg, cutoffs, nCutoffs, s, segLength, lane); }
         else if (K <= 128) { uint64_t k[2] = {sc.a[lane * 2], sc.a[lane * 2 + 1]}; mm_wave_bitonic<2>(k, lane); nOut = mm_l1_fused<2>(k, sc, outIdx, minHits, fl.hg, cutoffs, nCutoffs, s, segLength, lane); }
         else if (K <= 256) {
           uint64_t k[4] = {sc.a[lane * 4], sc.a[lane * 4 + 1], sc.a[lane * 4 + 2], sc.a[lane * 4 + 3]};

@@ -795,12 +795,10 @@ int mm_check_params(const mm_params* p, std::string& err) {
   if (s > MM_LDS_MAX_SKETCH) {
     // no LDS kernel holds this sketch: the global-memory sketch kernel (mm_sketch_global.hip) and the literal L2 kernels take every
     // fragment -- exact, slow; the stock binary runs these sizes (--dense at segments of 100 kbp), so they run here too
-    // ... except the index build: k_winnow_tiles (mm_winnow.hip) keeps the sketch of a reference window in LDS, 16 bytes per entry next to
-    // at least 64 candidates of 13 bytes -- checked here, so that a context mm_create accepts is one mm_index_build can serve
-    const size_t ldsWinnow = (size_t)(s + 1) * 16 + 64 * 13 + 16;
-    if (s > MM_MAX_SKETCH || ldsWinnow > lim) {
-      err = "mm_create: sketchSize " + std::to_string(s) + " is beyond " + std::to_string(MM_MAX_SKETCH) + " (the device index build holds a window's sketch in LDS: " +
-            std::to_string(ldsWinnow) + " bytes of a CU's " + std::to_string(lim) + ")";
+    // ... and so does the index build: k_winnow_tiles (mm_winnow.hip) keeps the sketch of a reference window in LDS up to
+    // MM_WINNOW_LDS_SKETCH entries and in HBM beyond
+    if (s > MM_MAX_SKETCH) {
+      err = "mm_create: sketchSize " + std::to_string(s) + " is beyond " + std::to_string(MM_MAX_SKETCH) + " (seeds are numbered in 16 bits by the literal mapping kernels)";
       return MM_ERR_ARG;
     }
     return MM_OK;

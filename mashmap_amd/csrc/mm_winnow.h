@@ -10,6 +10,7 @@ struct WinnowBuffers {       // grow-only device scratch shared by the contigs o
   DevBuf blockCnt, blockOff, cPos, cHash, cSt;
   DevBuf out, outCount, outOff, open, openCount, status, dense;
   DevBuf redoList, out2, outCount2, open2, openCount2, status2;
+  DevBuf skScratch;          // k_winnow_tiles<.., GSK>: the window's sketch per tile slot, for sketches LDS does not hold
   // page-locked landing area for a contig's records and open lists (hundreds of megabytes per contig at human scale): the copy down
   // runs at the link's rate instead of through the runtime's pageable staging, and the host vectors are filled from it in one pass
   // (a vector sized first is zero-filled first)
@@ -28,7 +29,7 @@ struct WinnowBuffers {       // grow-only device scratch shared by the contigs o
   void release() {
     for (int i = 0; i < 2; i++) if (hStage[i]) { (void)hipHostFree(hStage[i]); hStage[i] = nullptr; hStageBytes[i] = 0; }
     DevBuf* all[] = {&blockCnt, &blockOff, &cPos, &cHash, &cSt, &out, &outCount, &outOff, &open, &openCount, &status, &dense,
-                     &redoList, &out2, &outCount2, &open2, &openCount2, &status2};
+                     &redoList, &out2, &outCount2, &open2, &openCount2, &status2, &skScratch};
     for (DevBuf* b : all) b->release();
   }
 };

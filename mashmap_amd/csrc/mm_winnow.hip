@@ -139,9 +139,12 @@ struct WnSketch {
 // k_winnow_tiles<DENSE>: one wavefront per tile.
 //   index space: DENSE -> k-mer positions (H[i] == NONE: not a k-mer);  sparse -> indices into the candidate list
 // ---------------------------------------------------------------------------------------------
-template <bool DENSE>
+// GSK: the sketch of the window lives in HBM (skScratch: (s + 1) * 16 bytes per tile slot) instead of LDS -- sketches beyond what a CU's
+// 160 KB hold (sketchSize > 10 000: --dense at segments of 200 kbp and more, or a user's -J); the wave is the only reader and writer of
+// its slot, and its accesses are ordered by the same workgroup-scope fences as the LDS form's.
+template <bool DENSE, bool GSK = false>
 __global__ void __launch_bounds__(64)
-k_winnow_tiles(const int32_t* __restrict__ tileList,
+k_winnow_tiles(const int32_t* __restrict__ tileList, unsigned char* __restrict__ skScratch,
                const int32_t* __restrict__ cPos, const uint64_t* __restrict__ cHash, const int8_t* __restrict__ cSt, int64_t nCand,
                const uint64_t* __restrict__ H, const int8_t* __restrict__ ST,
                int len, int k, int w, int s, int TW, int nW, int ldsCand,
@@ -157,11 +160,12 @@ k_winnow_tiles(const int32_t* __restrict__ tileList,
   const bool lastTile = Wend == nW - 1;
 
   WnSketch sk;
-  sk.h = (uint64_t*)smem;
-  sk.start = (int32_t*)(smem + (size_t)(s + 1) * 8);
+  unsigned char* skMem = GSK ? skScratch + (size_t)slot * (size_t)(s + 1) * 16 : smem;
+  sk.h = (uint64_t*)skMem;
+  sk.start = (int32_t*)(skMem + (size_t)(s + 1) * 8);
   sk.sum = sk.start + (s + 1);
   sk.n = 0;
-  unsigned char* stage = smem + (size_t)(s + 1) * 16;
+  unsigned char* stage = GSK ? smem : smem + (size_t)(s + 1) * 16;
 
   // candidate view (flat pointers: LDS when the tile's candidates were staged, HBM otherwise)
   const int32_t* vPos = cPos; const uint64_t* vHash = DENSE ? H : cHash; const int8_t* vSt = DENSE ? ST : cSt;
@@ -366,19 +370,28 @@ int mm_winnow_contig_device(mm_ctx* c, WinnowBuffers& B, const uint64_t* dH, con
   MM_HIP(c, B.outCount.ensure((size_t)nTiles * 4 + 64)); MM_HIP(c, B.openCount.ensure((size_t)nTiles * 4 + 64));
   MM_HIP(c, B.status.ensure((size_t)nTiles * 4 + 64)); MM_HIP(c, B.open.ensure((size_t)nTiles * s * sizeof(WnOpenRun) + 64));
   MM_HIP(c, B.outOff.ensure((size_t)nTiles * 8 + 64));
-  const size_t ldsSketch = (size_t)(s + 1) * 16;
+  // the window's sketch in LDS while it fits next to at least 64 staged candidates (sketchSize <= MM_WINNOW_LDS_SKETCH), in HBM beyond
+  const bool gsk = s > MM_WINNOW_LDS_SKETCH;
+  const size_t ldsSketch = gsk ? 0 : (size_t)(s + 1) * 16;
   int ldsCand = 1024; while ((size_t)ldsCand * 13 + ldsSketch > 60 * 1024 && ldsCand > 64) ldsCand >>= 1;
   const size_t ldsSparse = ldsSketch + (size_t)ldsCand * 13 + 16;
-  MM_HIP(c, hipFuncSetAttribute((const void*)k_winnow_tiles<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsSparse));
-  MM_HIP(c, hipFuncSetAttribute((const void*)k_winnow_tiles<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsSketch + 16));
+  const size_t skBytes = (size_t)(s + 1) * 16;
+  if (gsk) MM_HIP(c, B.skScratch.ensure((size_t)nTiles * skBytes + 64));
+  unsigned char* skS = gsk ? B.skScratch.as<unsigned char>() : (unsigned char*)nullptr;
+  auto kSparse = gsk ? k_winnow_tiles<false, true> : k_winnow_tiles<false, false>;
+  auto kDense = gsk ? k_winnow_tiles<true, true> : k_winnow_tiles<true, false>;
+  if (!gsk) {
+    MM_HIP(c, hipFuncSetAttribute((const void*)k_winnow_tiles<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsSparse));
+    MM_HIP(c, hipFuncSetAttribute((const void*)k_winnow_tiles<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsSketch + 16));
+  }
   {
     KernelTimer t(c, MM_K_WINNOW);
     if (sparse)
-      hipLaunchKernelGGL((k_winnow_tiles<false>), dim3(nTiles), dim3(64), ldsSparse, c->stream, (const int32_t*)nullptr,
+      hipLaunchKernelGGL(kSparse, dim3(nTiles), dim3(64), ldsSparse, c->stream, (const int32_t*)nullptr, skS,
                          B.cPos.as<int32_t>(), B.cHash.as<uint64_t>(), B.cSt.as<int8_t>(), nCand, dH, dS, len, k, w, s, TW, nW, ldsCand,
                          B.out.as<mm_minmer>(), outCap, B.outCount.as<int32_t>(), B.open.as<WnOpenRun>(), B.openCount.as<int32_t>(), B.status.as<int32_t>());
     else
-      hipLaunchKernelGGL((k_winnow_tiles<true>), dim3(nTiles), dim3(64), ldsSketch + 16, c->stream, (const int32_t*)nullptr,
+      hipLaunchKernelGGL(kDense, dim3(nTiles), dim3(64), ldsSketch + 16, c->stream, (const int32_t*)nullptr, skS,
                          (const int32_t*)nullptr, (const uint64_t*)nullptr, (const int8_t*)nullptr, (int64_t)0, dH, dS, len, k, w, s, TW, nW, 0,
                          B.out.as<mm_minmer>(), outCap, B.outCount.as<int32_t>(), B.open.as<WnOpenRun>(), B.openCount.as<int32_t>(), B.status.as<int32_t>());
     MM_HIP(c, hipGetLastError());
@@ -431,8 +444,9 @@ int mm_winnow_contig_device(mm_ctx* c, WinnowBuffers& B, const uint64_t* dH, con
   MM_HIP(c, hipMemcpyAsync(B.redoList.p, redo.data(), (size_t)nRedo * 4, hipMemcpyHostToDevice, c->stream));
   {
     KernelTimer t(c, MM_K_WINNOW);
-    hipLaunchKernelGGL((k_winnow_tiles<true>), dim3(nRedo), dim3(64), ldsSketch + 16, c->stream, B.redoList.as<int32_t>(),
-                       (const int32_t*)nullptr, (const uint64_t*)nullptr, (const int8_t*)nullptr, (int64_t)0, dH, dS, len, k, w, s, TW, nW, 0,
+    if (gsk) MM_HIP(c, B.skScratch.ensure((size_t)nRedo * skBytes + 64));
+    hipLaunchKernelGGL(kDense, dim3(nRedo), dim3(64), ldsSketch + 16, c->stream, B.redoList.as<int32_t>(),
+                       gsk ? B.skScratch.as<unsigned char>() : (unsigned char*)nullptr, (const int32_t*)nullptr, (const uint64_t*)nullptr, (const int8_t*)nullptr, (int64_t)0, dH, dS, len, k, w, s, TW, nW, 0,
                        B.out2.as<mm_minmer>(), bigCap, B.outCount2.as<int32_t>(), B.open2.as<WnOpenRun>(), B.openCount2.as<int32_t>(), B.status2.as<int32_t>());
     MM_HIP(c, hipGetLastError());
   }

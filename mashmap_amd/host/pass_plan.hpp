@@ -35,7 +35,9 @@ class BatchChannel {
   // The items of one device pass: waits until `want` bases are queued -- or the producer is done, or the queue is full, or it holds
   // `maxItems` --, then takes items from the front until the pass holds `want` bases: at least one, at most `maxItems`.  false: the
   // producer is done and nothing is left.
-  bool getGroup(std::vector<T>& g, size_t want, size_t maxItems) {
+  // takeAll: once the wait is over the pass takes everything that is queued (up to maxItems), not just `want` bases' worth -- with a small
+  // `want` that is the greedy policy: a pass never waits for input that is not there yet and never leaves input behind that is.
+  bool getGroup(std::vector<T>& g, size_t want, size_t maxItems, bool takeAll = false) {
     std::unique_lock<std::mutex> lk(mu);
     cvEmpty.wait(lk, [&] {
       if (done || q.size() >= cap || q.size() >= maxItems) return !q.empty() || done;
@@ -44,7 +46,7 @@ class BatchChannel {
     });
     if (q.empty()) return false;
     size_t have = 0;
-    while (!q.empty() && g.size() < maxItems && (g.empty() || have < want)) { have += q.front().bases(); g.emplace_back(std::move(q.front())); q.pop_front(); }
+    while (!q.empty() && g.size() < maxItems && (g.empty() || takeAll || have < want)) { have += q.front().bases(); g.emplace_back(std::move(q.front())); q.pop_front(); }
     lk.unlock(); cvFull.notify_all();
     return true;
   }

@@ -17,9 +17,9 @@
 // chains / filters / prints batch i on param.threads std::threads.  Output order == input order (ThreadPool.hpp:187-211).
 // A device PASS covers as many parsed batches as it takes to fill the GPU (MASHMAP_HIP_COALESCE_MBP, default 3072 Mbp; the kernels of a
 // 512 Mbp pass run at ~120 Gbp/s, those of a 2 Gbp pass at ~150): the batches of a pass are laid end to end in HBM by
-// mm_reads_upload_packed_parts, each from its own page-locked buffer, so the reader's unit (and the memory it locks) stays small.  The
-// pass size ramps up from one batch (1, 1, 2, 4, 4 ...: the pipeline fills at once) and, when the input size is known, down again at the
-// end (the last pass and its post stage are what the run waits for with nothing overlapping them).
+// mm_reads_upload_packed_parts, each from its own page-locked buffer, so the reader's unit (and the memory it locks) stays small.  A
+// pass takes what is queued when the GPU falls free and never waits for more (greedy; MASHMAP_HIP_PASS_POLICY=ramp: the round-4 plan that
+// grew passes 1, 1, 2, 4 ... to the coalescing limit and shrank them towards a known end).
 //
 // Device stage.  The kernels report, per fragment, the candidate mappings doL2Mapping would have pushed (mm_mapping, k_l2_select);
 // with several contexts (MASHMAP_HIP_DEVICES, one per GPU, index replicated by Sketch) a batch -- 512 Mbp PER CONTEXT -- is cut into
@@ -86,7 +86,7 @@ class Map {
   // order (mm_reads_prefetch_packed_append), up to twice a pass's worth.  Whoever sees room sends the next block -- the reader the moment
   // it has parsed a batch, the device stage right after an upload has emptied part of the area -- so the copies of the batches behind a
   // pass always run under that pass's kernels.  stagedBases[i]: bases of queued batches already sent to context i (guarded by pfMu).
-  std::mutex pfMu; std::vector<size_t> stagedBases; size_t stageCapBases = 0; bool earlyPrefetch = true;
+  std::mutex pfMu; std::vector<size_t> stagedBases; size_t stageCapBases = 0, stageReserveBases = 0; bool earlyPrefetch = true;
   bool exchangeFellBack = false;                 // a default RCCL all-gatherv failed once: per-context downloads for the rest of the run
   skch::Time::time_point tStart = skch::Time::now();   // MASHMAP_HIP_TIMING lines carry the time since the Map was constructed
   // one write per diagnostic line: three stages log at once, and `std::cerr << a << b` from two threads interleaves inside a line
@@ -180,7 +180,8 @@ class Map {
     // carries 0.375 bytes per base instead of 1 (mm_reads_upload_packed); MASHMAP_HIP_ASCII_UPLOAD=1 ships ASCII to k_pack2bit instead
     earlyPrefetch = getenv("MASHMAP_HIP_NO_EARLY_PREFETCH") == nullptr;
     stagedBases.assign(ctxs.size(), 0);
-    stageCapBases = 2 * std::max(plan.passBases, batchBases) / ctxs.size();           // per context: the pass being assembled and the one behind it
+    stageCapBases = stagingCapBases(plan, ctxs.size());                               // per context: the pass being assembled and the one behind it (skch_types.hpp)
+    stageReserveBases = stagingReserveBases(plan, ctxs.size());
     // diagnostic (MASHMAP_HIP_STALL_TRACE=1): a thread that sleeps 0.5 ms at a time and reports when the sleep, a one-page mmap/munmap
     // (address-space lock) or a first touch of a fresh page took more than 3 ms -- tells a process-wide stall (scheduler, CPU quota)
     // from a lock inside the process when the stage timings show all three stages pausing at once
@@ -272,11 +273,18 @@ class Map {
     {
       // pass size: ramps up from one batch (so the post stage has work after one batch's worth of time), levels at the coalescing limit,
       // and comes down again towards the end of an input whose size is known (the last pass is followed by nothing that could hide it)
+      // Default: greedy -- a pass takes whatever the reader has queued when the GPU falls free (at least one batch, at most maxGroup) and
+      // never waits for more.  A one-batch pass costs more per base than the reader needs for a batch, so the queue grows and the next pass
+      // takes two or three: the sizes balance themselves where the device keeps up with the reader, the post stage gets its work in a
+      // steady trickle instead of six batches at a time, and what is left when the input ends is one small pass.
+      // MASHMAP_HIP_PASS_POLICY=ramp is the previous plan (1, 1, 2, 4 ... up to the coalescing limit, down again towards a known end).
+      const char* ppe = getenv("MASHMAP_HIP_PASS_POLICY");
+      const bool greedy = !(ppe && std::string(ppe) == "ramp");
       std::vector<Batch> grp;
       uint64_t doneBases = 0;
       while (true) {
-        const size_t want = maxGroup == 1 ? 0 : mmhost::passWant(batchBases, plan.passBases, plan.inputKnown, plan.inputBytes, doneBases);
-        if (!parsed.getGroup(grp, want, maxGroup)) break;
+        const size_t want = maxGroup == 1 ? 0 : greedy ? 1 : mmhost::passWant(batchBases, plan.passBases, plan.inputKnown, plan.inputBytes, doneBases);
+        if (!parsed.getGroup(grp, want, maxGroup, greedy && maxGroup > 1)) break;
         deviceStage(grp, parsed);
         for (auto& b : grp) { doneBases += b.bases(); mapped.put(std::move(b)); }
         grp.clear();
@@ -327,7 +335,7 @@ class Map {
     const size_t blockBases = (size_t)(b.in.offs[cut[i + 1]] - b.in.offs[cut[i]]);
     if (o1 <= o0 || stagedBases[i] + blockBases > stageCapBases) return;
     mm_ctx* c = ctxs[i];
-    const size_t reserve = stageCapBases + stageCapBases / 4 + (1u << 22);             // packed bases incl. the 32-base alignment of every read and the parser's gaps
+    const size_t reserve = stageReserveBases;                                          // what skch::Sketch has allocated behind the index build
     int staged = 0;
     if (mm_reads_prefetch_packed_append(c, b.in.bases2() + o0 / 16, b.in.nmask() + o0 / 32, (size_t)(o1 - o0), reserve, &staged) != MM_OK) die("mm_reads_prefetch_packed_append", c);
     if (!staged) return;                                    // the ring had no room under the pieces on their way: asked again when an upload has emptied part of it

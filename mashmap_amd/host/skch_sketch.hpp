@@ -95,7 +95,7 @@ class Sketch {
       // passes can hold one at a time: device, queue, post stage)
       if (!plan.inputKnown || plan.inputBytes > (64u << 20)) {
         const size_t perPass = (size_t)(std::min<uint64_t>(plan.passBases, plan.inputKnown ? plan.inputBytes : plan.passBases) / (uint64_t)std::max<offset_t>(1, p.segLength));
-        recsPrefill_ = std::thread([perPass]() { PinnedRecs<mm_mapping>::prefill(3, perPass + perPass / 4 + 1024); });
+        recsPrefill_ = std::thread([perPass]() { PinnedRecs<mm_mapping>::prefill(6, perPass + perPass / 4 + 1024); });
       }
       // ... and the query files' pages are mapped into this process meanwhile (seq_parse.hpp: MappedFileCache)
       if (!getenv("MASHMAP_HIP_NO_PREFAULT")) mmhost::MappedFileCache::instance().prefault(p.querySequences, 8);
@@ -105,6 +105,12 @@ class Sketch {
     if (!p.saveIndexFilename.empty()) this->saveIndex();
     for (size_t i = 1; i < ctxs_.size(); i++)        // replicas of the resident index, GPU to GPU
       if (mm_index_replicate(ctxs_[i], ctx_) != MM_OK) { std::cerr << "[mashmap_hip::skch::Sketch] ERROR: mm_index_replicate: " << mm_last_error(ctxs_[i]) << std::endl; exit(1); }
+    if (!getenv("MASHMAP_HIP_ASCII_UPLOAD") && !getenv("MASHMAP_HIP_NO_EARLY_PREFETCH")) {
+      // the staging area skch::Map's reader sends its packed batches ahead into (skch_map.hpp: issuePrefetch reserves the same size): allocated
+      // here, behind the index build, so that the reader's second batch does not wait ~10 ms for a multi-gigabyte hipMalloc
+      const QueryBatchPlan plan = queryBatchPlan(p.querySequences, ctxs_.size());
+      for (mm_ctx* c : ctxs_) (void)mm_reads_prefetch_reserve(c, stagingReserveBases(plan, ctxs_.size()));
+    }
     if (ctxs_.size() > 1 && mm_comm_init_local(ctxs_.data(), (int)ctxs_.size()) != MM_OK) {
       std::cerr << "[mashmap_hip::skch::Sketch] ERROR: mm_comm_init_local: " << mm_last_error(ctx_) << std::endl; exit(1);
     }

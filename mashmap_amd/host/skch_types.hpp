@@ -275,4 +275,15 @@ inline QueryBatchPlan queryBatchPlan(const std::vector<std::string>& queryFiles,
   q.buffers = (size_t)std::min<uint64_t>(inFlight, batches + 1);
   return q;
 }
+// packed bases the per-context staging area of the early prefetch holds (skch::Map sends parsed batches ahead into it; skch::Sketch
+// allocates it behind the index build): two passes' worth, but no more than the input, plus a quarter for the 32-base alignment of
+// every read and the parser's gaps
+inline size_t stagingCapBases(const QueryBatchPlan& plan, size_t nContexts) {
+  const size_t cap = 2 * std::max(plan.passBases, plan.batchBases) / std::max<size_t>(1, nContexts);
+  return plan.inputKnown ? (size_t)std::min<uint64_t>((uint64_t)cap, plan.inputBytes + (64u << 20)) : cap;
+}
+inline size_t stagingReserveBases(const QueryBatchPlan& plan, size_t nContexts) {
+  const size_t cap = stagingCapBases(plan, nContexts);
+  return cap + cap / 4 + (1u << 22);
+}
 }  // namespace skch

@@ -42,6 +42,10 @@ if "cpu_baseline" in d:
 if "e2e" in d:
     e = d["e2e"]
     print("e2e:", {k: e.get(k) for k in ("value", "map_s", "index_s", "paf_lines", "error")}, e.get("stages"), {k: v for k, v in (e.get("device_stage") or {}).items() if k != "note"})
+if isinstance(d.get("configs2"), dict):
+    one("configs2 (resident)", d["configs2"])
+    e = d["configs2"].get("e2e") or {}
+    print("   configs2 FASTA -> PAF:", {k: e.get(k) for k in ("value", "map_s", "paf_lines", "error")}, e.get("stages"))
 ns = d.get("north_star_target")
 if ns:
     one("north_star segLength 5000", ns)

@@ -1,5 +1,6 @@
-"""Parameter ranges that were refused until round 4, through both command lines (mashmap_hip and the stock binary built from the reference
-sources): --dense --pi 80 -s 100000 (sketchSize 9 998: the global-memory sketch kernel and the literal L2 kernel) and k-mers of more than
+"""Parameter ranges that were refused until rounds 4 / 6, through both command lines (mashmap_hip and the stock binary built from the reference
+sources): --dense --pi 80 -s 200000 (sketchSize 19 998: the index build's sketch in HBM too), -s 100000 (9 998: the global-memory sketch
+kernel and the literal L2 kernel) and k-mers of more than
 32 bases (-k 40 / 57); the PAF files must be byte-identical."""
 import os, subprocess, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,7 +18,7 @@ reads.append(("rc", U.revcomp(U.mutate(cs[0][900000:1300000], 77, 0.04))))
 reads.append(("short", cs[2][5000:45000].copy()))
 qf = os.path.join(td, "q.fa"); U.write_fasta(qf, reads)
 bad = 0
-for args in (["-s", "100000", "--pi", "80", "--dense"], ["-k", "40", "-s", "20000", "--pi", "95"], ["-k", "57", "-s", "10000", "--pi", "97", "-f", "none"]):
+for args in (["-s", "200000", "--pi", "80", "--dense"], ["-s", "100000", "--pi", "80", "--dense"], ["-k", "40", "-s", "20000", "--pi", "95"], ["-k", "57", "-s", "10000", "--pi", "97", "-f", "none"]):
     outs = {}
     for tag, exe in (("hip", HIP), ("ref", U.REF_BIN)):
         t0 = time.time()

@@ -56,14 +56,19 @@ def test_index_parameter_grid(oracle, k, s, L):
     _compare(oracle, contigs, k, L, s)
 
 
-def test_index_at_the_largest_sketch_size_and_refusal_beyond(oracle):
-    """sketchSize 10 000 is the most mm_create accepts: the device index build keeps a window's sketch in LDS (k_winnow_tiles, 16 bytes per
-    entry), and a context that is accepted must be one mm_index_build can serve (round 4 accepted up to 20 000 and would have failed
-    inside the build).  The reference's --dense at 100 kbp segments derives 9 998 (parseCmdArgs.hpp:626-630).  Device-built index at the
-    limit against the oracle, record for record; one beyond it refused with the sizes in the message."""
+def test_index_at_the_largest_lds_sketch_size_and_beyond(oracle):
+    """up to sketchSize 10 000 the device index build keeps a window's sketch in LDS (k_winnow_tiles, 16 bytes per entry; the reference's
+    --dense at 100 kbp segments derives 9 998, parseCmdArgs.hpp:626-630), beyond that in HBM (k_winnow_tiles<.., GSK>: --dense at 200 kbp
+    segments derives 19 998; the reference takes any size).  Device-built index against the oracle, record for record, at the last LDS
+    size, the first HBM size and at 19 998; 65 536 -- more seeds than the literal kernels' 16-bit seed numbers -- is refused by mm_create."""
     from mashmap_amd import capi
     contigs = [("c0", U.random_dna(901, 330000)), ("c1", U.with_n_runs(U.random_dna(902, 250000), 2, 20, 300))]
     nm, _ = _compare(oracle, contigs, k=19, L=100000, s=10000)
     assert nm > 10000
-    with pytest.raises(capi.MashmapError, match="sketchSize 10001 is beyond 10000"):
-        capi.Context(k=19, segLength=100000, sketchSize=10001)
+    nm, _ = _compare(oracle, contigs, k=19, L=100000, s=10001)
+    assert nm > 10000
+    contigs = [("c0", U.random_dna(903, 520000)), ("c1", U.with_n_runs(U.random_dna(904, 450000), 2, 20, 300))]
+    nm, _ = _compare(oracle, contigs, k=19, L=200000, s=19998)
+    assert nm > 19998
+    with pytest.raises(capi.MashmapError, match="sketchSize 65536 is beyond 65535"):
+        capi.Context(k=19, segLength=400000, sketchSize=65536)

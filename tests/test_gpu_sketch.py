@@ -216,7 +216,10 @@ def test_packed_parts_equal_one_upload():
     extra = capi.pack_reads([U.random_dna(430, 6000)])
     for stage in ((), (0, 1, 2, 3), (1, 3), (3,)):
         if stage == (3,):                                            # one more piece sent ahead than the upload names: it stays staged
-            ctx._ck(ctx.lib.mm_reads_prefetch_packed_append(ctx.h, capi._ptr(extra[0]), capi._ptr(extra[1]), extra[1].size * 32, 1 << 20), "append")
+            import ctypes as C
+            took = C.c_int(-1)
+            ctx._ck(ctx.lib.mm_reads_prefetch_packed_append(ctx.h, capi._ptr(extra[0]), capi._ptr(extra[1]), extra[1].size * 32, 1 << 20, C.byref(took)), "append")
+            assert took.value == 1                                   # the flag says staged (0: the ring had no room and the piece travels with its upload)
         assert ctx.reads_upload_packed_parts(parts, seqCounterBase=7, stage=stage) == nF
         sk_p, cnt_p = ctx.sketch()
         assert ctx.fragments().tobytes() == fr_a
@@ -225,6 +228,18 @@ def test_packed_parts_equal_one_upload():
     assert ctx.reads_upload_packed_parts([dict(packed=extra)], seqCounterBase=0) == 2          # a 6 000-base read: one full segment + the overlapping tail
     one = capi.Context(k=19, segLength=5000, sketchSize=130)
     one.reads_upload_packed(extra)
+    assert one.sketch()[0].tobytes() == ctx.sketch()[0].tobytes()
+    one.close()
+    # a staged piece whose host words are about to be reused is dropped (mm_reads_prefetch_drop): the upload that names the same two pointers
+    # and length afterwards reads the HOST words as they are now, not the stale copy in the staging area
+    stale = [x.copy() for x in extra]
+    ctx._ck(ctx.lib.mm_reads_prefetch_packed_append(ctx.h, capi._ptr(stale[0]), capi._ptr(stale[1]), stale[1].size * 32, 1 << 20, None), "append")
+    ctx._ck(ctx.lib.mm_reads_prefetch_drop(ctx.h), "drop")
+    other = capi.pack_reads([U.random_dna(431, 6000)])
+    stale[0][:] = other[0]; stale[1][:] = other[1]                   # same buffers, another read's words
+    assert ctx.reads_upload_packed_parts([dict(packed=(stale[0], stale[1], other[2], other[3]))], seqCounterBase=0) == 2
+    one = capi.Context(k=19, segLength=5000, sketchSize=130)
+    one.reads_upload_packed(other)
     assert one.sketch()[0].tobytes() == ctx.sketch()[0].tobytes()
     one.close()
     # without gaps the resident words are those of the single upload, bit for bit
