@@ -342,8 +342,8 @@ int mm_index_replicate(mm_ctx* dst, mm_ctx* src) {
   MM_HIP(dst, hipSetDevice(dst->device));
   DeviceIndex& D = dst->idx; DeviceIndex& S = src->idx;
   D.ready = false;
-  DevBuf* d[] = {&D.evKey, &D.evAux, &D.evHash, &D.evRev, &D.contigOff, &D.opKey, &D.opAux, &D.opHash, &D.blockOff, &D.evBlock, &D.contigBlock, &D.contigLen, &D.refGroup, &D.htSlots, &D.htTags, &D.filter, &D.ptKeys};
-  DevBuf* s[] = {&S.evKey, &S.evAux, &S.evHash, &S.evRev, &S.contigOff, &S.opKey, &S.opAux, &S.opHash, &S.blockOff, &S.evBlock, &S.contigBlock, &S.contigLen, &S.refGroup, &S.htSlots, &S.htTags, &S.filter, &S.ptKeys};
+  DevBuf* d[] = {&D.evKey, &D.evAux, &D.evHash, &D.contigOff, &D.opKey, &D.opAux, &D.opHash, &D.blockOff, &D.evBlock, &D.contigBlock, &D.contigLen, &D.refGroup, &D.htSlots, &D.htTags, &D.filter, &D.ptKeys};
+  DevBuf* s[] = {&S.evKey, &S.evAux, &S.evHash, &S.contigOff, &S.opKey, &S.opAux, &S.opHash, &S.blockOff, &S.evBlock, &S.contigBlock, &S.contigLen, &S.refGroup, &S.htSlots, &S.htTags, &S.filter, &S.ptKeys};
   for (size_t i = 0; i < sizeof d / sizeof d[0]; i++) {
     if (!s[i]->bytes) continue;
     MM_HIP(dst, d[i]->ensure(s[i]->bytes));

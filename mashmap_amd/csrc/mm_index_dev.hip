@@ -175,13 +175,6 @@ k_event_fill(size_t nEv, const mm_minmer* __restrict__ rec, const uint64_t* __re
   evAux[e] = (val[e] & 1u) ? 0u : ((uint32_t)m.wpos_end | (m.strand < 0 ? 0x80000000u : 0u));
   evHash[e] = m.hash;
 }
-// evRev: bit e = evAux[e] >> 31, one 64-bit word per wave (the buffer is zeroed first: the words behind the last event stay 0)
-__global__ void __launch_bounds__(256)
-k_event_rev_bits(size_t nEv, const uint32_t* __restrict__ evAux, uint64_t* __restrict__ evRev) {
-  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
-  const uint64_t m = __ballot(e < nEv && (evAux[e] >> 31));
-  if ((threadIdx.x & 63) == 0 && e < nEv) evRev[e >> 6] = m;
-}
 __global__ void k_contig_event_off(size_t nEv, const uint64_t* __restrict__ key, int nContigs, int64_t* __restrict__ off) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s > nContigs) return;
@@ -345,8 +338,6 @@ int mm_flatten_device_index(mm_ctx* c, const mm_minmer* dRec, size_t n, size_t n
   const size_t nEv = 2 * n;
   MM_HIP(c, I.evKey.ensure(nEv * 4 + 256)); MM_HIP(c, I.evAux.ensure(nEv * 4 + 256)); MM_HIP(c, I.evHash.ensure(nEv * 8 + 512));
   MM_HIP(c, I.contigOff.ensure((nContigs + 1) * 8));
-  MM_HIP(c, I.evRev.ensure((nEv / 64 + 4) * 8));
-  MM_HIP(c, hipMemsetAsync(I.evRev.p, 0, (nEv / 64 + 4) * 8, c->stream));
   if (n) {
     DevBuf& k0 = *T.make(); DevBuf& k1 = *T.make(); DevBuf& v0 = *T.make(); DevBuf& v1 = *T.make();
     MM_HIP(c, k0.ensure(nEv * 8)); MM_HIP(c, k1.ensure(nEv * 8)); MM_HIP(c, v0.ensure(nEv * 4)); MM_HIP(c, v1.ensure(nEv * 4));
@@ -355,7 +346,6 @@ int mm_flatten_device_index(mm_ctx* c, const mm_minmer* dRec, size_t n, size_t n
     int rc = sort_pairs(c, scratch, k0.as<uint64_t>(), k1.as<uint64_t>(), v0.as<uint32_t>(), v1.as<uint32_t>(), nEv, 0u, 32u + bits_for(nContigs));
     if (rc != MM_OK) return rc;
     K_LAUNCH(k_event_fill, nEv, nEv, dRec, k1.as<uint64_t>(), v1.as<uint32_t>(), I.evKey.as<uint32_t>(), I.evAux.as<uint32_t>(), I.evHash.as<uint64_t>());
-    K_LAUNCH(k_event_rev_bits, nEv, nEv, I.evAux.as<uint32_t>(), I.evRev.as<uint64_t>());
     hipLaunchKernelGGL(k_contig_event_off, dim3((unsigned)((nContigs + 1 + 255) / 256)), dim3(256), 0, c->stream, nEv, k1.as<uint64_t>(), nC, I.contigOff.as<int64_t>());
     MM_HIP(c, hipGetLastError());
     MM_HIP(c, hipStreamSynchronize(c->stream));

@@ -62,7 +62,6 @@ struct DeviceIndex {
   DevBuf evKey;                // uint32 pos*2 + isInsert
   DevBuf evAux;                // uint32 insert: wpos_end | REV<<31 ; eviction: 0
   DevBuf evHash;               // uint64 hash of the record
-  DevBuf evRev;                // uint64 words, bit e = event e is the insert of a REV record (evAux bit 31 once more, 1 bit instead of 4 bytes: all the slide of k_l2_locate needs of evAux)
   DevBuf contigOff;            // int64[nContigs+1] event offsets
   // records still open at every MM_OPEN_BLOCK-th position (wpos < B < wpos_end, index order), as insert events: the L2 pre-load of a
   // candidate starts from the list of its block instead of streaming a whole segLength of events (computeMap.hpp:1323-1338)

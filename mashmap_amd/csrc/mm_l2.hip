@@ -201,7 +201,7 @@ __global__ void __launch_bounds__(256)
 k_l2_locate(int cBase, int nCand, int64_t opsBase, int s, int NB, const mm_l1_candidate* __restrict__ l1, const mm_frag_stats* __restrict__ stats,
             const uint64_t* __restrict__ qHash, const int8_t* __restrict__ qStrand,
             const uint64_t* __restrict__ skHash, const int8_t* __restrict__ skStrand,
-            const uint32_t* __restrict__ evKey, const uint32_t* __restrict__ evAux, const uint64_t* __restrict__ evHash, const uint64_t* __restrict__ evRev,
+            const uint32_t* __restrict__ evKey, const uint32_t* __restrict__ evAux, const uint64_t* __restrict__ evHash,
             const uint32_t* __restrict__ opKey, const uint32_t* __restrict__ opAux, const uint64_t* __restrict__ opHash,
             const int64_t* __restrict__ contigOff, const L2Info* __restrict__ info, const int64_t* __restrict__ opOff,
             const int32_t* __restrict__ opCnt, uint32_t* __restrict__ ops, const int32_t* __restrict__ order /* candidates in reference order, or null */,
@@ -242,20 +242,9 @@ k_l2_locate(int cBase, int nCand, int64_t opsBase, int s, int NB, const mm_l1_ca
     auto loadChunk = [&](int ch, uint32_t& key, uint32_t& aux, uint64_t& h) {
       key = 0; aux = 0; h = 0;                                       // a lane without a record: no insert flag, nothing kept
       if (ch < nChO) { const int i = ch * 64 + lane; if (i < nOpen) { key = opKey[in.open0 + i]; aux = opAux[in.open0 + i]; h = opHash[in.open0 + i]; } }
-      else if (ch < nChPre) {
-        const int i = (ch - nChO) * 64 + lane;
-        if (i < nPre) { key = evKey[in.e0 + i]; aux = evAux[in.e0 + i]; h = evHash[in.e0 + i]; }
-      } else {
-        // the slide needs one bit of evAux -- is the inserted record a REV one -- and takes it from the bitmap (two wave-uniform words per
-        // chunk): 12 bytes per event instead of 16
-        const int i0 = nPre + (ch - nChPre) * 64;
-        const int i = i0 + lane;
-        if (i < nAll) { key = evKey[in.e0 + i]; h = evHash[in.e0 + i]; }
-        const int64_t e = in.e0 + i0;
-        const int sh = (int)(e & 63);
-        const uint64_t w0 = evRev[e >> 6], w1 = evRev[(e >> 6) + 1];
-        const uint64_t bits = sh ? (w0 >> sh) | (w1 << (64 - sh)) : w0;
-        aux = ((bits >> lane) & 1ull) ? 0x80000000u : 0u;
+      else {
+        const int i = ch < nChPre ? (ch - nChO) * 64 + lane : nPre + (ch - nChPre) * 64 + lane;
+        if (i < (ch < nChPre ? nPre : nAll)) { key = evKey[in.e0 + i]; aux = evAux[in.e0 + i]; h = evHash[in.e0 + i]; }
       }
     };
     uint32_t nKey, nAux; uint64_t nHash;
@@ -1229,7 +1218,7 @@ int mm_launch_l2(mm_ctx* c, unsigned long long* cnt, bool steady) {
       hipLaunchKernelGGL(kern, dim3(blocks), dim3(wpb * 64), ldsLoc, c->stream, ch.c0, ch.n, ch.base, s, NB, c->dL1.as<mm_l1_candidate>(),
                          c->dStats.as<mm_frag_stats>(), c->dQHash.as<uint64_t>(), c->dQStrand.as<int8_t>(), c->dSkHash.as<uint64_t>(), c->dSkStrand.as<int8_t>(),
                          I.evKey.as<uint32_t>(),
-                         I.evAux.as<uint32_t>(), I.evHash.as<uint64_t>(), I.evRev.as<uint64_t>(), I.opKey.as<uint32_t>(), I.opAux.as<uint32_t>(), I.opHash.as<uint64_t>(),
+                         I.evAux.as<uint32_t>(), I.evHash.as<uint64_t>(), I.opKey.as<uint32_t>(), I.opAux.as<uint32_t>(), I.opHash.as<uint64_t>(),
                          I.contigOff.as<int64_t>(),
                          c->dL2Info.as<L2Info>(), c->dL2Off.as<int64_t>(), c->dL2Cnt.as<int32_t>(), c->dL2Ops.as<uint32_t>(), order, cnt, nDev,
                          c->dL2InitCells.as<uint16_t>(), c->dL2InitState.as<L2Init>(), initStride, preLimit);

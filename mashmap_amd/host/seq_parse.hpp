@@ -261,15 +261,17 @@ class MappedFileCache {
       for (unsigned t = 0; t < std::max(1u, threads); t++) workers_.emplace_back([this] { run(); });
   }
   bool lookup(const std::string& path, Entry& out) { std::lock_guard<std::mutex> lk(mu_); auto it = map_.find(path); if (it == map_.end()) return false; out = it->second; return true; }
+  bool allPopulated() { std::lock_guard<std::mutex> lk(mu_); return next_ >= jobs_.size() && running_ == 0; }   // every mapping made so far is in the page tables
   void wait() { std::vector<std::thread> w; { std::lock_guard<std::mutex> lk(mu_); w.swap(workers_); } for (auto& t : w) t.join(); }
 
  private:
   struct Job { const char* p; size_t n; };
-  std::mutex mu_; std::unordered_map<std::string, Entry> map_; std::vector<Job> jobs_; size_t next_ = 0; std::vector<std::thread> workers_;
+  std::mutex mu_; std::unordered_map<std::string, Entry> map_; std::vector<Job> jobs_; size_t next_ = 0; std::vector<std::thread> workers_; int running_ = 0;
   void run() {
+    bool busy = false;
     for (;;) {
       Job j;
-      { std::lock_guard<std::mutex> lk(mu_); if (next_ >= jobs_.size()) return; j = jobs_[next_++]; }
+      { std::lock_guard<std::mutex> lk(mu_); if (busy) { running_--; busy = false; } if (next_ >= jobs_.size()) return; j = jobs_[next_++]; running_++; busy = true; }
       const uintptr_t a = (uintptr_t)j.p & ~(uintptr_t)4095, z = ((uintptr_t)j.p + j.n + 4095) & ~(uintptr_t)4095;
       if (madvise((void*)a, (size_t)(z - a), 22 /* MADV_POPULATE_READ, Linux >= 5.14 */) != 0) {
         volatile char sink = 0;                                      // older kernel: touch every page
@@ -297,7 +299,7 @@ class MmapSource : public RawSource {
   ~MmapSource() override { if (!owned_) return; if (data_) munmap((void*)data_, size_); if (fd_ >= 0) close(fd_); }
   bool prefaulted() const { return !owned_; }
   bool ok() const { return fd_ >= 0; }
-  bool fileMapped() const override { return true; }                 // also for a mapping from the cache: its own threads may not have reached this window yet (populating populated pages is cheap)
+  bool fileMapped() const override { return owned_ || !MappedFileCache::instance().allPopulated(); }   // a mapping from the cache whose pages are all in: the parser's workers need not ask again
   char first_byte() override { return size_ ? data_[0] : 0; }
   bool next(const char*& p, size_t& n, bool fasta, bool) override {
     if (pos_ >= size_) return false;

@@ -7,7 +7,8 @@
 #   quick            configs[1] headline only (no cpu baseline / e2e / north star), steps 10 / warmup 3
 #   rr               the repeat-rich north_star workload alone (bench.py --workload northstar --repeat-rich-reference)
 #   trace:WL         rocprofv3 --kernel-trace --stats of two passes of WL      -> kernel_stats_WL.csv
-#   pmc:WL           FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU passes of WL (one rocprofv3 run each) -> pmc_WL_*.csv (scripts/pmc_summary.py reduces them)
+#   pmc:WL           FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU passes of WL (one rocprofv3 run each) -> pmc_WL_*.csv (scripts/pmc_summary.py reduces them);
+#                    WL: configs1 | configs2 | configs3 | configs4 | northstar | northstar_seg10000 | northstar_repeat_rich (also for trace:)
 #   e2e              FASTA -> PAF through the mashmap_hip command line only (bench.py's e2e leg)
 #   fuzz:N           N random command lines through mashmap_hip and the stock binary, PAF bytes compared (MM_FUZZ_SEED)
 #   nosplit          --noSplit on 30 kbp reads through both command lines: same PAF, both times
@@ -22,7 +23,7 @@ cd "$GRAFT_REPO_ROOT" 2>/dev/null || true
 say() { echo "$@" | tee -a $OUT/log.txt; }
 # bench.py prints the short line the driver parses and writes the full record to gpurun_out/bench_last_full.json: keep it per run, digest that
 full() { cp gpurun_out/bench_last_full.json $OUT/$1_full.json 2>/dev/null && python scripts/bench_digest.py $OUT/$1_full.json | tee -a $OUT/log.txt; tail -c 6000 $OUT/$1.json | tail -1 | wc -c | sed 's/^/   final line bytes: /' | tee -a $OUT/log.txt; }
-wl_args() { case $1 in configs1|"") echo "";; *) echo "--workload $1";; esac; }
+wl_args() { case $1 in configs1|"") echo "";; northstar_seg10000) echo "--workload northstar --seg 10000";; northstar_repeat_rich) echo "--workload northstar --repeat-rich-reference";; *) echo "--workload $1";; esac; }
 for S in "$@"; do
 case $S in
 tests)
@@ -65,7 +66,7 @@ pmc:*)
   WL=${S#pmc:}
   for C in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU; do
     say "== $WL: rocprofv3 --pmc $C"
-    timeout 1500 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_${WL}_$C -o pmc -- python bench.py --steps 1 --warmup 3 --batches 1 $(wl_args $WL) --no-cpu-baseline --no-host-path --no-e2e --no-north-star > /dev/null 2> $OUT/pmc_${WL}_$C.err
+    timeout 1500 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_${WL}_$C -o pmc -- python bench.py --steps 1 --warmup 3 --batches 1 $(wl_args $WL) $MM_BENCH_EXTRA --no-cpu-baseline --no-host-path --no-e2e --no-north-star > /dev/null 2> $OUT/pmc_${WL}_$C.err
     python scripts/pmc_summary.py $OUT/pmc_${WL}_$C $C > $OUT/pmc_${WL}_$C.csv 2>> $OUT/log.txt; rm -rf $OUT/pmc_${WL}_$C
     head -8 $OUT/pmc_${WL}_$C.csv | cut -c1-160 | tee -a $OUT/log.txt
   done ;;

@@ -3,7 +3,7 @@
 bench.py reads for roofline.traffic / roofline.valu of that workload (bench.py names it as `traffic_source`: the counters come from
 committed rocprofv3 --pmc passes, not from the bench run).  HBM bytes per launch = 2 x FETCH_SIZE KiB (gfx950 counts 128-byte read
 requests as 64 bytes, MI355X_MICROARCH.md section HBM) + WRITE_SIZE KiB.
-usage: pmc_to_json.py TAG WORKLOAD     (WORKLOAD: configs1 | configs3 | configs4 | northstar | northstar_seg10000)"""
+usage: pmc_to_json.py TAG WORKLOAD     (WORKLOAD: configs1 | configs2 | configs3 | configs4 | northstar | northstar_seg10000 | northstar_repeat_rich)"""
 import csv
 import json
 import os
@@ -33,7 +33,7 @@ out["_source"] = tag
 sys.path.insert(0, root)
 import bench  # noqa: E402
 out["_csrc_sha16"] = bench.csrc_sha16()                      # the kernel sources these counters belong to (bench.py compares with the tree it runs on)
-out["_collected"] = os.environ.get("MM_PMC_COLLECTED", "round 5")
+out["_collected"] = os.environ.get("MM_PMC_COLLECTED", "round 6")
 out["_note"] = ("per launch at bench.py's `%s` workload; FETCH_SIZE/WRITE_SIZE in KiB as rocprofv3 reports them; read side doubled per the gfx950 "
                 "correction; from profiles/%s_pmc_*.csv" % (workload, tag))
 path = os.path.join(root, "profiles", "pmc_traffic.json")

@@ -56,6 +56,16 @@ def test_index_parameter_grid(oracle, k, s, L):
     _compare(oracle, contigs, k, L, s)
 
 
+@pytest.mark.parametrize("k,s,L", [(19, 130, 5000), (19, 498, 5000), (16, 50, 1000), (19, 2000, 20000), (21, 100, 500)])
+def test_index_with_the_blocked_window_sketch_at_small_sizes(oracle, monkeypatch, k, s, L):
+    """the HBM form of the index build's window sketch (k_winnow_tiles<.., GSK>: blocks of 64 entries under an LDS directory, used beyond
+    sketchSize 10 000) forced at ordinary sizes, where its blocks split, empty and merge thousands of times per tile: the same records as
+    the oracle's addMinmers, on random, tandem-repeat and N-rich contigs"""
+    monkeypatch.setenv("MM_WINNOW_GSK", "1")
+    contigs = [("x", U.random_dna(70 + k, 150000)), ("y", U.tandem_repeat(80, 60000, 311)), ("z", U.with_n_runs(U.random_dna(90, 50000), 2, 6, 40))]
+    _compare(oracle, contigs, k, L, s)
+
+
 def test_index_at_the_largest_lds_sketch_size_and_beyond(oracle):
     """up to sketchSize 10 000 the device index build keeps a window's sketch in LDS (k_winnow_tiles, 16 bytes per entry; the reference's
     --dense at 100 kbp segments derives 9 998, parseCmdArgs.hpp:626-630), beyond that in HBM (k_winnow_tiles<.., GSK>: --dense at 200 kbp
