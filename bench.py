@@ -638,8 +638,9 @@ def north_star_target(torch, dev, capi, local, warmup, steps, cpu_reads=0, nb=3,
              "fragments": nF, "interval_points_per_fragment": round(float(stats["nPoints"].mean()), 1), "l1_candidates_per_fragment": round(n1 / max(1, nF), 3),
              "l2_loci_per_fragment": round(n2 / max(1, nF), 3), "candidate_mappings_per_fragment": round(nmap / max(1, nF), 3),
              "hard_list_share": round(cnts.get("hard", 0) / max(1, nF), 5), "hbm_point_path_share": round(cnts["queued"] / max(1, nF), 5),
-             "workload": "%d x %d bp " + ("assembly contigs (the reference + 1%% substitutions + rearrangements)" if W.get("assembly") else "reads (10%% ONT-like error)") + " vs %.0f Mbp synthetic reference (%d contigs), k %d, segLength %d, sketchSize %d, pi %.2f: "
-                         "%d fragments, %.1f interval points per fragment, %d L1 candidates, %d L2 loci, %d candidate mappings (last pass)"
+             "workload": ("%d x %d bp " + ("assembly contigs (the reference + 1%% substitutions + rearrangements)" if W.get("assembly") else "reads (10%% ONT-like error)") +
+                          " vs %.0f Mbp synthetic reference (%d contigs), k %d, segLength %d, sketchSize %d, pi %.2f: "
+                          "%d fragments, %.1f interval points per fragment, %d L1 candidates, %d L2 loci, %d candidate mappings (last pass)")
                          % (nreads, READ_LEN, sum(len(a) for a in ref_np) / 1e6, len(ref_np), W["k"], W["seg"], W["sketch"], W["pi"], nF,
                             float(stats["nPoints"].mean()), n1, n2, nmap)}
         if lay:

@@ -49,7 +49,7 @@ typedef struct {
   int32_t segLength;      /* Parameters::segLength  */
   int32_t sketchSize;     /* Parameters::sketchSize (1 .. 65535.  Up to 8190 the sketch and L2 kernels keep their state in a CU's 160 KB of LDS -- mm_create
                              checks the combination with segLength and says what does not fit --; beyond, every fragment takes a global-memory sketch
-                             kernel and the literal L2 kernels, and beyond 10000 the index build keeps a window's sketch in HBM as well: exact, not fast) */
+                             kernel and the literal L2 kernels, and the index build keeps a window's sketch in HBM from 4097 on: exact, not tuned) */
   int32_t flags;          /* MM_FLAG_* */
 } mm_params;
 

@@ -238,8 +238,9 @@ int mm_launch_pack_raw(mm_ctx* c, const uint8_t* dAscii, const int64_t* dSrcOff,
 int mm_launch_sketch(mm_ctx* c);
 int mm_launch_sketch_global(mm_ctx* c);   // mm_sketch_global.hip: sketches no LDS table holds (sketchSize > MM_LDS_MAX_SKETCH)
 #define MM_LDS_MAX_SKETCH 8190             // beyond: the global-memory sketch kernel and the literal L2 kernels (any size up to MM_MAX_SKETCH)
-#define MM_WINNOW_LDS_SKETCH 10000         // the device index build keeps a window's sketch in LDS up to here (k_winnow_tiles: 16 bytes per entry + the candidate stage in a CU's
-                                           // 160 KB; the reference's --dense at 100 kbp segments derives 9 998, parseCmdArgs.hpp:626-630), in HBM beyond (k_winnow_tiles<.., GSK>)
+#define MM_WINNOW_LDS_SKETCH 4096          // the device index build keeps a window's sketch as one sorted array in LDS up to here (k_winnow_tiles: an insert shifts half of it), and as
+                                           // blocks of 64 entries in HBM under an LDS directory beyond (k_winnow_tiles<.., GSK>: 0.7 s against 8.7 s of index build at sketchSize 9 998,
+                                           // profiles/r14_11; LDS itself would hold 10 000 entries)
 #define MM_MAX_SKETCH 65535                // seeds are numbered in 16 bits where the literal kernels count windows per seed (mm_map.hip: ptIds); the reference takes any size
 int mm_launch_map(mm_ctx* c);
 // Steady state: once a pass of a context has sized every staging buffer, the next passes launch everything against

@@ -301,7 +301,7 @@ struct WnBlockSketch {
 //   index space: DENSE -> k-mer positions (H[i] == NONE: not a k-mer);  sparse -> indices into the candidate list
 // ---------------------------------------------------------------------------------------------
 // GSK: the sketch of the window lives in HBM (skScratch: (s + 1) * 16 bytes per tile slot) instead of LDS -- sketches beyond what a CU's
-// 160 KB hold (sketchSize > 10 000: --dense at segments of 200 kbp and more, or a user's -J); the wave is the only reader and writer of
+// 160 KB hold, and from sketchSize 4 097 on (MM_WINNOW_LDS_SKETCH: --dense at segments of 41 kbp and more, or a user's -J); the wave is the only reader and writer of
 // its slot, and its accesses are ordered by the same workgroup-scope fences as the LDS form's.
 template <bool DENSE, bool GSK = false>
 __global__ void __launch_bounds__(64)
@@ -567,7 +567,7 @@ int mm_winnow_contig_device(mm_ctx* c, WinnowBuffers& B, const uint64_t* dH, con
   const int k = c->P.kmerSize, w = c->P.segLength, s = c->P.sketchSize;
   const int nW = len - w + 1;
   const int wk = w - k + 1;
-  // windows per tile: a segment length's worth -- except with the sketch in HBM (sketchSize > 10 000), where a window step costs scans
+  // windows per tile: a segment length's worth -- except with the sketch in HBM (sketchSize > MM_WINNOW_LDS_SKETCH), where a window step costs scans
   // of tens of thousands of candidates and a cold start is one streamed pass: there the tiles shrink (down to w / 16) until there are
   // about four per CU, so that a small reference still fills the GPU
   const bool gskTiles = s > MM_WINNOW_LDS_SKETCH || getenv("MM_WINNOW_GSK") != nullptr;

@@ -59,7 +59,7 @@ def test_index_parameter_grid(oracle, k, s, L):
 @pytest.mark.parametrize("k,s,L", [(19, 130, 5000), (19, 498, 5000), (16, 50, 1000), (19, 2000, 20000), (21, 100, 500)])
 def test_index_with_the_blocked_window_sketch_at_small_sizes(oracle, monkeypatch, k, s, L):
     """the HBM form of the index build's window sketch (k_winnow_tiles<.., GSK>: blocks of 64 entries under an LDS directory, used beyond
-    sketchSize 10 000) forced at ordinary sizes, where its blocks split, empty and merge thousands of times per tile: the same records as
+    sketchSize 4 096) forced at ordinary sizes, where its blocks split, empty and merge thousands of times per tile: the same records as
     the oracle's addMinmers, on random, tandem-repeat and N-rich contigs"""
     monkeypatch.setenv("MM_WINNOW_GSK", "1")
     contigs = [("x", U.random_dna(70 + k, 150000)), ("y", U.tandem_repeat(80, 60000, 311)), ("z", U.with_n_runs(U.random_dna(90, 50000), 2, 6, 40))]
@@ -67,16 +67,15 @@ def test_index_with_the_blocked_window_sketch_at_small_sizes(oracle, monkeypatch
 
 
 def test_index_at_the_largest_lds_sketch_size_and_beyond(oracle):
-    """up to sketchSize 10 000 the device index build keeps a window's sketch in LDS (k_winnow_tiles, 16 bytes per entry; the reference's
-    --dense at 100 kbp segments derives 9 998, parseCmdArgs.hpp:626-630), beyond that in HBM (k_winnow_tiles<.., GSK>: --dense at 200 kbp
-    segments derives 19 998; the reference takes any size).  Device-built index against the oracle, record for record, at the last LDS
-    size, the first HBM size and at 19 998; 65 536 -- more seeds than the literal kernels' 16-bit seed numbers -- is refused by mm_create."""
+    """up to sketchSize 4 096 the device index build keeps a window's sketch as a sorted array in LDS, beyond that as blocks in HBM
+    (k_winnow_tiles<.., GSK>; the reference's --dense derives 9 998 at 100 kbp segments and 19 998 at 200 kbp, parseCmdArgs.hpp:626-630,
+    and takes any size).  Device-built index against the oracle, record for record, at 4 096 / 4 097 (last LDS, first HBM size), 10 000,
+    10 001 and 19 998; 65 536 -- more seeds than the literal kernels' 16-bit seed numbers -- is refused by mm_create."""
     from mashmap_amd import capi
     contigs = [("c0", U.random_dna(901, 330000)), ("c1", U.with_n_runs(U.random_dna(902, 250000), 2, 20, 300))]
-    nm, _ = _compare(oracle, contigs, k=19, L=100000, s=10000)
-    assert nm > 10000
-    nm, _ = _compare(oracle, contigs, k=19, L=100000, s=10001)
-    assert nm > 10000
+    for s in (4096, 4097, 10000, 10001):
+        nm, _ = _compare(oracle, contigs, k=19, L=100000, s=s)
+        assert nm > s
     contigs = [("c0", U.random_dna(903, 520000)), ("c1", U.with_n_runs(U.random_dna(904, 450000), 2, 20, 300))]
     nm, _ = _compare(oracle, contigs, k=19, L=200000, s=19998)
     assert nm > 19998
