@@ -28,7 +28,7 @@ for S in "$@"; do
 case $S in
 tests)
   say "== pytest -m gpu"
-  timeout 1700 python -m pytest tests -m gpu -q --maxfail=12 --timeout 900 -s 2>&1 | grep -v "^$" | tail -80 | tee -a $OUT/log.txt ;;
+  timeout 1700 python -m pytest tests -m gpu -q --maxfail=12 --timeout 900 -s --durations=12 2>&1 | grep -v "^$" | tail -80 | tee -a $OUT/log.txt ;;
 t:*)
   say "== pytest -m gpu -k ${S#t:}"
   timeout 1500 python -m pytest tests -m gpu -q --maxfail=12 --timeout 900 -k "${S#t:}" 2>&1 | tail -60 | tee -a $OUT/log.txt ;;
