@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- query Gbp/s of the sketch + L1/L2 hot path on N MI355X (one process per GPU).
 
-  python bench.py --gpus N --steps K --warmup W [--workload configs1|configs3|configs4|northstar] [--batches B]
+  python bench.py --gpus N --steps K --warmup W [--workload configs1|configs2|configs3|configs4|northstar] [--batches B]
 
 With N > 1 and no torch.distributed environment the script starts its own N ranks (torch.distributed.run, 127.0.0.1); started by
 a launcher it checks that WORLD_SIZE == N.  It never prints an `n_gpus` other than the N it was asked for.
@@ -17,6 +17,9 @@ timed region.
 
 Workloads (BASELINE.json `configs`; the default is configs[1], the configuration the metric is quoted on):
   configs1  1 M x 10 kbp reads (10 % ONT-like error) vs 100 Mbp, pi 85, segLength 5000, sketchSize 130
+  configs2  the 3 Gbp assembly (every reference contig with 1 % substitutions and 1-5 Mbp inversions / translocations) vs the 3 Gbp
+            reference, pi 95, segLength 10000, sketchSize 40 (-J 40), -f one-to-one: resident passes + FASTA -> PAF (--stock: the stock
+            binary on the same files, PAF bytes compared)
   configs3  per-GPU share of configs[3]: 1.25 M x 15 kbp reads vs 3 Gbp (24 x 125 Mbp), sketchSize 310 (the stock binary's value:
             its int32 referenceSize overflows for a 3 GB file; 220 mathematically -- SURVEY App. C)
   northstar the north_star target sentence: 1 M x 10 kbp reads, pi 85, against the 3 Gbp index (sketchSize 310 as for configs3)
@@ -30,7 +33,11 @@ The default run (configs1, nothing scaled, one GPU) carries three more measureme
   north_star_target   the north_star sentence -- 1 M x 10 kbp reads at pi 85 against the human-scale (3 Gbp) index --, stock segLength 5000
                       and the "10 kbp segments" variant, the stock binary beside it; and `repeat_rich`: the same workload on a reference
                       with human-like repeat structure (make_repeat_rich_reference: ~45 % interspersed repeat families, satellites, N gaps)
---no-e2e / --no-north-star skip them.
+--no-e2e / --no-north-star / --no-configs2 skip them.
+
+What rank 0 prints LAST is one JSON object of about 4 KB (compact_line: the contract's keys, `roofline`, `cpu_baseline`, one small numeric
+object per side measurement); the full record of the run goes to profiles/bench_last_full.json.  The synthetic inputs live in
+bench_workloads.py, the host / command-line side measurements in bench_e2e.py; this file holds the timed loop, the roofline and the line.
 """
 import argparse
 import json
@@ -49,355 +56,9 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
 SIMDS, CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs, max clock (MI355X_MICROARCH.md)
 
-WORKLOADS = {
-    "configs1": dict(label="configs[1]", k=19, seg=5000, sketch=130, pi=0.85, read_len=10000, err=(0.10, 0.10), reads=1_000_000,
-                     ref_contigs=10, ref_contig_len=10_000_000,
-                     sketch_note="130 = recommendedSketchSize for a 100 Mbp reference file (SURVEY App. C)"),
-    "configs2": dict(label="configs[2]", k=19, seg=10000, sketch=40, pi=0.95, read_len=125_000_000, err=(0.01, 0.01), reads=24,
-                     ref_contigs=24, ref_contig_len=125_000_000, assembly=True, cli=["-f", "one-to-one"],
-                     sketch_note="40 = what the stock binary derives at pi 95, segLength 10000 for a 3 GB reference file (int32 referenceSize overflow); 20 mathematically (SURVEY App. C); pinned with -J 40"),
-    "configs3": dict(label="configs[3] (per-GPU share of 10 M reads / 8 GPUs)", k=19, seg=5000, sketch=310, pi=0.85, read_len=15000,
-                     err=(0.10, 0.10), reads=1_250_000, ref_contigs=24, ref_contig_len=125_000_000,
-                     sketch_note="310 = what the stock binary derives for a 3 GB reference file (int32 referenceSize overflow); 220 mathematically (SURVEY App. C)"),
-    "northstar": dict(label="north_star target (10 kbp reads, pi 85, human-scale index)", k=19, seg=5000, sketch=310, pi=0.85, read_len=10000,
-                      err=(0.10, 0.10), reads=1_000_000, ref_contigs=24, ref_contig_len=125_000_000,
-                      sketch_note="310 = what the stock binary derives for a 3 GB reference file (int32 referenceSize overflow); 220 mathematically (SURVEY App. C)"),
-    "configs4": dict(label="configs[4] (per-GPU share of 5 M reads / 8 GPUs)", k=19, seg=5000, sketch=498, pi=0.80, read_len=20000,
-                     err=(0.15, 0.20), reads=625_000, ref_contigs=10, ref_contig_len=300_000_000,
-                     sketch_note="498 = --dense at pi 80: 0.02 (1 + 0.2 / 0.05) (5000 - 19) (parseCmdArgs.hpp:620-641); the 10 --rl files are 10 contigs of one index"),
-}
-
-
-def log(*a):
-    print(*a, file=sys.stderr, flush=True)
-
-
-def make_reference(torch, dev, ncontigs, clen, seed=1):
-    g = torch.Generator(device=dev); g.manual_seed(seed)
-    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
-    out = []
-    for _ in range(ncontigs):
-        out.append(lut[torch.randint(0, 4, (clen,), generator=g, device=dev, dtype=torch.int32).long()] if clen <= (1 << 27)
-                   else torch.cat([lut[torch.randint(0, 4, (min(1 << 27, clen - o),), generator=g, device=dev, dtype=torch.int32).long()]
-                                   for o in range(0, clen, 1 << 27)]))
-    return out
-
-
-# Human-like repeat structure for `north_star_target.repeat_rich` and tests/humanscale.py (sizes are for a 3 Gbp reference; copy numbers scale
-# with the reference so that the covered fraction stays): interspersed repeat families over ~45 % of the sequence -- copy numbers from 10^2
-# to 10^5, copies diverged from their family's consensus by 10-20 % (i.i.d. substitutions, random strand), the numerous families the more
-# diverged ones as in real genomes (old families are both) --, one satellite array per contig (171 bp monomers in a 12-monomer higher-order
-# repeat, copies 2 % apart) and N gaps.  (family, families, consensus bp, copies per family at 3 Gbp, 5'-truncated copies)
-REPEAT_FAMILIES = [("SINE-like", 10, 300, 100_000, False),               # 300 Mbp
-                   ("LINE-like", 20, 6000, 10_000, True),                # copies keep the last 500..6000 bp: 650 Mbp
-                   ("LTR/DNA-like", 100, 2000, 1_000, False),            # 200 Mbp
-                   ("segmental-duplication-like", 200, 10_000, 100, False)]   # 200 Mbp
-SATELLITE_BP, SATELLITE_MONOMER, SATELLITE_HOR, SATELLITE_DIV = 250_000, 171, 12, 0.02
-NGAP_BP, NGAP_END_BP = 500_000, 10_000
-
-
-def repeat_divergence(copies_at_3gbp):
-    return 0.10 + 0.10 * (np.log10(copies_at_3gbp) - 2.0) / 3.0
-
-
-def make_repeat_rich_reference(torch, dev, ncontigs, clen, seed=11):
-    """a reference with the repeat structure described at REPEAT_FAMILIES, as `ncontigs` consecutive views of one uint8 tensor (ASCII);
-    returns (contigs, summary)"""
-    g = torch.Generator(device=dev); g.manual_seed(seed)
-    total = ncontigs * clen
-    scale = total / 3e9
-    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
-    whole = torch.empty(total, dtype=torch.uint8, device=dev)
-    for o in range(0, total, 1 << 27):
-        n = min(1 << 27, total - o)
-        whole[o:o + n] = torch.randint(0, 4, (n,), generator=g, device=dev, dtype=torch.int32).to(torch.uint8)      # codes 0..3 until the end
-    covered = 0
-    fams = []
-    for name, nfam, clen_f, copies3, trunc in REPEAT_FAMILIES:
-        copies = max(2, int(round(copies3 * scale)))
-        div = float(repeat_divergence(copies3))
-        ar = torch.arange(clen_f, device=dev)
-        for _ in range(nfam):
-            cons = torch.randint(0, 4, (clen_f,), generator=g, device=dev, dtype=torch.int32).to(torch.uint8)
-            for c0 in range(0, copies, 1 << 14):                      # 16 k copies at a time (a LINE-like block is 100 M cells)
-                n = min(1 << 14, copies - c0)
-                cp = cons[None, :].expand(n, clen_f).clone()
-                sub = torch.rand(n, clen_f, generator=g, device=dev) < div
-                cp = torch.where(sub, (cp + torch.randint(1, 4, (n, clen_f), generator=g, device=dev, dtype=torch.int32).to(torch.uint8)) & 3, cp)
-                keep = torch.ones(n, clen_f, dtype=torch.bool, device=dev)
-                if trunc:
-                    ln = torch.randint(min(500, clen_f), clen_f + 1, (n,), generator=g, device=dev)
-                    keep = ar[None, :] >= (clen_f - ln)[:, None]
-                rev = torch.rand(n, generator=g, device=dev) < 0.5
-                cp = torch.where(rev[:, None], (3 - cp).flip(1), cp)
-                keep = torch.where(rev[:, None], keep.flip(1), keep)
-                ci = torch.randint(0, ncontigs, (n,), generator=g, device=dev)
-                st = (torch.rand(n, generator=g, device=dev, dtype=torch.float64) * (clen - clen_f)).long()
-                idx = (ci * clen + st)[:, None] + ar[None, :]
-                whole[idx[keep]] = cp[keep]
-                covered += int(keep.sum())
-                del cp, sub, keep, idx
-        fams.append({"family": name, "families": nfam, "consensus_bp": clen_f, "copies_per_family": copies, "divergence": round(div, 3)})
-    # satellites: one array per contig at 40 % of its length
-    sat_bp = min(SATELLITE_BP, clen // 20)
-    hor_len = SATELLITE_MONOMER * SATELLITE_HOR
-    for c in range(ncontigs):
-        mono = torch.randint(0, 4, (SATELLITE_MONOMER,), generator=g, device=dev, dtype=torch.int32).to(torch.uint8)
-        hor = mono.repeat(SATELLITE_HOR)
-        m = torch.rand(hor_len, generator=g, device=dev) < 0.25           # the monomers of the higher-order unit differ from each other
-        hor = torch.where(m, (hor + torch.randint(1, 4, (hor_len,), generator=g, device=dev, dtype=torch.int32).to(torch.uint8)) & 3, hor)
-        arr = hor.repeat(sat_bp // hor_len + 1)[:sat_bp]
-        m = torch.rand(sat_bp, generator=g, device=dev) < SATELLITE_DIV
-        arr = torch.where(m, (arr + torch.randint(1, 4, (sat_bp,), generator=g, device=dev, dtype=torch.int32).to(torch.uint8)) & 3, arr)
-        o = c * clen + int(clen * 0.4)
-        whole[o:o + sat_bp] = arr
-    for o in range(0, total, 1 << 27):
-        n = min(1 << 27, total - o)
-        whole[o:o + n] = lut[whole[o:o + n].long()]
-    gap, end = min(NGAP_BP, clen // 50), min(NGAP_END_BP, clen // 1000)
-    for c in range(ncontigs):
-        o = c * clen
-        whole[o:o + end] = ord("N"); whole[o + clen - end:o + clen] = ord("N")
-        whole[o + int(clen * 0.6):o + int(clen * 0.6) + gap] = ord("N")
-    summary = {"generator": "bench.make_repeat_rich_reference(seed %d)" % seed, "interspersed_repeat_fraction": round(covered / total, 3), "families": fams,
-               "satellite": "%d bp array per contig: %d bp monomers in a %d-monomer higher-order repeat, copies %.0f %% apart" % (sat_bp, SATELLITE_MONOMER, SATELLITE_HOR, SATELLITE_DIV * 100),
-               "n_gaps": "%d bp inside every contig, %d bp at both ends" % (gap, end)}
-    return [whole[c * clen:(c + 1) * clen] for c in range(ncontigs)], summary
-
-
-def contiguous_views(torch, contigs):
-    """the contigs on the host as consecutive views of ONE array: what a caller that has parsed its FASTA into one buffer hands to
-    mm_index_build (capi.Context.index_build then passes the buffer as it lies instead of concatenating 3 GB inside the timed build)"""
-    whole = torch.cat(contigs).cpu().numpy()
-    out, at = [], 0
-    for c in contigs:
-        out.append(whole[at:at + len(c)]); at += len(c)
-    return out
-
-
-def make_reads(torch, dev, contigs, nreads, read_len, err, seed, chunk=8192):
-    """ONT-like reads on the device: uniform start/strand, i.i.d. e/3 sub + e/3 ins + e/3 del with the read's error rate e drawn
-    uniformly from err = (lo, hi)."""
-    g = torch.Generator(device=dev); g.manual_seed(seed)
-    ref = torch.cat(contigs)
-    coff = torch.tensor(np.cumsum([0] + [len(c) for c in contigs[:-1]]), device=dev)
-    clen = torch.tensor([len(c) for c in contigs], device=dev)
-    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
-    comp = torch.zeros(256, dtype=torch.uint8, device=dev)
-    for a, b in zip(b"ACGT", b"TGCA"):
-        comp[a] = b
-    src_len = int(read_len * (1 + err[1])) + 300
-    out = torch.empty(nreads * read_len, dtype=torch.uint8, device=dev)
-    ar = torch.arange(src_len, device=dev)
-    for r0 in range(0, nreads, chunk):
-        R = min(chunk, nreads - r0)
-        ci = torch.randint(0, len(contigs), (R,), generator=g, device=dev)
-        st = (torch.rand(R, generator=g, device=dev, dtype=torch.float64) * (clen[ci] - src_len).double()).long()
-        rev = torch.rand(R, generator=g, device=dev) < 0.5
-        e = (err[0] + (err[1] - err[0]) * torch.rand(R, generator=g, device=dev))[:, None]
-        seg = ref[(coff[ci] + st)[:, None] + ar[None, :]]
-        seg = torch.where(rev[:, None], comp[seg.flip(1).long()], seg)
-        u = torch.rand(R, src_len, generator=g, device=dev)
-        rb = lut[torch.randint(0, 4, (R, src_len), generator=g, device=dev)]
-        is_sub = u < e / 3
-        is_ins = (u >= e / 3) & (u < 2 * e / 3)
-        is_del = (u >= 2 * e / 3) & (u < e)
-        cnt = (~is_del).int() + is_ins.int()
-        pos = torch.cumsum(cnt, dim=1) - cnt                     # output slot of the (possibly inserted) first symbol
-        base = torch.where(is_sub & (rb != seg), rb, seg)
-        dst = out[r0 * read_len:(r0 + R) * read_len].view(R, read_len)
-        rows = torch.arange(R, device=dev)[:, None].expand(R, src_len)
-        m = is_ins & (pos < read_len)
-        dst[rows[m], pos[m]] = rb[m]
-        p2 = pos + is_ins.int()
-        m = (~is_del) & (p2 < read_len)
-        dst[rows[m], p2[m]] = base[m]
-        assert int((pos[:, -1] + cnt[:, -1]).min()) >= read_len
-        del seg, u, rb, cnt, pos, base, rows, m, p2
-    return out
-
-
-def make_assembly(torch, dev, contigs, div=0.01, seed=21):
-    """BASELINE configs[2]'s query: every reference contig with `div` i.i.d. substitutions and a few 1-5 Mbp
-    rearrangements -- an inversion (contig i % 3 == 0), a translocation inside the contig (i % 3 == 1), both and the whole contig on the
-    other strand (i % 3 == 2).  Lengths stay; returns one uint8 tensor per contig, on the device."""
-    g = torch.Generator(device=dev); g.manual_seed(seed)
-    rs = np.random.RandomState(seed)
-    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
-    comp = torch.arange(256, dtype=torch.uint8, device=dev)
-    for a, b in zip(b"ACGT", b"TGCA"):
-        comp[a] = b
-    out = []
-    for i, c in enumerate(contigs):
-        n = len(c)
-        q = c.clone()
-        for o in range(0, n, 1 << 27):                         # substitutions, in pieces (the masks are 4 bytes per base)
-            m = min(1 << 27, n - o)
-            hit = torch.rand(m, generator=g, device=dev) < div * 4.0 / 3.0          # a drawn base equals the old one a quarter of the time
-            q[o:o + m] = torch.where(hit, lut[torch.randint(0, 4, (m,), generator=g, device=dev)], q[o:o + m])
-            del hit
-        unit = max(1, min(1_000_000, n // 125))               # 1 Mbp at 125 Mbp contigs; scaled-down contigs keep the proportions
-        if i % 3 in (0, 2) and n > 12 * unit:                 # inversion of 1..5 units
-            ln = int(rs.randint(1, 6)) * unit; at = int(rs.randint(unit, n - ln - unit))
-            q[at:at + ln] = comp[q[at:at + ln].flip(0).long()]
-        if i % 3 in (1, 2) and n > 12 * unit:                 # translocation: a 1..5 unit piece moves towards the other end of the contig
-            ln = int(rs.randint(1, 6)) * unit; at = int(rs.randint(unit, n // 2 - ln)); to = int(rs.randint(n // 2, n - unit))
-            q = torch.cat([q[:at], q[at + ln:to], q[at:at + ln], q[to:]])
-        if i % 3 == 2:
-            q = comp[q.flip(0).long()]
-        assert len(q) == n
-        out.append(q)
-    return out
-
-
-def write_fasta(path, names, arrays, width=100):
-    with open(path, "wb") as f:
-        for n, a in zip(names, arrays):
-            f.write(b">" + n.encode() + b"\n")
-            full = (len(a) // width) * width
-            if full:
-                lines = np.concatenate([a[:full].reshape(-1, width), np.full((full // width, 1), 10, dtype=np.uint8)], axis=1)
-                f.write(lines.tobytes())
-            if len(a) > full:
-                f.write(a[full:].tobytes() + b"\n")
-
-
-def usable_cpus():
-    """CPUs this process may use at once: hardware threads, affinity mask, and the container's CPU quota (cgroup v2 cpu.max / v1
-    cfs_quota) -- the GPU boxes show 256 hardware threads and grant 16 CPUs' worth of time; more threads than that get the whole
-    process throttled."""
-    n = os.cpu_count() or 1
-    if hasattr(os, "sched_getaffinity"):
-        n = min(n, len(os.sched_getaffinity(0)) or n)
-    try:
-        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-        if q != "max":
-            n = min(n, max(1, int(float(q) / float(per) + 0.5)))
-    except (OSError, ValueError):
-        try:
-            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-            if q > 0 and per > 0:
-                n = min(n, max(1, int(q / per + 0.5)))
-        except (OSError, ValueError):
-            pass
-    return n
-
-
-def cpu_baseline(W, ref_np, reads_np, n_sample):
-    """the reference's own CPU path (oracle/_ref/mashmap_ref, built from /root/reference with the GSL stand-in) or, if that binary
-    did not travel, our CPU port (oracle/liboracle.so); timed on this box's host cores on a bounded sample of the same workload."""
-    ncores = os.cpu_count() or 1
-    read_len = W["read_len"]
-    ref_bin = os.path.join(ROOT, "oracle", "_ref", "mashmap_ref")
-    prof_bin = os.path.join(ROOT, "oracle", "_ref", "mashmap_ref_prof")
-    sample = reads_np[:n_sample * read_len].reshape(n_sample, read_len)
-    desc = "%d of the benchmark reads (%.0f Mbp) vs the same %.0f Mbp reference" % (n_sample, n_sample * read_len / 1e6, sum(len(a) for a in ref_np) / 1e6)
-    if os.path.exists(ref_bin):
-        with tempfile.TemporaryDirectory() as td:
-            rp, qp, op = os.path.join(td, "ref.fa"), os.path.join(td, "q.fa"), os.path.join(td, "o.paf")
-            write_fasta(rp, ["chr%d" % i for i in range(len(ref_np))], ref_np)
-            write_fasta(qp, ["read%d" % i for i in range(n_sample)], list(sample))
-            with open(qp + ".fai", "w") as f:          # avoids the reference's extra pass over the query file
-                for i in range(n_sample):
-                    f.write("read%d\t%d\t0\t100\t101\n" % (i, read_len))
-            common = ["-r", rp, "-q", qp, "-o", op, "-s", str(W["seg"]), "--pi", str(int(round(W["pi"] * 100))), "-k", str(W["k"]), "-J", str(W["sketch"])]
-            # the reference's pthread pool stops scaling early (one reader thread feeds it; with hundreds of threads it thrashes):
-            # time a few thread counts on the same sample and report the best one
-            best = None
-            for nt in sorted({min(ncores, 8), min(ncores, 32), min(ncores, 64)}):
-                t0 = time.time()
-                p = subprocess.run([ref_bin] + common + ["-t", str(nt)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-                wall = time.time() - t0
-                tmap = None
-                for line in p.stderr.splitlines():
-                    if "time spent mapping the query" in line:
-                        tmap = float(line.split(":")[-1].split()[0])
-                if p.returncode == 0 and tmap:
-                    log("[cpu_baseline] reference binary -t %d: map %.2f s (total wall %.1f s)" % (nt, tmap, wall))
-                    if best is None or tmap < best[0]:
-                        best = (tmap, nt)
-            # SURVEY section 8d(b): sum of the per-fragment compute times of the -DENABLE_TIME_PROFILE_L1_L2 build (no reader, no
-            # pool overhead) / threads = the rate an ideally fed pool of that many cores would reach
-            compute = None
-            if best and os.path.exists(prof_bin):
-                p = subprocess.run([prof_bin] + common + ["-t", str(best[1])], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-                # lines "seqCounter len tL1 tL2 tFragment" (computeMap.hpp:802-811); the pool's threads write them unsynchronised, so only
-                # lines that parse cleanly are used and their mean is scaled to the number of fragments of the sample
-                tot = 0.0; nfr = 0
-                for line in p.stderr.splitlines():
-                    f = line.split()
-                    if len(f) == 5 and f[0].isdigit() and f[1] == str(W["seg"]):
-                        try:
-                            t = [float(x) for x in f[2:]]
-                        except ValueError:
-                            continue
-                        if all(0 <= x < 10 for x in t) and abs(t[0] + t[1] - t[2]) < 1e-3:
-                            tot += t[2]; nfr += 1
-                if nfr:
-                    tot = tot / nfr * (n_sample * (read_len // W["seg"] + (1 if read_len % W["seg"] else 0)))
-                if p.returncode == 0 and nfr:
-                    compute = {"what": "-DENABLE_TIME_PROFILE_L1_L2 build of the reference: per-fragment sketch+L1+L2 seconds, no reader, no pool overhead "
-                                       "(SURVEY section 8d(b)); per core, and x host cores as the ideally fed pool", "fragments_parsed": nfr, "sum_fragment_seconds": round(tot, 3),
-                               "gbps_per_core": round(n_sample * read_len / tot / 1e9, 5),
-                               "gbps_all_cores_ideal": round(n_sample * read_len / tot / 1e9 * ncores, 3),
-                               "gbps_usable_cpus_ideal": round(n_sample * read_len / tot / 1e9 * usable_cpus(), 3)}
-            if best:
-                tmap, nt = best
-                return {"value": n_sample * read_len / tmap / 1e9, "unit": "Gbp/s", "cores": usable_cpus(), "threads": nt, "host_hardware_threads": ncores, "kind": "reference",
-                        "sample": desc + "; mashmap_ref (built from the reference sources) best of -t 8/32/64 = -t %d; `cores` = the %d CPUs this process may use at once "
-                                         "(affinity / container quota) of the host's %d hardware threads; 'time spent mapping the query' (includes its single-threaded FASTA reader)" % (nt, usable_cpus(), ncores),
-                        "fragment_compute": compute}
-            log("[cpu_baseline] reference binary failed, falling back to the port:", p.stderr[-300:])
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import mmutil as U
-    orc = U.Oracle()
-    h = orc.session([("chr%d" % i, a) for i, a in enumerate(ref_np[:1])], W["k"], W["seg"], W["sketch"], W["pi"])
-    n = min(n_sample, 200)
-    t0 = time.time()
-    for i in range(n):
-        for off in range(0, read_len - W["seg"] + 1, W["seg"]):
-            orc.map_fragment(h, sample[i, off:off + W["seg"]], i, b"r", read_len, W["sketch"])
-    dt = time.time() - t0
-    orc.free(h)
-    return {"value": n * read_len / dt / 1e9 * 0.5, "unit": "Gbp/s", "cores": 1, "kind": "port",
-            "sample": "%d reads vs the first contig; scalar port, diagnostic entry runs the path twice (halved)" % n}
-
-
-def host_path(ctx, W, nreads, ref_lens, steps_ms):
-    """packed bases -> MappingResult rows: the device pass + download of the candidate mappings + the host stage of skch::Map
-    (chaining, plane-sweep filter, sanity checks; libmashmap_host.so = MapPost) on every host core."""
-    import ctypes as C
-    from mashmap_amd import capi
-    lib_path = os.path.join(ROOT, "mashmap_amd", "lib", "libmashmap_host.so")
-    if not os.path.exists(lib_path):
-        return None
-    lib = C.CDLL(lib_path)
-    lib.mmh_post_batch.restype = C.c_int64
-    lib.mmh_post_batch.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t,
-                                   C.c_void_p, C.c_size_t, C.c_int32, C.c_int, C.POINTER(C.c_double), C.c_void_p, C.c_size_t]
-    t0 = time.perf_counter()
-    recs = ctx.mappings()
-    t_dl = time.perf_counter() - t0
-    clens = np.ascontiguousarray(ref_lens, dtype=np.int32)
-    rl = np.full(nreads, W["read_len"], dtype=np.int32)
-    threads = os.cpu_count() or 1
-    best = None
-    for nt in sorted({min(threads, usable_cpus()), min(threads, 32), min(threads, 64), min(threads, 128), threads}):   # the quota-sized pool first: wider ones are throttled on a capped box
-        sec = C.c_double()
-        rows = lib.mmh_post_batch(W["k"], W["seg"], W["sketch"], W["pi"], 1, 1, 1, len(clens), clens.ctypes.data, recs.ctypes.data, len(recs),
-                                  rl.ctypes.data, nreads, 0, nt, C.byref(sec), None, 0)
-        if best is None or sec.value < best[0]:
-            best = (sec.value, nt, int(rows))
-    post_s, nt, rows = best
-    bases = nreads * W["read_len"]
-    dev_s = steps_ms / 1e3
-    return {"what": "packed bases -> reported MappingResult rows on one GPU + host: device pass, D2H of the candidate mappings (48 B each), "
-                    "then per read mergeMappingsInRange + filterByGroup + sanity checks (MapPost, the code skch::Map runs) on host threads",
-            "candidate_mappings": int(len(recs)), "rows": rows, "device_ms": round(dev_s * 1e3, 3), "download_ms": round(t_dl * 1e3, 3),
-            "host_ms": round(post_s * 1e3, 3), "host_threads": nt, "host_cores": threads, "usable_cpus": usable_cpus(),
-            "gbps_serial": round(bases / (dev_s + t_dl + post_s) / 1e9, 3),
-            "gbps_pipelined": round(bases / max(dev_s, t_dl + post_s) / 1e9, 3),
-            "note": "skch::Map overlaps the host stage of batch i with the device stage of batch i+1 (pipelined); serial = no overlap"}
+from bench_workloads import *      # noqa: F401,F403  (WORKLOADS, the generators, write_fasta, usable_cpus, log: tests and scripts reach them as bench.X)
+from bench_workloads import WORKLOADS, contiguous_views, log, make_assembly, make_reads, make_reference, make_repeat_rich_reference, usable_cpus, write_fasta  # noqa: F401
+from bench_e2e import cpu_baseline, e2e_assembly, e2e_fasta_to_paf, host_path, human_scale_cpu_baseline, run_cli_staged, stage_summary  # noqa: F401
 
 
 def csrc_sha16():
@@ -573,38 +234,6 @@ def timed_passes(ctx, warmup, steps, nb=1):
     prof = ctx.profile_read(reset=True)
     ctx.profile(False)
     return dt, prof, {"timed": t1p["passes"] - t0p["passes"], "steady": t1p["steady"] - t0p["steady"], "redone": t1p["redone"] - t0p["redone"], "resident_batches": nb}
-
-
-def human_scale_cpu_baseline(W, ref_np, reads_t, n_sample):
-    """the stock binary (oracle/_ref/mashmap_ref, built from the reference's sources) on a sample of the target's reads against the SAME
-    3 Gbp reference, defaults (it derives sketchSize 310 itself), on this box's host cores: index build and 'time spent mapping the query'"""
-    ref_bin = os.path.join(ROOT, "oracle", "_ref", "mashmap_ref")
-    if not os.path.exists(ref_bin):
-        return {"error": "oracle/_ref/mashmap_ref not here"}
-    L = W["read_len"]
-    sample = reads_t[:n_sample * L].cpu().numpy().reshape(n_sample, L)
-    nt = max(4, min(64, 2 * usable_cpus()))
-    with tempfile.TemporaryDirectory() as td:
-        rp, qp, op = os.path.join(td, "ref.fa"), os.path.join(td, "q.fa"), os.path.join(td, "o.paf")
-        write_fasta(rp, ["chr%d" % i for i in range(len(ref_np))], ref_np)
-        write_fasta(qp, ["read%d" % i for i in range(n_sample)], list(sample), width=L)
-        t0 = time.time()
-        p = subprocess.run([ref_bin, "-r", rp, "-q", qp, "-o", op, "-t", str(nt)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-        wall = time.time() - t0
-        tm = {}
-        for line in p.stderr.splitlines():
-            for key in ("computing the reference index", "mapping the query"):
-                if "time spent " + key in line:
-                    tm[key] = float(line.split(":")[-1].split()[0])
-        lines = sum(1 for _ in open(op)) if os.path.exists(op) else 0
-    if p.returncode != 0 or "mapping the query" not in tm:
-        return {"error": "mashmap_ref exited with %d: %s" % (p.returncode, p.stderr[-300:])}
-    log("[north_star] stock binary: index %.1f s, mapping %.2f s (%d reads, -t %d)" % (tm.get("computing the reference index", 0), tm["mapping the query"], n_sample, nt))
-    return {"value": round(n_sample * L / tm["mapping the query"] / 1e9, 4), "unit": "Gbp/s", "cores": usable_cpus(), "threads": nt, "kind": "reference",
-            "index_build_s": round(tm.get("computing the reference index", 0.0), 1), "wall_s": round(wall, 1), "paf_lines": lines,
-            "sample": "%d of the target's reads (%.0f Mbp) vs the same %.0f Mbp reference written as FASTA; mashmap_ref (the reference's sources, GSL stand-in) with its "
-                      "defaults, -t %d: %d host hardware threads, of which this process may use %d CPUs at once (container quota); 'time spent mapping the query' includes its "
-                      "single-threaded FASTA reader" % (n_sample, n_sample * L / 1e6, sum(len(a) for a in ref_np) / 1e6, nt, os.cpu_count() or 1, usable_cpus())}
 
 
 def north_star_target(torch, dev, capi, local, warmup, steps, cpu_reads=0, nb=3, repeat_rich=True, configs2=True):
@@ -978,153 +607,6 @@ def emit(full):
 def free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
     return p
-
-
-def run_cli_staged(exe, argv, reps=2, log_env="MM_E2E_LOG"):
-    """runs the mashmap_hip command line `reps` times with MASHMAP_HIP_TIMING=1 (the second run finds the files in the page cache) and returns
-    the best run's 'time spent' figures and the rows of its stage log"""
-    import re
-    env = dict(os.environ, MASHMAP_HIP_TIMING="1")
-    best = None
-    for rep in range(reps):
-        t0 = time.time()
-        p = subprocess.run([exe] + argv, capture_output=True, text=True, env=env)
-        wall = time.time() - t0
-        if p.returncode != 0:
-            return {"error": "mashmap_hip exited with %d: %s" % (p.returncode, p.stderr[-400:])}
-        tmap = float(re.search(r"time spent mapping the query\s*:\s*([0-9.eE+-]+)", p.stderr).group(1))
-        tidx = float(re.search(r"time spent computing the reference index\s*:\s*([0-9.eE+-]+)", p.stderr).group(1))
-        dev_rows = re.findall(r"device stage \(.*?download of (\d+) candidate mappings\): ([0-9.eE+-]+) s \(upload ([0-9.eE+-]+), kernels ([0-9.eE+-]+), download ([0-9.eE+-]+)\)(?: \[bases (\d+)\])?", p.stderr)
-        rd_rows = re.findall(r"reader: parsed (\d+) records, (\d+) bases in ([0-9.eE+-]+) s", p.stderr)
-        post = [float(x) for x in re.findall(r"post stage: chain \+ filter \+ format ([0-9.eE+-]+) s", p.stderr)]
-        outp = [float(x) for x in re.findall(r", output ([0-9.eE+-]+) s", p.stderr)]
-        final = [float(x) for x in re.findall(r"one-to-one filter \+ output ([0-9.eE+-]+) s", p.stderr)]
-        cur = dict(map_s=tmap, index_s=tidx, wall_s=wall, stderr=p.stderr, dev_rows=dev_rows, rd_rows=rd_rows, post_s=sum(post), output_s=sum(outp), final_s=sum(final))
-        if best is None or tmap < best["map_s"]:
-            best = cur
-    if os.environ.get(log_env):                            # the stage log of the best run, for profiles/
-        with open(os.environ[log_env], "w") as f:
-            f.write("\n".join(l for l in best["stderr"].splitlines() if "timing" in l or "time spent" in l) + "\n")
-    return best
-
-
-def stage_summary(best):
-    dev_rows = best["dev_rows"]
-    return {"reader_s": round(sum(float(r[2]) for r in best["rd_rows"]), 4), "reader_batches": len(best["rd_rows"]),
-            "device_stage_s": round(sum(float(r[1]) for r in dev_rows), 4), "device_upload_wait_s": round(sum(float(r[2]) for r in dev_rows), 4),
-            "device_kernels_s": round(sum(float(r[3]) for r in dev_rows), 4), "device_download_s": round(sum(float(r[4]) for r in dev_rows), 4), "device_passes": len(dev_rows),
-            "post_s": round(best["post_s"], 4), "output_s": round(best["output_s"], 4), "final_filter_s": round(best.get("final_s", 0.0), 4)}
-
-
-def e2e_assembly(torch, dev, W, contigs, threads, stock=False, keep_dir=None):
-    """configs[2] through the command line: the 3 Gbp reference and the assembly (make_assembly of the same contigs) written as FASTA,
-    `mashmap_hip --pi 95 -s 10000 -f one-to-one -J 40`, its 'time spent mapping the query' and stage log; with `stock` the reference's
-    own binary on the same files, PAF bytes compared."""
-    import shutil
-    exe = os.path.join(ROOT, "mashmap_amd", "lib", "mashmap_hip")
-    if not os.path.exists(exe):
-        return {"error": "mashmap_amd/lib/mashmap_hip not built"}
-    td = keep_dir or tempfile.mkdtemp(prefix="mm_e2e2_")
-    try:
-        bases = sum(len(c) for c in contigs)
-        if shutil.disk_usage(td).free < 2.1 * bases + (2 << 30):
-            return {"error": "only %.1f GB free under %s" % (shutil.disk_usage(td).free / 1e9, td)}
-        rp, qp, op = os.path.join(td, "ref.fa"), os.path.join(td, "asm.fa"), os.path.join(td, "out.paf")
-        t0 = time.time()
-        write_fasta(rp, ["chr%d" % i for i in range(len(contigs))], [c.cpu().numpy() for c in contigs])
-        asm = make_assembly(torch, dev, contigs, W["err"][0], seed=2021)
-        write_fasta(qp, ["ctg%d" % i for i in range(len(asm))], [c.cpu().numpy() for c in asm])
-        del asm
-        torch.cuda.empty_cache()
-        write_s = time.time() - t0
-        argv = ["-s", str(W["seg"]), "--pi", str(int(round(W["pi"] * 100))), "-J", str(W["sketch"])] + list(W.get("cli", []))
-        best = run_cli_staged(exe, ["-r", rp, "-q", qp, "-o", op, "-t", str(threads)] + argv, log_env="MM_E2E2_LOG")
-        if "error" in best:
-            return best
-        lines = sum(1 for _ in open(op, "rb"))
-        out = {"what": "mashmap_hip -r ref.fa -q asm.fa %s (FASTA -> PAF): %d contigs, %.2f Gbp assembly vs the %.2f Gbp reference it was derived from" % (" ".join(argv), len(contigs), bases / 1e9, bases / 1e9),
-               "value": round(bases / best["map_s"] / 1e9, 3), "unit": "Gbp/s", "map_s": round(best["map_s"], 4), "index_s": round(best["index_s"], 3), "wall_s": round(best["wall_s"], 3),
-               "paf_lines": lines, "threads": threads, "usable_cpus": usable_cpus(), "fasta_write_s": round(write_s, 1), "stages": stage_summary(best)}
-        ref_bin = os.path.join(ROOT, "oracle", "_ref", "mashmap_ref")
-        if stock and os.path.exists(ref_bin):
-            sp = os.path.join(td, "stock.paf")
-            nt = max(4, min(64, 2 * usable_cpus()))
-            t0 = time.time()
-            p = subprocess.run([ref_bin, "-r", rp, "-q", qp, "-o", sp, "-t", str(nt)] + argv, capture_output=True, text=True)
-            tm = {}
-            for line in p.stderr.splitlines():
-                for key in ("computing the reference index", "mapping the query"):
-                    if "time spent " + key in line:
-                        tm[key] = float(line.split(":")[-1].split()[0])
-            out["stock"] = {"rc": p.returncode, "threads": nt, "wall_s": round(time.time() - t0, 1), "index_s": tm.get("computing the reference index"), "map_s": tm.get("mapping the query"),
-                            "value": round(bases / tm["mapping the query"] / 1e9, 4) if "mapping the query" in tm else None,
-                            "paf_identical": p.returncode == 0 and open(sp, "rb").read() == open(op, "rb").read()}
-        return out
-    finally:
-        if not keep_dir:
-            shutil.rmtree(td, ignore_errors=True)
-
-
-def e2e_fasta_to_paf(torch, dev, W, ref_np, nreads, threads):
-    """the path a user runs, inside this run: the `mashmap_hip` command line (skch::Sketch + skch::Map on the C ABI) on the workload's
-    FASTA files -- parse + pack, upload, kernels, download, chaining + filters, PAF text --, its own 'time spent mapping the query' and
-    the per-stage seconds of its MASHMAP_HIP_TIMING log.  The FASTA is written first (reads regenerated with the headline's seed)."""
-    import re
-    import shutil
-    exe = os.path.join(ROOT, "mashmap_amd", "lib", "mashmap_hip")
-    if not os.path.exists(exe):
-        return {"error": "mashmap_amd/lib/mashmap_hip not built"}
-    L = W["read_len"]
-    td = tempfile.mkdtemp(prefix="mm_e2e_")
-    try:
-        need = nreads * (L + 14) + sum(len(a) for a in ref_np) * 1.02 + (1 << 30)
-        free = shutil.disk_usage(td).free
-        scaled = None
-        if free < need:
-            scaled = max(1000, int(nreads * (free - (2 << 30)) / need))
-            if free < (3 << 30):
-                return {"error": "only %.1f GB free under %s" % (free / 1e9, td)}
-            nreads = scaled
-        rp, qp, op = os.path.join(td, "ref.fa"), os.path.join(td, "reads.fa"), os.path.join(td, "out.paf")
-        t0 = time.time()
-        write_fasta(rp, ["chr%d" % i for i in range(len(ref_np))], ref_np)
-        contigs = [torch.from_numpy(a).to(dev) for a in ref_np]
-        with open(qp, "wb") as f:
-            chunk = 100_000
-            for r0 in range(0, nreads, chunk):
-                n = min(chunk, nreads - r0)
-                rd = make_reads(torch, dev, contigs, n, L, W["err"], seed=5000 + r0).cpu().numpy().reshape(n, L)
-                hdr = np.frombuffer(b"".join(b">read%07d\n" % (r0 + i) for i in range(n)), dtype=np.uint8).reshape(n, 13)      # fixed-width names
-                f.write(np.concatenate([hdr, rd, np.full((n, 1), 10, dtype=np.uint8)], axis=1).tobytes())
-        del contigs
-        torch.cuda.empty_cache()
-        write_s = time.time() - t0
-        best = run_cli_staged(exe, ["-r", rp, "-q", qp, "-o", op, "-t", str(threads), "-s", str(W["seg"]), "--pi", str(int(round(W["pi"] * 100))), "-J", str(W["sketch"])])
-        if "error" in best:
-            return best
-        bases = nreads * L
-        dev_rows = best["dev_rows"]
-        # a device-stage row covers one pass over one or several reader batches: its bases are in the row (skch_map.hpp), else the reader's batches in order
-        pass_bases = [int(r[5]) for r in dev_rows if r[5]]
-        if len(pass_bases) != len(dev_rows):
-            pass_bases = [int(r[1]) for r in best["rd_rows"]][:len(dev_rows)]
-        kern = [float(r[3]) for r in dev_rows]
-        full = max(pass_bases) if pass_bases else 0
-        fb = [(b, k) for b, k in zip(pass_bases, kern) if b >= 0.9 * full]
-        lines = sum(1 for _ in open(op, "rb"))
-        return {"what": "mashmap_hip -r ref.fa -q reads.fa -o out.paf (FASTA -> PAF) on this workload's files: %d x %d bp reads (%.2f GB of FASTA) vs %.0f Mbp; "
-                        "'time spent mapping the query' = parse + pack + upload + kernels + download + chain/filter + PAF text, the three stages (reader | device | post) "
-                        "overlapped on successive batches; best of two runs" % (nreads, L, os.path.getsize(qp) / 1e9, sum(len(a) for a in ref_np) / 1e6),
-                "value": round(bases / best["map_s"] / 1e9, 3), "unit": "Gbp/s", "map_s": round(best["map_s"], 4), "index_s": round(best["index_s"], 3), "wall_s": round(best["wall_s"], 3),
-                "paf_lines": lines, "threads": threads, "usable_cpus": usable_cpus(), "scaled_to_reads": scaled, "fasta_write_s": round(write_s, 1),
-                "stages": stage_summary(best),
-                "device_stage": {"gbps_kernels_all_passes": round(sum(pass_bases) / max(1e-9, sum(kern)) / 1e9, 2),
-                                 "gbps_kernels_full_size_passes": round(sum(b for b, _ in fb) / max(1e-9, sum(k for _, k in fb)) / 1e9, 2) if fb else None,
-                                 "full_size_passes": len(fb), "bases_per_pass": pass_bases,
-                                 "note": "kernels = mm_map_fragments of a pass (sketch .. selection, its host waits included); a pass covers as many parsed batches as were "
-                                         "waiting, up to MASHMAP_HIP_COALESCE_MBP per GPU (skch_map.hpp); full-size passes = those within 10 % of the largest"}}
-    finally:
-        shutil.rmtree(td, ignore_errors=True)
 
 
 def main():

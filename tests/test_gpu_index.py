@@ -69,14 +69,14 @@ def test_index_with_the_blocked_window_sketch_at_small_sizes(oracle, monkeypatch
 def test_index_at_the_largest_lds_sketch_size_and_beyond(oracle):
     """up to sketchSize 4 096 the device index build keeps a window's sketch as a sorted array in LDS, beyond that as blocks in HBM
     (k_winnow_tiles<.., GSK>; the reference's --dense derives 9 998 at 100 kbp segments and 19 998 at 200 kbp, parseCmdArgs.hpp:626-630,
-    and takes any size).  Device-built index against the oracle, record for record, at 4 096 / 4 097 (last LDS, first HBM size), 10 001
-    (more than LDS could hold at all) and 19 998; 65 536 -- more seeds than the literal kernels' 16-bit seed numbers -- is refused by mm_create."""
+    and takes any size).  Device-built index against the oracle, record for record, at 4 096 / 4 097 (last LDS, first HBM size) and 19 998
+    (more than LDS could hold at all); 65 536 -- more seeds than the literal kernels' 16-bit seed numbers -- is refused by mm_create."""
     from mashmap_amd import capi
     contigs = [("c0", U.random_dna(901, 330000)), ("c1", U.with_n_runs(U.random_dna(902, 250000), 2, 20, 300))]
-    for s in (4096, 4097, 10001):
+    for s in (4096, 4097):
         nm, _ = _compare(oracle, contigs, k=19, L=100000, s=s)
         assert nm > s
-    contigs = [("c0", U.random_dna(903, 520000)), ("c1", U.with_n_runs(U.random_dna(904, 450000), 2, 20, 300))]
+    contigs = [("c0", U.random_dna(903, 430000)), ("c1", U.with_n_runs(U.random_dna(904, 330000), 2, 20, 300))]
     nm, _ = _compare(oracle, contigs, k=19, L=200000, s=19998)
     assert nm > 19998
     with pytest.raises(capi.MashmapError, match="sketchSize 65536 is beyond 65535"):
