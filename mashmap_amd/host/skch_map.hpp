@@ -387,7 +387,8 @@ class Map {
     // downloads with one warning (an explicit one is fatal).
     const char* xe = getenv("MASHMAP_HIP_EXCHANGE");
     const bool gatherAsked = xe && std::string(xe) == "allgather";
-    bool gatherOnDevice = nCtx > 1 && !exchangeFellBack && (xe ? gatherAsked : refSketch.distinctDevices());
+    if (gatherAsked && nCtx > 1 && !refSketch.commReady()) die("MASHMAP_HIP_EXCHANGE=allgather, but the contexts have no communicator (mm_comm_init_local failed)");
+    bool gatherOnDevice = nCtx > 1 && !exchangeFellBack && refSketch.commReady() && (xe ? gatherAsked : refSketch.distinctDevices());
     std::vector<PinnedRecs<mm_mapping>> blockRecs(nCtx == 1 ? 0 : nCtx);
     auto all = std::make_shared<PinnedRecs<mm_mapping>>();
     double phase[3] = {0, 0, 0};                           // context 0: upload, kernels, download (seconds)

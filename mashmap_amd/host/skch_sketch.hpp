@@ -38,6 +38,7 @@ class Sketch {
   size_t nMinmers_ = 0;                            // |minmerIndex| on the device (after the frequent-seed drop)
   mm_ctx* ctx_ = nullptr;                          // the context the index is built on (first device of the list)
   std::vector<mm_ctx*> ctxs_;                      // one per entry of MASHMAP_HIP_DEVICES; ctxs_[0] == ctx_
+  bool commReady_ = false;
   mutable std::mutex materializeMu_; mutable bool minmerIndexReady_ = false;
   std::thread recsPrefill_;                        // page-locks the record buffers of skch::Map's device passes while the index is built
   Sketch();
@@ -111,8 +112,12 @@ class Sketch {
       const QueryBatchPlan plan = queryBatchPlan(p.querySequences, ctxs_.size());
       for (mm_ctx* c : ctxs_) (void)mm_reads_prefetch_reserve(c, stagingReserveBases(plan, ctxs_.size()));
     }
-    if (ctxs_.size() > 1 && mm_comm_init_local(ctxs_.data(), (int)ctxs_.size()) != MM_OK) {
-      std::cerr << "[mashmap_hip::skch::Sketch] ERROR: mm_comm_init_local: " << mm_last_error(ctx_) << std::endl; exit(1);
+    if (ctxs_.size() > 1) {
+      // the communicator of the device-side exchange step (RCCL between distinct GPUs, peer copies between contexts that share one).  A
+      // machine where it cannot be had still maps: skch::Map then lets every context hand its block to the host (one warning here)
+      commReady_ = mm_comm_init_local(ctxs_.data(), (int)ctxs_.size()) == MM_OK;
+      if (!commReady_) std::cerr << "[mashmap_hip::skch::Sketch] WARNING: mm_comm_init_local: " << mm_last_error(ctx_)
+                                 << "; the candidate mappings of the GPUs are exchanged through the host" << std::endl;
     }
   }
   ~Sketch() { if (recsPrefill_.joinable()) recsPrefill_.join(); for (mm_ctx* c : ctxs_) mm_destroy(c); }
@@ -121,6 +126,7 @@ class Sketch {
 
   mm_ctx* ctx() const { return ctx_; }
   const std::vector<mm_ctx*>& contexts() const { return ctxs_; }
+  bool commReady() const { return commReady_; }    // mm_comm_init_local succeeded (several contexts only)
   // every context has a GPU of its own: what an RCCL communicator over them needs (two contexts on one GPU exchange by device copies)
   bool distinctDevices() const {
     std::vector<int> d = devicesFromEnv();
