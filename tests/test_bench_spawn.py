@@ -58,7 +58,7 @@ def _events(prefix, world):
     return [[json.loads(l) for l in open("%s.%d" % (prefix, r))] for r in range(world)]
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])       # 8: the node the driver's scaling run uses
 def test_rank_loop_overlapped_exchange_order_and_timed_region(world, tmp_path):
     """step = rotate batch, map, _end of the previous exchange, _begin of this one; the fence before the clock starts leaves no exchange in
     flight, the last exchange of the timed steps is waited for BEFORE the clock stops; one exchange in flight at most; every exchange
