@@ -2,8 +2,10 @@
 # One visit to a GPU box (gpurun): scripts/gpu.sh TAG STEP [STEP ...]; everything lands under gpurun_out/TAG/ (log.txt has the gist).
 #   tests            pytest -m gpu (the whole suite)             t:PATTERN   pytest -m gpu -k PATTERN
 #   smoke            __graft_entry__.smoke()
-#   bench            the default bench line (configs[1] + e2e + north_star_target incl. repeat_rich), steps 20 / warmup 5
+#   bench            the default bench line (configs[1] + e2e + north_star_target incl. repeat_rich + configs2), steps 20 / warmup 5; the full
+#                    record of every bench run is kept as <step>_full.json and digested (the last stdout line is the short one the driver parses)
 #   bench:WL         bench.py --workload WL (configs3 | configs4 | northstar), steps 5 / warmup 3, no side measurements
+#   c2               bench.py --workload configs2: resident passes + FASTA -> PAF of the 3 Gbp assembly (C2_EXTRA=--stock: the stock binary beside it)
 #   quick            configs[1] headline only (no cpu baseline / e2e / north star), steps 10 / warmup 3
 #   rr               the repeat-rich north_star workload alone (bench.py --workload northstar --repeat-rich-reference)
 #   trace:WL         rocprofv3 --kernel-trace --stats of two passes of WL      -> kernel_stats_WL.csv
