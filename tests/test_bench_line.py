@@ -96,3 +96,17 @@ def test_emit_prints_the_parsed_line_last(tmp_path, monkeypatch):
     assert json.loads(out[-8000:].strip().split("\n")[-1]) == last           # what survives the driver's 8 000-character tail
     assert json.load(open(tmp_path / "profiles" / "bench_last_full.json")) == full
     assert last["full"] == "profiles/bench_last_full.json"
+
+
+def test_line_from_the_round_6_record_carries_configs2():
+    """the full record of round 6's final default run (profiles/r14_18_bench_full.json: configs[1] + e2e + north_star variants + configs2)"""
+    full = json.load(open(os.path.join(ROOT, "profiles", "r14_18_bench_full.json")))
+    line = bench.compact_line(full, "profiles/bench_last_full.json")
+    assert len(json.dumps(line)) < 6000
+    for k in CONTRACT + ("configs2", "e2e", "host_path"):
+        assert k in line, k
+    c2 = line["configs2"]
+    assert c2["value"] > 150 and c2["e2e"]["paf_lines"] > 0 and c2["roofline"]["pmc_unchanged"] is True
+    assert line["roofline"]["pmc_tree"]["unchanged"] is True and line["roofline"]["bound"] == "valu"
+    assert line["north_star_target"]["repeat_rich"]["hbm_point_path_share"] < 0.08
+    assert line["passes"]["redone"] == 0 and line["config"]["parallelism"] == "single GPU"
